@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (/root/reference) on the CPU.
+
+Runs only in the build container (the reference tree does not exist on the GPU box and never
+travels).  What is committed is data: seeds/shape descriptors of the inputs and the reference's
+outputs (loss scalars, strided output samples, gradient norms/samples).  Inputs and weights are
+re-created anywhere from ``oracle.ref_cpu``'s RNG-free generators, so no large tensor is stored.
+
+Environment shim: the reference calls ``torch.cuda.FloatTensor`` and
+``.cuda()`` unconditionally; aliasing them to the CPU types lets the unmodified code run here.
+
+Usage:  python oracle/make_golden.py [--only NAME ...]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+torch.cuda.FloatTensor = torch.FloatTensor
+torch.cuda.LongTensor = torch.LongTensor
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+
+REF = "/root/reference"
+sys.path.insert(0, REF)
+import joint_model as RM  # noqa: E402  (the reference's module zoo)
+from utils import evaluation as REV  # noqa: E402  (the reference's loss functions)
+
+sys.path.remove(REF)
+from oracle import ref_cpu as O  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+torch.set_num_threads(8)
+
+
+# ----------------------------------------------------------------------------------------------
+def sample_idx(n, k=64):
+    """k deterministic flat indices spread over [0,n)."""
+    if n <= k:
+        return np.arange(n)
+    return (np.arange(k, dtype=np.int64) * (n - 1)) // (k - 1)
+
+
+def summarize(t, k=64):
+    a = t.detach().double().reshape(-1).numpy()
+    return {"sum": a.sum(), "abssum": np.abs(a).sum(), "max": a.max(), "min": a.min(),
+            "l2": np.sqrt((a * a).sum()), "samples": a[sample_idx(a.size, k)].astype(np.float32)}
+
+
+def put(d, prefix, t, k=64):
+    for kk, v in summarize(t, k).items():
+        d[prefix + "." + kk] = np.asarray(v)
+
+
+def put_grads(d, prefix, module, k=16):
+    for name, p in module.named_parameters():
+        if p.grad is None:
+            d["%s.grad.%s.none" % (prefix, name)] = np.asarray(1)
+        else:
+            g = p.grad.detach().double().reshape(-1).numpy()
+            d["%s.grad.%s.l2" % (prefix, name)] = np.asarray(np.sqrt((g * g).sum()))
+            d["%s.grad.%s.samples" % (prefix, name)] = g[sample_idx(g.size, k)].astype(np.float32)
+
+
+def main_source_avg_dsc(s, t, bot, top, eps=1e-4):
+    """avg_dsc as redefined in the reference's main_source.py:150-182 (eps 1e-4), which cannot be
+    imported (argparse + missing deps at import).  Formula transcribed for the multi-channel
+    return_mean=True branch only; utils.evaluation.avg_dsc (eps 1e-6) is called directly elsewhere."""
+    d = 2 * torch.sum(s * t, (2, 3, 4)) / (torch.sum(s, (2, 3, 4)) + torch.sum(t, (2, 3, 4)) + eps)
+    return torch.mean(d[:, bot:top])
+
+
+def save(name, d):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote %s (%d keys, %.1f KB)" % (path, len(d), os.path.getsize(path) / 1024))
+
+
+# ----------------------------------------------------------------------------------------------
+def gold_kats():
+    d = {}
+    b = {"mean": torch.zeros(2, 3), "std": torch.ones(2, 3)}
+    d["kl1"] = REV.KLloss(b).numpy()
+    b = {"mean": torch.tensor([[1.0, -2.0, 0.5]]), "std": torch.tensor([[0.0, 2.0, 0.5]])}
+    d["kl2"] = REV.KLloss(b).numpy()
+    s1 = torch.tensor([.9, .1, .8, .2, .7, .3, .6, .4]).view(1, 1, 2, 2, 2)
+    t1 = torch.tensor([1., 0, 1, 0, 0, 1, 1, 0]).view(1, 1, 2, 2, 2)
+    b = {"s": torch.cat((1 - s1, s1), 1), "t": torch.cat((1 - t1, t1), 1)}
+    d["dice1"] = REV.avg_dsc(b, "s", "t", botindex=1, topindex=2).numpy()
+    d["dice1_all"] = REV.avg_dsc(b, "s", "t", botindex=0, topindex=2).numpy()
+    d["dice1_nomean"] = REV.avg_dsc(b, "s", "t", botindex=1, topindex=2, return_mean=False).numpy()
+    d["dice2_binary"] = REV.avg_dsc(b, "s", "t", botindex=1, topindex=2, binary=True).numpy()
+    d["dice3_eps1e4"] = main_source_avg_dsc(b["s"], b["t"], 1, 2).numpy()
+    d["dice_fn"] = REV.dice(b["s"], b["t"]).numpy()
+    d["bin"] = REV.binarize(torch.tensor([.49, .5, .81])).numpy()
+    d["cbin"] = REV.confident_binarize(torch.tensor([.1, .2, .5, .8, .81])).numpy()
+    x = torch.arange(16.).view(1, 2, 2, 2, 2)
+    d["in_relu"] = torch.relu(RM.Normalization(1, 2)(x)).reshape(-1).numpy()
+    p = torch.tensor([.9, .2, .6, .4]).view(1, 1, 1, 2, 2)
+    q = torch.tensor([1., 0, 1, 0]).view(1, 1, 1, 2, 2)
+    d["bce"] = REV.avg_ce({"a": p, "b": q}, "a", "b").numpy()
+    save("kats", d)
+
+
+def block_case(d, tag, ref_mod, shape, seed):
+    """fwd+bwd of one reference block on a hashed input; loss = sum(out * w) with hashed w."""
+    O.deterministic_fill_(ref_mod, seed=seed)
+    n = int(np.prod(shape))
+    x = torch.from_numpy(2 * O.hashed_uniform(n, 7001, seed) - 1).view(shape).requires_grad_(True)
+    y = ref_mod(x)
+    w = torch.from_numpy(2 * O.hashed_uniform(y.numel(), 7002, seed) - 1).view_as(y)
+    (y * w).sum().backward()
+    d[tag + ".shape"] = np.asarray(shape)
+    d[tag + ".seed"] = np.asarray(seed)
+    put(d, tag + ".out", y)
+    put(d, tag + ".gin", x.grad)
+    put_grads(d, tag, ref_mod)
+
+
+def gold_blocks():
+    d = {}
+    block_case(d, "conv_2_8", RM.Conv(2, 8, norm_type=1), (2, 2, 16, 16, 16), 11)
+    block_case(d, "dconv_8_16", RM.DoubleConv(8, 16, norm_type=1), (2, 8, 16, 16, 16), 12)
+    block_case(d, "down_8_16", RM.Down(8, 16, norm_type=1), (2, 8, 16, 16, 16), 13)
+    block_case(d, "up_16_8", RM.Up(16, 8, norm_type=1), (2, 16, 8, 8, 8), 14)
+    block_case(d, "down_64_128", RM.Down(64, 128, norm_type=1), (1, 64, 8, 8, 8), 15)
+    block_case(d, "up_256_128", RM.Up(256, 128, norm_type=1), (1, 256, 3, 3, 3), 16)
+    save("blocks", d)
+
+
+def gold_seg32():
+    d = {}
+    seg = RM.Segmentation(n_channels=1, n_class=2, norm_type=1)
+    O.deterministic_fill_(seg, seed=0)
+    img, lab = O.synthetic_image(2, 32, seed=2), O.synthetic_label(2, 32, seed=3)
+    batch = {"img": img, "gt": O.one_hot(lab)}
+    batch = seg(batch, "img", "pred")
+    dsc = 1 - REV.avg_dsc(batch, "pred", "gt", botindex=1, topindex=2)
+    dsc.backward()
+    d["dice_loss_eps1e6"] = dsc.detach().numpy()
+    d["dice_loss_eps1e4"] = (1 - main_source_avg_dsc(batch["pred"], batch["gt"], 1, 2)).detach().numpy()
+    put(d, "pred", batch["pred"], 256)
+    put_grads(d, "seg", seg)
+    save("seg32", d)
+
+
+def composed_vae(ref_vae, side):
+    """The reference VAE's own sub-modules around fc layers of width 256*side^3: the
+    reference forward hard-codes 16384 / view(256,4,4,4) (joint_model.py:241,253), so for S != 128
+    the trunk/decoder blocks are called exactly as joint_model.py:235-240,255-266 does and only the
+    three linears are resized."""
+    flat = 256 * side ** 3
+    dim = ref_vae.fc_mean.out_features
+    ref_vae.fc_mean = torch.nn.Linear(flat, dim)
+    ref_vae.fc_std = torch.nn.Linear(flat, dim)
+    ref_vae.fc2 = torch.nn.Linear(dim, flat)
+
+    def fwd(x, if_random=False, scale=1, noise=None):
+        v = ref_vae
+        x = v.down5(v.down4(v.down3(v.down2(v.down1(v.in_block(x))))))
+        x = x.view(x.size(0), flat)
+        mean = v.fc_mean(x)
+        std = torch.relu(v.fc_std(x))
+        z = mean + noise * std * scale if if_random else mean
+        x = v.fc2(z).view(x.size(0), 256, side, side, side)
+        x = v.up5(v.up4(v.up3(v.up2(v.up1(x)))))
+        return v.final(v.out_block(x)), mean, std
+    return fwd
+
+
+def gold_vae64():
+    d = {}
+    vae = RM.VAE(n_channels=2, n_class=2, norm_type=1, dim=128)
+    fwd = composed_vae(vae, 2)
+    O.deterministic_fill_(vae, seed=0)
+    gt = O.one_hot(O.synthetic_label(2, 64, seed=3))
+    noise = torch.from_numpy(2 * O.hashed_uniform(2 * 128, 7100, 5) - 1).view(2, 128)
+    recon, mean, std = fwd(gt, if_random=True, scale=0.35, noise=noise)
+    b = {"recon": recon, "gt": gt, "mean": mean, "std": std}
+    kl = REV.KLloss(b)
+    dsc = 1 - main_source_avg_dsc(recon, gt, 1, 2)
+    final = dsc + 0.00002 * kl
+    final.backward()
+    d["kl"], d["dice_loss"], d["final"] = kl.detach().numpy(), dsc.detach().numpy(), final.detach().numpy()
+    d["mean"], d["std"] = mean.detach().numpy(), std.detach().numpy()
+    put(d, "recon", recon, 256)
+    put_grads(d, "vae", vae)
+    save("vae64_train", d)
+
+
+def joint_case(side, native):
+    """joint_train step (main_source.py:449-471,660) on the reference Joint."""
+    seg = RM.Segmentation(n_channels=1, n_class=2, norm_type=1)
+    vae = RM.VAE(n_channels=2, n_class=2, norm_type=1, dim=128)
+    joint = RM.Joint(models=[seg, vae])
+    if not native:
+        fwd = composed_vae(vae, side // 32)
+    O.deterministic_fill_(joint, seed=0)
+    for p in joint.Vae.parameters():
+        p.requires_grad = False
+    joint.Vae.eval()
+    return joint, (None if native else fwd)
+
+
+def gold_joint(side, batch_size, name):
+    d = {}
+    native = side == 128
+    joint, fwd = joint_case(side, native)
+    img, lab = O.synthetic_image(batch_size, side, seed=2), O.synthetic_label(batch_size, side, seed=3)
+    batch = {"img": img, "gt": O.one_hot(lab)}
+    t0 = time.time()
+    if native:
+        batch = joint(batch, "img", "pred", "recon")
+    else:
+        batch = joint.Seg(batch, "img", "pred")
+        batch["recon"], batch["mean"], batch["std"] = fwd(batch["pred"])
+    recon_loss = 1 - main_source_avg_dsc(batch["pred"], batch["recon"], 1, 2)
+    dsc_loss = 1 - main_source_avg_dsc(batch["pred"], batch["gt"], 1, 2)
+    final = 0.1 * recon_loss + dsc_loss
+    final.backward()
+    print("  %s fwd+bwd %.1fs" % (name, time.time() - t0))
+    d["recon_loss"], d["dice_loss"], d["final"] = (recon_loss.detach().numpy(), dsc_loss.detach().numpy(),
+                                                   final.detach().numpy())
+    d["recon_loss_eps1e6"] = (1 - REV.avg_dsc(batch, "pred", "recon", botindex=1, topindex=2)).detach().numpy()
+    d["kl"] = REV.KLloss(batch).detach().numpy()
+    d["mean"], d["std"] = batch["mean"].detach().numpy(), batch["std"].detach().numpy()
+    put(d, "pred", batch["pred"], 512)
+    put(d, "recon", batch["recon"], 512)
+    put_grads(d, "seg", joint.Seg)
+    d["vae_grads_none"] = np.asarray(all(p.grad is None for p in joint.Vae.parameters()))
+    save(name, d)
+
+
+def gold_da128():
+    """domain_adaptation step (main_target.py:531-596), vae_mont_number=1, teacher = copy of student,
+    dropout rates 0, lambda_vae 1.0, domain_loss_type 0 (grads) and 8/9 (loss values)."""
+    d = {}
+    student, _ = joint_case(128, True)
+    teacher, _ = joint_case(128, True)
+    # make the teacher differ from the student so the pseudo-label is not the student's own argmax
+    O.deterministic_fill_(teacher.Seg, seed=1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    teacher.eval()
+    img, lab = O.synthetic_image(1, 128, seed=2), O.synthetic_label(1, 128, seed=3)
+    batch = {"img": img, "gt": O.one_hot(lab)}
+    batch = student(batch, "img", "pred", "recon", dropout=True)
+    with torch.no_grad():
+        batch = teacher(batch, "img", "fake", "_asdf")
+    fake_soft = batch["fake"]
+    batch["fake"] = REV.binarize(fake_soft)
+    recon_loss = 1 - REV.avg_dsc(batch, "pred", "recon", botindex=1, topindex=2)
+    klloss = REV.KLloss(batch)
+    dsc_loss = 1 - REV.avg_dsc(batch, "pred", "gt", botindex=1, topindex=2)
+    fake_loss = 1 - REV.avg_dsc(batch, "pred", "fake", botindex=1, topindex=2)
+    final0 = 1.0 * recon_loss + fake_loss
+    final0.backward()
+    cur = O.lambda_schedule(recon_loss, 1.0)
+    final8 = (recon_loss + 1 / cur * fake_loss) if cur > 1 else (cur * recon_loss + fake_loss)
+    final9 = (cur * recon_loss + fake_loss) / (1 + cur)
+    for k, v in (("recon_loss", recon_loss), ("kl", klloss), ("dice_loss", dsc_loss), ("fake_loss", fake_loss),
+                 ("final0", final0), ("final8", final8), ("final9", final9)):
+        d[k] = v.detach().numpy()
+    d["cur_lambda"] = np.asarray(cur)
+    d["teacher_mean"], d["teacher_std"] = batch["mean"].detach().numpy(), batch["std"].detach().numpy()
+    put(d, "pred", batch["pred"], 512)
+    put(d, "fake_soft", fake_soft, 512)
+    d["fake.sum"] = batch["fake"].double().sum().numpy()
+    cb = REV.confident_binarize(fake_soft)
+    d["cfake.sum"] = cb.double().sum().numpy()
+    put_grads(d, "seg", student.Seg)
+    save("da128", d)
+
+
+def gold_vae128_native():
+    """vae_train step on the NATIVE reference VAE (main_source.py:389-413): z is the reference's own
+    torch.randn draw under torch.manual_seed(123), recorded so the oracle / HIP path can inject it."""
+    d = {}
+    vae = RM.VAE(n_channels=2, n_class=2, norm_type=1, dim=128)
+    O.deterministic_fill_(vae, seed=0)
+    gt = O.one_hot(O.synthetic_label(1, 128, seed=3))
+    torch.manual_seed(123)
+    z = torch.randn(1, 128)
+    torch.manual_seed(123)
+    recon, mean, std = vae(gt, if_random=True, scale=0.35)
+    b = {"recon": recon, "gt": gt, "mean": mean, "std": std}
+    kl = REV.KLloss(b)
+    dsc = 1 - main_source_avg_dsc(recon, gt, 1, 2)
+    final = dsc + 0.00002 * kl
+    final.backward()
+    d["z"] = z.numpy()
+    d["kl"], d["dice_loss"], d["final"] = kl.detach().numpy(), dsc.detach().numpy(), final.detach().numpy()
+    d["mean"], d["std"] = mean.detach().numpy(), std.detach().numpy()
+    put(d, "recon", recon, 512)
+    put_grads(d, "vae", vae)
+    save("vae128_train", d)
+
+
+CASES = {
+    "kats": gold_kats,
+    "blocks": gold_blocks,
+    "seg32": gold_seg32,
+    "vae64_train": gold_vae64,
+    "joint64": lambda: gold_joint(64, 2, "joint64"),
+    "joint96": lambda: gold_joint(96, 2, "joint96"),
+    "joint128": lambda: gold_joint(128, 1, "joint128"),
+    "da128": gold_da128,
+    "vae128_train": gold_vae128_native,
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    a = ap.parse_args()
+    for nm, fn in CASES.items():
+        if a.only and nm not in a.only:
+            continue
+        t = time.time()
+        fn()
+        print("%s done in %.1fs" % (nm, time.time() - t))

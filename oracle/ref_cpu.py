@@ -1,0 +1,419 @@
+"""CPU oracle for the 3D VAE + segmentation training path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch fp32 restatement (stock ``nn.Conv3d`` / ``nn.ConvTranspose3d`` /
+``nn.InstanceNorm3d`` / ``nn.Linear`` on the CPU) of the hot path of yyNoBug/VAE_segmentation.
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it; the product (``vae_segmentation_amd``) never does and has no CPU fallback.
+
+Parity pin: the reference holds no tests / golden vectors of its own, so this
+oracle is pinned against outputs of the *reference itself* run in the build container:
+``oracle/make_golden.py`` imports ``/root/reference/joint_model.py`` and
+``/root/reference/utils/evaluation.py`` unmodified and writes ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks this file against those fixtures.
+
+What each piece follows in the reference (file:line, all under /root/reference):
+  * ``norm_layer``                joint_model.py:9-15   (norm_type 1 -> InstanceNorm3d, 2 -> BatchNorm3d)
+  * ``Conv``                      joint_model.py:101-112
+  * ``DoubleConv``                joint_model.py:35-52  (three conv/norm/act triples)
+  * ``Up`` / ``Down``             joint_model.py:114-136
+  * ``VAE``                       joint_model.py:204-272 (generalised: ``spatial`` replaces the hard-wired 128)
+  * ``Segmentation``              joint_model.py:349-390
+  * ``Joint``                     joint_model.py:438-452
+  * ``dice_scores`` / ``avg_dsc`` utils/evaluation.py:48-80 (eps 1e-6) and main_source.py:150-182 (eps 1e-4)
+  * ``KLloss``                    utils/evaluation.py:42-45
+  * ``binarize`` / ``confident_binarize``  utils/evaluation.py:9-18
+  * ``avg_ce``                    utils/evaluation.py:29-39
+  * ``one_hot``                   main_source.py:449-451
+  * ``joint_train_losses``        main_source.py:469-471
+  * ``vae_train_losses``          main_source.py:393-413
+  * ``seg_train_losses``          main_source.py:440-441
+  * ``domain_adaptation_losses``  main_target.py:531-596
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+FMAPS = (8, 16, 32, 64, 128, 256)
+
+
+# --------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------
+def norm_layer(norm_type, channels):
+    if norm_type == 1:
+        return nn.InstanceNorm3d(channels)
+    if norm_type == 2:
+        return nn.BatchNorm3d(channels, momentum=0.1)
+    raise ValueError("oracle covers norm_type 1 (InstanceNorm3d) and 2 (BatchNorm3d) only")
+
+
+def _act(soft, inplace):
+    return nn.Softplus() if soft else nn.ReLU(inplace=inplace)
+
+
+def _cna(cin, cout, norm_type, soft, inplace):
+    """conv3x3x3 -> norm -> activation, as three Sequential entries."""
+    return [nn.Conv3d(cin, cout, 3, padding=1), norm_layer(norm_type, cout), _act(soft, inplace)]
+
+
+class Conv(nn.Module):
+    def __init__(self, in_ch, out_ch, norm_type=2, num_group=1, activation=True, norm=True, soft=False):
+        super().__init__()
+        self.conv = nn.Sequential(*_cna(in_ch, out_ch, norm_type, soft, True))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class DoubleConv(nn.Module):
+    def __init__(self, in_ch, out_ch, norm_type=2, soft=False):
+        super().__init__()
+        layers = []
+        for cin in (in_ch, out_ch, out_ch):
+            layers += _cna(cin, out_ch, norm_type, soft, False)
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Up(nn.Module):
+    def __init__(self, in_ch, out_ch, norm_type=2, kernal_size=(2, 2, 2), stride=(2, 2, 2), soft=False):
+        super().__init__()
+        self.conv = nn.Sequential(nn.ConvTranspose3d(in_ch, in_ch, kernal_size, stride=stride, padding=0),
+                                  DoubleConv(in_ch, out_ch, norm_type, soft=False))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Down(nn.Module):
+    def __init__(self, in_ch, out_ch, norm_type=2, kernal_size=(2, 2, 2), stride=(2, 2, 2), soft=False):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv3d(in_ch, in_ch, kernal_size, stride=stride, padding=0),
+                                  DoubleConv(in_ch, out_ch, norm_type, soft=False))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+def _maybe_dropout(x, p):
+    return F.dropout(x, p=p, training=True) if p else x
+
+
+class VAE(nn.Module):
+    """Shape VAE.  ``spatial`` = input side S (multiple of 32); latent flatten = 256*(S/32)^3.
+
+    The reference hard-wires S=128 (flatten 16384, view(B,256,4,4,4)); ``spatial=128`` gives the
+    reference's state_dict shapes exactly.  ``noise`` lets a test inject the z the reference drew.
+    """
+
+    def __init__(self, n_channels, n_class, norm_type=2, n_fmaps=FMAPS, dim=1024, soft=False, spatial=128):
+        super().__init__()
+        f = list(n_fmaps)
+        self.in_block = Conv(n_class, f[0], norm_type=norm_type)
+        for i in range(5):
+            setattr(self, "down%d" % (i + 1), Down(f[i], f[i + 1], norm_type=norm_type))
+        self.side = spatial // 32
+        self.top_ch = f[5]
+        self.flat = f[5] * self.side ** 3
+        self.fc_mean = nn.Linear(self.flat, dim)
+        self.fc_std = nn.Linear(self.flat, dim)
+        self.fc2 = nn.Linear(dim, self.flat)
+        for i in range(5):
+            setattr(self, "up%d" % (i + 1), Up(f[5 - i], f[4 - i], norm_type=norm_type))
+        self.out_block = nn.Conv3d(f[0], n_class, 3, padding=1)
+        self.final = nn.Softmax(dim=1)
+        self.n_class = n_class
+
+    def encode(self, x):
+        x = self.in_block(x)
+        for i in range(1, 6):
+            x = getattr(self, "down%d" % i)(x)
+        x = x.reshape(x.size(0), self.flat)
+        return self.fc_mean(x), F.relu(self.fc_std(x))
+
+    def decode(self, z, dropout=0.0):
+        x = self.fc2(z).view(z.size(0), self.top_ch, self.side, self.side, self.side)
+        for i in range(1, 6):
+            x = _maybe_dropout(getattr(self, "up%d" % i)(x), dropout)
+        return self.final(self.out_block(x))
+
+    def forward(self, x, if_random=False, scale=1, mid_input=False, dropout=0.0, noise=None):
+        if mid_input:
+            return self.decode(x, dropout)
+        mean, std = self.encode(x)
+        if noise is None:
+            noise = torch.randn(mean.size(0), mean.size(1))
+        z = mean + noise.to(mean) * std * scale if if_random else mean
+        return self.decode(z, dropout), mean, std
+
+
+class Segmentation(nn.Module):
+    def __init__(self, n_channels, n_class, norm_type=2, n_fmaps=FMAPS):
+        super().__init__()
+        f = list(n_fmaps)
+        self.in_block = Conv(n_channels, f[0], norm_type=norm_type)
+        for i in range(4):
+            setattr(self, "down%d" % (i + 1), Down(f[i], f[i + 1], norm_type=norm_type))
+        for i in range(4):
+            setattr(self, "up%d" % (i + 2), Up(f[4 - i], f[3 - i], norm_type=norm_type))
+        self.out_block = nn.Conv3d(f[0], n_class, 3, padding=1)
+        self.final = nn.Softmax(dim=1)
+        self.n_class = n_class
+
+    def forward(self, data_dict, in_key, out_key, dropout=0.0):
+        x1 = self.in_block(data_dict[in_key])
+        x2 = self.down1(x1)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        x5 = self.down4(x4)
+        x = _maybe_dropout(self.up2(x5), dropout)
+        x = _maybe_dropout(self.up3(x) + x3, dropout)
+        x = _maybe_dropout(self.up4(x) + x2, dropout)
+        x = _maybe_dropout(self.up5(x), dropout)
+        x = _maybe_dropout(self.out_block(x), dropout)
+        data_dict[out_key] = self.final(x)
+        return data_dict
+
+
+class Joint(nn.Module):
+    def __init__(self, models, vae_forward_scale=0.0, vae_decoder_dropout=0.0, seg_dropout=0.0):
+        super().__init__()
+        self.Seg, self.Vae = models[0], models[1]
+        self.vae_forward_scale = vae_forward_scale
+        self.vae_decoder_dropout = vae_decoder_dropout
+        self.seg_dropout = seg_dropout
+
+    def forward(self, data_dict, in_key, out_key, out_key_recon, dropout=False):
+        if dropout:
+            data_dict = self.Seg(data_dict, in_key, out_key, dropout=self.seg_dropout)
+            data_dict[out_key_recon], _, _ = self.Vae(data_dict[out_key], if_random=False,
+                                                      scale=self.vae_forward_scale,
+                                                      dropout=self.vae_decoder_dropout)
+        else:
+            data_dict = self.Seg(data_dict, in_key, out_key)
+            (data_dict[out_key_recon], data_dict["mean"], data_dict["std"]) = self.Vae(
+                data_dict[out_key], if_random=False, scale=self.vae_forward_scale)
+        return data_dict
+
+
+# --------------------------------------------------------------------------------------
+# losses / label prep
+# --------------------------------------------------------------------------------------
+EPS_EVALUATION = 1e-6   # utils/evaluation.py:72-79
+EPS_MAIN_SOURCE = 1e-4  # main_source.py:174-181
+
+
+def one_hot(label, n_class=2):
+    """(B,1,D,H,W) integer-valued labels -> (B,n_class,D,H,W) float one-hot."""
+    lab = label.long()
+    out = torch.zeros(lab.size(0), n_class, *lab.shape[2:], dtype=torch.float32)
+    return out.scatter_(1, lab, 1)
+
+
+def _hard(mask):
+    idx = torch.argmax(mask, dim=1, keepdim=True)
+    return torch.zeros_like(mask).scatter_(1, idx, 1)
+
+
+def dice_scores(s, t, eps=EPS_EVALUATION):
+    """per (b,c) soft dice 2*sum(s*t)/(sum s + sum t + eps); -> (B,C)."""
+    dims = (2, 3, 4)
+    return 2 * torch.sum(s * t, dims) / (torch.sum(s, dims) + torch.sum(t, dims) + eps)
+
+
+def avg_dsc(data_dict, source_key="align_lung", target_key="source_lung", binary=False, topindex=2,
+            botindex=0, pad=(0, 0, 0), return_mean=True, detach=False, eps=EPS_EVALUATION):
+    s, t = data_dict[source_key], data_dict[target_key]
+    if detach:
+        t = t.detach()
+    if binary:
+        s, t = _hard(s), _hard(t)
+    d = dice_scores(s, t, eps)
+    if s.shape[1] > 1:
+        d = d[:, botindex:topindex]
+        return torch.mean(d) if return_mean else torch.mean(d, 1)
+    return torch.mean(d) if return_mean else torch.mean(d, 1)
+
+
+def dice(a, b):
+    return 2.0 * torch.sum(a * b) / (torch.sum(a) + torch.sum(b) + 1e-6)
+
+
+def KLloss(data_dict, mean_key="mean", std_key="std"):
+    m, s = data_dict[mean_key], data_dict[std_key]
+    per_sample = 0.5 * ((s * s).sum(1) + (m * m).sum(1) - 2 * torch.log(s + 1e-5).sum(1))
+    return per_sample.mean()
+
+
+def binarize(a):
+    return (a >= 0.5).float()
+
+
+def confident_binarize(a, max=0.8, min=0.2):
+    b = a.clone()
+    b[b > max] = 1
+    b[b < min] = 0
+    return b
+
+
+def avg_ce(data_dict, source_key="align_lung", target_key="source_lung"):
+    src = data_dict[source_key]
+    if not isinstance(src, list):
+        src = [src]
+    crit = nn.BCELoss()
+    return sum(crit(im, data_dict[target_key]) for im in src) / len(src)
+
+
+# --------------------------------------------------------------------------------------
+# train-step loss bodies (what the benchmark times, minus data loading / logging)
+# --------------------------------------------------------------------------------------
+def joint_train_losses(joint, img, label, lambda_vae=0.1, eps=EPS_MAIN_SOURCE, n_class=2):
+    batch = {"img": img, "gt": one_hot(label, n_class)}
+    batch = joint(batch, "img", "pred", "recon")
+    recon_loss = 1 - avg_dsc(batch, "pred", "recon", botindex=1, topindex=n_class, eps=eps)
+    dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=eps)
+    final = lambda_vae * recon_loss + dsc_loss
+    return final, {"recon_loss": recon_loss, "dice_loss": dsc_loss, "batch": batch}
+
+
+def seg_train_losses(seg, img, label, eps=EPS_MAIN_SOURCE, n_class=2):
+    batch = {"img": img, "gt": one_hot(label, n_class)}
+    batch = seg(batch, "img", "pred")
+    dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=eps)
+    return dsc_loss, {"dice_loss": dsc_loss, "batch": batch}
+
+
+def vae_train_losses(vae, label, scale=0.35, noise=None, eps=EPS_MAIN_SOURCE, n_class=2):
+    gt = one_hot(label, n_class)
+    recon, mean, std = vae(gt, if_random=True, scale=scale, noise=noise)
+    batch = {"gt": gt, "recon": recon, "mean": mean, "std": std}
+    kl = KLloss(batch)
+    dsc_loss = 1 - avg_dsc(batch, "recon", "gt", botindex=1, topindex=n_class, eps=eps)
+    final = dsc_loss + 0.00002 * kl
+    return final, {"dice_loss": dsc_loss, "kl_loss": kl, "batch": batch}
+
+
+def lambda_schedule(recon_loss, lambda_vae):
+    """main_target.py:551-554 (domain_loss_type 8/9/15/16)."""
+    r = float(recon_loss)
+    if r < 0.15:
+        return lambda_vae * 0.6
+    if r < 0.225:
+        return lambda_vae * 1.2
+    if r < 0.3:
+        return lambda_vae * 2.0
+    return lambda_vae * 3.0
+
+
+def domain_adaptation_losses(student, teacher, img, label, lambda_vae=1.0, domain_loss_type=0, kl=False,
+                             use_confident_binarize=False, eps=EPS_EVALUATION, n_class=2):
+    """One Monte-Carlo pass (vae_mont_number=1) of main_target.py:531-596."""
+    batch = {"img": img, "gt": one_hot(label, n_class)}
+    batch = student(batch, "img", "pred", "recon", dropout=True)
+    with torch.no_grad():
+        batch = teacher(batch, "img", "fake", "_unused")
+    fake = batch["fake"]
+    batch["fake"] = confident_binarize(fake) if use_confident_binarize else binarize(fake)
+    recon_loss = 1 - avg_dsc(batch, "pred", "recon", botindex=1, topindex=n_class, eps=eps)
+    klloss = KLloss(batch)
+    dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=eps)
+    fake_loss = 1 - avg_dsc(batch, "pred", "fake", botindex=1, topindex=n_class, eps=eps)
+    if domain_loss_type == 8:
+        cur = lambda_schedule(recon_loss, lambda_vae)
+        if cur > 1:
+            final = recon_loss + (klloss if kl else 0) + 1 / cur * fake_loss
+        else:
+            final = cur * (recon_loss + (klloss if kl else 0)) + fake_loss
+    elif domain_loss_type == 9:
+        cur = lambda_schedule(recon_loss, lambda_vae)
+        final = (cur * recon_loss + fake_loss) / (1 + cur)
+    elif domain_loss_type == 0:
+        final = lambda_vae * recon_loss + fake_loss
+        if kl:
+            final = final + 0.00002 * lambda_vae * klloss
+    else:
+        raise ValueError("oracle restates domain_loss_type 0, 8, 9")
+    return final, {"recon_loss": recon_loss, "kl_loss": klloss, "dice_loss": dsc_loss,
+                   "dice_loss_fake": fake_loss, "batch": batch}
+
+
+# --------------------------------------------------------------------------------------
+# deterministic, RNG-free parameter fill and synthetic inputs (shared by goldens, tests, bench)
+# --------------------------------------------------------------------------------------
+def _mix64(x):
+    """splitmix64 finaliser on uint64 numpy arrays (wraps mod 2^64)."""
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def hashed_uniform(n, stream, seed=0):
+    """n floats in [0,1), a pure function of (seed, stream, index)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        key = np.uint64((seed * 0x9E3779B97F4A7C15 + stream * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) % (1 << 64))
+        h = _mix64(idx * np.uint64(0x9E3779B97F4A7C15) + key)
+    return ((h >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
+
+
+def _name_stream(name):
+    return zlib.crc32(name.encode("utf-8")) & 0x7FFFFFFF
+
+
+def _fan_in(name, p):
+    if p.dim() >= 2:
+        return int(np.prod(p.shape[1:]))
+    return max(int(p.numel()), 1)
+
+
+def deterministic_fill_(module, seed=0, gain=1.0):
+    """Fill every parameter with uniform(-a, a), a = gain*sqrt(3/fan_in) for weights and a = 0.1 for
+    biases.  No RNG: values depend only on (seed, crc32(parameter name), element index), so the same call
+    on the reference modules, on this oracle and on the HIP modules gives identical weights."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            u = hashed_uniform(p.numel(), _name_stream(name), seed)
+            bound = 0.1 if p.dim() == 1 else gain * math.sqrt(3.0 / _fan_in(name, p))
+            vals = (2.0 * u - 1.0) * np.float32(bound)
+            p.copy_(torch.from_numpy(vals).view_as(p))
+    return module
+
+
+def synthetic_image(batch, side, seed=2):
+    """~ clip(N(0,1), -1, 1), shape (B,1,S,S,S); Box-Muller on the hashed uniforms."""
+    n = batch * side ** 3
+    u1 = np.maximum(hashed_uniform(n, 1001, seed), 1e-7).astype(np.float64)
+    u2 = hashed_uniform(n, 1002, seed).astype(np.float64)
+    g = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return torch.from_numpy(np.clip(g, -1, 1).astype(np.float32)).view(batch, 1, side, side, side)
+
+
+def synthetic_label(batch, side, seed=3, kind="ellipsoid"):
+    """(B,1,S,S,S) float labels in {0,1}: a centred ellipsoid with a hashed ragged rim, or Bernoulli(0.1)."""
+    n = batch * side ** 3
+    u = hashed_uniform(n, 2001, seed).reshape(batch, side, side, side)
+    if kind == "bernoulli":
+        lab = (u < 0.1)
+    else:
+        ax = (np.arange(side, dtype=np.float32) + 0.5) / side - 0.5
+        z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+        r = (z / 0.30) ** 2 + (y / 0.22) ** 2 + (x / 0.36) ** 2
+        lab = (r[None] + 0.35 * (u - 0.5)) < 1.0
+    return torch.from_numpy(lab.astype(np.float32)).view(batch, 1, side, side, side)
+
+
+def build_joint(spatial, dim=128, seed=0):
+    seg = Segmentation(n_channels=1, n_class=2, norm_type=1)
+    vae = VAE(n_channels=2, n_class=2, norm_type=1, dim=dim, spatial=spatial)
+    joint = Joint([seg, vae])
+    deterministic_fill_(joint, seed=seed)
+    for p in joint.Vae.parameters():
+        p.requires_grad = False
+    joint.Vae.eval()
+    return joint

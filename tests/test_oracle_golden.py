@@ -1,0 +1,139 @@
+"""CPU: the oracle (oracle/ref_cpu.py) reproduces what the unmodified reference produced
+(tests/golden/*.npz, written by oracle/make_golden.py in the build container)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu as O
+from tests import golden_util as G
+
+torch.set_num_threads(8)
+
+
+def test_kats():
+    g = G.load("kats")
+    assert np.allclose(O.KLloss({"mean": torch.zeros(2, 3), "std": torch.ones(2, 3)}).numpy(), g["kl1"], rtol=0, atol=0)
+    b = {"mean": torch.tensor([[1.0, -2.0, 0.5]]), "std": torch.tensor([[0.0, 2.0, 0.5]])}
+    assert np.allclose(O.KLloss(b).numpy(), g["kl2"], rtol=1e-7)
+    s1 = torch.tensor([.9, .1, .8, .2, .7, .3, .6, .4]).view(1, 1, 2, 2, 2)
+    t1 = torch.tensor([1., 0, 1, 0, 0, 1, 1, 0]).view(1, 1, 2, 2, 2)
+    b = {"s": torch.cat((1 - s1, s1), 1), "t": torch.cat((1 - t1, t1), 1)}
+    assert O.avg_dsc(b, "s", "t", botindex=1, topindex=2).item() == pytest.approx(float(g["dice1"]), rel=1e-7)
+    assert O.avg_dsc(b, "s", "t", botindex=0, topindex=2).item() == pytest.approx(float(g["dice1_all"]), rel=1e-7)
+    assert np.allclose(O.avg_dsc(b, "s", "t", botindex=1, topindex=2, return_mean=False).numpy(), g["dice1_nomean"])
+    assert O.avg_dsc(b, "s", "t", botindex=1, topindex=2, binary=True).item() == pytest.approx(float(g["dice2_binary"]), rel=1e-7)
+    assert O.avg_dsc(b, "s", "t", botindex=1, topindex=2, eps=1e-4).item() == pytest.approx(float(g["dice3_eps1e4"]), rel=1e-7)
+    assert O.dice(b["s"], b["t"]).item() == pytest.approx(float(g["dice_fn"]), rel=1e-7)
+    assert np.array_equal(O.binarize(torch.tensor([.49, .5, .81])).numpy(), g["bin"])
+    assert np.array_equal(O.confident_binarize(torch.tensor([.1, .2, .5, .8, .81])).numpy(), g["cbin"])
+    x = torch.arange(16.).view(1, 2, 2, 2, 2)
+    assert np.allclose(torch.relu(O.norm_layer(1, 2)(x)).reshape(-1).numpy(), g["in_relu"], rtol=1e-6)
+    # the values SURVEY.md §4 recorded from the reference
+    assert float(g["kl1"]) == pytest.approx(1.4999699592590332, rel=1e-7)
+    assert float(g["dice1"]) == pytest.approx(0.6499999165534973, rel=1e-7)
+    p = torch.tensor([.9, .2, .6, .4]).view(1, 1, 1, 2, 2)
+    q = torch.tensor([1., 0, 1, 0]).view(1, 1, 1, 2, 2)
+    assert O.avg_ce({"a": p, "b": q}, "a", "b").item() == pytest.approx(float(g["bce"]), rel=1e-6)
+
+
+BLOCKS = {
+    "conv_2_8": lambda: O.Conv(2, 8, norm_type=1),
+    "dconv_8_16": lambda: O.DoubleConv(8, 16, norm_type=1),
+    "down_8_16": lambda: O.Down(8, 16, norm_type=1),
+    "up_16_8": lambda: O.Up(16, 8, norm_type=1),
+    "down_64_128": lambda: O.Down(64, 128, norm_type=1),
+    "up_256_128": lambda: O.Up(256, 128, norm_type=1),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(BLOCKS))
+def test_blocks(tag):
+    g = G.load("blocks")
+    mod = BLOCKS[tag]()
+    seed = int(g[tag + ".seed"])
+    shape = tuple(int(v) for v in g[tag + ".shape"])
+    O.deterministic_fill_(mod, seed=seed)
+    x = torch.from_numpy(2 * O.hashed_uniform(int(np.prod(shape)), 7001, seed) - 1).view(shape).requires_grad_(True)
+    y = mod(x)
+    w = torch.from_numpy(2 * O.hashed_uniform(y.numel(), 7002, seed) - 1).view_as(y)
+    (y * w).sum().backward()
+    G.check_tensor(g, tag + ".out", y, rtol=1e-5, what=tag)
+    G.check_tensor(g, tag + ".gin", x.grad, rtol=1e-5, what=tag)
+    G.check_grads(g, tag, [(n, p.grad) for n, p in mod.named_parameters()], rtol=1e-5, what=tag)
+
+
+def test_seg32():
+    g = G.load("seg32")
+    seg = O.deterministic_fill_(O.Segmentation(1, 2, norm_type=1), seed=0)
+    loss, aux = O.seg_train_losses(seg, O.synthetic_image(2, 32, 2), O.synthetic_label(2, 32, 3), eps=1e-6)
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["dice_loss_eps1e6"]), rel=1e-6)
+    G.check_tensor(g, "pred", aux["batch"]["pred"], k=256, rtol=1e-5)
+    G.check_grads(g, "seg", [(n, p.grad) for n, p in seg.named_parameters()], rtol=1e-5)
+    l4, _ = O.seg_train_losses(seg, O.synthetic_image(2, 32, 2), O.synthetic_label(2, 32, 3), eps=1e-4)
+    assert l4.item() == pytest.approx(float(g["dice_loss_eps1e4"]), rel=1e-6)
+
+
+def test_vae64_train():
+    g = G.load("vae64_train")
+    vae = O.deterministic_fill_(O.VAE(2, 2, norm_type=1, dim=128, spatial=64), seed=0)
+    noise = torch.from_numpy(2 * O.hashed_uniform(2 * 128, 7100, 5) - 1).view(2, 128)
+    final, aux = O.vae_train_losses(vae, O.synthetic_label(2, 64, 3), scale=0.35, noise=noise)
+    final.backward()
+    assert final.item() == pytest.approx(float(g["final"]), rel=1e-6)
+    assert aux["kl_loss"].item() == pytest.approx(float(g["kl"]), rel=1e-5)
+    assert np.allclose(aux["batch"]["mean"].detach().numpy(), g["mean"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(aux["batch"]["std"].detach().numpy(), g["std"], rtol=1e-4, atol=1e-6)
+    G.check_tensor(g, "recon", aux["batch"]["recon"], k=256, rtol=1e-5)
+    G.check_grads(g, "vae", [(n, p.grad) for n, p in vae.named_parameters()], rtol=1e-4)
+
+
+@pytest.mark.parametrize("side,bs,name", [(64, 2, "joint64"), (96, 2, "joint96"), (128, 1, "joint128")])
+def test_joint_train(side, bs, name):
+    g = G.load(name)
+    joint = O.build_joint(side)
+    final, aux = O.joint_train_losses(joint, O.synthetic_image(bs, side, 2), O.synthetic_label(bs, side, 3))
+    final.backward()
+    assert final.item() == pytest.approx(float(g["final"]), rel=1e-6)
+    assert aux["recon_loss"].item() == pytest.approx(float(g["recon_loss"]), rel=1e-5)
+    assert aux["dice_loss"].item() == pytest.approx(float(g["dice_loss"]), rel=1e-6)
+    b = aux["batch"]
+    assert O.KLloss(b).item() == pytest.approx(float(g["kl"]), rel=1e-5)
+    G.check_tensor(g, "pred", b["pred"], k=512, rtol=1e-5)
+    G.check_tensor(g, "recon", b["recon"], k=512, rtol=1e-5)
+    G.check_grads(g, "seg", [(n, p.grad) for n, p in joint.Seg.named_parameters()], rtol=1e-4)
+    assert all(p.grad is None for p in joint.Vae.parameters()) and bool(g["vae_grads_none"])
+
+
+def test_domain_adaptation128():
+    g = G.load("da128")
+    student, teacher = O.build_joint(128), O.build_joint(128)
+    O.deterministic_fill_(teacher.Seg, seed=1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    img, lab = O.synthetic_image(1, 128, 2), O.synthetic_label(1, 128, 3)
+    final, aux = O.domain_adaptation_losses(student, teacher, img, lab, lambda_vae=1.0, domain_loss_type=0)
+    final.backward()
+    assert final.item() == pytest.approx(float(g["final0"]), rel=1e-6)
+    for k_o, k_g in (("recon_loss", "recon_loss"), ("kl_loss", "kl"), ("dice_loss", "dice_loss"),
+                     ("dice_loss_fake", "fake_loss")):
+        assert aux[k_o].item() == pytest.approx(float(g[k_g]), rel=1e-5), k_o
+    assert aux["batch"]["fake"].double().sum().item() == float(g["fake.sum"])
+    G.check_grads(g, "seg", [(n, p.grad) for n, p in student.Seg.named_parameters()], rtol=1e-4)
+    cur = O.lambda_schedule(aux["recon_loss"].detach(), 1.0)
+    assert cur == pytest.approx(float(g["cur_lambda"]))
+    r, f = aux["recon_loss"].item(), aux["dice_loss_fake"].item()
+    f8 = (r + f / cur) if cur > 1 else (cur * r + f)
+    assert f8 == pytest.approx(float(g["final8"]), rel=1e-5)
+    assert (cur * r + f) / (1 + cur) == pytest.approx(float(g["final9"]), rel=1e-5)
+
+
+def test_vae128_native_with_recorded_noise():
+    g = G.load("vae128_train")
+    vae = O.deterministic_fill_(O.VAE(2, 2, norm_type=1, dim=128, spatial=128), seed=0)
+    assert vae.fc_mean.weight.shape == (128, 16384)      # reference state_dict shape at the native size
+    final, aux = O.vae_train_losses(vae, O.synthetic_label(1, 128, 3), scale=0.35, noise=torch.from_numpy(g["z"]))
+    final.backward()
+    assert final.item() == pytest.approx(float(g["final"]), rel=1e-6)
+    G.check_tensor(g, "recon", aux["batch"]["recon"], k=512, rtol=1e-5)
+    G.check_grads(g, "vae", [(n, p.grad) for n, p in vae.named_parameters()], rtol=1e-4)
