@@ -1,0 +1,186 @@
+/* libvaeseg — C ABI of the MI355X (gfx950) kernels behind the joint_model.py surface.
+ *
+ * The reference (yyNoBug/VAE_segmentation) has no FFI of its own: its hot path is the stock ATen ops
+ * that joint_model.py / utils/evaluation.py invoke.  Each entry point below replaces one such op (or a
+ * fused group of them); the reference call site it stands in for is cited as file:line under
+ * /root/reference.  INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); nothing is allocated, freed or
+ *     synchronised inside; every launch goes to `stream` (a hipStream_t passed as void*).
+ *   - activations are channels-last: [N][D][H][W][C], C a multiple of 8, element type `dtype`
+ *     (VS_F32 or VS_BF16).  "planar" tensors are the reference's NCDHW fp32: [N][C][D*H*W].
+ *   - a *lazy* activation is a raw conv output plus `stats`: double[N][C][2] = (sum, sum of squares)
+ *     over the D*H*W voxels of each (n,c), accumulated by the producing kernel.  Passing `stats` to a
+ *     consumer makes it read relu((x-mean)*rstd) — InstanceNorm3d(affine=False, eps) + ReLU
+ *     (joint_model.py:11,41-48,107-108) — without that tensor ever being materialised.  stats == NULL
+ *     means "use x as is".
+ *   - return value: 0 on success, negative VS_E* on a rejected call, positive = hipError_t.
+ *   - the library is re-entrant: no mutable globals.
+ */
+#ifndef VAESEG_H
+#define VAESEG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_VERSION 100
+
+enum { VS_F32 = 0, VS_BF16 = 1 };
+enum { VS_OK = 0, VS_EINVAL = -1, VS_ESHAPE = -2, VS_EDTYPE = -3, VS_EWORKSPACE = -4, VS_EALIGN = -5 };
+
+/* geometry of an implicit-GEMM convolution */
+enum {
+    VS_CONV_K3 = 0,     /* 3x3x3, stride 1, pad 1          nn.Conv3d(...,3,padding=1)        joint_model.py:40,43,46,106,224,366 */
+    VS_CONV_K2S2 = 1,   /* 2x2x2, stride 2, pad 0          nn.Conv3d(C,C,2,stride=2)         joint_model.py:130 */
+    VS_CONV_T2S2 = 2    /* 2x2x2 transposed, stride 2      nn.ConvTranspose3d(C,C,2,stride=2) joint_model.py:118 */
+};
+
+/* how a weight tensor src[d0][d1][ntaps] (fp32, the reference's parameter layout) is packed into MFMA
+ * fragment order for a GEMM whose rows are output channels m and whose k runs over (tap, channel c) */
+enum {
+    VS_PACK_ROWS_D0 = 0,       /* m = d0, c = d1                 : Conv3d forward; ConvTranspose3d backward-data        */
+    VS_PACK_ROWS_D1_FLIP = 1,  /* m = d1, c = d0, taps mirrored  : Conv3d(k3,p1) backward-data                          */
+    VS_PACK_SCATTER_D1 = 2     /* rows (tap, m = d1), k = c = d0 : ConvTranspose3d forward; Conv3d(k2,s2) backward-data */
+};
+
+int vs_version(void);
+const char* vs_strerror(int code);
+
+/* ---- weights ---------------------------------------------------------------------------------- */
+/* bytes of the packed image of a weight with `rows` GEMM rows (any count; padded to 16 inside),
+ * `c_pad` k-side channels (multiple of 8) and ntaps taps (27, 8, or 1 for VS_PACK_SCATTER_D1). */
+size_t vs_packed_weight_bytes(int rows, int c_pad, int ntaps, int dtype);
+/* src: float[d0][d1][ntaps]; c_pad >= the k-side channel count, zero-filled beyond it. */
+int vs_pack_weight(const float* src, void* dst, int d0, int d1, int ntaps, int c_pad, int form, int dtype, void* stream);
+
+/* ---- convolutions (implicit GEMM on MFMA) ------------------------------------------------------ */
+/* y[n,v,m] = bias[m] + sum_{tap,c} act(x)[n, v*s + off(tap) - p, c] * W[m][tap][c]
+ *   kind K3  : x,y both (N,D,H,W);   kind K2S2: x is (N,D,H,W), y is (N,D/2,H/2,W/2).
+ * Also the backward-data of K3 (with VS_PACK_ROWS_D1_FLIP weights) and of T2S2 (kind K2S2 with the
+ * transposed-conv weight packed VS_PACK_ROWS_D0).
+ *   x_stats  : lazy-activation stats of x or NULL         y_stats : if non-NULL, (sum,sumsq) of y are
+ *   bias     : float[m_out] or NULL                                 ACCUMULATED into it (caller zeroes)
+ *   c_in     : channels of x (multiple of 8)   m_out : channels of y (multiple of 8; rows beyond the
+ *              real weight rows come out as bias/zero)
+ */
+int vs_conv_gather_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                       void* y, double* y_stats, int n, int d, int h, int w, int c_in, int m_out,
+                       int kind, int dtype, float eps, void* stream);
+
+/* y[n, 2v+off(tap), m] = bias[m] + sum_c act(x)[n,v,c] * W[tap][m][c]      (x is (N,D,H,W), y (N,2D,2H,2W))
+ * ConvTranspose3d(k2,s2) forward (joint_model.py:118) and Conv3d(k2,s2) backward-data. */
+int vs_conv_scatter_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                        void* y, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);
+
+/* out_block + Softmax(dim=1) fused (joint_model.py:224-225,265-266,366-367,386-388):
+ * prob[n][k][v] (planar fp32, k < 2) = softmax_k( bias[k] + conv3x3x3(act(x))[k] ). */
+int vs_conv_k3_softmax2_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                            float* prob, int n, int d, int h, int w, int c_in, int dtype, float eps, void* stream);
+
+/* weight gradient of all three conv kinds:
+ *   dW[m][c][tap] = sum_{n,v} actP(P)[n,v,m] * actQ(Q)[n, v*s + off(tap) - p, c]        (fp32, reference layout)
+ * Conv3d (K3/K2S2): P = dL/dy on the OUTPUT grid (dp,hp,wp), Q = the conv input  -> dW[co][ci][tap].
+ * ConvTranspose3d : P = the (coarse) input on (dp,hp,wp), Q = dL/dy (fine grid), kind = VS_CONV_K2S2 -> dW[ci][co][tap].
+ * m_real / c_real: how many leading channels of P / Q are real (dW has exactly m_real*c_real*ntaps floats).
+ * workspace: vs_conv_wgrad_workspace_bytes() bytes, contents undefined on entry. */
+size_t vs_conv_wgrad_workspace_bytes(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind);
+int vs_conv_wgrad(const void* p, const double* p_stats, const void* q, const double* q_stats, float* dw,
+                  void* workspace, size_t workspace_bytes, int n, int dp, int hp, int wp, int m_ch, int c_ch,
+                  int m_real, int c_real, int kind, int dtype, float eps, void* stream);
+/* db[c] = sum over rows of g[rows][c_ch], c < c_real (bias gradient of a conv whose bias is live). */
+int vs_bias_grad(const void* g, float* db, long long rows, int c_ch, int c_real, int dtype, void* stream);
+
+/* ---- InstanceNorm3d + ReLU ---------------------------------------------------------------------- */
+/* (sum,sumsq) per (n,c) of x, accumulated into stats (caller zeroes) — only needed when the producer
+ * of x was not one of the convs above. */
+int vs_instnorm_stats(const void* x, double* stats, int n, long long voxels, int c, int dtype, void* stream);
+/* a = relu((x-mean)*rstd) [+ relu((x2-mean2)*rstd2)]  — materialises a lazy activation; with the second
+ * operand it is the U-Net skip `up(x)+x3` (joint_model.py:380,382). */
+int vs_instnorm_relu_fwd(const void* x, const double* x_stats, const void* x2, const double* x2_stats,
+                         void* out, int n, long long voxels, int c, int dtype, float eps, void* stream);
+/* backward of a = relu(instnorm(x)) given g = dL/da:
+ *   reduce: sums[n][c] = (sum g*[xhat>0], sum g*[xhat>0]*xhat)   (ACCUMULATED, caller zeroes)
+ *   apply : gx = rstd * (g*[xhat>0] - mean_v(.) - xhat * mean_v(. * xhat))                                      */
+int vs_instnorm_relu_bwd_reduce(const void* g, const void* x, const double* x_stats, double* sums,
+                                int n, long long voxels, int c, int dtype, float eps, void* stream);
+int vs_instnorm_relu_bwd_apply(const void* g, const void* x, const double* x_stats, const double* sums,
+                               void* gx, int n, long long voxels, int c, int dtype, float eps, void* stream);
+
+/* ---- layout glue at the NCDHW boundary ----------------------------------------------------------- */
+/* planar fp32 [N][c_src][V] -> channels-last [N][V][c_pad] (zero-filled channels >= c_src) */
+int vs_pack_planar(const float* src, void* dst, int n, long long voxels, int c_src, int c_pad, int dtype, void* stream);
+/* channels-last [N][V][c_pad] -> planar fp32 [N][c_dst][V] */
+int vs_unpack_planar(const void* src, float* dst, int n, long long voxels, int c_dst, int c_pad, int dtype, void* stream);
+/* backward of the 2-class softmax: glogit[n,v,k] = p_k (g_k - sum_j p_j g_j), written channels-last with c_pad
+ * channels (k >= 2 zero).  prob, gprob planar fp32 [N][2][V]. */
+int vs_softmax2_bwd(const float* prob, const float* gprob, void* glogit, int n, long long voxels, int c_pad, int dtype, void* stream);
+/* label (float, values 0..n_class-1) [N][1][V] -> one-hot planar fp32 [N][n_class][V]   (main_source.py:449-451) */
+int vs_onehot(const float* label, float* out, int n, long long voxels, int n_class, void* stream);
+/* mode 0: (a >= 0.5) ; mode 1: a>hi -> 1, a<lo -> 0, else a        (utils/evaluation.py:9-18) */
+int vs_binarize(const float* a, float* out, long long count, int mode, float lo, float hi, void* stream);
+
+/* ---- fully connected (VAE bottleneck, joint_model.py:216-218,242-243,248-253) -------------------- */
+/* y[b][j] = act( bias[j] + sum_k W[j][k] * x[b][phys(k)] )  with phys(k) = (k % pv)*pc + k / pv when pc > 0:
+ * x is a channels-last activation [B][pv voxels][pc channels] read in the reference's flatten order
+ * (k = c*pv + v); pc == 0 means x is a plain float[B][K].  x_dtype applies to x; y, W, bias are fp32. */
+int vs_linear_fwd(const void* x, int x_dtype, const float* wgt, const float* bias, float* y, int batch, int k_in,
+                  int j_out, int pc, int pv, int relu, void* stream);
+/* y[b][phys(j)] = bias[j] + sum_k W[j][k] * z[b][k]   — fc2: fp32 latent in, channels-last activation out. */
+int vs_linear_fwd_perm_out(const float* z, const float* wgt, const float* bias, void* y, int y_dtype, int batch,
+                           int k_in, int j_out, int pc, int pv, void* stream);
+/* backward of vs_linear_fwd: gy is float[B][J] (already masked by the caller's ReLU if any).
+ * gx (may be NULL) gets dL/dx in x's layout/dtype; gw / gb (may be NULL) are fp32 [J][K] / [J]. */
+int vs_linear_bwd(const void* x, int x_dtype, const float* wgt, const float* gy, const float* y_for_relu,
+                  void* gx, float* gw, float* gb, int batch, int k_in, int j_out, int pc, int pv, void* stream);
+/* backward of vs_linear_fwd_perm_out: gy channels-last; gz float[B][K] (may be NULL); gw,gb may be NULL. */
+int vs_linear_perm_out_bwd(const float* z, const float* wgt, const void* gy, int y_dtype, float* gz, float* gw,
+                           float* gb, int batch, int k_in, int j_out, int pc, int pv, void* stream);
+
+/* ---- VAE latent ---------------------------------------------------------------------------------- */
+/* z = mean + noise*std*scale  (joint_model.py:248) ; bwd: gmean = gz, gstd = gz*noise*scale */
+int vs_reparam_fwd(const float* mean, const float* std_, const float* noise, float scale, float* z, long long count, void* stream);
+int vs_reparam_bwd(const float* gz, const float* noise, float scale, float* gmean, float* gstd, long long count, void* stream);
+/* out = mean_b 0.5*(sum std^2 + sum mean^2 - 2 sum log(std+1e-5))     (utils/evaluation.py:42-45) */
+int vs_kl_fwd(const float* mean, const float* std_, float* out, int batch, int dim, void* stream);
+int vs_kl_bwd(const float* mean, const float* std_, const float* gout, float* gmean, float* gstd, int batch, int dim, void* stream);
+
+/* ---- losses ---------------------------------------------------------------------------------------- */
+/* soft Dice (utils/evaluation.py:48-80; main_source.py:150-182):  s,t planar fp32 [B][C][V].
+ *   sums[b][c] = (sum s*t, sum s, sum t) for bot <= c < top (double[B][C][3], fully overwritten)
+ *   per_sample[b] = mean_{c in [bot,top)} 2*I/(S+T+eps) ;  mean_out[0] = mean_b per_sample[b]            */
+int vs_dice_fwd(const float* s, const float* t, double* sums, float* per_sample, float* mean_out,
+                int batch, int channels, long long voxels, int bot, int top, float eps, void* stream);
+/* gs/gt (either may be NULL) = d(sum_b w[b]*per_sample[b])/d(s|t); channels outside [bot,top) get 0.
+ * gout_is_mean == 0: w[b] = gout[b] (float[B], upstream gradient of each per-sample score);
+ * gout_is_mean == 1: w[b] = gout[0]/B (upstream gradient of mean_out). */
+int vs_dice_bwd(const float* s, const float* t, const double* sums, const float* gout, int gout_is_mean, float* gs,
+                float* gt, int batch, int channels, long long voxels, int bot, int top, float eps, void* stream);
+/* nn.BCELoss() mean reduction (utils/evaluation.py:29-39), log clamped at -100 like torch */
+int vs_bce_fwd(const float* p, const float* t, float* out, double* scratch, long long count, void* stream);
+int vs_bce_bwd(const float* p, const float* t, const float* gout, float* gp, long long count, void* stream);
+
+/* ---- optimiser / teacher ---------------------------------------------------------------------------- */
+/* multi-tensor updates: ptr tables are DEVICE arrays of n_tensors device pointers, sizes[] element counts,
+ * block_map[] = (tensor index, first element) pairs, one per 65536-element chunk (n_blocks of them).
+ * SGD (torch.optim.SGD semantics, main_source.py:279-291): g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf */
+int vs_sgd_momentum_multi(float* const* params, const float* const* grads, float* const* bufs, const long long* sizes,
+                          const int* block_map, int n_blocks, float lr, float momentum, float weight_decay,
+                          int first_step, void* stream);
+/* Adam (torch.optim.Adam, betas (b1,b2), eps 1e-8, L2 weight decay; main_source.py:292-294); step >= 1 */
+int vs_adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                  const long long* sizes, const int* block_map, int n_blocks, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, void* stream);
+/* EMA teacher: t = alpha*t + (1-alpha)*s       (main_target.py:512-516) */
+int vs_ema_multi(float* const* teacher, const float* const* student, const long long* sizes, const int* block_map,
+                 int n_blocks, float alpha, void* stream);
+/* flat helpers used by the DDP bucket path: dst[i] = src[i]*scale */
+int vs_scale_copy(const float* src, float* dst, long long count, float scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VAESEG_H */

@@ -1,0 +1,6 @@
+"""Drop-in for the reference's joint_model.py (loaded by name: main_source.py:247, main_target.py:314).
+
+Same class names, constructor / forward signatures and state_dict keys; the arithmetic runs on the
+hand-written gfx950 kernels of vae_segmentation_amd (libvaeseg.so).  GPU only — no CPU fallback."""
+from vae_segmentation_amd.modules import (Conv, DoubleConv, Down, Joint, Normalization, Segmentation, Up, VAE,  # noqa: F401
+                                          set_default_kernel_dtype, set_kernel_dtype)

@@ -31,11 +31,21 @@ torch.Tensor.cuda = lambda self, *a, **k: self
 torch.nn.Module.cuda = lambda self, *a, **k: self
 
 REF = "/root/reference"
-sys.path.insert(0, REF)
-import joint_model as RM  # noqa: E402  (the reference's module zoo)
-from utils import evaluation as REV  # noqa: E402  (the reference's loss functions)
 
-sys.path.remove(REF)
+
+def _load_reference(name, relpath):
+    """Import one of the reference's files by PATH under a private module name, so the repo's own drop-in
+    joint_model.py / utils/evaluation.py (same import names) can never be picked up by mistake."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert os.path.realpath(mod.__file__).startswith(REF + os.sep)
+    return mod
+
+
+RM = _load_reference("_reference_joint_model", "joint_model.py")        # the reference's module zoo
+REV = _load_reference("_reference_evaluation", "utils/evaluation.py")   # the reference's loss functions
 from oracle import ref_cpu as O  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
@@ -77,6 +87,16 @@ def main_source_avg_dsc(s, t, bot, top, eps=1e-4):
     return_mean=True branch only; utils.evaluation.avg_dsc (eps 1e-6) is called directly elsewhere."""
     d = 2 * torch.sum(s * t, (2, 3, 4)) / (torch.sum(s, (2, 3, 4)) + torch.sum(t, (2, 3, 4)) + eps)
     return torch.mean(d[:, bot:top])
+
+
+def both_precisions(fn):
+    """Run fn(dtype) -> dict for float32 (stored as is) and float64 (keys suffixed '@f64').
+    The fp64 run of the same reference code is the yardstick for how far fp32 rounding alone moves each
+    quantity (the reference publishes no tolerance of its own)."""
+    d = fn(torch.float32)
+    for k, v in fn(torch.float64).items():
+        d[k + "@f64"] = v
+    return d
 
 
 def save(name, d):
@@ -139,11 +159,16 @@ def gold_blocks():
 
 
 def gold_seg32():
+    save("seg32", both_precisions(_seg32))
+
+
+def _seg32(dt):
     d = {}
     seg = RM.Segmentation(n_channels=1, n_class=2, norm_type=1)
     O.deterministic_fill_(seg, seed=0)
-    img, lab = O.synthetic_image(2, 32, seed=2), O.synthetic_label(2, 32, seed=3)
-    batch = {"img": img, "gt": O.one_hot(lab)}
+    seg = seg.to(dt)
+    img, lab = O.synthetic_image(2, 32, seed=2).to(dt), O.synthetic_label(2, 32, seed=3)
+    batch = {"img": img, "gt": O.one_hot(lab).to(dt)}
     batch = seg(batch, "img", "pred")
     dsc = 1 - REV.avg_dsc(batch, "pred", "gt", botindex=1, topindex=2)
     dsc.backward()
@@ -151,7 +176,7 @@ def gold_seg32():
     d["dice_loss_eps1e4"] = (1 - main_source_avg_dsc(batch["pred"], batch["gt"], 1, 2)).detach().numpy()
     put(d, "pred", batch["pred"], 256)
     put_grads(d, "seg", seg)
-    save("seg32", d)
+    return d
 
 
 def composed_vae(ref_vae, side):
@@ -179,12 +204,17 @@ def composed_vae(ref_vae, side):
 
 
 def gold_vae64():
+    save("vae64_train", both_precisions(_vae64))
+
+
+def _vae64(dt):
     d = {}
     vae = RM.VAE(n_channels=2, n_class=2, norm_type=1, dim=128)
     fwd = composed_vae(vae, 2)
     O.deterministic_fill_(vae, seed=0)
-    gt = O.one_hot(O.synthetic_label(2, 64, seed=3))
-    noise = torch.from_numpy(2 * O.hashed_uniform(2 * 128, 7100, 5) - 1).view(2, 128)
+    vae.to(dt)
+    gt = O.one_hot(O.synthetic_label(2, 64, seed=3)).to(dt)
+    noise = torch.from_numpy(2 * O.hashed_uniform(2 * 128, 7100, 5) - 1).view(2, 128).to(dt)
     recon, mean, std = fwd(gt, if_random=True, scale=0.35, noise=noise)
     b = {"recon": recon, "gt": gt, "mean": mean, "std": std}
     kl = REV.KLloss(b)
@@ -195,10 +225,10 @@ def gold_vae64():
     d["mean"], d["std"] = mean.detach().numpy(), std.detach().numpy()
     put(d, "recon", recon, 256)
     put_grads(d, "vae", vae)
-    save("vae64_train", d)
+    return d
 
 
-def joint_case(side, native):
+def joint_case(side, native, dt=torch.float32):
     """joint_train step (main_source.py:449-471,660) on the reference Joint."""
     seg = RM.Segmentation(n_channels=1, n_class=2, norm_type=1)
     vae = RM.VAE(n_channels=2, n_class=2, norm_type=1, dim=128)
@@ -206,6 +236,7 @@ def joint_case(side, native):
     if not native:
         fwd = composed_vae(vae, side // 32)
     O.deterministic_fill_(joint, seed=0)
+    joint.to(dt)
     for p in joint.Vae.parameters():
         p.requires_grad = False
     joint.Vae.eval()
@@ -213,11 +244,15 @@ def joint_case(side, native):
 
 
 def gold_joint(side, batch_size, name):
+    save(name, both_precisions(lambda dt: _joint(side, batch_size, name, dt)))
+
+
+def _joint(side, batch_size, name, dt):
     d = {}
     native = side == 128
-    joint, fwd = joint_case(side, native)
-    img, lab = O.synthetic_image(batch_size, side, seed=2), O.synthetic_label(batch_size, side, seed=3)
-    batch = {"img": img, "gt": O.one_hot(lab)}
+    joint, fwd = joint_case(side, native, dt)
+    img, lab = O.synthetic_image(batch_size, side, seed=2).to(dt), O.synthetic_label(batch_size, side, seed=3)
+    batch = {"img": img, "gt": O.one_hot(lab).to(dt)}
     t0 = time.time()
     if native:
         batch = joint(batch, "img", "pred", "recon")
@@ -238,22 +273,27 @@ def gold_joint(side, batch_size, name):
     put(d, "recon", batch["recon"], 512)
     put_grads(d, "seg", joint.Seg)
     d["vae_grads_none"] = np.asarray(all(p.grad is None for p in joint.Vae.parameters()))
-    save(name, d)
+    return d
 
 
 def gold_da128():
     """domain_adaptation step (main_target.py:531-596), vae_mont_number=1, teacher = copy of student,
     dropout rates 0, lambda_vae 1.0, domain_loss_type 0 (grads) and 8/9 (loss values)."""
+    save("da128", both_precisions(_da128))
+
+
+def _da128(dt):
     d = {}
-    student, _ = joint_case(128, True)
-    teacher, _ = joint_case(128, True)
+    student, _ = joint_case(128, True, dt)
+    teacher, _ = joint_case(128, True, dt)
     # make the teacher differ from the student so the pseudo-label is not the student's own argmax
-    O.deterministic_fill_(teacher.Seg, seed=1)
+    O.deterministic_fill_(teacher.Seg.float(), seed=1)
+    teacher.to(dt)
     for p in teacher.parameters():
         p.requires_grad = False
     teacher.eval()
-    img, lab = O.synthetic_image(1, 128, seed=2), O.synthetic_label(1, 128, seed=3)
-    batch = {"img": img, "gt": O.one_hot(lab)}
+    img, lab = O.synthetic_image(1, 128, seed=2).to(dt), O.synthetic_label(1, 128, seed=3)
+    batch = {"img": img, "gt": O.one_hot(lab).to(dt)}
     batch = student(batch, "img", "pred", "recon", dropout=True)
     with torch.no_grad():
         batch = teacher(batch, "img", "fake", "_asdf")
@@ -279,20 +319,31 @@ def gold_da128():
     cb = REV.confident_binarize(fake_soft)
     d["cfake.sum"] = cb.double().sum().numpy()
     put_grads(d, "seg", student.Seg)
-    save("da128", d)
+    return d
 
 
 def gold_vae128_native():
     """vae_train step on the NATIVE reference VAE (main_source.py:389-413): z is the reference's own
     torch.randn draw under torch.manual_seed(123), recorded so the oracle / HIP path can inject it."""
+    save("vae128_train", both_precisions(_vae128))
+
+
+def _vae128(dt):
     d = {}
     vae = RM.VAE(n_channels=2, n_class=2, norm_type=1, dim=128)
     O.deterministic_fill_(vae, seed=0)
-    gt = O.one_hot(O.synthetic_label(1, 128, seed=3))
+    vae.to(dt)
+    gt = O.one_hot(O.synthetic_label(1, 128, seed=3)).to(dt)
     torch.manual_seed(123)
     z = torch.randn(1, 128)
     torch.manual_seed(123)
-    recon, mean, std = vae(gt, if_random=True, scale=0.35)
+    if dt == torch.float64:
+        # the reference casts its noise with .type(torch.cuda.FloatTensor); for the fp64 yardstick alias that to double
+        torch.cuda.FloatTensor = torch.DoubleTensor
+    try:
+        recon, mean, std = vae(gt, if_random=True, scale=0.35)
+    finally:
+        torch.cuda.FloatTensor = torch.FloatTensor
     b = {"recon": recon, "gt": gt, "mean": mean, "std": std}
     kl = REV.KLloss(b)
     dsc = 1 - main_source_avg_dsc(recon, gt, 1, 2)
@@ -303,7 +354,7 @@ def gold_vae128_native():
     d["mean"], d["std"] = mean.detach().numpy(), std.detach().numpy()
     put(d, "recon", recon, 512)
     put_grads(d, "vae", vae)
-    save("vae128_train", d)
+    return d
 
 
 CASES = {

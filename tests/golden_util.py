@@ -66,3 +66,65 @@ def check_grads(gold, prefix, named_grads, k=16, rtol=1e-3, dead_atol=1e-5, what
         worst = max(worst, e1, e2)
         assert max(e1, e2) <= rtol, "%s: grad %s rel err l2 %g samples %g > %g" % (what, name, e1, e2, rtol)
     return worst
+
+
+# ---------------------------------------------------------------------------------------------------
+# fp64-yardstick checks.  The goldens hold the reference's fp32 result AND the same reference code run in
+# fp64 (keys suffixed "@f64").  A candidate passes when its distance to the fp64 result is within
+# max(floor, factor x the reference-fp32 run's own distance to fp64): "as close to exact arithmetic as
+# the reference's eager fp32 path is" (north_star: 1e-3 relative fp32 => floor 1e-3).
+# ---------------------------------------------------------------------------------------------------
+def _sample_err(s, ref, rms):
+    return float(np.abs(s - ref).max() / max(np.abs(ref).max(), rms, 1e-30))
+
+
+def scalar_close(gold, key, val, floor=1e-3, factor=3.0):
+    f64, f32 = float(gold[key + "@f64"]), float(gold[key])
+    mine, theirs = abs(float(val) - f64), abs(f32 - f64)
+    lim = max(floor * abs(f64), factor * theirs)
+    assert mine <= lim, "%s: |%.9g - %.9g(f64)| = %.3g > %.3g (reference fp32 is off by %.3g)" % (key, float(val), f64, mine, lim, theirs)
+    return mine / max(abs(f64), 1e-30)
+
+
+def check_tensor_f64(gold, prefix, t, k=64, floor=1e-3, factor=3.0, what=""):
+    a = flat64(t)
+    l64 = float(gold[prefix + ".l2@f64"])
+    rms = l64 / np.sqrt(a.size)
+    s64 = gold[prefix + ".samples@f64"].astype(np.float64)
+    s32 = gold[prefix + ".samples"].astype(np.float64)
+    mine = _sample_err(a[sample_idx(a.size, k)], s64, rms)
+    theirs = _sample_err(s32, s64, rms)
+    lim = max(floor, factor * theirs)
+    assert mine <= lim, "%s %s: sample err vs fp64 %.3g > %.3g (reference fp32: %.3g)" % (what, prefix, mine, lim, theirs)
+    l_mine = abs(float(np.sqrt((a * a).sum())) - l64) / max(l64, 1e-30)
+    l_theirs = abs(float(gold[prefix + ".l2"]) - l64) / max(l64, 1e-30)
+    lim2 = max(floor, factor * l_theirs)
+    assert l_mine <= lim2, "%s %s: l2 err vs fp64 %.3g > %.3g (reference fp32: %.3g)" % (what, prefix, l_mine, lim2, l_theirs)
+    return mine, theirs
+
+
+def check_grads_f64(gold, prefix, named_grads, k=16, floor=2e-3, factor=3.0, dead_atol=1e-5, what=""):
+    """Per-parameter gradient check against the fp64 yardstick; returns [(name, mine, reference-fp32)]."""
+    report = []
+    for name, g in named_grads:
+        key = "%s.grad.%s" % (prefix, name)
+        if key + ".none" in gold:
+            assert g is None, "%s: expected no grad for %s" % (what, name)
+            continue
+        assert g is not None, "%s: missing grad for %s" % (what, name)
+        a = flat64(g)
+        l64 = float(gold[key + ".l2@f64"])
+        my_l2 = float(np.sqrt((a * a).sum()))
+        if l64 < dead_atol * np.sqrt(a.size) * 10:        # dead parameter (conv bias feeding InstanceNorm): exact value is 0
+            l32 = float(gold[key + ".l2"])
+            assert my_l2 <= max(10 * l32, dead_atol * np.sqrt(a.size) * 10), "%s: dead grad %s = %g" % (what, name, my_l2)
+            continue
+        rms = l64 / np.sqrt(a.size)
+        s64 = gold[key + ".samples@f64"].astype(np.float64)
+        s32 = gold[key + ".samples"].astype(np.float64)
+        mine = max(_sample_err(a[sample_idx(a.size, k)], s64, rms), abs(my_l2 - l64) / l64)
+        theirs = max(_sample_err(s32, s64, rms), abs(float(gold[key + ".l2"]) - l64) / l64)
+        report.append((name, mine, theirs))
+        lim = max(floor, factor * theirs)
+        assert mine <= lim, "%s: grad %s err vs fp64 %.3g > %.3g (reference fp32: %.3g)" % (what, name, mine, lim, theirs)
+    return report

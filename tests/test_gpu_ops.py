@@ -1,0 +1,314 @@
+"""GPU parity, op level: every libvaeseg kernel against the stock fp32 PyTorch op it replaces, run on the CPU.
+
+Tolerances: fp32 kernels (exact-f32 MFMA, fp32/fp64 reductions) 2e-5 relative to the tensor's max magnitude;
+bf16 kernels are compared with the same fp32 reference evaluated on bf16-rounded operands, 1.5e-2 (one bf16
+rounding of the stored result is 2^-9 = 2e-3; the lazy InstanceNorm input adds another rounding)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.5e-2}
+
+
+def _ops():
+    from vae_segmentation_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def q(t, dtype):
+    """round to the kernel dtype and back (what the kernel sees)."""
+    return t.detach().to(dtype).float().clone()
+
+
+def to_cl(x, cp, dtype):
+    n, c = x.shape[:2]
+    out = torch.zeros((n,) + tuple(x.shape[2:]) + (cp,), dtype=torch.float32)
+    out[..., :c] = x.detach().permute(0, 2, 3, 4, 1)
+    return out.to(dtype).cuda().contiguous()
+
+
+def from_cl(y, c):
+    return y.float().cpu()[..., :c].permute(0, 4, 1, 2, 3).contiguous()
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-20))
+
+
+def in_relu(x):
+    return torch.relu(F.instance_norm(x))
+
+
+CONV_CASES = [  # (N, Cin, Cout, D, H, W)
+    (2, 8, 8, 8, 8, 16), (1, 8, 16, 5, 6, 20), (1, 16, 8, 4, 4, 16), (1, 16, 16, 6, 5, 7), (1, 32, 16, 4, 4, 8),
+    (1, 16, 32, 4, 8, 16), (1, 32, 32, 3, 3, 3), (1, 64, 32, 4, 4, 4), (1, 32, 64, 6, 6, 6), (1, 64, 128, 3, 3, 3),
+    (1, 128, 64, 3, 3, 3), (2, 256, 256, 3, 3, 3), (1, 2, 8, 8, 8, 8), (1, 1, 8, 4, 4, 16),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("lazy", [False, True])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_k3_fwd_bwd(case, lazy, dtype):
+    ops = _ops()
+    n, cin, cout, d, h, w = case
+    x = rnd(n, cin, d, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, 3, seed=2, scale=(3.0 / (27 * cin)) ** 0.5)
+    gy = rnd(n, cout, d, h, w, seed=3)
+    xq, wq, gq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), q(gy, dtype)
+    a = in_relu(xq) if lazy else xq
+    if lazy and dtype == torch.bfloat16:
+        pass  # the kernel normalises in fp32 and rounds the activation to bf16 when staging: covered by TOL
+    y_ref = F.conv3d(a, wq, None, padding=1)
+    (y_ref * gq).sum().backward()
+
+    x_cl = to_cl(x, ops.cpad(cin), dtype).requires_grad_(True)
+    xs = ops.instnorm_stats(x_cl.detach()) if lazy else None
+    w_gpu = wt.cuda().requires_grad_(True)
+    if dtype == torch.bfloat16:
+        w_gpu = q(wt, dtype).cuda().requires_grad_(True)
+    y, ys = ops.ConvK3.apply(x_cl, xs, w_gpu, None)
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    assert relerr(from_cl(y, cout), y_ref.detach()) < tol
+    yr = q(y_ref.detach(), dtype).double()
+    st = ys.cpu()[:, :cout]
+    ref_sum, ref_sq = yr.sum((2, 3, 4)), (yr * yr).sum((2, 3, 4))
+    assert float((st[..., 0] - ref_sum).abs().max() / ref_sq.sqrt().max()) < tol
+    assert float((st[..., 1] - ref_sq).abs().max() / ref_sq.max()) < tol
+    if ops.cpad(cout) > cout:
+        assert float(y.float()[..., cout:].abs().max()) == 0.0
+    y.backward(to_cl(gy, ops.cpad(cout), dtype))
+    torch.cuda.synchronize()
+    gtol = tol * (4 if lazy else 1)
+    assert relerr(from_cl(x_cl.grad, cin), xq.grad) < gtol
+    assert relerr(w_gpu.grad.cpu(), wq.grad) < gtol
+
+
+K2_CASES = [(2, 8, 8, 8, 16), (1, 16, 4, 6, 10), (1, 32, 4, 4, 4), (1, 64, 2, 2, 6), (1, 128, 2, 2, 2), (2, 256, 2, 2, 2)]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("lazy", [False, True])
+@pytest.mark.parametrize("case", K2_CASES)
+def test_conv_k2s2_fwd_bwd(case, lazy, dtype):
+    ops = _ops()
+    n, c, d, h, w = case
+    x = rnd(n, c, d, h, w, seed=4)
+    wt = rnd(c, c, 2, 2, 2, seed=5, scale=(3.0 / (8 * c)) ** 0.5)
+    b = rnd(c, seed=6, scale=0.1)
+    gy = rnd(n, c, d // 2, h // 2, w // 2, seed=7)
+    xq, wq, bq, gq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), b.clone().requires_grad_(True), q(gy, dtype)
+    a = in_relu(xq) if lazy else xq
+    y_ref = F.conv3d(a, wq, bq, stride=2)
+    (y_ref * gq).sum().backward()
+    x_cl = to_cl(x, c, dtype).requires_grad_(True)
+    xs = ops.instnorm_stats(x_cl.detach()) if lazy else None
+    w_gpu, b_gpu = q(wt, dtype).cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.ConvK2S2.apply(x_cl, xs, w_gpu, b_gpu)
+    tol = TOL[dtype]
+    assert relerr(from_cl(y, c), y_ref.detach()) < tol
+    y.backward(to_cl(gy, c, dtype))
+    torch.cuda.synchronize()
+    gtol = tol * (4 if lazy else 1)
+    assert relerr(from_cl(x_cl.grad, c), xq.grad) < gtol
+    assert relerr(w_gpu.grad.cpu(), wq.grad) < gtol
+    assert relerr(b_gpu.grad.cpu(), bq.grad) < gtol
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("lazy", [False, True])
+@pytest.mark.parametrize("case", [(2, 16, 4, 4, 8), (1, 32, 3, 5, 7), (1, 64, 2, 2, 3), (1, 128, 3, 3, 3), (2, 256, 2, 2, 2)])
+def test_conv_transpose_fwd_bwd(case, lazy, dtype):
+    ops = _ops()
+    n, c, d, h, w = case
+    x = rnd(n, c, d, h, w, seed=8)
+    wt = rnd(c, c, 2, 2, 2, seed=9, scale=(3.0 / c) ** 0.5)
+    b = rnd(c, seed=10, scale=0.1)
+    gy = rnd(n, c, 2 * d, 2 * h, 2 * w, seed=11)
+    xq, wq, bq, gq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), b.clone().requires_grad_(True), q(gy, dtype)
+    a = in_relu(xq) if lazy else xq
+    y_ref = F.conv_transpose3d(a, wq, bq, stride=2)
+    (y_ref * gq).sum().backward()
+    x_cl = to_cl(x, c, dtype).requires_grad_(True)
+    xs = ops.instnorm_stats(x_cl.detach()) if lazy else None
+    w_gpu, b_gpu = q(wt, dtype).cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = ops.ConvT2S2.apply(x_cl, xs, w_gpu, b_gpu)
+    tol = TOL[dtype]
+    assert relerr(from_cl(y, c), y_ref.detach()) < tol
+    y.backward(to_cl(gy, c, dtype))
+    torch.cuda.synchronize()
+    gtol = tol * (4 if lazy else 1)
+    assert relerr(from_cl(x_cl.grad, c), xq.grad) < gtol
+    assert relerr(w_gpu.grad.cpu(), wq.grad) < gtol
+    assert relerr(b_gpu.grad.cpu(), bq.grad) < gtol
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_out_block_softmax(dtype):
+    ops = _ops()
+    n, d, h, w = 2, 6, 8, 20
+    x = rnd(n, 8, d, h, w, seed=12)
+    wt = rnd(2, 8, 3, 3, 3, seed=13, scale=0.3)
+    b = rnd(2, seed=14, scale=0.2)
+    gp = rnd(n, 2, d, h, w, seed=15)
+    xq, wq, bq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), b.clone().requires_grad_(True)
+    p_ref = torch.softmax(F.conv3d(in_relu(xq), wq, bq, padding=1), dim=1)
+    (p_ref * gp).sum().backward()
+    x_cl = to_cl(x, 8, dtype).requires_grad_(True)
+    xs = ops.instnorm_stats(x_cl.detach())
+    w_gpu, b_gpu = q(wt, dtype).cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    p = ops.ConvK3Softmax.apply(x_cl, xs, w_gpu, b_gpu)
+    tol = TOL[dtype]
+    assert relerr(p.cpu(), p_ref.detach()) < tol
+    p.backward(gp.cuda())
+    torch.cuda.synchronize()
+    assert relerr(from_cl(x_cl.grad, 8), xq.grad) < tol * 4
+    assert relerr(w_gpu.grad.cpu(), wq.grad) < tol * 4
+    assert relerr(b_gpu.grad.cpu(), bq.grad) < tol * 4
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c", [8, 16, 32, 64, 128, 256])
+def test_materialize_skip_add(c, dtype):
+    ops = _ops()
+    n, d, h, w = 2, 3, 5, 4
+    x1, x2 = rnd(n, c, d, h, w, seed=16), rnd(n, c, d, h, w, seed=17) * 2 + 0.3
+    g = rnd(n, c, d, h, w, seed=18)
+    a1, a2 = q(x1, dtype).requires_grad_(True), q(x2, dtype).requires_grad_(True)
+    ref = in_relu(a1) + in_relu(a2)
+    (ref * q(g, dtype)).sum().backward()
+    c1, c2 = to_cl(x1, c, dtype).requires_grad_(True), to_cl(x2, c, dtype).requires_grad_(True)
+    out = ops.Materialize.apply(c1, ops.instnorm_stats(c1.detach()), c2, ops.instnorm_stats(c2.detach()))
+    tol = TOL[dtype]
+    assert relerr(from_cl(out, c), ref.detach()) < tol
+    out.backward(to_cl(g, c, dtype))
+    torch.cuda.synchronize()
+    assert relerr(from_cl(c1.grad, c), a1.grad) < tol * 2
+    assert relerr(from_cl(c2.grad, c), a2.grad) < tol * 2
+
+
+def test_pack_unpack_planar_roundtrip():
+    ops = _ops()
+    for dtype in DT:
+        x = rnd(2, 2, 4, 4, 8, seed=19)
+        cl = ops.PackPlanar.apply(x.cuda(), dtype)
+        assert cl.shape == (2, 4, 4, 8, 8)
+        assert torch.equal(from_cl(cl, 2), q(x, dtype))
+        assert float(cl.float()[..., 2:].abs().max()) == 0.0
+        back = ops.UnpackPlanar.apply(cl, 2)
+        assert torch.equal(back.cpu(), q(x, dtype))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_linear_layers(dtype):
+    ops = _ops()
+    b, c, s, dim = 2, 256, 3, 128
+    feat = rnd(b, c, s, s, s, seed=20)
+    w1, b1 = rnd(dim, c * s ** 3, seed=21, scale=0.02), rnd(dim, seed=22, scale=0.1)
+    fq, w1r, b1r = q(feat, dtype).requires_grad_(True), w1.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+    for relu in (False, True):
+        fq.grad = w1r.grad = b1r.grad = None
+        y_ref = F.linear(fq.reshape(b, -1), w1r, b1r)
+        if relu:
+            y_ref = torch.relu(y_ref)
+        gy = rnd(b, dim, seed=23)
+        (y_ref * gy).sum().backward()
+        x_cl = to_cl(feat, c, dtype).requires_grad_(True)
+        wg, bg = w1.cuda().requires_grad_(True), b1.cuda().requires_grad_(True)
+        y = ops.LinearCL.apply(x_cl, wg, bg, relu)
+        assert relerr(y.cpu(), y_ref.detach()) < 2e-5
+        y.backward(gy.cuda())
+        torch.cuda.synchronize()
+        assert relerr(from_cl(x_cl.grad, c), fq.grad) < TOL[dtype]
+        assert relerr(wg.grad.cpu(), w1r.grad) < 2e-5
+        assert relerr(bg.grad.cpu(), b1r.grad) < 2e-5
+    # fc2: latent -> channels-last
+    z = rnd(b, dim, seed=24).requires_grad_(True)
+    w2, b2 = rnd(c * s ** 3, dim, seed=25, scale=0.1).requires_grad_(True), rnd(c * s ** 3, seed=26, scale=0.1).requires_grad_(True)
+    h_ref = F.linear(z, w2, b2).view(b, c, s, s, s)
+    gh = rnd(b, c, s, s, s, seed=27)
+    (h_ref * q(gh, dtype)).sum().backward()
+    zg, w2g, b2g = z.detach().cuda().requires_grad_(True), w2.detach().cuda().requires_grad_(True), b2.detach().cuda().requires_grad_(True)
+    hh = ops.LinearToCL.apply(zg, w2g, b2g, c, s, dtype)
+    assert relerr(from_cl(hh, c), h_ref.detach()) < TOL[dtype]
+    hh.backward(to_cl(gh, c, dtype))
+    torch.cuda.synchronize()
+    assert relerr(zg.grad.cpu(), z.grad) < 2e-5
+    assert relerr(w2g.grad.cpu(), w2.grad) < 2e-5
+    assert relerr(b2g.grad.cpu(), b2.grad) < 2e-5
+
+
+def test_reparam_kl_dice_bce_label_ops():
+    ops = _ops()
+    from oracle import ref_cpu as O
+    from vae_segmentation_amd import evaluation as E
+    mean, std, noise = rnd(2, 128, seed=28).requires_grad_(True), rnd(2, 128, seed=29).abs().requires_grad_(True), rnd(2, 128, seed=30)
+    z_ref = mean + noise * std * 0.35
+    kl_ref = O.KLloss({"mean": mean, "std": std})
+    (z_ref.sum() * 0.5 + kl_ref).backward()
+    mg, sg = mean.detach().cuda().requires_grad_(True), std.detach().cuda().requires_grad_(True)
+    z = ops.Reparam.apply(mg, sg, noise.cuda(), 0.35)
+    kl = E.KLloss({"mean": mg, "std": sg})
+    (z.sum() * 0.5 + kl).backward()
+    assert relerr(z.cpu(), z_ref.detach()) < 1e-6
+    assert abs(kl.item() - kl_ref.item()) / abs(kl_ref.item()) < 1e-5
+    assert relerr(mg.grad.cpu(), mean.grad) < 1e-5 and relerr(sg.grad.cpu(), std.grad) < 1e-5
+    # KL with a zero std (log(1e-5) branch, SURVEY KAT KL-2)
+    b = {"mean": torch.tensor([[1.0, -2.0, 0.5]]).cuda(), "std": torch.tensor([[0.0, 2.0, 0.5]]).cuda()}
+    assert abs(E.KLloss(b).item() - 16.26289939880371) < 1e-4
+    # Dice, both eps, channel slices, mean / per-sample, gradients to both operands
+    s = torch.softmax(rnd(2, 2, 8, 8, 8, seed=31) * 3, 1).requires_grad_(True)
+    t = torch.softmax(rnd(2, 2, 8, 8, 8, seed=32) * 3, 1).requires_grad_(True)
+    for eps in (1e-6, 1e-4):
+        for bot, top in ((1, 2), (0, 2)):
+            for rm in (True, False):
+                s.grad = t.grad = None
+                ref = O.avg_dsc({"s": s, "t": t}, "s", "t", botindex=bot, topindex=top, return_mean=rm, eps=eps)
+                wgt = torch.tensor([0.3, 0.7]) if not rm else torch.tensor(1.0)
+                (ref * wgt).sum().backward()
+                sg_, tg_ = s.detach().cuda().requires_grad_(True), t.detach().cuda().requires_grad_(True)
+                got = E.avg_dsc({"s": sg_, "t": tg_}, "s", "t", botindex=bot, topindex=top, return_mean=rm, eps=eps)
+                (got * wgt.cuda()).sum().backward()
+                assert relerr(got.detach().cpu(), ref.detach()) < 1e-6
+                assert relerr(sg_.grad.cpu(), s.grad) < 1e-5 and relerr(tg_.grad.cpu(), t.grad) < 1e-5
+    # hard dice + reference KATs (tests/golden/kats.npz values)
+    from tests import golden_util as G
+    g = G.load("kats")
+    s1 = torch.tensor([.9, .1, .8, .2, .7, .3, .6, .4]).view(1, 1, 2, 2, 2)
+    t1 = torch.tensor([1., 0, 1, 0, 0, 1, 1, 0]).view(1, 1, 2, 2, 2)
+    bb = {"s": torch.cat((1 - s1, s1), 1).cuda(), "t": torch.cat((1 - t1, t1), 1).cuda()}
+    assert abs(E.avg_dsc(bb, "s", "t", botindex=1, topindex=2).item() - float(g["dice1"])) < 1e-6
+    assert abs(E.avg_dsc(bb, "s", "t", botindex=1, topindex=2, binary=True).item() - float(g["dice2_binary"])) < 1e-6
+    assert abs(E.avg_dsc(bb, "s", "t", botindex=1, topindex=2, eps=1e-4).item() - float(g["dice3_eps1e4"])) < 1e-6
+    assert abs(E.dice(bb["s"], bb["t"]).item() - float(g["dice_fn"])) < 1e-6
+    assert np.array_equal(E.binarize(torch.tensor([.49, .5, .81]).cuda()).cpu().numpy(), g["bin"])
+    assert np.array_equal(E.confident_binarize(torch.tensor([.1, .2, .5, .8, .81]).cuda()).cpu().numpy(), g["cbin"])
+    # BCE
+    p = torch.sigmoid(rnd(2, 1, 4, 4, 4, seed=33)).requires_grad_(True)
+    tt = (rnd(2, 1, 4, 4, 4, seed=34) > 0).float()
+    ref = O.avg_ce({"a": p, "b": tt}, "a", "b")
+    ref.backward()
+    pg = p.detach().cuda().requires_grad_(True)
+    got = E.avg_ce({"a": pg, "b": tt.cuda()}, "a", "b")
+    got.backward()
+    assert abs(got.item() - ref.item()) < 1e-6 and relerr(pg.grad.cpu(), p.grad) < 1e-5
+    # one-hot
+    lab = (rnd(2, 1, 4, 4, 4, seed=35) > 0.5).float()
+    assert torch.equal(ops.onehot(lab.cuda(), 2).cpu(), O.one_hot(lab, 2))
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    import joint_model
+    seg = joint_model.Segmentation(1, 2, norm_type=1)
+    with pytest.raises(RuntimeError):
+        seg({"x": torch.zeros(1, 1, 16, 16, 16)}, "x", "y")

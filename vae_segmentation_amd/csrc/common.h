@@ -1,0 +1,105 @@
+// Shared device helpers for libvaeseg (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vaeseg.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define VS_WAVE 64
+
+// ---- bf16 <-> f32 ------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
+
+// element type traits: T = float or unsigned short (bf16 bits)
+template <typename T> struct ET;
+template <> struct ET<float> {
+    static constexpr int EPL = 4;   // elements per 16-byte lane fragment
+    static constexpr int KG = 16;   // k's per k-group (4 lane groups x EPL)
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float rnd(float v) { return v; }
+};
+template <> struct ET<unsigned short> {
+    static constexpr int EPL = 8;
+    static constexpr int KG = 32;
+    __device__ static __forceinline__ float ld(const unsigned short* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(unsigned short* p, float v) { *p = f2bf(v); }
+    __device__ static __forceinline__ float rnd(float v) { return round_bf(v); }
+};
+
+// unpack a 16-byte fragment into EPL floats / pack back
+__device__ __forceinline__ void frag_unpack(const u32x4& r, float (&v)[4], float*) {
+    v[0] = __uint_as_float(r[0]); v[1] = __uint_as_float(r[1]);
+    v[2] = __uint_as_float(r[2]); v[3] = __uint_as_float(r[3]);
+}
+__device__ __forceinline__ void frag_unpack(const u32x4& r, float (&v)[8], unsigned short*) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __uint_as_float(r[i] << 16);
+        v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ u32x4 frag_pack(const float (&v)[4], float*) {
+    u32x4 r;
+    r[0] = __float_as_uint(v[0]); r[1] = __float_as_uint(v[1]);
+    r[2] = __float_as_uint(v[2]); r[3] = __float_as_uint(v[3]);
+    return r;
+}
+__device__ __forceinline__ u32x4 frag_pack(const float (&v)[8], unsigned short*) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (unsigned int)f2bf(v[2 * i]) | ((unsigned int)f2bf(v[2 * i + 1]) << 16);
+    return r;
+}
+
+// ---- MFMA: one 16-byte A fragment x one 16-byte B fragment -> 16x16 f32 tile ---------------------
+// bf16: one v_mfma_f32_16x16x32_bf16 (k = 8*(lane>>4)+j, j = 0..7).
+// f32 : four v_mfma_f32_16x16x4_f32; MFMA j covers k = 4*(lane>>4)+j, so a lane's four k's are contiguous.
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c, unsigned short*) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c, float*) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[j]), __uint_as_float(b[j]), c, 0, 0, 0);
+    return c;
+}
+
+// ---- wave reductions ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// mean / rstd of one (n,c) from the fp64 (sum, sumsq) pair a producer accumulated
+__device__ __forceinline__ void stats_to_mean_rstd(const double* st, double inv_count, float eps, float& mean, float& rstd) {
+    double m = st[0] * inv_count;
+    double var = st[1] * inv_count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+#define VS_CHECK_LAUNCH()                                  \
+    do {                                                   \
+        hipError_t e__ = hipGetLastError();                \
+        if (e__ != hipSuccess) return (int)e__;            \
+    } while (0)
+
+static inline int vs_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,107 @@
+// C-ABI launchers of the implicit-GEMM convolutions (forward / backward-data).
+#include "igemm_dispatch.h"
+
+int g1_dispatch_k3_f32(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
+int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
+
+static int pick_mt(int rows16, long long tiles) {
+    // largest row tile that still leaves >= 256 workgroups (one per CU); 16 when the layer is too small for that
+    const int cands[3] = {64, 32, 16};
+    for (int i = 0; i < 3; ++i) {
+        const int mt = cands[i];
+        if (rows16 % mt) continue;
+        if (tiles * (rows16 / mt) >= 256 || mt == 16) return mt;
+    }
+    return 16;
+}
+
+static int check_common(const void* x, const void* w, int n, int d, int h, int w_, int c_in, int dtype) {
+    if (!x || !w) return VS_EINVAL;
+    if (n <= 0 || d <= 0 || h <= 0 || w_ <= 0) return VS_ESHAPE;
+    if (!(c_in == 8 || c_in == 16 || (c_in % 32 == 0 && c_in > 0 && c_in <= 256))) return VS_ESHAPE;
+    if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return VS_EALIGN;
+    return VS_OK;
+}
+
+extern "C" int vs_conv_gather_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                                  void* y, double* y_stats, int n, int d, int h, int w, int c_in, int m_out,
+                                  int kind, int dtype, float eps, void* stream) {
+    int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
+    if (rc) return rc;
+    if (!y || m_out <= 0 || m_out % 8 || ((uintptr_t)y & 15)) return VS_EINVAL;
+    if (kind != VS_CONV_K3 && kind != VS_CONV_K2S2) return VS_EINVAL;
+    if (kind == VS_CONV_K2S2 && ((d | h | w) & 1)) return VS_ESHAPE;
+    G1Params p{};
+    p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = y; p.y_stats = y_stats; p.prob = nullptr;
+    p.N = n; p.D = d; p.H = h; p.W = w;
+    p.C = c_in; p.M = m_out;
+    p.rb_total = (m_out + 15) / 16;
+    const int ck = c_in < 32 ? c_in : 32;
+    p.nch = c_in / ck;
+    p.eps = eps;
+    p.inv_count_in = 1.0 / ((double)d * h * w);
+    long long tiles;
+    if (kind == VS_CONV_K3) {
+        p.Do = d; p.Ho = h; p.Wo = w;
+        p.tyn = (h + 3) / 4; p.txn = (w + 15) / 16;
+        p.tiles_per_sample = ((d + 3) / 4) * p.tyn * p.txn;
+    } else {
+        p.Do = d / 2; p.Ho = h / 2; p.Wo = w / 2;
+        p.tyn = p.txn = 0;
+        p.tiles_per_sample = vs_ceil_div((long long)p.Do * p.Ho * p.Wo, 256);
+    }
+    tiles = (long long)p.tiles_per_sample * n;
+    const int rows16 = p.rb_total * 16;
+    const int mt = pick_mt(rows16, tiles);
+    const int row_tiles = rows16 / mt;
+    if (kind == VS_CONV_K3)
+        return dtype == VS_F32 ? g1_dispatch_k3_f32(p, ck, mt, EPI_RAW, (int)tiles, row_tiles, (hipStream_t)stream)
+                               : g1_dispatch_k3_bf16(p, ck, mt, EPI_RAW, (int)tiles, row_tiles, (hipStream_t)stream);
+    return g1_dispatch_k2s2(p, dtype, ck, mt, (int)tiles, row_tiles, (hipStream_t)stream);
+}
+
+extern "C" int vs_conv_scatter_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                                   void* y, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps,
+                                   void* stream) {
+    int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
+    if (rc) return rc;
+    if (!y || m_out <= 0 || m_out % 8 || ((uintptr_t)y & 15)) return VS_EINVAL;
+    G1Params p{};
+    p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = y; p.y_stats = nullptr; p.prob = nullptr;
+    p.N = n; p.D = d; p.H = h; p.W = w;
+    p.Do = d; p.Ho = h; p.Wo = w;
+    p.C = c_in; p.M = m_out;
+    p.rb_total = (8 * m_out + 15) / 16;
+    const int ck = c_in < 32 ? c_in : 32;
+    p.nch = c_in / ck;
+    p.eps = eps;
+    p.inv_count_in = 1.0 / ((double)d * h * w);
+    p.tiles_per_sample = vs_ceil_div((long long)d * h * w, 256);
+    const long long tiles = (long long)p.tiles_per_sample * n;
+    const int rows16 = p.rb_total * 16;
+    const int mt = pick_mt(rows16, tiles);
+    return g1_dispatch_pw(p, dtype, ck, mt, (int)tiles, rows16 / mt, (hipStream_t)stream);
+}
+
+extern "C" int vs_conv_k3_softmax2_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                                       float* prob, int n, int d, int h, int w, int c_in, int dtype, float eps,
+                                       void* stream) {
+    int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
+    if (rc) return rc;
+    if (!prob || c_in != 8) return VS_ESHAPE;
+    G1Params p{};
+    p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = nullptr; p.y_stats = nullptr; p.prob = prob;
+    p.N = n; p.D = d; p.H = h; p.W = w;
+    p.Do = d; p.Ho = h; p.Wo = w;
+    p.C = c_in; p.M = 8;
+    p.rb_total = 1;
+    p.nch = 1;
+    p.eps = eps;
+    p.inv_count_in = 1.0 / ((double)d * h * w);
+    p.tyn = (h + 3) / 4; p.txn = (w + 15) / 16;
+    p.tiles_per_sample = ((d + 3) / 4) * p.tyn * p.txn;
+    const long long tiles = (long long)p.tiles_per_sample * n;
+    return dtype == VS_F32 ? g1_dispatch_k3_f32(p, 8, 16, EPI_SOFTMAX2, (int)tiles, 1, (hipStream_t)stream)
+                           : g1_dispatch_k3_bf16(p, 8, 16, EPI_SOFTMAX2, (int)tiles, 1, (hipStream_t)stream);
+}

@@ -1,0 +1,340 @@
+// Implicit-GEMM convolution kernels (forward / backward-data of every conv kind) for gfx950.
+//
+// GEMM orientation: D[row = output channel m][col = voxel] = sum_k A[m][k] * B[k][voxel]
+//   A = packed weights (fragment order, see pack.hip), loaded 16 B/lane straight from global (L1/L2 hits)
+//   B = activations: k runs over (tap, channel); a lane's 16-byte fragment is EPL contiguous channels of one
+//       input voxel — read from an LDS-staged halo tile (K3) or directly from global (K2S2 / scatter).
+// The accumulator layout (col = lane&15, row = 4*(lane>>4)+reg) gives every lane 4 consecutive output
+// channels of one voxel, i.e. one 16-byte (f32) / 8-byte (bf16) channels-last store.
+#pragma once
+#include "common.h"
+
+enum { G1_K3 = 0, G1_K2S2 = 1, G1_PW = 2 };
+enum { EPI_RAW = 0, EPI_SOFTMAX2 = 1, EPI_SCATTER = 2 };
+
+struct G1Params {
+    const void* x;
+    const double* x_stats;
+    const void* wp;
+    const float* bias;
+    void* y;
+    double* y_stats;
+    float* prob;
+    int N, D, H, W;       // input grid
+    int Do, Ho, Wo;       // column grid (K3: = input; K2S2: input/2; PW: = input)
+    int C;                // input channels (padded)
+    int M;                // stored output channels (multiple of 8); for scatter: channels per tap
+    int rb_total;         // 16-row blocks in the packed weight
+    int nch;              // C / CK
+    int tiles_per_sample; // column tiles per sample
+    int tyn, txn;         // K3 tiling: tiles along y and x
+    float eps;
+    double inv_count_in;  // 1 / (D*H*W) of the input grid
+};
+
+// LDS carve (bytes)
+#define G1_LDS_MEAN 0       // float[256]
+#define G1_LDS_RSTD 1024    // float[256]
+#define G1_LDS_RED 2048     // float[4][64][2]
+#define G1_LDS_TAPS 4096    // int[64]
+#define G1_LDS_TILE 4352    // halo tile
+#define G1_TILE_VOX 648     // 6*6*18
+
+template <typename T, int CK>
+__device__ __forceinline__ u32x4 act_transform(u32x4 raw, const float* s_mean, const float* s_rstd, int c0) {
+    constexpr int EPL = ET<T>::EPL;
+    float v[EPL];
+    frag_unpack(raw, v, (T*)nullptr);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        float t = (v[j] - s_mean[c0 + j]) * s_rstd[c0 + j];
+        v[j] = t > 0.f ? t : 0.f;
+    }
+    return frag_pack(v, (T*)nullptr);
+}
+
+template <typename T, int CK, int KIND, int MT, int EPI>
+__global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
+    using E = ET<T>;
+    constexpr int EPL = E::EPL, KG = E::KG;
+    constexpr int NTAPS = KIND == G1_K3 ? 27 : (KIND == G1_K2S2 ? 8 : 1);
+    constexpr int NKG = (NTAPS * CK + KG - 1) / KG;
+    constexpr int RB = MT / 16;
+    constexpr int CKB = CK * (int)sizeof(T);          // bytes per voxel-chunk
+    constexpr int TPK = KG > CK ? KG / CK : 1;        // taps covered by one k-group
+    constexpr int KPT = KG > CK ? 1 : CK / KG;        // k-groups per tap
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_mean = (float*)(smem + G1_LDS_MEAN);
+    float* s_rstd = (float*)(smem + G1_LDS_RSTD);
+    float* s_red = (float*)(smem + G1_LDS_RED);
+    int* s_taps = (int*)(smem + G1_LDS_TAPS);
+    char* s_tile = smem + G1_LDS_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int col = lane & 15;
+    const int g = lane >> 4;
+    const int n = blockIdx.x / p.tiles_per_sample;
+    const int tile = blockIdx.x - n * p.tiles_per_sample;
+    const int rb0 = blockIdx.y * RB;
+    const bool has_stats = p.x_stats != nullptr;
+    const T* __restrict__ xin = (const T*)p.x;
+
+    // ---- per-(n,c) mean / rstd of the lazy input ----
+    if (has_stats) {
+        for (int c = tid; c < p.C; c += 256) {
+            float m, r;
+            stats_to_mean_rstd(p.x_stats + ((size_t)n * p.C + c) * 2, p.inv_count_in, p.eps, m, r);
+            s_mean[c] = m;
+            s_rstd[c] = r;
+        }
+    }
+    if (KIND == G1_K3 && tid < 32) {
+        int t = tid < 27 ? tid : 13;      // padded taps read the centre voxel (their weights are zero)
+        int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+        s_taps[tid] = ((dz * 6 + dy) * 18 + dx) * CKB;
+    }
+
+    // ---- column geometry ----
+    int z0 = 0, y0 = 0, x0 = 0;                 // K3: tile origin (output coords)
+    int lds_base[4];                            // K3: byte offset of this lane's column voxel at tap (0,0,0)
+    long long gofs[4];                          // direct: element offset of the column's input voxel (tap 0)
+    bool cvalid[4];
+    int oz[4], oy[4], ox[4];
+    if constexpr (KIND == G1_K3) {
+        const int tx = tile % p.txn;
+        const int ty = (tile / p.txn) % p.tyn;
+        const int tz = tile / (p.txn * p.tyn);
+        z0 = tz * 4; y0 = ty * 4; x0 = tx * 16;
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+            oz[cg] = z0 + wave; oy[cg] = y0 + cg; ox[cg] = x0 + col;
+            cvalid[cg] = oz[cg] < p.D && oy[cg] < p.H && ox[cg] < p.W;
+            lds_base[cg] = ((wave * 6 + cg) * 18 + col) * CKB + ((g * EPL) % CK) * (int)sizeof(T);
+        }
+    } else {
+        const long long vcol = (long long)p.Do * p.Ho * p.Wo;
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+            long long v = (long long)tile * 256 + wave * 64 + cg * 16 + col;
+            cvalid[cg] = v < vcol;
+            if (!cvalid[cg]) v = 0;
+            ox[cg] = (int)(v % p.Wo);
+            long long t2 = v / p.Wo;
+            oy[cg] = (int)(t2 % p.Ho);
+            oz[cg] = (int)(t2 / p.Ho);
+            const int s = KIND == G1_K2S2 ? 2 : 1;
+            gofs[cg] = ((((long long)n * p.D + oz[cg] * s) * p.H + oy[cg] * s) * p.W + ox[cg] * s) * p.C;
+        }
+    }
+
+    f32x4 acc[RB][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const u32x4* __restrict__ wp = (const u32x4*)p.wp;
+    __syncthreads();
+
+    for (int ch = 0; ch < p.nch; ++ch) {
+        if constexpr (KIND == G1_K3) {
+            if (ch > 0) __syncthreads();
+            // ---- stage the (4+2)x(4+2)x(16+2) halo tile of this channel chunk, activation applied ----
+            constexpr int U = CKB / 16;
+            for (int u = tid; u < G1_TILE_VOX * U; u += 256) {
+                const int tv = u / U, part = u - tv * U;
+                const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / 108;
+                const int gz = z0 + tz_ - 1, gy = y0 + ty_ - 1, gx = x0 + tx_ - 1;
+                u32x4 val = u32x4{0u, 0u, 0u, 0u};
+                if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                    const size_t e = ((((size_t)n * p.D + gz) * p.H + gy) * p.W + gx) * p.C + ch * CK + part * EPL;
+                    val = *(const u32x4*)(xin + e);
+                    if (has_stats) val = act_transform<T, CK>(val, s_mean, s_rstd, ch * CK + part * EPL);
+                }
+                *(u32x4*)(s_tile + tv * CKB + part * 16) = val;
+            }
+            __syncthreads();
+        }
+        const u32x4* wch = wp + (size_t)ch * NKG * 64 + lane;
+        const size_t rb_stride = (size_t)p.nch * NKG * 64;
+
+        if constexpr (KG > CK) {
+            // several taps per k-group: per-lane tap = kg*TPK + (g*EPL)/CK
+            const int sub = (g * EPL) / CK;
+#pragma unroll
+            for (int kg = 0; kg < NKG; ++kg) {
+                u32x4 a[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
+                u32x4 b[4];
+                const int tap = kg * TPK + sub;
+                if constexpr (KIND == G1_K3) {
+                    const int toff = s_taps[tap];
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff);
+                } else {
+                    const int tt = tap < NTAPS ? tap : 0;
+                    const int dz = (tt >> 2) & 1, dy = (tt >> 1) & 1, dx = tt & 1;
+                    const long long toff = (((long long)dz * p.H + dy) * p.W + dx) * p.C + ch * CK + (g * EPL) % CK;
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) {
+                        b[cg] = *(const u32x4*)(xin + gofs[cg] + toff);
+                        if (has_stats) b[cg] = act_transform<T, CK>(b[cg], s_mean, s_rstd, ch * CK + (g * EPL) % CK);
+                    }
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
+            }
+        } else {
+            // wave-uniform tap; KPT k-groups per tap
+#pragma unroll 1
+            for (int tap = 0; tap < NTAPS; ++tap) {
+                int toff_l = 0;
+                long long toff_g = 0;
+                if constexpr (KIND == G1_K3) {
+                    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                    toff_l = ((dz * 6 + dy) * 18 + dx) * CKB;
+                } else {
+                    const int dz = (tap >> 2) & 1, dy = (tap >> 1) & 1, dx = tap & 1;
+                    toff_g = (((long long)dz * p.H + dy) * p.W + dx) * p.C + ch * CK;
+                }
+#pragma unroll
+                for (int kk = 0; kk < KPT; ++kk) {
+                    const int kg = tap * KPT + kk;
+                    u32x4 a[RB];
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
+                    u32x4 b[4];
+                    if constexpr (KIND == G1_K3) {
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg)
+                            b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff_l + kk * KG * (int)sizeof(T));
+                    } else {
+                        const int cc = kk * KG + g * EPL;
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg) {
+                            b[cg] = *(const u32x4*)(xin + gofs[cg] + toff_g + cc);
+                            if (has_stats) b[cg] = act_transform<T, CK>(b[cg], s_mean, s_rstd, ch * CK + cc);
+                        }
+                    }
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
+                }
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // epilogues
+    // ------------------------------------------------------------------------------------------
+    if constexpr (EPI == EPI_SOFTMAX2) {
+        if (g == 0) {
+            const float b0 = p.bias ? p.bias[0] : 0.f, b1 = p.bias ? p.bias[1] : 0.f;
+            const size_t V = (size_t)p.D * p.H * p.W;
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) {
+                if (!cvalid[cg]) continue;
+                const float l0 = acc[0][cg][0] + b0, l1 = acc[0][cg][1] + b1;
+                const float mx = fmaxf(l0, l1);
+                const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx);
+                const float inv = 1.f / (e0 + e1);
+                const size_t v = ((size_t)oz[cg] * p.H + oy[cg]) * p.W + ox[cg];
+                p.prob[((size_t)n * 2 + 0) * V + v] = e0 * inv;
+                p.prob[((size_t)n * 2 + 1) * V + v] = e1 * inv;
+            }
+        }
+        return;
+    }
+
+    T* __restrict__ yout = (T*)p.y;
+    float ssum[RB][4], ssq[RB][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[rb][r] = 0.f; ssq[rb][r] = 0.f; }
+
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int row = (rb0 + rb) * 16 + 4 * g;          // first of this lane's 4 consecutive rows
+        int m = row, tap = 0;
+        if constexpr (EPI == EPI_SCATTER) { tap = row / p.M; m = row - tap * p.M; }
+        const bool rvalid = EPI == EPI_SCATTER ? (tap < 8) : (row < p.M);
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && rvalid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[r] = p.bias[m + r];
+        }
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+            if (!(rvalid && cvalid[cg])) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = E::rnd(acc[rb][cg][r] + bv[r]);
+            size_t e;
+            if constexpr (EPI == EPI_SCATTER) {
+                const int dz = (tap >> 2) & 1, dy = (tap >> 1) & 1, dx = tap & 1;
+                e = ((((size_t)n * (2 * p.D) + 2 * oz[cg] + dz) * (2 * p.H) + 2 * oy[cg] + dy) * (2 * p.W) + 2 * ox[cg] + dx) * p.M + m;
+            } else {
+                e = ((((size_t)n * p.Do + oz[cg]) * p.Ho + oy[cg]) * p.Wo + ox[cg]) * p.M + m;
+            }
+            if constexpr (sizeof(T) == 4) {
+                *(f32x4*)((float*)yout + e) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                u32x2 pk;
+                pk[0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
+                pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
+                *(u32x2*)((unsigned short*)yout + e) = pk;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ssum[rb][r] += v[r]; ssq[rb][r] += v[r] * v[r]; }
+        }
+    }
+
+    if (EPI == EPI_RAW && p.y_stats != nullptr) {
+        // reduce over the 16 columns held by lanes with equal g, then over waves, then one fp64 atomic per (m, stat)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = ssum[rb][r], q = ssq[rb][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                if (col == 0) {
+                    const int lr = rb * 16 + 4 * g + r;      // row within the WG's MT rows
+                    s_red[(wave * 64 + lr) * 2 + 0] = s;
+                    s_red[(wave * 64 + lr) * 2 + 1] = q;
+                }
+            }
+        __syncthreads();
+        if (tid < MT * 2) {
+            const int lr = tid >> 1, st = tid & 1;
+            const int row = rb0 * 16 + lr;
+            if (row < p.M) {
+                double tot = (double)s_red[(0 * 64 + lr) * 2 + st] + (double)s_red[(1 * 64 + lr) * 2 + st] +
+                             (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
+                atomicAdd(p.y_stats + ((size_t)n * p.M + row) * 2 + st, tot);
+            }
+        }
+    }
+}
+
+template <typename T, int CK, int KIND, int MT, int EPI>
+static int g1_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
+    constexpr size_t lds = G1_LDS_TILE + (KIND == G1_K3 ? (size_t)G1_TILE_VOX * CK * sizeof(T) : 0);
+    auto kern = g1_kernel<T, CK, KIND, MT, EPI>;
+    if (lds > 64 * 1024) {
+        // idempotent one-time opt-in to >64 KiB dynamic LDS (not a stream operation)
+        static const hipError_t attr_err =
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr_err != hipSuccess) return (int)attr_err;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles_total, row_tiles), dim3(256), lds, stream, p);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}

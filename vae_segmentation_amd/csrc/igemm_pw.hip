@@ -1,0 +1,6 @@
+#include "igemm_dispatch.h"
+int g1_dispatch_pw(const G1Params& p, int dtype, int ck, int mt, int tiles, int row_tiles, hipStream_t s) {
+    if (dtype == VS_F32) { G1_ALL(float, G1_PW, EPI_SCATTER) }
+    else { G1_ALL(unsigned short, G1_PW, EPI_SCATTER) }
+    return VS_ESHAPE;
+}

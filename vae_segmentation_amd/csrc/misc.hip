@@ -1,0 +1,541 @@
+// Small / streaming kernels of the training step: softmax backward, label prep, VAE bottleneck (fc, reparam, KL),
+// Dice / BCE losses, multi-tensor SGD / Adam / EMA.
+#include "common.h"
+
+extern "C" int vs_version(void) { return VS_VERSION; }
+extern "C" const char* vs_strerror(int code) {
+    switch (code) {
+        case VS_OK: return "ok";
+        case VS_EINVAL: return "invalid argument (null pointer or non-positive size)";
+        case VS_ESHAPE: return "unsupported shape (channels must be 8, 16 or a multiple of 32 up to 256; even dims for stride 2; batch <= 16 for wgrad)";
+        case VS_EDTYPE: return "unsupported dtype (VS_F32 or VS_BF16)";
+        case VS_EWORKSPACE: return "workspace too small";
+        case VS_EALIGN: return "pointer not 16-byte aligned";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown libvaeseg error";
+    }
+}
+
+#define GRID1D(n) dim3((unsigned)((((n) + 255) / 256) < 65536LL * 16 ? (((n) + 255) / 256) : 65536LL * 16))
+
+// ---- softmax (2 classes) backward ----------------------------------------------------------------
+template <typename T>
+__global__ void softmax2_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ gprob, T* __restrict__ gl,
+                                    long long voxels, int c_pad, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / voxels, v = i - n * voxels;
+        const float p0 = prob[(n * 2 + 0) * voxels + v], p1 = prob[(n * 2 + 1) * voxels + v];
+        const float g0 = gprob[(n * 2 + 0) * voxels + v], g1 = gprob[(n * 2 + 1) * voxels + v];
+        const float dot = p0 * g0 + p1 * g1;
+        float f[ET<T>::EPL];
+#pragma unroll
+        for (int j = 0; j < ET<T>::EPL; ++j) f[j] = 0.f;
+        f[0] = p0 * (g0 - dot);
+        f[1] = p1 * (g1 - dot);
+        T* o = gl + i * c_pad;
+        *(u32x4*)o = frag_pack(f, (T*)nullptr);
+        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+        for (int c0 = ET<T>::EPL; c0 < c_pad; c0 += ET<T>::EPL) *(u32x4*)(o + c0) = z;
+    }
+}
+
+extern "C" int vs_softmax2_bwd(const float* prob, const float* gprob, void* glogit, int n, long long voxels, int c_pad,
+                               int dtype, void* stream) {
+    if (!prob || !gprob || !glogit || n <= 0 || voxels <= 0 || c_pad % 8 || c_pad <= 0) return VS_EINVAL;
+    const long long total = (long long)n * voxels;
+    if (dtype == VS_F32)
+        hipLaunchKernelGGL(softmax2_bwd_kernel<float>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (float*)glogit, voxels, c_pad, total);
+    else if (dtype == VS_BF16)
+        hipLaunchKernelGGL(softmax2_bwd_kernel<unsigned short>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (unsigned short*)glogit, voxels, c_pad, total);
+    else return VS_EDTYPE;
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// ---- one-hot / binarize ---------------------------------------------------------------------------
+__global__ void onehot_kernel(const float* __restrict__ label, float* __restrict__ out, long long voxels, int n_class, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / voxels, v = i - n * voxels;
+        const int k = (int)label[i];          // .long() truncation, as label.type(LongTensor)
+        for (int c = 0; c < n_class; ++c) out[(n * n_class + c) * voxels + v] = c == k ? 1.f : 0.f;
+    }
+}
+extern "C" int vs_onehot(const float* label, float* out, int n, long long voxels, int n_class, void* stream) {
+    if (!label || !out || n <= 0 || voxels <= 0 || n_class <= 0) return VS_EINVAL;
+    const long long total = (long long)n * voxels;
+    hipLaunchKernelGGL(onehot_kernel, GRID1D(total), dim3(256), 0, (hipStream_t)stream, label, out, voxels, n_class, total);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+__global__ void binarize_kernel(const float* __restrict__ a, float* __restrict__ out, long long count, int mode, float lo, float hi) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        const float v = a[i];
+        float r;
+        if (mode == 0) r = v >= 0.5f ? 1.f : 0.f;
+        else r = v > hi ? 1.f : (v < lo ? 0.f : v);
+        out[i] = r;
+    }
+}
+extern "C" int vs_binarize(const float* a, float* out, long long count, int mode, float lo, float hi, void* stream) {
+    if (!a || !out || count <= 0) return VS_EINVAL;
+    hipLaunchKernelGGL(binarize_kernel, GRID1D(count), dim3(256), 0, (hipStream_t)stream, a, out, count, mode, lo, hi);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// ---- fully connected --------------------------------------------------------------------------------
+__device__ __forceinline__ long long phys_index(int k, int pc, int pv) { return pc > 0 ? (long long)(k % pv) * pc + k / pv : k; }
+__device__ __forceinline__ float ld_any(const void* p, int dtype, long long i) {
+    return dtype == VS_F32 ? ((const float*)p)[i] : bf2f(((const unsigned short*)p)[i]);
+}
+__device__ __forceinline__ void st_any(void* p, int dtype, long long i, float v) {
+    if (dtype == VS_F32) ((float*)p)[i] = v; else ((unsigned short*)p)[i] = f2bf(v);
+}
+#define LIN_MAXB 16
+
+// one workgroup per output j: y[b][j] = act(bias[j] + sum_k W[j][k] x[b][phys(k)])
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const void* __restrict__ x, int x_dtype, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int batch, int k_in,
+                                                         int j_out, int pc, int pv, int relu) {
+    const int j = blockIdx.x;
+    float acc[LIN_MAXB];
+#pragma unroll
+    for (int b = 0; b < LIN_MAXB; ++b) acc[b] = 0.f;
+    const float* wr = w + (size_t)j * k_in;
+    for (int k = threadIdx.x; k < k_in; k += 256) {
+        const float wv = wr[k];
+        const long long ph = phys_index(k, pc, pv);
+#pragma unroll
+        for (int b = 0; b < LIN_MAXB; ++b)
+            if (b < batch) acc[b] += wv * ld_any(x, x_dtype, (long long)b * k_in + ph);
+    }
+    __shared__ float red[4][LIN_MAXB];
+#pragma unroll
+    for (int b = 0; b < LIN_MAXB; ++b) {
+        const float s = wave_sum(acc[b]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][b] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < batch) {
+        float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x] + (bias ? bias[j] : 0.f);
+        if (relu && s < 0.f) s = 0.f;
+        y[(size_t)threadIdx.x * j_out + j] = s;
+    }
+}
+
+extern "C" int vs_linear_fwd(const void* x, int x_dtype, const float* wgt, const float* bias, float* y, int batch, int k_in,
+                             int j_out, int pc, int pv, int relu, void* stream) {
+    if (!x || !wgt || !y || batch <= 0 || batch > LIN_MAXB || k_in <= 0 || j_out <= 0) return VS_EINVAL;
+    if (pc > 0 && (long long)pc * pv != k_in) return VS_ESHAPE;
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3(j_out), dim3(256), 0, (hipStream_t)stream, x, x_dtype, wgt, bias, y, batch, k_in, j_out, pc, pv, relu);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// one wave per output j (k_in is small, e.g. 128): y[b][phys(j)] = bias[j] + sum_k W[j][k] z[b][k]
+__global__ __launch_bounds__(256) void linear_fwd_perm_out_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, void* __restrict__ y, int y_dtype,
+                                                                  int batch, int k_in, int j_out, int pc, int pv) {
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= j_out) return;
+    const float* wr = w + (size_t)j * k_in;
+    const long long ph = phys_index(j, pc, pv);
+    for (int b = 0; b < batch; ++b) {
+        float s = 0.f;
+        for (int k = lane; k < k_in; k += 64) s += wr[k] * z[(size_t)b * k_in + k];
+        s = wave_sum(s);
+        if (lane == 0) st_any(y, y_dtype, (long long)b * j_out + ph, s + (bias ? bias[j] : 0.f));
+    }
+}
+
+extern "C" int vs_linear_fwd_perm_out(const float* z, const float* wgt, const float* bias, void* y, int y_dtype, int batch,
+                                      int k_in, int j_out, int pc, int pv, void* stream) {
+    if (!z || !wgt || !y || batch <= 0 || k_in <= 0 || j_out <= 0) return VS_EINVAL;
+    if (pc > 0 && (long long)pc * pv != j_out) return VS_ESHAPE;
+    hipLaunchKernelGGL(linear_fwd_perm_out_kernel, dim3((j_out + 3) / 4), dim3(256), 0, (hipStream_t)stream, z, wgt, bias, y, y_dtype, batch, k_in, j_out, pc, pv);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// gx[b][phys(k)] = sum_j gy'[b][j] W[j][k]   (gy' = gy masked by y>0 when y_for_relu given)
+__global__ void linear_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ gy, const float* __restrict__ yrelu,
+                                    void* __restrict__ gx, int x_dtype, int batch, int k_in, int j_out, int pc, int pv) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= k_in) return;
+    const long long ph = phys_index(k, pc, pv);
+    for (int b = 0; b < batch; ++b) {
+        float s = 0.f;
+        for (int j = 0; j < j_out; ++j) {
+            float g = gy[(size_t)b * j_out + j];
+            if (yrelu && !(yrelu[(size_t)b * j_out + j] > 0.f)) g = 0.f;
+            s += g * w[(size_t)j * k_in + k];
+        }
+        st_any(gx, x_dtype, (long long)b * k_in + ph, s);
+    }
+}
+// gw[j][k] = sum_b gy'[b][j] x[b][phys(k)] ; gb[j] = sum_b gy'[b][j]
+__global__ void linear_bwd_w_kernel(const void* __restrict__ x, int x_dtype, const float* __restrict__ gy, const float* __restrict__ yrelu,
+                                    float* __restrict__ gw, float* __restrict__ gb, int batch, int k_in, int j_out, int pc, int pv) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)j_out * k_in) return;
+    const int j = (int)(i / k_in), k = (int)(i - (long long)j * k_in);
+    const long long ph = phys_index(k, pc, pv);
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < batch; ++b) {
+        float g = gy[(size_t)b * j_out + j];
+        if (yrelu && !(yrelu[(size_t)b * j_out + j] > 0.f)) g = 0.f;
+        s += g * ld_any(x, x_dtype, (long long)b * k_in + ph);
+        sb += g;
+    }
+    if (gw) gw[i] = s;
+    if (gb && k == 0) gb[j] = sb;
+}
+
+extern "C" int vs_linear_bwd(const void* x, int x_dtype, const float* wgt, const float* gy, const float* y_for_relu, void* gx,
+                             float* gw, float* gb, int batch, int k_in, int j_out, int pc, int pv, void* stream) {
+    if (!wgt || !gy || batch <= 0 || k_in <= 0 || j_out <= 0) return VS_EINVAL;
+    if (pc > 0 && (long long)pc * pv != k_in) return VS_ESHAPE;
+    if (gx) {
+        hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((k_in + 255) / 256), dim3(256), 0, (hipStream_t)stream, wgt, gy, y_for_relu, gx, x_dtype, batch, k_in, j_out, pc, pv);
+        VS_CHECK_LAUNCH();
+    }
+    if (gw || gb) {
+        if (!x) return VS_EINVAL;
+        const long long total = (long long)j_out * k_in;
+        hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, gy, y_for_relu, gw, gb, batch, k_in, j_out, pc, pv);
+        VS_CHECK_LAUNCH();
+    }
+    return VS_OK;
+}
+
+// backward of y[b][phys(j)] = bias[j] + sum_k W[j][k] z[b][k]
+__global__ __launch_bounds__(256) void linear_perm_out_bwd_z_kernel(const float* __restrict__ w, const void* __restrict__ gy, int y_dtype,
+                                                                    float* __restrict__ gz, int batch, int k_in, int j_out, int pc, int pv) {
+    // one workgroup per (b, k): reduce over j
+    const int b = blockIdx.y, k = blockIdx.x;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < j_out; j += 256)
+        s += ld_any(gy, y_dtype, (long long)b * j_out + phys_index(j, pc, pv)) * w[(size_t)j * k_in + k];
+    __shared__ float red[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) gz[(size_t)b * k_in + k] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void linear_perm_out_bwd_w_kernel(const float* __restrict__ z, const void* __restrict__ gy, int y_dtype, float* __restrict__ gw,
+                                             float* __restrict__ gb, int batch, int k_in, int j_out, int pc, int pv) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)j_out * k_in) return;
+    const int j = (int)(i / k_in), k = (int)(i - (long long)j * k_in);
+    const long long ph = phys_index(j, pc, pv);
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < batch; ++b) {
+        const float g = ld_any(gy, y_dtype, (long long)b * j_out + ph);
+        s += g * z[(size_t)b * k_in + k];
+        sb += g;
+    }
+    if (gw) gw[i] = s;
+    if (gb && k == 0) gb[j] = sb;
+}
+extern "C" int vs_linear_perm_out_bwd(const float* z, const float* wgt, const void* gy, int y_dtype, float* gz, float* gw,
+                                      float* gb, int batch, int k_in, int j_out, int pc, int pv, void* stream) {
+    if (!wgt || !gy || batch <= 0 || k_in <= 0 || j_out <= 0) return VS_EINVAL;
+    if (pc > 0 && (long long)pc * pv != j_out) return VS_ESHAPE;
+    if (gz) {
+        hipLaunchKernelGGL(linear_perm_out_bwd_z_kernel, dim3(k_in, batch), dim3(256), 0, (hipStream_t)stream, wgt, gy, y_dtype, gz, batch, k_in, j_out, pc, pv);
+        VS_CHECK_LAUNCH();
+    }
+    if (gw || gb) {
+        if (!z) return VS_EINVAL;
+        const long long total = (long long)j_out * k_in;
+        hipLaunchKernelGGL(linear_perm_out_bwd_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, gy, y_dtype, gw, gb, batch, k_in, j_out, pc, pv);
+        VS_CHECK_LAUNCH();
+    }
+    return VS_OK;
+}
+
+// ---- reparameterisation / KL -----------------------------------------------------------------------
+__global__ void reparam_fwd_kernel(const float* mean, const float* sd, const float* noise, float scale, float* z, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) z[i] = mean[i] + noise[i] * sd[i] * scale;
+}
+__global__ void reparam_bwd_kernel(const float* gz, const float* noise, float scale, float* gmean, float* gstd, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        if (gmean) gmean[i] = gz[i];
+        if (gstd) gstd[i] = gz[i] * noise[i] * scale;
+    }
+}
+extern "C" int vs_reparam_fwd(const float* mean, const float* std_, const float* noise, float scale, float* z, long long count, void* stream) {
+    if (!mean || !std_ || !noise || !z || count <= 0) return VS_EINVAL;
+    hipLaunchKernelGGL(reparam_fwd_kernel, GRID1D(count), dim3(256), 0, (hipStream_t)stream, mean, std_, noise, scale, z, count);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+extern "C" int vs_reparam_bwd(const float* gz, const float* noise, float scale, float* gmean, float* gstd, long long count, void* stream) {
+    if (!gz || !noise || count <= 0) return VS_EINVAL;
+    hipLaunchKernelGGL(reparam_bwd_kernel, GRID1D(count), dim3(256), 0, (hipStream_t)stream, gz, noise, scale, gmean, gstd, count);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ mean, const float* __restrict__ sd, float* __restrict__ out, int batch, int dim) {
+    // single workgroup: total = sum_b 0.5*(sum sd^2 + sum mean^2 - 2 sum log(sd+1e-5)) / batch
+    double s = 0.0;
+    for (int i = threadIdx.x; i < batch * dim; i += 256) {
+        const float m = mean[i], d = sd[i];
+        s += 0.5 * ((double)d * d + (double)m * m - 2.0 * (double)logf(d + 0.00001f));
+    }
+    __shared__ double red[4];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) / batch);
+}
+__global__ void kl_bwd_kernel(const float* mean, const float* sd, const float* gout, float* gmean, float* gstd, int batch, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * dim) return;
+    const float g = gout[0] / batch;
+    if (gmean) gmean[i] = g * mean[i];
+    if (gstd) gstd[i] = g * (sd[i] - 1.f / (sd[i] + 0.00001f));
+}
+extern "C" int vs_kl_fwd(const float* mean, const float* std_, float* out, int batch, int dim, void* stream) {
+    if (!mean || !std_ || !out || batch <= 0 || dim <= 0) return VS_EINVAL;
+    hipLaunchKernelGGL(kl_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean, std_, out, batch, dim);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+extern "C" int vs_kl_bwd(const float* mean, const float* std_, const float* gout, float* gmean, float* gstd, int batch, int dim, void* stream) {
+    if (!mean || !std_ || !gout || batch <= 0 || dim <= 0) return VS_EINVAL;
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3((batch * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, mean, std_, gout, gmean, gstd, batch, dim);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// ---- soft Dice ------------------------------------------------------------------------------------------
+// grid (blocks, channel slot, b): float4 streaming over the voxels of one (b,c) plane; fp64 atomics per block.
+__global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict__ s, const float* __restrict__ t, double* __restrict__ sums,
+                                                        int channels, long long voxels, int bot) {
+    const int c = bot + blockIdx.y, b = blockIdx.z;
+    const float* sp = s + ((size_t)b * channels + c) * voxels;
+    const float* tp = t + ((size_t)b * channels + c) * voxels;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const long long v4 = voxels / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v4; i += (long long)gridDim.x * 256) {
+        const f32x4 x = *(const f32x4*)(sp + i * 4), y = *(const f32x4*)(tp + i * 4);
+        a0 += (double)(x[0] * y[0] + x[1] * y[1]) + (double)(x[2] * y[2] + x[3] * y[3]);
+        a1 += (double)(x[0] + x[1]) + (double)(x[2] + x[3]);
+        a2 += (double)(y[0] + y[1]) + (double)(y[2] + y[3]);
+    }
+    if (blockIdx.x == 0)
+        for (long long i = v4 * 4 + threadIdx.x; i < voxels; i += 256) { a0 += (double)sp[i] * tp[i]; a1 += sp[i]; a2 += tp[i]; }
+    __shared__ double red[4][3];
+    a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a0; red[threadIdx.x >> 6][1] = a1; red[threadIdx.x >> 6][2] = a2; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(sums + ((size_t)b * channels + c) * 3 + threadIdx.x, tot);
+    }
+}
+__global__ void dice_finish_kernel(const double* __restrict__ sums, float* per_sample, float* mean_out, int batch, int channels, int bot, int top, float eps) {
+    // single small block; thread b computes per-sample mean over channels
+    __shared__ float ps[64];
+    const int b = threadIdx.x;
+    float v = 0.f;
+    if (b < batch) {
+        for (int c = bot; c < top; ++c) {
+            const double* q = sums + ((size_t)b * channels + c) * 3;
+            // fp32 arithmetic as torch does on the fp32 sums
+            const float I = (float)q[0], S = (float)q[1], Tt = (float)q[2];
+            v += 2.f * I / (S + Tt + eps);
+        }
+        v /= (float)(top - bot);
+        if (per_sample) per_sample[b] = v;
+        ps[b] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && mean_out) {
+        float m = 0.f;
+        for (int i = 0; i < batch; ++i) m += ps[i];
+        mean_out[0] = m / batch;
+    }
+}
+extern "C" int vs_dice_fwd(const float* s, const float* t, double* sums, float* per_sample, float* mean_out, int batch,
+                           int channels, long long voxels, int bot, int top, float eps, void* stream) {
+    if (!s || !t || !sums || batch <= 0 || batch > 64 || channels <= 0 || voxels <= 0 || bot < 0 || top > channels || bot >= top) return VS_EINVAL;
+    if (((uintptr_t)s & 15) || ((uintptr_t)t & 15) || (voxels & 3)) return VS_EALIGN;
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 3 * batch * channels, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    long long blocks = (voxels / 4 + 256 * 8 - 1) / (256 * 8);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(dice_sums_kernel, dim3((unsigned)blocks, top - bot, batch), dim3(256), 0, (hipStream_t)stream, s, t, sums, channels, voxels, bot);
+    VS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dice_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, per_sample, mean_out, batch, channels, bot, top, eps);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// d/ds_i [2I/(S+T+eps)] = 2 t_i/den - 2I/den^2 ; d/dt_i symmetric.  grid (blocks, channels, b)
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ s, const float* __restrict__ t, const double* __restrict__ sums,
+                                                       const float* __restrict__ gout, int gout_is_mean, int batch,
+                                                       float* __restrict__ gs, float* __restrict__ gt,
+                                                       int channels, long long voxels, int bot, int top, float eps) {
+    const int c = blockIdx.y, b = blockIdx.z;
+    const size_t plane = ((size_t)b * channels + c) * voxels;
+    const long long v4 = voxels / 4;
+    if (c < bot || c >= top) {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v4; i += (long long)gridDim.x * 256) {
+            if (gs) *(f32x4*)(gs + plane + i * 4) = z;
+            if (gt) *(f32x4*)(gt + plane + i * 4) = z;
+        }
+        return;
+    }
+    const double* q = sums + ((size_t)b * channels + c) * 3;
+    const float I = (float)q[0], den = (float)q[1] + (float)q[2] + eps;
+    const float g = (gout_is_mean ? gout[0] / (float)batch : gout[b]) / (float)(top - bot);
+    const float k1 = g * 2.f / den, k2 = g * 2.f * I / (den * den);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v4; i += (long long)gridDim.x * 256) {
+        if (gs) { const f32x4 y = *(const f32x4*)(t + plane + i * 4); *(f32x4*)(gs + plane + i * 4) = f32x4{k1 * y[0] - k2, k1 * y[1] - k2, k1 * y[2] - k2, k1 * y[3] - k2}; }
+        if (gt) { const f32x4 x = *(const f32x4*)(s + plane + i * 4); *(f32x4*)(gt + plane + i * 4) = f32x4{k1 * x[0] - k2, k1 * x[1] - k2, k1 * x[2] - k2, k1 * x[3] - k2}; }
+    }
+}
+extern "C" int vs_dice_bwd(const float* s, const float* t, const double* sums, const float* gout, int gout_is_mean, float* gs,
+                           float* gt, int batch, int channels, long long voxels, int bot, int top, float eps, void* stream) {
+    if (!s || !t || !sums || !gout || batch <= 0 || channels <= 0 || voxels <= 0 || (voxels & 3)) return VS_EINVAL;
+    long long blocks = (voxels / 4 + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(dice_bwd_kernel, dim3((unsigned)blocks, channels, batch), dim3(256), 0, (hipStream_t)stream, s, t, sums, gout, gout_is_mean, batch, gs, gt, channels, voxels, bot, top, eps);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// ---- BCE ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_sum_kernel(const float* __restrict__ p, const float* __restrict__ t, double* __restrict__ acc, long long count) {
+    double s = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const float lp = fmaxf(logf(p[i]), -100.f), lq = fmaxf(logf(1.f - p[i]), -100.f);
+        s -= (double)(t[i] * lp + (1.f - t[i]) * lq);
+    }
+    __shared__ double red[4];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void bce_finish_kernel(const double* acc, float* out, long long count) { out[0] = (float)(acc[0] / (double)count); }
+__global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ gout, float* __restrict__ gp, long long count) {
+    const float g = gout[0] / (float)count;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const float d = fmaxf(p[i] * (1.f - p[i]), 1e-12f);
+        gp[i] = g * (p[i] - t[i]) / d;
+    }
+}
+extern "C" int vs_bce_fwd(const float* p, const float* t, float* out, double* scratch, long long count, void* stream) {
+    if (!p || !t || !out || !scratch || count <= 0) return VS_EINVAL;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    long long blocks = (count + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(bce_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, t, scratch, count);
+    VS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scratch, out, count);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+extern "C" int vs_bce_bwd(const float* p, const float* t, const float* gout, float* gp, long long count, void* stream) {
+    if (!p || !t || !gout || !gp || count <= 0) return VS_EINVAL;
+    hipLaunchKernelGGL(bce_bwd_kernel, GRID1D(count), dim3(256), 0, (hipStream_t)stream, p, t, gout, gp, count);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// ---- multi-tensor optimiser steps -----------------------------------------------------------------------------
+#define MT_CHUNK 65536
+__global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* params, const float* const* grads, float* const* bufs,
+                                                        const long long* sizes, const int* block_map, float lr, float momentum,
+                                                        float wd, int first) {
+    const int ti = block_map[2 * blockIdx.x], start = block_map[2 * blockIdx.x + 1];
+    float* p = params[ti];
+    const float* g = grads[ti];
+    float* m = bufs[ti];
+    const long long n = sizes[ti];
+    const long long end = (long long)start + MT_CHUNK < n ? (long long)start + MT_CHUNK : n;
+    for (long long i = start + threadIdx.x; i < end; i += 256) {
+        float gi = g[i] + wd * p[i];
+        float bi = first ? gi : momentum * m[i] + gi;
+        m[i] = bi;
+        p[i] -= lr * (momentum != 0.f ? bi : gi);
+    }
+}
+extern "C" int vs_sgd_momentum_multi(float* const* params, const float* const* grads, float* const* bufs, const long long* sizes,
+                                     const int* block_map, int n_blocks, float lr, float momentum, float weight_decay,
+                                     int first_step, void* stream) {
+    if (!params || !grads || !bufs || !sizes || !block_map || n_blocks <= 0) return VS_EINVAL;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, params, grads, bufs, sizes, block_map, lr, momentum, weight_decay, first_step);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(float* const* params, const float* const* grads, float* const* m1, float* const* m2,
+                                                         const long long* sizes, const int* block_map, float lr, float b1, float b2,
+                                                         float eps, float wd, float bc1, float bc2) {
+    const int ti = block_map[2 * blockIdx.x], start = block_map[2 * blockIdx.x + 1];
+    float* p = params[ti];
+    const float* g = grads[ti];
+    float* a = m1[ti];
+    float* v = m2[ti];
+    const long long n = sizes[ti];
+    const long long end = (long long)start + MT_CHUNK < n ? (long long)start + MT_CHUNK : n;
+    const float step_size = lr / bc1;
+    const float bc2s = sqrtf(bc2);
+    for (long long i = start + threadIdx.x; i < end; i += 256) {
+        const float gi = g[i] + wd * p[i];
+        const float ai = b1 * a[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        a[i] = ai; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2s + eps;
+        p[i] -= step_size * ai / denom;
+    }
+}
+extern "C" int vs_adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                             const long long* sizes, const int* block_map, int n_blocks, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, void* stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || !block_map || n_blocks <= 0 || step < 1) return VS_EINVAL;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes, block_map, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+__global__ __launch_bounds__(256) void ema_multi_kernel(float* const* teacher, const float* const* student, const long long* sizes,
+                                                        const int* block_map, float alpha) {
+    const int ti = block_map[2 * blockIdx.x], start = block_map[2 * blockIdx.x + 1];
+    float* t = teacher[ti];
+    const float* s = student[ti];
+    const long long n = sizes[ti];
+    const long long end = (long long)start + MT_CHUNK < n ? (long long)start + MT_CHUNK : n;
+    for (long long i = start + threadIdx.x; i < end; i += 256) t[i] = alpha * t[i] + (1.f - alpha) * s[i];
+}
+extern "C" int vs_ema_multi(float* const* teacher, const float* const* student, const long long* sizes, const int* block_map,
+                            int n_blocks, float alpha, void* stream) {
+    if (!teacher || !student || !sizes || !block_map || n_blocks <= 0) return VS_EINVAL;
+    hipLaunchKernelGGL(ema_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, teacher, student, sizes, block_map, alpha);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+__global__ void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, float scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i] * scale;
+}
+extern "C" int vs_scale_copy(const float* src, float* dst, long long count, float scale, void* stream) {
+    if (!src || !dst || count <= 0) return VS_EINVAL;
+    long long blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, count, scale);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}

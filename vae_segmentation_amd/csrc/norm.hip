@@ -1,0 +1,293 @@
+// InstanceNorm3d(affine=False)+ReLU helpers on channels-last tensors: standalone statistics, materialisation
+// (with the optional U-Net skip add), and the two-pass backward (per-(n,c) reductions, then the apply pass).
+// All are HBM-bound streaming kernels: 16-byte fragments, one workgroup = 256 threads laid out as
+// (C/EPL channel fragments) x (voxel sub-rows), fp64 atomics only once per (block, channel, statistic).
+#include "common.h"
+
+#define NB_MAX_C 256
+
+template <typename T>
+struct RowIter {
+    // thread -> (channel fragment fx, voxel sub-row fy); a block covers `rows_per_it` voxels per iteration
+    int fx, fy, frags, rows_per_it;
+    __device__ RowIter(int c) {
+        frags = c / ET<T>::EPL;
+        fx = threadIdx.x % frags;
+        fy = threadIdx.x / frags;
+        rows_per_it = 256 / frags;
+    }
+    __device__ bool active() const { return fy < rows_per_it; }
+};
+
+__device__ __forceinline__ void load_mean_rstd(const double* stats, int n, int c, double inv_count, float eps,
+                                               float* s_mean, float* s_rstd) {
+    for (int i = threadIdx.x; i < c; i += blockDim.x) {
+        float m = 0.f, r = 1.f;
+        if (stats) stats_to_mean_rstd(stats + ((size_t)n * c + i) * 2, inv_count, eps, m, r);
+        s_mean[i] = m;
+        s_rstd[i] = r;
+    }
+}
+
+// block-level reduction of per-thread channel partials (EPL channels x NS statistics) + fp64 atomics
+template <typename T, int NS>
+__device__ __forceinline__ void reduce_and_atomic(const RowIter<T>& it, double (&part)[ET<T>::EPL][NS], double* out,
+                                                  int n, int c, double* s_red /* [256][EPL*NS] */) {
+    constexpr int EPL = ET<T>::EPL;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) s_red[threadIdx.x * (EPL * NS) + j * NS + s] = it.active() ? part[j][s] : 0.0;
+    __syncthreads();
+    // thread t < c*NS sums one (channel, statistic) over the voxel sub-rows
+    for (int o = threadIdx.x; o < c * NS; o += 256) {
+        const int ch = o / NS, s = o - ch * NS;
+        const int fx = ch / EPL, j = ch - fx * EPL;
+        double tot = 0.0;
+        for (int fy = 0; fy < it.rows_per_it; ++fy) tot += s_red[(fy * it.frags + fx) * (EPL * NS) + j * NS + s];
+        atomicAdd(out + ((size_t)n * c + ch) * NS + s, tot);
+    }
+}
+
+// ---- statistics -------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stats_kernel(const T* __restrict__ x, double* __restrict__ stats, long long voxels, int c) {
+    constexpr int EPL = ET<T>::EPL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* s_red = (double*)smem;
+    RowIter<T> it(c);
+    const int n = blockIdx.y;
+    double part[EPL][2];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) part[j][0] = part[j][1] = 0.0;
+    if (it.active()) {
+        const T* base = x + (size_t)n * voxels * c + it.fx * EPL;
+        for (long long v = (long long)blockIdx.x * it.rows_per_it + it.fy; v < voxels; v += (long long)gridDim.x * it.rows_per_it) {
+            float f[EPL];
+            frag_unpack(*(const u32x4*)(base + v * c), f, (T*)nullptr);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) { part[j][0] += f[j]; part[j][1] += (double)f[j] * f[j]; }
+        }
+    }
+    reduce_and_atomic<T, 2>(it, part, stats, n, c, s_red);
+}
+
+// ---- materialise relu(norm(x)) [+ relu(norm(x2))] ------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_fwd_kernel(const T* __restrict__ x, const double* xs, const T* __restrict__ x2,
+                                                          const double* x2s, T* __restrict__ out, long long voxels, int c,
+                                                          double inv_count, float eps) {
+    constexpr int EPL = ET<T>::EPL;
+    __shared__ float s_m[NB_MAX_C], s_r[NB_MAX_C], s_m2[NB_MAX_C], s_r2[NB_MAX_C];
+    const int n = blockIdx.y;
+    load_mean_rstd(xs, n, c, inv_count, eps, s_m, s_r);
+    if (x2) load_mean_rstd(x2s, n, c, inv_count, eps, s_m2, s_r2);
+    __syncthreads();
+    RowIter<T> it(c);
+    if (!it.active()) return;
+    const size_t sample = (size_t)n * voxels * c + it.fx * EPL;
+    for (long long v = (long long)blockIdx.x * it.rows_per_it + it.fy; v < voxels; v += (long long)gridDim.x * it.rows_per_it) {
+        float f[EPL], o[EPL];
+        frag_unpack(*(const u32x4*)(x + sample + v * c), f, (T*)nullptr);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            float t = f[j];
+            if (xs) { t = (t - s_m[it.fx * EPL + j]) * s_r[it.fx * EPL + j]; t = t > 0.f ? t : 0.f; }
+            o[j] = t;
+        }
+        if (x2) {
+            frag_unpack(*(const u32x4*)(x2 + sample + v * c), f, (T*)nullptr);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                float t = f[j];
+                if (x2s) { t = (t - s_m2[it.fx * EPL + j]) * s_r2[it.fx * EPL + j]; t = t > 0.f ? t : 0.f; }
+                o[j] += t;
+            }
+        }
+        *(u32x4*)(out + sample + v * c) = frag_pack(o, (T*)nullptr);
+    }
+}
+
+// ---- backward: reductions ------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ x, const double* xs,
+                                                                 double* __restrict__ sums, long long voxels, int c,
+                                                                 double inv_count, float eps) {
+    constexpr int EPL = ET<T>::EPL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* s_red = (double*)smem;
+    __shared__ float s_m[NB_MAX_C], s_r[NB_MAX_C];
+    const int n = blockIdx.y;
+    load_mean_rstd(xs, n, c, inv_count, eps, s_m, s_r);
+    __syncthreads();
+    RowIter<T> it(c);
+    double part[EPL][2];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) part[j][0] = part[j][1] = 0.0;
+    if (it.active()) {
+        const size_t sample = (size_t)n * voxels * c + it.fx * EPL;
+        for (long long v = (long long)blockIdx.x * it.rows_per_it + it.fy; v < voxels; v += (long long)gridDim.x * it.rows_per_it) {
+            float fg[EPL], fx_[EPL];
+            frag_unpack(*(const u32x4*)(g + sample + v * c), fg, (T*)nullptr);
+            frag_unpack(*(const u32x4*)(x + sample + v * c), fx_, (T*)nullptr);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const float xh = (fx_[j] - s_m[it.fx * EPL + j]) * s_r[it.fx * EPL + j];
+                const float gm = xh > 0.f ? fg[j] : 0.f;
+                part[j][0] += gm;
+                part[j][1] += (double)gm * xh;
+            }
+        }
+    }
+    reduce_and_atomic<T, 2>(it, part, sums, n, c, s_red);
+}
+
+// ---- backward: apply -----------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x, const double* xs,
+                                                                const double* __restrict__ sums, T* __restrict__ gx,
+                                                                long long voxels, int c, double inv_count, float eps) {
+    constexpr int EPL = ET<T>::EPL;
+    __shared__ float s_m[NB_MAX_C], s_r[NB_MAX_C], s_a[NB_MAX_C], s_b[NB_MAX_C];
+    const int n = blockIdx.y;
+    load_mean_rstd(xs, n, c, inv_count, eps, s_m, s_r);
+    for (int i = threadIdx.x; i < c; i += 256) {
+        s_a[i] = (float)(sums[((size_t)n * c + i) * 2 + 0] * inv_count);
+        s_b[i] = (float)(sums[((size_t)n * c + i) * 2 + 1] * inv_count);
+    }
+    __syncthreads();
+    RowIter<T> it(c);
+    if (!it.active()) return;
+    const size_t sample = (size_t)n * voxels * c + it.fx * EPL;
+    for (long long v = (long long)blockIdx.x * it.rows_per_it + it.fy; v < voxels; v += (long long)gridDim.x * it.rows_per_it) {
+        float fg[EPL], fx_[EPL], o[EPL];
+        frag_unpack(*(const u32x4*)(g + sample + v * c), fg, (T*)nullptr);
+        frag_unpack(*(const u32x4*)(x + sample + v * c), fx_, (T*)nullptr);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int ch = it.fx * EPL + j;
+            const float xh = (fx_[j] - s_m[ch]) * s_r[ch];
+            const float gm = xh > 0.f ? fg[j] : 0.f;
+            o[j] = s_r[ch] * (gm - s_a[ch] - xh * s_b[ch]);
+        }
+        *(u32x4*)(gx + sample + v * c) = frag_pack(o, (T*)nullptr);
+    }
+}
+
+// ---- bias gradient ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ g, float* __restrict__ db, long long rows, int c, int c_real) {
+    constexpr int EPL = ET<T>::EPL;
+    __shared__ double s_red[256 * 8];
+    RowIter<T> it(c);
+    double part[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) part[j] = 0.0;
+    if (it.active()) {
+        for (long long v = (long long)blockIdx.x * it.rows_per_it + it.fy; v < rows; v += (long long)gridDim.x * it.rows_per_it) {
+            float f[EPL];
+            frag_unpack(*(const u32x4*)(g + v * c + it.fx * EPL), f, (T*)nullptr);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) part[j] += f[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) s_red[threadIdx.x * EPL + j] = it.active() ? part[j] : 0.0;
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c_real; ch += 256) {
+        const int fx = ch / EPL, j = ch - fx * EPL;
+        double tot = 0.0;
+        for (int fy = 0; fy < it.rows_per_it; ++fy) tot += s_red[(fy * it.frags + fx) * EPL + j];
+        atomicAdd(db + ch, (float)tot);
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------
+static int check_cl(const void* a, int n, long long voxels, int c, int dtype) {
+    if (!a || n <= 0 || voxels <= 0) return VS_EINVAL;
+    if (c <= 0 || c % 8 || c > NB_MAX_C || (256 % (c / 8)) ) return VS_ESHAPE;
+    if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
+    return VS_OK;
+}
+static int row_blocks(long long voxels, int c, int dtype) {
+    const int frags = c / (dtype == VS_F32 ? 4 : 8);
+    const int rpi = 256 / frags;
+    long long b = (voxels + rpi - 1) / rpi;
+    // each block should stream >= ~16 iterations; cap at 8 blocks per CU overall
+    long long cap = (voxels + (long long)rpi * 16 - 1) / ((long long)rpi * 16);
+    if (cap < 1) cap = 1;
+    if (cap > 2048) cap = 2048;
+    return (int)(b < cap ? b : cap);
+}
+static size_t red_lds(int dtype, int ns) { return (size_t)256 * (dtype == VS_F32 ? 4 : 8) * ns * sizeof(double); }
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
+    if ((dtype) == VS_F32) { CALL_F32; } else { CALL_BF16; }
+
+extern "C" int vs_instnorm_stats(const void* x, double* stats, int n, long long voxels, int c, int dtype, void* stream) {
+    int rc = check_cl(x, n, voxels, c, dtype);
+    if (rc) return rc;
+    if (!stats) return VS_EINVAL;
+    dim3 grid(row_blocks(voxels, c, dtype), n);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(stats_kernel<float>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const float*)x, stats, voxels, c),
+        hipLaunchKernelGGL(stats_kernel<unsigned short>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const unsigned short*)x, stats, voxels, c));
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_instnorm_relu_fwd(const void* x, const double* x_stats, const void* x2, const double* x2_stats,
+                                    void* out, int n, long long voxels, int c, int dtype, float eps, void* stream) {
+    int rc = check_cl(x, n, voxels, c, dtype);
+    if (rc) return rc;
+    if (!out) return VS_EINVAL;
+    dim3 grid(row_blocks(voxels, c, dtype), n);
+    const double inv = 1.0 / (double)voxels;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(in_relu_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, x_stats, (const float*)x2, x2_stats, (float*)out, voxels, c, inv, eps),
+        hipLaunchKernelGGL(in_relu_fwd_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, x_stats, (const unsigned short*)x2, x2_stats, (unsigned short*)out, voxels, c, inv, eps));
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_instnorm_relu_bwd_reduce(const void* g, const void* x, const double* x_stats, double* sums, int n,
+                                           long long voxels, int c, int dtype, float eps, void* stream) {
+    int rc = check_cl(x, n, voxels, c, dtype);
+    if (rc) return rc;
+    if (!g || !x_stats || !sums) return VS_EINVAL;
+    dim3 grid(row_blocks(voxels, c, dtype), n);
+    const double inv = 1.0 / (double)voxels;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(in_relu_bwd_reduce_kernel<float>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const float*)g, (const float*)x, x_stats, sums, voxels, c, inv, eps),
+        hipLaunchKernelGGL(in_relu_bwd_reduce_kernel<unsigned short>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const unsigned short*)g, (const unsigned short*)x, x_stats, sums, voxels, c, inv, eps));
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_instnorm_relu_bwd_apply(const void* g, const void* x, const double* x_stats, const double* sums,
+                                          void* gx, int n, long long voxels, int c, int dtype, float eps, void* stream) {
+    int rc = check_cl(x, n, voxels, c, dtype);
+    if (rc) return rc;
+    if (!g || !x_stats || !sums || !gx) return VS_EINVAL;
+    dim3 grid(row_blocks(voxels, c, dtype), n);
+    const double inv = 1.0 / (double)voxels;
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(in_relu_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)x, x_stats, sums, (float*)gx, voxels, c, inv, eps),
+        hipLaunchKernelGGL(in_relu_bwd_apply_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)g, (const unsigned short*)x, x_stats, sums, (unsigned short*)gx, voxels, c, inv, eps));
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_bias_grad(const void* g, float* db, long long rows, int c_ch, int c_real, int dtype, void* stream) {
+    int rc = check_cl(g, 1, rows, c_ch, dtype);
+    if (rc) return rc;
+    if (!db || c_real <= 0 || c_real > c_ch) return VS_EINVAL;
+    hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * c_real, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid(row_blocks(rows, c_ch, dtype));
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, db, rows, c_ch, c_real),
+        hipLaunchKernelGGL(bias_grad_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)g, db, rows, c_ch, c_real));
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}

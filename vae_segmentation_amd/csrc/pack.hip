@@ -1,0 +1,137 @@
+// Weight packing into MFMA fragment order + layout glue at the planar (NCDHW fp32) boundary.
+#include "common.h"
+
+// Packed image: [row-block rb][channel chunk ch][k-group kg][lane][EPL elements]
+//   row = rb*16 + (lane & 15);  k within the chunk = kg*KG + (lane >> 4)*EPL + j;  tap = k / CK, c = ch*CK + k % CK
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int d0, int d1, int ntaps,
+                                   int c_pad, int form, long long total) {
+    constexpr int EPL = ET<T>::EPL, KG = ET<T>::KG;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int CK = c_pad < 32 ? c_pad : 32;
+    const int nch = c_pad / CK;
+    const int gemm_taps = form == VS_PACK_SCATTER_D1 ? 1 : ntaps;
+    const int nkg = (gemm_taps * CK + KG - 1) / KG;
+    const int j = (int)(i % EPL);
+    long long r = i / EPL;
+    const int lane = (int)(r % 64); r /= 64;
+    const int kg = (int)(r % nkg); r /= nkg;
+    const int ch = (int)(r % nch);
+    const int rb = (int)(r / nch);
+    const int row = rb * 16 + (lane & 15);
+    const int kk = kg * KG + (lane >> 4) * EPL + j;
+    const int tap = kk / CK;
+    const int c = ch * CK + kk % CK;
+    float v = 0.f;
+    if (form == VS_PACK_ROWS_D0) {
+        if (row < d0 && tap < ntaps && c < d1) v = src[((size_t)row * d1 + c) * ntaps + tap];
+    } else if (form == VS_PACK_ROWS_D1_FLIP) {
+        if (row < d1 && tap < ntaps && c < d0) v = src[((size_t)c * d1 + row) * ntaps + (ntaps - 1 - tap)];
+    } else {  // VS_PACK_SCATTER_D1: rows (t, m = d1 index), k = c = d0 index
+        const int t = row / d1, m = row - t * d1;
+        if (t < ntaps && tap < 1 && c < d0) v = src[((size_t)c * d1 + m) * ntaps + t];
+    }
+    ET<T>::st(dst + i, v);
+}
+
+static long long packed_elems(int rows, int c_pad, int gemm_taps, int dtype) {
+    const int EPL = dtype == VS_F32 ? 4 : 8, KG = 4 * EPL;
+    const int CK = c_pad < 32 ? c_pad : 32;
+    const int nch = c_pad / CK;
+    const int nkg = (gemm_taps * CK + KG - 1) / KG;
+    const int rbt = (rows + 15) / 16;
+    return (long long)rbt * nch * nkg * 64 * EPL;
+}
+
+extern "C" size_t vs_packed_weight_bytes(int rows, int c_pad, int ntaps, int dtype) {
+    return (size_t)packed_elems(rows, c_pad, ntaps, dtype) * (dtype == VS_F32 ? 4 : 2);
+}
+
+extern "C" int vs_pack_weight(const float* src, void* dst, int d0, int d1, int ntaps, int c_pad, int form, int dtype,
+                              void* stream) {
+    if (!src || !dst || d0 <= 0 || d1 <= 0) return VS_EINVAL;
+    if (!(c_pad == 8 || c_pad == 16 || (c_pad % 32 == 0 && c_pad > 0))) return VS_ESHAPE;
+    if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
+    int rows, kc, gemm_taps;
+    if (form == VS_PACK_ROWS_D0) { rows = d0; kc = d1; gemm_taps = ntaps; }
+    else if (form == VS_PACK_ROWS_D1_FLIP) { rows = d1; kc = d0; gemm_taps = ntaps; }
+    else if (form == VS_PACK_SCATTER_D1) { rows = ntaps * d1; kc = d0; gemm_taps = 1; }
+    else return VS_EINVAL;
+    if (kc > c_pad) return VS_ESHAPE;
+    if (!(ntaps == 27 || ntaps == 8)) return VS_ESHAPE;
+    const long long total = packed_elems(rows, c_pad, gemm_taps, dtype);
+    const int blocks = vs_ceil_div(total, 256);
+    if (dtype == VS_F32)
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (float*)dst,
+                           d0, d1, ntaps, c_pad, form, total);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel<unsigned short>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
+                           (unsigned short*)dst, d0, d1, ntaps, c_pad, form, total);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// ---- planar fp32 [N][Cs][V]  <->  channels-last [N][V][Cp] ---------------------------------------
+template <typename T>
+__global__ void pack_planar_kernel(const float* __restrict__ src, T* __restrict__ dst, long long voxels, int c_src,
+                                   int c_pad, long long total_vox) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (n, v)
+    if (i >= total_vox) return;
+    const long long n = i / voxels, v = i - n * voxels;
+    T* o = dst + i * c_pad;
+    for (int c0 = 0; c0 < c_pad; c0 += ET<T>::EPL) {
+        float f[ET<T>::EPL];
+#pragma unroll
+        for (int j = 0; j < ET<T>::EPL; ++j) {
+            const int c = c0 + j;
+            f[j] = c < c_src ? src[(n * c_src + c) * voxels + v] : 0.f;
+        }
+        *(u32x4*)(o + c0) = frag_pack(f, (T*)nullptr);
+    }
+}
+
+template <typename T>
+__global__ void unpack_planar_kernel(const T* __restrict__ src, float* __restrict__ dst, long long voxels, int c_dst,
+                                     int c_pad, long long total_vox) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_vox) return;
+    const long long n = i / voxels, v = i - n * voxels;
+    for (int c0 = 0; c0 < c_dst; c0 += ET<T>::EPL) {
+        float f[ET<T>::EPL];
+        frag_unpack(*(const u32x4*)(src + i * c_pad + c0), f, (T*)nullptr);
+#pragma unroll
+        for (int j = 0; j < ET<T>::EPL; ++j)
+            if (c0 + j < c_dst) dst[(n * c_dst + c0 + j) * voxels + v] = f[j];
+    }
+}
+
+extern "C" int vs_pack_planar(const float* src, void* dst, int n, long long voxels, int c_src, int c_pad, int dtype,
+                              void* stream) {
+    if (!src || !dst || n <= 0 || voxels <= 0 || c_src <= 0 || c_src > c_pad || c_pad % 8) return VS_EINVAL;
+    const long long tv = (long long)n * voxels;
+    if (dtype == VS_F32)
+        hipLaunchKernelGGL(pack_planar_kernel<float>, dim3(vs_ceil_div(tv, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                           (float*)dst, voxels, c_src, c_pad, tv);
+    else if (dtype == VS_BF16)
+        hipLaunchKernelGGL(pack_planar_kernel<unsigned short>, dim3(vs_ceil_div(tv, 256)), dim3(256), 0,
+                           (hipStream_t)stream, src, (unsigned short*)dst, voxels, c_src, c_pad, tv);
+    else return VS_EDTYPE;
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_unpack_planar(const void* src, float* dst, int n, long long voxels, int c_dst, int c_pad, int dtype,
+                                void* stream) {
+    if (!src || !dst || n <= 0 || voxels <= 0 || c_dst <= 0 || c_dst > c_pad || c_pad % 8) return VS_EINVAL;
+    const long long tv = (long long)n * voxels;
+    if (dtype == VS_F32)
+        hipLaunchKernelGGL(unpack_planar_kernel<float>, dim3(vs_ceil_div(tv, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)src, dst, voxels, c_dst, c_pad, tv);
+    else if (dtype == VS_BF16)
+        hipLaunchKernelGGL(unpack_planar_kernel<unsigned short>, dim3(vs_ceil_div(tv, 256)), dim3(256), 0,
+                           (hipStream_t)stream, (const unsigned short*)src, dst, voxels, c_dst, c_pad, tv);
+    else return VS_EDTYPE;
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}

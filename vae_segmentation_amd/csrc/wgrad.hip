@@ -1,0 +1,265 @@
+// Weight-gradient kernels for every conv kind:
+//   dW[m][c][tap] = sum_{n,v} actP(P)[n,v,m] * actQ(Q)[n, v*s + off(tap) - p, c]
+// GEMM orientation: D[row = m][col = (tap, c)] += sum_{k = voxel} A[m][k] * B[k][col], on the exact-f32
+// MFMA (v_mfma_f32_16x16x4_f32) for both storage types: with one element per lane per operand the
+// channels-last tiles are consumed as they lie in LDS (no transposition), and fp32 products keep the
+// gradient exact for bf16 activations as well.
+// Each wave accumulates over its share of voxels in registers and writes one partial slab; a second
+// kernel sums the slabs in a fixed order (bitwise reproducible) straight into the reference's
+// [m][c][tap] fp32 layout.
+#include "common.h"
+
+enum { G3_K3 = 0, G3_K2S2 = 1 };
+#define G3_MAXN 16
+
+struct G3Params {
+    const void* P; const double* P_stats;
+    const void* Q; const double* Q_stats;
+    float* ws;
+    int N, Dp, Hp, Wp;        // P grid (the voxel loop runs over it)
+    int Dq, Hq, Wq;           // Q grid
+    int Mch, Cch;             // stored channels of P / Q
+    int mbn, cbn;             // 16-row blocks of m, CB-channel blocks of c
+    int ksplit, total_tiles, tiles_per_sample, tyn, txn;
+    float eps;
+    double inv_cnt_p, inv_cnt_q;
+};
+
+template <int CB, int KIND> struct G3Geo {
+    static constexpr int NTAPS = KIND == G3_K3 ? 27 : 8;
+    static constexpr int NCB = CB == 16 ? NTAPS : (NTAPS + 1) / 2;
+    static constexpr int QZ = KIND == G3_K3 ? 6 : 8, QY = KIND == G3_K3 ? 6 : 8, QX = KIND == G3_K3 ? 18 : 32;
+    static constexpr int QV = QZ * QY * QX;
+};
+
+#define G3_LDS_STATS 0                 // 4 x float[G3_MAXN][16]
+#define G3_LDS_P (4 * G3_MAXN * 16 * 4)
+#define G3_LDS_Q (G3_LDS_P + 256 * 16 * 4)
+
+template <typename T, int CB, int KIND>
+__global__ __launch_bounds__(256) void g3_kernel(const G3Params p) {
+    using GEO = G3Geo<CB, KIND>;
+    constexpr int NTAPS = GEO::NTAPS, NCB = GEO::NCB, QY = GEO::QY, QX = GEO::QX, QV = GEO::QV;
+    constexpr int EPL = ET<T>::EPL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_pm = (float*)(smem + G3_LDS_STATS);
+    float* s_pr = s_pm + G3_MAXN * 16;
+    float* s_qm = s_pr + G3_MAXN * 16;
+    float* s_qr = s_qm + G3_MAXN * 16;
+    float* s_p = (float*)(smem + G3_LDS_P);
+    float* s_q = (float*)(smem + G3_LDS_Q);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
+    const int mb = blockIdx.x / p.cbn, cb = blockIdx.x - mb * p.cbn;
+    const int ks = blockIdx.y;
+    const T* __restrict__ Pp = (const T*)p.P;
+    const T* __restrict__ Qp = (const T*)p.Q;
+    const bool p_stats = p.P_stats != nullptr, q_stats = p.Q_stats != nullptr;
+
+    // mean / rstd tables for this WG's channel blocks, all samples
+    for (int i = tid; i < p.N * 16; i += 256) {
+        const int n = i >> 4, c = i & 15;
+        float m = 0.f, r = 1.f;
+        const int pc = mb * 16 + c;
+        if (p_stats && pc < p.Mch) stats_to_mean_rstd(p.P_stats + ((size_t)n * p.Mch + pc) * 2, p.inv_cnt_p, p.eps, m, r);
+        s_pm[i] = m; s_pr[i] = r;
+        m = 0.f; r = 1.f;
+        const int qc = cb * CB + c;
+        if (q_stats && c < CB && qc < p.Cch) stats_to_mean_rstd(p.Q_stats + ((size_t)n * p.Cch + qc) * 2, p.inv_cnt_q, p.eps, m, r);
+        s_qm[i] = m; s_qr[i] = r;
+    }
+
+    // per-lane B-side tap offsets (in Q-tile voxels) for each column block
+    int qoff[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) {
+        int tap = CB == 16 ? k : 2 * k + (col >> 3);
+        if (tap >= NTAPS) tap = KIND == G3_K3 ? 13 : 0;     // padded column: reads a valid voxel, result discarded
+        int dz, dy, dx;
+        if (KIND == G3_K3) { dz = tap / 9; dy = (tap / 3) % 3; dx = tap % 3; }
+        else { dz = (tap >> 2) & 1; dy = (tap >> 1) & 1; dx = tap & 1; }
+        qoff[k] = (dz * QY + dy) * QX + dx;
+    }
+    const int cq = CB == 16 ? col : (col & 7);
+
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = ks; t < p.total_tiles; t += p.ksplit) {
+        const int n = t / p.tiles_per_sample;
+        const int tl = t - n * p.tiles_per_sample;
+        const int tx = tl % p.txn, ty = (tl / p.txn) % p.tyn, tz = tl / (p.txn * p.tyn);
+        const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+        __syncthreads();      // previous tile fully consumed (also orders the stats tables on the first pass)
+        // ---- stage P: 256 voxels x 16 channels of the m-block, fp32 in LDS ----
+        for (int u = tid; u < 256 * (16 / EPL); u += 256) {
+            const int v = u / (16 / EPL), part = u - v * (16 / EPL);
+            const int lx = v & 15, ly = (v >> 4) & 3, lz = v >> 6;
+            const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+            const int c0 = mb * 16 + part * EPL;
+            float f[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) f[j] = 0.f;
+            if (gz < p.Dp && gy < p.Hp && gx < p.Wp && c0 < p.Mch) {
+                const size_t e = ((((size_t)n * p.Dp + gz) * p.Hp + gy) * p.Wp + gx) * p.Mch + c0;
+                frag_unpack(*(const u32x4*)(Pp + e), f, (T*)nullptr);
+                if (p_stats) {
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) {
+                        const float tt = (f[j] - s_pm[n * 16 + part * EPL + j]) * s_pr[n * 16 + part * EPL + j];
+                        f[j] = tt > 0.f ? tt : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; j += 4)
+                *(f32x4*)(s_p + v * 16 + part * EPL + j) = f32x4{f[j], f[j + 1], f[j + 2], f[j + 3]};
+        }
+        // ---- stage Q: halo (K3) or 2x-upsampled (K2S2) region x CB channels ----
+        for (int u = tid; u < QV * (CB / EPL); u += 256) {
+            const int v = u / (CB / EPL), part = u - v * (CB / EPL);
+            const int lx = v % QX, ly = (v / QX) % QY, lz = v / (QX * QY);
+            int gz, gy, gx;
+            if (KIND == G3_K3) { gz = z0 + lz - 1; gy = y0 + ly - 1; gx = x0 + lx - 1; }
+            else { gz = 2 * z0 + lz; gy = 2 * y0 + ly; gx = 2 * x0 + lx; }
+            const int c0 = cb * CB + part * EPL;
+            float f[EPL];
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) f[j] = 0.f;
+            if (gz >= 0 && gz < p.Dq && gy >= 0 && gy < p.Hq && gx >= 0 && gx < p.Wq && c0 < p.Cch) {
+                const size_t e = ((((size_t)n * p.Dq + gz) * p.Hq + gy) * p.Wq + gx) * p.Cch + c0;
+                frag_unpack(*(const u32x4*)(Qp + e), f, (T*)nullptr);
+                if (q_stats) {
+#pragma unroll
+                    for (int j = 0; j < EPL; ++j) {
+                        const float tt = (f[j] - s_qm[n * 16 + part * EPL + j]) * s_qr[n * 16 + part * EPL + j];
+                        f[j] = tt > 0.f ? tt : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < EPL; j += 4)
+                *(f32x4*)(s_q + v * CB + part * EPL + j) = f32x4{f[j], f[j + 1], f[j + 2], f[j + 3]};
+        }
+        __syncthreads();
+        // ---- 64 voxels of this wave's z-slice, 4 per MFMA step ----
+#pragma unroll 2
+        for (int step = 0; step < 16; ++step) {
+            const int ly = step >> 2, lx = (step & 3) * 4 + g;
+            const float a = s_p[((wave * 4 + ly) * 16 + lx) * 16 + col];
+            int qbase;
+            if (KIND == G3_K3) qbase = ((wave * QY + ly) * QX + lx);
+            else qbase = ((2 * wave * QY + 2 * ly) * QX + 2 * lx);
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) {
+                const float b = s_q[(qbase + qoff[k]) * CB + cq];
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[k], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- partial slab of this wave: [slab][mb*cbn+cb][k][col][row] ----
+    const size_t slab_elems = (size_t)p.mbn * p.cbn * NCB * 256;
+    float* o = p.ws + ((size_t)(ks * 4 + wave)) * slab_elems + ((size_t)blockIdx.x * NCB) * 256 + col * 16 + 4 * g;
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) *(f32x4*)(o + (size_t)k * 256) = acc[k];
+}
+
+template <int CB, int KIND>
+__global__ void g3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int m_real, int c_real, int mbn,
+                                 int cbn, int nslabs) {
+    using GEO = G3Geo<CB, KIND>;
+    constexpr int NTAPS = GEO::NTAPS, NCB = GEO::NCB;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)m_real * c_real * NTAPS;
+    if (i >= total) return;
+    const int tap = (int)(i % NTAPS);
+    const int c = (int)((i / NTAPS) % c_real);
+    const int m = (int)(i / ((long long)NTAPS * c_real));
+    const int mb = m >> 4, row = m & 15;
+    int cb, k, col;
+    if (CB == 16) { cb = c >> 4; col = c & 15; k = tap; }
+    else { cb = c >> 3; col = ((tap & 1) << 3) | (c & 7); k = tap >> 1; }
+    const size_t slab_elems = (size_t)mbn * cbn * NCB * 256;
+    const size_t off = ((size_t)(mb * cbn + cb) * NCB + k) * 256 + col * 16 + row;
+    float s = 0.f;
+    for (int sl = 0; sl < nslabs; ++sl) s += ws[sl * slab_elems + off];
+    dw[i] = s;
+}
+
+static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind, int& cbsz, int& mbn, int& cbn,
+                    int& ncb, int& tiles_per_sample, int& tyn, int& txn, int& ksplit) {
+    cbsz = c_ch >= 16 ? 16 : 8;
+    mbn = (m_ch + 15) / 16;
+    cbn = (c_ch + cbsz - 1) / cbsz;
+    const int ntaps = kind == VS_CONV_K3 ? 27 : 8;
+    ncb = cbsz == 16 ? ntaps : (ntaps + 1) / 2;
+    tyn = (hp + 3) / 4; txn = (wp + 15) / 16;
+    tiles_per_sample = ((dp + 3) / 4) * tyn * txn;
+    const long long total = (long long)tiles_per_sample * n;
+    long long want = (768 + (long long)mbn * cbn - 1) / ((long long)mbn * cbn);   // ~3 WGs per CU overall
+    if (want < 1) want = 1;
+    if (want > total) want = total;
+    // keep the slab workspace <= 64 MiB
+    const double slab_bytes = (double)mbn * cbn * ncb * 256 * 4;
+    while (want > 1 && want * 4 * slab_bytes > 64.0 * 1024 * 1024) --want;
+    ksplit = (int)want;
+}
+
+extern "C" size_t vs_conv_wgrad_workspace_bytes(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind) {
+    int cbsz, mbn, cbn, ncb, tps, tyn, txn, ksplit;
+    g3_plan(n, dp, hp, wp, m_ch, c_ch, kind == VS_CONV_K3 ? VS_CONV_K3 : VS_CONV_K2S2, cbsz, mbn, cbn, ncb, tps, tyn, txn, ksplit);
+    return (size_t)ksplit * 4 * mbn * cbn * ncb * 256 * 4;
+}
+
+template <typename T, int CB, int KIND>
+static int g3_run(const G3Params& p, float* dw, int m_real, int c_real, hipStream_t s) {
+    using GEO = G3Geo<CB, KIND>;
+    constexpr size_t lds = G3_LDS_Q + (size_t)GEO::QV * CB * 4;
+    auto kern = g3_kernel<T, CB, KIND>;
+    if (lds > 64 * 1024) {
+        static const hipError_t attr_err =
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr_err != hipSuccess) return (int)attr_err;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.mbn * p.cbn, p.ksplit), dim3(256), lds, s, p);
+    VS_CHECK_LAUNCH();
+    const long long total = (long long)m_real * c_real * GEO::NTAPS;
+    hipLaunchKernelGGL((g3_reduce_kernel<CB, KIND>), dim3(vs_ceil_div(total, 256)), dim3(256), 0, s, p.ws, dw, m_real,
+                       c_real, p.mbn, p.cbn, p.ksplit * 4);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_conv_wgrad(const void* P, const double* p_stats, const void* Q, const double* q_stats, float* dw,
+                             void* workspace, size_t workspace_bytes, int n, int dp, int hp, int wp, int m_ch, int c_ch,
+                             int m_real, int c_real, int kind, int dtype, float eps, void* stream) {
+    if (!P || !Q || !dw || !workspace) return VS_EINVAL;
+    if (n <= 0 || n > G3_MAXN || dp <= 0 || hp <= 0 || wp <= 0) return VS_ESHAPE;
+    if (m_ch % 8 || c_ch % 8 || m_real > m_ch || c_real > c_ch || m_real <= 0 || c_real <= 0) return VS_ESHAPE;
+    if (kind != VS_CONV_K3 && kind != VS_CONV_K2S2) return VS_EINVAL;
+    if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
+    G3Params p{};
+    int cbsz, ncb;
+    g3_plan(n, dp, hp, wp, m_ch, c_ch, kind, cbsz, p.mbn, p.cbn, ncb, p.tiles_per_sample, p.tyn, p.txn, p.ksplit);
+    const size_t need = (size_t)p.ksplit * 4 * p.mbn * p.cbn * ncb * 256 * 4;
+    if (workspace_bytes < need) return VS_EWORKSPACE;
+    p.P = P; p.P_stats = p_stats; p.Q = Q; p.Q_stats = q_stats; p.ws = (float*)workspace;
+    p.N = n; p.Dp = dp; p.Hp = hp; p.Wp = wp;
+    const int s = kind == VS_CONV_K3 ? 1 : 2;
+    p.Dq = dp * s; p.Hq = hp * s; p.Wq = wp * s;
+    p.Mch = m_ch; p.Cch = c_ch;
+    p.total_tiles = p.tiles_per_sample * n;
+    p.eps = eps;
+    p.inv_cnt_p = 1.0 / ((double)dp * hp * wp);
+    p.inv_cnt_q = 1.0 / ((double)p.Dq * p.Hq * p.Wq);
+    hipStream_t st = (hipStream_t)stream;
+#define G3_GO(T) \
+    if (kind == VS_CONV_K3) return cbsz == 16 ? g3_run<T, 16, G3_K3>(p, dw, m_real, c_real, st) : g3_run<T, 8, G3_K3>(p, dw, m_real, c_real, st); \
+    return cbsz == 16 ? g3_run<T, 16, G3_K2S2>(p, dw, m_real, c_real, st) : g3_run<T, 8, G3_K2S2>(p, dw, m_real, c_real, st);
+    if (dtype == VS_F32) { G3_GO(float) }
+    G3_GO(unsigned short)
+#undef G3_GO
+}
+

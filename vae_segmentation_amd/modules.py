@@ -1,0 +1,289 @@
+"""The nn.Module surface of the reference's joint_model.py, executed by the libvaeseg HIP kernels.
+
+Class names, constructor / forward signatures, attribute names (``.Seg`` / ``.Vae``, ``in_block``, ``down1`` ...) and
+state_dict keys / shapes follow /root/reference/joint_model.py (cited per class) so checkpoints and the
+main_source.py / main_target.py loops keep working.  Parameters live in ordinary ``nn.Conv3d`` /
+``nn.ConvTranspose3d`` / ``nn.Linear`` holders placed at the same Sequential indices as in the reference
+(InstanceNorm3d / ReLU entries are parameter-less there too), but ``forward`` never calls those holders:
+it launches the fused kernels through ``ops``.  There is no CPU path — inputs must be CUDA tensors.
+
+Only the configuration every entry point of the reference uses is implemented natively: ``norm_type=1``
+(InstanceNorm3d), ReLU (``soft=False``), two classes.  Other settings raise NotImplementedError.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+_DEFAULT_DTYPE = torch.float32
+
+
+def set_default_kernel_dtype(dtype):
+    """fp32 (parity mode, exact-f32 MFMA) or bf16 (throughput mode, fp32 accumulate)."""
+    global _DEFAULT_DTYPE
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("kernel dtype must be torch.float32 or torch.bfloat16")
+    _DEFAULT_DTYPE = dtype
+
+
+def set_kernel_dtype(module, dtype):
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("kernel dtype must be torch.float32 or torch.bfloat16")
+    for m in module.modules():
+        if hasattr(m, "kernel_dtype"):
+            m.kernel_dtype = dtype
+    return module
+
+
+class Act:
+    """A channels-last activation travelling between blocks: ``raw`` (N,D,H,W,C) and, when the
+    InstanceNorm+ReLU that follows its producer has not been applied yet, the producer's ``stats``."""
+    __slots__ = ("raw", "stats")
+
+    def __init__(self, raw, stats=None):
+        self.raw, self.stats = raw, stats
+
+
+def Normalization(norm_type, out_channels, num_group=1):
+    """joint_model.py:9-15 — parameter-less holder kept for Sequential index / repr parity."""
+    if norm_type == 1:
+        return nn.InstanceNorm3d(out_channels)
+    raise NotImplementedError("native kernels implement norm_type=1 (InstanceNorm3d), the only value the "
+                              "reference's entry points use (main_source.py:250-272, main_target.py:317-342)")
+
+
+def _check_soft(soft):
+    if soft:
+        raise NotImplementedError("Softplus variant (soft=True) has no native kernel; every entry point passes soft=False")
+
+
+def _as_act(x, dtype):
+    """Accept a planar NCDHW tensor at a block boundary (tests / ad-hoc use) or an Act."""
+    if isinstance(x, Act):
+        return x, False
+    ops._require_cuda(x)
+    return Act(ops.PackPlanar.apply(x, dtype), None), True
+
+
+def _as_tensor(a, channels):
+    return ops.UnpackPlanar.apply(ops.Materialize.apply(a.raw, a.stats, None, None), channels)
+
+
+def _conv3(conv, a):
+    y, ys = ops.ConvK3.apply(a.raw, a.stats, conv.weight, conv.bias)
+    return Act(y, ys)
+
+
+class DoubleConv(nn.Module):
+    """joint_model.py:35-52 — three (conv3x3x3 -> norm -> act) triples, Sequential indices 0..8."""
+
+    def __init__(self, in_ch, out_ch, norm_type=2, soft=False):
+        super().__init__()
+        _check_soft(soft)
+        layers = []
+        for cin in (in_ch, out_ch, out_ch):
+            layers += [nn.Conv3d(cin, out_ch, 3, padding=1), Normalization(norm_type, out_ch), nn.ReLU(inplace=False)]
+        self.conv = nn.Sequential(*layers)
+        self.out_ch = out_ch
+        self.kernel_dtype = _DEFAULT_DTYPE
+
+    def forward(self, x):
+        a, wrapped = _as_act(x, self.kernel_dtype)
+        for i in (0, 3, 6):
+            a = _conv3(self.conv[i], a)
+        return _as_tensor(a, self.out_ch) if wrapped else a
+
+
+class Conv(nn.Module):
+    """joint_model.py:101-112 — conv3x3x3 -> norm -> ReLU."""
+
+    def __init__(self, in_ch, out_ch, norm_type=2, num_group=1, activation=True, norm=True, soft=False):
+        super().__init__()
+        _check_soft(soft)
+        self.conv = nn.Sequential(nn.Conv3d(in_ch, out_ch, 3, padding=1), Normalization(norm_type, out_ch),
+                                  nn.ReLU(inplace=True))
+        self.out_ch = out_ch
+        self.kernel_dtype = _DEFAULT_DTYPE
+
+    def forward(self, x):
+        a, wrapped = _as_act(x, self.kernel_dtype)
+        a = _conv3(self.conv[0], a)
+        return _as_tensor(a, self.out_ch) if wrapped else a
+
+
+class Up(nn.Module):
+    """joint_model.py:114-124 — ConvTranspose3d(in,in,2,2) -> DoubleConv(in,out)."""
+
+    def __init__(self, in_ch, out_ch, norm_type=2, kernal_size=(2, 2, 2), stride=(2, 2, 2), soft=False):
+        super().__init__()
+        if tuple(kernal_size) != (2, 2, 2) or tuple(stride) != (2, 2, 2):
+            raise NotImplementedError("native transposed conv is written for kernel 2, stride 2")
+        self.conv = nn.Sequential(nn.ConvTranspose3d(in_ch, in_ch, kernal_size, stride=stride, padding=0),
+                                  DoubleConv(in_ch, out_ch, norm_type, soft=False))
+        self.out_ch = out_ch
+        self.kernel_dtype = _DEFAULT_DTYPE
+
+    def forward(self, x):
+        a, wrapped = _as_act(x, self.kernel_dtype)
+        t = self.conv[0]
+        a = self.conv[1](Act(ops.ConvT2S2.apply(a.raw, a.stats, t.weight, t.bias), None))
+        return _as_tensor(a, self.out_ch) if wrapped else a
+
+
+class Down(nn.Module):
+    """joint_model.py:126-136 — Conv3d(in,in,2,stride 2) -> DoubleConv(in,out)."""
+
+    def __init__(self, in_ch, out_ch, norm_type=2, kernal_size=(2, 2, 2), stride=(2, 2, 2), soft=False):
+        super().__init__()
+        if tuple(kernal_size) != (2, 2, 2) or tuple(stride) != (2, 2, 2):
+            raise NotImplementedError("native strided conv is written for kernel 2, stride 2")
+        self.conv = nn.Sequential(nn.Conv3d(in_ch, in_ch, kernal_size, stride=stride, padding=0),
+                                  DoubleConv(in_ch, out_ch, norm_type, soft=False))
+        self.out_ch = out_ch
+        self.kernel_dtype = _DEFAULT_DTYPE
+
+    def forward(self, x):
+        a, wrapped = _as_act(x, self.kernel_dtype)
+        c = self.conv[0]
+        a = self.conv[1](Act(ops.ConvK2S2.apply(a.raw, a.stats, c.weight, c.bias), None))
+        return _as_tensor(a, self.out_ch) if wrapped else a
+
+
+def _no_dropout(p, where):
+    if p:
+        raise NotImplementedError("%s: dropout > 0 has no native kernel yet (the reference defaults are 0: "
+                                  "main_target.py:70-71)" % where)
+
+
+class VAE(nn.Module):
+    """joint_model.py:204-272.  ``spatial`` generalises the reference's hard-wired 128^3 input
+    (Linear(16384, dim), view(B,256,4,4,4)); the default reproduces the reference state_dict exactly.
+    ``noise`` (optional, (B, dim)) replaces the reference's CPU torch.randn draw (joint_model.py:246)."""
+
+    def __init__(self, n_channels, n_class, norm_type=2, n_fmaps=[8, 16, 32, 64, 128, 256], dim=1024, soft=False,
+                 spatial=128):
+        super().__init__()
+        if n_class != 2:
+            raise NotImplementedError("native softmax / label kernels are written for n_class == 2")
+        if spatial % 32 or spatial < 64:
+            raise ValueError("spatial must be a multiple of 32 and >= 64 (InstanceNorm needs > 1 voxel at down5)")
+        f = list(n_fmaps)
+        self.in_block = Conv(n_class, f[0], norm_type=norm_type, soft=False)
+        self.down1 = Down(f[0], f[1], norm_type=norm_type, soft=False)
+        self.down2 = Down(f[1], f[2], norm_type=norm_type, soft=False)
+        self.down3 = Down(f[2], f[3], norm_type=norm_type, soft=False)
+        self.down4 = Down(f[3], f[4], norm_type=norm_type, soft=False)
+        self.down5 = Down(f[4], f[5], norm_type=norm_type, soft=False)
+        self.side = spatial // 32
+        self.top_ch = f[5]
+        flat = f[5] * self.side ** 3
+        self.fc_mean = nn.Linear(flat, dim)
+        self.fc_std = nn.Linear(flat, dim)
+        self.fc2 = nn.Linear(dim, flat)
+        self.up1 = Up(f[5], f[4], norm_type=norm_type, soft=False)
+        self.up2 = Up(f[4], f[3], norm_type=norm_type, soft=False)
+        self.up3 = Up(f[3], f[2], norm_type=norm_type, soft=False)
+        self.up4 = Up(f[2], f[1], norm_type=norm_type, soft=False)
+        self.up5 = Up(f[1], f[0], norm_type=norm_type, soft=False)
+        self.out_block = nn.Conv3d(f[0], n_class, 3, padding=1)
+        self.final = nn.Softmax(dim=1)
+        self.n_class = n_class
+        self.spatial = spatial
+        self.kernel_dtype = _DEFAULT_DTYPE
+
+    def forward(self, x, if_random=False, scale=1, mid_input=False, dropout=0.0, noise=None):
+        _no_dropout(dropout, "VAE.forward")
+        ops._require_cuda(x)
+        if not mid_input:
+            if x.shape[-1] != self.spatial:
+                raise ValueError("VAE built for spatial=%d got input side %d" % (self.spatial, x.shape[-1]))
+            a = Act(ops.PackPlanar.apply(x, self.kernel_dtype), None)
+            a = self.in_block(a)
+            for blk in (self.down1, self.down2, self.down3, self.down4, self.down5):
+                a = blk(a)
+            feat = ops.Materialize.apply(a.raw, a.stats, None, None)
+            x_mean = ops.LinearCL.apply(feat, self.fc_mean.weight, self.fc_mean.bias, False)
+            x_std = ops.LinearCL.apply(feat, self.fc_std.weight, self.fc_std.bias, True)
+            if if_random:
+                if noise is None:
+                    noise = torch.randn(x_mean.shape, device=x_mean.device, dtype=torch.float32)
+                z = ops.Reparam.apply(x_mean, x_std, noise.to(x_mean.device, torch.float32).contiguous(), scale)
+            else:
+                z = x_mean
+        else:
+            z = x
+        h = ops.LinearToCL.apply(z, self.fc2.weight, self.fc2.bias, self.top_ch, self.side, self.kernel_dtype)
+        a = Act(h, None)
+        for blk in (self.up1, self.up2, self.up3, self.up4, self.up5):
+            a = blk(a)
+        recon = ops.ConvK3Softmax.apply(a.raw, a.stats, self.out_block.weight, self.out_block.bias)
+        if not mid_input:
+            return recon, x_mean, x_std
+        return recon
+
+
+class Segmentation(nn.Module):
+    """joint_model.py:349-390 — U-Net with additive skips at up3 / up4, dict-in / dict-out."""
+
+    def __init__(self, n_channels, n_class, norm_type=2, n_fmaps=[8, 16, 32, 64, 128, 256]):
+        super().__init__()
+        if n_class != 2:
+            raise NotImplementedError("native softmax / label kernels are written for n_class == 2")
+        f = list(n_fmaps)
+        self.in_block = Conv(n_channels, f[0], norm_type=norm_type, soft=False)
+        self.down1 = Down(f[0], f[1], norm_type=norm_type, soft=False)
+        self.down2 = Down(f[1], f[2], norm_type=norm_type, soft=False)
+        self.down3 = Down(f[2], f[3], norm_type=norm_type, soft=False)
+        self.down4 = Down(f[3], f[4], norm_type=norm_type, soft=False)
+        self.up2 = Up(f[4], f[3], norm_type=norm_type, soft=False)
+        self.up3 = Up(f[3], f[2], norm_type=norm_type, soft=False)
+        self.up4 = Up(f[2], f[1], norm_type=norm_type, soft=False)
+        self.up5 = Up(f[1], f[0], norm_type=norm_type, soft=False)
+        self.out_block = nn.Conv3d(f[0], n_class, 3, padding=1)
+        self.final = nn.Softmax(dim=1)
+        self.n_class = n_class
+        self.kernel_dtype = _DEFAULT_DTYPE
+
+    def forward(self, data_dict, in_key, out_key, dropout=0.0):
+        _no_dropout(dropout, "Segmentation.forward")
+        x = data_dict[in_key]
+        ops._require_cuda(x)
+        if any(s % 16 for s in x.shape[2:]):
+            raise ValueError("Segmentation needs spatial sizes that are multiples of 16, got %s" % (tuple(x.shape[2:]),))
+        a = Act(ops.PackPlanar.apply(x, self.kernel_dtype), None)
+        x1 = self.in_block(a)
+        x2 = self.down1(x1)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        x5 = self.down4(x4)
+        u = self.up2(x5)
+        u = self.up3(u)
+        u = Act(ops.Materialize.apply(u.raw, u.stats, x3.raw, x3.stats), None)
+        u = self.up4(u)
+        u = Act(ops.Materialize.apply(u.raw, u.stats, x2.raw, x2.stats), None)
+        u = self.up5(u)
+        data_dict[out_key] = ops.ConvK3Softmax.apply(u.raw, u.stats, self.out_block.weight, self.out_block.bias)
+        return data_dict
+
+
+class Joint(nn.Module):
+    """joint_model.py:438-452."""
+
+    def __init__(self, models, vae_forward_scale=0.0, vae_decoder_dropout=0.0, seg_dropout=0.0):
+        super().__init__()
+        self.Seg = models[0]
+        self.Vae = models[1]
+        self.vae_forward_scale = vae_forward_scale
+        self.vae_decoder_dropout = vae_decoder_dropout
+        self.seg_dropout = seg_dropout
+
+    def forward(self, data_dict, in_key, out_key, out_key_recon, dropout=False):
+        if dropout:
+            data_dict = self.Seg(data_dict, in_key, out_key, dropout=self.seg_dropout)
+            data_dict[out_key_recon], _, _ = self.Vae(data_dict[out_key], if_random=False, scale=self.vae_forward_scale,
+                                                      dropout=self.vae_decoder_dropout)
+        else:
+            data_dict = self.Seg(data_dict, in_key, out_key)
+            data_dict[out_key_recon], data_dict["mean"], data_dict["std"] = self.Vae(
+                data_dict[out_key], if_random=False, scale=self.vae_forward_scale)
+        return data_dict

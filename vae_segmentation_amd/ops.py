@@ -1,0 +1,566 @@
+"""torch.autograd.Function wrappers around the libvaeseg C ABI (include/vaeseg.h).
+
+PyTorch supplies device memory, streams and the autograd graph; every byte of arithmetic on the hot path
+is done by the HIP kernels.  Nothing here has a CPU path: tensors must live on the GPU.
+
+Internal activations are channels-last ``(N, D, H, W, C)`` tensors in the kernel dtype (fp32 or bf16).
+A *lazy* activation is the pair ``(raw, stats)``: ``raw`` is a conv output before InstanceNorm+ReLU and
+``stats`` the fp64 ``(N, C, 2)`` (sum, sumsq) its producer accumulated; consumers normalise on load.
+For autograd, ``stats`` is a non-differentiable side output and the gradient attached to ``raw`` is the
+total derivative (the InstanceNorm+ReLU backward is applied by the consumer's backward).
+"""
+import torch
+
+from . import _lib
+from ._lib import (VS_BF16, VS_CONV_K2S2, VS_CONV_K3, VS_F32, VS_PACK_ROWS_D0, VS_PACK_ROWS_D1_FLIP,
+                   VS_PACK_SCATTER_D1, check, lib)
+
+EPS_IN = 1e-5       # nn.InstanceNorm3d default eps (joint_model.py:11)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def vs_dtype(t):
+    if t.dtype == torch.float32:
+        return VS_F32
+    if t.dtype == torch.bfloat16:
+        return VS_BF16
+    raise TypeError("kernel dtype must be float32 or bfloat16, got %s" % t.dtype)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vae_segmentation_amd runs on the GPU only (libvaeseg HIP kernels); "
+                               "got a CPU tensor — there is no CPU fallback")
+
+
+def cpad(c):
+    if c <= 8:
+        return 8
+    if c <= 16:
+        return 16
+    return (c + 31) // 32 * 32
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packing (fragment order); frozen weights are packed once and cached
+# ------------------------------------------------------------------------------------------------
+_PACK_CACHE = {}
+
+
+def pack_weight(w, form, c_pad, dtype):
+    """w: (d0, d1, k, k, k) fp32 parameter -> uint8 buffer holding the MFMA-fragment image."""
+    _require_cuda(w)
+    w = w.detach()
+    if not w.is_contiguous():
+        w = w.contiguous()
+    d0, d1 = w.shape[0], w.shape[1]
+    ntaps = w[0, 0].numel()
+    dt = VS_F32 if dtype == torch.float32 else VS_BF16
+    if form == VS_PACK_ROWS_D0:
+        rows, gemm_taps = d0, ntaps
+    elif form == VS_PACK_ROWS_D1_FLIP:
+        rows, gemm_taps = d1, ntaps
+    else:
+        rows, gemm_taps = ntaps * d1, 1
+    nbytes = lib.vs_packed_weight_bytes(rows, c_pad, gemm_taps, dt)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(lib.vs_pack_weight(w.data_ptr(), buf.data_ptr(), d0, d1, ntaps, c_pad, form, dt, _stream()), "pack_weight")
+    return buf
+
+
+def pack_weight_cached(param, form, c_pad, dtype):
+    """Frozen parameters (requires_grad False) are packed once per (storage, version)."""
+    if param.requires_grad:
+        return pack_weight(param, form, c_pad, dtype)
+    dt = VS_F32 if dtype == torch.float32 else VS_BF16
+    key = (param.data_ptr(), param._version, tuple(param.shape), form, c_pad, dt)
+    hit = _PACK_CACHE.get(key)
+    if hit is None:
+        hit = pack_weight(param, form, c_pad, dtype)
+        if len(_PACK_CACHE) > 4096:
+            _PACK_CACHE.clear()
+        _PACK_CACHE[key] = hit
+    return hit
+
+
+def clear_pack_cache():
+    _PACK_CACHE.clear()
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launch helpers (no autograd)
+# ------------------------------------------------------------------------------------------------
+def _new_stats(n, c, device):
+    return torch.zeros(n, c, 2, dtype=torch.float64, device=device)
+
+
+def conv_gather(x, xs, wp, bias, m_out, kind, want_stats):
+    n, d, h, w, c = x.shape
+    if kind == VS_CONV_K2S2:
+        out_shape = (n, d // 2, h // 2, w // 2, m_out)
+    else:
+        out_shape = (n, d, h, w, m_out)
+    y = torch.empty(out_shape, dtype=x.dtype, device=x.device)
+    ys = _new_stats(n, m_out, x.device) if want_stats else None
+    check(lib.vs_conv_gather_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), y.data_ptr(), _p(ys), n, d, h, w, c,
+                                 m_out, kind, vs_dtype(x), EPS_IN, _stream()), "conv_gather_fwd")
+    return y, ys
+
+
+def conv_scatter(x, xs, wp, bias, m_out):
+    n, d, h, w, c = x.shape
+    y = torch.empty((n, 2 * d, 2 * h, 2 * w, m_out), dtype=x.dtype, device=x.device)
+    check(lib.vs_conv_scatter_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), y.data_ptr(), n, d, h, w, c, m_out,
+                                  vs_dtype(x), EPS_IN, _stream()), "conv_scatter_fwd")
+    return y
+
+
+def conv_wgrad(p, ps, q, qs, m_real, c_real, kind, out_shape):
+    """dW (fp32, reference layout [m][c][taps]) ; the voxel loop runs over p's grid."""
+    n, dp, hp, wp_, m_ch = p.shape
+    c_ch = q.shape[-1]
+    nbytes = lib.vs_conv_wgrad_workspace_bytes(n, dp, hp, wp_, m_ch, c_ch, kind)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
+    dw = torch.empty(out_shape, dtype=torch.float32, device=p.device)
+    check(lib.vs_conv_wgrad(p.data_ptr(), _p(ps), q.data_ptr(), _p(qs), dw.data_ptr(), ws.data_ptr(), nbytes, n, dp, hp,
+                            wp_, m_ch, c_ch, m_real, c_real, kind, vs_dtype(p), EPS_IN, _stream()), "conv_wgrad")
+    return dw
+
+
+def bias_grad(g, c_real):
+    c_ch = g.shape[-1]
+    rows = g.numel() // c_ch
+    db = torch.empty(c_real, dtype=torch.float32, device=g.device)
+    check(lib.vs_bias_grad(g.data_ptr(), db.data_ptr(), rows, c_ch, c_real, vs_dtype(g), _stream()), "bias_grad")
+    return db
+
+
+def in_relu_bwd(g, x, xs, inplace=True):
+    """gradient w.r.t. the raw tensor x of a = relu(instnorm(x)), given g = dL/da (same layout)."""
+    if xs is None:
+        return g
+    n, c = x.shape[0], x.shape[-1]
+    voxels = x.numel() // (n * c)
+    sums = _new_stats(n, c, x.device)
+    dt = vs_dtype(x)
+    check(lib.vs_instnorm_relu_bwd_reduce(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), n, voxels, c, dt,
+                                          EPS_IN, _stream()), "instnorm_relu_bwd_reduce")
+    gx = g if inplace else torch.empty_like(g)
+    check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), gx.data_ptr(), n,
+                                         voxels, c, dt, EPS_IN, _stream()), "instnorm_relu_bwd_apply")
+    return gx
+
+
+def _contig(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions
+# ------------------------------------------------------------------------------------------------
+class ConvK3(torch.autograd.Function):
+    """3x3x3 conv (pad 1) on a lazy input; output is lazy (raw + stats) — joint_model.py:40-48,106-108.
+    The bias of a conv that feeds InstanceNorm is mathematically dead: it is neither added
+    nor differentiated (its gradient is returned as zeros, the reference's is ~1e-7 noise)."""
+
+    @staticmethod
+    def forward(ctx, x, xs, weight, bias):
+        _require_cuda(x, weight)
+        cout, cin = weight.shape[0], weight.shape[1]
+        wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, x.shape[-1], x.dtype)
+        y, ys = conv_gather(x, xs, wp, None, cpad(cout), VS_CONV_K3, True)
+        ctx.save_for_backward(x, xs, weight)
+        ctx.has_bias = bias is not None
+        ctx.bias_shape = None if bias is None else bias.shape
+        ctx.mark_non_differentiable(ys)
+        return y, ys
+
+    @staticmethod
+    def backward(ctx, gy, _gys):
+        x, xs, weight = ctx.saved_tensors
+        gy = _contig(gy)
+        cout, cin = weight.shape[0], weight.shape[1]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, gy.shape[-1], gy.dtype)
+            ga, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K3, False)
+            gx = in_relu_bwd(ga, x, xs)
+        if ctx.needs_input_grad[2]:
+            gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K3, weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gb = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=gy.device)
+        return gx, None, gw, gb
+
+
+class ConvK3Softmax(torch.autograd.Function):
+    """out_block (3x3x3 conv, live bias) + Softmax(dim=1) over 2 classes -> planar fp32 probabilities
+    (joint_model.py:224-225,265-266 / 366-367,386-388)."""
+
+    @staticmethod
+    def forward(ctx, x, xs, weight, bias):
+        _require_cuda(x, weight)
+        if weight.shape[0] != 2:
+            raise NotImplementedError("fused out_block+softmax kernel is written for n_class == 2")
+        n, d, h, w, c = x.shape
+        wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, c, x.dtype)
+        prob = torch.empty((n, 2, d, h, w), dtype=torch.float32, device=x.device)
+        check(lib.vs_conv_k3_softmax2_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), prob.data_ptr(), n, d, h, w, c,
+                                          vs_dtype(x), EPS_IN, _stream()), "conv_k3_softmax2_fwd")
+        ctx.save_for_backward(x, xs, weight, prob)
+        ctx.has_bias = bias is not None
+        return prob
+
+    @staticmethod
+    def backward(ctx, gprob):
+        x, xs, weight, prob = ctx.saved_tensors
+        n, d, h, w, c = x.shape
+        gprob = _contig(gprob.float())
+        gl = torch.empty((n, d, h, w, 8), dtype=x.dtype, device=x.device)
+        check(lib.vs_softmax2_bwd(prob.data_ptr(), gprob.data_ptr(), gl.data_ptr(), n, d * h * w, 8, vs_dtype(x),
+                                  _stream()), "softmax2_bwd")
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, x.dtype)
+            ga, _ = conv_gather(gl, None, wpb, None, c, VS_CONV_K3, False)
+            gx = in_relu_bwd(ga, x, xs)
+        if ctx.needs_input_grad[2]:
+            gw = conv_wgrad(gl, None, x, xs, 2, weight.shape[1], VS_CONV_K3, weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gb = bias_grad(gl, 2)
+        return gx, None, gw, gb
+
+
+class ConvK2S2(torch.autograd.Function):
+    """Conv3d(C, C, 2, stride 2) with live bias on a lazy input; output is final (feeds a conv directly)
+    — joint_model.py:130."""
+
+    @staticmethod
+    def forward(ctx, x, xs, weight, bias):
+        _require_cuda(x, weight)
+        wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, x.shape[-1], x.dtype)
+        y, _ = conv_gather(x, xs, wp, bias, cpad(weight.shape[0]), VS_CONV_K2S2, False)
+        ctx.save_for_backward(x, xs, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, xs, weight = ctx.saved_tensors
+        gy = _contig(gy)
+        cout, cin = weight.shape[0], weight.shape[1]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wpb = pack_weight_cached(weight, VS_PACK_SCATTER_D1, gy.shape[-1], gy.dtype)
+            ga = conv_scatter(gy, None, wpb, None, x.shape[-1])
+            gx = in_relu_bwd(ga, x, xs)
+        if ctx.needs_input_grad[2]:
+            gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K2S2, weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gb = bias_grad(gy, cout)
+        return gx, None, gw, gb
+
+
+class ConvT2S2(torch.autograd.Function):
+    """ConvTranspose3d(C, C, 2, stride 2) with live bias on a lazy input; final output — joint_model.py:118."""
+
+    @staticmethod
+    def forward(ctx, x, xs, weight, bias):
+        _require_cuda(x, weight)
+        wp = pack_weight_cached(weight, VS_PACK_SCATTER_D1, x.shape[-1], x.dtype)
+        y = conv_scatter(x, xs, wp, bias, cpad(weight.shape[1]))
+        ctx.save_for_backward(x, xs, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, xs, weight = ctx.saved_tensors
+        gy = _contig(gy)
+        cin, cout = weight.shape[0], weight.shape[1]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wpb = pack_weight_cached(weight, VS_PACK_ROWS_D0, gy.shape[-1], gy.dtype)
+            ga, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K2S2, False)
+            gx = in_relu_bwd(ga, x, xs)
+        if ctx.needs_input_grad[2]:
+            gw = conv_wgrad(x, xs, gy, None, cin, cout, VS_CONV_K2S2, weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gb = bias_grad(gy, cout)
+        return gx, None, gw, gb
+
+
+class Materialize(torch.autograd.Function):
+    """(raw, stats) [+ (raw2, stats2)] -> relu(instnorm(raw)) [+ relu(instnorm(raw2))] as a final tensor.
+    With two operands this is the additive U-Net skip (joint_model.py:380,382)."""
+
+    @staticmethod
+    def forward(ctx, x, xs, x2, x2s):
+        _require_cuda(x)
+        n, c = x.shape[0], x.shape[-1]
+        voxels = x.numel() // (n * c)
+        out = torch.empty_like(x)
+        check(lib.vs_instnorm_relu_fwd(x.data_ptr(), _p(xs), _p(x2), _p(x2s), out.data_ptr(), n, voxels, c, vs_dtype(x),
+                                       EPS_IN, _stream()), "instnorm_relu_fwd")
+        ctx.save_for_backward(x, xs, x2, x2s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xs, x2, x2s = ctx.saved_tensors
+        g = _contig(g)
+        g1 = g2 = None
+        if ctx.needs_input_grad[0]:
+            g1 = in_relu_bwd(g, x, xs, inplace=False) if xs is not None else g
+        if x2 is not None and ctx.needs_input_grad[2]:
+            g2 = in_relu_bwd(g, x2, x2s, inplace=False) if x2s is not None else g
+        return g1, None, g2, None
+
+
+class PackPlanar(torch.autograd.Function):
+    """planar fp32 (N, C, D, H, W) -> channels-last (N, D, H, W, 8) in the kernel dtype (zero padded)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _require_cuda(x)
+        x = _contig(x.float())
+        n, c, d, h, w = x.shape
+        out = torch.empty((n, d, h, w, cpad(c)), dtype=dtype, device=x.device)
+        check(lib.vs_pack_planar(x.data_ptr(), out.data_ptr(), n, d * h * w, c, cpad(c), vs_dtype(out), _stream()),
+              "pack_planar")
+        ctx.c = c
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _contig(g)
+        n, d, h, w, cp = g.shape
+        out = torch.empty((n, ctx.c, d, h, w), dtype=torch.float32, device=g.device)
+        check(lib.vs_unpack_planar(g.data_ptr(), out.data_ptr(), n, d * h * w, ctx.c, cp, vs_dtype(g), _stream()),
+              "unpack_planar")
+        return out, None
+
+
+class UnpackPlanar(torch.autograd.Function):
+    """channels-last (N, D, H, W, Cp) -> planar fp32 (N, C, D, H, W), C <= Cp."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        _require_cuda(x)
+        x = _contig(x)
+        n, d, h, w, cp = x.shape
+        out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=x.device)
+        check(lib.vs_unpack_planar(x.data_ptr(), out.data_ptr(), n, d * h * w, c, cp, vs_dtype(x), _stream()), "unpack_planar")
+        ctx.meta = (cp, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cp, dtype = ctx.meta
+        g = _contig(g.float())
+        n, c, d, h, w = g.shape
+        out = torch.empty((n, d, h, w, cp), dtype=dtype, device=g.device)
+        check(lib.vs_pack_planar(g.data_ptr(), out.data_ptr(), n, d * h * w, c, cp, vs_dtype(out), _stream()), "pack_planar")
+        return out, None
+
+
+class LinearCL(torch.autograd.Function):
+    """y = act(W x + b) where x is a channels-last activation read in the reference's NCDHW flatten order
+    (joint_model.py:241-243).  y is fp32 (B, J)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        _require_cuda(x, weight)
+        n, d, h, w, c = x.shape
+        k_in, j_out = c * d * h * w, weight.shape[0]
+        y = torch.empty((n, j_out), dtype=torch.float32, device=x.device)
+        check(lib.vs_linear_fwd(x.data_ptr(), vs_dtype(x), weight.data_ptr(), _p(bias), y.data_ptr(), n, k_in, j_out, c,
+                                d * h * w, 1 if relu else 0, _stream()), "linear_fwd")
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, yrelu = ctx.saved_tensors
+        gy = _contig(gy.float())
+        n, d, h, w, c = x.shape
+        k_in, j_out = c * d * h * w, weight.shape[0]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        gb = torch.empty(j_out, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        check(lib.vs_linear_bwd(x.data_ptr(), vs_dtype(x), weight.data_ptr(), gy.data_ptr(), _p(yrelu), _p(gx), _p(gw),
+                                _p(gb), n, k_in, j_out, c, d * h * w, _stream()), "linear_bwd")
+        return gx, gw, gb, None
+
+
+class LinearToCL(torch.autograd.Function):
+    """fc2 (joint_model.py:248-253): fp32 latent (B, K) -> channels-last activation (B, s, s, s, C) holding
+    view(B, C, s, s, s) of the reference's output."""
+
+    @staticmethod
+    def forward(ctx, z, weight, bias, c, side, dtype):
+        _require_cuda(z, weight)
+        z = _contig(z.float())
+        b, k_in = z.shape
+        j_out = weight.shape[0]
+        y = torch.empty((b, side, side, side, c), dtype=dtype, device=z.device)
+        check(lib.vs_linear_fwd_perm_out(z.data_ptr(), weight.data_ptr(), _p(bias), y.data_ptr(), vs_dtype(y), b, k_in,
+                                         j_out, c, side ** 3, _stream()), "linear_fwd_perm_out")
+        ctx.save_for_backward(z, weight)
+        ctx.has_bias = bias is not None
+        ctx.geom = (c, side)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        z, weight = ctx.saved_tensors
+        gy = _contig(gy)
+        c, side = ctx.geom
+        b, k_in = z.shape
+        j_out = weight.shape[0]
+        gz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
+        gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        gb = torch.empty(j_out, dtype=torch.float32, device=z.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        check(lib.vs_linear_perm_out_bwd(z.data_ptr(), weight.data_ptr(), gy.data_ptr(), vs_dtype(gy), _p(gz), _p(gw),
+                                         _p(gb), b, k_in, j_out, c, side ** 3, _stream()), "linear_perm_out_bwd")
+        return gz, gw, gb, None, None, None
+
+
+class Reparam(torch.autograd.Function):
+    """z = mean + noise * std * scale (joint_model.py:248)."""
+
+    @staticmethod
+    def forward(ctx, mean, std, noise, scale):
+        _require_cuda(mean, std, noise)
+        z = torch.empty_like(mean)
+        check(lib.vs_reparam_fwd(mean.data_ptr(), std.data_ptr(), noise.data_ptr(), float(scale), z.data_ptr(),
+                                 mean.numel(), _stream()), "reparam_fwd")
+        ctx.save_for_backward(noise)
+        ctx.scale = float(scale)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        (noise,) = ctx.saved_tensors
+        gz = _contig(gz)
+        gm = torch.empty_like(gz) if ctx.needs_input_grad[0] else None
+        gs = torch.empty_like(gz) if ctx.needs_input_grad[1] else None
+        check(lib.vs_reparam_bwd(gz.data_ptr(), noise.data_ptr(), ctx.scale, _p(gm), _p(gs), gz.numel(), _stream()),
+              "reparam_bwd")
+        return gm, gs, None, None
+
+
+class KL(torch.autograd.Function):
+    """utils/evaluation.py:42-45."""
+
+    @staticmethod
+    def forward(ctx, mean, std):
+        _require_cuda(mean, std)
+        mean, std = _contig(mean.float()), _contig(std.float())
+        out = torch.empty((), dtype=torch.float32, device=mean.device)
+        check(lib.vs_kl_fwd(mean.data_ptr(), std.data_ptr(), out.data_ptr(), mean.shape[0], mean.shape[1], _stream()), "kl_fwd")
+        ctx.save_for_backward(mean, std)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mean, std = ctx.saved_tensors
+        g = _contig(g.float())
+        gm = torch.empty_like(mean) if ctx.needs_input_grad[0] else None
+        gs = torch.empty_like(std) if ctx.needs_input_grad[1] else None
+        check(lib.vs_kl_bwd(mean.data_ptr(), std.data_ptr(), g.data_ptr(), _p(gm), _p(gs), mean.shape[0], mean.shape[1],
+                            _stream()), "kl_bwd")
+        return gm, gs
+
+
+class Dice(torch.autograd.Function):
+    """Soft Dice over channels [bot, top) of two planar fp32 (B, C, D, H, W) tensors.
+    return_mean=True -> scalar mean over (b, c); False -> per-sample (B,) means (utils/evaluation.py:68-79)."""
+
+    @staticmethod
+    def forward(ctx, s, t, bot, top, eps, return_mean):
+        _require_cuda(s, t)
+        s, t = _contig(s.float()), _contig(t.float())
+        b, c = s.shape[0], s.shape[1]
+        voxels = s.numel() // (b * c)
+        sums = torch.empty((b, c, 3), dtype=torch.float64, device=s.device)
+        per = torch.empty(b, dtype=torch.float32, device=s.device)
+        mean = torch.empty((), dtype=torch.float32, device=s.device)
+        check(lib.vs_dice_fwd(s.data_ptr(), t.data_ptr(), sums.data_ptr(), per.data_ptr(), mean.data_ptr(), b, c, voxels,
+                              bot, top, float(eps), _stream()), "dice_fwd")
+        ctx.save_for_backward(s, t, sums)
+        ctx.cfg = (bot, top, float(eps), bool(return_mean))
+        return mean if return_mean else per
+
+    @staticmethod
+    def backward(ctx, g):
+        s, t, sums = ctx.saved_tensors
+        bot, top, eps, return_mean = ctx.cfg
+        g = _contig(g.float())
+        b, c = s.shape[0], s.shape[1]
+        voxels = s.numel() // (b * c)
+        gs = torch.empty_like(s) if ctx.needs_input_grad[0] else None
+        gt = torch.empty_like(t) if ctx.needs_input_grad[1] else None
+        if gs is not None or gt is not None:
+            check(lib.vs_dice_bwd(s.data_ptr(), t.data_ptr(), sums.data_ptr(), g.data_ptr(), 1 if return_mean else 0,
+                                  _p(gs), _p(gt), b, c, voxels, bot, top, eps, _stream()), "dice_bwd")
+        return gs, gt, None, None, None, None
+
+
+class BCE(torch.autograd.Function):
+    """nn.BCELoss() (mean) — utils/evaluation.py:29-39."""
+
+    @staticmethod
+    def forward(ctx, p, t):
+        _require_cuda(p, t)
+        p, t = _contig(p.float()), _contig(t.float())
+        out = torch.empty((), dtype=torch.float32, device=p.device)
+        scratch = torch.empty(1, dtype=torch.float64, device=p.device)
+        check(lib.vs_bce_fwd(p.data_ptr(), t.data_ptr(), out.data_ptr(), scratch.data_ptr(), p.numel(), _stream()), "bce_fwd")
+        ctx.save_for_backward(p, t)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t = ctx.saved_tensors
+        gp = torch.empty_like(p)
+        g = _contig(g.float())
+        check(lib.vs_bce_bwd(p.data_ptr(), t.data_ptr(), g.data_ptr(), gp.data_ptr(), p.numel(), _stream()), "bce_bwd")
+        return gp, None
+
+
+# ------------------------------------------------------------------------------------------------
+# non-differentiable helpers
+# ------------------------------------------------------------------------------------------------
+def onehot(label, n_class=2):
+    """(B,1,D,H,W) labels (any real dtype, values 0..n_class-1) -> planar fp32 one-hot (main_source.py:449-451)."""
+    _require_cuda(label)
+    lab = _contig(label.float())
+    b = lab.shape[0]
+    out = torch.empty((b, n_class) + tuple(lab.shape[2:]), dtype=torch.float32, device=lab.device)
+    check(lib.vs_onehot(lab.data_ptr(), out.data_ptr(), b, lab.numel() // b, n_class, _stream()), "onehot")
+    return out
+
+
+def binarize(a, mode=0, lo=0.2, hi=0.8):
+    _require_cuda(a)
+    a = _contig(a.detach().float())
+    out = torch.empty_like(a)
+    check(lib.vs_binarize(a.data_ptr(), out.data_ptr(), a.numel(), mode, float(lo), float(hi), _stream()), "binarize")
+    return out
+
+
+def instnorm_stats(x):
+    n, c = x.shape[0], x.shape[-1]
+    st = _new_stats(n, c, x.device)
+    check(lib.vs_instnorm_stats(x.data_ptr(), st.data_ptr(), n, x.numel() // (n * c), c, vs_dtype(x), _stream()),
+          "instnorm_stats")
+    return st

@@ -1,0 +1,119 @@
+"""Multi-tensor optimiser steps on libvaeseg kernels: one launch per param group instead of the reference's
+per-tensor torch.optim loops (main_source.py:279-294, main_target.py:347-352), and the EMA teacher update
+(main_target.py:512-516).  Semantics and state keys follow torch.optim.SGD / torch.optim.Adam so optimizer
+state_dicts stay interchangeable with the reference's checkpoints (main_source.py:827-843)."""
+import torch
+
+from . import ops
+from ._lib import check, lib
+
+_CHUNK = 65536
+
+
+class _Tables:
+    """Device-side pointer / size / block tables for a list of tensor tuples; rebuilt only when an address changes."""
+
+    def __init__(self):
+        self.key = None
+        self.dev = None
+        self.n_blocks = 0
+
+    def get(self, lists, device):
+        key = tuple(t.data_ptr() for lst in lists for t in lst) + tuple(t.numel() for t in lists[0])
+        if key != self.key:
+            n = len(lists[0])
+            ptrs = [torch.tensor([t.data_ptr() for t in lst], dtype=torch.int64) for lst in lists]
+            sizes = torch.tensor([t.numel() for t in lists[0]], dtype=torch.int64)
+            bm = []
+            for i, t in enumerate(lists[0]):
+                for start in range(0, t.numel(), _CHUNK):
+                    bm += [i, start]
+            bm = torch.tensor(bm, dtype=torch.int32)
+            self.dev = [p.to(device) for p in ptrs] + [sizes.to(device), bm.to(device)]
+            self.n_blocks = bm.numel() // 2
+            self.key = key
+        return self.dev, self.n_blocks
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class SGD(torch.optim.Optimizer):
+    """torch.optim.SGD(lr, momentum, weight_decay) — dampening 0, no nesterov — as one kernel per group."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self._tables = {}
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("vae_segmentation_amd.optim.SGD needs contiguous fp32 CUDA parameters")
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            bufs = []
+            for p in ps:
+                st = self.state[p]
+                if "momentum_buffer" not in st or st["momentum_buffer"] is None:
+                    st["momentum_buffer"] = torch.zeros_like(p)      # buf = 0*m + g on the first step = torch's clone(g)
+                bufs.append(st["momentum_buffer"])
+            tab = self._tables.setdefault(gi, _Tables())
+            (pp, gp, bp, sizes, bm), nb = tab.get([ps, grads, bufs], ps[0].device)
+            check(lib.vs_sgd_momentum_multi(pp.data_ptr(), gp.data_ptr(), bp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb,
+                                            float(group["lr"]) * float(grad_scale), float(group["momentum"]),
+                                            float(group["weight_decay"]), 0, _stream()), "sgd_momentum_multi")
+        return None
+
+
+class Adam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, betas, eps, weight_decay) as one kernel per group."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = {}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            m1, m2 = [], []
+            for p in ps:
+                st = self.state[p]
+                if "exp_avg" not in st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                st["step"] = int(st["step"]) + 1
+                m1.append(st["exp_avg"])
+                m2.append(st["exp_avg_sq"])
+            step = int(self.state[ps[0]]["step"])
+            tab = self._tables.setdefault(gi, _Tables())
+            (pp, gp, ap, vp, sizes, bm), nb = tab.get([ps, grads, m1, m2], ps[0].device)
+            b1, b2 = group["betas"]
+            check(lib.vs_adam_multi(pp.data_ptr(), gp.data_ptr(), ap.data_ptr(), vp.data_ptr(), sizes.data_ptr(), bm.data_ptr(),
+                                    nb, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                    float(group["weight_decay"]), step, _stream()), "adam_multi")
+        return None
+
+
+_EMA_TABLES = {}
+
+
+@torch.no_grad()
+def ema_update(teacher, student, alpha):
+    """teacher <- alpha*teacher + (1-alpha)*student over matching state_dict entries (main_target.py:512-516)."""
+    sd_t, sd_s = teacher.state_dict(), student.state_dict()
+    ts = [sd_t[k] for k in sd_s if sd_s[k].dtype == torch.float32]
+    ss = [sd_s[k] for k in sd_s if sd_s[k].dtype == torch.float32]
+    tab = _EMA_TABLES.setdefault((id(teacher), id(student)), _Tables())
+    (tp, sp, sizes, bm), nb = tab.get([ts, ss], ts[0].device)
+    check(lib.vs_ema_multi(tp.data_ptr(), sp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb, float(alpha), _stream()), "ema_multi")
+    ops.clear_pack_cache()      # the teacher's cached packed weights are stale now
