@@ -177,7 +177,12 @@ int vs_adam_multi(float* const* params, const float* const* grads, float* const*
 /* EMA teacher: t = alpha*t + (1-alpha)*s       (main_target.py:512-516) */
 int vs_ema_multi(float* const* teacher, const float* const* student, const long long* sizes, const int* block_map,
                  int n_blocks, float alpha, void* stream);
-/* flat helpers used by the DDP bucket path: dst[i] = src[i]*scale */
+/* dst_k[i] = src_k[i]*scale for every tensor k: gathers the (scattered) gradient tensors into the slices of one flat
+ * all-reduce bucket, with the 1/world_size factor folded in — replaces nn.DataParallel's ReduceAddCoalesced staging
+ * (main_source.py:354). */
+int vs_copy_scale_multi(const float* const* srcs, float* const* dsts, const long long* sizes, const int* block_map,
+                        int n_blocks, float scale, void* stream);
+/* flat helper: dst[i] = src[i]*scale */
 int vs_scale_copy(const float* src, float* dst, long long count, float scale, void* stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,105 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol include/vaeseg.h declares,
+argument validation rejects bad calls without touching a GPU, the host-side helpers, and the world_size-2
+gradient exchange (gloo) used by the data-parallel step."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vae_segmentation_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 35
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(raw, name), name
+    for must in ("vs_conv_gather_fwd", "vs_conv_scatter_fwd", "vs_conv_k3_softmax2_fwd", "vs_conv_wgrad", "vs_pack_weight",
+                 "vs_instnorm_relu_fwd", "vs_instnorm_relu_bwd_reduce", "vs_instnorm_relu_bwd_apply", "vs_softmax2_bwd",
+                 "vs_dice_fwd", "vs_dice_bwd", "vs_kl_fwd", "vs_kl_bwd", "vs_reparam_fwd", "vs_linear_fwd", "vs_onehot",
+                 "vs_binarize", "vs_bce_fwd", "vs_sgd_momentum_multi", "vs_adam_multi", "vs_ema_multi", "vs_strerror",
+                 "vs_version", "vs_conv_wgrad_workspace_bytes", "vs_copy_scale_multi"):
+        assert must in protos, must
+    assert _lib.lib.vs_version() == 100
+    assert b"dtype" in _lib.lib.vs_strerror(-3)
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected on the host before any launch (no compute call is made here)."""
+    from vae_segmentation_amd._lib import lib
+    assert lib.vs_conv_gather_fwd(None, None, None, None, None, None, 1, 4, 4, 4, 8, 8, 0, 0, 1e-5, None) == -1
+    assert lib.vs_pack_weight(None, None, 8, 8, 27, 8, 0, 0, None) == -1
+    assert lib.vs_dice_fwd(None, None, None, None, None, 1, 2, 64, 1, 2, 1e-4, None) == -1
+    # packed-weight sizing is pure host arithmetic: 16 rows x (27 taps x 8 ch -> 7 k-groups of 32) bf16 fragments
+    assert lib.vs_packed_weight_bytes(8, 8, 27, 1) == 1 * 1 * 7 * 64 * 8 * 2
+    assert lib.vs_packed_weight_bytes(64, 64, 27, 0) == 4 * 2 * 54 * 64 * 4 * 4
+    assert lib.vs_conv_wgrad_workspace_bytes(2, 96, 96, 96, 8, 8, 0) > 0
+
+
+def test_host_helpers():
+    from vae_segmentation_amd import ops
+    assert [ops.cpad(c) for c in (1, 2, 8, 9, 16, 17, 32, 33, 256)] == [8, 8, 8, 16, 16, 32, 32, 64, 256]
+    from tests import golden_util as G
+    assert G.is_dead_bias("in_block.conv.0.bias") and G.is_dead_bias("up5.conv.1.conv.6.bias")
+    assert not G.is_dead_bias("down1.conv.0.bias") and not G.is_dead_bias("out_block.bias") and not G.is_dead_bias("fc2.bias")
+    with pytest.raises(RuntimeError):
+        ops._require_cuda(torch.zeros(1))
+
+
+def test_module_surface_on_cpu_is_constructible_but_not_runnable():
+    import joint_model as M
+    seg = M.Segmentation(1, 2, norm_type=1)
+    vae = M.VAE(2, 2, norm_type=1, dim=128, spatial=96)
+    assert vae.fc_mean.weight.shape == (128, 6912) and vae.fc2.weight.shape == (6912, 128)
+    joint = M.Joint(models=[seg, vae])
+    assert [n.split(".")[0] for n, _ in joint.named_parameters()][0] == "Seg"
+    with pytest.raises(RuntimeError):
+        joint({"x": torch.zeros(1, 1, 96, 96, 96)}, "x", "p", "r")
+    with pytest.raises(NotImplementedError):
+        M.Segmentation(1, 2, norm_type=2)
+    with pytest.raises(NotImplementedError):
+        M.Segmentation(1, 3, norm_type=1)
+
+
+WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from vae_segmentation_amd.ddp import FlatGradSync
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(0)
+params = [torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(7))]
+if rank == 1:
+    for p in params: p.data.add_(1.0)          # replicas start different; broadcast must fix that
+sync = FlatGradSync(params)
+sync.broadcast_parameters(0)
+ref0 = [torch.randn(3, 4, generator=torch.Generator().manual_seed(10)), torch.randn(7, generator=torch.Generator().manual_seed(11))]
+ref1 = [torch.randn(3, 4, generator=torch.Generator().manual_seed(20)), torch.randn(7, generator=torch.Generator().manual_seed(21))]
+mine = ref0 if rank == 0 else ref1
+views = sync([g.clone() for g in mine])
+for v, a, b in zip(views, ref0, ref1):
+    assert torch.allclose(v, (a + b) / 2, atol=1e-6), "rank %%d: averaged gradient mismatch" %% rank
+chk = torch.cat([p.data.reshape(-1) for p in params])
+gathered = [torch.zeros_like(chk) for _ in range(world)]
+dist.all_gather(gathered, chk)
+assert torch.equal(gathered[0], gathered[1]), "parameters differ across ranks after broadcast"
+dist.destroy_process_group()
+print("rank %%d ok" %% rank)
+"""
+
+
+def test_ddp_flat_grad_sync_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % REPO)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+    assert all("ok" in o for o in outs)

@@ -528,6 +528,23 @@ extern "C" int vs_ema_multi(float* const* teacher, const float* const* student, 
     return VS_OK;
 }
 
+__global__ __launch_bounds__(256) void copy_scale_multi_kernel(const float* const* srcs, float* const* dsts, const long long* sizes,
+                                                               const int* block_map, float scale) {
+    const int ti = block_map[2 * blockIdx.x], start = block_map[2 * blockIdx.x + 1];
+    const float* s = srcs[ti];
+    float* d = dsts[ti];
+    const long long n = sizes[ti];
+    const long long end = (long long)start + MT_CHUNK < n ? (long long)start + MT_CHUNK : n;
+    for (long long i = start + threadIdx.x; i < end; i += 256) d[i] = s[i] * scale;
+}
+extern "C" int vs_copy_scale_multi(const float* const* srcs, float* const* dsts, const long long* sizes, const int* block_map,
+                                   int n_blocks, float scale, void* stream) {
+    if (!srcs || !dsts || !sizes || !block_map || n_blocks <= 0) return VS_EINVAL;
+    hipLaunchKernelGGL(copy_scale_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, srcs, dsts, sizes, block_map, scale);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
 __global__ void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, float scale) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i] * scale;
 }

@@ -183,9 +183,9 @@ __global__ void g3_reduce_kernel(const float* __restrict__ ws, float* __restrict
     else { cb = c >> 3; col = ((tap & 1) << 3) | (c & 7); k = tap >> 1; }
     const size_t slab_elems = (size_t)mbn * cbn * NCB * 256;
     const size_t off = ((size_t)(mb * cbn + cb) * NCB + k) * 256 + col * 16 + row;
-    float s = 0.f;
-    for (int sl = 0; sl < nslabs; ++sl) s += ws[sl * slab_elems + off];
-    dw[i] = s;
+    double s = 0.0;      // fp64: the slabs are partial sums of a cancellation-heavy total
+    for (int sl = 0; sl < nslabs; ++sl) s += (double)ws[sl * slab_elems + off];
+    dw[i] = (float)s;
 }
 
 static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind, int& cbsz, int& mbn, int& cbn,

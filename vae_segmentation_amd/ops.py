@@ -22,6 +22,45 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-launch timing (bench.py roofline leg): when a list is installed here, every C-ABI launch below is
+# bracketed by HIP events recorded on the stream the kernel is launched on; entries are
+# (kernel id, algorithmic bytes, algorithmic flops, start event, end event).
+PROFILE = None
+
+
+def _esize(t):
+    return 4 if t.dtype == torch.float32 else 2
+
+
+def _pick_mt(rows16, tiles):
+    """mirror of pick_mt() in csrc/conv_api.hip (kernel instantiation naming only)."""
+    for mt in (64, 32, 16):
+        if rows16 % mt:
+            continue
+        if tiles * (rows16 // mt) >= 256 or mt == 16:
+            return mt
+    return 16
+
+
+class _timed:
+    def __init__(self, kid, nbytes, flops):
+        self.rec = None if PROFILE is None else [kid, float(nbytes), float(flops)]
+
+    def __enter__(self):
+        if self.rec is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.rec.append(e)
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.rec.append(e)
+            PROFILE.append(tuple(self.rec))
+        return False
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -52,7 +91,6 @@ def cpad(c):
 # ------------------------------------------------------------------------------------------------
 # weight packing (fragment order); frozen weights are packed once and cached
 # ------------------------------------------------------------------------------------------------
-_PACK_CACHE = {}
 
 
 def pack_weight(w, form, c_pad, dtype):
@@ -77,22 +115,29 @@ def pack_weight(w, form, c_pad, dtype):
 
 
 def pack_weight_cached(param, form, c_pad, dtype):
-    """Frozen parameters (requires_grad False) are packed once per (storage, version)."""
+    """Frozen parameters (requires_grad False) are packed once per (tensor object, version); the cache lives on
+    the tensor itself, so it dies with it and a recycled device address can never alias another weight."""
     if param.requires_grad:
         return pack_weight(param, form, c_pad, dtype)
     dt = VS_F32 if dtype == torch.float32 else VS_BF16
-    key = (param.data_ptr(), param._version, tuple(param.shape), form, c_pad, dt)
-    hit = _PACK_CACHE.get(key)
+    cache = getattr(param, "_vs_pack_cache", None)
+    if cache is None or cache[0] != (param._version, param.data_ptr(), _PACK_EPOCH[0]):
+        cache = ((param._version, param.data_ptr(), _PACK_EPOCH[0]), {})
+        param._vs_pack_cache = cache
+    key = (form, c_pad, dt)
+    hit = cache[1].get(key)
     if hit is None:
         hit = pack_weight(param, form, c_pad, dtype)
-        if len(_PACK_CACHE) > 4096:
-            _PACK_CACHE.clear()
-        _PACK_CACHE[key] = hit
+        cache[1][key] = hit
     return hit
 
 
+_PACK_EPOCH = [0]
+
+
 def clear_pack_cache():
-    _PACK_CACHE.clear()
+    """Invalidate every cached packed weight (call after writing frozen weights through raw pointers, e.g. EMA)."""
+    _PACK_EPOCH[0] += 1
 
 
 # ------------------------------------------------------------------------------------------------
@@ -102,7 +147,7 @@ def _new_stats(n, c, device):
     return torch.zeros(n, c, 2, dtype=torch.float64, device=device)
 
 
-def conv_gather(x, xs, wp, bias, m_out, kind, want_stats):
+def conv_gather(x, xs, wp, bias, m_out, kind, want_stats, real_channels=None):
     n, d, h, w, c = x.shape
     if kind == VS_CONV_K2S2:
         out_shape = (n, d // 2, h // 2, w // 2, m_out)
@@ -110,16 +155,39 @@ def conv_gather(x, xs, wp, bias, m_out, kind, want_stats):
         out_shape = (n, d, h, w, m_out)
     y = torch.empty(out_shape, dtype=x.dtype, device=x.device)
     ys = _new_stats(n, m_out, x.device) if want_stats else None
-    check(lib.vs_conv_gather_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), y.data_ptr(), _p(ys), n, d, h, w, c,
-                                 m_out, kind, vs_dtype(x), EPS_IN, _stream()), "conv_gather_fwd")
+    kid = nb = fl = None
+    if PROFILE is not None:
+        ck, taps = min(c, 32), (27 if kind == VS_CONV_K3 else 8)
+        if kind == VS_CONV_K3:
+            tiles = n * ((d + 3) // 4) * ((h + 3) // 4) * ((w + 15) // 16)
+        else:
+            tiles = n * ((y.numel() // (n * m_out) + 255) // 256)
+        rows16 = (m_out + 15) // 16 * 16
+        kid = "g1_kernel<%s,%d,%d,%d,0>" % ("float" if x.dtype == torch.float32 else "unsigned short", ck, kind, _pick_mt(rows16, tiles))
+        cr = real_channels[0] if real_channels else c
+        mr = real_channels[1] if real_channels else m_out
+        vox_out = y.numel() // m_out
+        nb = (x.numel() // c * cr + vox_out * mr) * _esize(x) + cr * mr * taps * _esize(x)
+        fl = 2.0 * vox_out * taps * cr * mr
+    with _timed(kid, nb, fl):
+        check(lib.vs_conv_gather_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), y.data_ptr(), _p(ys), n, d, h, w, c,
+                                     m_out, kind, vs_dtype(x), EPS_IN, _stream()), "conv_gather_fwd")
     return y, ys
 
 
 def conv_scatter(x, xs, wp, bias, m_out):
     n, d, h, w, c = x.shape
     y = torch.empty((n, 2 * d, 2 * h, 2 * w, m_out), dtype=x.dtype, device=x.device)
-    check(lib.vs_conv_scatter_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), y.data_ptr(), n, d, h, w, c, m_out,
-                                  vs_dtype(x), EPS_IN, _stream()), "conv_scatter_fwd")
+    kid = nb = fl = None
+    if PROFILE is not None:
+        tiles = n * ((d * h * w + 255) // 256)
+        rows16 = (8 * m_out + 15) // 16 * 16
+        kid = "g1_kernel<%s,%d,2,%d,2>" % ("float" if x.dtype == torch.float32 else "unsigned short", min(c, 32), _pick_mt(rows16, tiles))
+        nb = (x.numel() + y.numel()) * _esize(x) + 8 * c * m_out * _esize(x)
+        fl = 2.0 * (x.numel() // c) * 8 * c * m_out
+    with _timed(kid, nb, fl):
+        check(lib.vs_conv_scatter_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), y.data_ptr(), n, d, h, w, c, m_out,
+                                      vs_dtype(x), EPS_IN, _stream()), "conv_scatter_fwd")
     return y
 
 
@@ -130,8 +198,16 @@ def conv_wgrad(p, ps, q, qs, m_real, c_real, kind, out_shape):
     nbytes = lib.vs_conv_wgrad_workspace_bytes(n, dp, hp, wp_, m_ch, c_ch, kind)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
     dw = torch.empty(out_shape, dtype=torch.float32, device=p.device)
-    check(lib.vs_conv_wgrad(p.data_ptr(), _p(ps), q.data_ptr(), _p(qs), dw.data_ptr(), ws.data_ptr(), nbytes, n, dp, hp,
-                            wp_, m_ch, c_ch, m_real, c_real, kind, vs_dtype(p), EPS_IN, _stream()), "conv_wgrad")
+    kid = nb = fl = None
+    if PROFILE is not None:
+        taps = 27 if kind == VS_CONV_K3 else 8
+        kid = "g3_kernel<%s,%d,%d>" % ("float" if p.dtype == torch.float32 else "unsigned short", 16 if c_ch >= 16 else 8,
+                                       0 if kind == VS_CONV_K3 else 1)
+        nb = (p.numel() // m_ch * m_real + q.numel() // c_ch * c_real) * _esize(p) + m_real * c_real * taps * 4
+        fl = 2.0 * (p.numel() // m_ch) * taps * m_real * c_real
+    with _timed(kid, nb, fl):
+        check(lib.vs_conv_wgrad(p.data_ptr(), _p(ps), q.data_ptr(), _p(qs), dw.data_ptr(), ws.data_ptr(), nbytes, n, dp, hp,
+                                wp_, m_ch, c_ch, m_real, c_real, kind, vs_dtype(p), EPS_IN, _stream()), "conv_wgrad")
     return dw
 
 
@@ -151,11 +227,14 @@ def in_relu_bwd(g, x, xs, inplace=True):
     voxels = x.numel() // (n * c)
     sums = _new_stats(n, c, x.device)
     dt = vs_dtype(x)
-    check(lib.vs_instnorm_relu_bwd_reduce(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), n, voxels, c, dt,
-                                          EPS_IN, _stream()), "instnorm_relu_bwd_reduce")
+    tname = "float" if x.dtype == torch.float32 else "unsigned short"
+    with _timed("in_relu_bwd_reduce_kernel<%s>" % tname, 2 * x.numel() * _esize(x), 4.0 * x.numel()):
+        check(lib.vs_instnorm_relu_bwd_reduce(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), n, voxels, c, dt,
+                                              EPS_IN, _stream()), "instnorm_relu_bwd_reduce")
     gx = g if inplace else torch.empty_like(g)
-    check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), gx.data_ptr(), n,
-                                         voxels, c, dt, EPS_IN, _stream()), "instnorm_relu_bwd_apply")
+    with _timed("in_relu_bwd_apply_kernel<%s>" % tname, 3 * x.numel() * _esize(x), 6.0 * x.numel()):
+        check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), gx.data_ptr(), n,
+                                             voxels, c, dt, EPS_IN, _stream()), "instnorm_relu_bwd_apply")
     return gx
 
 
@@ -176,7 +255,7 @@ class ConvK3(torch.autograd.Function):
         _require_cuda(x, weight)
         cout, cin = weight.shape[0], weight.shape[1]
         wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, x.shape[-1], x.dtype)
-        y, ys = conv_gather(x, xs, wp, None, cpad(cout), VS_CONV_K3, True)
+        y, ys = conv_gather(x, xs, wp, None, cpad(cout), VS_CONV_K3, True, real_channels=(cin, cout))
         ctx.save_for_backward(x, xs, weight)
         ctx.has_bias = bias is not None
         ctx.bias_shape = None if bias is None else bias.shape
@@ -191,7 +270,7 @@ class ConvK3(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, gy.shape[-1], gy.dtype)
-            ga, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K3, False)
+            ga, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K3, False, real_channels=(cout, cin))
             gx = in_relu_bwd(ga, x, xs)
         if ctx.needs_input_grad[2]:
             gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K3, weight.shape)

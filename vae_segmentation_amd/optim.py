@@ -47,15 +47,26 @@ class SGD(torch.optim.Optimizer):
         self._tables = {}
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0):
+    def step_with(self, params, grads):
+        """step() with explicit gradient tensors (e.g. the views of a DDP flat bucket) instead of p.grad."""
+        return self.step(_override={id(p): g for p, g in zip(params, grads)})
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0, _override=None):
         for gi, group in enumerate(self.param_groups):
-            ps = [p for p in group["params"] if p.grad is not None]
+            if _override is not None:
+                ps = [p for p in group["params"] if id(p) in _override]
+            else:
+                ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
                 continue
             for p in ps:
                 if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("vae_segmentation_amd.optim.SGD needs contiguous fp32 CUDA parameters")
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
+            if _override is not None:
+                grads = [_override[id(p)] for p in ps]
+            else:
+                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
             bufs = []
             for p in ps:
                 st = self.state[p]
