@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--detail", action="store_true", help="print the slowest individual launches (stderr)")
     return ap.parse_args()
 
 
@@ -181,6 +182,11 @@ def main():
     if rank == 0:
         # dominant-kernel timing: HIP events around every launch of that kernel inside real (eager) steps
         roof = profiling.dominant_kernel_roofline(lambda: (loss_fn()[0]).backward(), seg_params, a.dtype, steps=2)
+        if a.detail:
+            tot = sum(r[0] for r in profiling.LAST_LAUNCHES) / 2
+            print("timed launches: %.3f ms per step over %d launches" % (tot, len(profiling.LAST_LAUNCHES) // 2), file=sys.stderr)
+            for ms, kid, det, nb, fl in profiling.LAST_LAUNCHES[:60]:
+                print("%8.1f us  %-42s %-52s %7.1f GB/s %8.2f TF/s" % (ms * 1e3, kid, det, nb / ms / 1e6, fl / ms / 1e9), file=sys.stderr)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

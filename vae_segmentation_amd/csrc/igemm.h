@@ -142,18 +142,37 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         if constexpr (KIND == G1_K3) {
             if (ch > 0) __syncthreads();
             // ---- stage the (4+2)x(4+2)x(16+2) halo tile of this channel chunk, activation applied ----
+            // All global loads of a batch are issued before any is consumed (out-of-volume lanes read element 0 and
+            // are zeroed afterwards), so a workgroup pays one memory latency per batch instead of one per fragment.
             constexpr int U = CKB / 16;
-            for (int u = tid; u < G1_TILE_VOX * U; u += 256) {
-                const int tv = u / U, part = u - tv * U;
-                const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / 108;
-                const int gz = z0 + tz_ - 1, gy = y0 + ty_ - 1, gx = x0 + tx_ - 1;
-                u32x4 val = u32x4{0u, 0u, 0u, 0u};
-                if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                    const size_t e = ((((size_t)n * p.D + gz) * p.H + gy) * p.W + gx) * p.C + ch * CK + part * EPL;
-                    val = *(const u32x4*)(xin + e);
-                    if (has_stats) val = act_transform<T, CK>(val, s_mean, s_rstd, ch * CK + part * EPL);
+            constexpr int NU = G1_TILE_VOX * U;
+            constexpr int NIT = (NU + 255) / 256;
+            constexpr int SB = NIT <= 12 ? NIT : (NIT + 1) / 2;
+#pragma unroll
+            for (int it0 = 0; it0 < NIT; it0 += SB) {
+                u32x4 vals[SB];
+                bool ok[SB];
+#pragma unroll
+                for (int b = 0; b < SB; ++b) {
+                    const int u = tid + (it0 + b) * 256;
+                    const int tv = u / U, part = u - tv * U;
+                    const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / 108;
+                    const int gz = z0 + tz_ - 1, gy = y0 + ty_ - 1, gx = x0 + tx_ - 1;
+                    ok[b] = (it0 + b < NIT) && u < NU && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                    const size_t e = ok[b] ? ((((size_t)n * p.D + gz) * p.H + gy) * p.W + gx) * p.C + ch * CK + part * EPL : 0;
+                    vals[b] = *(const u32x4*)(xin + e);
                 }
-                *(u32x4*)(s_tile + tv * CKB + part * 16) = val;
+#pragma unroll
+                for (int b = 0; b < SB; ++b) {
+                    const int u = tid + (it0 + b) * 256;
+                    if (it0 + b < NIT && u < NU) {
+                        const int tv = u / U, part = u - tv * U;
+                        u32x4 val = vals[b];
+                        if (has_stats) val = act_transform<T, CK>(val, s_mean, s_rstd, ch * CK + part * EPL);
+                        if (!ok[b]) val = u32x4{0u, 0u, 0u, 0u};
+                        *(u32x4*)(s_tile + tv * CKB + part * 16) = val;
+                    }
+                }
             }
             __syncthreads();
         }
@@ -190,41 +209,51 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                     for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
             }
         } else {
-            // wave-uniform tap; KPT k-groups per tap
+            // wave-uniform tap; KPT k-groups per tap.  The A (weight) fragments come straight from global memory, so the
+            // loop is software-pipelined: fragments for k-group kg+PD are requested while k-group kg is multiplied.
+            constexpr int NK = NTAPS * KPT;
+            constexpr int PD = RB <= 2 ? 9 : 3;          // prefetch distance in k-groups (register budget RB*PD*4 VGPRs)
+            u32x4 abuf[PD][RB];
+#pragma unroll
+            for (int j = 0; j < PD; ++j)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    abuf[j][rb] = j < NK ? wch[(size_t)(rb0 + rb) * rb_stride + j * 64] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll 1
-            for (int tap = 0; tap < NTAPS; ++tap) {
-                int toff_l = 0;
-                long long toff_g = 0;
-                if constexpr (KIND == G1_K3) {
-                    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                    toff_l = ((dz * 6 + dy) * 18 + dx) * CKB;
-                } else {
-                    const int dz = (tap >> 2) & 1, dy = (tap >> 1) & 1, dx = tap & 1;
-                    toff_g = (((long long)dz * p.H + dy) * p.W + dx) * p.C + ch * CK;
-                }
+            for (int kgb = 0; kgb < NK; kgb += PD) {
 #pragma unroll
-                for (int kk = 0; kk < KPT; ++kk) {
-                    const int kg = tap * KPT + kk;
-                    u32x4 a[RB];
+                for (int j = 0; j < PD; ++j) {
+                    const int kg = kgb + j;
+                    if (kg < NK) {
+                        u32x4 a[RB];
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
-                    u32x4 b[4];
-                    if constexpr (KIND == G1_K3) {
+                        for (int rb = 0; rb < RB; ++rb) a[rb] = abuf[j][rb];
+                        if (kg + PD < NK) {
 #pragma unroll
-                        for (int cg = 0; cg < 4; ++cg)
-                            b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff_l + kk * KG * (int)sizeof(T));
-                    } else {
-                        const int cc = kk * KG + g * EPL;
-#pragma unroll
-                        for (int cg = 0; cg < 4; ++cg) {
-                            b[cg] = *(const u32x4*)(xin + gofs[cg] + toff_g + cc);
-                            if (has_stats) b[cg] = act_transform<T, CK>(b[cg], s_mean, s_rstd, ch * CK + cc);
+                            for (int rb = 0; rb < RB; ++rb) abuf[j][rb] = wch[(size_t)(rb0 + rb) * rb_stride + (kg + PD) * 64];
                         }
+                        const int tap = kg / KPT, kk = kg - tap * KPT;
+                        u32x4 b[4];
+                        if constexpr (KIND == G1_K3) {
+                            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                            const int toff_l = ((dz * 6 + dy) * 18 + dx) * CKB + kk * KG * (int)sizeof(T);
+#pragma unroll
+                            for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff_l);
+                        } else {
+                            const int dz = (tap >> 2) & 1, dy = (tap >> 1) & 1, dx = tap & 1;
+                            const int cc = kk * KG + g * EPL;
+                            const long long toff_g = (((long long)dz * p.H + dy) * p.W + dx) * p.C + ch * CK + cc;
+#pragma unroll
+                            for (int cg = 0; cg < 4; ++cg) {
+                                b[cg] = *(const u32x4*)(xin + gofs[cg] + toff_g);
+                                if (has_stats) b[cg] = act_transform<T, CK>(b[cg], s_mean, s_rstd, ch * CK + cc);
+                            }
+                        }
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
                     }
-#pragma unroll
-                    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                        for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
                 }
             }
         }

@@ -36,6 +36,29 @@ template <int CB, int KIND> struct G3Geo {
 #define G3_LDS_P (4 * G3_MAXN * 16 * 4)
 #define G3_LDS_Q (G3_LDS_P + 256 * 16 * 4)
 
+
+// Sum the four waves' accumulators in a fixed order (w0+w1+w2+w3: bitwise reproducible) through LDS and write ONE
+// partial slab per workgroup: ws[ks][mb*cbn+cb][k][col][row].  `s_buf` needs NCB*256 floats.
+template <int NCB>
+__device__ __forceinline__ void g3_finish(f32x4 (&acc)[NCB], float* s_buf, float* ws_tile, int wave, int col, int g) {
+    float* mine = s_buf + col * 16 + 4 * g;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) {
+                f32x4 v = acc[k];
+                if (w > 0) {
+                    const f32x4 o = *(const f32x4*)(mine + k * 256);
+                    v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                }
+                if (w < 3) *(f32x4*)(mine + k * 256) = v;
+                else *(f32x4*)(ws_tile + (size_t)k * 256 + col * 16 + 4 * g) = v;
+            }
+        }
+    }
+}
+
 template <typename T, int CB, int KIND>
 __global__ __launch_bounds__(256) void g3_kernel(const G3Params p) {
     using GEO = G3Geo<CB, KIND>;
@@ -159,33 +182,227 @@ __global__ __launch_bounds__(256) void g3_kernel(const G3Params p) {
         }
     }
 
-    // ---- partial slab of this wave: [slab][mb*cbn+cb][k][col][row] ----
     const size_t slab_elems = (size_t)p.mbn * p.cbn * NCB * 256;
-    float* o = p.ws + ((size_t)(ks * 4 + wave)) * slab_elems + ((size_t)blockIdx.x * NCB) * 256 + col * 16 + 4 * g;
-#pragma unroll
-    for (int k = 0; k < NCB; ++k) *(f32x4*)(o + (size_t)k * 256) = acc[k];
+    g3_finish<NCB>(acc, s_p, p.ws + (size_t)ks * slab_elems + ((size_t)blockIdx.x * NCB) * 256, wave, col, g);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// bf16 storage: the same GEMM on v_mfma_f32_16x16x32_bf16.  The MFMA wants 8 consecutive k (= voxels) per lane
+// for a fixed row/column (= channel) while the tiles are channels-last, so the operands are read with
+// ds_read_b64_tr_b16: per 16-lane group it fetches a 4-voxel x 16-channel block and hands lane i channel i of
+// the 4 voxels.  k-mapping of a K-step (32 voxels = two x-rows of the wave's 4x16 z-slice): hardware
+// k = 8g + 4r + e  <->  voxel (y = 2s + r, x = 4g + e); A and B use the same map, so the sum is unchanged,
+// and the four lane groups of one read touch 512 contiguous bytes (conflict-free).
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* s_base, int off0, int off1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s_base + off0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s_base + off1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+#define G3B_LDS_P (4 * G3_MAXN * 16 * 4)
+#define G3B_LDS_Q (G3B_LDS_P + 256 * 16 * 2)
+
 template <int CB, int KIND>
-__global__ void g3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int m_real, int c_real, int mbn,
-                                 int cbn, int nslabs) {
+__global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) {
+    using GEO = G3Geo<CB, KIND>;
+    typedef unsigned short T;
+    constexpr int NTAPS = GEO::NTAPS, NCB = GEO::NCB, QY = GEO::QY, QX = GEO::QX, QV = GEO::QV;
+    constexpr int QROW = CB * 2;                 // bytes per Q-tile voxel
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_pm = (float*)(smem + G3_LDS_STATS);
+    float* s_pr = s_pm + G3_MAXN * 16;
+    float* s_qm = s_pr + G3_MAXN * 16;
+    float* s_qr = s_qm + G3_MAXN * 16;
+    char* s_p = smem + G3B_LDS_P;                // [256 voxels][16 ch] bf16
+    char* s_q = smem + G3B_LDS_Q;                // [QV voxels][CB ch] bf16
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
+    const int q4 = col >> 2, p4 = col & 3;       // tr-read addressing: this lane supplies row q4, columns 4*p4..4*p4+3
+    const int mb = blockIdx.x / p.cbn, cb = blockIdx.x - mb * p.cbn;
+    const int ks = blockIdx.y;
+    const T* __restrict__ Pp = (const T*)p.P;
+    const T* __restrict__ Qp = (const T*)p.Q;
+    const bool p_stats = p.P_stats != nullptr, q_stats = p.Q_stats != nullptr;
+
+    for (int i = tid; i < p.N * 16; i += 256) {
+        const int n = i >> 4, c = i & 15;
+        float m = 0.f, r = 1.f;
+        const int pc = mb * 16 + c;
+        if (p_stats && pc < p.Mch) stats_to_mean_rstd(p.P_stats + ((size_t)n * p.Mch + pc) * 2, p.inv_cnt_p, p.eps, m, r);
+        s_pm[i] = m; s_pr[i] = r;
+        m = 0.f; r = 1.f;
+        const int qc = cb * CB + c;
+        if (q_stats && c < CB && qc < p.Cch) stats_to_mean_rstd(p.Q_stats + ((size_t)n * p.Cch + qc) * 2, p.inv_cnt_q, p.eps, m, r);
+        s_qm[i] = m; s_qr[i] = r;
+    }
+
+    // per-lane byte offsets into the Q tile of this lane's tr-read row for each column block (tap part only)
+    int qoff[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) {
+        int tap = CB == 16 ? k : 2 * k + (p4 >> 1);
+        if (tap >= NTAPS) tap = KIND == G3_K3 ? 13 : 0;
+        int dz, dy, dx;
+        if (KIND == G3_K3) { dz = tap / 9; dy = (tap / 3) % 3; dx = tap % 3; }
+        else { dz = (tap >> 2) & 1; dy = (tap >> 1) & 1; dx = tap & 1; }
+        qoff[k] = ((dz * QY + dy) * QX + dx) * QROW + (CB == 16 ? p4 * 8 : (p4 & 1) * 8);
+    }
+
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = ks; t < p.total_tiles; t += p.ksplit) {
+        const int n = t / p.tiles_per_sample;
+        const int tl = t - n * p.tiles_per_sample;
+        const int tx = tl % p.txn, ty = (tl / p.txn) % p.tyn, tz = tl / (p.txn * p.tyn);
+        const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+        __syncthreads();
+        // ---- stage P (256 voxels x 16 ch) and Q (halo / strided region x CB ch) as bf16; every global load of a batch
+        //      is issued before any is consumed; out-of-range fragments read element 0 and are zeroed afterwards ----
+        {
+            u32x4 pv[2];
+            bool pok[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int u = tid + b * 256;
+                const int v = u >> 1, part = u & 1;
+                const int lx = v & 15, ly = (v >> 4) & 3, lz = v >> 6;
+                const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
+                const int c0 = mb * 16 + part * 8;
+                pok[b] = gz < p.Dp && gy < p.Hp && gx < p.Wp && c0 < p.Mch;
+                const size_t e = pok[b] ? ((((size_t)n * p.Dp + gz) * p.Hp + gy) * p.Wp + gx) * p.Mch + c0 : 0;
+                pv[b] = *(const u32x4*)(Pp + e);
+            }
+            constexpr int QU = CB / 8;
+            constexpr int NQ = QV * QU;
+            constexpr int NITQ = (NQ + 255) / 256;
+            constexpr int SBQ = NITQ <= 8 ? NITQ : 8;
+#pragma unroll 1
+            for (int it0 = 0; it0 < NITQ; it0 += SBQ) {
+                u32x4 qv[SBQ];
+                bool qok[SBQ];
+#pragma unroll
+                for (int b = 0; b < SBQ; ++b) {
+                    const int u = tid + (it0 + b) * 256;
+                    const int v = u / QU, part = u - v * QU;
+                    const int lx = v % QX, ly = (v / QX) % QY, lz = v / (QX * QY);
+                    int gz, gy, gx;
+                    if (KIND == G3_K3) { gz = z0 + lz - 1; gy = y0 + ly - 1; gx = x0 + lx - 1; }
+                    else { gz = 2 * z0 + lz; gy = 2 * y0 + ly; gx = 2 * x0 + lx; }
+                    const int c0 = cb * CB + part * 8;
+                    qok[b] = (it0 + b < NITQ) && u < NQ && gz >= 0 && gz < p.Dq && gy >= 0 && gy < p.Hq && gx >= 0 && gx < p.Wq && c0 < p.Cch;
+                    const size_t e = qok[b] ? ((((size_t)n * p.Dq + gz) * p.Hq + gy) * p.Wq + gx) * p.Cch + c0 : 0;
+                    qv[b] = *(const u32x4*)(Qp + e);
+                }
+#pragma unroll
+                for (int b = 0; b < SBQ; ++b) {
+                    const int u = tid + (it0 + b) * 256;
+                    if (it0 + b < NITQ && u < NQ) {
+                        const int v = u / QU, part = u - v * QU;
+                        u32x4 val = qv[b];
+                        if (q_stats) {
+                            float f[8];
+                            frag_unpack(val, f, (T*)nullptr);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float tt = (f[j] - s_qm[n * 16 + part * 8 + j]) * s_qr[n * 16 + part * 8 + j];
+                                f[j] = tt > 0.f ? tt : 0.f;
+                            }
+                            val = frag_pack(f, (T*)nullptr);
+                        }
+                        if (!qok[b]) val = u32x4{0u, 0u, 0u, 0u};
+                        *(u32x4*)(s_q + v * QROW + part * 16) = val;
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int u = tid + b * 256;
+                const int v = u >> 1, part = u & 1;
+                u32x4 val = pv[b];
+                if (p_stats) {
+                    float f[8];
+                    frag_unpack(val, f, (T*)nullptr);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float tt = (f[j] - s_pm[n * 16 + part * 8 + j]) * s_pr[n * 16 + part * 8 + j];
+                        f[j] = tt > 0.f ? tt : 0.f;
+                    }
+                    val = frag_pack(f, (T*)nullptr);
+                }
+                if (!pok[b]) val = u32x4{0u, 0u, 0u, 0u};
+                *(u32x4*)(s_p + v * 32 + part * 16) = val;
+            }
+        }
+        __syncthreads();
+        // ---- two K-steps of 32 voxels: y rows (2s, 2s+1) of this wave's z-slice ----
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int xr = 4 * g + q4;                                   // this lane's tr-read row: voxel x
+            const int pa0 = (((wave * 4 + 2 * s) * 16 + xr) * 32) + p4 * 8;
+            const bf16x8 a = tr_pair(s_p, pa0, pa0 + 16 * 32);
+            int qb0, qb1;
+            if (KIND == G3_K3) {
+                qb0 = ((wave * QY + 2 * s) * QX + xr) * QROW;
+                qb1 = qb0 + QX * QROW;
+            } else {
+                qb0 = ((2 * wave * QY + 2 * (2 * s)) * QX + 2 * xr) * QROW;
+                qb1 = qb0 + 2 * QX * QROW;
+            }
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) {
+                const bf16x8 b = tr_pair(s_q, qb0 + qoff[k], qb1 + qoff[k]);
+                acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[k], 0, 0, 0);
+            }
+        }
+    }
+
+    const size_t slab_elems = (size_t)p.mbn * p.cbn * NCB * 256;
+    g3_finish<NCB>(acc, (float*)s_p, p.ws + (size_t)ks * slab_elems + ((size_t)blockIdx.x * NCB) * 256, wave, col, g);
+}
+
+// Sum the partial slabs (fixed order, fp64) into the reference's [m][c][tap] layout.  64 outputs per block; the four
+// waves each take every 4th slab with 8 loads in flight, then combine through LDS.
+template <int CB, int KIND>
+__global__ __launch_bounds__(256) void g3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int m_real, int c_real, int mbn,
+                                                        int cbn, int nslabs) {
     using GEO = G3Geo<CB, KIND>;
     constexpr int NTAPS = GEO::NTAPS, NCB = GEO::NCB;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double red[4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + lane;
     const long long total = (long long)m_real * c_real * NTAPS;
-    if (i >= total) return;
-    const int tap = (int)(i % NTAPS);
-    const int c = (int)((i / NTAPS) % c_real);
-    const int m = (int)(i / ((long long)NTAPS * c_real));
-    const int mb = m >> 4, row = m & 15;
-    int cb, k, col;
-    if (CB == 16) { cb = c >> 4; col = c & 15; k = tap; }
-    else { cb = c >> 3; col = ((tap & 1) << 3) | (c & 7); k = tap >> 1; }
-    const size_t slab_elems = (size_t)mbn * cbn * NCB * 256;
-    const size_t off = ((size_t)(mb * cbn + cb) * NCB + k) * 256 + col * 16 + row;
-    double s = 0.0;      // fp64: the slabs are partial sums of a cancellation-heavy total
-    for (int sl = 0; sl < nslabs; ++sl) s += (double)ws[sl * slab_elems + off];
-    dw[i] = (float)s;
+    double s = 0.0;
+    if (i < total) {
+        const int tap = (int)(i % NTAPS);
+        const int c = (int)((i / NTAPS) % c_real);
+        const int m = (int)(i / ((long long)NTAPS * c_real));
+        const int mb = m >> 4, row = m & 15;
+        int cb, k, col;
+        if (CB == 16) { cb = c >> 4; col = c & 15; k = tap; }
+        else { cb = c >> 3; col = ((tap & 1) << 3) | (c & 7); k = tap >> 1; }
+        const size_t slab_elems = (size_t)mbn * cbn * NCB * 256;
+        const float* src = ws + ((size_t)(mb * cbn + cb) * NCB + k) * 256 + col * 16 + row;
+        int sl = part;
+        for (; sl + 28 < nslabs; sl += 32) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(sl + 4 * j) * slab_elems];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (double)v[j];
+        }
+        for (; sl < nslabs; sl += 4) s += (double)src[(size_t)sl * slab_elems];
+    }
+    red[part][lane] = s;
+    __syncthreads();
+    if (part == 0 && i < total) dw[i] = (float)(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
 }
 
 static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind, int& cbsz, int& mbn, int& cbn,
@@ -198,19 +415,38 @@ static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind,
     tyn = (hp + 3) / 4; txn = (wp + 15) / 16;
     tiles_per_sample = ((dp + 3) / 4) * tyn * txn;
     const long long total = (long long)tiles_per_sample * n;
-    long long want = (768 + (long long)mbn * cbn - 1) / ((long long)mbn * cbn);   // ~3 WGs per CU overall
+    long long want = (512 + (long long)mbn * cbn - 1) / ((long long)mbn * cbn);   // ~2 workgroups per CU overall
     if (want < 1) want = 1;
     if (want > total) want = total;
     // keep the slab workspace <= 64 MiB
     const double slab_bytes = (double)mbn * cbn * ncb * 256 * 4;
-    while (want > 1 && want * 4 * slab_bytes > 64.0 * 1024 * 1024) --want;
+    while (want > 1 && want * slab_bytes > 64.0 * 1024 * 1024) --want;
     ksplit = (int)want;
 }
 
 extern "C" size_t vs_conv_wgrad_workspace_bytes(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind) {
     int cbsz, mbn, cbn, ncb, tps, tyn, txn, ksplit;
     g3_plan(n, dp, hp, wp, m_ch, c_ch, kind == VS_CONV_K3 ? VS_CONV_K3 : VS_CONV_K2S2, cbsz, mbn, cbn, ncb, tps, tyn, txn, ksplit);
-    return (size_t)ksplit * 4 * mbn * cbn * ncb * 256 * 4;
+    return (size_t)ksplit * mbn * cbn * ncb * 256 * 4;
+}
+
+template <int CB, int KIND>
+static int g3b_run(const G3Params& p, float* dw, int m_real, int c_real, hipStream_t s) {
+    using GEO = G3Geo<CB, KIND>;
+    constexpr size_t lds = G3B_LDS_Q + (size_t)GEO::QV * CB * 2;
+    auto kern = g3b_kernel<CB, KIND>;
+    if (lds > 64 * 1024) {
+        static const hipError_t attr_err =
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr_err != hipSuccess) return (int)attr_err;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.mbn * p.cbn, p.ksplit), dim3(256), lds, s, p);
+    VS_CHECK_LAUNCH();
+    const long long total = (long long)m_real * c_real * GEO::NTAPS;
+    hipLaunchKernelGGL((g3_reduce_kernel<CB, KIND>), dim3(vs_ceil_div(total, 64)), dim3(256), 0, s, p.ws, dw, m_real,
+                       c_real, p.mbn, p.cbn, p.ksplit);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
 }
 
 template <typename T, int CB, int KIND>
@@ -226,8 +462,8 @@ static int g3_run(const G3Params& p, float* dw, int m_real, int c_real, hipStrea
     hipLaunchKernelGGL(kern, dim3(p.mbn * p.cbn, p.ksplit), dim3(256), lds, s, p);
     VS_CHECK_LAUNCH();
     const long long total = (long long)m_real * c_real * GEO::NTAPS;
-    hipLaunchKernelGGL((g3_reduce_kernel<CB, KIND>), dim3(vs_ceil_div(total, 256)), dim3(256), 0, s, p.ws, dw, m_real,
-                       c_real, p.mbn, p.cbn, p.ksplit * 4);
+    hipLaunchKernelGGL((g3_reduce_kernel<CB, KIND>), dim3(vs_ceil_div(total, 64)), dim3(256), 0, s, p.ws, dw, m_real,
+                       c_real, p.mbn, p.cbn, p.ksplit);
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -243,7 +479,7 @@ extern "C" int vs_conv_wgrad(const void* P, const double* p_stats, const void* Q
     G3Params p{};
     int cbsz, ncb;
     g3_plan(n, dp, hp, wp, m_ch, c_ch, kind, cbsz, p.mbn, p.cbn, ncb, p.tiles_per_sample, p.tyn, p.txn, p.ksplit);
-    const size_t need = (size_t)p.ksplit * 4 * p.mbn * p.cbn * ncb * 256 * 4;
+    const size_t need = (size_t)p.ksplit * p.mbn * p.cbn * ncb * 256 * 4;
     if (workspace_bytes < need) return VS_EWORKSPACE;
     p.P = P; p.P_stats = p_stats; p.Q = Q; p.Q_stats = q_stats; p.ws = (float*)workspace;
     p.N = n; p.Dp = dp; p.Hp = hp; p.Wp = wp;
@@ -259,7 +495,8 @@ extern "C" int vs_conv_wgrad(const void* P, const double* p_stats, const void* Q
     if (kind == VS_CONV_K3) return cbsz == 16 ? g3_run<T, 16, G3_K3>(p, dw, m_real, c_real, st) : g3_run<T, 8, G3_K3>(p, dw, m_real, c_real, st); \
     return cbsz == 16 ? g3_run<T, 16, G3_K2S2>(p, dw, m_real, c_real, st) : g3_run<T, 8, G3_K2S2>(p, dw, m_real, c_real, st);
     if (dtype == VS_F32) { G3_GO(float) }
-    G3_GO(unsigned short)
 #undef G3_GO
+    if (kind == VS_CONV_K3) return cbsz == 16 ? g3b_run<16, G3_K3>(p, dw, m_real, c_real, st) : g3b_run<8, G3_K3>(p, dw, m_real, c_real, st);
+    return cbsz == 16 ? g3b_run<16, G3_K2S2>(p, dw, m_real, c_real, st) : g3b_run<8, G3_K2S2>(p, dw, m_real, c_real, st);
 }
 

@@ -43,8 +43,8 @@ def _pick_mt(rows16, tiles):
 
 
 class _timed:
-    def __init__(self, kid, nbytes, flops):
-        self.rec = None if PROFILE is None else [kid, float(nbytes), float(flops)]
+    def __init__(self, kid, nbytes, flops, detail=""):
+        self.rec = None if PROFILE is None else [kid, float(nbytes), float(flops), detail]
 
     def __enter__(self):
         if self.rec is not None:
@@ -169,7 +169,7 @@ def conv_gather(x, xs, wp, bias, m_out, kind, want_stats, real_channels=None):
         vox_out = y.numel() // m_out
         nb = (x.numel() // c * cr + vox_out * mr) * _esize(x) + cr * mr * taps * _esize(x)
         fl = 2.0 * vox_out * taps * cr * mr
-    with _timed(kid, nb, fl):
+    with _timed(kid, nb, fl, "x%s->m%d" % (tuple(x.shape), m_out)):
         check(lib.vs_conv_gather_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), y.data_ptr(), _p(ys), n, d, h, w, c,
                                      m_out, kind, vs_dtype(x), EPS_IN, _stream()), "conv_gather_fwd")
     return y, ys
@@ -185,7 +185,7 @@ def conv_scatter(x, xs, wp, bias, m_out):
         kid = "g1_kernel<%s,%d,2,%d,2>" % ("float" if x.dtype == torch.float32 else "unsigned short", min(c, 32), _pick_mt(rows16, tiles))
         nb = (x.numel() + y.numel()) * _esize(x) + 8 * c * m_out * _esize(x)
         fl = 2.0 * (x.numel() // c) * 8 * c * m_out
-    with _timed(kid, nb, fl):
+    with _timed(kid, nb, fl, "x%s->m%d" % (tuple(x.shape), m_out)):
         check(lib.vs_conv_scatter_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), y.data_ptr(), n, d, h, w, c, m_out,
                                       vs_dtype(x), EPS_IN, _stream()), "conv_scatter_fwd")
     return y
@@ -205,7 +205,7 @@ def conv_wgrad(p, ps, q, qs, m_real, c_real, kind, out_shape):
                                        0 if kind == VS_CONV_K3 else 1)
         nb = (p.numel() // m_ch * m_real + q.numel() // c_ch * c_real) * _esize(p) + m_real * c_real * taps * 4
         fl = 2.0 * (p.numel() // m_ch) * taps * m_real * c_real
-    with _timed(kid, nb, fl):
+    with _timed(kid, nb, fl, "p%s q%s" % (tuple(p.shape), tuple(q.shape))):
         check(lib.vs_conv_wgrad(p.data_ptr(), _p(ps), q.data_ptr(), _p(qs), dw.data_ptr(), ws.data_ptr(), nbytes, n, dp, hp,
                                 wp_, m_ch, c_ch, m_real, c_real, kind, vs_dtype(p), EPS_IN, _stream()), "conv_wgrad")
     return dw
@@ -228,11 +228,11 @@ def in_relu_bwd(g, x, xs, inplace=True):
     sums = _new_stats(n, c, x.device)
     dt = vs_dtype(x)
     tname = "float" if x.dtype == torch.float32 else "unsigned short"
-    with _timed("in_relu_bwd_reduce_kernel<%s>" % tname, 2 * x.numel() * _esize(x), 4.0 * x.numel()):
+    with _timed("in_relu_bwd_reduce_kernel<%s>" % tname, 2 * x.numel() * _esize(x), 4.0 * x.numel(), str(tuple(x.shape))):
         check(lib.vs_instnorm_relu_bwd_reduce(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), n, voxels, c, dt,
                                               EPS_IN, _stream()), "instnorm_relu_bwd_reduce")
     gx = g if inplace else torch.empty_like(g)
-    with _timed("in_relu_bwd_apply_kernel<%s>" % tname, 3 * x.numel() * _esize(x), 6.0 * x.numel()):
+    with _timed("in_relu_bwd_apply_kernel<%s>" % tname, 3 * x.numel() * _esize(x), 6.0 * x.numel(), str(tuple(x.shape))):
         check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), gx.data_ptr(), n,
                                              voxels, c, dt, EPS_IN, _stream()), "instnorm_relu_bwd_apply")
     return gx

@@ -4,6 +4,7 @@ import torch
 
 from . import ops
 
+LAST_LAUNCHES = []
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
@@ -25,7 +26,9 @@ def collect(fwd_bwd, params, steps=2):
     finally:
         ops.PROFILE = None
     agg = {}
-    for kid, nb, fl, e0, e1 in recs:
+    global LAST_LAUNCHES
+    LAST_LAUNCHES = sorted(((e0.elapsed_time(e1), kid, det, nb, fl) for kid, nb, fl, det, e0, e1 in recs), reverse=True)
+    for kid, nb, fl, det, e0, e1 in recs:
         a = agg.setdefault(kid, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
         a["launches"] += 1
         a["ms"] += e0.elapsed_time(e1)
