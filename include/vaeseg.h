@@ -165,7 +165,7 @@ int vs_bce_bwd(const float* p, const float* t, const float* gout, float* gp, lon
 
 /* ---- optimiser / teacher ---------------------------------------------------------------------------- */
 /* multi-tensor updates: ptr tables are DEVICE arrays of n_tensors device pointers, sizes[] element counts,
- * block_map[] = (tensor index, first element) pairs, one per 65536-element chunk (n_blocks of them).
+ * block_map[] = (tensor index, first element) pairs, one per 4096-element chunk (n_blocks of them).
  * SGD (torch.optim.SGD semantics, main_source.py:279-291): g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf */
 int vs_sgd_momentum_multi(float* const* params, const float* const* grads, float* const* bufs, const long long* sizes,
                           const int* block_map, int n_blocks, float lr, float momentum, float weight_decay,

@@ -1,0 +1,297 @@
+// 3x3x3 (pad 1) implicit-GEMM convolution, forward and backward-data: persistent, register-prefetched.
+//
+// Same GEMM orientation, fragment formats, LDS halo tile and epilogues as g1_kernel (igemm.h), restructured for the
+// fact that on this op a workgroup is latency-bound, not MFMA-bound (a 4x4x16 tile is ~450 MFMA cycles against
+// microseconds of global-load latency): a fixed grid of workgroups walks the tile list (tile index strided by the grid,
+// so concurrently processed tiles are spatial neighbours and share halos in L2), and while tile i is multiplied out of
+// LDS the global loads of stage i+1 (next channel chunk or next tile) are already in flight into registers
+// (issue-early / write-late staging).  Per-(n,c) statistics are kept in registers across the tiles of one sample and
+// flushed with one fp64 atomic per (row, statistic) when the sample changes.
+#pragma once
+#include "igemm.h"
+
+#define K3_LDS_RED 0          // float[4][64][2]
+#define K3_LDS_TAPS 2048      // int[64]
+#define K3_LDS_TILE 2304      // halo tile, then mean/rstd tables float[2][N*C]
+
+template <typename T, int CK, int MT, int EPI>
+__global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
+    using E = ET<T>;
+    constexpr int EPL = E::EPL, KG = E::KG;
+    constexpr int NTAPS = 27;
+    constexpr int NKG = (NTAPS * CK + KG - 1) / KG;
+    constexpr int RB = MT / 16;
+    constexpr int CKB = CK * (int)sizeof(T);
+    constexpr int TPK = KG > CK ? KG / CK : 1;
+    constexpr int KPT = KG > CK ? 1 : CK / KG;
+    constexpr int U = CKB / 16;
+    constexpr int NU = G1_TILE_VOX * U;
+    constexpr int NIT = (NU + 255) / 256;
+    constexpr bool PF = NIT <= 12;                       // prefetch the next stage into registers while computing
+    constexpr int SB = PF ? NIT : (NIT + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_red = (float*)(smem + K3_LDS_RED);
+    int* s_taps = (int*)(smem + K3_LDS_TAPS);
+    char* s_tile = smem + K3_LDS_TILE;
+    float* s_mean = (float*)(s_tile + G1_TILE_VOX * CKB);
+    float* s_rstd = s_mean + p.N * p.C;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
+    const int rb0 = blockIdx.y * RB;
+    const bool has_stats = p.x_stats != nullptr;
+    const T* __restrict__ xin = (const T*)p.x;
+    const int total_tiles = p.tiles_per_sample * p.N;
+
+    if (has_stats) {
+        for (int i = tid; i < p.N * p.C; i += 256) {
+            float m, r;
+            stats_to_mean_rstd(p.x_stats + (size_t)i * 2, p.inv_count_in, p.eps, m, r);
+            s_mean[i] = m;
+            s_rstd[i] = r;
+        }
+    }
+    if (tid < 32) {
+        const int t = tid < 27 ? tid : 13;
+        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+        s_taps[tid] = ((dz * 6 + dy) * 18 + dx) * CKB;
+    }
+    int lds_base[4];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) lds_base[cg] = ((wave * 6 + cg) * 18 + col) * CKB + ((g * EPL) % CK) * (int)sizeof(T);
+
+    const u32x4* __restrict__ wp = (const u32x4*)p.wp;
+    const size_t rb_stride = (size_t)p.nch * NKG * 64;
+
+    // ---- staging helpers --------------------------------------------------------------------------------
+    u32x4 vals[SB];
+    bool ok[SB];
+    auto tile_origin = [&](int t, int& n, int& z0, int& y0, int& x0) {
+        n = t / p.tiles_per_sample;
+        const int tl = t - n * p.tiles_per_sample;
+        x0 = (tl % p.txn) * 16;
+        y0 = ((tl / p.txn) % p.tyn) * 4;
+        z0 = (tl / (p.txn * p.tyn)) * 4;
+    };
+    auto stage_load = [&](int t, int ch, int it0) {
+        int n, z0, y0, x0;
+        tile_origin(t, n, z0, y0, x0);
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            const int u = tid + (it0 + b) * 256;
+            const int tv = u / U, part = u - tv * U;
+            const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / 108;
+            const int gz = z0 + tz_ - 1, gy = y0 + ty_ - 1, gx = x0 + tx_ - 1;
+            ok[b] = (it0 + b < NIT) && u < NU && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const size_t e = ok[b] ? ((((size_t)n * p.D + gz) * p.H + gy) * p.W + gx) * p.C + ch * CK + part * EPL : 0;
+            vals[b] = *(const u32x4*)(xin + e);
+        }
+    };
+    auto stage_write = [&](int n, int ch, int it0) {
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            const int u = tid + (it0 + b) * 256;
+            if (it0 + b < NIT && u < NU) {
+                const int tv = u / U, part = u - tv * U;
+                u32x4 val = vals[b];
+                if (has_stats) val = act_transform<T, CK>(val, s_mean + n * p.C, s_rstd + n * p.C, ch * CK + part * EPL);
+                if (!ok[b]) val = u32x4{0u, 0u, 0u, 0u};
+                *(u32x4*)(s_tile + tv * CKB + part * 16) = val;
+            }
+        }
+    };
+
+    float ssum[RB][4], ssq[RB][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[rb][r] = 0.f; ssq[rb][r] = 0.f; }
+
+    int t = blockIdx.x;
+    __syncthreads();                                     // tables visible
+    if (PF && t < total_tiles) stage_load(t, 0, 0);
+
+    for (; t < total_tiles; t += gridDim.x) {
+        int n, z0, y0, x0;
+        tile_origin(t, n, z0, y0, x0);
+        f32x4 acc[RB][4];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int ch = 0; ch < p.nch; ++ch) {
+            if constexpr (PF) {
+                __syncthreads();                         // every wave is done reading the previous stage's tile
+                stage_write(n, ch, 0);
+                __syncthreads();
+                const bool more_ch = ch + 1 < p.nch;
+                const int tn = more_ch ? t : t + (int)gridDim.x;
+                if (tn < total_tiles) stage_load(tn, more_ch ? ch + 1 : 0, 0);
+            } else {
+                __syncthreads();
+#pragma unroll 1
+                for (int it0 = 0; it0 < NIT; it0 += SB) {
+                    stage_load(t, ch, it0);
+                    stage_write(n, ch, it0);
+                }
+                __syncthreads();
+            }
+            const u32x4* wch = wp + (size_t)ch * NKG * 64 + lane;
+
+            if constexpr (KG > CK) {
+                const int sub = (g * EPL) / CK;
+#pragma unroll
+                for (int kg = 0; kg < NKG; ++kg) {
+                    u32x4 a[RB];
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
+                    const int toff = s_taps[kg * TPK + sub];
+                    u32x4 b[4];
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
+                }
+            } else {
+                constexpr int NK = NTAPS * KPT;
+                constexpr int PD = RB <= 2 ? 9 : 3;
+                u32x4 abuf[PD][RB];
+#pragma unroll
+                for (int j = 0; j < PD; ++j)
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+                        abuf[j][rb] = j < NK ? wch[(size_t)(rb0 + rb) * rb_stride + j * 64] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll 1
+                for (int kgb = 0; kgb < NK; kgb += PD) {
+#pragma unroll
+                    for (int j = 0; j < PD; ++j) {
+                        const int kg = kgb + j;
+                        if (kg < NK) {
+                            u32x4 a[RB];
+#pragma unroll
+                            for (int rb = 0; rb < RB; ++rb) a[rb] = abuf[j][rb];
+                            if (kg + PD < NK) {
+#pragma unroll
+                                for (int rb = 0; rb < RB; ++rb) abuf[j][rb] = wch[(size_t)(rb0 + rb) * rb_stride + (kg + PD) * 64];
+                            }
+                            const int tap = kg / KPT, kk = kg - tap * KPT;
+                            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                            const int toff_l = ((dz * 6 + dy) * 18 + dx) * CKB + kk * KG * (int)sizeof(T);
+                            u32x4 b[4];
+#pragma unroll
+                            for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff_l);
+#pragma unroll
+                            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                                for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue of this tile ----
+        const int oz = z0 + wave;
+        if constexpr (EPI == EPI_SOFTMAX2) {
+            if (g == 0) {
+                const float b0 = p.bias ? p.bias[0] : 0.f, b1 = p.bias ? p.bias[1] : 0.f;
+                const size_t V = (size_t)p.D * p.H * p.W;
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) {
+                    const int oy = y0 + cg, ox = x0 + col;
+                    if (!(oz < p.D && oy < p.H && ox < p.W)) continue;
+                    const float l0 = acc[0][cg][0] + b0, l1 = acc[0][cg][1] + b1;
+                    const float mx = fmaxf(l0, l1);
+                    const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx);
+                    const float inv = 1.f / (e0 + e1);
+                    const size_t v = ((size_t)oz * p.H + oy) * p.W + ox;
+                    p.prob[((size_t)n * 2 + 0) * V + v] = e0 * inv;
+                    p.prob[((size_t)n * 2 + 1) * V + v] = e1 * inv;
+                }
+            }
+        } else {
+            T* __restrict__ yout = (T*)p.y;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int row = (rb0 + rb) * 16 + 4 * g;
+                const bool rvalid = row < p.M;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias && rvalid) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv[r] = p.bias[row + r];
+                }
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) {
+                    const int oy = y0 + cg, ox = x0 + col;
+                    if (!(rvalid && oz < p.D && oy < p.H && ox < p.W)) continue;
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = E::rnd(acc[rb][cg][r] + bv[r]);
+                    const size_t e = ((((size_t)n * p.D + oz) * p.H + oy) * p.W + ox) * p.M + row;
+                    if constexpr (sizeof(T) == 4) {
+                        *(f32x4*)((float*)yout + e) = f32x4{v[0], v[1], v[2], v[3]};
+                    } else {
+                        u32x2 pk;
+                        pk[0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
+                        pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
+                        *(u32x2*)((unsigned short*)yout + e) = pk;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ssum[rb][r] += v[r]; ssq[rb][r] += v[r] * v[r]; }
+                }
+            }
+            if (p.y_stats != nullptr) {
+                const int tn = t + (int)gridDim.x;
+                const bool flush = tn >= total_tiles || tn / p.tiles_per_sample != n;     // workgroup-uniform
+                if (flush) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float s = ssum[rb][r], q = ssq[rb][r];
+#pragma unroll
+                            for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                            if (col == 0) {
+                                const int lr = rb * 16 + 4 * g + r;
+                                s_red[(wave * 64 + lr) * 2 + 0] = s;
+                                s_red[(wave * 64 + lr) * 2 + 1] = q;
+                            }
+                            ssum[rb][r] = 0.f; ssq[rb][r] = 0.f;
+                        }
+                    __syncthreads();
+                    if (tid < MT * 2) {
+                        const int lr = tid >> 1, st = tid & 1;
+                        const int row = rb0 * 16 + lr;
+                        if (row < p.M) {
+                            const double tot = (double)s_red[(0 * 64 + lr) * 2 + st] + (double)s_red[(1 * 64 + lr) * 2 + st] +
+                                               (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
+                            atomicAdd(p.y_stats + ((size_t)n * p.M + row) * 2 + st, tot);
+                        }
+                    }
+                    __syncthreads();                     // s_red is reused by a later flush
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int CK, int MT, int EPI>
+static int k3_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
+    const size_t tables = p.x_stats ? (size_t)2 * p.N * p.C * sizeof(float) : 0;
+    const size_t lds = K3_LDS_TILE + (size_t)G1_TILE_VOX * CK * sizeof(T) + tables;
+    if (lds > 160 * 1024) return VS_ESHAPE;
+    auto kern = k3_kernel<T, CK, MT, EPI>;
+    // idempotent one-time opt-in to the full 160 KiB of dynamic LDS (not a stream operation)
+    static const hipError_t attr_err =
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_err != hipSuccess) return (int)attr_err;
+    // persistent grid: a few workgroups per CU, each walking a strided slice of the tile list
+    int wg = 256 * 4 / (row_tiles < 4 ? row_tiles : 4);
+    if (wg < 256) wg = 256;
+    const int gx = tiles_total < wg ? tiles_total : wg;
+    hipLaunchKernelGGL(kern, dim3(gx, row_tiles), dim3(256), lds, stream, p);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}

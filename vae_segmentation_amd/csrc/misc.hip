@@ -454,7 +454,7 @@ extern "C" int vs_bce_bwd(const float* p, const float* t, const float* gout, flo
 }
 
 // ---- multi-tensor optimiser steps -----------------------------------------------------------------------------
-#define MT_CHUNK 65536
+#define MT_CHUNK 4096
 __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* params, const float* const* grads, float* const* bufs,
                                                         const long long* sizes, const int* block_map, float lr, float momentum,
                                                         float wd, int first) {

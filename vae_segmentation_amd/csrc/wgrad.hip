@@ -368,41 +368,46 @@ __global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) {
     g3_finish<NCB>(acc, (float*)s_p, p.ws + (size_t)ks * slab_elems + ((size_t)blockIdx.x * NCB) * 256, wave, col, g);
 }
 
-// Sum the partial slabs (fixed order, fp64) into the reference's [m][c][tap] layout.  64 outputs per block; the four
-// waves each take every 4th slab with 8 loads in flight, then combine through LDS.
+// Sum the partial slabs (fixed order, fp64) into the reference's [m][c][tap] layout.  A block = 64 consecutive slab
+// elements (coalesced reads) x 16 slab partitions; each thread keeps 8 loads in flight, LDS combines the partitions.
 template <int CB, int KIND>
-__global__ __launch_bounds__(256) void g3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int m_real, int c_real, int mbn,
-                                                        int cbn, int nslabs) {
+__global__ __launch_bounds__(1024) void g3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int m_real, int c_real, int mbn,
+                                                         int cbn, int nslabs) {
     using GEO = G3Geo<CB, KIND>;
     constexpr int NTAPS = GEO::NTAPS, NCB = GEO::NCB;
-    __shared__ double red[4][64];
+    __shared__ double red[16][64];
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 64 + lane;
-    const long long total = (long long)m_real * c_real * NTAPS;
+    const size_t slab_elems = (size_t)mbn * cbn * NCB * 256;
+    const size_t e = (size_t)blockIdx.x * 64 + lane;          // element within a slab: [(mb*cbn+cb)][k][col][row]
     double s = 0.0;
-    if (i < total) {
-        const int tap = (int)(i % NTAPS);
-        const int c = (int)((i / NTAPS) % c_real);
-        const int m = (int)(i / ((long long)NTAPS * c_real));
-        const int mb = m >> 4, row = m & 15;
-        int cb, k, col;
-        if (CB == 16) { cb = c >> 4; col = c & 15; k = tap; }
-        else { cb = c >> 3; col = ((tap & 1) << 3) | (c & 7); k = tap >> 1; }
-        const size_t slab_elems = (size_t)mbn * cbn * NCB * 256;
-        const float* src = ws + ((size_t)(mb * cbn + cb) * NCB + k) * 256 + col * 16 + row;
+    if (e < slab_elems) {
+        const float* src = ws + e;
         int sl = part;
-        for (; sl + 28 < nslabs; sl += 32) {
+        for (; sl + 112 < nslabs; sl += 128) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(sl + 4 * j) * slab_elems];
+            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(sl + 16 * j) * slab_elems];
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += (double)v[j];
         }
-        for (; sl < nslabs; sl += 4) s += (double)src[(size_t)sl * slab_elems];
+        for (; sl < nslabs; sl += 16) s += (double)src[(size_t)sl * slab_elems];
     }
     red[part][lane] = s;
     __syncthreads();
-    if (part == 0 && i < total) dw[i] = (float)(red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+    if (part == 0 && e < slab_elems) {
+        double tot = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tot += red[q][lane];
+        const int row = (int)(e & 15), col = (int)((e >> 4) & 15);
+        const int k = (int)((e >> 8) % NCB);
+        const int pair = (int)(e / ((size_t)NCB * 256));
+        const int mb = pair / cbn, cb = pair - mb * cbn;
+        const int m = mb * 16 + row;
+        int c, tap;
+        if (CB == 16) { c = cb * 16 + col; tap = k; }
+        else { c = cb * 8 + (col & 7); tap = 2 * k + (col >> 3); }
+        if (m < m_real && c < c_real && tap < NTAPS) dw[((size_t)m * c_real + c) * NTAPS + tap] = (float)tot;
+    }
 }
 
 static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind, int& cbsz, int& mbn, int& cbn,
@@ -442,8 +447,8 @@ static int g3b_run(const G3Params& p, float* dw, int m_real, int c_real, hipStre
     }
     hipLaunchKernelGGL(kern, dim3(p.mbn * p.cbn, p.ksplit), dim3(256), lds, s, p);
     VS_CHECK_LAUNCH();
-    const long long total = (long long)m_real * c_real * GEO::NTAPS;
-    hipLaunchKernelGGL((g3_reduce_kernel<CB, KIND>), dim3(vs_ceil_div(total, 64)), dim3(256), 0, s, p.ws, dw, m_real,
+    const long long slab_elems = (long long)p.mbn * p.cbn * GEO::NCB * 256;
+    hipLaunchKernelGGL((g3_reduce_kernel<CB, KIND>), dim3(vs_ceil_div(slab_elems, 64)), dim3(1024), 0, s, p.ws, dw, m_real,
                        c_real, p.mbn, p.cbn, p.ksplit);
     VS_CHECK_LAUNCH();
     return VS_OK;
@@ -461,8 +466,8 @@ static int g3_run(const G3Params& p, float* dw, int m_real, int c_real, hipStrea
     }
     hipLaunchKernelGGL(kern, dim3(p.mbn * p.cbn, p.ksplit), dim3(256), lds, s, p);
     VS_CHECK_LAUNCH();
-    const long long total = (long long)m_real * c_real * GEO::NTAPS;
-    hipLaunchKernelGGL((g3_reduce_kernel<CB, KIND>), dim3(vs_ceil_div(total, 64)), dim3(256), 0, s, p.ws, dw, m_real,
+    const long long slab_elems = (long long)p.mbn * p.cbn * GEO::NCB * 256;
+    hipLaunchKernelGGL((g3_reduce_kernel<CB, KIND>), dim3(vs_ceil_div(slab_elems, 64)), dim3(1024), 0, s, p.ws, dw, m_real,
                        c_real, p.mbn, p.cbn, p.ksplit);
     VS_CHECK_LAUNCH();
     return VS_OK;

@@ -197,6 +197,7 @@ class VAE(nn.Module):
         if not mid_input:
             if x.shape[-1] != self.spatial:
                 raise ValueError("VAE built for spatial=%d got input side %d" % (self.spatial, x.shape[-1]))
+            ops.stats_arena_begin(x.device)
             a = Act(ops.PackPlanar.apply(x, self.kernel_dtype), None)
             a = self.in_block(a)
             for blk in (self.down1, self.down2, self.down3, self.down4, self.down5):
@@ -211,6 +212,7 @@ class VAE(nn.Module):
             else:
                 z = x_mean
         else:
+            ops.stats_arena_begin(x.device)
             z = x
         h = ops.LinearToCL.apply(z, self.fc2.weight, self.fc2.bias, self.top_ch, self.side, self.kernel_dtype)
         a = Act(h, None)
@@ -250,6 +252,7 @@ class Segmentation(nn.Module):
         ops._require_cuda(x)
         if any(s % 16 for s in x.shape[2:]):
             raise ValueError("Segmentation needs spatial sizes that are multiples of 16, got %s" % (tuple(x.shape[2:]),))
+        ops.stats_arena_begin(x.device)
         a = Act(ops.PackPlanar.apply(x, self.kernel_dtype), None)
         x1 = self.in_block(a)
         x2 = self.down1(x1)

@@ -143,8 +143,32 @@ def clear_pack_cache():
 # ------------------------------------------------------------------------------------------------
 # raw launch helpers (no autograd)
 # ------------------------------------------------------------------------------------------------
-def _new_stats(n, c, device):
-    return torch.zeros(n, c, 2, dtype=torch.float64, device=device)
+# The fp64 (sum, sumsq) buffers must be zero before their producer's atomics; allocating each with torch.zeros costs
+# one ~4 us fill launch per layer (~170 per step).  Instead the top-level modules open an arena per forward: ONE zeroed
+# fp64 buffer sized from the previous step's use, from which the per-layer buffers are carved as views (the views keep
+# the arena's storage alive for backward; a new forward gets a new arena, so nothing is ever re-zeroed under a reader).
+_ARENA = {"buf": None, "off": 0, "used": 0, "need": 1 << 14}
+
+
+def stats_arena_begin(device):
+    """Start a new zeroed arena (call at the top of a forward pass; backward keeps carving from the same one)."""
+    a = _ARENA
+    a["need"] = max(a["need"], a["used"])
+    a["buf"] = torch.zeros(a["need"] + (a["need"] >> 2), dtype=torch.float64, device=device)
+    a["off"] = 0
+    a["used"] = 0
+
+
+def _new_stats(n, c, device, width=2):
+    a = _ARENA
+    cnt = n * c * width
+    a["used"] += cnt
+    buf = a["buf"]
+    if buf is None or buf.device != device or a["off"] + cnt > buf.numel():
+        return torch.zeros(n, c, width, dtype=torch.float64, device=device)
+    out = buf[a["off"]:a["off"] + cnt].view(n, c, width)
+    a["off"] += cnt
+    return out
 
 
 def conv_gather(x, xs, wp, bias, m_out, kind, want_stats, real_channels=None):

@@ -7,7 +7,7 @@ import torch
 from . import ops
 from ._lib import check, lib
 
-_CHUNK = 65536
+_CHUNK = 4096        # must equal MT_CHUNK in csrc/misc.hip
 
 
 class _Tables:
