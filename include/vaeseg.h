@@ -76,6 +76,16 @@ int vs_conv_gather_fwd(const void* x, const double* x_stats, const void* w_packe
 int vs_conv_scatter_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                         void* y, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);
 
+/* Backward-data forms of the two calls above with the InstanceNorm+ReLU-backward REDUCTION fused into the epilogue:
+ * y here is g = dL/da of a lazy activation a = relu(instnorm(mask_x)) (mask_x: raw tensor shaped like y, mask_stats
+ * its (sum,sumsq)); besides writing g the kernel ACCUMULATES sums[n][m] = (sum g*[xhat>0], sum g*[xhat>0]*xhat)
+ * (caller zeroes), i.e. exactly what vs_instnorm_relu_bwd_reduce(g, mask_x, mask_stats) would return, without re-reading g. */
+int vs_conv_gather_bwd_data(const void* x, const void* w_packed, void* y, const void* mask_x, const double* mask_stats,
+                            double* sums, int n, int d, int h, int w, int c_in, int m_out, int kind, int dtype, float eps,
+                            void* stream);
+int vs_conv_scatter_bwd_data(const void* x, const void* w_packed, void* y, const void* mask_x, const double* mask_stats,
+                             double* sums, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);
+
 /* out_block + Softmax(dim=1) fused (joint_model.py:224-225,265-266,366-367,386-388):
  * prob[n][k][v] (planar fp32, k < 2) = softmax_k( bias[k] + conv3x3x3(act(x))[k] ). */
 int vs_conv_k3_softmax2_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,

@@ -2,7 +2,7 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import joint_model as M
 from oracle import ref_cpu as O
 from vae_segmentation_amd import ops

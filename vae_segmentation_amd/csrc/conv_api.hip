@@ -21,12 +21,13 @@ static int check_common(const void* x, const void* w, int n, int d, int h, int w
     if (!(c_in == 8 || c_in == 16 || (c_in % 32 == 0 && c_in > 0 && c_in <= 256))) return VS_ESHAPE;
     if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return VS_EALIGN;
+    if ((double)n * d * h * w_ * c_in >= 2147483648.0) return VS_ESHAPE;      // kernels index activations with 32-bit element offsets
     return VS_OK;
 }
 
-extern "C" int vs_conv_gather_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
-                                  void* y, double* y_stats, int n, int d, int h, int w, int c_in, int m_out,
-                                  int kind, int dtype, float eps, void* stream) {
+static int gather_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                       void* y, double* y_stats, const void* mask_x, const double* mask_stats, double* sums,
+                       int n, int d, int h, int w, int c_in, int m_out, int kind, int dtype, float eps, void* stream) {
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
     if (!y || m_out <= 0 || m_out % 8 || ((uintptr_t)y & 15)) return VS_EINVAL;
@@ -34,6 +35,8 @@ extern "C" int vs_conv_gather_fwd(const void* x, const double* x_stats, const vo
     if (kind == VS_CONV_K2S2 && ((d | h | w) & 1)) return VS_ESHAPE;
     G1Params p{};
     p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = y; p.y_stats = y_stats; p.prob = nullptr;
+    p.mask_x = mask_x; p.mask_stats = mask_stats; p.sums = sums;
+    if (sums && (!mask_x || !mask_stats || y_stats)) return VS_EINVAL;
     p.N = n; p.D = d; p.H = h; p.W = w;
     p.C = c_in; p.M = m_out;
     p.rb_total = (m_out + 15) / 16;
@@ -52,6 +55,7 @@ extern "C" int vs_conv_gather_fwd(const void* x, const double* x_stats, const vo
         p.tiles_per_sample = vs_ceil_div((long long)p.Do * p.Ho * p.Wo, 256);
     }
     tiles = (long long)p.tiles_per_sample * n;
+    p.inv_count_out = 1.0 / ((double)p.Do * p.Ho * p.Wo);
     const int rows16 = p.rb_total * 16;
     const int mt = pick_mt(rows16, tiles);
     const int row_tiles = rows16 / mt;
@@ -61,14 +65,29 @@ extern "C" int vs_conv_gather_fwd(const void* x, const double* x_stats, const vo
     return g1_dispatch_k2s2(p, dtype, ck, mt, (int)tiles, row_tiles, (hipStream_t)stream);
 }
 
-extern "C" int vs_conv_scatter_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
-                                   void* y, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps,
-                                   void* stream) {
+extern "C" int vs_conv_gather_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                                  void* y, double* y_stats, int n, int d, int h, int w, int c_in, int m_out,
+                                  int kind, int dtype, float eps, void* stream) {
+    return gather_impl(x, x_stats, w_packed, bias, y, y_stats, nullptr, nullptr, nullptr, n, d, h, w, c_in, m_out, kind, dtype, eps, stream);
+}
+
+extern "C" int vs_conv_gather_bwd_data(const void* x, const void* w_packed, void* y, const void* mask_x,
+                                       const double* mask_stats, double* sums, int n, int d, int h, int w, int c_in,
+                                       int m_out, int kind, int dtype, float eps, void* stream) {
+    if (!mask_x || !mask_stats || !sums) return VS_EINVAL;
+    return gather_impl(x, nullptr, w_packed, nullptr, y, nullptr, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, kind, dtype, eps, stream);
+}
+
+static int scatter_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias, void* y,
+                        const void* mask_x, const double* mask_stats, double* sums, int n, int d, int h, int w, int c_in,
+                        int m_out, int dtype, float eps, void* stream) {
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
     if (!y || m_out <= 0 || m_out % 8 || ((uintptr_t)y & 15)) return VS_EINVAL;
     G1Params p{};
     p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = y; p.y_stats = nullptr; p.prob = nullptr;
+    p.mask_x = mask_x; p.mask_stats = mask_stats; p.sums = sums;
+    p.inv_count_out = 1.0 / (8.0 * d * h * w);
     p.N = n; p.D = d; p.H = h; p.W = w;
     p.Do = d; p.Ho = h; p.Wo = w;
     p.C = c_in; p.M = m_out;
@@ -84,6 +103,19 @@ extern "C" int vs_conv_scatter_fwd(const void* x, const double* x_stats, const v
     return g1_dispatch_pw(p, dtype, ck, mt, (int)tiles, rows16 / mt, (hipStream_t)stream);
 }
 
+extern "C" int vs_conv_scatter_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                                   void* y, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps,
+                                   void* stream) {
+    return scatter_impl(x, x_stats, w_packed, bias, y, nullptr, nullptr, nullptr, n, d, h, w, c_in, m_out, dtype, eps, stream);
+}
+
+extern "C" int vs_conv_scatter_bwd_data(const void* x, const void* w_packed, void* y, const void* mask_x,
+                                        const double* mask_stats, double* sums, int n, int d, int h, int w, int c_in,
+                                        int m_out, int dtype, float eps, void* stream) {
+    if (!mask_x || !mask_stats || !sums) return VS_EINVAL;
+    return scatter_impl(x, nullptr, w_packed, nullptr, y, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, dtype, eps, stream);
+}
+
 extern "C" int vs_conv_k3_softmax2_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                                        float* prob, int n, int d, int h, int w, int c_in, int dtype, float eps,
                                        void* stream) {
@@ -92,6 +124,7 @@ extern "C" int vs_conv_k3_softmax2_fwd(const void* x, const double* x_stats, con
     if (!prob || c_in != 8) return VS_ESHAPE;
     G1Params p{};
     p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = nullptr; p.y_stats = nullptr; p.prob = prob;
+    p.mask_x = nullptr; p.mask_stats = nullptr; p.sums = nullptr; p.inv_count_out = 1.0 / ((double)d * h * w);
     p.N = n; p.D = d; p.H = h; p.W = w;
     p.Do = d; p.Ho = h; p.Wo = w;
     p.C = c_in; p.M = 8;

@@ -20,6 +20,12 @@ struct G1Params {
     void* y;
     double* y_stats;
     float* prob;
+    // optional fused InstanceNorm+ReLU-backward reduction on the OUTPUT g (backward-data use): with a = relu(norm(mx)),
+    // sums[n][m] += (sum g*[xhat>0], sum g*[xhat>0]*xhat) over the voxels this kernel writes
+    const void* mask_x;
+    const double* mask_stats;
+    double* sums;
+    double inv_count_out;
     int N, D, H, W;       // input grid
     int Do, Ho, Wo;       // column grid (K3: = input; K2S2: input/2; PW: = input)
     int C;                // input channels (padded)
@@ -86,6 +92,16 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         for (int c = tid; c < p.C; c += 256) {
             float m, r;
             stats_to_mean_rstd(p.x_stats + ((size_t)n * p.C + c) * 2, p.inv_count_in, p.eps, m, r);
+            s_mean[c] = m;
+            s_rstd[c] = r;
+        }
+    }
+    if (p.sums != nullptr) {
+        // fused IN-backward sums (backward-data use; x_stats is NULL then, so the tables are free): mean / rstd of the
+        // mask tensor's channels of this sample
+        for (int c = tid; c < p.M; c += 256) {
+            float m, r;
+            stats_to_mean_rstd(p.mask_stats + ((size_t)n * p.M + c) * 2, p.inv_count_out, p.eps, m, r);
             s_mean[c] = m;
             s_rstd[c] = r;
         }
@@ -282,11 +298,11 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     }
 
     T* __restrict__ yout = (T*)p.y;
-    float ssum[RB][4], ssq[RB][4];
+    float ssum[RB][4], ssq[RB][4], mk_mean[RB][4], mk_rstd[RB][4];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ssum[rb][r] = 0.f; ssq[rb][r] = 0.f; }
+        for (int r = 0; r < 4; ++r) { ssum[rb][r] = 0.f; ssq[rb][r] = 0.f; mk_mean[rb][r] = 0.f; mk_rstd[rb][r] = 1.f; }
 
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -298,6 +314,10 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         if (p.bias && rvalid) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[r] = p.bias[m + r];
+        }
+        if (p.sums != nullptr && rvalid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { mk_mean[rb][r] = s_mean[m + r]; mk_rstd[rb][r] = s_rstd[m + r]; }
         }
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) {
@@ -320,12 +340,31 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                 pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
                 *(u32x2*)((unsigned short*)yout + e) = pk;
             }
+            if (p.sums != nullptr) {
+                float xv[4];
+                if constexpr (sizeof(T) == 4) {
+                    const f32x4 xx = *(const f32x4*)((const float*)p.mask_x + e);
+                    xv[0] = xx[0]; xv[1] = xx[1]; xv[2] = xx[2]; xv[3] = xx[3];
+                } else {
+                    const u32x2 xx = *(const u32x2*)((const unsigned short*)p.mask_x + e);
+                    xv[0] = __uint_as_float(xx[0] << 16); xv[1] = __uint_as_float(xx[0] & 0xffff0000u);
+                    xv[2] = __uint_as_float(xx[1] << 16); xv[3] = __uint_as_float(xx[1] & 0xffff0000u);
+                }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { ssum[rb][r] += v[r]; ssq[rb][r] += v[r] * v[r]; }
+                for (int r = 0; r < 4; ++r) {
+                    const float xh = (xv[r] - mk_mean[rb][r]) * mk_rstd[rb][r];
+                    const float gm = xh > 0.f ? v[r] : 0.f;
+                    ssum[rb][r] += gm; ssq[rb][r] += gm * xh;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ssum[rb][r] += v[r]; ssq[rb][r] += v[r] * v[r]; }
+            }
         }
     }
 
-    if (EPI == EPI_RAW && p.y_stats != nullptr) {
+    double* const red_dst = p.sums != nullptr ? p.sums : p.y_stats;
+    if ((EPI == EPI_RAW || EPI == EPI_SCATTER) && red_dst != nullptr) {
         // reduce over the 16 columns held by lanes with equal g, then over waves, then one fp64 atomic per (m, stat)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -341,14 +380,22 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                 }
             }
         __syncthreads();
-        if (tid < MT * 2) {
-            const int lr = tid >> 1, st = tid & 1;
-            const int row = rb0 * 16 + lr;
-            if (row < p.M) {
-                double tot = (double)s_red[(0 * 64 + lr) * 2 + st] + (double)s_red[(1 * 64 + lr) * 2 + st] +
-                             (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
-                atomicAdd(p.y_stats + ((size_t)n * p.M + row) * 2 + st, tot);
+        // one atomic per (channel, statistic) per workgroup; scatter rows (tap, channel) of equal channel are folded first
+        const int nch_here = (EPI == EPI_SCATTER && p.M < MT) ? p.M : MT;
+        if (tid < nch_here * 2) {
+            const int lc = tid >> 1, st = tid & 1;
+            double tot = 0.0;
+            int ch_out = -1;
+            for (int lr = lc; lr < MT; lr += nch_here) {
+                const int row = rb0 * 16 + lr;
+                const bool rok = EPI == EPI_SCATTER ? (row < 8 * p.M) : (row < p.M);
+                if (rok) {
+                    ch_out = EPI == EPI_SCATTER ? row % p.M : row;
+                    tot += (double)s_red[(0 * 64 + lr) * 2 + st] + (double)s_red[(1 * 64 + lr) * 2 + st] +
+                           (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
+                }
             }
+            if (ch_out >= 0) atomicAdd(red_dst + ((size_t)n * p.M + ch_out) * 2 + st, tot);
         }
     }
 }

@@ -8,6 +8,7 @@
 // (issue-early / write-late staging).  Per-(n,c) statistics are kept in registers across the tiles of one sample and
 // flushed with one fp64 atomic per (row, statistic) when the sample changes.
 #pragma once
+#include <stdlib.h>
 #include "igemm.h"
 
 #define K3_LDS_RED 0          // float[4][64][2]
@@ -35,6 +36,8 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     char* s_tile = smem + K3_LDS_TILE;
     float* s_mean = (float*)(s_tile + G1_TILE_VOX * CKB);
     float* s_rstd = s_mean + p.N * p.C;
+    float* s_mkm = s_rstd + p.N * p.C;                   // mean / rstd of the mask tensor's channels (fused IN-bwd sums)
+    float* s_mkr = s_mkm + p.N * p.M;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int rb0 = blockIdx.y * RB;
@@ -50,6 +53,14 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
             s_rstd[i] = r;
         }
     }
+    if (p.sums != nullptr) {
+        for (int i = tid; i < p.N * p.M; i += 256) {
+            float m, r;
+            stats_to_mean_rstd(p.mask_stats + (size_t)i * 2, p.inv_count_out, p.eps, m, r);
+            s_mkm[i] = m;
+            s_mkr[i] = r;
+        }
+    }
     if (tid < 32) {
         const int t = tid < 27 ? tid : 13;
         const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
@@ -63,8 +74,24 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     const size_t rb_stride = (size_t)p.nch * NKG * 64;
 
     // ---- staging helpers --------------------------------------------------------------------------------
+    // The integer work of mapping a thread's fragments to tile voxels (divisions by 18 / 6 / U, 64-bit offsets) used to
+    // cost ~80 VALU instructions per fragment per stage and made the kernel issue-bound (PMC: 10k VALU vs 0.9k MFMA per
+    // wave on the 3^3 layers).  Everything tile-independent is computed once per thread: the fragment's offset relative
+    // to the tile origin, its packed tile coordinates (for the bounds test) and its LDS byte offset.
     u32x4 vals[SB];
     bool ok[SB];
+    int rel_off[SB], tzyx[SB], lds_w[SB];
+    if constexpr (PF) {
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            const int u = tid + b * 256;
+            const int tv = u / U, part = u - tv * U;
+            const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / 108;
+            rel_off[b] = ((tz_ * p.H + ty_) * p.W + tx_) * p.C + part * EPL;
+            tzyx[b] = u < NU ? (tz_ | (ty_ << 8) | (tx_ << 16)) : 0x00ffffff;      // out-of-list fragments fail every bounds test
+            lds_w[b] = tv * CKB + part * 16;
+        }
+    }
     auto tile_origin = [&](int t, int& n, int& z0, int& y0, int& x0) {
         n = t / p.tiles_per_sample;
         const int tl = t - n * p.tiles_per_sample;
@@ -75,15 +102,27 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     auto stage_load = [&](int t, int ch, int it0) {
         int n, z0, y0, x0;
         tile_origin(t, n, z0, y0, x0);
+        if constexpr (PF) {
+            // element offset of tile voxel (0,0,0) = volume voxel (z0-1, y0-1, x0-1); fits 32 bits (checked on the host)
+            const int base = (((n * p.D + z0 - 1) * p.H + y0 - 1) * p.W + x0 - 1) * p.C + ch * CK;
 #pragma unroll
-        for (int b = 0; b < SB; ++b) {
-            const int u = tid + (it0 + b) * 256;
-            const int tv = u / U, part = u - tv * U;
-            const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / 108;
-            const int gz = z0 + tz_ - 1, gy = y0 + ty_ - 1, gx = x0 + tx_ - 1;
-            ok[b] = (it0 + b < NIT) && u < NU && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            const size_t e = ok[b] ? ((((size_t)n * p.D + gz) * p.H + gy) * p.W + gx) * p.C + ch * CK + part * EPL : 0;
-            vals[b] = *(const u32x4*)(xin + e);
+            for (int b = 0; b < SB; ++b) {
+                const int gz = z0 - 1 + (tzyx[b] & 0xff), gy = y0 - 1 + ((tzyx[b] >> 8) & 0xff), gx = x0 - 1 + (tzyx[b] >> 16);
+                ok[b] = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                const int e = ok[b] ? base + rel_off[b] : 0;
+                vals[b] = *(const u32x4*)(xin + e);
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                const int u = tid + (it0 + b) * 256;
+                const int tv = u / U, part = u - tv * U;
+                const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / 108;
+                const int gz = z0 + tz_ - 1, gy = y0 + ty_ - 1, gx = x0 + tx_ - 1;
+                ok[b] = (it0 + b < NIT) && u < NU && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                const size_t e = ok[b] ? ((((size_t)n * p.D + gz) * p.H + gy) * p.W + gx) * p.C + ch * CK + part * EPL : 0;
+                vals[b] = *(const u32x4*)(xin + e);
+            }
         }
     };
     auto stage_write = [&](int n, int ch, int it0) {
@@ -91,11 +130,15 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
         for (int b = 0; b < SB; ++b) {
             const int u = tid + (it0 + b) * 256;
             if (it0 + b < NIT && u < NU) {
-                const int tv = u / U, part = u - tv * U;
-                u32x4 val = vals[b];
-                if (has_stats) val = act_transform<T, CK>(val, s_mean + n * p.C, s_rstd + n * p.C, ch * CK + part * EPL);
-                if (!ok[b]) val = u32x4{0u, 0u, 0u, 0u};
-                *(u32x4*)(s_tile + tv * CKB + part * 16) = val;
+                int lw, c0;
+                if constexpr (PF) { lw = lds_w[b]; c0 = ch * CK + ((lw >> 4) % U) * EPL; }
+                else { const int tv = u / U, part = u - tv * U; lw = tv * CKB + part * 16; c0 = ch * CK + part * EPL; }
+                u32x4 val = u32x4{0u, 0u, 0u, 0u};
+                if (ok[b]) {        // halo fragments outside the volume stay zero and skip the normalisation arithmetic
+                    val = vals[b];
+                    if (has_stats) val = act_transform<T, CK>(val, s_mean + n * p.C, s_rstd + n * p.C, c0);
+                }
+                *(u32x4*)(s_tile + lw) = val;
             }
         }
     };
@@ -105,6 +148,17 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[rb][r] = 0.f; ssq[rb][r] = 0.f; }
+
+    // Single-chunk layers (C <= 16): the workgroup's weight fragments are the same for every tile, so they COULD be loaded
+    // once into registers (optional path, off: see WREG).
+    constexpr bool WREG = false;   // measured: keeping the fragments in registers costs occupancy and runs 15 % slower (49 -> 58 us, 8->8 @96^3)
+    u32x4 wreg[WREG ? NKG : 1][RB];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int kg = 0; kg < NKG; ++kg)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) wreg[kg][rb] = wp[(size_t)(rb0 + rb) * rb_stride + kg * 64 + lane];
+    }
 
     int t = blockIdx.x;
     __syncthreads();                                     // tables visible
@@ -124,9 +178,11 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                 __syncthreads();                         // every wave is done reading the previous stage's tile
                 stage_write(n, ch, 0);
                 __syncthreads();
-                const bool more_ch = ch + 1 < p.nch;
-                const int tn = more_ch ? t : t + (int)gridDim.x;
-                if (tn < total_tiles) stage_load(tn, more_ch ? ch + 1 : 0, 0);
+                if constexpr (KG > CK) {              // (weights in registers or few loads: prefetch right away)
+                    const bool more_ch = ch + 1 < p.nch;
+                    const int tn = more_ch ? t : t + (int)gridDim.x;
+                    if (tn < total_tiles) stage_load(tn, more_ch ? ch + 1 : 0, 0);
+                }
             } else {
                 __syncthreads();
 #pragma unroll 1
@@ -144,7 +200,10 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                 for (int kg = 0; kg < NKG; ++kg) {
                     u32x4 a[RB];
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
+                    for (int rb = 0; rb < RB; ++rb) {
+                        if constexpr (WREG) a[rb] = wreg[kg][rb];
+                        else a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
+                    }
                     const int toff = s_taps[kg * TPK + sub];
                     u32x4 b[4];
 #pragma unroll
@@ -156,32 +215,52 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                 }
             } else {
                 constexpr int NK = NTAPS * KPT;
-                constexpr int PD = RB <= 2 ? 9 : 3;
+                constexpr int PD = RB <= 2 ? 9 : 3;          // prefetch distance in k-groups (27 was tried for RB=1: slower)
                 u32x4 abuf[PD][RB];
 #pragma unroll
                 for (int j = 0; j < PD; ++j)
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
                         abuf[j][rb] = j < NK ? wch[(size_t)(rb0 + rb) * rb_stride + j * 64] : u32x4{0u, 0u, 0u, 0u};
+                // B fragments (LDS) are fetched one k-group ahead as well: with few waves per CU on the deep layers an
+                // un-prefetched ds_read -> MFMA chain exposes the full LDS latency on every MFMA.
+                auto lds_off = [&](int kg) {
+                    const int tap = kg / KPT, kk = kg - tap * KPT;
+                    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+                    return ((dz * 6 + dy) * 18 + dx) * CKB + kk * KG * (int)sizeof(T);
+                };
+                u32x4 bnext[4];
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) bnext[cg] = *(const u32x4*)(s_tile + lds_base[cg] + lds_off(0));
 #pragma unroll 1
                 for (int kgb = 0; kgb < NK; kgb += PD) {
 #pragma unroll
                     for (int j = 0; j < PD; ++j) {
                         const int kg = kgb + j;
                         if (kg < NK) {
-                            u32x4 a[RB];
+                            u32x4 a[RB], b[4];
 #pragma unroll
                             for (int rb = 0; rb < RB; ++rb) a[rb] = abuf[j][rb];
+#pragma unroll
+                            for (int cg = 0; cg < 4; ++cg) b[cg] = bnext[cg];
+                            if (kg + 1 < NK) {
+                                const int o = lds_off(kg + 1);
+#pragma unroll
+                                for (int cg = 0; cg < 4; ++cg) bnext[cg] = *(const u32x4*)(s_tile + lds_base[cg] + o);
+                            }
                             if (kg + PD < NK) {
 #pragma unroll
                                 for (int rb = 0; rb < RB; ++rb) abuf[j][rb] = wch[(size_t)(rb0 + rb) * rb_stride + (kg + PD) * 64];
                             }
-                            const int tap = kg / KPT, kk = kg - tap * KPT;
-                            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                            const int toff_l = ((dz * 6 + dy) * 18 + dx) * CKB + kk * KG * (int)sizeof(T);
-                            u32x4 b[4];
-#pragma unroll
-                            for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff_l);
+                            if constexpr (PF) {
+                                // vmcnt retires loads in issue order: the next stage's activation loads are requested only
+                                // after this chunk's last weight fragment, so no weight fragment ever waits behind them
+                                if (kg + PD == NK || (NK <= PD && kg == 0)) {
+                                    const bool more_ch = ch + 1 < p.nch;
+                                    const int tn = more_ch ? t : t + (int)gridDim.x;
+                                    if (tn < total_tiles) stage_load(tn, more_ch ? ch + 1 : 0, 0);
+                                }
+                            }
 #pragma unroll
                             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -238,11 +317,30 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                         pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
                         *(u32x2*)((unsigned short*)yout + e) = pk;
                     }
+                    if (p.sums != nullptr) {
+                        float xv[4];
+                        if constexpr (sizeof(T) == 4) {
+                            const f32x4 xx = *(const f32x4*)((const float*)p.mask_x + e);
+                            xv[0] = xx[0]; xv[1] = xx[1]; xv[2] = xx[2]; xv[3] = xx[3];
+                        } else {
+                            const u32x2 xx = *(const u32x2*)((const unsigned short*)p.mask_x + e);
+                            xv[0] = __uint_as_float(xx[0] << 16); xv[1] = __uint_as_float(xx[0] & 0xffff0000u);
+                            xv[2] = __uint_as_float(xx[1] << 16); xv[3] = __uint_as_float(xx[1] & 0xffff0000u);
+                        }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { ssum[rb][r] += v[r]; ssq[rb][r] += v[r] * v[r]; }
+                        for (int r = 0; r < 4; ++r) {
+                            const float xh = (xv[r] - s_mkm[n * p.M + row + r]) * s_mkr[n * p.M + row + r];
+                            const float gm = xh > 0.f ? v[r] : 0.f;
+                            ssum[rb][r] += gm; ssq[rb][r] += gm * xh;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ssum[rb][r] += v[r]; ssq[rb][r] += v[r] * v[r]; }
+                    }
                 }
             }
-            if (p.y_stats != nullptr) {
+            double* const red_dst = p.sums != nullptr ? p.sums : p.y_stats;
+            if (red_dst != nullptr) {
                 const int tn = t + (int)gridDim.x;
                 const bool flush = tn >= total_tiles || tn / p.tiles_per_sample != n;     // workgroup-uniform
                 if (flush) {
@@ -267,7 +365,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                         if (row < p.M) {
                             const double tot = (double)s_red[(0 * 64 + lr) * 2 + st] + (double)s_red[(1 * 64 + lr) * 2 + st] +
                                                (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
-                            atomicAdd(p.y_stats + ((size_t)n * p.M + row) * 2 + st, tot);
+                            atomicAdd(red_dst + ((size_t)n * p.M + row) * 2 + st, tot);
                         }
                     }
                     __syncthreads();                     // s_red is reused by a later flush
@@ -279,7 +377,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
 
 template <typename T, int CK, int MT, int EPI>
 static int k3_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
-    const size_t tables = p.x_stats ? (size_t)2 * p.N * p.C * sizeof(float) : 0;
+    const size_t tables = (size_t)2 * p.N * p.C * sizeof(float) + (p.sums ? (size_t)2 * p.N * p.M * sizeof(float) : 0);
     const size_t lds = K3_LDS_TILE + (size_t)G1_TILE_VOX * CK * sizeof(T) + tables;
     if (lds > 160 * 1024) return VS_ESHAPE;
     auto kern = k3_kernel<T, CK, MT, EPI>;
@@ -288,7 +386,8 @@ static int k3_launch(const G1Params& p, int tiles_total, int row_tiles, hipStrea
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
     // persistent grid: a few workgroups per CU, each walking a strided slice of the tile list
-    int wg = 256 * 4 / (row_tiles < 4 ? row_tiles : 4);
+    static const int per_cu = getenv("VS_K3_WGS_PER_CU") ? atoi(getenv("VS_K3_WGS_PER_CU")) : 4;   // tuning knob
+    int wg = 256 * per_cu / (row_tiles < per_cu ? row_tiles : per_cu);
     if (wg < 256) wg = 256;
     const int gx = tiles_total < wg ? tiles_total : wg;
     hipLaunchKernelGGL(kern, dim3(gx, row_tiles), dim3(256), lds, stream, p);

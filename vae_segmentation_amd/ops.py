@@ -215,6 +215,52 @@ def conv_scatter(x, xs, wp, bias, m_out):
     return y
 
 
+def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
+    """Gradient w.r.t. the raw tensor x of a lazy activation a = relu(instnorm(x)) that fed a conv:
+    g = conv-backward-data(gy) with the InstanceNorm+ReLU-backward sums accumulated in the same kernel's epilogue,
+    then the (in-place) apply pass.  kind / scatter select the backward-data form of the forward conv."""
+    n, c = x.shape[0], x.shape[-1]
+    sums = _new_stats(n, c, x.device)
+    g = torch.empty_like(x)
+    gn, gd, gh, gw, gc = gy.shape
+    dt = vs_dtype(x)
+    if scatter:
+        kid = nb = fl = None
+        if PROFILE is not None:
+            tiles = gn * ((gd * gh * gw + 255) // 256)
+            kid = "g1_kernel<%s,%d,2,%d,2>" % ("float" if x.dtype == torch.float32 else "unsigned short", min(gc, 32),
+                                               _pick_mt((8 * c + 15) // 16 * 16, tiles))
+            nb = (gy.numel() + 2 * g.numel()) * _esize(x) + 8 * gc * c * _esize(x)
+            fl = 2.0 * (gy.numel() // gc) * 8 * gc * c
+        with _timed(kid, nb, fl, "bwd gy%s->m%d" % (tuple(gy.shape), c)):
+            check(lib.vs_conv_scatter_bwd_data(gy.data_ptr(), wpb.data_ptr(), g.data_ptr(), x.data_ptr(), xs.data_ptr(),
+                                               sums.data_ptr(), gn, gd, gh, gw, gc, c, dt, EPS_IN, _stream()), "conv_scatter_bwd_data")
+    else:
+        kid = nb = fl = None
+        if PROFILE is not None:
+            taps = 27 if kind == VS_CONV_K3 else 8
+            if kind == VS_CONV_K3:
+                tiles = gn * ((gd + 3) // 4) * ((gh + 3) // 4) * ((gw + 15) // 16)
+            else:
+                tiles = n * ((g.numel() // (n * c) + 255) // 256)
+            kid = "g1_kernel<%s,%d,%d,%d,0>" % ("float" if x.dtype == torch.float32 else "unsigned short", min(gc, 32), kind,
+                                                _pick_mt((c + 15) // 16 * 16, tiles))
+            cr = real_channels[0] if real_channels else gc
+            mr = real_channels[1] if real_channels else c
+            vox_out = g.numel() // c
+            nb = (gy.numel() // gc * cr + 2 * vox_out * mr) * _esize(x) + cr * mr * taps * _esize(x)
+            fl = 2.0 * vox_out * taps * cr * mr
+        with _timed(kid, nb, fl, "bwd gy%s->m%d" % (tuple(gy.shape), c)):
+            check(lib.vs_conv_gather_bwd_data(gy.data_ptr(), wpb.data_ptr(), g.data_ptr(), x.data_ptr(), xs.data_ptr(),
+                                              sums.data_ptr(), gn, gd, gh, gw, gc, c, kind, dt, EPS_IN, _stream()), "conv_gather_bwd_data")
+    voxels = x.numel() // (n * c)
+    tname = "float" if x.dtype == torch.float32 else "unsigned short"
+    with _timed("in_relu_bwd_apply_kernel<%s>" % tname, 3 * x.numel() * _esize(x), 6.0 * x.numel(), str(tuple(x.shape))):
+        check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), g.data_ptr(), n, voxels,
+                                             c, dt, EPS_IN, _stream()), "instnorm_relu_bwd_apply")
+    return g
+
+
 def conv_wgrad(p, ps, q, qs, m_real, c_real, kind, out_shape):
     """dW (fp32, reference layout [m][c][taps]) ; the voxel loop runs over p's grid."""
     n, dp, hp, wp_, m_ch = p.shape
@@ -294,8 +340,10 @@ class ConvK3(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, gy.shape[-1], gy.dtype)
-            ga, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K3, False, real_channels=(cout, cin))
-            gx = in_relu_bwd(ga, x, xs)
+            if xs is not None:
+                gx = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K3, real_channels=(cout, cin))
+            else:
+                gx, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K3, False, real_channels=(cout, cin))
         if ctx.needs_input_grad[2]:
             gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K3, weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[3]:
@@ -332,8 +380,10 @@ class ConvK3Softmax(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, x.dtype)
-            ga, _ = conv_gather(gl, None, wpb, None, c, VS_CONV_K3, False)
-            gx = in_relu_bwd(ga, x, xs)
+            if xs is not None:
+                gx = conv_bwd_data_lazy(gl, wpb, x, xs, VS_CONV_K3, real_channels=(2, weight.shape[1]))
+            else:
+                gx, _ = conv_gather(gl, None, wpb, None, c, VS_CONV_K3, False)
         if ctx.needs_input_grad[2]:
             gw = conv_wgrad(gl, None, x, xs, 2, weight.shape[1], VS_CONV_K3, weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[3]:
@@ -362,8 +412,10 @@ class ConvK2S2(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_SCATTER_D1, gy.shape[-1], gy.dtype)
-            ga = conv_scatter(gy, None, wpb, None, x.shape[-1])
-            gx = in_relu_bwd(ga, x, xs)
+            if xs is not None:
+                gx = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K2S2, scatter=True)
+            else:
+                gx = conv_scatter(gy, None, wpb, None, x.shape[-1])
         if ctx.needs_input_grad[2]:
             gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K2S2, weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[3]:
@@ -391,8 +443,10 @@ class ConvT2S2(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D0, gy.shape[-1], gy.dtype)
-            ga, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K2S2, False)
-            gx = in_relu_bwd(ga, x, xs)
+            if xs is not None:
+                gx = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K2S2)
+            else:
+                gx, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K2S2, False)
         if ctx.needs_input_grad[2]:
             gw = conv_wgrad(x, xs, gy, None, cin, cout, VS_CONV_K2S2, weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[3]:
