@@ -187,7 +187,12 @@ def conv_gather(x, xs, wp, bias, m_out, kind, want_stats, real_channels=None):
         else:
             tiles = n * ((y.numel() // (n * m_out) + 255) // 256)
         rows16 = (m_out + 15) // 16 * 16
-        kid = "g1_kernel<%s,%d,%d,%d,0>" % ("float" if x.dtype == torch.float32 else "unsigned short", ck, kind, _pick_mt(rows16, tiles))
+        tname = "float" if x.dtype == torch.float32 else "unsigned short"
+        if kind == VS_CONV_K3:
+            small = x.dtype == torch.bfloat16 and c % 32 == 0 and d * h * w <= 224 and (d + 2) * (h + 2) * (w + 2) <= 512
+            kid = "k3_small_kernel" if small else "k3_kernel<%s,%d,%d,0>" % (tname, ck, _pick_mt(rows16, tiles))
+        else:
+            kid = "g1_kernel<%s,%d,%d,%d,0>" % (tname, ck, kind, _pick_mt(rows16, tiles))
         cr = real_channels[0] if real_channels else c
         mr = real_channels[1] if real_channels else m_out
         vox_out = y.numel() // m_out
@@ -243,8 +248,12 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
                 tiles = gn * ((gd + 3) // 4) * ((gh + 3) // 4) * ((gw + 15) // 16)
             else:
                 tiles = n * ((g.numel() // (n * c) + 255) // 256)
-            kid = "g1_kernel<%s,%d,%d,%d,0>" % ("float" if x.dtype == torch.float32 else "unsigned short", min(gc, 32), kind,
-                                                _pick_mt((c + 15) // 16 * 16, tiles))
+            tname = "float" if x.dtype == torch.float32 else "unsigned short"
+            if kind == VS_CONV_K3:
+                small = x.dtype == torch.bfloat16 and gc % 32 == 0 and gd * gh * gw <= 224 and (gd + 2) * (gh + 2) * (gw + 2) <= 512
+                kid = "k3_small_kernel" if small else "k3_kernel<%s,%d,%d,0>" % (tname, min(gc, 32), _pick_mt((c + 15) // 16 * 16, tiles))
+            else:
+                kid = "g1_kernel<%s,%d,%d,%d,0>" % (tname, min(gc, 32), kind, _pick_mt((c + 15) // 16 * 16, tiles))
             cr = real_channels[0] if real_channels else gc
             mr = real_channels[1] if real_channels else c
             vox_out = g.numel() // c
