@@ -411,7 +411,7 @@ __global__ __launch_bounds__(1024) void g3_reduce_kernel(const float* __restrict
 }
 
 static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind, int& cbsz, int& mbn, int& cbn,
-                    int& ncb, int& tiles_per_sample, int& tyn, int& txn, int& ksplit) {
+                    int& ncb, int& tiles_per_sample, int& tyn, int& txn, int& ksplit, bool short_chains = false) {
     cbsz = c_ch >= 16 ? 16 : 8;
     mbn = (m_ch + 15) / 16;
     cbn = (c_ch + cbsz - 1) / cbsz;
@@ -421,6 +421,9 @@ static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind,
     tiles_per_sample = ((dp + 3) / 4) * tyn * txn;
     const long long total = (long long)tiles_per_sample * n;
     long long want = (512 + (long long)mbn * cbn - 1) / ((long long)mbn * cbn);   // ~2 workgroups per CU overall
+    // fp32 (parity) mode: at most two tiles per workgroup, so an fp32 MFMA accumulator never chains more than 128
+    // products before the fp64 slab reduction
+    if (short_chains && (total + 1) / 2 > want) want = (total + 1) / 2;
     if (want < 1) want = 1;
     if (want > total) want = total;
     // keep the slab workspace <= 64 MiB
@@ -430,8 +433,9 @@ static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind,
 }
 
 extern "C" size_t vs_conv_wgrad_workspace_bytes(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind) {
+    // sized for the fp32-mode plan (the larger of the two), so one query serves both dtypes
     int cbsz, mbn, cbn, ncb, tps, tyn, txn, ksplit;
-    g3_plan(n, dp, hp, wp, m_ch, c_ch, kind == VS_CONV_K3 ? VS_CONV_K3 : VS_CONV_K2S2, cbsz, mbn, cbn, ncb, tps, tyn, txn, ksplit);
+    g3_plan(n, dp, hp, wp, m_ch, c_ch, kind == VS_CONV_K3 ? VS_CONV_K3 : VS_CONV_K2S2, cbsz, mbn, cbn, ncb, tps, tyn, txn, ksplit, true);
     return (size_t)ksplit * mbn * cbn * ncb * 256 * 4;
 }
 
@@ -483,7 +487,7 @@ extern "C" int vs_conv_wgrad(const void* P, const double* p_stats, const void* Q
     if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
     G3Params p{};
     int cbsz, ncb;
-    g3_plan(n, dp, hp, wp, m_ch, c_ch, kind, cbsz, p.mbn, p.cbn, ncb, p.tiles_per_sample, p.tyn, p.txn, p.ksplit);
+    g3_plan(n, dp, hp, wp, m_ch, c_ch, kind, cbsz, p.mbn, p.cbn, ncb, p.tiles_per_sample, p.tyn, p.txn, p.ksplit, dtype == VS_F32);
     const size_t need = (size_t)p.ksplit * p.mbn * p.cbn * ncb * 256 * 4;
     if (workspace_bytes < need) return VS_EWORKSPACE;
     p.P = P; p.P_stats = p_stats; p.Q = Q; p.Q_stats = q_stats; p.ws = (float*)workspace;
