@@ -57,6 +57,17 @@ size_t vs_packed_weight_bytes(int rows, int c_pad, int ntaps, int dtype);
 /* src: float[d0][d1][ntaps]; c_pad >= the k-side channel count, zero-filled beyond it. */
 int vs_pack_weight(const float* src, void* dst, int d0, int d1, int ntaps, int c_pad, int form, int dtype, void* stream);
 
+/* One launch packing many weights (all trainable convs of a network after an optimiser step): descs is a DEVICE array. */
+typedef struct vs_pack_desc {
+    const float* src;      /* float[d0][d1][ntaps] */
+    void* dst;             /* packed image, vs_packed_weight_bytes() bytes */
+    int d0, d1, ntaps, c_pad, form, dtype;
+    int first_block;       /* index of this weight's first 256-thread block in the launch */
+    int pad_;
+    long long total;       /* packed elements of this weight */
+} vs_pack_desc;
+int vs_pack_weight_multi(const vs_pack_desc* descs, int n_desc, int total_blocks, void* stream);
+
 /* ---- convolutions (implicit GEMM on MFMA) ------------------------------------------------------ */
 /* y[n,v,m] = bias[m] + sum_{tap,c} act(x)[n, v*s + off(tap) - p, c] * W[m][tap][c]
  *   kind K3  : x,y both (N,D,H,W);   kind K2S2: x is (N,D,H,W), y is (N,D/2,H/2,W/2).

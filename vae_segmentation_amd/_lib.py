@@ -37,6 +37,7 @@ def parse_header(path=HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
     protos = {}
     for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(vs_\w+)\s*\(([^)]*)\)\s*;", src):
         ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()

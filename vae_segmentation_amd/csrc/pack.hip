@@ -4,10 +4,9 @@
 // Packed image: [row-block rb][channel chunk ch][k-group kg][lane][EPL elements]
 //   row = rb*16 + (lane & 15);  k within the chunk = kg*KG + (lane >> 4)*EPL + j;  tap = k / CK, c = ch*CK + k % CK
 template <typename T>
-__global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int d0, int d1, int ntaps,
-                                   int c_pad, int form, long long total) {
+__device__ __forceinline__ void pack_one(const float* __restrict__ src, T* __restrict__ dst, int d0, int d1, int ntaps,
+                                         int c_pad, int form, long long total, long long i) {
     constexpr int EPL = ET<T>::EPL, KG = ET<T>::KG;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int CK = c_pad < 32 ? c_pad : 32;
     const int nch = c_pad / CK;
@@ -33,6 +32,32 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict_
         if (t < ntaps && tap < 1 && c < d0) v = src[((size_t)c * d1 + m) * ntaps + t];
     }
     ET<T>::st(dst + i, v);
+}
+
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int d0, int d1, int ntaps,
+                                   int c_pad, int form, long long total) {
+    pack_one<T>(src, dst, d0, d1, ntaps, c_pad, form, total, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const vs_pack_desc* __restrict__ descs, int n_desc) {
+    // binary search: last descriptor whose first_block <= blockIdx.x
+    int lo = 0, hi = n_desc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const vs_pack_desc d = descs[lo];
+    const long long i = (long long)(blockIdx.x - d.first_block) * 256 + threadIdx.x;
+    if (d.dtype == VS_F32) pack_one<float>(d.src, (float*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
+    else pack_one<unsigned short>(d.src, (unsigned short*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
+}
+
+extern "C" int vs_pack_weight_multi(const vs_pack_desc* descs, int n_desc, int total_blocks, void* stream) {
+    if (!descs || n_desc <= 0 || total_blocks <= 0) return VS_EINVAL;
+    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, descs, n_desc);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
 }
 
 static long long packed_elems(int rows, int c_pad, int gemm_taps, int dtype) {

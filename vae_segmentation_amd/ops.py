@@ -115,21 +115,70 @@ def pack_weight(w, form, c_pad, dtype):
 
 
 def pack_weight_cached(param, form, c_pad, dtype):
-    """Frozen parameters (requires_grad False) are packed once per (tensor object, version); the cache lives on
-    the tensor itself, so it dies with it and a recycled device address can never alias another weight."""
-    if param.requires_grad:
-        return pack_weight(param, form, c_pad, dtype)
+    """Packed image of a conv weight.
+    Frozen parameters: packed once per (tensor object, version, epoch); the cache lives on the tensor itself, so it dies
+    with it and a recycled device address can never alias another weight.
+    Trainable parameters: the first use registers (param, form, c_pad, dtype) in a repack plan and packs it; afterwards
+    `repack_trainable()` — called by the native optimisers right after their update kernel — refreshes EVERY registered
+    image in one multi-tensor launch, so a training step issues no per-layer pack launches.  An image is trusted only if
+    it was packed at the parameter's current (version, epoch); otherwise it is re-packed on the spot."""
     dt = VS_F32 if dtype == torch.float32 else VS_BF16
+    key = (form, c_pad, dt)
+    if param.requires_grad:
+        plan = getattr(param, "_vs_pack_plan", None)
+        if plan is None:
+            plan = {}
+            param._vs_pack_plan = plan
+        ent = plan.get(key)
+        stamp = (param._version, param.data_ptr(), _TRAIN_EPOCH[0])
+        if ent is None:
+            buf = pack_weight(param, form, c_pad, dtype)
+            plan[key] = [buf, stamp]
+            _REPACK["params"][id(param)] = param
+            _REPACK["dirty"] = True
+            return buf
+        if ent[1] != stamp:
+            ent[0].copy_(pack_weight(param, form, c_pad, dtype))
+            ent[1] = stamp
+        return ent[0]
     cache = getattr(param, "_vs_pack_cache", None)
     if cache is None or cache[0] != (param._version, param.data_ptr(), _PACK_EPOCH[0]):
         cache = ((param._version, param.data_ptr(), _PACK_EPOCH[0]), {})
         param._vs_pack_cache = cache
-    key = (form, c_pad, dt)
     hit = cache[1].get(key)
     if hit is None:
         hit = pack_weight(param, form, c_pad, dtype)
         cache[1][key] = hit
     return hit
+
+
+_TRAIN_EPOCH = [0]
+_REPACK = {"params": {}, "dirty": True, "descs": None, "blocks": 0, "n": 0, "entries": []}
+
+
+def repack_trainable():
+    """Re-pack every registered trainable weight image with ONE launch (call after the weights changed in place)."""
+    import struct
+    r = _REPACK
+    live = [p for p in r["params"].values() if getattr(p, "_vs_pack_plan", None)]
+    if not live:
+        return
+    if r["dirty"]:
+        recs, entries, blocks = [], [], 0
+        for p in live:
+            d0, d1 = p.shape[0], p.shape[1]
+            ntaps = p[0, 0].numel()
+            for (form, c_pad, dt), ent in p._vs_pack_plan.items():
+                total = ent[0].numel() // (4 if dt == VS_F32 else 2)
+                recs.append(struct.pack("<QQiiiiiiiiq", p.data_ptr(), ent[0].data_ptr(), d0, d1, ntaps, c_pad, form, dt, blocks, 0, total))
+                entries.append((p, ent))
+                blocks += (total + 255) // 256
+        raw = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8)
+        r["descs"] = raw.to(live[0].device)
+        r["blocks"], r["n"], r["entries"], r["dirty"] = blocks, len(recs), entries, False
+    check(lib.vs_pack_weight_multi(r["descs"].data_ptr(), r["n"], r["blocks"], _stream()), "pack_weight_multi")
+    for p, ent in r["entries"]:
+        ent[1] = (p._version, p.data_ptr(), _TRAIN_EPOCH[0])
 
 
 _PACK_EPOCH = [0]
@@ -138,6 +187,13 @@ _PACK_EPOCH = [0]
 def clear_pack_cache():
     """Invalidate every cached packed weight (call after writing frozen weights through raw pointers, e.g. EMA)."""
     _PACK_EPOCH[0] += 1
+
+
+def weights_changed():
+    """Called by the native optimisers after they updated parameters through raw pointers (torch's version counters do
+    not see that): start a new epoch and refresh all registered trainable images in one launch."""
+    _TRAIN_EPOCH[0] += 1
+    repack_trainable()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -165,6 +221,7 @@ def _new_stats(n, c, device, width=2):
     a["used"] += cnt
     buf = a["buf"]
     if buf is None or buf.device != device or a["off"] + cnt > buf.numel():
+        a["fallbacks"] = a.get("fallbacks", 0) + 1
         return torch.zeros(n, c, width, dtype=torch.float64, device=device)
     out = buf[a["off"]:a["off"] + cnt].view(n, c, width)
     a["off"] += cnt
@@ -339,11 +396,14 @@ class ConvK3(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.bias_shape = None if bias is None else bias.shape
         ctx.mark_non_differentiable(ys)
+        ctx.set_materialize_grads(False)      # otherwise autograd zero-fills a gradient for the stats output every backward
         return y, ys
 
     @staticmethod
     def backward(ctx, gy, _gys):
         x, xs, weight = ctx.saved_tensors
+        if gy is None:
+            return None, None, None, None
         gy = _contig(gy)
         cout, cin = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
@@ -356,7 +416,7 @@ class ConvK3(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K3, weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            gb = torch.zeros(ctx.bias_shape, dtype=torch.float32, device=gy.device)
+            gb = _new_stats(1, (ctx.bias_shape[0] + 1) // 2, gy.device, width=1).view(-1).view(torch.float32)[:ctx.bias_shape[0]]
         return gx, None, gw, gb
 
 

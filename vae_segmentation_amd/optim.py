@@ -78,6 +78,7 @@ class SGD(torch.optim.Optimizer):
             check(lib.vs_sgd_momentum_multi(pp.data_ptr(), gp.data_ptr(), bp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb,
                                             float(group["lr"]) * float(grad_scale), float(group["momentum"]),
                                             float(group["weight_decay"]), 0, _stream()), "sgd_momentum_multi")
+        ops.weights_changed()
         return None
 
 
@@ -112,6 +113,7 @@ class Adam(torch.optim.Optimizer):
             check(lib.vs_adam_multi(pp.data_ptr(), gp.data_ptr(), ap.data_ptr(), vp.data_ptr(), sizes.data_ptr(), bm.data_ptr(),
                                     nb, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                     float(group["weight_decay"]), step, _stream()), "adam_multi")
+        ops.weights_changed()
         return None
 
 
