@@ -142,6 +142,9 @@ def main():
         return T.joint_train_losses(joint, img, lab, lambda_vae=0.1)
 
     if a.no_graph:
+        from vae_segmentation_amd import ops as _ops
+        _ops.set_overlap(True)
+
         def step():
             for p in seg_params:
                 p.grad = None

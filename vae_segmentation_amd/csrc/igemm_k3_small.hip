@@ -13,6 +13,16 @@
 #include "igemm_dispatch.h"
 
 #define KS_MAXCG 14
+
+#ifdef VS_STAMPS   // diagnostic build only: per-phase s_memtime stamps of wave 0 of every workgroup (never in the product)
+__device__ unsigned long long g_ks_stamps[256 * 16];
+#define STAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_ks_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t_; } } while (0)
+extern "C" int vs_debug_read_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ks_stamps), sizeof(unsigned long long) * n);
+}
+#else
+#define STAMP(i)
+#endif
 #define KS_LDS_RED 0                  // float[4][64][2]  (stats flush)
 #define KS_LDS_MEAN 2048              // float[256] mean, float[256] rstd of the input; then the same for the mask tensor
 #define KS_LDS_SLOTS (2048 + 4 * 1024)
@@ -32,22 +42,10 @@ __global__ __launch_bounds__(256) void k3_small_kernel(const G1Params p, int PD_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int n = blockIdx.x, rb = blockIdx.y;
+    STAMP(0);
     const int V = p.D * p.H * p.W;
     const bool has_stats = p.x_stats != nullptr;
     const T* __restrict__ xin = (const T*)p.x;
-
-    for (int c = tid; c < p.C; c += 256) {
-        float m = 0.f, r = 1.f;
-        if (has_stats) stats_to_mean_rstd(p.x_stats + ((size_t)n * p.C + c) * 2, p.inv_count_in, p.eps, m, r);
-        s_mean[c] = m; s_rstd[c] = r;
-    }
-    if (p.sums != nullptr) {
-        for (int c = tid; c < p.M; c += 256) {
-            float m, r;
-            stats_to_mean_rstd(p.mask_stats + ((size_t)n * p.M + c) * 2, p.inv_count_out, p.eps, m, r);
-            s_mkm[c] = m; s_mkr[c] = r;
-        }
-    }
 
     // ---- per-thread staging table: up to 8 fragments (16 B = 8 channels of one padded voxel) per chunk ----
     constexpr int SB = 8;
@@ -78,61 +76,100 @@ __global__ __launch_bounds__(256) void k3_small_kernel(const G1Params p, int PD_
     for (int cg = 0; cg < KS_MAXCG; ++cg) acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
-    __syncthreads();
+    STAMP(1);
 
     for (int round = 0; round * 4 < p.nch; ++round) {
         // ---- stage up to four channel chunks (one per wave's slot), activation applied, halo zero ----
-        __syncthreads();                                 // previous round's slots fully consumed
-        for (int s = 0; s < 4; ++s) {
-            const int ch = round * 4 + s;
-            if (ch >= p.nch) break;
-            u32x4 vals[SB];
+        {
+            // all global loads of the round (up to 4 chunks x 8 fragments) are in flight before the first is consumed;
+            // in round 0 they are issued BEFORE the statistics tables are computed, so that latency is paid once
+            u32x4 vals[4][SB];
 #pragma unroll
-            for (int b = 0; b < SB; ++b) vals[b] = *(const u32x4*)(xin + g_off[b] + ch * CK);
+            for (int s = 0; s < 4; ++s) {
+                const int ch = round * 4 + s < p.nch ? round * 4 + s : p.nch - 1;
 #pragma unroll
-            for (int b = 0; b < SB; ++b) {
-                if (inlist[b]) {
-                    u32x4 val = u32x4{0u, 0u, 0u, 0u};
-                    if (real[b]) {
-                        val = vals[b];
-                        if (has_stats) val = act_transform<T, CK>(val, s_mean, s_rstd, ch * CK + (tid & 3) * 8);
+                for (int b = 0; b < SB; ++b) vals[s][b] = *(const u32x4*)(xin + g_off[b] + ch * CK);
+            }
+            STAMP(2);
+            if (round == 0) {
+            for (int c = tid; c < p.C; c += 256) {
+                float m = 0.f, r = 1.f;
+                if (has_stats) stats_to_mean_rstd(p.x_stats + ((size_t)n * p.C + c) * 2, p.inv_count_in, p.eps, m, r);
+                s_mean[c] = m; s_rstd[c] = r;
+            }
+            if (p.sums != nullptr) {
+                for (int c = tid; c < p.M; c += 256) {
+                    float m, r;
+                    stats_to_mean_rstd(p.mask_stats + ((size_t)n * p.M + c) * 2, p.inv_count_out, p.eps, m, r);
+                    s_mkm[c] = m; s_mkr[c] = r;
+                }
+            }
+            }
+            STAMP(3);
+            __syncthreads();                             // tables visible / previous round's slots fully consumed
+            STAMP(4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ch = round * 4 + s;
+                if (ch < p.nch) {
+#pragma unroll
+                    for (int b = 0; b < SB; ++b) {
+                        if (inlist[b]) {
+                            u32x4 val = u32x4{0u, 0u, 0u, 0u};
+                            if (real[b]) {
+                                val = vals[s][b];
+                                if (has_stats) val = act_transform<T, CK>(val, s_mean, s_rstd, ch * CK + (tid & 3) * 8);
+                            }
+                            *(u32x4*)(s_slots + s * slot_bytes + l_off[b]) = val;
+                        }
                     }
-                    *(u32x4*)(s_slots + s * slot_bytes + l_off[b]) = val;
                 }
             }
         }
-        __syncthreads();
-        // ---- each wave multiplies its own chunk: 27 k-groups, all weight fragments requested up front ----
+        // ---- each wave multiplies its own chunk: 27 k-groups; all weight fragments are requested before the barrier so
+        //      their latency overlaps the other waves' staging writes ----
+        STAMP(5);
         const int ch = round * 4 + wave;
-        if (ch < p.nch) {
-            const char* slot = s_slots + wave * slot_bytes;
-            const u32x4* wch = wp + ((size_t)(rb * p.nch + ch) * NKG) * 64 + lane;
-            u32x4 a[NKG];
+        const int chc = ch < p.nch ? ch : p.nch - 1;
+        u32x4 a[NKG];
+        {
+            const u32x4* wch = wp + ((size_t)(rb * p.nch + chc) * NKG) * 64 + lane;
 #pragma unroll
             for (int kg = 0; kg < NKG; ++kg) a[kg] = wch[kg * 64];
+        }
+        STAMP(6);
+        __syncthreads();
+        STAMP(7);
+        if (ch < p.nch) {
+            const char* slot = s_slots + wave * slot_bytes;
 #pragma unroll
             for (int kg = 0; kg < NKG; ++kg) {
                 const int dz = kg / 9, dy = (kg / 3) % 3, dx = kg % 3;
                 const int toff = ((dz * PH_ + dy) * PW_ + dx) * CKB;
+                // all B fragments of the k-group are requested before the first MFMA (one LDS latency per k-group instead
+                // of one per MFMA: with a single wave per SIMD nothing else hides it)
+                u32x4 b[KS_MAXCG];
 #pragma unroll
-                for (int cg = 0; cg < KS_MAXCG; ++cg) {
-                    if (cg < ncg) {
-                        const u32x4 b = *(const u32x4*)(slot + cbase[cg] + toff);
-                        acc[cg] = mfma16(a[kg], b, acc[cg], (T*)nullptr);
-                    }
-                }
+                for (int cg = 0; cg < KS_MAXCG; ++cg)
+                    if (cg < ncg) b[cg] = *(const u32x4*)(slot + cbase[cg] + toff);
+#pragma unroll
+                for (int cg = 0; cg < KS_MAXCG; ++cg)
+                    if (cg < ncg) acc[cg] = mfma16(a[kg], b[cg], acc[cg], (T*)nullptr);
             }
         }
     }
 
     // ---- sum the four waves' partial accumulators (fixed order) ----
+    STAMP(8);
     __syncthreads();
+    STAMP(9);
     f32x4* s_part = (f32x4*)s_slots;                     // [wave][cg][lane]
 #pragma unroll
     for (int cg = 0; cg < KS_MAXCG; ++cg)
         if (cg < ncg) s_part[(wave * KS_MAXCG + cg) * 64 + lane] = acc[cg];
     __syncthreads();
 
+    STAMP(10);
     // ---- epilogue: wave w finishes column groups w, w+4, ... ----
     T* __restrict__ yout = (T*)p.y;
     const int row = rb * 16 + 4 * g;
@@ -176,6 +213,7 @@ __global__ __launch_bounds__(256) void k3_small_kernel(const G1Params p, int PD_
             for (int r = 0; r < 4; ++r) { ssum[r] += vv[r]; ssq[r] += vv[r] * vv[r]; }
         }
     }
+    STAMP(11);
     double* const red_dst = p.sums != nullptr ? p.sums : p.y_stats;
     if (red_dst != nullptr) {
 #pragma unroll
@@ -199,6 +237,7 @@ __global__ __launch_bounds__(256) void k3_small_kernel(const G1Params p, int PD_
             }
         }
     }
+    STAMP(12);
 }
 
 // returns VS_OK if launched, K3_SMALL_NA if the shape is not one this kernel handles (caller falls back to the tile kernel)

@@ -38,6 +38,8 @@ class FlatGradSync:
         """grads: tensors aligned with self.params (default: p.grad).  Returns the averaged-gradient views."""
         grads = [p.grad for p in self.params] if grads is None else grads
         if self.flat.is_cuda:
+            from . import ops
+            ops.join_side()
             (sp, dp, sizes, bm), nb = self._tab.get([grads, self.views], self.flat.device)
             check(lib.vs_copy_scale_multi(sp.data_ptr(), dp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb,
                                           1.0 / self.world, torch.cuda.current_stream().cuda_stream), "copy_scale_multi")

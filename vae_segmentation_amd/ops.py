@@ -89,6 +89,56 @@ def cpad(c):
 
 
 # ------------------------------------------------------------------------------------------------
+# side stream for weight-gradient kernels
+# ------------------------------------------------------------------------------------------------
+# In backward the chain  bwd-data(L) -> IN-backward(L-1) -> bwd-data(L-1) ...  is strictly sequential, while the weight
+# (and bias) gradient of each layer is a leaf: nothing in backward reads it.  With overlap enabled those kernels are
+# issued on a second HIP stream (forked from / joined to the main stream with events, so it also works inside HIP-graph
+# capture, where it becomes a parallel branch of the graph) and fill the CUs that the small critical-path kernels leave
+# idle.  Inputs are kept referenced until the join so the allocator cannot recycle them under the side stream.  The
+# produced gradients are NOT held: autograd's AccumulateGrad must find them unshared so that it adopts the tensor as
+# .grad without launching a copy on the main stream (a copy would read the buffer before the side stream wrote it).
+_SIDE = {"enabled": False, "stream": None, "pending": [], "forked": False}
+
+
+def set_overlap(enabled=True):
+    """Issue weight/bias-gradient kernels on a side stream.  The native optimisers, FlatGradSync and GraphedStep join it
+    before gradients are read; with a foreign optimiser call ops.join_side() after backward()."""
+    _SIDE["enabled"] = bool(enabled)
+
+
+class _side_stream:
+    def __init__(self, weight, *keep):
+        self.on = _SIDE["enabled"] and weight.grad is None
+        self.keep = keep
+
+    def __enter__(self):
+        if self.on:
+            if _SIDE["stream"] is None:
+                _SIDE["stream"] = torch.cuda.Stream()
+            self.main = torch.cuda.current_stream()
+            _SIDE["stream"].wait_stream(self.main)
+            self.ctx = torch.cuda.stream(_SIDE["stream"])
+            self.ctx.__enter__()
+            _SIDE["pending"].extend(self.keep)
+            _SIDE["forked"] = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_side():
+    """Make the current stream wait for every side-stream kernel issued so far and release the held tensors."""
+    if _SIDE["forked"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["pending"].clear()
+        _SIDE["forked"] = False
+
+
+# ------------------------------------------------------------------------------------------------
 # weight packing (fragment order); frozen weights are packed once and cached
 # ------------------------------------------------------------------------------------------------
 
@@ -414,7 +464,8 @@ class ConvK3(torch.autograd.Function):
             else:
                 gx, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K3, False, real_channels=(cout, cin))
         if ctx.needs_input_grad[2]:
-            gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K3, weight.shape)
+            with _side_stream(weight, gy, x, xs) as sd:
+                gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K3, weight.shape)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gb = _new_stats(1, (ctx.bias_shape[0] + 1) // 2, gy.device, width=1).view(-1).view(torch.float32)[:ctx.bias_shape[0]]
         return gx, None, gw, gb
@@ -454,8 +505,11 @@ class ConvK3Softmax(torch.autograd.Function):
             else:
                 gx, _ = conv_gather(gl, None, wpb, None, c, VS_CONV_K3, False)
         if ctx.needs_input_grad[2]:
-            gw = conv_wgrad(gl, None, x, xs, 2, weight.shape[1], VS_CONV_K3, weight.shape)
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+            with _side_stream(weight, gl, x, xs) as sd:
+                gw = conv_wgrad(gl, None, x, xs, 2, weight.shape[1], VS_CONV_K3, weight.shape)
+                if ctx.has_bias and ctx.needs_input_grad[3]:
+                    gb = bias_grad(gl, 2)
+        elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gl, 2)
         return gx, None, gw, gb
 
@@ -486,8 +540,11 @@ class ConvK2S2(torch.autograd.Function):
             else:
                 gx = conv_scatter(gy, None, wpb, None, x.shape[-1])
         if ctx.needs_input_grad[2]:
-            gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K2S2, weight.shape)
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+            with _side_stream(weight, gy, x, xs) as sd:
+                gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K2S2, weight.shape)
+                if ctx.has_bias and ctx.needs_input_grad[3]:
+                    gb = bias_grad(gy, cout)
+        elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gy, cout)
         return gx, None, gw, gb
 
@@ -517,8 +574,11 @@ class ConvT2S2(torch.autograd.Function):
             else:
                 gx, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K2S2, False)
         if ctx.needs_input_grad[2]:
-            gw = conv_wgrad(x, xs, gy, None, cin, cout, VS_CONV_K2S2, weight.shape)
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+            with _side_stream(weight, gy, x, xs) as sd:
+                gw = conv_wgrad(x, xs, gy, None, cin, cout, VS_CONV_K2S2, weight.shape)
+                if ctx.has_bias and ctx.needs_input_grad[3]:
+                    gb = bias_grad(gy, cout)
+        elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gy, cout)
         return gx, None, gw, gb
 

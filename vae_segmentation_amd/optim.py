@@ -53,6 +53,7 @@ class SGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0, _override=None):
+        ops.join_side()
         for gi, group in enumerate(self.param_groups):
             if _override is not None:
                 ps = [p for p in group["params"] if id(p) in _override]
@@ -91,6 +92,7 @@ class Adam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        ops.join_side()
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:

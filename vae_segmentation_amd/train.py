@@ -86,7 +86,8 @@ class GraphedStep:
 
     ``loss_fn()`` must read its inputs from tensors that stay at fixed addresses (copy new data into them)."""
 
-    def __init__(self, loss_fn, params, optimizer, grad_sync=None, warmup=2):
+    def __init__(self, loss_fn, params, optimizer, grad_sync=None, warmup=2, overlap=True):
+        ops.set_overlap(overlap)
         self.loss_fn, self.params, self.optimizer, self.grad_sync = loss_fn, list(params), optimizer, grad_sync
         self.graph = None
         self.loss = None
@@ -109,6 +110,7 @@ class GraphedStep:
             p.grad = None
         self.loss, self.aux = self.loss_fn()
         self.loss.backward()
+        ops.join_side()          # weight-gradient kernels run on a side stream (a parallel branch of the captured graph)
 
     def step(self):
         self.graph.replay()
