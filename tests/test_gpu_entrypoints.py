@@ -1,0 +1,33 @@
+"""GPU: the main_source.py / main_target.py entry points run end to end on synthetic volumes (tiny budgets)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, cwd):
+    out = subprocess.run([sys.executable] + args, cwd=cwd, env=dict(os.environ, PYTHONPATH=REPO), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    return out.stdout
+
+
+def test_main_source_joint_train_then_main_target_domain_adaptation(tmp_path):
+    common = ["--size", "64", "-b", "1", "-E", "1", "--eval_epoch", "1", "--save_epoch", "1", "--synthetic_train", "2",
+              "--synthetic_val", "1", "--max_iters", "2", "--display_freq", "1"]
+    out = _run([os.path.join(REPO, "main_source.py"), "src", "-M", "joint_train"] + common, str(tmp_path))
+    assert "Finished Training" in out and "validation result" in out
+    ck = tmp_path / "3dmodel" / "src" / "model_epoch1.ckpt"
+    assert ck.exists()
+    import torch
+    blob = torch.load(str(ck), map_location="cpu")
+    assert set(blob) == {"epoch", "model_state_dict", "optimizer_state_dict"}
+    assert any(k.startswith("Seg.in_block.conv.0.") for k in blob["model_state_dict"])
+    assert json.load(open(tmp_path / "tensorboard" / "src" / "score_0.json"))
+    out = _run([os.path.join(REPO, "main_target.py"), "tgt", "-M", "domain_adaptation", "--load_prefix_joint", "src",
+                "--checkpoint_name", "model_epoch1.ckpt", "--domain_loss_type", "8"] + common, str(tmp_path))
+    assert "Finished Training" in out

@@ -1,0 +1,281 @@
+"""Shared machinery of the main_source.py / main_target.py entry points.
+
+The reference's scripts (main_source.py 853 lines, main_target.py 1063 lines) are argparse + a NumPy/SimpleITK data
+pipeline + the train / validate / checkpoint loop.  The data pipeline, TensorBoard writer and plotting are out of scope
+ and their dependencies are absent, so the entry points here keep the reference's flag names and
+loop semantics (methods, loss bodies, frozen sub-nets, optimiser groups, epoch arithmetic, checkpoint dict layout, score
+JSON) and feed the step from a deterministic synthetic dataset (`--synthetic`, the only data source available).
+
+One process per GPU: under torchrun (WORLD_SIZE > 1) every rank builds the same replica, takes its own shard of the
+synthetic volumes and averages gradients with one RCCL all-reduce per step (vae_segmentation_amd.ddp) — the replacement
+for the reference's nn.DataParallel wrap (main_source.py:354, main_target.py:436-438).
+"""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ddp, ops, optim
+from . import train as T
+from .evaluation import EPS_EVALUATION, EPS_MAIN_SOURCE, avg_dsc
+from .modules import Joint, Segmentation, VAE, set_kernel_dtype
+
+LABEL_KEY, IMG_KEY = "venous_pancreas", "venous"          # main_source.py:355-356
+
+
+# ----------------------------------------------------------------------------------------------------
+# synthetic data (stands in for BaseDataset + the transform stack of main_source.py:189-243)
+# ----------------------------------------------------------------------------------------------------
+def _hash_uniform(n, stream, seed):
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = idx * np.uint64(0x9E3779B97F4A7C15) + np.uint64((seed * 0x9E3779B97F4A7C15 + stream * 0xD1B54A32D192ED03 + 12345) % (1 << 64))
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    return ((x >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
+
+
+class SyntheticVolumes(torch.utils.data.Dataset):
+    """Image ~ clip(N(0,1) + blob contrast, -1, 1) as after Clip / CenterIntensities (main_source.py:211-212); label = a
+    jittered ellipsoid (1 = organ).  Item i is a pure function of (seed, i): every rank / run sees the same volumes."""
+
+    def __init__(self, count, side, seed=0):
+        self.count, self.side, self.seed = count, side, seed
+
+    def __len__(self):
+        return self.count
+
+    def __getitem__(self, i):
+        s = self.side
+        u = _hash_uniform(8, 17, self.seed * 100003 + i)
+        ax = (np.arange(s, dtype=np.float32) + 0.5) / s - 0.5
+        z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+        c = (u[0:3] - 0.5) * 0.2
+        r = 0.18 + 0.14 * u[3:6]
+        d2 = ((z - c[0]) / r[0]) ** 2 + ((y - c[1]) / r[1]) ** 2 + ((x - c[2]) / r[2]) ** 2
+        label = (d2 < 1.0).astype(np.float32)
+        n = s ** 3
+        u1 = np.maximum(_hash_uniform(n, 1, self.seed * 7919 + i), 1e-7).astype(np.float64)
+        u2 = _hash_uniform(n, 2, self.seed * 7919 + i).astype(np.float64)
+        noise = (np.sqrt(-2 * np.log(u1)) * np.cos(2 * np.pi * u2)).astype(np.float32).reshape(s, s, s)
+        img = np.clip(0.6 * noise + 0.8 * label - 0.2, -1, 1)
+        return {IMG_KEY: torch.from_numpy(img[None]), LABEL_KEY: torch.from_numpy(label[None])}
+
+
+def make_loaders(args, rank, world):
+    train = SyntheticVolumes(args.synthetic_train, args.size, seed=1)
+    val = SyntheticVolumes(args.synthetic_val, args.size, seed=2)
+    sampler = None
+    if world > 1:
+        sampler = torch.utils.data.distributed.DistributedSampler(train, num_replicas=world, rank=rank, shuffle=True, drop_last=True)
+    tl = torch.utils.data.DataLoader(train, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
+                                     num_workers=0, pin_memory=True, drop_last=True)        # drop_last: main_source.py:237
+    vl = torch.utils.data.DataLoader(val, batch_size=1, shuffle=False, num_workers=0, pin_memory=True)
+    return tl, vl, sampler
+
+
+# ----------------------------------------------------------------------------------------------------
+# model / optimiser construction (main_source.py:245-294, 300-346; main_target.py:314-352, 395-433)
+# ----------------------------------------------------------------------------------------------------
+def n_class_of(args):
+    return 1 + len(str(args.pan_index).split(",")) if str(args.pan_index) != "10" else 2
+
+
+def build_joint(args):
+    nc = n_class_of(args)
+    seg = Segmentation(n_channels=1, n_class=nc, norm_type=1)
+    vae = VAE(n_channels=nc, n_class=nc, norm_type=1, dim=128, spatial=args.size)
+    return Joint(models=[seg, vae])
+
+
+def freeze(module):
+    for p in module.parameters():
+        p.requires_grad = False
+    module.eval()
+    return module
+
+
+def load_prefix(module, prefix, name="best_model.ckpt"):
+    """--load_prefix* : '3dmodel/<prefix>/<name>' holding {'epoch','model_state_dict','optimizer_state_dict'}."""
+    path = os.path.join("3dmodel", prefix, name)
+    sd = torch.load(path, map_location="cpu")["model_state_dict"]
+    module.load_state_dict(sd)
+    ops.clear_pack_cache()
+    print("loaded %s" % path)
+
+
+def make_optimizer(args, groups):
+    if getattr(args, "adam", False):
+        return optim.Adam(groups, lr=args.lr_seg, betas=(0.9, 0.999), weight_decay=0.0)
+    return optim.SGD(groups, lr=args.lr_seg, momentum=0.9, weight_decay=0.0)
+
+
+def save_checkpoint(prefix, epoch_label, model, optimizer, best):
+    path = os.path.join("3dmodel", prefix)
+    os.makedirs(path, exist_ok=True)
+    blob = {"epoch": epoch_label, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict()}
+    torch.save(blob, os.path.join(path, "model_epoch%d.ckpt" % epoch_label))
+    if best:
+        torch.save(blob, os.path.join(path, "best_model.ckpt"))
+
+
+# ----------------------------------------------------------------------------------------------------
+# validation (main_source.py:688-822): batch 1, hard Dice of the argmax prediction against the label
+# ----------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def validate(method, model, loader, nc):
+    scores = {}
+    for i, batch in enumerate(loader):
+        gt = ops.onehot(batch[LABEL_KEY].cuda(non_blocking=True), nc)
+        if method == "vae_train":
+            pred, _, _ = model(gt, if_random=False)
+        else:
+            seg = model.Seg if hasattr(model, "Seg") else model
+            pred = seg({IMG_KEY: batch[IMG_KEY].cuda(non_blocking=True)}, IMG_KEY, "pred")["pred"]
+        scores[i] = avg_dsc({"p": pred, "g": gt}, "p", "g", binary=True, botindex=1, topindex=nc).item()
+    return scores
+
+
+# ----------------------------------------------------------------------------------------------------
+# the loop
+# ----------------------------------------------------------------------------------------------------
+def run(args, side="source"):
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("the native kernels need a GPU (there is no CPU path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not args.synthetic:
+        raise SystemExit("only --synthetic data is available in this build: the reference's NumPy/SimpleITK/batchgenerators "
+                         "pipeline (utils/utils.py) is out of scope and its dependencies are not installed")
+    assert args.save_epoch % args.eval_epoch == 0
+    nc = n_class_of(args)
+    method = args.method
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    eps = EPS_MAIN_SOURCE if side == "source" else EPS_EVALUATION          # the two scripts use different epsilons
+
+    teacher = None
+    if method == "vae_train":
+        model = VAE(n_channels=nc, n_class=nc, norm_type=1, dim=128, soft=bool(args.softrelu), spatial=args.size)
+        trainable = model
+    elif method == "seg_train":
+        model = Segmentation(n_channels=1, n_class=nc, norm_type=1)
+        trainable = model
+    elif method in ("joint_train", "domain_adaptation"):
+        model = build_joint(args)
+        trainable = model.Seg
+        if method == "domain_adaptation":
+            teacher = build_joint(args)
+    else:
+        raise NotImplementedError("method %r: native kernels cover vae_train, seg_train, joint_train and domain_adaptation "
+                                  "(the methods the reference's launch scripts use, SURVEY.md §2.1); embed_train / refine_vae / "
+                                  "sep_joint_train / discriminator methods are listed as next in SURVEY.md §8f" % method)
+    model = model.cuda()
+    if args.load_prefix:
+        load_prefix(model.Seg if hasattr(model, "Seg") else model, args.load_prefix, args.checkpoint_name)
+    if args.load_prefix_vae and hasattr(model, "Vae"):
+        load_prefix(model.Vae, args.load_prefix_vae)
+    if args.load_prefix_joint and hasattr(model, "Seg"):
+        load_prefix(model, args.load_prefix_joint, args.checkpoint_name)
+    if hasattr(model, "Vae"):
+        freeze(model.Vae)                                                   # main_source.py:343-346
+    if teacher is not None:
+        teacher = teacher.cuda()
+        teacher.load_state_dict(model.state_dict())                         # main_target.py:420-423
+        freeze(teacher)
+        set_kernel_dtype(teacher, dtype)
+    set_kernel_dtype(model, dtype)
+
+    if hasattr(model, "Seg"):
+        groups = [{"params": list(model.Seg.parameters()), "lr": args.lr_seg, "model": "Seg"},
+                  {"params": list(model.Vae.parameters()), "lr": args.lr_vae, "model": "Vae"}]
+    else:
+        groups = [{"params": list(model.parameters()), "lr": args.lr_seg}]
+    optimizer = make_optimizer(args, groups)
+    params = [p for p in trainable.parameters() if p.requires_grad]
+    sync = ddp.FlatGradSync(params) if world > 1 else None
+    if sync is not None:
+        sync.broadcast_parameters(0)
+    ops.set_overlap(True)
+
+    train_loader, val_loader, sampler = make_loaders(args, rank, world)
+    lambda_vae = args.lambda_vae
+    best, n_outer = 0.0, max(1, args.max_epoch // args.eval_epoch)
+    for epoch in range(n_outer):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        if not args.test_only:
+            model.train()
+            if hasattr(model, "Vae"):
+                model.Vae.eval()
+            t0, seen = time.time(), 0
+            for idx, batch in enumerate(train_loader):
+                img = batch[IMG_KEY].cuda(non_blocking=True)
+                lab = batch[LABEL_KEY].cuda(non_blocking=True)
+                for p in params:
+                    p.grad = None
+                if method == "vae_train":
+                    loss, aux = T.vae_train_losses(model, lab, scale=0.35, eps=eps, n_class=nc)
+                elif method == "seg_train":
+                    loss, aux = T.seg_train_losses(model, img, lab, eps=eps, n_class=nc)
+                elif method == "joint_train":
+                    loss, aux = T.joint_train_losses(model, img, lab, lambda_vae=lambda_vae, eps=eps, n_class=nc)
+                else:
+                    if getattr(args, "pseudo_save_epoch", 0) and getattr(args, "update_every_iteration", False):
+                        optim.ema_update(teacher.Seg, model.Seg, args.alpha)      # main_target.py:508-518
+                    loss, aux = T.domain_adaptation_losses(model, teacher, img, lab, lambda_vae=lambda_vae,
+                                                           domain_loss_type=getattr(args, "domain_loss_type", 0),
+                                                           kl=getattr(args, "kl", False),
+                                                           use_confident_binarize=getattr(args, "use_confident_binarize", False),
+                                                           eps=eps, n_class=nc)
+                loss.backward()
+                if sync is not None:
+                    optimizer.step_with(params, sync())
+                else:
+                    optimizer.step()
+                seen += img.shape[0]
+                if rank == 0 and idx % args.display_freq == 0:              # logging syncs the host every display_freq steps only
+                    parts = ", ".join("%s %.4f" % (k, v.item()) for k, v in aux.items() if k != "batch")
+                    print("[%3d, %3d] loss: %s" % ((epoch + 1) * args.eval_epoch, idx + 1, parts))
+                if args.max_iters and idx + 1 >= args.max_iters:
+                    break
+            torch.cuda.synchronize()
+            if rank == 0:
+                print("epoch %d: %.2f volumes/s per rank" % (epoch + 1, seen / max(time.time() - t0, 1e-9)))
+        if rank == 0:
+            model.eval()
+            scores = validate(method, model, val_loader, nc)
+            mean = float(np.mean(list(scores.values()))) if scores else 0.0
+            os.makedirs(os.path.join("tensorboard", args.prefix), exist_ok=True)
+            with open(os.path.join("tensorboard", args.prefix, "score_%d.json" % epoch), "w") as f:
+                json.dump(scores, f)
+            print("epoch %d validation result: %f, best result %f." % (epoch + 1, mean, best))
+            if not args.test_only and (epoch + 1) % max(1, args.save_epoch // args.eval_epoch) == 0:
+                save_checkpoint(args.prefix, (epoch + 1) * args.eval_epoch, model, optimizer, mean > best)
+            best = max(best, mean)
+        if world > 1:
+            dist.barrier()
+        if args.test_only:
+            break
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print("Finished Training")
+    return best
+
+
+def add_native_flags(parser):
+    g = parser.add_argument_group("native (MI355X) additions")
+    g.add_argument("--synthetic", action="store_true", default=True, help="synthetic volumes (the only data source in this build)")
+    g.add_argument("--size", type=int, default=128, help="cubic patch side (reference: patch_size 128, main_source.py:117)")
+    g.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="kernel storage dtype")
+    g.add_argument("--synthetic_train", type=int, default=16)
+    g.add_argument("--synthetic_val", type=int, default=2)
+    g.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many steps (0 = whole loader)")
+    g.add_argument("--display_freq", type=int, default=10)
