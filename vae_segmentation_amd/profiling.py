@@ -40,6 +40,28 @@ def collect(fwd_bwd, params, steps=2):
     return agg
 
 
+def _norm_name(name):
+    name = name.replace("void ", "").split("(")[0]
+    return name.replace(" ", "")
+
+
+def measured_traffic(kid, path=None):
+    """HBM bytes per launch of kernel `kid` from the committed PMC summary (tools/pmc_traffic.py over two rocprofv3 --pmc
+    passes, FETCH_SIZE doubled per MI355X_MICROARCH.md); None when no summary covers this kernel."""
+    import json
+    import os
+    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_hbm_traffic.json")
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    want = _norm_name(kid)
+    for name, rec in table.items():
+        if _norm_name(name) == want:
+            return rec["hbm_bytes_per_launch"]
+    return None
+
+
 def dominant_kernel_roofline(fwd_bwd, params, dtype, steps=2, kernel=None):
     agg = collect(fwd_bwd, params, steps)
     if not agg:
@@ -57,7 +79,7 @@ def dominant_kernel_roofline(fwd_bwd, params, dtype, steps=2, kernel=None):
     else:
         ach, peak, unit, bound = a["flops"] / sec / 1e12, mfma_peak, "TFLOP/s", "mfma"
     top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:6]
-    return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": None,
+    return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": measured_traffic(kid),
             "kernel": kid, "launches_per_step": a["launches"], "avg_launch_us": 1e3 * a["ms"] / a["launches"],
             "share_of_timed_kernel_time": a["ms"] / total_ms,
             "algorithmic_bytes_per_launch": a["bytes"] / a["launches"], "algorithmic_flops_per_launch": a["flops"] / a["launches"],
