@@ -8,6 +8,11 @@ import ctypes
 import os
 import re
 
+# PyTorch-ROCm ships its own libamdhip64.so; libvaeseg.so links against the same SONAME.  torch must be loaded FIRST so
+# that the single HIP runtime in the process is torch's (the one that owns the device context and the streams we are
+# handed): loading libvaeseg.so first pulls /opt/rocm's copy instead and torch then fails with hipErrorNoDevice (100).
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vaeseg.h")
 LIB_PATH = os.path.join(_HERE, "libvaeseg.so")

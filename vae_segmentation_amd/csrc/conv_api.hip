@@ -1,16 +1,19 @@
 // C-ABI launchers of the implicit-GEMM convolutions (forward / backward-data).
+#include <stdlib.h>
 #include "igemm_dispatch.h"
 
 int g1_dispatch_k3_f32(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 
 static int pick_mt(int rows16, long long tiles) {
-    // largest row tile that still leaves >= 256 workgroups (one per CU); 16 when the layer is too small for that
+    // largest row tile that still leaves >= VS_MT_MIN_WGS workgroups; 16 when the layer is too small for that.
+    // (more rows per wave = more MFMAs per B fragment read from LDS, fewer workgroups)
+    static const int min_wgs = getenv("VS_MT_MIN_WGS") ? atoi(getenv("VS_MT_MIN_WGS")) : 256;
     const int cands[3] = {64, 32, 16};
     for (int i = 0; i < 3; ++i) {
         const int mt = cands[i];
         if (rows16 % mt) continue;
-        if (tiles * (rows16 / mt) >= 256 || mt == 16) return mt;
+        if (tiles * (rows16 / mt) >= min_wgs || mt == 16) return mt;
     }
     return 16;
 }
