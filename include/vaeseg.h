@@ -101,6 +101,11 @@ int vs_conv_scatter_bwd_data(const void* x, const void* w_packed, void* y, const
  * prob[n][k][v] (planar fp32, k < 2) = softmax_k( bias[k] + conv3x3x3(act(x))[k] ). */
 int vs_conv_k3_softmax2_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                             float* prob, int n, int d, int h, int w, int c_in, int dtype, float eps, void* stream);
+/* same with F.dropout applied to the two logits before the softmax (Segmentation.forward's last dropout site,
+ * joint_model.py:386-388); drop_p == 0 is the call above. */
+int vs_conv_k3_softmax2_dropout_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                                    float* prob, int n, int d, int h, int w, int c_in, int dtype, float eps, float drop_p,
+                                    unsigned long long drop_seed, void* stream);
 
 /* weight gradient of all three conv kinds:
  *   dW[m][c][tap] = sum_{n,v} actP(P)[n,v,m] * actQ(Q)[n, v*s + off(tap) - p, c]        (fp32, reference layout)
@@ -131,6 +136,11 @@ int vs_instnorm_relu_bwd_reduce(const void* g, const void* x, const double* x_st
 int vs_instnorm_relu_bwd_apply(const void* g, const void* x, const double* x_stats, const double* sums,
                                void* gx, int n, long long voxels, int c, int dtype, float eps, void* stream);
 
+/* F.dropout(x, p, training=True) on a channels-last tensor (joint_model.py:256-264,379-385): out = x * keep / (1-p),
+ * keep ~ Bernoulli(1-p) from a counter-based hash of (seed, element index) — the same call with the same seed applied to
+ * the incoming gradient is the backward.  (The reference draws from torch's Philox stream; only the distribution matches.) */
+int vs_dropout(const void* x, void* out, long long count, float p, unsigned long long seed, int dtype, void* stream);
+
 /* ---- layout glue at the NCDHW boundary ----------------------------------------------------------- */
 /* planar fp32 [N][c_src][V] -> channels-last [N][V][c_pad] (zero-filled channels >= c_src) */
 int vs_pack_planar(const float* src, void* dst, int n, long long voxels, int c_src, int c_pad, int dtype, void* stream);
@@ -139,6 +149,9 @@ int vs_unpack_planar(const void* src, float* dst, int n, long long voxels, int c
 /* backward of the 2-class softmax: glogit[n,v,k] = p_k (g_k - sum_j p_j g_j), written channels-last with c_pad
  * channels (k >= 2 zero).  prob, gprob planar fp32 [N][2][V]. */
 int vs_softmax2_bwd(const float* prob, const float* gprob, void* glogit, int n, long long voxels, int c_pad, int dtype, void* stream);
+/* same, followed by the backward of the logit dropout of vs_conv_k3_softmax2_dropout_fwd (same p / seed) */
+int vs_softmax2_dropout_bwd(const float* prob, const float* gprob, void* glogit, int n, long long voxels, int c_pad, int dtype,
+                            float drop_p, unsigned long long drop_seed, void* stream);
 /* label (float, values 0..n_class-1) [N][1][V] -> one-hot planar fp32 [N][n_class][V]   (main_source.py:449-451) */
 int vs_onehot(const float* label, float* out, int n, long long voxels, int n_class, void* stream);
 /* mode 0: (a >= 0.5) ; mode 1: a>hi -> 1, a<lo -> 0, else a        (utils/evaluation.py:9-18) */

@@ -312,3 +312,42 @@ def test_cpu_tensor_is_rejected_loudly():
     seg = joint_model.Segmentation(1, 2, norm_type=1)
     with pytest.raises(RuntimeError):
         seg({"x": torch.zeros(1, 1, 16, 16, 16)}, "x", "y")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_dropout_forward_backward_share_the_mask(dtype):
+    """F.dropout(training=True) semantics with a counter-based mask: kept fraction ~ 1-p, kept values scaled by 1/(1-p),
+    the backward applies the SAME mask, a different seed gives a different mask."""
+    ops = _ops()
+    x = (rnd(2, 16, 8, 8, 8, seed=40).abs() + 0.5)
+    x_cl = to_cl(x, 16, dtype).requires_grad_(True)
+    p, seed = 0.3, ops.next_dropout_seed()
+    y = ops.Dropout.apply(x_cl, p, seed)
+    keep = (y != 0)
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.01
+    ratio = (y.float()[keep] / x_cl.detach().float()[keep])
+    assert float((ratio - 1 / (1 - p)).abs().max()) < (2e-2 if dtype == torch.bfloat16 else 1e-5)
+    g = to_cl(rnd(2, 16, 8, 8, 8, seed=41).abs() + 0.5, 16, dtype)
+    y.backward(g)
+    assert torch.equal(x_cl.grad != 0, keep)
+    y2 = ops.Dropout.apply(x_cl.detach(), p, ops.next_dropout_seed())
+    assert not torch.equal(y2 != 0, keep)
+
+
+def test_segmentation_and_vae_with_dropout_run_and_stay_normalised():
+    """dropout > 0 at every site of the reference (joint_model.py:256-264, 379-388): probabilities still sum to 1,
+    gradients are finite, and two calls differ (fresh masks)."""
+    import joint_model as M
+    from oracle import ref_cpu as O
+    seg = O.deterministic_fill_(M.Segmentation(1, 2, norm_type=1), seed=0).cuda()
+    img = O.synthetic_image(1, 32, 2).cuda()
+    a = seg({"x": img}, "x", "p", dropout=0.2)["p"]
+    b = seg({"x": img}, "x", "p", dropout=0.2)["p"]
+    assert float((a.sum(1) - 1).abs().max()) < 1e-5
+    assert float((a - b).abs().max()) > 1e-4
+    a[:, 1].mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in seg.parameters())
+    vae = O.deterministic_fill_(M.VAE(2, 2, norm_type=1, dim=128, spatial=64), seed=0).cuda()
+    r, m, s = vae(O.one_hot(O.synthetic_label(1, 64, 3)).cuda(), dropout=0.1)
+    assert float((r.sum(1) - 1).abs().max()) < 1e-5 and torch.isfinite(r).all()

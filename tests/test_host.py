@@ -15,7 +15,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from vae_segmentation_amd import _lib
     protos = _lib.parse_header()
-    assert len(protos) >= 35
+    assert len(protos) >= 43
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(raw, name), name
@@ -23,7 +23,9 @@ def test_library_exports_every_declared_symbol():
                  "vs_instnorm_relu_fwd", "vs_instnorm_relu_bwd_reduce", "vs_instnorm_relu_bwd_apply", "vs_softmax2_bwd",
                  "vs_dice_fwd", "vs_dice_bwd", "vs_kl_fwd", "vs_kl_bwd", "vs_reparam_fwd", "vs_linear_fwd", "vs_onehot",
                  "vs_binarize", "vs_bce_fwd", "vs_sgd_momentum_multi", "vs_adam_multi", "vs_ema_multi", "vs_strerror",
-                 "vs_version", "vs_conv_wgrad_workspace_bytes", "vs_copy_scale_multi"):
+                 "vs_version", "vs_conv_wgrad_workspace_bytes", "vs_copy_scale_multi", "vs_conv_gather_bwd_data",
+                 "vs_conv_scatter_bwd_data", "vs_pack_weight_multi", "vs_dropout", "vs_softmax2_dropout_bwd",
+                 "vs_conv_k3_softmax2_dropout_fwd"):
         assert must in protos, must
     assert _lib.lib.vs_version() == 100
     assert b"dtype" in _lib.lib.vs_strerror(-3)

@@ -21,7 +21,7 @@ VS_F32, VS_BF16 = 0, 1
 VS_CONV_K3, VS_CONV_K2S2, VS_CONV_T2S2 = 0, 1, 2
 VS_PACK_ROWS_D0, VS_PACK_ROWS_D1_FLIP, VS_PACK_SCATTER_D1 = 0, 1, 2
 
-_SCALARS = {"int": ctypes.c_int, "long long": ctypes.c_longlong, "float": ctypes.c_float,
+_SCALARS = {"int": ctypes.c_int, "unsigned long long": ctypes.c_ulonglong, "long long": ctypes.c_longlong, "float": ctypes.c_float,
             "size_t": ctypes.c_size_t, "double": ctypes.c_double}
 
 

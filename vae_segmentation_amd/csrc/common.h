@@ -96,6 +96,18 @@ __device__ __forceinline__ void stats_to_mean_rstd(const double* st, double inv_
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// counter-based Bernoulli(keep) for dropout: splitmix64 finaliser of (seed, index) -> uniform in [0,1)
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx) {
+    unsigned long long x = idx * 0x9E3779B97F4A7C15ull + seed;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float dropout_scale(unsigned long long seed, unsigned long long idx, float p) {
+    return hash_uniform(seed, idx) >= p ? 1.0f / (1.0f - p) : 0.0f;
+}
+
 #define VS_CHECK_LAUNCH()                                  \
     do {                                                   \
         hipError_t e__ = hipGetLastError();                \

@@ -125,12 +125,20 @@ extern "C" int vs_conv_scatter_bwd_data(const void* x, const void* w_packed, voi
 extern "C" int vs_conv_k3_softmax2_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                                        float* prob, int n, int d, int h, int w, int c_in, int dtype, float eps,
                                        void* stream) {
+    return vs_conv_k3_softmax2_dropout_fwd(x, x_stats, w_packed, bias, prob, n, d, h, w, c_in, dtype, eps, 0.f, 0ull, stream);
+}
+
+extern "C" int vs_conv_k3_softmax2_dropout_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                                               float* prob, int n, int d, int h, int w, int c_in, int dtype, float eps,
+                                               float drop_p, unsigned long long drop_seed, void* stream) {
+    if (drop_p < 0.f || drop_p >= 1.f) return VS_EINVAL;
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
     if (!prob || c_in != 8) return VS_ESHAPE;
     G1Params p{};
     p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = nullptr; p.y_stats = nullptr; p.prob = prob;
     p.mask_x = nullptr; p.mask_stats = nullptr; p.sums = nullptr; p.inv_count_out = 1.0 / ((double)d * h * w);
+    p.drop_p = drop_p; p.drop_seed = drop_seed;
     p.N = n; p.D = d; p.H = h; p.W = w;
     p.Do = d; p.Ho = h; p.Wo = w;
     p.C = c_in; p.M = 8;

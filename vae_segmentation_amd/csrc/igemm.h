@@ -26,6 +26,8 @@ struct G1Params {
     const double* mask_stats;
     double* sums;
     double inv_count_out;
+    float drop_p;                   // SOFTMAX2 epilogue only: dropout on the two logits (0 = off)
+    unsigned long long drop_seed;
     int N, D, H, W;       // input grid
     int Do, Ho, Wo;       // column grid (K3: = input; K2S2: input/2; PW: = input)
     int C;                // input channels (padded)

@@ -281,11 +281,15 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                 for (int cg = 0; cg < 4; ++cg) {
                     const int oy = y0 + cg, ox = x0 + col;
                     if (!(oz < p.D && oy < p.H && ox < p.W)) continue;
-                    const float l0 = acc[0][cg][0] + b0, l1 = acc[0][cg][1] + b1;
+                    float l0 = acc[0][cg][0] + b0, l1 = acc[0][cg][1] + b1;
+                    const size_t v = ((size_t)oz * p.H + oy) * p.W + ox;
+                    if (p.drop_p > 0.f) {
+                        l0 *= dropout_scale(p.drop_seed, ((unsigned long long)n * 2 + 0) * V + v, p.drop_p);
+                        l1 *= dropout_scale(p.drop_seed, ((unsigned long long)n * 2 + 1) * V + v, p.drop_p);
+                    }
                     const float mx = fmaxf(l0, l1);
                     const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx);
                     const float inv = 1.f / (e0 + e1);
-                    const size_t v = ((size_t)oz * p.H + oy) * p.W + ox;
                     p.prob[((size_t)n * 2 + 0) * V + v] = e0 * inv;
                     p.prob[((size_t)n * 2 + 1) * V + v] = e1 * inv;
                 }

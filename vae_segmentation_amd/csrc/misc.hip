@@ -19,8 +19,33 @@ extern "C" const char* vs_strerror(int code) {
 
 // ---- softmax (2 classes) backward ----------------------------------------------------------------
 template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, long long frags, float p, unsigned long long seed) {
+    constexpr int EPL = ET<T>::EPL;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < frags; i += (long long)gridDim.x * blockDim.x) {
+        float f[EPL];
+        frag_unpack(*(const u32x4*)(x + i * EPL), f, (T*)nullptr);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) f[j] *= dropout_scale(seed, (unsigned long long)i * EPL + j, p);
+        *(u32x4*)(out + i * EPL) = frag_pack(f, (T*)nullptr);
+    }
+}
+extern "C" int vs_dropout(const void* x, void* out, long long count, float p, unsigned long long seed, int dtype, void* stream) {
+    if (!x || !out || count <= 0 || p < 0.f || p >= 1.f) return VS_EINVAL;
+    const int epl = dtype == VS_F32 ? 4 : 8;
+    if (count % epl) return VS_ESHAPE;
+    const long long frags = count / epl;
+    if (dtype == VS_F32)
+        hipLaunchKernelGGL(dropout_kernel<float>, GRID1D(frags), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, frags, p, seed);
+    else if (dtype == VS_BF16)
+        hipLaunchKernelGGL(dropout_kernel<unsigned short>, GRID1D(frags), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)out, frags, p, seed);
+    else return VS_EDTYPE;
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+template <typename T>
 __global__ void softmax2_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ gprob, T* __restrict__ gl,
-                                    long long voxels, int c_pad, long long total) {
+                                    long long voxels, int c_pad, long long total, float drop_p, unsigned long long drop_seed) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long n = i / voxels, v = i - n * voxels;
         const float p0 = prob[(n * 2 + 0) * voxels + v], p1 = prob[(n * 2 + 1) * voxels + v];
@@ -31,6 +56,10 @@ __global__ void softmax2_bwd_kernel(const float* __restrict__ prob, const float*
         for (int j = 0; j < ET<T>::EPL; ++j) f[j] = 0.f;
         f[0] = p0 * (g0 - dot);
         f[1] = p1 * (g1 - dot);
+        if (drop_p > 0.f) {          // backward of the logit dropout fused into the out_block epilogue
+            f[0] *= dropout_scale(drop_seed, ((unsigned long long)n * 2 + 0) * voxels + v, drop_p);
+            f[1] *= dropout_scale(drop_seed, ((unsigned long long)n * 2 + 1) * voxels + v, drop_p);
+        }
         T* o = gl + i * c_pad;
         *(u32x4*)o = frag_pack(f, (T*)nullptr);
         const u32x4 z = u32x4{0u, 0u, 0u, 0u};
@@ -40,12 +69,17 @@ __global__ void softmax2_bwd_kernel(const float* __restrict__ prob, const float*
 
 extern "C" int vs_softmax2_bwd(const float* prob, const float* gprob, void* glogit, int n, long long voxels, int c_pad,
                                int dtype, void* stream) {
+    return vs_softmax2_dropout_bwd(prob, gprob, glogit, n, voxels, c_pad, dtype, 0.f, 0ull, stream);
+}
+
+extern "C" int vs_softmax2_dropout_bwd(const float* prob, const float* gprob, void* glogit, int n, long long voxels, int c_pad,
+                                       int dtype, float drop_p, unsigned long long drop_seed, void* stream) {
     if (!prob || !gprob || !glogit || n <= 0 || voxels <= 0 || c_pad % 8 || c_pad <= 0) return VS_EINVAL;
     const long long total = (long long)n * voxels;
     if (dtype == VS_F32)
-        hipLaunchKernelGGL(softmax2_bwd_kernel<float>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (float*)glogit, voxels, c_pad, total);
+        hipLaunchKernelGGL(softmax2_bwd_kernel<float>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (float*)glogit, voxels, c_pad, total, drop_p, drop_seed);
     else if (dtype == VS_BF16)
-        hipLaunchKernelGGL(softmax2_bwd_kernel<unsigned short>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (unsigned short*)glogit, voxels, c_pad, total);
+        hipLaunchKernelGGL(softmax2_bwd_kernel<unsigned short>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (unsigned short*)glogit, voxels, c_pad, total, drop_p, drop_seed);
     else return VS_EDTYPE;
     VS_CHECK_LAUNCH();
     return VS_OK;

@@ -89,7 +89,8 @@ def build_joint(args):
     nc = n_class_of(args)
     seg = Segmentation(n_channels=1, n_class=nc, norm_type=1)
     vae = VAE(n_channels=nc, n_class=nc, norm_type=1, dim=128, spatial=args.size)
-    return Joint(models=[seg, vae])
+    return Joint(models=[seg, vae], vae_decoder_dropout=getattr(args, "vae_decoder_dropout", 0.0),
+                 seg_dropout=getattr(args, "seg_dropout", 0.0))
 
 
 def freeze(module):

@@ -8,7 +8,8 @@ main_source.py / main_target.py loops keep working.  Parameters live in ordinary
 it launches the fused kernels through ``ops``.  There is no CPU path — inputs must be CUDA tensors.
 
 Only the configuration every entry point of the reference uses is implemented natively: ``norm_type=1``
-(InstanceNorm3d), ReLU (``soft=False``), two classes.  Other settings raise NotImplementedError.
+(InstanceNorm3d), ReLU (``soft=False``), two classes; dropout at the reference's sites is native too.
+Other settings raise NotImplementedError.
 """
 import torch
 import torch.nn as nn
@@ -149,10 +150,13 @@ class Down(nn.Module):
         return _as_tensor(a, self.out_ch) if wrapped else a
 
 
-def _no_dropout(p, where):
-    if p:
-        raise NotImplementedError("%s: dropout > 0 has no native kernel yet (the reference defaults are 0: "
-                                  "main_target.py:70-71)" % where)
+def _dropout(a, p):
+    """F.dropout(x, p, training=True) after an Up block (joint_model.py:256-264,379-385): the lazy activation is
+    materialised, masked and scaled; p == 0 (the reference default, main_target.py:70-71) costs nothing."""
+    if not p:
+        return a
+    x = ops.Materialize.apply(a.raw, a.stats, None, None) if a.stats is not None else a.raw
+    return Act(ops.Dropout.apply(x, float(p), ops.next_dropout_seed()), None)
 
 
 class VAE(nn.Module):
@@ -192,7 +196,6 @@ class VAE(nn.Module):
         self.kernel_dtype = _DEFAULT_DTYPE
 
     def forward(self, x, if_random=False, scale=1, mid_input=False, dropout=0.0, noise=None):
-        _no_dropout(dropout, "VAE.forward")
         ops._require_cuda(x)
         if not mid_input:
             if x.shape[-1] != self.spatial:
@@ -217,7 +220,7 @@ class VAE(nn.Module):
         h = ops.LinearToCL.apply(z, self.fc2.weight, self.fc2.bias, self.top_ch, self.side, self.kernel_dtype)
         a = Act(h, None)
         for blk in (self.up1, self.up2, self.up3, self.up4, self.up5):
-            a = blk(a)
+            a = _dropout(blk(a), dropout)
         recon = ops.ConvK3Softmax.apply(a.raw, a.stats, self.out_block.weight, self.out_block.bias)
         if not mid_input:
             return recon, x_mean, x_std
@@ -247,7 +250,6 @@ class Segmentation(nn.Module):
         self.kernel_dtype = _DEFAULT_DTYPE
 
     def forward(self, data_dict, in_key, out_key, dropout=0.0):
-        _no_dropout(dropout, "Segmentation.forward")
         x = data_dict[in_key]
         ops._require_cuda(x)
         if any(s % 16 for s in x.shape[2:]):
@@ -259,13 +261,17 @@ class Segmentation(nn.Module):
         x3 = self.down2(x2)
         x4 = self.down3(x3)
         x5 = self.down4(x4)
-        u = self.up2(x5)
+        u = _dropout(self.up2(x5), dropout)
         u = self.up3(u)
-        u = Act(ops.Materialize.apply(u.raw, u.stats, x3.raw, x3.stats), None)
+        u = _dropout(Act(ops.Materialize.apply(u.raw, u.stats, x3.raw, x3.stats), None), dropout)
         u = self.up4(u)
-        u = Act(ops.Materialize.apply(u.raw, u.stats, x2.raw, x2.stats), None)
-        u = self.up5(u)
-        data_dict[out_key] = ops.ConvK3Softmax.apply(u.raw, u.stats, self.out_block.weight, self.out_block.bias)
+        u = _dropout(Act(ops.Materialize.apply(u.raw, u.stats, x2.raw, x2.stats), None), dropout)
+        u = _dropout(self.up5(u), dropout)
+        if dropout:     # the reference also drops the two logits before the softmax (joint_model.py:386-388): fused epilogue
+            data_dict[out_key] = ops.ConvK3Softmax.apply(u.raw, u.stats, self.out_block.weight, self.out_block.bias,
+                                                         float(dropout), ops.next_dropout_seed())
+        else:
+            data_dict[out_key] = ops.ConvK3Softmax.apply(u.raw, u.stats, self.out_block.weight, self.out_block.bias)
         return data_dict
 
 

@@ -476,17 +476,18 @@ class ConvK3Softmax(torch.autograd.Function):
     (joint_model.py:224-225,265-266 / 366-367,386-388)."""
 
     @staticmethod
-    def forward(ctx, x, xs, weight, bias):
+    def forward(ctx, x, xs, weight, bias, drop_p=0.0, drop_seed=0):
         _require_cuda(x, weight)
         if weight.shape[0] != 2:
             raise NotImplementedError("fused out_block+softmax kernel is written for n_class == 2")
         n, d, h, w, c = x.shape
         wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, c, x.dtype)
         prob = torch.empty((n, 2, d, h, w), dtype=torch.float32, device=x.device)
-        check(lib.vs_conv_k3_softmax2_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), prob.data_ptr(), n, d, h, w, c,
-                                          vs_dtype(x), EPS_IN, _stream()), "conv_k3_softmax2_fwd")
+        check(lib.vs_conv_k3_softmax2_dropout_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), prob.data_ptr(), n, d, h, w, c,
+                                                  vs_dtype(x), EPS_IN, float(drop_p), drop_seed, _stream()), "conv_k3_softmax2_fwd")
         ctx.save_for_backward(x, xs, weight, prob)
         ctx.has_bias = bias is not None
+        ctx.drop = (float(drop_p), drop_seed)
         return prob
 
     @staticmethod
@@ -495,8 +496,8 @@ class ConvK3Softmax(torch.autograd.Function):
         n, d, h, w, c = x.shape
         gprob = _contig(gprob.float())
         gl = torch.empty((n, d, h, w, 8), dtype=x.dtype, device=x.device)
-        check(lib.vs_softmax2_bwd(prob.data_ptr(), gprob.data_ptr(), gl.data_ptr(), n, d * h * w, 8, vs_dtype(x),
-                                  _stream()), "softmax2_bwd")
+        check(lib.vs_softmax2_dropout_bwd(prob.data_ptr(), gprob.data_ptr(), gl.data_ptr(), n, d * h * w, 8, vs_dtype(x),
+                                          ctx.drop[0], ctx.drop[1], _stream()), "softmax2_bwd")
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, x.dtype)
@@ -511,7 +512,7 @@ class ConvK3Softmax(torch.autograd.Function):
                     gb = bias_grad(gl, 2)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gl, 2)
-        return gx, None, gw, gb
+        return gx, None, gw, gb, None, None
 
 
 class ConvK2S2(torch.autograd.Function):
@@ -608,6 +609,37 @@ class Materialize(torch.autograd.Function):
         if x2 is not None and ctx.needs_input_grad[2]:
             g2 = in_relu_bwd(g, x2, x2s, inplace=False) if x2s is not None else g
         return g1, None, g2, None
+
+
+_DROPOUT_CALLS = [0]
+
+
+def next_dropout_seed():
+    """A fresh 64-bit seed per dropout site per call, a pure function of torch's seed and a call counter (host side: no
+    device sync).  Under HIP-graph replay the captured seeds repeat, so GraphedStep refuses models with dropout > 0."""
+    _DROPOUT_CALLS[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROPOUT_CALLS[0] * 0xD1B54A32D192ED03) % (1 << 64)
+
+
+class Dropout(torch.autograd.Function):
+    """F.dropout(x, p, training=True) on a final channels-last activation (joint_model.py:256-264,379-385)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _require_cuda(x)
+        x = _contig(x)
+        out = torch.empty_like(x)
+        check(lib.vs_dropout(x.data_ptr(), out.data_ptr(), x.numel(), float(p), seed, vs_dtype(x), _stream()), "dropout")
+        ctx.cfg = (float(p), seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed = ctx.cfg
+        g = _contig(g)
+        out = torch.empty_like(g)
+        check(lib.vs_dropout(g.data_ptr(), out.data_ptr(), g.numel(), p, seed, vs_dtype(g), _stream()), "dropout")
+        return out, None, None
 
 
 class PackPlanar(torch.autograd.Function):
