@@ -1,0 +1,49 @@
+"""Diagnostic: per-phase cycle sums of k3_kernel (needs tools/_dbg/libvaeseg_stamps.so from tools/build_stamps.sh)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from vae_segmentation_amd import _lib, ops
+dbg = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dbg", "libvaeseg_stamps.so"))
+for name, (restype, argtypes) in _lib.parse_header().items():
+    fn = getattr(dbg, name); fn.restype = restype; fn.argtypes = argtypes
+dbg.vs_debug_read_k3_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+n, c, m, s = [int(v) for v in sys.argv[1:5]]
+x = torch.randn(n, s, s, s, c, device="cuda").to(torch.bfloat16)
+w = torch.randn(m, c, 3, 3, 3, device="cuda") * 0.05
+wp = ops.pack_weight(w, 0, c, torch.bfloat16)
+xs = ops.instnorm_stats(x)
+y = torch.empty(n, s, s, s, m, device="cuda", dtype=torch.bfloat16)
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for it in range(3):
+    ys = torch.zeros(n, m, 2, dtype=torch.float64, device="cuda")
+    ev0.record()
+    rc = dbg.vs_conv_gather_fwd(x.data_ptr(), xs.data_ptr(), wp.data_ptr(), None, y.data_ptr(), ys.data_ptr(), n, s, s, s, c, m, 0, 1, 1e-5, None)
+    ev1.record()
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+print("launch %.1f us" % (ev0.elapsed_time(ev1) * 1e3))
+nwg = 2048
+buf = np.zeros(nwg * 8, dtype=np.uint64)
+dbg.vs_debug_read_k3_stamps(buf.ctypes.data, nwg * 8)
+st = buf.reshape(nwg, 8).astype(np.int64)
+st = st[st.sum(1) > 0]
+names = ["(loop top)", "barrier 1 (prev tile read by all)", "vmcnt wait + transform + LDS write", "barrier 2", "prefetch issue", "MFMA phase", "epilogue", "-"]
+tot = st.sum(1)
+print("workgroups with stamps:", len(st), " median total ticks/WG:", int(np.median(tot)))
+for i, nm in enumerate(names[:7]):
+    print("%-38s median %8d ticks  %5.1f %%" % (nm, np.median(st[:, i]), 100 * np.median(st[:, i]) / np.median(tot)))
+buf = np.zeros(2048 * 20, dtype=np.uint64)
+dbg.vs_debug_read_k3_stamps(buf.ctypes.data, 2048 * 20)
+ab = buf[2048 * 8:].reshape(2048, 12).astype(np.int64)
+ab = ab[ab[:, 0] > 0]
+rt = (ab[:, 11] - ab[:, 10]); ck = (ab[:, 9] - ab[:, 0])
+print("memtime ticks per 10ns realtime tick: %.2f  (=> %.2f GHz)" % (np.median(ck / np.maximum(rt, 1)), np.median(ck / np.maximum(rt, 1)) / 10))
+t0 = ab[:, 0].min()
+print("WG start skew: median %d max %d ticks; kernel span %d ticks" % (np.median(ab[:, 0] - t0), (ab[:, 0] - t0).max(), ab[:, 9].max() - t0))
+an = ["entry", "stats tables computed", "barrier (tables visible)", "first stage_load issued", "tile0: barrier 1", "tile0: LDS written", "tile0: barrier 2", "tile0: MFMA done", "tile0: epilogue done", "kernel end"]
+prev = None
+for i, nm in enumerate(an):
+    v = np.median(ab[:, i] - ab[:, 0])
+    print("%-28s +%8d ticks  (phase %7d)" % (nm, v, v - (prev or 0)))
+    prev = v

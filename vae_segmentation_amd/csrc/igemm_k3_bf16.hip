@@ -1,14 +1,19 @@
 #include "igemm_dispatch.h"
-#include "igemm_k3.h"
+#include "igemm_k3b.h"
 
-#define K3_CASE(CKV, MTV) if (ck == CKV && mt == MTV) return k3_launch<unsigned short, CKV, MTV, EPI_RAW>(p, tiles, row_tiles, s);
-#define K3_ALL_MT(CKV) K3_CASE(CKV, 16) K3_CASE(CKV, 32) K3_CASE(CKV, 64)
+#define K3B_CASE(CKV, MTV)                                                                              \
+    if (ck == CKV && mt == MTV)                                                                          \
+        return p.sums ? k3b_launch<CKV, MTV, EPI_RAW, true>(p, tiles, row_tiles, s)                      \
+                      : k3b_launch<CKV, MTV, EPI_RAW, false>(p, tiles, row_tiles, s);
 
+// bf16 3x3x3 convolutions run k3b_kernel with 16- or 32-row tiles (a 64-row weight block does not fit LDS next to the halo
+// tile): a 64-row request from pick_mt() is served as twice as many 32-row workgroups.
 int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s) {
     if (epi == EPI_SOFTMAX2) {
-        if (ck == 8 && mt == 16) return k3_launch<unsigned short, 8, 16, EPI_SOFTMAX2>(p, tiles, row_tiles, s);
+        if (ck == 8 && mt == 16) return k3b_launch<8, 16, EPI_SOFTMAX2, false>(p, tiles, row_tiles, s);
         return VS_ESHAPE;
     }
-    K3_ALL_MT(8) K3_ALL_MT(16) K3_ALL_MT(32)
+    if (mt == 64) { mt = 32; row_tiles *= 2; }
+    K3B_CASE(8, 16) K3B_CASE(8, 32) K3B_CASE(16, 16) K3B_CASE(16, 32) K3B_CASE(32, 16) K3B_CASE(32, 32)
     return VS_ESHAPE;
 }
