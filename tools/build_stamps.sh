@@ -1,9 +1,9 @@
 #!/bin/bash
-# Diagnostic build of libvaeseg with -DVS_STAMPS (s_memtime phase stamps in k3_small / k3_kernel); never shipped.
+# Diagnostic build of libvaeseg with -DVS_STAMPS (s_memtime phase stamps in k3b_kernel); never shipped.
 set -e
 cd "$(dirname "$0")/../vae_segmentation_amd/csrc"
 mkdir -p ../../tools/_dbg/obj
-for f in igemm_k3_f32 igemm_k3_bf16 igemm_k3_small igemm_k2s2 igemm_pw conv_api wgrad pack norm misc; do
+for f in igemm_k3_f32 igemm_k3_bf16 igemm_k2s2 igemm_pw conv_api wgrad pack norm misc; do
   /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -DVS_STAMPS -Wno-unused-variable -c $f.hip -o ../../tools/_dbg/obj/$f.o &
 done
 wait

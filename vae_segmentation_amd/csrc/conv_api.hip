@@ -63,8 +63,6 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     const int mt = pick_mt(rows16, tiles);
     const int row_tiles = rows16 / mt;
     if (kind == VS_CONV_K3) {
-        const int rs = k3_small_try(p, dtype, (hipStream_t)stream);      // deepest levels: flattened-column split-K kernel
-        if (rs != K3_SMALL_NA) return rs;
         return dtype == VS_F32 ? g1_dispatch_k3_f32(p, ck, mt, EPI_RAW, (int)tiles, row_tiles, (hipStream_t)stream)
                                : g1_dispatch_k3_bf16(p, ck, mt, EPI_RAW, (int)tiles, row_tiles, (hipStream_t)stream);
     }

@@ -38,6 +38,7 @@ struct G1Params {
     int tyn, txn;         // K3 tiling: tiles along y and x
     float eps;
     double inv_count_in;  // 1 / (D*H*W) of the input grid
+    unsigned int fd_m[3], fd_s[3];   // k3b_kernel: multiply-shift pairs for / tiles_per_sample, / (txn*tyn), / txn (k3b_launch fills them)
 };
 
 // LDS carve (bytes)

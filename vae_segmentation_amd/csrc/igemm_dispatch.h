@@ -4,8 +4,6 @@
 
 int g1_dispatch_k3(const G1Params& p, int dtype, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_dispatch_k2s2(const G1Params& p, int dtype, int ck, int mt, int tiles, int row_tiles, hipStream_t s);
-#define K3_SMALL_NA (-1000)
-int k3_small_try(const G1Params& p, int dtype, hipStream_t stream);
 int g1_dispatch_pw(const G1Params& p, int dtype, int ck, int mt, int tiles, int row_tiles, hipStream_t s);
 
 #define G1_CASE(T, CKV, KIND, MTV, EPI) \

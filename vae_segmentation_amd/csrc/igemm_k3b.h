@@ -26,6 +26,14 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // raw buffer load: lanes whose byte offset is >= num_records return 0 (hardware bounds check, stride 0)
 __device__ i32x4 vs_raw_buffer_load_b128(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+__device__ i32x2 vs_raw_buffer_load_b64(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2i32");
+// raw buffer store: lanes whose byte offset is out of range are dropped
+__device__ void vs_raw_buffer_store_b64(i32x2 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
+
+// n / d for 0 <= n < 2^31 with the host-made pair (m, s) of k3b_fastdiv(): (mulhi(n, m) + n) >> s  (Granlund-Montgomery round-up)
+__device__ __forceinline__ int fdiv(int n, unsigned int m, unsigned int sh) { return (int)((__umulhi((unsigned int)n, m) + (unsigned int)n) >> sh); }
+
 __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned int bytes) {
     const unsigned long long a = (unsigned long long)base;
     i32x4 r;
@@ -53,6 +61,20 @@ __device__ __forceinline__ u32x4 act8(const u32x4 raw, const f32x2 (&sc)[4], con
     return r;
 }
 
+#ifdef VS_STAMPS   // diagnostic build only (tools/build_stamps.sh, tools/stamps_k3.py): per-phase cycle sums of wave 0
+__device__ unsigned long long g_k3_stamps[2048 * 8];
+extern "C" int vs_debug_read_k3_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k3_stamps), sizeof(unsigned long long) * n);
+}
+#define K3_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk_acc[i] += now_ - tk_last; tk_last = now_; } while (0)
+#define K3_TICK_INIT unsigned long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk_last = __builtin_amdgcn_s_memtime();
+#define K3_TICK_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) g_k3_stamps[((blockIdx.y * gridDim.x + blockIdx.x) & 2047) * 8 + i_] = tk_acc[i_]; } } while (0)
+#else
+#define K3_TICK(i)
+#define K3_TICK_INIT
+#define K3_TICK_FLUSH
+#endif
+
 #define K3B_LDS_RED 0          // float[4][64][2]
 #define K3B_LDS_TAPS 2048      // int[64]: byte offset of (k-group, lane group)'s tap in the halo tile (C = 8 / 16)
 #define K3B_LDS_TILE 2304      // halo tile, weight block, then the per-(n,c) tables
@@ -73,6 +95,7 @@ struct K3BGeom {
 template <int CK, int MT, int EPI, bool SUMS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? (MT == 32 ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : (CK == 16 && SUMS ? 3 : 4)), 8))) void k3b_kernel(const G1Params p) {
     typedef unsigned short T;
+    K3_TICK_INIT
     using GEO = K3BGeom<CK, MT>;
     static_assert(CK == 8 || CK == 16 || CK == 32, "chunk width");
     constexpr int RB = GEO::RB, NKGC = GEO::NKGC, CKB = GEO::CKB, NWF = GEO::NWF;
@@ -127,20 +150,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
 
     u32x4 xv[NIT], wv[NWI];
     unsigned int okbits = 0;
-    auto tile_origin = [&](int t, int& n, int& z0, int& y0, int& x0) {
-        n = t / p.tiles_per_sample;
-        const int tl = t - n * p.tiles_per_sample;
-        x0 = (tl % p.txn) * 16;
-        y0 = ((tl / p.txn) % p.tyn) * 4;
-        z0 = (tl / (p.txn * p.tyn)) * 4;
+    struct Coord { int n, z0, y0, x0; };
+    auto tile_coord = [&](int t) {                        // scalar: t is workgroup-uniform
+        Coord c;
+        c.n = fdiv(t, p.fd_m[0], p.fd_s[0]);
+        const int tl = t - c.n * p.tiles_per_sample;
+        const int tz = fdiv(tl, p.fd_m[1], p.fd_s[1]);
+        const int r = tl - tz * (p.txn * p.tyn);
+        const int ty = fdiv(r, p.fd_m[2], p.fd_s[2]);
+        c.z0 = tz * 4; c.y0 = ty * 4; c.x0 = (r - ty * p.txn) * 16;
+        return c;
     };
     auto load_w = [&](int ch) {
 #pragma unroll
         for (int i = 0; i < NWI; ++i) wv[i] = wp[w_off[i] + ch * (NKGC * 64)];
     };
-    auto load_x = [&](int t, int ch) {
-        int n, z0, y0, x0;
-        tile_origin(t, n, z0, y0, x0);
+    auto load_x = [&](const Coord& c, int ch) {
+        const int n = c.n, z0 = c.z0, y0 = c.y0, x0 = c.x0;
         const int base = ((((n * p.D + z0 - 1) * p.H + y0 - 1) * p.W + x0 - 1) * p.C + ch * CK) * 2;
         okbits = 0;
 #pragma unroll
@@ -182,8 +208,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
 
     // ---- first stage in flight before anything else; the statistics tables meanwhile ----------------------------------
     int t = blockIdx.x;                                  // the grid never exceeds the tile count
+    Coord cur = tile_coord(t), nxt = cur;
     load_w(0);
-    load_x(t, 0);
+    load_x(cur, 0);
+    // bias of this workgroup's rows (registers: a load inside the tile loop would queue behind the prefetch)
+    float bv[RB][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = (rb0 + rb) * 16 + 4 * g + r;
+            bv[rb][r] = (p.bias != nullptr && row < (EPI == EPI_SOFTMAX2 ? 2 : p.M)) ? p.bias[row] : 0.f;
+        }
+    const i32x4 yrsrc = make_rsrc(p.y, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.M * 2));
+    const i32x4 mrsrc = make_rsrc(p.mask_x, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.M * 2));
     if (has_stats) {
         for (int i = tid; i < p.N * p.C; i += 256) {
             float m, r;
@@ -228,15 +266,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[rb][r] = 0.f; ssq[rb][r] = 0.f; }
 
+    // consume the bias here: its wait belongs to the prologue (left to the first use, the compiler waits for it inside
+    // the tile loop, i.e. for the whole prefetch queued behind it, on every tile)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bv[rb][r]));
     constexpr bool restage_w = !SMALLC;                  // C = 8 / 16 is a single chunk: the weight block is staged once
     bool first = true;
     if constexpr (SMALLC) write_w();
     __syncthreads();                                     // tables visible
+    K3_TICK(0);                                          // prologue
 
     for (; t < total_tiles; t += gridDim.x) {
-        int n, z0, y0, x0;
-        tile_origin(t, n, z0, y0, x0);
+        const int n = cur.n, z0 = cur.z0, y0 = cur.y0, x0 = cur.x0;
         const int oz = z0 + wave;
+        // byte offset of output voxel (n, oz, y0 + cg, x0 + col), row 4g of row block rb: ebase + cg * W*M*2 + rb * 32; -1 = dropped
+        const int ebase = ((((n * p.D + oz) * p.H + y0) * p.W + x0 + col) * p.M + rb0 * 16 + 4 * g) * 2;
+        const bool zx_ok = oz < p.D && x0 + col < p.W;
         f32x4 acc[RB][4];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -246,35 +293,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
 
         for (int ch = 0; ch < p.nch; ++ch) {
             if (!first) __syncthreads();                 // every wave is done reading the previous stage
+            K3_TICK(1);
             write_x(n, ch);
             if constexpr (restage_w) write_w();
             first = false;
+            K3_TICK(2);
             __syncthreads();
+            K3_TICK(3);
             // requests of the next stage, oldest-needed first (vmcnt retires in issue order)
             const bool last_ch = ch + 1 == p.nch;
             if constexpr (EPI == EPI_RAW) {
                 if (has_sums && last_ch) {
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) {
-                        const int row = (rb0 + rb) * 16 + 4 * g;
+                    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                         for (int cg = 0; cg < 4; ++cg) {
-                            const int oy = y0 + cg, ox = x0 + col;
-                            const bool valid = row < p.M && oz < p.D && oy < p.H && ox < p.W;
-                            const size_t e = valid ? ((((size_t)n * p.D + oz) * p.H + oy) * p.W + ox) * p.M + row : 0;
-                            mk[rb][cg] = *(const u32x2*)((const unsigned short*)p.mask_x + e);
+                            const bool valid = zx_ok && y0 + cg < p.H && (rb0 + rb) * 16 + 4 * g < p.M;
+                            mk[rb][cg] = __builtin_bit_cast(u32x2, vs_raw_buffer_load_b64(mrsrc, valid ? ebase + cg * p.W * p.M * 2 + rb * 32 : -1, 0, 0));
                         }
-                    }
                 }
             }
             {
                 const int tn = last_ch ? t + (int)gridDim.x : t;
+                if (last_ch) nxt = tile_coord(tn);
                 if (tn < total_tiles) {
                     if constexpr (restage_w) load_w(last_ch ? 0 : ch + 1);
-                    load_x(tn, last_ch ? 0 : ch + 1);
+                    load_x(last_ch ? nxt : cur, last_ch ? 0 : ch + 1);
                 }
             }
 
+            K3_TICK(4);
             // ---- multiply this stage out of LDS ----
             // fragments of k-group kg+1 are read while k-group kg is multiplied; the scheduling barriers keep the compiler
             // from hoisting the whole unrolled loop's reads (hundreds of live registers) in front of the first MFMA
@@ -305,9 +353,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
         }
 
         // ---- epilogue of this tile ----
+        K3_TICK(5);
         if constexpr (EPI == EPI_SOFTMAX2) {
             if (g == 0) {
-                const float b0 = p.bias ? p.bias[0] : 0.f, b1 = p.bias ? p.bias[1] : 0.f;
+                const float b0 = bv[0][0], b1 = bv[0][1];
                 const size_t V = (size_t)p.D * p.H * p.W;
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg) {
@@ -327,36 +376,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
                 }
             }
         } else {
-            T* __restrict__ yout = (T*)p.y;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const int row = (rb0 + rb) * 16 + 4 * g;
-                const bool rvalid = row < p.M;
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias && rvalid) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bv[r] = p.bias[row + r];
-                }
+                const bool rvalid = (rb0 + rb) * 16 + 4 * g < p.M;
                 float mm[4] = {0.f, 0.f, 0.f, 0.f}, mr[4] = {0.f, 0.f, 0.f, 0.f};
                 if (has_sums && rvalid) {
+                    const int row = (rb0 + rb) * 16 + 4 * g;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { mm[r] = s_mkm[n * p.M + row + r]; mr[r] = s_mkr[n * p.M + row + r]; }
                 }
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg) {
-                    const int oy = y0 + cg, ox = x0 + col;
-                    const bool valid = rvalid && oz < p.D && oy < p.H && ox < p.W;
+                    const bool valid = rvalid && zx_ok && y0 + cg < p.H;
+                    // round once to bf16; the statistics are those of the stored values
+                    f32x2 lo, hi;
+                    lo[0] = acc[rb][cg][0] + bv[rb][0]; lo[1] = acc[rb][cg][1] + bv[rb][1];
+                    hi[0] = acc[rb][cg][2] + bv[rb][2]; hi[1] = acc[rb][cg][3] + bv[rb][3];
+                    i32x2 pk;
+                    pk[0] = __builtin_bit_cast(int, __builtin_convertvector(lo, bf16x2));
+                    pk[1] = __builtin_bit_cast(int, __builtin_convertvector(hi, bf16x2));
+                    vs_raw_buffer_store_b64(pk, yrsrc, valid ? ebase + cg * p.W * p.M * 2 + rb * 32 : -1, 0, 0);
                     float v[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = round_bf(acc[rb][cg][r] + bv[r]);
-                    if (valid) {
-                        const size_t e = ((((size_t)n * p.D + oz) * p.H + oy) * p.W + ox) * p.M + row;
-                        u32x2 pk;
-                        pk[0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
-                        pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
-                        *(u32x2*)(yout + e) = pk;
-                    }
-                    const float keep = valid ? 1.f : 0.f;
+                    v[0] = __uint_as_float((unsigned int)pk[0] << 16); v[1] = __uint_as_float((unsigned int)pk[0] & 0xffff0000u);
+                    v[2] = __uint_as_float((unsigned int)pk[1] << 16); v[3] = __uint_as_float((unsigned int)pk[1] & 0xffff0000u);
+                    if (!valid) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
                     if (has_sums) {
                         const u32x2 xx = mk[rb][cg];
                         float xv4[4];
@@ -365,19 +408,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float xh = (xv4[r] - mm[r]) * mr[r];
-                            const float gm = xh > 0.f ? v[r] * keep : 0.f;
+                            const float gm = xh > 0.f ? v[r] : 0.f;
                             ssum[rb][r] += gm; ssq[rb][r] += gm * xh;
                         }
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { const float vk = v[r] * keep; ssum[rb][r] += vk; ssq[rb][r] += vk * vk; }
+                        for (int r = 0; r < 4; ++r) { ssum[rb][r] += v[r]; ssq[rb][r] += v[r] * v[r]; }
                     }
                 }
             }
             double* const red_dst = has_sums ? p.sums : p.y_stats;
             if (red_dst != nullptr) {
-                const int tn = t + (int)gridDim.x;
-                const bool flush = tn >= total_tiles || tn / p.tiles_per_sample != n;     // workgroup-uniform
+                const bool flush = t + (int)gridDim.x >= total_tiles || nxt.n != n;       // workgroup-uniform
                 if (flush) {
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
@@ -407,16 +449,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
                 }
             }
         }
+        cur = nxt;
+        K3_TICK(6);
     }
+    K3_TICK_FLUSH;
+}
+
+// (m, s) with n / d == (mulhi(n, m) + n) >> s for every 0 <= n < 2^31
+static inline void k3b_fastdiv(int d, unsigned int& m, unsigned int& s) {
+    s = 0;
+    while ((1ll << s) < d) ++s;
+    m = (unsigned int)((((1ull << (32 + s)) + (unsigned long long)d - 1) / (unsigned long long)d) - (1ull << 32));
 }
 
 template <int CK, int MT, int EPI, bool SUMS>
-static int k3b_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
+static int k3b_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
     using GEO = K3BGeom<CK, MT>;
-    const size_t tables = (size_t)2 * p.N * p.C * sizeof(float) + (p.sums ? (size_t)2 * p.N * p.M * sizeof(float) : 0);
+    const size_t tables = (size_t)2 * p_in.N * p_in.C * sizeof(float) + (p_in.sums ? (size_t)2 * p_in.N * p_in.M * sizeof(float) : 0);
     const size_t lds = K3B_LDS_TILE + (size_t)GEO::TILE_BYTES + GEO::W_BYTES + tables;
     if (lds > 160 * 1024) return VS_ESHAPE;
-    if ((long long)p.N * p.D * p.H * p.W * p.C * 2 >= 4294967296ll) return VS_ESHAPE;     // buffer offsets are 32-bit bytes
+    G1Params p = p_in;
+    // buffer offsets are 32-bit bytes, signed on the device
+    if ((long long)p.N * p.D * p.H * p.W * p.C * 2 >= 2147483648ll || (long long)p.N * p.D * p.H * p.W * p.M * 2 >= 2147483648ll) return VS_ESHAPE;
+    k3b_fastdiv(p.tiles_per_sample, p.fd_m[0], p.fd_s[0]);
+    k3b_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
+    k3b_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
     if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr)) return VS_EINVAL;
     auto kern = k3b_kernel<CK, MT, EPI, SUMS>;
     // idempotent one-time opt-in to the full 160 KiB of dynamic LDS (not a stream operation)

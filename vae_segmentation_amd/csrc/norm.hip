@@ -147,30 +147,62 @@ template <typename T>
 __global__ __launch_bounds__(256) void in_relu_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x, const double* xs,
                                                                 const double* __restrict__ sums, T* __restrict__ gx,
                                                                 long long voxels, int c, double inv_count, float eps) {
+    // Streaming pass, 3 tensors: a thread keeps UN (g, x) fragment pairs in flight and requests the next batch before it
+    // works on the current one; the first batch is requested before the statistics tables are built, so the kernel's
+    // start-up is one memory round trip, not two (most of its 58 launches per step are small and start-up bound).
     constexpr int EPL = ET<T>::EPL;
+    constexpr int UN = 4;
     __shared__ float s_m[NB_MAX_C], s_r[NB_MAX_C], s_a[NB_MAX_C], s_b[NB_MAX_C];
     const int n = blockIdx.y;
+    RowIter<T> it(c);
+    const bool act = it.active();
+    const size_t sample = (size_t)n * voxels * c + it.fx * EPL;
+    const long long stride = (long long)gridDim.x * it.rows_per_it;
+    long long v = (long long)blockIdx.x * it.rows_per_it + it.fy;
+    u32x4 gq[UN], xq[UN];
+    auto request = [&](long long v0) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long vv = v0 + u * stride;
+            const size_t e = (act && vv < voxels) ? sample + vv * c : sample - it.fx * EPL;     // clamped lanes re-read voxel 0
+            gq[u] = *(const u32x4*)(g + e);
+            xq[u] = *(const u32x4*)(x + e);
+        }
+    };
+    request(v);
     load_mean_rstd(xs, n, c, inv_count, eps, s_m, s_r);
     for (int i = threadIdx.x; i < c; i += 256) {
         s_a[i] = (float)(sums[((size_t)n * c + i) * 2 + 0] * inv_count);
         s_b[i] = (float)(sums[((size_t)n * c + i) * 2 + 1] * inv_count);
     }
     __syncthreads();
-    RowIter<T> it(c);
-    if (!it.active()) return;
-    const size_t sample = (size_t)n * voxels * c + it.fx * EPL;
-    for (long long v = (long long)blockIdx.x * it.rows_per_it + it.fy; v < voxels; v += (long long)gridDim.x * it.rows_per_it) {
-        float fg[EPL], fx_[EPL], o[EPL];
-        frag_unpack(*(const u32x4*)(g + sample + v * c), fg, (T*)nullptr);
-        frag_unpack(*(const u32x4*)(x + sample + v * c), fx_, (T*)nullptr);
+    if (!act) return;
+    float m[EPL], r[EPL], a[EPL], b[EPL];
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            const int ch = it.fx * EPL + j;
-            const float xh = (fx_[j] - s_m[ch]) * s_r[ch];
-            const float gm = xh > 0.f ? fg[j] : 0.f;
-            o[j] = s_r[ch] * (gm - s_a[ch] - xh * s_b[ch]);
+    for (int j = 0; j < EPL; ++j) {
+        const int ch = it.fx * EPL + j;
+        m[j] = s_m[ch]; r[j] = s_r[ch]; a[j] = s_a[ch]; b[j] = s_b[ch];
+    }
+    for (; v < voxels; v += UN * stride) {
+        u32x4 gc[UN], xc[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { gc[u] = gq[u]; xc[u] = xq[u]; }
+        request(v + UN * stride);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long vv = v + u * stride;
+            if (vv >= voxels) break;
+            float fg[EPL], fx_[EPL], o[EPL];
+            frag_unpack(gc[u], fg, (T*)nullptr);
+            frag_unpack(xc[u], fx_, (T*)nullptr);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const float xh = (fx_[j] - m[j]) * r[j];
+                const float gm = xh > 0.f ? fg[j] : 0.f;
+                o[j] = r[j] * (gm - a[j] - xh * b[j]);
+            }
+            *(u32x4*)(gx + sample + vv * c) = frag_pack(o, (T*)nullptr);
         }
-        *(u32x4*)(gx + sample + v * c) = frag_pack(o, (T*)nullptr);
     }
 }
 
@@ -269,7 +301,12 @@ extern "C" int vs_instnorm_relu_bwd_apply(const void* g, const void* x, const do
     int rc = check_cl(x, n, voxels, c, dtype);
     if (rc) return rc;
     if (!g || !x_stats || !sums || !gx) return VS_EINVAL;
-    dim3 grid(row_blocks(voxels, c, dtype), n);
+    // one batch of 4 rows per thread where the volume allows it, at most ~8 workgroups per CU over the n samples
+    const int rpi = 256 / (c / (dtype == VS_F32 ? 4 : 8));
+    long long gb = (voxels + (long long)rpi * 4 - 1) / ((long long)rpi * 4);
+    const long long gcap = 2048 / n > 0 ? 2048 / n : 1;
+    if (gb > gcap) gb = gcap;
+    dim3 grid((unsigned)gb, n);
     const double inv = 1.0 / (double)voxels;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(in_relu_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)x, x_stats, sums, (float*)gx, voxels, c, inv, eps),

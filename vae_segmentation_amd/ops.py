@@ -42,10 +42,8 @@ def _pick_mt(rows16, tiles):
     return 16
 
 
-def _k3_kid(tname, ck, mt, small):
+def _k3_kid(tname, ck, mt):
     """kernel instantiation name of a 3x3x3 launch (mirrors g1_dispatch_k3_* in csrc; rocprof prints the same string)."""
-    if small:
-        return "k3_small_kernel"
     if tname == "float":
         return "k3_kernel<float,%d,%d,0>" % (ck, mt)
     return "k3b_kernel<%d,%d,0>" % (ck, min(mt, 32))
@@ -305,8 +303,7 @@ def conv_gather(x, xs, wp, bias, m_out, kind, want_stats, real_channels=None):
         rows16 = (m_out + 15) // 16 * 16
         tname = "float" if x.dtype == torch.float32 else "unsigned short"
         if kind == VS_CONV_K3:
-            small = x.dtype == torch.bfloat16 and c % 32 == 0 and d * h * w <= 224 and (d + 2) * (h + 2) * (w + 2) <= 512
-            kid = _k3_kid(tname, ck, _pick_mt(rows16, tiles), small)
+            kid = _k3_kid(tname, ck, _pick_mt(rows16, tiles))
         else:
             kid = "g1_kernel<%s,%d,%d,%d,0>" % (tname, ck, kind, _pick_mt(rows16, tiles))
         cr = real_channels[0] if real_channels else c
@@ -366,8 +363,7 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
                 tiles = n * ((g.numel() // (n * c) + 255) // 256)
             tname = "float" if x.dtype == torch.float32 else "unsigned short"
             if kind == VS_CONV_K3:
-                small = x.dtype == torch.bfloat16 and gc % 32 == 0 and gd * gh * gw <= 224 and (gd + 2) * (gh + 2) * (gw + 2) <= 512
-                kid = _k3_kid(tname, min(gc, 32), _pick_mt((c + 15) // 16 * 16, tiles), small)
+                kid = _k3_kid(tname, min(gc, 32), _pick_mt((c + 15) // 16 * 16, tiles))
             else:
                 kid = "g1_kernel<%s,%d,%d,%d,0>" % (tname, min(gc, 32), kind, _pick_mt((c + 15) // 16 * 16, tiles))
             cr = real_channels[0] if real_channels else gc
