@@ -18,49 +18,6 @@
 #include <stdlib.h>
 #include "igemm.h"
 
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) short i16x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-
-// raw buffer load: lanes whose byte offset is >= num_records return 0 (hardware bounds check, stride 0)
-__device__ i32x4 vs_raw_buffer_load_b128(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
-
-typedef __attribute__((ext_vector_type(2))) int i32x2;
-__device__ i32x2 vs_raw_buffer_load_b64(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2i32");
-// raw buffer store: lanes whose byte offset is out of range are dropped
-__device__ void vs_raw_buffer_store_b64(i32x2 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");
-
-// n / d for 0 <= n < 2^31 with the host-made pair (m, s) of k3b_fastdiv(): (mulhi(n, m) + n) >> s  (Granlund-Montgomery round-up)
-__device__ __forceinline__ int fdiv(int n, unsigned int m, unsigned int sh) { return (int)((__umulhi((unsigned int)n, m) + (unsigned int)n) >> sh); }
-
-__device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned int bytes) {
-    const unsigned long long a = (unsigned long long)base;
-    i32x4 r;
-    r[0] = (int)(unsigned int)a;
-    r[1] = (int)(unsigned int)((a >> 32) & 0xffffu);     // stride 0, no swizzle
-    r[2] = (int)bytes;
-    r[3] = 0x00020000;                                   // gfx9 raw buffer, 32-bit data format
-    return r;
-}
-
-// relu(x * scale + shift) on one 16-byte fragment of 8 bf16 channels
-__device__ __forceinline__ u32x4 act8(const u32x4 raw, const f32x2 (&sc)[4], const f32x2 (&sh)[4]) {
-    u32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f32x2 v;
-        v[0] = __uint_as_float(raw[i] << 16);
-        v[1] = __uint_as_float(raw[i] & 0xffff0000u);
-        v = v * sc[i] + sh[i];
-        const bf16x2 h = __builtin_convertvector(v, bf16x2);
-        i16x2 s = __builtin_bit_cast(i16x2, h);
-        s = __builtin_elementwise_max(s, i16x2{0, 0});  // ReLU on the bf16 bit patterns: negative floats are negative int16
-        r[i] = __builtin_bit_cast(unsigned int, s);
-    }
-    return r;
-}
-
 #ifdef VS_STAMPS   // diagnostic build only (tools/build_stamps.sh, tools/stamps_k3.py): per-phase cycle sums of wave 0
 __device__ unsigned long long g_k3_stamps[2048 * 8];
 extern "C" int vs_debug_read_k3_stamps(unsigned long long* host, int n) {

@@ -208,17 +208,22 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* s_base, int off0, int off1
 #define G3B_LDS_P (4 * G3_MAXN * 16 * 4)
 #define G3B_LDS_Q (G3B_LDS_P + 256 * 16 * 2)
 
+// Tile t+ksplit's P and Q fragments are requested (bounds-checked buffer loads: out-of-volume fragments read as zero,
+// no branches) right after tile t went to LDS, so their latency is covered by tile t's MFMA phase; the lazy operands'
+// normalise+ReLU runs as packed fma / packed max (common.h act8).
 template <int CB, int KIND>
 __global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) {
     using GEO = G3Geo<CB, KIND>;
-    typedef unsigned short T;
     constexpr int NTAPS = GEO::NTAPS, NCB = GEO::NCB, QY = GEO::QY, QX = GEO::QX, QV = GEO::QV;
     constexpr int QROW = CB * 2;                 // bytes per Q-tile voxel
+    constexpr int QU = CB / 8;                   // 16-byte fragments per Q-tile voxel
+    constexpr int NQ = QV * QU;
+    constexpr int NITQ = (NQ + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* s_pm = (float*)(smem + G3_LDS_STATS);
-    float* s_pr = s_pm + G3_MAXN * 16;
-    float* s_qm = s_pr + G3_MAXN * 16;
-    float* s_qr = s_qm + G3_MAXN * 16;
+    float* s_psc = (float*)(smem + G3_LDS_STATS);     // scale (rstd) / shift (-mean * rstd) of P's and Q's 16 channels, per sample
+    float* s_psh = s_psc + G3_MAXN * 16;
+    float* s_qsc = s_psh + G3_MAXN * 16;
+    float* s_qsh = s_qsc + G3_MAXN * 16;
     char* s_p = smem + G3B_LDS_P;                // [256 voxels][16 ch] bf16
     char* s_q = smem + G3B_LDS_Q;                // [QV voxels][CB ch] bf16
 
@@ -226,20 +231,111 @@ __global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) {
     const int q4 = col >> 2, p4 = col & 3;       // tr-read addressing: this lane supplies row q4, columns 4*p4..4*p4+3
     const int mb = blockIdx.x / p.cbn, cb = blockIdx.x - mb * p.cbn;
     const int ks = blockIdx.y;
-    const T* __restrict__ Pp = (const T*)p.P;
-    const T* __restrict__ Qp = (const T*)p.Q;
     const bool p_stats = p.P_stats != nullptr, q_stats = p.Q_stats != nullptr;
+    const i32x4 prsrc = make_rsrc(p.P, (unsigned int)((long long)p.N * p.Dp * p.Hp * p.Wp * p.Mch * 2));
+    const i32x4 qrsrc = make_rsrc(p.Q, (unsigned int)((long long)p.N * p.Dq * p.Hq * p.Wq * p.Cch * 2));
 
+    // ---- tile-independent fragment geometry ----
+    // P fragment b: voxel v = (tid + 256 b) >> 1 of the 4x4x16 tile, channel half `ppart`; Q fragment b: voxel qv of the halo /
+    // strided region, 16-byte part `qpart` (constant per thread: 256 % QU == 0)
+    const int ppart = tid & 1, qpart = tid % QU;
+    const bool pch_ok = mb * 16 + ppart * 8 < p.Mch, qch_ok = cb * CB + qpart * 8 < p.Cch;
+    int prel[2], pzyx[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int v = (tid + b * 256) >> 1;
+        const int lx = v & 15, ly = (v >> 4) & 3, lz = v >> 6;
+        prel[b] = (((lz * p.Hp + ly) * p.Wp + lx) * p.Mch + mb * 16 + ppart * 8) * 2;
+        pzyx[b] = pch_ok ? (lz | (ly << 8) | (lx << 16)) : 0x00ffffff;
+    }
+    int qrel[NITQ], qzyx[NITQ];
+#pragma unroll
+    for (int b = 0; b < NITQ; ++b) {
+        const int u = tid + b * 256;
+        const int v = u / QU;
+        const int lx = v % QX, ly = (v / QX) % QY, lz = v / (QX * QY);
+        qrel[b] = (((lz * p.Hq + ly) * p.Wq + lx) * p.Cch + cb * CB + qpart * 8) * 2;
+        qzyx[b] = (u < NQ && qch_ok) ? (lz | (ly << 8) | (lx << 16)) : 0x00ffffff;
+    }
+    u32x4 pv[2], qv[NITQ];
+    unsigned int okbits = 0;                     // bit b: P fragment b inside the volume; bit 2 + b: Q fragment b
+    auto request = [&](int t) {
+        const int n = t / p.tiles_per_sample;
+        const int tl = t - n * p.tiles_per_sample;
+        const int tx = tl % p.txn, ty = (tl / p.txn) % p.tyn, tz = tl / (p.txn * p.tyn);
+        const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+        okbits = 0;
+        const int pbase = (((n * p.Dp + z0) * p.Hp + y0) * p.Wp + x0) * p.Mch * 2;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int gz = z0 + (pzyx[b] & 0xff), gy = y0 + ((pzyx[b] >> 8) & 0xff), gx = x0 + (pzyx[b] >> 16);
+            const bool ok = gz < p.Dp && gy < p.Hp && gx < p.Wp;
+            okbits |= ok ? (1u << b) : 0u;
+            pv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(prsrc, ok ? pbase + prel[b] : -1, 0, 0));
+        }
+        const int qz0 = KIND == G3_K3 ? z0 - 1 : 2 * z0, qy0 = KIND == G3_K3 ? y0 - 1 : 2 * y0, qx0 = KIND == G3_K3 ? x0 - 1 : 2 * x0;
+        const int qbase = (((n * p.Dq + qz0) * p.Hq + qy0) * p.Wq + qx0) * p.Cch * 2;
+#pragma unroll
+        for (int b = 0; b < NITQ; ++b) {
+            const int gz = qz0 + (qzyx[b] & 0xff), gy = qy0 + ((qzyx[b] >> 8) & 0xff), gx = qx0 + (qzyx[b] >> 16);
+            const bool ok = (unsigned)gz < (unsigned)p.Dq && (unsigned)gy < (unsigned)p.Hq && (unsigned)gx < (unsigned)p.Wq;
+            okbits |= ok ? (4u << b) : 0u;
+            qv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(qrsrc, ok ? qbase + qrel[b] : -1, 0, 0));
+        }
+    };
+    auto commit = [&](int n) {                   // registers -> (normalised) LDS tiles
+        f32x2 sc[4], sh[4];
+        if (p_stats) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sc[i] = *(const f32x2*)(s_psc + n * 16 + ppart * 8 + 2 * i);
+                sh[i] = *(const f32x2*)(s_psh + n * 16 + ppart * 8 + 2 * i);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            u32x4 v = pv[b];
+            if (p_stats) {
+                const u32x4 a = act8(v, sc, sh);
+                const bool ok = (okbits >> b) & 1u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
+            }
+            *(u32x4*)(s_p + ((tid + b * 256) >> 1) * 32 + ppart * 16) = v;
+        }
+        if (q_stats) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sc[i] = *(const f32x2*)(s_qsc + n * 16 + qpart * 8 + 2 * i);
+                sh[i] = *(const f32x2*)(s_qsh + n * 16 + qpart * 8 + 2 * i);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NITQ; ++b) {
+            u32x4 v = qv[b];
+            if (q_stats) {
+                const u32x4 a = act8(v, sc, sh);
+                const bool ok = (okbits >> (2 + b)) & 1u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
+            }
+            const int u = tid + b * 256;
+            if (b < NITQ - 1 || u < NQ) *(u32x4*)(s_q + (u / QU) * QROW + qpart * 16) = v;
+        }
+    };
+
+    int t = ks;                                  // ksplit never exceeds the tile count
+    request(t);
     for (int i = tid; i < p.N * 16; i += 256) {
         const int n = i >> 4, c = i & 15;
         float m = 0.f, r = 1.f;
         const int pc = mb * 16 + c;
         if (p_stats && pc < p.Mch) stats_to_mean_rstd(p.P_stats + ((size_t)n * p.Mch + pc) * 2, p.inv_cnt_p, p.eps, m, r);
-        s_pm[i] = m; s_pr[i] = r;
+        s_psc[i] = r; s_psh[i] = -m * r;
         m = 0.f; r = 1.f;
         const int qc = cb * CB + c;
         if (q_stats && c < CB && qc < p.Cch) stats_to_mean_rstd(p.Q_stats + ((size_t)n * p.Cch + qc) * 2, p.inv_cnt_q, p.eps, m, r);
-        s_qm[i] = m; s_qr[i] = r;
+        s_qsc[i] = r; s_qsh[i] = -m * r;
     }
 
     // per-lane byte offsets into the Q tile of this lane's tr-read row for each column block (tap part only)
@@ -258,90 +354,11 @@ __global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) {
 #pragma unroll
     for (int k = 0; k < NCB; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int t = ks; t < p.total_tiles; t += p.ksplit) {
-        const int n = t / p.tiles_per_sample;
-        const int tl = t - n * p.tiles_per_sample;
-        const int tx = tl % p.txn, ty = (tl / p.txn) % p.tyn, tz = tl / (p.txn * p.tyn);
-        const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+    for (; t < p.total_tiles; t += p.ksplit) {
+        __syncthreads();                         // tables visible / every wave is done reading the previous tile
+        commit(t / p.tiles_per_sample);
         __syncthreads();
-        // ---- stage P (256 voxels x 16 ch) and Q (halo / strided region x CB ch) as bf16; every global load of a batch
-        //      is issued before any is consumed; out-of-range fragments read element 0 and are zeroed afterwards ----
-        {
-            u32x4 pv[2];
-            bool pok[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int u = tid + b * 256;
-                const int v = u >> 1, part = u & 1;
-                const int lx = v & 15, ly = (v >> 4) & 3, lz = v >> 6;
-                const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
-                const int c0 = mb * 16 + part * 8;
-                pok[b] = gz < p.Dp && gy < p.Hp && gx < p.Wp && c0 < p.Mch;
-                const size_t e = pok[b] ? ((((size_t)n * p.Dp + gz) * p.Hp + gy) * p.Wp + gx) * p.Mch + c0 : 0;
-                pv[b] = *(const u32x4*)(Pp + e);
-            }
-            constexpr int QU = CB / 8;
-            constexpr int NQ = QV * QU;
-            constexpr int NITQ = (NQ + 255) / 256;
-            constexpr int SBQ = NITQ <= 8 ? NITQ : 8;
-#pragma unroll 1
-            for (int it0 = 0; it0 < NITQ; it0 += SBQ) {
-                u32x4 qv[SBQ];
-                bool qok[SBQ];
-#pragma unroll
-                for (int b = 0; b < SBQ; ++b) {
-                    const int u = tid + (it0 + b) * 256;
-                    const int v = u / QU, part = u - v * QU;
-                    const int lx = v % QX, ly = (v / QX) % QY, lz = v / (QX * QY);
-                    int gz, gy, gx;
-                    if (KIND == G3_K3) { gz = z0 + lz - 1; gy = y0 + ly - 1; gx = x0 + lx - 1; }
-                    else { gz = 2 * z0 + lz; gy = 2 * y0 + ly; gx = 2 * x0 + lx; }
-                    const int c0 = cb * CB + part * 8;
-                    qok[b] = (it0 + b < NITQ) && u < NQ && gz >= 0 && gz < p.Dq && gy >= 0 && gy < p.Hq && gx >= 0 && gx < p.Wq && c0 < p.Cch;
-                    const size_t e = qok[b] ? ((((size_t)n * p.Dq + gz) * p.Hq + gy) * p.Wq + gx) * p.Cch + c0 : 0;
-                    qv[b] = *(const u32x4*)(Qp + e);
-                }
-#pragma unroll
-                for (int b = 0; b < SBQ; ++b) {
-                    const int u = tid + (it0 + b) * 256;
-                    if (it0 + b < NITQ && u < NQ) {
-                        const int v = u / QU, part = u - v * QU;
-                        u32x4 val = qv[b];
-                        if (q_stats) {
-                            float f[8];
-                            frag_unpack(val, f, (T*)nullptr);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const float tt = (f[j] - s_qm[n * 16 + part * 8 + j]) * s_qr[n * 16 + part * 8 + j];
-                                f[j] = tt > 0.f ? tt : 0.f;
-                            }
-                            val = frag_pack(f, (T*)nullptr);
-                        }
-                        if (!qok[b]) val = u32x4{0u, 0u, 0u, 0u};
-                        *(u32x4*)(s_q + v * QROW + part * 16) = val;
-                    }
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int u = tid + b * 256;
-                const int v = u >> 1, part = u & 1;
-                u32x4 val = pv[b];
-                if (p_stats) {
-                    float f[8];
-                    frag_unpack(val, f, (T*)nullptr);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float tt = (f[j] - s_pm[n * 16 + part * 8 + j]) * s_pr[n * 16 + part * 8 + j];
-                        f[j] = tt > 0.f ? tt : 0.f;
-                    }
-                    val = frag_pack(f, (T*)nullptr);
-                }
-                if (!pok[b]) val = u32x4{0u, 0u, 0u, 0u};
-                *(u32x4*)(s_p + v * 32 + part * 16) = val;
-            }
-        }
-        __syncthreads();
+        if (t + p.ksplit < p.total_tiles) request(t + p.ksplit);
         // ---- two K-steps of 32 voxels: y rows (2s, 2s+1) of this wave's z-slice ----
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -505,6 +522,8 @@ extern "C" int vs_conv_wgrad(const void* P, const double* p_stats, const void* Q
     return cbsz == 16 ? g3_run<T, 16, G3_K2S2>(p, dw, m_real, c_real, st) : g3_run<T, 8, G3_K2S2>(p, dw, m_real, c_real, st);
     if (dtype == VS_F32) { G3_GO(float) }
 #undef G3_GO
+    // g3b_kernel addresses P and Q with signed 32-bit byte offsets
+    if ((long long)n * dp * hp * wp * m_ch * 2 >= 2147483648ll || (long long)n * p.Dq * p.Hq * p.Wq * c_ch * 2 >= 2147483648ll) return VS_ESHAPE;
     if (kind == VS_CONV_K3) return cbsz == 16 ? g3b_run<16, G3_K3>(p, dw, m_real, c_real, st) : g3b_run<8, G3_K3>(p, dw, m_real, c_real, st);
     return cbsz == 16 ? g3b_run<16, G3_K2S2>(p, dw, m_real, c_real, st) : g3b_run<8, G3_K2S2>(p, dw, m_real, c_real, st);
 }
