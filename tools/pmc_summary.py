@@ -1,6 +1,6 @@
 """Summarise a rocprofv3 --pmc counter_collection.csv per kernel (mean per dispatch)."""
 import collections, csv, glob, sys
-path = glob.glob(sys.argv[1] + "/*/*counter_collection.csv")[0]
+path = (glob.glob(sys.argv[1] + "/*/*counter_collection.csv") + glob.glob(sys.argv[1] + "/*counter_collection.csv"))[0]
 rows = list(csv.DictReader(open(path)))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}

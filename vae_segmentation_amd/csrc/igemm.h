@@ -7,6 +7,7 @@
 // The accumulator layout (col = lane&15, row = 4*(lane>>4)+reg) gives every lane 4 consecutive output
 // channels of one voxel, i.e. one 16-byte (f32) / 8-byte (bf16) channels-last store.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 enum { G1_K3 = 0, G1_K2S2 = 1, G1_PW = 2 };
@@ -133,16 +134,16 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
             lds_base[cg] = ((wave * 6 + cg) * 18 + col) * CKB + ((g * EPL) % CK) * (int)sizeof(T);
         }
     } else {
-        const long long vcol = (long long)p.Do * p.Ho * p.Wo;
+        const int vcol = p.Do * p.Ho * p.Wo;             // < 2^31 (host check); 32-bit divisions: the 64-bit ones cost ~100 instructions each
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) {
-            long long v = (long long)tile * 256 + wave * 64 + cg * 16 + col;
+            int v = tile * 256 + wave * 64 + cg * 16 + col;
             cvalid[cg] = v < vcol;
             if (!cvalid[cg]) v = 0;
-            ox[cg] = (int)(v % p.Wo);
-            long long t2 = v / p.Wo;
-            oy[cg] = (int)(t2 % p.Ho);
-            oz[cg] = (int)(t2 / p.Ho);
+            ox[cg] = v % p.Wo;
+            const int t2 = v / p.Wo;
+            oy[cg] = t2 % p.Ho;
+            oz[cg] = t2 / p.Ho;
             const int s = KIND == G1_K2S2 ? 2 : 1;
             gofs[cg] = ((((long long)n * p.D + oz[cg] * s) * p.H + oy[cg] * s) * p.W + ox[cg] * s) * p.C;
         }
@@ -157,6 +158,11 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
     __syncthreads();
 
+    // The chunk loop is instantiated twice, with has_stats a compile-time constant: as a run-time flag its branch sat between
+    // every direct-from-global B load and its use, and the compiler drained vmcnt(0) after each load (32 serialized memory
+    // round trips per chunk on the stride-2 / transposed convs).
+    auto chunk_loop = [&](auto hs_tag) {
+    constexpr bool HS = decltype(hs_tag)::value;
     for (int ch = 0; ch < p.nch; ++ch) {
         if constexpr (KIND == G1_K3) {
             if (ch > 0) __syncthreads();
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                     if (it0 + b < NIT && u < NU) {
                         const int tv = u / U, part = u - tv * U;
                         u32x4 val = vals[b];
-                        if (has_stats) val = act_transform<T, CK>(val, s_mean, s_rstd, ch * CK + part * EPL);
+                        if (HS) val = act_transform<T, CK>(val, s_mean, s_rstd, ch * CK + part * EPL);
                         if (!ok[b]) val = u32x4{0u, 0u, 0u, 0u};
                         *(u32x4*)(s_tile + tv * CKB + part * 16) = val;
                     }
@@ -217,9 +223,10 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                     const int dz = (tt >> 2) & 1, dy = (tt >> 1) & 1, dx = tt & 1;
                     const long long toff = (((long long)dz * p.H + dy) * p.W + dx) * p.C + ch * CK + (g * EPL) % CK;
 #pragma unroll
-                    for (int cg = 0; cg < 4; ++cg) {
-                        b[cg] = *(const u32x4*)(xin + gofs[cg] + toff);
-                        if (has_stats) b[cg] = act_transform<T, CK>(b[cg], s_mean, s_rstd, ch * CK + (g * EPL) % CK);
+                    for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(xin + gofs[cg] + toff);
+                    if (HS) {
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg) b[cg] = act_transform<T, CK>(b[cg], s_mean, s_rstd, ch * CK + (g * EPL) % CK);
                     }
                 }
 #pragma unroll
@@ -263,9 +270,10 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                             const int cc = kk * KG + g * EPL;
                             const long long toff_g = (((long long)dz * p.H + dy) * p.W + dx) * p.C + ch * CK + cc;
 #pragma unroll
-                            for (int cg = 0; cg < 4; ++cg) {
-                                b[cg] = *(const u32x4*)(xin + gofs[cg] + toff_g);
-                                if (has_stats) b[cg] = act_transform<T, CK>(b[cg], s_mean, s_rstd, ch * CK + cc);
+                            for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(xin + gofs[cg] + toff_g);
+                            if (HS) {
+#pragma unroll
+                                for (int cg = 0; cg < 4; ++cg) b[cg] = act_transform<T, CK>(b[cg], s_mean, s_rstd, ch * CK + cc);
                             }
                         }
 #pragma unroll
@@ -277,6 +285,8 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
             }
         }
     }
+    };
+    if (has_stats) chunk_loop(std::true_type{}); else chunk_loop(std::false_type{});
 
     // ------------------------------------------------------------------------------------------
     // epilogues
