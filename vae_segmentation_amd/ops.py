@@ -9,6 +9,8 @@ A *lazy* activation is the pair ``(raw, stats)``: ``raw`` is a conv output befor
 For autograd, ``stats`` is a non-differentiable side output and the gradient attached to ``raw`` is the
 total derivative (the InstanceNorm+ReLU backward is applied by the consumer's backward).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -42,11 +44,11 @@ def _pick_mt(rows16, tiles):
     return 16
 
 
-def _k3_kid(tname, ck, mt):
+def _k3_kid(tname, ck, mt, sums=False):
     """kernel instantiation name of a 3x3x3 launch (mirrors g1_dispatch_k3_* in csrc; rocprof prints the same string)."""
     if tname == "float":
         return "k3_kernel<float,%d,%d,0>" % (ck, mt)
-    return "k3b_kernel<%d,%d,0>" % (ck, min(mt, 32))
+    return "k3b_kernel<%d,%d,0,%s>" % (ck, min(mt, 32), "true" if sums else "false")
 
 
 class _timed:
@@ -105,40 +107,64 @@ def cpad(c):
 # idle.  Inputs are kept referenced until the join so the allocator cannot recycle them under the side stream.  The
 # produced gradients are NOT held: autograd's AccumulateGrad must find them unshared so that it adopts the tensor as
 # .grad without launching a copy on the main stream (a copy would read the buffer before the side stream wrote it).
-_SIDE = {"enabled": False, "stream": None, "pending": [], "forked": False}
+_SIDE = {"enabled": False, "stream": None, "pending": [], "forked": False, "queue": [], "callback": False,
+         "batch": int(os.environ.get("VS_SIDE_BATCH", "3"))}
+# Every fork of the side stream is a cross-queue dependency in the captured graph, and the kernel trace shows each one
+# costs a 13-20 us bubble on BOTH branches (signal + barrier packets): forking per layer ate what the overlap won.  The
+# launches are therefore queued as closures and issued in batches of VS_SIDE_BATCH layers behind one fork; the closures
+# write into gradient tensors allocated at submit time, addressed by raw pointer (holding the tensor would make
+# AccumulateGrad copy it on the main stream before the side stream wrote it; .grad keeps the storage alive until the join).
 
 
 def set_overlap(enabled=True):
-    """Issue weight/bias-gradient kernels on a side stream.  The native optimisers, FlatGradSync and GraphedStep join it
-    before gradients are read; with a foreign optimiser call ops.join_side() after backward()."""
+    """Issue weight/bias-gradient kernels on a side stream, joined to the launching stream when the backward pass ends."""
+    if not enabled:
+        _flush_side()
     _SIDE["enabled"] = bool(enabled)
 
 
-class _side_stream:
-    def __init__(self, weight, *keep):
-        self.on = _SIDE["enabled"] and weight.grad is None
-        self.keep = keep
+def side_submit(weight, keep, fn):
+    """Run fn() — kernel launches into preallocated outputs only — on the side stream with the next batch (immediately, on
+    the current stream, when overlap is off, the parameter accumulates into an existing .grad, or a profile is running)."""
+    if not (_SIDE["enabled"] and weight.grad is None and PROFILE is None):
+        fn()
+        return
+    if not _SIDE["callback"]:
+        # issue the tail of the queue and join when this backward pass ends, so that gradients are complete (in stream
+        # order) by the time backward() returns, whoever reads them
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_backward_done)
+            _SIDE["callback"] = True
+        except RuntimeError:
+            pass                                # not inside a backward pass: the caller joins
+    _SIDE["queue"].append((fn, keep))
+    if len(_SIDE["queue"]) >= _SIDE["batch"]:
+        _flush_side()
 
-    def __enter__(self):
-        if self.on:
-            if _SIDE["stream"] is None:
-                _SIDE["stream"] = torch.cuda.Stream()
-            self.main = torch.cuda.current_stream()
-            _SIDE["stream"].wait_stream(self.main)
-            self.ctx = torch.cuda.stream(_SIDE["stream"])
-            self.ctx.__enter__()
-            _SIDE["pending"].extend(self.keep)
-            _SIDE["forked"] = True
-        return self
 
-    def __exit__(self, *exc):
-        if self.on:
-            self.ctx.__exit__(*exc)
-        return False
+def _backward_done():
+    _SIDE["callback"] = False
+    join_side()
+
+
+def _flush_side():
+    q = _SIDE["queue"]
+    if not q:
+        return
+    if _SIDE["stream"] is None:
+        _SIDE["stream"] = torch.cuda.Stream()
+    _SIDE["stream"].wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(_SIDE["stream"]):
+        for fn, keep in q:
+            fn()
+            _SIDE["pending"].extend(keep)      # inputs stay referenced until the join: the allocator must not recycle them
+    q.clear()
+    _SIDE["forked"] = True
 
 
 def join_side():
-    """Make the current stream wait for every side-stream kernel issued so far and release the held tensors."""
+    """Issue what is still queued, make the current stream wait for every side-stream kernel and release the held tensors."""
+    _flush_side()
     if _SIDE["forked"]:
         torch.cuda.current_stream().wait_stream(_SIDE["stream"])
         _SIDE["pending"].clear()
@@ -363,7 +389,7 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
                 tiles = n * ((g.numel() // (n * c) + 255) // 256)
             tname = "float" if x.dtype == torch.float32 else "unsigned short"
             if kind == VS_CONV_K3:
-                kid = _k3_kid(tname, min(gc, 32), _pick_mt((c + 15) // 16 * 16, tiles))
+                kid = _k3_kid(tname, min(gc, 32), _pick_mt((c + 15) // 16 * 16, tiles), sums=True)
             else:
                 kid = "g1_kernel<%s,%d,%d,%d,0>" % (tname, min(gc, 32), kind, _pick_mt((c + 15) // 16 * 16, tiles))
             cr = real_channels[0] if real_channels else gc
@@ -382,13 +408,15 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
     return g
 
 
-def conv_wgrad(p, ps, q, qs, m_real, c_real, kind, out_shape):
-    """dW (fp32, reference layout [m][c][taps]) ; the voxel loop runs over p's grid."""
+def conv_wgrad(p, ps, q, qs, m_real, c_real, kind, out_shape, out_ptr=None):
+    """dW (fp32, reference layout [m][c][taps]) ; the voxel loop runs over p's grid.  With out_ptr the result goes to that
+    preallocated fp32 buffer of out_shape (deferred side-stream launches) and nothing is returned."""
     n, dp, hp, wp_, m_ch = p.shape
     c_ch = q.shape[-1]
     nbytes = lib.vs_conv_wgrad_workspace_bytes(n, dp, hp, wp_, m_ch, c_ch, kind)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
-    dw = torch.empty(out_shape, dtype=torch.float32, device=p.device)
+    dw = torch.empty(out_shape, dtype=torch.float32, device=p.device) if out_ptr is None else None
+    dw_ptr = dw.data_ptr() if out_ptr is None else out_ptr
     kid = nb = fl = None
     if PROFILE is not None:
         taps = 27 if kind == VS_CONV_K3 else 8
@@ -397,17 +425,33 @@ def conv_wgrad(p, ps, q, qs, m_real, c_real, kind, out_shape):
         nb = (p.numel() // m_ch * m_real + q.numel() // c_ch * c_real) * _esize(p) + m_real * c_real * taps * 4
         fl = 2.0 * (p.numel() // m_ch) * taps * m_real * c_real
     with _timed(kid, nb, fl, "p%s q%s" % (tuple(p.shape), tuple(q.shape))):
-        check(lib.vs_conv_wgrad(p.data_ptr(), _p(ps), q.data_ptr(), _p(qs), dw.data_ptr(), ws.data_ptr(), nbytes, n, dp, hp,
+        check(lib.vs_conv_wgrad(p.data_ptr(), _p(ps), q.data_ptr(), _p(qs), dw_ptr, ws.data_ptr(), nbytes, n, dp, hp,
                                 wp_, m_ch, c_ch, m_real, c_real, kind, vs_dtype(p), EPS_IN, _stream()), "conv_wgrad")
     return dw
 
 
-def bias_grad(g, c_real):
+def bias_grad(g, c_real, out_ptr=None):
     c_ch = g.shape[-1]
     rows = g.numel() // c_ch
-    db = torch.empty(c_real, dtype=torch.float32, device=g.device)
-    check(lib.vs_bias_grad(g.data_ptr(), db.data_ptr(), rows, c_ch, c_real, vs_dtype(g), _stream()), "bias_grad")
+    db = torch.empty(c_real, dtype=torch.float32, device=g.device) if out_ptr is None else None
+    check(lib.vs_bias_grad(g.data_ptr(), db.data_ptr() if out_ptr is None else out_ptr, rows, c_ch, c_real, vs_dtype(g), _stream()),
+          "bias_grad")
     return db
+
+
+def _side_grads(weight, keep, wgrad_args, bias_args):
+    """Allocate dW (and db) now, queue their kernels for the side stream; -> (gw, gb)."""
+    dev = keep[0].device
+    gw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+    gb = torch.empty(bias_args[1], dtype=torch.float32, device=dev) if bias_args is not None else None
+    gw_ptr, gb_ptr = gw.data_ptr(), (gb.data_ptr() if gb is not None else None)
+
+    def launch():
+        conv_wgrad(*wgrad_args, weight.shape, out_ptr=gw_ptr)
+        if bias_args is not None:
+            bias_grad(bias_args[0], bias_args[1], out_ptr=gb_ptr)
+    side_submit(weight, keep, launch)
+    return gw, gb
 
 
 def in_relu_bwd(g, x, xs, inplace=True):
@@ -469,8 +513,7 @@ class ConvK3(torch.autograd.Function):
             else:
                 gx, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K3, False, real_channels=(cout, cin))
         if ctx.needs_input_grad[2]:
-            with _side_stream(weight, gy, x, xs) as sd:
-                gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K3, weight.shape)
+            gw, _ = _side_grads(weight, (gy, x, xs), (gy, None, x, xs, cout, cin, VS_CONV_K3), None)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gb = _new_stats(1, (ctx.bias_shape[0] + 1) // 2, gy.device, width=1).view(-1).view(torch.float32)[:ctx.bias_shape[0]]
         return gx, None, gw, gb
@@ -511,10 +554,8 @@ class ConvK3Softmax(torch.autograd.Function):
             else:
                 gx, _ = conv_gather(gl, None, wpb, None, c, VS_CONV_K3, False)
         if ctx.needs_input_grad[2]:
-            with _side_stream(weight, gl, x, xs) as sd:
-                gw = conv_wgrad(gl, None, x, xs, 2, weight.shape[1], VS_CONV_K3, weight.shape)
-                if ctx.has_bias and ctx.needs_input_grad[3]:
-                    gb = bias_grad(gl, 2)
+            gw, gb = _side_grads(weight, (gl, x, xs), (gl, None, x, xs, 2, weight.shape[1], VS_CONV_K3),
+                                 (gl, 2) if ctx.has_bias and ctx.needs_input_grad[3] else None)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gl, 2)
         return gx, None, gw, gb, None, None
@@ -546,10 +587,8 @@ class ConvK2S2(torch.autograd.Function):
             else:
                 gx = conv_scatter(gy, None, wpb, None, x.shape[-1])
         if ctx.needs_input_grad[2]:
-            with _side_stream(weight, gy, x, xs) as sd:
-                gw = conv_wgrad(gy, None, x, xs, cout, cin, VS_CONV_K2S2, weight.shape)
-                if ctx.has_bias and ctx.needs_input_grad[3]:
-                    gb = bias_grad(gy, cout)
+            gw, gb = _side_grads(weight, (gy, x, xs), (gy, None, x, xs, cout, cin, VS_CONV_K2S2),
+                                 (gy, cout) if ctx.has_bias and ctx.needs_input_grad[3] else None)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gy, cout)
         return gx, None, gw, gb
@@ -580,10 +619,8 @@ class ConvT2S2(torch.autograd.Function):
             else:
                 gx, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K2S2, False)
         if ctx.needs_input_grad[2]:
-            with _side_stream(weight, gy, x, xs) as sd:
-                gw = conv_wgrad(x, xs, gy, None, cin, cout, VS_CONV_K2S2, weight.shape)
-                if ctx.has_bias and ctx.needs_input_grad[3]:
-                    gb = bias_grad(gy, cout)
+            gw, gb = _side_grads(weight, (gy, x, xs), (x, xs, gy, None, cin, cout, VS_CONV_K2S2),
+                                 (gy, cout) if ctx.has_bias and ctx.needs_input_grad[3] else None)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gy, cout)
         return gx, None, gw, gb
