@@ -79,6 +79,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
     const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.C * 2));
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
 
+    // the (sum, sumsq) pair this thread turns into a table entry is requested first of all: it is the oldest load in the
+    // queue (vmcnt retires in order), so the tables are built while the first stage's fragments are still in flight
+    const double* st_src = SUMS ? p.mask_stats : p.x_stats;
+    const int st_n = SUMS ? p.N * p.M : (has_stats ? p.N * p.C : 0);
+    double st_pre[2] = {0.0, 1.0};
+    if (tid < st_n) { st_pre[0] = st_src[(size_t)tid * 2]; st_pre[1] = st_src[(size_t)tid * 2 + 1]; }
+
     // ---- per-thread stage geometry (tile independent) -----------------------------------------------------------------
     // fragment b of this thread is 16-byte part `part` (the same for every b: 256 % U == 0) of tile voxel tv_b
     const int part = tid % U;
@@ -179,21 +186,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
         }
     const i32x4 yrsrc = make_rsrc(p.y, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.M * 2));
     const i32x4 mrsrc = make_rsrc(p.mask_x, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.M * 2));
-    if (has_stats) {
-        for (int i = tid; i < p.N * p.C; i += 256) {
-            float m, r;
-            stats_to_mean_rstd(p.x_stats + (size_t)i * 2, p.inv_count_in, p.eps, m, r);
-            s_scale[i] = r;
-            s_shift[i] = -m * r;
-        }
-    }
-    if (has_sums) {
-        for (int i = tid; i < p.N * p.M; i += 256) {
-            float m, r;
-            stats_to_mean_rstd(p.mask_stats + (size_t)i * 2, p.inv_count_out, p.eps, m, r);
-            s_mkm[i] = m;
-            s_mkr[i] = r;
-        }
+    for (int i = tid; i < st_n; i += 256) {
+        double st[2] = {st_pre[0], st_pre[1]};
+        if (i != tid) { st[0] = st_src[(size_t)i * 2]; st[1] = st_src[(size_t)i * 2 + 1]; }
+        float m, r;
+        stats_to_mean_rstd(st, SUMS ? p.inv_count_out : p.inv_count_in, p.eps, m, r);
+        if constexpr (SUMS) { s_mkm[i] = m; s_mkr[i] = r; }
+        else { s_scale[i] = r; s_shift[i] = -m * r; }
     }
 
     // ---- LDS read addresses ---------------------------------------------------------------------------------------------
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
                             atomicAdd(red_dst + ((size_t)n * p.M + row) * 2 + st, tot);
                         }
                     }
-                    __syncthreads();                     // s_red is reused by a later flush
+                    if (t + (int)gridDim.x < total_tiles) __syncthreads();     // s_red is reused by a later flush
                 }
             }
         }
