@@ -219,6 +219,12 @@ int vs_copy_scale_multi(const float* const* srcs, float* const* dsts, const long
 /* flat helper: dst[i] = src[i]*scale */
 int vs_scale_copy(const float* src, float* dst, long long count, float scale, void* stream);
 
+/* Measurement aid (no reference counterpart): one wave idles on the stream for `microseconds` (<= 1000).  bench.py's live
+ * per-kernel timing enqueues it in front of each HIP-event bracket so that the event, kernel and event packets are already
+ * queued when it retires; without it every packet of an eager step meets an idle queue and the bracket measures the
+ * command processor's wake-up latency (2-7 us) on top of the kernel. */
+int vs_spin(int microseconds, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ import collections, csv, glob, json, sys
 
 
 def per_kernel(d, counter):
-    rows = list(csv.DictReader(open(glob.glob(d + "/*/*counter_collection.csv")[0])))
+    rows = list(csv.DictReader(open((glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0])))
     acc = collections.defaultdict(list)
     for r in rows:
         if r["Counter_Name"] == counter:

@@ -590,3 +590,18 @@ extern "C" int vs_scale_copy(const float* src, float* dst, long long count, floa
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
+
+// ---- measurement aid: keep the queue busy for a given time (see include/vaeseg.h) -------------------------------------
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+    for (int i = 0; i < (1 << 22); ++i) {                                     // bounded: every wave exits
+        if (__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+extern "C" int vs_spin(int microseconds, void* stream) {
+    if (microseconds < 0 || microseconds > 1000) return VS_EINVAL;
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
