@@ -55,6 +55,17 @@ CONV_CASES = [  # (N, Cin, Cout, D, H, W)
 ]
 
 
+# shapes that make the persistent 3x3x3 kernels walk several tiles per workgroup (more tiles than the grid), cross a sample
+# boundary mid-walk (statistics flush), use 32-row weight blocks, two channel chunks, and ragged edges in all three axes
+CONV_CASES_LARGE = [(2, 8, 8, 48, 48, 64), (2, 32, 32, 16, 32, 64), (1, 16, 32, 37, 30, 50), (3, 64, 32, 9, 10, 21)]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", CONV_CASES_LARGE)
+def test_conv_k3_fwd_bwd_large(case, dtype):
+    test_conv_k3_fwd_bwd(case, True, dtype)
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("lazy", [False, True])
 @pytest.mark.parametrize("case", CONV_CASES)
