@@ -41,6 +41,9 @@ def parse(argv=None):
     p.add_argument("--alpha", type=float, default=0.995)
     p.add_argument("--seg_dropout", type=float, default=0.0)
     p.add_argument("--vae_decoder_dropout", type=float, default=0.0)
+    p.add_argument("--val_finetune", type=int, default=0, help="test-time training iterations per validation case (main_target.py:72)")
+    p.add_argument("--lr_finetune", type=float, default=1e-2)
+    p.add_argument("--only_pseudo", action="store_true")
     p.add_argument("--test_only", action="store_true")
     p.add_argument("--adam", action="store_true")
     driver.add_native_flags(p)

@@ -322,6 +322,61 @@ def _da128(dt):
     return d
 
 
+def gold_ft128():
+    """test-time training of one validation case (main_target.py:809-900, scripts/target/domain_msd_dh_ft1.bash:
+    domain_loss_type 8, lambda_vae 1.0, lr_finetune 1e-2, momentum 0) — two iterations so that the second runs on updated
+    weights — followed by the hard-Dice validation of the case with and without finetuning (:902-953)."""
+    save("ft128", both_precisions(_ft128))
+
+
+def _ft128(dt):
+    d = {}
+    model, _ = joint_case(128, True, dt)
+    model_ft, _ = joint_case(128, True, dt)
+    teacher, _ = joint_case(128, True, dt)
+    O.deterministic_fill_(teacher.Seg.float(), seed=1)
+    teacher.to(dt)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    teacher.eval()
+    img, lab = O.synthetic_image(1, 128, seed=2).to(dt), O.synthetic_label(1, 128, seed=3)
+    lr, steps, lambda_vae = 1e-2, 2, 1.0
+    model_ft.load_state_dict(model.state_dict())                                        # :811
+    for it in range(steps):                                                               # :812
+        batch = {"img": img, "gt": O.one_hot(lab).to(dt)}                                # :814-816
+        batch = model_ft(batch, "img", "pred", "recon", dropout=True)                    # :818
+        batch = teacher(batch, "img", "fake", "_asdf")                                   # :819
+        klloss = REV.KLloss(batch)                                                        # :820
+        batch["fake"] = REV.binarize(batch["fake"])                                       # :825
+        recon_loss = 1 - REV.avg_dsc(batch, "pred", "recon", botindex=1, topindex=2, return_mean=True)     # :831
+        dsc_loss = 1 - REV.avg_dsc(batch, "pred", "gt", botindex=1, topindex=2, return_mean=True)          # :832
+        fake_loss = 1 - REV.avg_dsc(batch, "pred", "fake", botindex=1, topindex=2, return_mean=True)       # :833
+        cur = O.lambda_schedule(recon_loss, lambda_vae)                                   # :838-841
+        final = (recon_loss + 1 / cur * fake_loss) if cur > 1 else (cur * recon_loss + fake_loss)          # :842-847, kl off
+        opt = torch.optim.SGD(model_ft.parameters(), lr=lr, weight_decay=0, momentum=0)  # :886-887
+        opt.zero_grad()
+        final.backward()
+        opt.step()
+        for k, v in (("recon_loss", recon_loss), ("dice_loss", dsc_loss), ("fake_loss", fake_loss), ("final", final), ("kl", klloss)):
+            d["it%d.%s" % (it, k)] = v.detach().numpy()
+        d["it%d.cur_lambda" % it] = np.asarray(cur)
+    # accumulated update of every Seg tensor, in units of lr (= -(g0 + g1)): the gradient-parity yardstick of the loop
+    ref = dict(model.Seg.named_parameters())
+    for name, p in model_ft.Seg.named_parameters():
+        u = ((p.detach().double() - ref[name].detach().double()) / lr).reshape(-1).numpy()
+        d["upd.grad.%s.l2" % name] = np.asarray(np.sqrt((u * u).sum()))            # "grad" naming: golden_util.check_grads* reads it
+        d["upd.grad.%s.samples" % name] = u[sample_idx(u.size, 16)].astype(np.float32)
+    with torch.no_grad():                                                                  # :902-953
+        batch = {"img": img, "gt": O.one_hot(lab).to(dt)}
+        batch = model(batch, "img", "pred_noft", "recon_noft")
+        batch = model_ft(batch, "img", "pred", "recon")
+        d["score_noft"] = REV.avg_dsc(batch, "pred_noft", "gt", binary=True, botindex=1, topindex=2).numpy()
+        d["score"] = REV.avg_dsc(batch, "pred", "gt", binary=True, botindex=1, topindex=2).numpy()
+        put(d, "pred", batch["pred"], 512)
+        put(d, "pred_noft", batch["pred_noft"], 512)
+    return d
+
+
 def gold_vae128_native():
     """vae_train step on the NATIVE reference VAE (main_source.py:389-413): z is the reference's own
     torch.randn draw under torch.manual_seed(123), recorded so the oracle / HIP path can inject it."""
@@ -367,6 +422,7 @@ CASES = {
     "joint128": lambda: gold_joint(128, 1, "joint128"),
     "da128": gold_da128,
     "vae128_train": gold_vae128_native,
+    "ft128": gold_ft128,
 }
 
 if __name__ == "__main__":

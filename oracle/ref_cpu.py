@@ -343,6 +343,53 @@ def domain_adaptation_losses(student, teacher, img, label, lambda_vae=1.0, domai
                    "dice_loss_fake": fake_loss, "batch": batch}
 
 
+def finetune_loss(recon_loss, fake_loss, klloss, lambda_vae=1.0, domain_loss_type=0, kl=False, only_pseudo=False):
+    """Loss of one test-time-training iteration, main_target.py:835-884 — the branches the shipped scripts reach:
+    only_pseudo (:835-836), domain_loss_type 8 (:837-847) and 9 (:848-853), and the default
+    `lambda_vae * recon_loss + dsc_loss_fake` (:881-882; epoch >= lambda_vae_warmup, turn_epoch == -1)."""
+    if only_pseudo:
+        return fake_loss
+    if domain_loss_type == 8:
+        cur = lambda_schedule(recon_loss, lambda_vae)
+        if cur > 1:
+            return recon_loss + (klloss if kl else 0) + 1 / cur * fake_loss
+        return cur * (recon_loss + (klloss if kl else 0)) + fake_loss
+    if domain_loss_type == 9:
+        cur = lambda_schedule(recon_loss, lambda_vae)
+        return (cur * recon_loss + fake_loss) / (1 + cur)
+    if domain_loss_type == 0:
+        return lambda_vae * recon_loss + fake_loss
+    raise ValueError("oracle restates the finetune loss for only_pseudo and domain_loss_type 0, 8, 9")
+
+
+def test_time_finetune(model, model_ft, teacher, img, label, steps, lr=1e-2, weight_decay=0.0, lambda_vae=1.0,
+                       domain_loss_type=0, kl=False, only_pseudo=False, use_confident_binarize=False, n_class=2):
+    """Per-case test-time training, main_target.py:809-900: model_ft starts from model's weights (:811), then `steps`
+    iterations of [student = model_ft forward (dropout flag on, rates as configured), frozen teacher forward, binarised pseudo-label,
+    three Dice terms (evaluation eps), loss above, a fresh SGD(lr, weight_decay, momentum=0) step (:886-891)].
+    -> list of per-iteration dicts of loss scalars (as the reference logs them, :893-897)."""
+    model_ft.load_state_dict(model.state_dict())
+    log = []
+    for _ in range(steps):
+        batch = {"img": img, "gt": one_hot(label, n_class).to(img.dtype)}
+        batch = model_ft(batch, "img", "pred", "recon", dropout=True)
+        batch = teacher(batch, "img", "fake", "_unused")            # not under no_grad in the reference; the teacher is frozen
+        klloss = KLloss(batch)
+        fake = batch["fake"]
+        batch["fake"] = confident_binarize(fake) if use_confident_binarize else binarize(fake)
+        recon_loss = 1 - avg_dsc(batch, "pred", "recon", botindex=1, topindex=n_class, eps=EPS_EVALUATION)
+        dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=EPS_EVALUATION)
+        fake_loss = 1 - avg_dsc(batch, "pred", "fake", botindex=1, topindex=n_class, eps=EPS_EVALUATION)
+        final = finetune_loss(recon_loss, fake_loss, klloss, lambda_vae, domain_loss_type, kl, only_pseudo)
+        opt = torch.optim.SGD([p for p in model_ft.parameters() if p.requires_grad], lr=lr, weight_decay=weight_decay, momentum=0)
+        opt.zero_grad()
+        final.backward()
+        opt.step()
+        log.append({"recon_loss": recon_loss.detach(), "dice_loss_fake": fake_loss.detach(), "dice_loss": dsc_loss.detach(),
+                    "final_loss": final.detach()})
+    return log
+
+
 # --------------------------------------------------------------------------------------
 # deterministic, RNG-free parameter fill and synthetic inputs (shared by goldens, tests, bench)
 # --------------------------------------------------------------------------------------

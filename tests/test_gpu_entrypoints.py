@@ -31,3 +31,9 @@ def test_main_source_joint_train_then_main_target_domain_adaptation(tmp_path):
     out = _run([os.path.join(REPO, "main_target.py"), "tgt", "-M", "domain_adaptation", "--load_prefix_joint", "src",
                 "--checkpoint_name", "model_epoch1.ckpt", "--domain_loss_type", "8"] + common, str(tmp_path))
     assert "Finished Training" in out
+    # test-time training of each validation case (main_target.py --val_finetune, scripts/target/domain_msd_dh_ft1.bash)
+    out = _run([os.path.join(REPO, "main_target.py"), "tgt_ft", "-M", "domain_adaptation", "--load_prefix_joint", "src",
+                "--checkpoint_name", "model_epoch1.ckpt", "--domain_loss_type", "8", "--val_finetune", "1", "--test_only"] + common,
+               str(tmp_path))
+    assert "validation result without finetuning" in out and "Finished Training" in out
+    assert json.load(open(tmp_path / "tensorboard" / "tgt_ft" / "score_0.json"))

@@ -166,6 +166,35 @@ def test_domain_adaptation128_vs_reference_golden():
     G.scalar_close(g, "final8", f8.item(), RTOL_FP32)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_test_time_finetune128_vs_reference_golden(graph):
+    """per-case test-time training (main_target.py:809-953), eager and HIP-graph replayed, against the loop
+    run on the reference's modules: per-iteration losses, the accumulated weight update (= two gradients, the second taken on
+    updated weights) and the hard-Dice scores with / without finetuning."""
+    M, O, T = _mods()
+    g = G.load("ft128")
+    model, model_ft, teacher = _build_joint(M, O, 128), _build_joint(M, O, 128), _build_joint(M, O, 128)
+    O.deterministic_fill_(teacher.Seg, seed=1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    img, lab = O.synthetic_image(1, 128, 2).cuda(), O.synthetic_label(1, 128, 3).cuda()
+    runner = T.TestTimeFinetune(model, model_ft, teacher, 128, steps=2, lr=1e-2, lambda_vae=1.0, domain_loss_type=8, graph=graph)
+    for rep in range(2 if graph else 1):            # a second case on the same runner must start from model's weights again
+        log, score_noft, score, pred = runner.run(img, lab)
+        for it, rec in enumerate(log):
+            for k_o, k_g in (("recon_loss", "recon_loss"), ("dice_loss", "dice_loss"), ("dice_loss_fake", "fake_loss"), ("final_loss", "final")):
+                G.scalar_close(g, "it%d.%s" % (it, k_g), rec[k_o].item(), RTOL_FP32)
+        ref = dict(model.Seg.named_parameters())
+        upd = [(n, (p.detach() - ref[n].detach()) / 1e-2) for n, p in model_ft.Seg.named_parameters()]
+        G.check_grads_f64(g, "upd", upd, floor=RTOL_GRAD_FP32)
+        # hard Dice counts argmax voxels: a handful may flip where the two probabilities are within rounding of each other
+        assert abs(score_noft.item() - float(g["score_noft@f64"])) < 2e-3
+        assert abs(score.item() - float(g["score@f64"])) < 2e-3
+        G.check_tensor_f64(g, "pred", pred, k=512, floor=RTOL_FP32)
+    from vae_segmentation_amd import ops
+    ops.set_overlap(False)
+
+
 def test_vae128_native_shapes_vs_reference_golden():
     M, O, T = _mods()
     g = G.load("vae128_train")

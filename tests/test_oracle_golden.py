@@ -128,6 +128,32 @@ def test_domain_adaptation128():
     assert (cur * r + f) / (1 + cur) == pytest.approx(float(g["final9"]), rel=1e-5)
 
 
+def test_test_time_finetune128():
+    """main_target.py:809-953 (two test-time-training iterations at lr 1e-2, domain_loss_type 8, then hard-Dice validation) restated
+    in the oracle against the same loop run on the reference's own modules (oracle/make_golden.py:_ft128)."""
+    g = G.load("ft128")
+    model, model_ft, teacher = O.build_joint(128), O.build_joint(128), O.build_joint(128)
+    O.deterministic_fill_(teacher.Seg, seed=1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    img, lab = O.synthetic_image(1, 128, 2), O.synthetic_label(1, 128, 3)
+    log = O.test_time_finetune(model, model_ft, teacher, img, lab, steps=2, lr=1e-2, lambda_vae=1.0, domain_loss_type=8)
+    for it, rec in enumerate(log):
+        for k_o, k_g in (("recon_loss", "recon_loss"), ("dice_loss", "dice_loss"), ("dice_loss_fake", "fake_loss"), ("final_loss", "final")):
+            assert rec[k_o].item() == pytest.approx(float(g["it%d.%s" % (it, k_g)]), rel=1e-5), (it, k_o)
+    ref = dict(model.Seg.named_parameters())
+    upd = [(n, (p.detach() - ref[n].detach()) / 1e-2) for n, p in model_ft.Seg.named_parameters()]
+    # the update is a difference of fp32 weights divided by lr: its own rounding noise is ~6e-8*|w|/lr per element
+    G.check_grads(g, "upd", upd, rtol=2e-3)
+    with torch.no_grad():
+        batch = {"img": img, "gt": O.one_hot(lab)}
+        batch = model(batch, "img", "pred_noft", "recon_noft")
+        batch = model_ft(batch, "img", "pred", "recon")
+        assert O.avg_dsc(batch, "pred_noft", "gt", binary=True, botindex=1, topindex=2).item() == pytest.approx(float(g["score_noft"]), rel=1e-5)
+        assert O.avg_dsc(batch, "pred", "gt", binary=True, botindex=1, topindex=2).item() == pytest.approx(float(g["score"]), rel=1e-5)
+    G.check_tensor(g, "pred", batch["pred"], k=512, rtol=1e-4)
+
+
 def test_vae128_native_with_recorded_noise():
     g = G.load("vae128_train")
     vae = O.deterministic_fill_(O.VAE(2, 2, norm_type=1, dim=128, spatial=128), seed=0)

@@ -141,6 +141,16 @@ def validate(method, model, loader, nc):
     return scores
 
 
+def validate_finetune(runner, loader):
+    """main_target.py:807-953 with --val_finetune k: per case, test-time training of a copy of the model, then hard Dice of the
+    finetuned and of the untouched network.  -> (scores, scores_noft)"""
+    scores, scores_noft = {}, {}
+    for i, batch in enumerate(loader):
+        _, noft, ft, _ = runner.run(batch[IMG_KEY].cuda(non_blocking=True), batch[LABEL_KEY].cuda(non_blocking=True))
+        scores[i], scores_noft[i] = ft.item(), noft.item()
+    return scores, scores_noft
+
+
 # ----------------------------------------------------------------------------------------------------
 # the loop
 # ----------------------------------------------------------------------------------------------------
@@ -205,6 +215,15 @@ def run(args, side="source"):
         sync.broadcast_parameters(0)
     ops.set_overlap(True)
 
+    runner = None
+    if method == "domain_adaptation" and getattr(args, "val_finetune", 0) and rank == 0:
+        model_ft = build_joint(args).cuda()
+        set_kernel_dtype(model_ft, dtype)
+        runner = T.TestTimeFinetune(model, model_ft, teacher, args.size, steps=args.val_finetune, lr=args.lr_finetune,
+                                    lambda_vae=args.lambda_vae, domain_loss_type=getattr(args, "domain_loss_type", 0),
+                                    kl=getattr(args, "kl", False), only_pseudo=getattr(args, "only_pseudo", False),
+                                    use_confident_binarize=getattr(args, "use_confident_binarize", False), n_class=nc)
+
     train_loader, val_loader, sampler = make_loaders(args, rank, world)
     lambda_vae = args.lambda_vae
     best, n_outer = 0.0, max(1, args.max_epoch // args.eval_epoch)
@@ -251,7 +270,11 @@ def run(args, side="source"):
                 print("epoch %d: %.2f volumes/s per rank" % (epoch + 1, seen / max(time.time() - t0, 1e-9)))
         if rank == 0:
             model.eval()
-            scores = validate(method, model, val_loader, nc)
+            if runner is not None and (epoch != 0 or args.test_only):             # main_target.py:811
+                scores, scores_noft = validate_finetune(runner, val_loader)
+                print("epoch %d validation result without finetuning: %f" % (epoch + 1, float(np.mean(list(scores_noft.values())))))
+            else:
+                scores = validate(method, model, val_loader, nc)
             mean = float(np.mean(list(scores.values()))) if scores else 0.0
             os.makedirs(os.path.join("tensorboard", args.prefix), exist_ok=True)
             with open(os.path.join("tensorboard", args.prefix, "score_%d.json" % epoch), "w") as f:

@@ -5,6 +5,7 @@ HIP-graph replayed step.  Each *_losses function mirrors the loss arithmetic of 
   seg_train_losses          main_source.py:421-441
   vae_train_losses          main_source.py:389-413     (1-Dice(recon,gt)) + 2e-5*KL, z = mean + noise*std*0.35
   domain_adaptation_losses  main_target.py:520-596     student/teacher, domain_loss_type 0 / 8 / 9, eps 1e-6
+  finetune_losses / TestTimeFinetune   main_target.py:809-953   per-case test-time training + hard-Dice validation
 """
 import torch
 
@@ -118,3 +119,116 @@ class GraphedStep:
             self.grad_sync()
         self.optimizer.step()
         return self.loss
+
+
+# ----------------------------------------------------------------------------------------------------
+# test-time training (main_target.py:809-953)
+# ----------------------------------------------------------------------------------------------------
+def lambda_schedule_device(recon_loss, lambda_vae):
+    """lambda_schedule (main_target.py:838-841) evaluated on the device: the reference branches on the host value of the loss
+    (`if recon_loss < 0.15`), which would force a sync per iteration and cannot be captured into a HIP graph; torch.where on
+    the detached loss selects the same constant."""
+    r = recon_loss.detach()
+    lam = float(lambda_vae)
+    c = lambda v: torch.full_like(r, v)
+    return torch.where(r < 0.15, c(lam * 0.6), torch.where(r < 0.225, c(lam * 1.2), torch.where(r < 0.3, c(lam * 2.0), c(lam * 3.0))))
+
+
+def finetune_loss(recon_loss, fake_loss, klloss, lambda_vae=1.0, domain_loss_type=0, kl=False, only_pseudo=False):
+    """Loss of one test-time-training iteration, main_target.py:835-884 — the branches the shipped scripts reach: only_pseudo
+    (:835-836), domain_loss_type 8 (:837-847) and 9 (:848-853), and the default lambda_vae*recon + fake (:881-882)."""
+    if only_pseudo:
+        return fake_loss
+    k = klloss if kl else 0
+    if domain_loss_type == 8:
+        cur = lambda_schedule_device(recon_loss, lambda_vae)
+        return torch.where(cur > 1, recon_loss + k + fake_loss / cur, cur * (recon_loss + k) + fake_loss)
+    if domain_loss_type == 9:
+        cur = lambda_schedule_device(recon_loss, lambda_vae)
+        return (cur * recon_loss + fake_loss) / (1 + cur)
+    if domain_loss_type == 0:
+        return lambda_vae * recon_loss + fake_loss
+    raise NotImplementedError("finetune loss: only_pseudo and domain_loss_type 0, 8, 9 (the variants the reference's scripts use)")
+
+
+def finetune_losses(student, teacher, img, label, lambda_vae=1.0, domain_loss_type=0, kl=False, only_pseudo=False,
+                    use_confident_binarize=False, n_class=2):
+    """Forward + losses of one test-time-training iteration (main_target.py:814-884)."""
+    batch = {"img": img, "gt": ops.onehot(label, n_class)}
+    batch = student(batch, "img", "pred", "recon", dropout=True)
+    with torch.no_grad():                       # the reference leaves autograd on here; its teacher is frozen, so nothing differs
+        batch = teacher(batch, "img", "fake", "_unused")
+    klloss = KLloss(batch)
+    batch["fake"] = confident_binarize(batch["fake"]) if use_confident_binarize else binarize(batch["fake"])
+    recon_loss = 1 - avg_dsc(batch, "pred", "recon", botindex=1, topindex=n_class, eps=EPS_EVALUATION)
+    dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=EPS_EVALUATION)
+    fake_loss = 1 - avg_dsc(batch, "pred", "fake", botindex=1, topindex=n_class, eps=EPS_EVALUATION)
+    final = finetune_loss(recon_loss, fake_loss, klloss, lambda_vae, domain_loss_type, kl, only_pseudo)
+    return final, {"recon_loss": recon_loss, "dice_loss_fake": fake_loss, "dice_loss": dsc_loss, "final_loss": final}
+
+
+class TestTimeFinetune:
+    """Per-case test-time training + validation of the reference (main_target.py:809-953).
+
+    ``model`` is the adapted network, ``model_ft`` its per-case copy, ``teacher`` the frozen pseudo-label network (all Joint).
+    run(img, label): model_ft <- model (:811); ``steps`` iterations of finetune_losses + SGD(lr, weight_decay, momentum 0)
+    (:886-891); then the batch-1 forward of both networks and their hard Dice against the label (:902-953).
+    The iteration is B=1 and launch-latency bound, so it is captured once into a HIP graph (inputs are copied into fixed
+    buffers) and replayed; nothing in the loop syncs with the host — the per-iteration loss scalars stay on the device and are
+    returned as tensors.  The frozen VAE of model_ft is synchronised with model's once, at construction (the reference
+    re-copies identical values on every case)."""
+
+    __test__ = False                           # not a pytest class
+
+    def __init__(self, model, model_ft, teacher, spatial, steps=1, lr=1e-2, weight_decay=0.0, lambda_vae=1.0, domain_loss_type=0,
+                 kl=False, only_pseudo=False, use_confident_binarize=False, n_class=2, graph=True, device="cuda"):
+        from . import optim
+        self.model, self.model_ft, self.teacher, self.steps, self.n_class = model, model_ft, teacher, int(steps), n_class
+        with torch.no_grad():
+            model_ft.load_state_dict(model.state_dict())
+        for p in model_ft.Vae.parameters():
+            p.requires_grad = False
+        model_ft.Vae.eval()
+        ops.clear_pack_cache()
+        self.params = [p for p in model_ft.Seg.parameters() if p.requires_grad]
+        self.src = [p for p in model.Seg.parameters()][:len(self.params)]
+        self.img = torch.zeros(1, 1, spatial, spatial, spatial, device=device)
+        self.label = torch.zeros(1, 1, spatial, spatial, spatial, device=device)
+        self.opt = optim.SGD(self.params, lr=lr, momentum=0.0, weight_decay=weight_decay)
+        kw = dict(lambda_vae=lambda_vae, domain_loss_type=domain_loss_type, kl=kl, only_pseudo=only_pseudo,
+                  use_confident_binarize=use_confident_binarize, n_class=n_class)
+        self.loss_fn = lambda: finetune_losses(self.model_ft, self.teacher, self.img, self.label, **kw)
+        self.stepper = GraphedStep(self.loss_fn, self.params, self.opt) if graph else None
+        if graph:                               # the capture's warm-up iterations moved model_ft: start every case from model
+            self._reset()
+
+    @torch.no_grad()
+    def _reset(self):
+        for d, s in zip(self.params, self.src):
+            d.copy_(s)
+        ops.weights_changed()
+
+    def run(self, img, label):
+        """-> (per-iteration list of loss dicts [device scalars], score_noft, score, pred)"""
+        self.img.copy_(img)
+        self.label.copy_(label)
+        self._reset()
+        log = []
+        for _ in range(self.steps):
+            if self.stepper is not None:
+                self.stepper.step()
+                aux = self.stepper.aux
+            else:
+                for p in self.params:
+                    p.grad = None
+                loss, aux = self.loss_fn()
+                loss.backward()
+                self.opt.step()
+            log.append({k: v.detach().clone() for k, v in aux.items()})
+        with torch.no_grad():
+            batch = {"img": self.img, "gt": ops.onehot(self.label, self.n_class)}
+            batch = self.model(batch, "img", "pred_noft", "recon_noft")
+            batch = self.model_ft(batch, "img", "pred", "recon")
+            score_noft = avg_dsc(batch, "pred_noft", "gt", binary=True, botindex=1, topindex=self.n_class)
+            score = avg_dsc(batch, "pred", "gt", binary=True, botindex=1, topindex=self.n_class)
+        return log, score_noft, score, batch["pred"]
