@@ -57,7 +57,9 @@ CONV_CASES = [  # (N, Cin, Cout, D, H, W)
 
 # shapes that make the persistent 3x3x3 kernels walk several tiles per workgroup (more tiles than the grid), cross a sample
 # boundary mid-walk (statistics flush), use 32-row weight blocks, two channel chunks, and ragged edges in all three axes
-CONV_CASES_LARGE = [(2, 8, 8, 48, 48, 64), (2, 32, 32, 16, 32, 64), (1, 16, 32, 37, 30, 50), (3, 64, 32, 9, 10, 21)]
+# the last two take the tall-tile (4x8x16) variant of the bf16 kernel (one wave of 256..1024 workgroups), one with a ragged y edge
+CONV_CASES_LARGE = [(2, 8, 8, 48, 48, 64), (2, 32, 32, 16, 32, 64), (1, 16, 32, 37, 30, 50), (3, 64, 32, 9, 10, 21),
+                    (2, 16, 16, 32, 64, 64), (1, 8, 8, 32, 100, 48)]
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from vae_segmentation_amd import _lib, ops
-dbg = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dbg", "libvaeseg_stamps.so"))
+dbg = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dbg", os.environ.get("VS_DBG_LIB", "libvaeseg_stamps.so")))
 for name, (restype, argtypes) in _lib.parse_header().items():
     fn = getattr(dbg, name); fn.restype = restype; fn.argtypes = argtypes
 dbg.vs_debug_read_k3_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -15,7 +15,7 @@ wp = ops.pack_weight(w, 0, c, torch.bfloat16)
 xs = ops.instnorm_stats(x)
 y = torch.empty(n, s, s, s, m, device="cuda", dtype=torch.bfloat16)
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for it in range(3):
+for it in range(int(os.environ.get('VS_ITERS', 3))):
     ys = torch.zeros(n, m, 2, dtype=torch.float64, device="cuda")
     ev0.record()
     rc = dbg.vs_conv_gather_fwd(x.data_ptr(), xs.data_ptr(), wp.data_ptr(), None, y.data_ptr(), ys.data_ptr(), n, s, s, s, c, m, 0, 1, 1e-5, None)

@@ -9,9 +9,15 @@
 // bf16 3x3x3 convolutions run k3b_kernel with 16- or 32-row tiles (a 64-row weight block does not fit LDS next to the halo
 // tile): a 64-row request from pick_mt() is served as twice as many 32-row workgroups.
 int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s) {
+    const bool tall = mt == 16 && ck < 32 && k3b_use_tall(p);
     if (epi == EPI_SOFTMAX2) {
-        if (ck == 8 && mt == 16) return k3b_launch<8, 16, EPI_SOFTMAX2, false>(p, tiles, row_tiles, s);
+        if (ck == 8 && mt == 16)
+            return tall ? k3b_launch<8, 16, EPI_SOFTMAX2, false, 8>(p, tiles, row_tiles, s) : k3b_launch<8, 16, EPI_SOFTMAX2, false>(p, tiles, row_tiles, s);
         return VS_ESHAPE;
+    }
+    if (tall) {
+        if (ck == 8) return p.sums ? k3b_launch<8, 16, EPI_RAW, true, 8>(p, tiles, row_tiles, s) : k3b_launch<8, 16, EPI_RAW, false, 8>(p, tiles, row_tiles, s);
+        return p.sums ? k3b_launch<16, 16, EPI_RAW, true, 8>(p, tiles, row_tiles, s) : k3b_launch<16, 16, EPI_RAW, false, 8>(p, tiles, row_tiles, s);
     }
     if (mt == 64) { mt = 32; row_tiles *= 2; }
     K3B_CASE(8, 16) K3B_CASE(8, 32) K3B_CASE(16, 16) K3B_CASE(16, 32) K3B_CASE(32, 16) K3B_CASE(32, 32)

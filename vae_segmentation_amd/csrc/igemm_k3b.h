@@ -36,29 +36,35 @@ extern "C" int vs_debug_read_k3_stamps(unsigned long long* host, int n) {
 #define K3B_LDS_TAPS 2048      // int[64]: byte offset of (k-group, lane group)'s tap in the halo tile (C = 8 / 16)
 #define K3B_LDS_TILE 2304      // halo tile, weight block, then the per-(n,c) tables
 
-template <int CK, int MT>
+// YT = tile extent in y (4 or 8): a wave owns YT rows of 16 voxels of its z-plane.  YT = 8 (halo 6x10x18: 2.1x the outputs
+// instead of 2.5x, half the per-tile bookkeeping) is used for the large-volume small-channel layers.
+template <int CK, int MT, int YT = 4>
 struct K3BGeom {
     static constexpr int RB = MT / 16;
+    static constexpr int TV = 6 * (YT + 2) * 18;                             // staged halo voxels
     static constexpr bool SMALLC = CK < 32;                                  // several taps per 32-wide k-group, one chunk
     static constexpr int NKGC = SMALLC ? (27 * CK + 31) / 32 : 27;           // k-groups per channel chunk
     static constexpr int CKB = CK * 2;
-    static constexpr int TILE_BYTES = 648 * CKB;
+    static constexpr int TILE_BYTES = TV * CKB;
     static constexpr int NWF = RB * NKGC * 64;                               // 16-byte weight fragments per chunk per workgroup
     static constexpr int W_BYTES = NWF * 16;
 };
 
 // register budget: 4 workgroups per CU (one wave per SIMD each) for the small-channel kernels, 2 for the 32-channel chunks
 // SUMS: backward-data use (input = a materialised gradient, no statistics; epilogue accumulates the fused IN-backward sums)
-template <int CK, int MT, int EPI, bool SUMS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? (MT == 32 ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : (CK == 16 && SUMS ? 3 : 4)), 8))) void k3b_kernel(const G1Params p) {
+template <int CK, int MT, int EPI, bool SUMS, int YT = 4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
+    YT == 8 ? 2 : (CK == 32 ? (MT == 32 ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : (CK == 16 && SUMS ? 3 : 4))), 8))) void k3b_kernel(const G1Params p) {
     typedef unsigned short T;
     K3_TICK_INIT
-    using GEO = K3BGeom<CK, MT>;
+    using GEO = K3BGeom<CK, MT, YT>;
+    static_assert(YT == 4 || (YT == 8 && CK < 32 && MT == 16), "tall tiles: single-chunk layers, 16 rows");
+    constexpr int TV = GEO::TV, PLANE = (YT + 2) * 18;
     static_assert(CK == 8 || CK == 16 || CK == 32, "chunk width");
     constexpr int RB = GEO::RB, NKGC = GEO::NKGC, CKB = GEO::CKB, NWF = GEO::NWF;
     constexpr bool SMALLC = GEO::SMALLC;
     constexpr int U = CKB / 16;                          // 16-byte fragments per staged voxel
-    constexpr int NU = 648 * U;
+    constexpr int NU = TV * U;
     constexpr int NIT = (NU + 255) / 256;                // activation fragments per thread per stage
     constexpr int NWI = (NWF + 255) / 256;               // weight fragments per thread per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
     for (int b = 0; b < NIT; ++b) {
         const int u = tid + b * 256;
         const int tv = u / U;
-        const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / 108;
+        const int tx_ = tv % 18, ty_ = (tv / 18) % (YT + 2), tz_ = tv / PLANE;
         rel_off[b] = (((tz_ * p.H + ty_) * p.W + tx_) * p.C + part * 8) * 2;              // bytes from the tile's (0,0,0) halo voxel
         tzyx[b] = u < NU ? (tz_ | (ty_ << 8) | (tx_ << 16)) : 0x00ffffff;                 // out-of-list fragments fail every bounds test
         if (CK == 32) swzbits |= (unsigned int)((tx_ >> 2) & 1) << b;                     // see baddr[] below
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
         const int tz = fdiv(tl, p.fd_m[1], p.fd_s[1]);
         const int r = tl - tz * (p.txn * p.tyn);
         const int ty = fdiv(r, p.fd_m[2], p.fd_s[2]);
-        c.z0 = tz * 4; c.y0 = ty * 4; c.x0 = (r - ty * p.txn) * 16;
+        c.z0 = tz * 4; c.y0 = ty * YT; c.x0 = (r - ty * p.txn) * 16;
         return c;
     };
     auto load_w = [&](int ch) {
@@ -171,7 +177,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
     };
 
     // ---- first stage in flight before anything else; the statistics tables meanwhile ----------------------------------
-    int t = blockIdx.x;                                  // the grid never exceeds the tile count
+    // XCD-aware walk: consecutive workgroup ids land on different XCDs (8, each with its own L2), so workgroup b starts at
+    // tile (b % 8) * (G / 8) + b / 8 — the workgroups of one XCD then work on one contiguous run of tiles at any time and find
+    // their neighbours' halos in that XCD's L2 (G is a multiple of 8 whenever it is >= 8, see k3b_launch)
+    const int G = (int)gridDim.x;
+    int t = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     Coord cur = tile_coord(t), nxt = cur;
     load_w(0);
     load_x(cur, 0);
@@ -207,12 +217,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
             int tap = (tid >> 2) * (32 / CK) + ((tid & 3) * 8) / CK;
             if (tap > 26) tap = 13;                      // padded taps read the centre voxel (their weights are zero)
             const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-            s_taps[tid] = ((dz * 6 + dy) * 18 + dx) * CKB + (((tid & 3) * 8) % CK) * 2;
+            s_taps[tid] = (dz * PLANE + dy * 18 + dx) * CKB + (((tid & 3) * 8) % CK) * 2;
         }
-        baddr[0] = (wave * 108 + col) * CKB;
+        baddr[0] = (wave * PLANE + col) * CKB;
     } else {
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) baddr[dx] = (wave * 108 + col) * CKB + ((g ^ ((((col + dx) >> 2) & 1) << 1)) * 16);
+        for (int dx = 0; dx < 3; ++dx) baddr[dx] = (wave * PLANE + col) * CKB + ((g ^ ((((col + dx) >> 2) & 1) << 1)) * 16);
     }
     const char* s_wl = s_w + lane * 16;
 
@@ -240,12 +250,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
         // byte offset of output voxel (n, oz, y0 + cg, x0 + col), row 4g of row block rb: ebase + cg * W*M*2 + rb * 32; -1 = dropped
         const int ebase = ((((n * p.D + oz) * p.H + y0) * p.W + x0 + col) * p.M + rb0 * 16 + 4 * g) * 2;
         const bool zx_ok = oz < p.D && x0 + col < p.W;
-        f32x4 acc[RB][4];
+        f32x4 acc[RB][YT];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x2 mk[RB][4];                                 // mask tensor values under this tile's outputs (fused IN-bwd sums)
+            for (int cg = 0; cg < YT; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x2 mk[RB][YT];                                // mask tensor values under this tile's outputs (fused IN-bwd sums)
 
         for (int ch = 0; ch < p.nch; ++ch) {
             if (!first) __syncthreads();                 // every wave is done reading the previous stage
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                        for (int cg = 0; cg < 4; ++cg) {
+                        for (int cg = 0; cg < YT; ++cg) {
                             const bool valid = zx_ok && y0 + cg < p.H && (rb0 + rb) * 16 + 4 * g < p.M;
                             mk[rb][cg] = __builtin_bit_cast(u32x2, vs_raw_buffer_load_b64(mrsrc, valid ? ebase + cg * p.W * p.M * 2 + rb * 32 : -1, 0, 0));
                         }
@@ -282,20 +292,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
             // ---- multiply this stage out of LDS ----
             // fragments of k-group kg+1 are read while k-group kg is multiplied; the scheduling barriers keep the compiler
             // from hoisting the whole unrolled loop's reads (hundreds of live registers) in front of the first MFMA
-            auto read_kg = [&](int kg, u32x4 (&a)[RB], u32x4 (&b)[4]) {
+            auto read_kg = [&](int kg, u32x4 (&a)[RB], u32x4 (&b)[YT]) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) a[rb] = *(const u32x4*)(s_wl + (rb * NKGC + kg) * 1024);
                 if constexpr (SMALLC) {
                     const int o = baddr[0] + s_taps[kg * 4 + g];
 #pragma unroll
-                    for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + o + cg * 18 * CKB);
+                    for (int cg = 0; cg < YT; ++cg) b[cg] = *(const u32x4*)(s_tile + o + cg * 18 * CKB);
                 } else {
                     const int dz = kg / 9, dy = (kg / 3) % 3, dx = kg % 3;
 #pragma unroll
-                    for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + baddr[dx] + (((dz * 6 + dy + cg) * 18 + dx) * CKB));
+                    for (int cg = 0; cg < YT; ++cg) b[cg] = *(const u32x4*)(s_tile + baddr[dx] + ((dz * PLANE + (dy + cg) * 18 + dx) * CKB));
                 }
             };
-            u32x4 fa[2][RB], fb[2][4];
+            u32x4 fa[2][RB], fb[2][YT];
             read_kg(0, fa[0], fb[0]);
 #pragma unroll
             for (int kg = 0; kg < NKGC; ++kg) {
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                    for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(fa[kg & 1][rb], fb[kg & 1][cg], acc[rb][cg], (T*)nullptr);
+                    for (int cg = 0; cg < YT; ++cg) acc[rb][cg] = mfma16(fa[kg & 1][rb], fb[kg & 1][cg], acc[rb][cg], (T*)nullptr);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
                 const float b0 = bv[0][0], b1 = bv[0][1];
                 const size_t V = (size_t)p.D * p.H * p.W;
 #pragma unroll
-                for (int cg = 0; cg < 4; ++cg) {
+                for (int cg = 0; cg < YT; ++cg) {
                     const int oy = y0 + cg, ox = x0 + col;
                     if (!(oz < p.D && oy < p.H && ox < p.W)) continue;
                     float l0 = acc[0][cg][0] + b0, l1 = acc[0][cg][1] + b1;
@@ -342,7 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 ? 
                     for (int r = 0; r < 4; ++r) { mm[r] = s_mkm[n * p.M + row + r]; mr[r] = s_mkr[n * p.M + row + r]; }
                 }
 #pragma unroll
-                for (int cg = 0; cg < 4; ++cg) {
+                for (int cg = 0; cg < YT; ++cg) {
                     const bool valid = rvalid && zx_ok && y0 + cg < p.H;
                     // round once to bf16; the statistics are those of the stored values
                     f32x2 lo, hi;
@@ -418,20 +428,25 @@ static inline void k3b_fastdiv(int d, unsigned int& m, unsigned int& s) {
     m = (unsigned int)((((1ull << (32 + s)) + (unsigned long long)d - 1) / (unsigned long long)d) - (1ull << 32));
 }
 
-template <int CK, int MT, int EPI, bool SUMS>
+template <int CK, int MT, int EPI, bool SUMS, int YT = 4>
 static int k3b_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
-    using GEO = K3BGeom<CK, MT>;
+    using GEO = K3BGeom<CK, MT, YT>;
     const size_t tables = (size_t)2 * p_in.N * p_in.C * sizeof(float) + (p_in.sums ? (size_t)2 * p_in.N * p_in.M * sizeof(float) : 0);
     const size_t lds = K3B_LDS_TILE + (size_t)GEO::TILE_BYTES + GEO::W_BYTES + tables;
     if (lds > 160 * 1024) return VS_ESHAPE;
     G1Params p = p_in;
+    if (YT != 4) {                                       // re-tile the volume in 4 x YT x 16 tiles
+        p.tyn = (p.H + YT - 1) / YT;
+        p.tiles_per_sample = ((p.D + 3) / 4) * p.tyn * p.txn;
+        tiles_total = p.tiles_per_sample * p.N;
+    }
     // buffer offsets are 32-bit bytes, signed on the device
     if ((long long)p.N * p.D * p.H * p.W * p.C * 2 >= 2147483648ll || (long long)p.N * p.D * p.H * p.W * p.M * 2 >= 2147483648ll) return VS_ESHAPE;
     k3b_fastdiv(p.tiles_per_sample, p.fd_m[0], p.fd_s[0]);
     k3b_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3b_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
     if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr)) return VS_EINVAL;
-    auto kern = k3b_kernel<CK, MT, EPI, SUMS>;
+    auto kern = k3b_kernel<CK, MT, EPI, SUMS, YT>;
     // idempotent one-time opt-in to the full 160 KiB of dynamic LDS (not a stream operation)
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -440,8 +455,19 @@ static int k3b_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipS
     static const int per_cu = getenv("VS_K3_WGS_PER_CU") ? atoi(getenv("VS_K3_WGS_PER_CU")) : 4;   // tuning knob
     int wg = 256 * per_cu / (row_tiles < per_cu ? row_tiles : per_cu);
     if (wg < 256) wg = 256;
-    const int gx = tiles_total < wg ? tiles_total : wg;
+    int gx = tiles_total < wg ? tiles_total : wg;
+    if (gx >= 8) gx &= ~7;                               // multiple of the XCD count (kernel: XCD-aware tile walk)
     hipLaunchKernelGGL(kern, dim3(gx, row_tiles), dim3(256), lds, stream, p);
     VS_CHECK_LAUNCH();
     return VS_OK;
+}
+
+// Tall (4x8x16) tiles: measured faster (16->16 @48^3: 19.4 -> 15.4 us) where the layer is one wave of workgroups anyway — fewer,
+// fatter workgroups, 2.1x instead of 2.5x halo — and slower (8->8 @96^3: 40 -> 45 us) where workgroups walk many tiles and the
+// lower occupancy of the taller tile costs more than its halo saves.  VS_K3_TALL=0/1 forces the choice (tuning / tests).
+static inline bool k3b_use_tall(const G1Params& p) {
+    static const int force = getenv("VS_K3_TALL") ? atoi(getenv("VS_K3_TALL")) : -1;
+    if (force >= 0) return force != 0;
+    const long long tall = (long long)((p.D + 3) / 4) * ((p.H + 7) / 8) * p.txn * p.N;
+    return tall >= 256 && (long long)p.tiles_per_sample * p.N <= 2048;
 }
