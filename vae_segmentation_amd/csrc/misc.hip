@@ -127,25 +127,37 @@ __device__ __forceinline__ void st_any(void* p, int dtype, long long i, float v)
 }
 #define LIN_MAXB 16
 
-// one workgroup per output j: y[b][j] = act(bias[j] + sum_k W[j][k] x[b][phys(k)])
+// one workgroup per output j: y[b][j] = act(bias[j] + sum_k W[j][k] x[b][phys(k)]).  NB = batch rounded up to 1/2/4/8/16 at compile
+// time (padding rows re-read row batch-1 and are dropped), k unrolled by 4: 4 weight + 4*NB activation loads are in flight per
+// thread instead of one dependent load per FMA (the bottleneck GEMV is latency-, not bandwidth-bound: 27 k-steps per thread).
+template <int NB>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const void* __restrict__ x, int x_dtype, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int batch, int k_in,
                                                          int j_out, int pc, int pv, int relu) {
     const int j = blockIdx.x;
-    float acc[LIN_MAXB];
+    float acc[NB];
 #pragma unroll
-    for (int b = 0; b < LIN_MAXB; ++b) acc[b] = 0.f;
+    for (int b = 0; b < NB; ++b) acc[b] = 0.f;
     const float* wr = w + (size_t)j * k_in;
-    for (int k = threadIdx.x; k < k_in; k += 256) {
-        const float wv = wr[k];
-        const long long ph = phys_index(k, pc, pv);
+    for (int k0 = threadIdx.x; k0 < k_in; k0 += 256 * 4) {
+        float wv[4], xv[4][NB];
 #pragma unroll
-        for (int b = 0; b < LIN_MAXB; ++b)
-            if (b < batch) acc[b] += wv * ld_any(x, x_dtype, (long long)b * k_in + ph);
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 256;
+            const bool ok = k < k_in;
+            wv[u] = ok ? wr[k] : 0.f;
+            const long long ph = phys_index(ok ? k : 0, pc, pv);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) xv[u][b] = ld_any(x, x_dtype, (long long)(b < batch ? b : batch - 1) * k_in + ph);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[b] += wv[u] * xv[u][b];
     }
-    __shared__ float red[4][LIN_MAXB];
+    __shared__ float red[4][NB];
 #pragma unroll
-    for (int b = 0; b < LIN_MAXB; ++b) {
+    for (int b = 0; b < NB; ++b) {
         const float s = wave_sum(acc[b]);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][b] = s;
     }
@@ -161,7 +173,9 @@ extern "C" int vs_linear_fwd(const void* x, int x_dtype, const float* wgt, const
                              int j_out, int pc, int pv, int relu, void* stream) {
     if (!x || !wgt || !y || batch <= 0 || batch > LIN_MAXB || k_in <= 0 || j_out <= 0) return VS_EINVAL;
     if (pc > 0 && (long long)pc * pv != k_in) return VS_ESHAPE;
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(j_out), dim3(256), 0, (hipStream_t)stream, x, x_dtype, wgt, bias, y, batch, k_in, j_out, pc, pv, relu);
+#define LIN_FWD(NB) hipLaunchKernelGGL(linear_fwd_kernel<NB>, dim3(j_out), dim3(256), 0, (hipStream_t)stream, x, x_dtype, wgt, bias, y, batch, k_in, j_out, pc, pv, relu)
+    if (batch == 1) LIN_FWD(1); else if (batch == 2) LIN_FWD(2); else if (batch <= 4) LIN_FWD(4); else if (batch <= 8) LIN_FWD(8); else LIN_FWD(16);
+#undef LIN_FWD
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -192,21 +206,36 @@ extern "C" int vs_linear_fwd_perm_out(const float* z, const float* wgt, const fl
     return VS_OK;
 }
 
-// gx[b][phys(k)] = sum_j gy'[b][j] W[j][k]   (gy' = gy masked by y>0 when y_for_relu given)
+// gx[b][phys(k)] = sum_j gy'[b][j] W[j][k]   (gy' = gy masked by y>0 when y_for_relu given); one thread per k, 8 weight rows in
+// flight per step (a dependent load per FMA made this the longest launch of the step: 64 us for 6912 x 128)
+template <int NB>
 __global__ void linear_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ gy, const float* __restrict__ yrelu,
                                     void* __restrict__ gx, int x_dtype, int batch, int k_in, int j_out, int pc, int pv) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= k_in) return;
-    const long long ph = phys_index(k, pc, pv);
-    for (int b = 0; b < batch; ++b) {
-        float s = 0.f;
-        for (int j = 0; j < j_out; ++j) {
-            float g = gy[(size_t)b * j_out + j];
-            if (yrelu && !(yrelu[(size_t)b * j_out + j] > 0.f)) g = 0.f;
-            s += g * w[(size_t)j * k_in + k];
+    float s[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s[b] = 0.f;
+    for (int j0 = 0; j0 < j_out; j0 += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = j0 + u < j_out ? w[(size_t)(j0 + u) * k_in + k] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u < j_out ? j0 + u : j_out - 1;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const int bb = b < batch ? b : batch - 1;
+                float g = gy[(size_t)bb * j_out + j];
+                if (yrelu && !(yrelu[(size_t)bb * j_out + j] > 0.f)) g = 0.f;
+                s[b] += g * wv[u];
+            }
         }
-        st_any(gx, x_dtype, (long long)b * k_in + ph, s);
     }
+    const long long ph = phys_index(k, pc, pv);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b < batch) st_any(gx, x_dtype, (long long)b * k_in + ph, s[b]);
 }
 // gw[j][k] = sum_b gy'[b][j] x[b][phys(k)] ; gb[j] = sum_b gy'[b][j]
 __global__ void linear_bwd_w_kernel(const void* __restrict__ x, int x_dtype, const float* __restrict__ gy, const float* __restrict__ yrelu,
@@ -231,7 +260,10 @@ extern "C" int vs_linear_bwd(const void* x, int x_dtype, const float* wgt, const
     if (!wgt || !gy || batch <= 0 || k_in <= 0 || j_out <= 0) return VS_EINVAL;
     if (pc > 0 && (long long)pc * pv != k_in) return VS_ESHAPE;
     if (gx) {
-        hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((k_in + 255) / 256), dim3(256), 0, (hipStream_t)stream, wgt, gy, y_for_relu, gx, x_dtype, batch, k_in, j_out, pc, pv);
+        if (batch > LIN_MAXB) return VS_EINVAL;
+#define LIN_BX(NB) hipLaunchKernelGGL(linear_bwd_x_kernel<NB>, dim3((k_in + 63) / 64), dim3(64), 0, (hipStream_t)stream, wgt, gy, y_for_relu, gx, x_dtype, batch, k_in, j_out, pc, pv)
+        if (batch == 1) LIN_BX(1); else if (batch == 2) LIN_BX(2); else if (batch <= 4) LIN_BX(4); else if (batch <= 8) LIN_BX(8); else LIN_BX(16);
+#undef LIN_BX
         VS_CHECK_LAUNCH();
     }
     if (gw || gb) {
