@@ -1,9 +1,10 @@
-// Implicit-GEMM convolution kernels (forward / backward-data of every conv kind) for gfx950.
+// Implicit-GEMM convolution: shared parameter block and fragment conventions of every conv kernel, and g1_kernel — the
+// direct-from-global kernel of the 2x2x2 stride-2 convolution (K2S2) and the pointwise + 2x scatter = transposed convolution (PW).
+// The 3x3x3 kernels (LDS-staged halo tiles) are igemm_k3b.h (bf16) and igemm_k3.h (fp32).
 //
 // GEMM orientation: D[row = output channel m][col = voxel] = sum_k A[m][k] * B[k][voxel]
-//   A = packed weights (fragment order, see pack.hip), loaded 16 B/lane straight from global (L1/L2 hits)
-//   B = activations: k runs over (tap, channel); a lane's 16-byte fragment is EPL contiguous channels of one
-//       input voxel — read from an LDS-staged halo tile (K3) or directly from global (K2S2 / scatter).
+//   A = packed weights (fragment order, see pack.hip), 16 B/lane
+//   B = activations: k runs over (tap, channel); a lane's 16-byte fragment is EPL contiguous channels of one input voxel
 // The accumulator layout (col = lane&15, row = 4*(lane>>4)+reg) gives every lane 4 consecutive output
 // channels of one voxel, i.e. one 16-byte (f32) / 8-byte (bf16) channels-last store.
 #pragma once
@@ -46,9 +47,8 @@ struct G1Params {
 #define G1_LDS_MEAN 0       // float[256]
 #define G1_LDS_RSTD 1024    // float[256]
 #define G1_LDS_RED 2048     // float[4][64][2]
-#define G1_LDS_TAPS 4096    // int[64]
-#define G1_LDS_TILE 4352    // halo tile
-#define G1_TILE_VOX 648     // 6*6*18
+#define G1_LDS_BYTES 4096
+#define G1_TILE_VOX 648     // 3x3x3 kernels: (4+2)*(4+2)*(16+2) halo voxels
 
 template <typename T, int CK>
 __device__ __forceinline__ u32x4 act_transform(u32x4 raw, const float* s_mean, const float* s_rstd, int c0) {
@@ -67,7 +67,9 @@ template <typename T, int CK, int KIND, int MT, int EPI>
 __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     using E = ET<T>;
     constexpr int EPL = E::EPL, KG = E::KG;
-    constexpr int NTAPS = KIND == G1_K3 ? 27 : (KIND == G1_K2S2 ? 8 : 1);
+    static_assert(KIND == G1_K2S2 || KIND == G1_PW, "the 3x3x3 kernels live in igemm_k3b.h / igemm_k3.h");
+    static_assert(EPI == EPI_RAW || EPI == EPI_SCATTER, "softmax epilogue: 3x3x3 kernels only");
+    constexpr int NTAPS = KIND == G1_K2S2 ? 8 : 1;
     constexpr int NKG = (NTAPS * CK + KG - 1) / KG;
     constexpr int RB = MT / 16;
     constexpr int CKB = CK * (int)sizeof(T);          // bytes per voxel-chunk
@@ -77,8 +79,6 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     float* s_mean = (float*)(smem + G1_LDS_MEAN);
     float* s_rstd = (float*)(smem + G1_LDS_RSTD);
     float* s_red = (float*)(smem + G1_LDS_RED);
-    int* s_taps = (int*)(smem + G1_LDS_TAPS);
-    char* s_tile = smem + G1_LDS_TILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,30 +110,11 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
             s_rstd[c] = r;
         }
     }
-    if (KIND == G1_K3 && tid < 32) {
-        int t = tid < 27 ? tid : 13;      // padded taps read the centre voxel (their weights are zero)
-        int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-        s_taps[tid] = ((dz * 6 + dy) * 18 + dx) * CKB;
-    }
-
-    // ---- column geometry ----
-    int z0 = 0, y0 = 0, x0 = 0;                 // K3: tile origin (output coords)
-    int lds_base[4];                            // K3: byte offset of this lane's column voxel at tap (0,0,0)
-    long long gofs[4];                          // direct: element offset of the column's input voxel (tap 0)
+    // ---- column geometry: 256 output voxels per workgroup, 64 per wave ----
+    long long gofs[4];                          // element offset of the column's input voxel (tap 0)
     bool cvalid[4];
     int oz[4], oy[4], ox[4];
-    if constexpr (KIND == G1_K3) {
-        const int tx = tile % p.txn;
-        const int ty = (tile / p.txn) % p.tyn;
-        const int tz = tile / (p.txn * p.tyn);
-        z0 = tz * 4; y0 = ty * 4; x0 = tx * 16;
-#pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
-            oz[cg] = z0 + wave; oy[cg] = y0 + cg; ox[cg] = x0 + col;
-            cvalid[cg] = oz[cg] < p.D && oy[cg] < p.H && ox[cg] < p.W;
-            lds_base[cg] = ((wave * 6 + cg) * 18 + col) * CKB + ((g * EPL) % CK) * (int)sizeof(T);
-        }
-    } else {
+    {
         const int vcol = p.Do * p.Ho * p.Wo;             // < 2^31 (host check); 32-bit divisions: the 64-bit ones cost ~100 instructions each
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) {
@@ -160,65 +141,22 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
 
     // The chunk loop is instantiated twice, with has_stats a compile-time constant: as a run-time flag its branch sat between
     // every direct-from-global B load and its use, and the compiler drained vmcnt(0) after each load (32 serialized memory
-    // round trips per chunk on the stride-2 / transposed convs).
+    // round trips per chunk).
     auto chunk_loop = [&](auto hs_tag) {
-    constexpr bool HS = decltype(hs_tag)::value;
-    for (int ch = 0; ch < p.nch; ++ch) {
-        if constexpr (KIND == G1_K3) {
-            if (ch > 0) __syncthreads();
-            // ---- stage the (4+2)x(4+2)x(16+2) halo tile of this channel chunk, activation applied ----
-            // All global loads of a batch are issued before any is consumed (out-of-volume lanes read element 0 and
-            // are zeroed afterwards), so a workgroup pays one memory latency per batch instead of one per fragment.
-            constexpr int U = CKB / 16;
-            constexpr int NU = G1_TILE_VOX * U;
-            constexpr int NIT = (NU + 255) / 256;
-            constexpr int SB = NIT <= 12 ? NIT : (NIT + 1) / 2;
+        constexpr bool HS = decltype(hs_tag)::value;
+        for (int ch = 0; ch < p.nch; ++ch) {
+            const u32x4* wch = wp + (size_t)ch * NKG * 64 + lane;
+            const size_t rb_stride = (size_t)p.nch * NKG * 64;
+            if constexpr (KG > CK) {
+                // several taps per k-group: per-lane tap = kg*TPK + (g*EPL)/CK
+                const int sub = (g * EPL) / CK;
 #pragma unroll
-            for (int it0 = 0; it0 < NIT; it0 += SB) {
-                u32x4 vals[SB];
-                bool ok[SB];
+                for (int kg = 0; kg < NKG; ++kg) {
+                    u32x4 a[RB];
 #pragma unroll
-                for (int b = 0; b < SB; ++b) {
-                    const int u = tid + (it0 + b) * 256;
-                    const int tv = u / U, part = u - tv * U;
-                    const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / 108;
-                    const int gz = z0 + tz_ - 1, gy = y0 + ty_ - 1, gx = x0 + tx_ - 1;
-                    ok[b] = (it0 + b < NIT) && u < NU && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                    const size_t e = ok[b] ? ((((size_t)n * p.D + gz) * p.H + gy) * p.W + gx) * p.C + ch * CK + part * EPL : 0;
-                    vals[b] = *(const u32x4*)(xin + e);
-                }
-#pragma unroll
-                for (int b = 0; b < SB; ++b) {
-                    const int u = tid + (it0 + b) * 256;
-                    if (it0 + b < NIT && u < NU) {
-                        const int tv = u / U, part = u - tv * U;
-                        u32x4 val = vals[b];
-                        if (HS) val = act_transform<T, CK>(val, s_mean, s_rstd, ch * CK + part * EPL);
-                        if (!ok[b]) val = u32x4{0u, 0u, 0u, 0u};
-                        *(u32x4*)(s_tile + tv * CKB + part * 16) = val;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        const u32x4* wch = wp + (size_t)ch * NKG * 64 + lane;
-        const size_t rb_stride = (size_t)p.nch * NKG * 64;
-
-        if constexpr (KG > CK) {
-            // several taps per k-group: per-lane tap = kg*TPK + (g*EPL)/CK
-            const int sub = (g * EPL) / CK;
-#pragma unroll
-            for (int kg = 0; kg < NKG; ++kg) {
-                u32x4 a[RB];
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
-                u32x4 b[4];
-                const int tap = kg * TPK + sub;
-                if constexpr (KIND == G1_K3) {
-                    const int toff = s_taps[tap];
-#pragma unroll
-                    for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff);
-                } else {
+                    for (int rb = 0; rb < RB; ++rb) a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
+                    u32x4 b[4];
+                    const int tap = kg * TPK + sub;
                     const int tt = tap < NTAPS ? tap : 0;
                     const int dz = (tt >> 2) & 1, dy = (tt >> 1) & 1, dx = tt & 1;
                     const long long toff = (((long long)dz * p.H + dy) * p.W + dx) * p.C + ch * CK + (g * EPL) % CK;
@@ -228,44 +166,37 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
 #pragma unroll
                         for (int cg = 0; cg < 4; ++cg) b[cg] = act_transform<T, CK>(b[cg], s_mean, s_rstd, ch * CK + (g * EPL) % CK);
                     }
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
                 }
+            } else {
+                // wave-uniform tap; KPT k-groups per tap.  The A (weight) fragments come straight from global memory, so the
+                // loop is software-pipelined: fragments for k-group kg+PD are requested while k-group kg is multiplied.
+                constexpr int NK = NTAPS * KPT;
+                constexpr int PD = RB <= 2 ? 9 : 3;          // prefetch distance in k-groups (register budget RB*PD*4 VGPRs)
+                u32x4 abuf[PD][RB];
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
+                for (int j = 0; j < PD; ++j)
 #pragma unroll
-                    for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
-            }
-        } else {
-            // wave-uniform tap; KPT k-groups per tap.  The A (weight) fragments come straight from global memory, so the
-            // loop is software-pipelined: fragments for k-group kg+PD are requested while k-group kg is multiplied.
-            constexpr int NK = NTAPS * KPT;
-            constexpr int PD = RB <= 2 ? 9 : 3;          // prefetch distance in k-groups (register budget RB*PD*4 VGPRs)
-            u32x4 abuf[PD][RB];
-#pragma unroll
-            for (int j = 0; j < PD; ++j)
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-                    abuf[j][rb] = j < NK ? wch[(size_t)(rb0 + rb) * rb_stride + j * 64] : u32x4{0u, 0u, 0u, 0u};
+                    for (int rb = 0; rb < RB; ++rb)
+                        abuf[j][rb] = j < NK ? wch[(size_t)(rb0 + rb) * rb_stride + j * 64] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll 1
-            for (int kgb = 0; kgb < NK; kgb += PD) {
+                for (int kgb = 0; kgb < NK; kgb += PD) {
 #pragma unroll
-                for (int j = 0; j < PD; ++j) {
-                    const int kg = kgb + j;
-                    if (kg < NK) {
-                        u32x4 a[RB];
+                    for (int j = 0; j < PD; ++j) {
+                        const int kg = kgb + j;
+                        if (kg < NK) {
+                            u32x4 a[RB];
 #pragma unroll
-                        for (int rb = 0; rb < RB; ++rb) a[rb] = abuf[j][rb];
-                        if (kg + PD < NK) {
+                            for (int rb = 0; rb < RB; ++rb) a[rb] = abuf[j][rb];
+                            if (kg + PD < NK) {
 #pragma unroll
-                            for (int rb = 0; rb < RB; ++rb) abuf[j][rb] = wch[(size_t)(rb0 + rb) * rb_stride + (kg + PD) * 64];
-                        }
-                        const int tap = kg / KPT, kk = kg - tap * KPT;
-                        u32x4 b[4];
-                        if constexpr (KIND == G1_K3) {
-                            const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                            const int toff_l = ((dz * 6 + dy) * 18 + dx) * CKB + kk * KG * (int)sizeof(T);
-#pragma unroll
-                            for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff_l);
-                        } else {
+                                for (int rb = 0; rb < RB; ++rb) abuf[j][rb] = wch[(size_t)(rb0 + rb) * rb_stride + (kg + PD) * 64];
+                            }
+                            const int tap = kg / KPT, kk = kg - tap * KPT;
+                            u32x4 b[4];
                             const int dz = (tap >> 2) & 1, dy = (tap >> 1) & 1, dx = tap & 1;
                             const int cc = kk * KG + g * EPL;
                             const long long toff_g = (((long long)dz * p.H + dy) * p.W + dx) * p.C + ch * CK + cc;
@@ -275,41 +206,21 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
 #pragma unroll
                                 for (int cg = 0; cg < 4; ++cg) b[cg] = act_transform<T, CK>(b[cg], s_mean, s_rstd, ch * CK + cc);
                             }
+#pragma unroll
+                            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                                for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
                         }
-#pragma unroll
-                        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
                     }
                 }
             }
         }
-    }
     };
     if (has_stats) chunk_loop(std::true_type{}); else chunk_loop(std::false_type{});
 
     // ------------------------------------------------------------------------------------------
     // epilogues
     // ------------------------------------------------------------------------------------------
-    if constexpr (EPI == EPI_SOFTMAX2) {
-        if (g == 0) {
-            const float b0 = p.bias ? p.bias[0] : 0.f, b1 = p.bias ? p.bias[1] : 0.f;
-            const size_t V = (size_t)p.D * p.H * p.W;
-#pragma unroll
-            for (int cg = 0; cg < 4; ++cg) {
-                if (!cvalid[cg]) continue;
-                const float l0 = acc[0][cg][0] + b0, l1 = acc[0][cg][1] + b1;
-                const float mx = fmaxf(l0, l1);
-                const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx);
-                const float inv = 1.f / (e0 + e1);
-                const size_t v = ((size_t)oz[cg] * p.H + oy[cg]) * p.W + ox[cg];
-                p.prob[((size_t)n * 2 + 0) * V + v] = e0 * inv;
-                p.prob[((size_t)n * 2 + 1) * V + v] = e1 * inv;
-            }
-        }
-        return;
-    }
-
     T* __restrict__ yout = (T*)p.y;
     float ssum[RB][4], ssq[RB][4], mk_mean[RB][4], mk_rstd[RB][4];
 #pragma unroll
@@ -415,14 +326,8 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
 
 template <typename T, int CK, int KIND, int MT, int EPI>
 static int g1_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
-    constexpr size_t lds = G1_LDS_TILE + (KIND == G1_K3 ? (size_t)G1_TILE_VOX * CK * sizeof(T) : 0);
+    constexpr size_t lds = G1_LDS_BYTES;
     auto kern = g1_kernel<T, CK, KIND, MT, EPI>;
-    if (lds > 64 * 1024) {
-        // idempotent one-time opt-in to >64 KiB dynamic LDS (not a stream operation)
-        static const hipError_t attr_err =
-            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr_err != hipSuccess) return (int)attr_err;
-    }
     hipLaunchKernelGGL(kern, dim3(tiles_total, row_tiles), dim3(256), lds, stream, p);
     VS_CHECK_LAUNCH();
     return VS_OK;

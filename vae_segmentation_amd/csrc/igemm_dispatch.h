@@ -2,7 +2,6 @@
 #pragma once
 #include "igemm.h"
 
-int g1_dispatch_k3(const G1Params& p, int dtype, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_dispatch_k2s2(const G1Params& p, int dtype, int ck, int mt, int tiles, int row_tiles, hipStream_t s);
 int g1_dispatch_pw(const G1Params& p, int dtype, int ck, int mt, int tiles, int row_tiles, hipStream_t s);
 

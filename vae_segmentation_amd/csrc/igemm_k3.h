@@ -1,4 +1,5 @@
 // 3x3x3 (pad 1) implicit-GEMM convolution, forward and backward-data: persistent, register-prefetched.
+// Instantiated for fp32 storage (the parity mode); bf16 storage runs k3b_kernel (igemm_k3b.h).
 //
 // Same GEMM orientation, fragment formats, LDS halo tile and epilogues as g1_kernel (igemm.h), restructured for the
 // fact that on this op a workgroup is latency-bound, not MFMA-bound (a 4x4x16 tile is ~450 MFMA cycles against
@@ -149,17 +150,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[rb][r] = 0.f; ssq[rb][r] = 0.f; }
 
-    // Single-chunk layers (C <= 16): the workgroup's weight fragments are the same for every tile, so they COULD be loaded
-    // once into registers (optional path, off: see WREG).
-    constexpr bool WREG = false;   // measured: keeping the fragments in registers costs occupancy and runs 15 % slower (49 -> 58 us, 8->8 @96^3)
-    u32x4 wreg[WREG ? NKG : 1][RB];
-    if constexpr (WREG) {
-#pragma unroll
-        for (int kg = 0; kg < NKG; ++kg)
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) wreg[kg][rb] = wp[(size_t)(rb0 + rb) * rb_stride + kg * 64 + lane];
-    }
-
+    // (tried: keeping the single-chunk layers' weight fragments in registers — costs occupancy, 15 % slower)
     int t = blockIdx.x;
     __syncthreads();                                     // tables visible
     if (PF && t < total_tiles) stage_load(t, 0, 0);
@@ -178,7 +169,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                 __syncthreads();                         // every wave is done reading the previous stage's tile
                 stage_write(n, ch, 0);
                 __syncthreads();
-                if constexpr (KG > CK) {              // (weights in registers or few loads: prefetch right away)
+                if constexpr (KG > CK) {              // (few weight loads per tile: prefetch right away)
                     const bool more_ch = ch + 1 < p.nch;
                     const int tn = more_ch ? t : t + (int)gridDim.x;
                     if (tn < total_tiles) stage_load(tn, more_ch ? ch + 1 : 0, 0);
@@ -200,10 +191,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                 for (int kg = 0; kg < NKG; ++kg) {
                     u32x4 a[RB];
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) {
-                        if constexpr (WREG) a[rb] = wreg[kg][rb];
-                        else a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
-                    }
+                    for (int rb = 0; rb < RB; ++rb) a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
                     const int toff = s_taps[kg * TPK + sub];
                     u32x4 b[4];
 #pragma unroll
