@@ -2,5 +2,6 @@
 
 Same class names, constructor / forward signatures and state_dict keys; the arithmetic runs on the
 hand-written gfx950 kernels of vae_segmentation_amd (libvaeseg.so).  GPU only — no CPU fallback."""
-from vae_segmentation_amd.modules import (Conv, DoubleConv, Down, Joint, Normalization, Segmentation, Up, VAE,  # noqa: F401
+from vae_segmentation_amd.modules import (Conv, DoubleConv, Down, Embed, Encoder, Fusion, Joint, Joint2, Normalization,  # noqa: F401
+                                          Segmentation, Up, VAE,
                                           set_default_kernel_dtype, set_kernel_dtype)

@@ -377,6 +377,80 @@ def _ft128(dt):
     return d
 
 
+def gold_rank4():
+    """SURVEY.md §8f rank 4 — the remaining model surface built from the same blocks (joint_model.py:274-303 Encoder,
+    :392-437 Fusion, :469-500 Embed), forward + backward on the reference modules with representative scalar losses."""
+    save("enc128", both_precisions(_enc128))
+    save("fusion64", both_precisions(_fusion64))
+    save("embed128", both_precisions(_embed128))
+
+
+def _enc128(dt):
+    d = {}
+    enc = RM.Encoder(n_channels=1, dim=1, norm_type=1)                    # the discriminator of main_target.py:338-341
+    O.deterministic_fill_(enc, seed=4)
+    enc.to(dt)
+    x = O.synthetic_image(1, 128, seed=5).abs().to(dt).requires_grad_(True)   # a probability-like map in [0, 1]
+    out = enc(x)
+    out.sum().backward()
+    d["out"] = out.detach().numpy()
+    put(d, "gx", x.grad, 512)
+    put_grads(d, "enc", enc)
+    return d
+
+
+def _fusion64(dt):
+    d = {}
+    fus = RM.Fusion(n_channels_img=1, n_channels_mask=2, n_class=2, norm_type=1)
+    O.deterministic_fill_(fus, seed=6)
+    fus.to(dt)
+    img = O.synthetic_image(1, 64, seed=2).to(dt)
+    gt = O.one_hot(O.synthetic_label(1, 64, seed=3)).to(dt)
+    mask = O.one_hot(O.synthetic_label(1, 64, seed=7)).to(dt).requires_grad_(True)
+    batch = fus({"img": img, "mask": mask}, "img", "mask", "pred")
+    loss = 1 - main_source_avg_dsc(batch["pred"], gt, 1, 2)
+    loss.backward()
+    d["loss"] = loss.detach().numpy()
+    put(d, "pred", batch["pred"], 512)
+    put(d, "gmask", mask.grad, 512)
+    put_grads(d, "fus", fus)
+    return d
+
+
+def _embed128(dt):
+    d = {}
+    enc = RM.Encoder(n_channels=1, dim=128, norm_type=1)
+    vae = RM.VAE(n_channels=2, n_class=2, norm_type=1, dim=128)
+    fus = RM.Fusion(n_channels_img=1, n_channels_mask=2, n_class=2, norm_type=1)
+    emb = RM.Embed(models=[enc, vae, fus])
+    O.deterministic_fill_(emb, seed=8)
+    emb.to(dt)
+    img = O.synthetic_image(1, 128, seed=2).to(dt)
+    gt = O.one_hot(O.synthetic_label(1, 128, seed=3)).to(dt)
+    torch.manual_seed(123)
+    z = torch.randn(1, 128)
+    torch.manual_seed(123)
+    if dt == torch.float64:
+        torch.cuda.FloatTensor = torch.DoubleTensor          # the reference casts its noise with .type(torch.cuda.FloatTensor)
+    try:
+        batch = emb({"img": img, "venous_pancreas_only": gt}, "img", "pred")
+    finally:
+        torch.cuda.FloatTensor = torch.FloatTensor
+    dsc = 1 - main_source_avg_dsc(batch["pred"], gt, 1, 2)
+    lat = torch.mean((batch["latent_code"] - batch["latent_code_gt"].detach()) ** 2)
+    loss = dsc + lat
+    loss.backward()
+    d["z"] = z.numpy()
+    d["dice_loss"], d["latent_loss"], d["loss"] = dsc.detach().numpy(), lat.detach().numpy(), loss.detach().numpy()
+    d["latent_code"], d["latent_code_gt"] = batch["latent_code"].detach().numpy(), batch["latent_code_gt"].detach().numpy()
+    for k in ("pred", "gt_recon", "init_seg", "seg_recon"):
+        put(d, k, batch[k], 512)
+    put_grads(d, "enc", enc)
+    put_grads(d, "vae", vae)
+    put_grads(d, "fus", fus)
+    return d
+
+
 def gold_vae128_native():
     """vae_train step on the NATIVE reference VAE (main_source.py:389-413): z is the reference's own
     torch.randn draw under torch.manual_seed(123), recorded so the oracle / HIP path can inject it."""
@@ -423,6 +497,7 @@ CASES = {
     "da128": gold_da128,
     "vae128_train": gold_vae128_native,
     "ft128": gold_ft128,
+    "rank4": gold_rank4,
 }
 
 if __name__ == "__main__":

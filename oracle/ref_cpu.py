@@ -202,6 +202,110 @@ class Joint(nn.Module):
         return data_dict
 
 
+class Encoder(nn.Module):
+    """joint_model.py:274-303 — the VAE encoder trunk + fc1/fc2/fc_mean, sigmoid output (the discriminator `Dis` of
+    domain_adaptation_dis, main_target.py:338-341, and the image encoder of Embed).  ``spatial`` as in VAE (reference: 128)."""
+
+    def __init__(self, n_channels, dim, norm_type=2, n_fmaps=FMAPS, soft=False, spatial=128):
+        super().__init__()
+        f = list(n_fmaps)
+        self.in_block = Conv(n_channels, f[0], norm_type=norm_type)
+        for i in range(5):
+            setattr(self, "down%d" % (i + 1), Down(f[i], f[i + 1], norm_type=norm_type))
+        self.flat = f[5] * (spatial // 32) ** 3
+        self.fc1 = nn.Linear(self.flat, 1024)
+        self.fc2 = nn.Linear(1024, 128)
+        self.fc_mean = nn.Linear(128, dim)
+
+    def forward(self, x):
+        x = self.in_block(x)
+        for i in range(1, 6):
+            x = getattr(self, "down%d" % i)(x)
+        x = F.relu(self.fc1(x.reshape(x.size(0), self.flat)))
+        x = F.relu(self.fc2(x))
+        return torch.sigmoid(self.fc_mean(x))
+
+
+class Fusion(nn.Module):
+    """joint_model.py:392-437 — U-Net over an image and a mask branch merged (added) at half resolution."""
+
+    def __init__(self, n_channels_img, n_channels_mask, n_class, norm_type=2, n_fmaps=FMAPS):
+        super().__init__()
+        f = list(n_fmaps)
+        self.in_block = Conv(n_channels_img, f[0], norm_type=norm_type)
+        self.down1 = Down(f[0], f[1], norm_type=norm_type)
+        self.in_block_mask = Conv(n_channels_mask, f[0], norm_type=norm_type)
+        self.down1_mask = Down(f[0], f[1], norm_type=norm_type)
+        self.merge = Conv(f[1], f[1], norm_type=norm_type)
+        self.down2 = Down(f[1], f[2], norm_type=norm_type)
+        self.down3 = Down(f[2], f[3], norm_type=norm_type)
+        self.down4 = Down(f[3], f[4], norm_type=norm_type)
+        self.up2 = Up(f[4], f[3], norm_type=norm_type)
+        self.up3 = Up(f[3], f[2], norm_type=norm_type)
+        self.up4 = Up(f[2], f[1], norm_type=norm_type)
+        self.up5 = Up(f[1], f[0], norm_type=norm_type)
+        self.out_block = nn.Conv3d(f[0], n_class, 3, padding=1)
+        self.final = nn.Softmax(dim=1)
+        self.n_class = n_class
+
+    def forward(self, data_dict, in_key_img, in_key_mask, out_key):
+        x2 = self.down1(self.in_block(data_dict[in_key_img])) + self.down1_mask(self.in_block_mask(data_dict[in_key_mask]))
+        x2 = self.merge(x2)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        x5 = self.down4(x4)
+        x = self.up2(x5)
+        x = self.up3(x) + x3
+        x = self.up4(x) + x2
+        x = self.up5(x)
+        data_dict[out_key] = self.final(self.out_block(x))
+        return data_dict
+
+
+class Joint2(nn.Module):
+    """joint_model.py:454-466 — segmenter + discriminator on the foreground probability."""
+
+    def __init__(self, models, seg_dropout=0.0):
+        super().__init__()
+        self.Seg, self.Dis = models[0], models[1]
+        self.seg_dropout = seg_dropout
+
+    def forward(self, data_dict, in_key, out_key, score_key, dropout=False):
+        if dropout:
+            data_dict = self.Seg(data_dict, in_key, out_key, dropout=self.seg_dropout)
+        else:
+            data_dict = self.Seg(data_dict, in_key, out_key)
+        data_dict[score_key] = self.Dis(data_dict[out_key][:, 1:2, :, :, :])
+        return data_dict
+
+
+class Embed(nn.Module):
+    """joint_model.py:469-500 — image encoder -> latent code -> VAE decoder (initial segmentation) -> Fusion refinement."""
+
+    def __init__(self, models):
+        super().__init__()
+        self.Encoder, self.Vae, self.Fusion = models[0], models[1], models[2]
+
+    def forward(self, data_dict, in_key, out_key, test_mode=False, loop_input=None, seg_input=None, latent_input=None, noise=None):
+        data_dict["latent_code"] = data_dict[latent_input] if latent_input else self.Encoder(data_dict[in_key])
+        data_dict["gt_recon"], data_dict["latent_code_gt"], data_dict["latent_code_std"] = self.Vae(
+            data_dict["venous_pancreas_only"], if_random=True, scale=0.5, mid_input=False, noise=noise)
+        if loop_input:
+            data_dict[loop_input], data_dict["latent_code_loop"], _ = self.Vae(data_dict[loop_input], if_random=False, scale=0, mid_input=False)
+        if seg_input:
+            data_dict["init_seg"] = data_dict[seg_input]
+        else:
+            data_dict["init_seg"] = self.Vae(data_dict["latent_code"], if_random=False, scale=0, mid_input=True)
+        if loop_input:
+            data_dict = self.Fusion(data_dict, in_key, loop_input, out_key)
+        elif test_mode:
+            data_dict = self.Fusion(data_dict, in_key, "init_seg", out_key)
+        else:
+            data_dict = self.Fusion(data_dict, in_key, "gt_recon", out_key)
+        data_dict["seg_recon"], _, _ = self.Vae(data_dict["init_seg"].detach(), if_random=False, scale=0, mid_input=False)
+        return data_dict
+
+
 # --------------------------------------------------------------------------------------
 # losses / label prep
 # --------------------------------------------------------------------------------------

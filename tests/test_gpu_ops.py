@@ -52,6 +52,7 @@ CONV_CASES = [  # (N, Cin, Cout, D, H, W)
     (2, 8, 8, 8, 8, 16), (1, 8, 16, 5, 6, 20), (1, 16, 8, 4, 4, 16), (1, 16, 16, 6, 5, 7), (1, 32, 16, 4, 4, 8),
     (1, 16, 32, 4, 8, 16), (1, 32, 32, 3, 3, 3), (1, 64, 32, 4, 4, 4), (1, 32, 64, 6, 6, 6), (1, 64, 128, 3, 3, 3),
     (1, 128, 64, 3, 3, 3), (2, 256, 256, 3, 3, 3), (1, 2, 8, 8, 8, 8), (1, 1, 8, 4, 4, 16),
+    (1, 128, 128, 8, 8, 8), (1, 64, 64, 16, 16, 16), (2, 128, 64, 8, 8, 8),
 ]
 
 

@@ -163,3 +163,52 @@ def test_vae128_native_with_recorded_noise():
     assert final.item() == pytest.approx(float(g["final"]), rel=1e-6)
     G.check_tensor(g, "recon", aux["batch"]["recon"], k=512, rtol=1e-5)
     G.check_grads(g, "vae", [(n, p.grad) for n, p in vae.named_parameters()], rtol=1e-4)
+
+
+# ---- Encoder / Fusion / Embed (oracle/make_golden.py: gold_rank4) ------------------------------
+def _dsc_main_source(s, t, bot, top, eps=1e-4):
+    d = 2 * torch.sum(s * t, (2, 3, 4)) / (torch.sum(s, (2, 3, 4)) + torch.sum(t, (2, 3, 4)) + eps)
+    return torch.mean(d[:, bot:top])
+
+
+def test_encoder128():
+    g = G.load("enc128")
+    enc = O.deterministic_fill_(O.Encoder(1, 1, norm_type=1), seed=4)
+    assert enc.fc1.weight.shape == (1024, 16384)          # reference state_dict shape
+    x = O.synthetic_image(1, 128, seed=5).abs().requires_grad_(True)
+    out = enc(x)
+    out.sum().backward()
+    assert np.allclose(out.detach().numpy(), g["out"], rtol=1e-5)
+    G.check_tensor(g, "gx", x.grad, k=512, rtol=1e-4)
+    G.check_grads(g, "enc", [(n, p.grad) for n, p in enc.named_parameters()], rtol=1e-4)
+
+
+def test_fusion64():
+    g = G.load("fusion64")
+    fus = O.deterministic_fill_(O.Fusion(1, 2, 2, norm_type=1), seed=6)
+    img, gt = O.synthetic_image(1, 64, seed=2), O.one_hot(O.synthetic_label(1, 64, seed=3))
+    mask = O.one_hot(O.synthetic_label(1, 64, seed=7)).requires_grad_(True)
+    batch = fus({"img": img, "mask": mask}, "img", "mask", "pred")
+    loss = 1 - _dsc_main_source(batch["pred"], gt, 1, 2)
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-6)
+    G.check_tensor(g, "pred", batch["pred"], k=512, rtol=1e-5)
+    G.check_tensor(g, "gmask", mask.grad, k=512, rtol=1e-4)
+    G.check_grads(g, "fus", [(n, p.grad) for n, p in fus.named_parameters()], rtol=1e-4)
+
+
+def test_embed128():
+    g = G.load("embed128")
+    emb = O.Embed([O.Encoder(1, 128, norm_type=1), O.VAE(2, 2, norm_type=1, dim=128), O.Fusion(1, 2, 2, norm_type=1)])
+    O.deterministic_fill_(emb, seed=8)
+    img, gt = O.synthetic_image(1, 128, seed=2), O.one_hot(O.synthetic_label(1, 128, seed=3))
+    batch = emb({"img": img, "venous_pancreas_only": gt}, "img", "pred", noise=torch.from_numpy(g["z"]))
+    dsc = 1 - _dsc_main_source(batch["pred"], gt, 1, 2)
+    lat = torch.mean((batch["latent_code"] - batch["latent_code_gt"].detach()) ** 2)
+    (dsc + lat).backward()
+    assert dsc.item() == pytest.approx(float(g["dice_loss"]), rel=1e-5)
+    assert lat.item() == pytest.approx(float(g["latent_loss"]), rel=1e-5)
+    for k in ("pred", "gt_recon", "init_seg", "seg_recon"):
+        G.check_tensor(g, k, batch[k], k=512, rtol=1e-4)
+    for pre, mod in (("enc", emb.Encoder), ("vae", emb.Vae), ("fus", emb.Fusion)):
+        G.check_grads(g, pre, [(n, p.grad) for n, p in mod.named_parameters()], rtol=2e-4)

@@ -296,3 +296,136 @@ class Joint(nn.Module):
             data_dict[out_key_recon], data_dict["mean"], data_dict["std"] = self.Vae(
                 data_dict[out_key], if_random=False, scale=self.vae_forward_scale)
         return data_dict
+
+
+def _linear(x2d, fc, relu):
+    """nn.Linear on a (B, K) fp32 tensor through the native GEMV (LinearCL with a 1x1x1 grid: identity flatten order)."""
+    return ops.LinearCL.apply(x2d.contiguous().view(x2d.shape[0], 1, 1, 1, x2d.shape[1]), fc.weight, fc.bias, relu)
+
+
+class Encoder(nn.Module):
+    """joint_model.py:274-303 — VAE encoder trunk + fc1 / fc2 / fc_mean with a sigmoid output: the discriminator `Dis` of
+    domain_adaptation_dis (main_target.py:338-341) and the image encoder of Embed.  ``spatial`` as in VAE (reference: 128)."""
+
+    def __init__(self, n_channels, dim, norm_type=2, n_fmaps=[8, 16, 32, 64, 128, 256], soft=False, spatial=128):
+        super().__init__()
+        if spatial % 32 or spatial < 64:
+            raise ValueError("spatial must be a multiple of 32 and >= 64")
+        f = list(n_fmaps)
+        self.in_block = Conv(n_channels, f[0], norm_type=norm_type, soft=False)
+        self.down1 = Down(f[0], f[1], norm_type=norm_type, soft=False)
+        self.down2 = Down(f[1], f[2], norm_type=norm_type, soft=False)
+        self.down3 = Down(f[2], f[3], norm_type=norm_type, soft=False)
+        self.down4 = Down(f[3], f[4], norm_type=norm_type, soft=False)
+        self.down5 = Down(f[4], f[5], norm_type=norm_type, soft=False)
+        self.fc1 = nn.Linear(f[5] * (spatial // 32) ** 3, 1024)
+        self.fc2 = nn.Linear(1024, 128)
+        self.fc_mean = nn.Linear(128, dim)
+        self.spatial = spatial
+        self.kernel_dtype = _DEFAULT_DTYPE
+
+    def forward(self, x):
+        ops._require_cuda(x)
+        if x.shape[-1] != self.spatial:
+            raise ValueError("Encoder built for spatial=%d got input side %d" % (self.spatial, x.shape[-1]))
+        ops.stats_arena_begin(x.device)
+        a = Act(ops.PackPlanar.apply(x.contiguous(), self.kernel_dtype), None)
+        a = self.in_block(a)
+        for blk in (self.down1, self.down2, self.down3, self.down4, self.down5):
+            a = blk(a)
+        feat = ops.Materialize.apply(a.raw, a.stats, None, None)
+        h = ops.LinearCL.apply(feat, self.fc1.weight, self.fc1.bias, True)
+        h = _linear(h, self.fc2, True)
+        return torch.sigmoid(_linear(h, self.fc_mean, False))           # (B, dim) scalars: host-side glue like the loss combines
+
+
+class Fusion(nn.Module):
+    """joint_model.py:392-437 — U-Net over an image and a mask branch, added at half resolution, additive skips at up3 / up4."""
+
+    def __init__(self, n_channels_img, n_channels_mask, n_class, norm_type=2, n_fmaps=[8, 16, 32, 64, 128, 256]):
+        super().__init__()
+        if n_class != 2:
+            raise NotImplementedError("native softmax / label kernels are written for n_class == 2")
+        f = list(n_fmaps)
+        self.in_block = Conv(n_channels_img, f[0], norm_type=norm_type, soft=False)
+        self.down1 = Down(f[0], f[1], norm_type=norm_type, soft=False)
+        self.in_block_mask = Conv(n_channels_mask, f[0], norm_type=norm_type, soft=False)
+        self.down1_mask = Down(f[0], f[1], norm_type=norm_type, soft=False)
+        self.merge = Conv(f[1], f[1], norm_type=norm_type, soft=False)
+        self.down2 = Down(f[1], f[2], norm_type=norm_type, soft=False)
+        self.down3 = Down(f[2], f[3], norm_type=norm_type, soft=False)
+        self.down4 = Down(f[3], f[4], norm_type=norm_type, soft=False)
+        self.up2 = Up(f[4], f[3], norm_type=norm_type, soft=False)
+        self.up3 = Up(f[3], f[2], norm_type=norm_type, soft=False)
+        self.up4 = Up(f[2], f[1], norm_type=norm_type, soft=False)
+        self.up5 = Up(f[1], f[0], norm_type=norm_type, soft=False)
+        self.out_block = nn.Conv3d(f[0], n_class, 3, padding=1)
+        self.final = nn.Softmax(dim=1)
+        self.n_class = n_class
+        self.kernel_dtype = _DEFAULT_DTYPE
+
+    def forward(self, data_dict, in_key_img, in_key_mask, out_key):
+        x_img, x_mask = data_dict[in_key_img], data_dict[in_key_mask]
+        ops._require_cuda(x_img, x_mask)
+        if any(s % 16 for s in x_img.shape[2:]):
+            raise ValueError("Fusion needs spatial sizes that are multiples of 16, got %s" % (tuple(x_img.shape[2:]),))
+        ops.stats_arena_begin(x_img.device)
+        a_img = self.down1(self.in_block(Act(ops.PackPlanar.apply(x_img.contiguous(), self.kernel_dtype), None)))
+        a_mask = self.down1_mask(self.in_block_mask(Act(ops.PackPlanar.apply(x_mask.contiguous(), self.kernel_dtype), None)))
+        x2 = self.merge(Act(ops.Materialize.apply(a_img.raw, a_img.stats, a_mask.raw, a_mask.stats), None))
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        x5 = self.down4(x4)
+        u = self.up3(self.up2(x5))
+        u = self.up4(Act(ops.Materialize.apply(u.raw, u.stats, x3.raw, x3.stats), None))
+        u = self.up5(Act(ops.Materialize.apply(u.raw, u.stats, x2.raw, x2.stats), None))
+        data_dict[out_key] = ops.ConvK3Softmax.apply(u.raw, u.stats, self.out_block.weight, self.out_block.bias)
+        return data_dict
+
+
+class Joint2(nn.Module):
+    """joint_model.py:454-466 — segmenter + discriminator on the foreground probability."""
+
+    def __init__(self, models, seg_dropout=0.0):
+        super().__init__()
+        self.Seg = models[0]
+        self.Dis = models[1]
+        self.seg_dropout = seg_dropout
+
+    def forward(self, data_dict, in_key, out_key, score_key, dropout=False):
+        if dropout:
+            data_dict = self.Seg(data_dict, in_key, out_key, dropout=self.seg_dropout)
+        else:
+            data_dict = self.Seg(data_dict, in_key, out_key)
+        data_dict[score_key] = self.Dis(data_dict[out_key][:, 1:2, :, :, :])
+        return data_dict
+
+
+class Embed(nn.Module):
+    """joint_model.py:469-500 — image encoder -> latent code -> VAE decoder (initial segmentation) -> Fusion refinement.
+    ``noise`` (optional) replaces the VAE's own draw for the `gt_recon` pass, as in VAE.forward."""
+
+    def __init__(self, models):
+        super().__init__()
+        self.Encoder = models[0]
+        self.Vae = models[1]
+        self.Fusion = models[2]
+
+    def forward(self, data_dict, in_key, out_key, test_mode=False, loop_input=None, seg_input=None, latent_input=None, noise=None):
+        data_dict["latent_code"] = data_dict[latent_input] if latent_input else self.Encoder(data_dict[in_key])
+        data_dict["gt_recon"], data_dict["latent_code_gt"], data_dict["latent_code_std"] = self.Vae(
+            data_dict["venous_pancreas_only"], if_random=True, scale=0.5, mid_input=False, noise=noise)
+        if loop_input:
+            data_dict[loop_input], data_dict["latent_code_loop"], _ = self.Vae(data_dict[loop_input], if_random=False, scale=0, mid_input=False)
+        if seg_input:
+            data_dict["init_seg"] = data_dict[seg_input]
+        else:
+            data_dict["init_seg"] = self.Vae(data_dict["latent_code"], if_random=False, scale=0, mid_input=True)
+        if loop_input:
+            data_dict = self.Fusion(data_dict, in_key, loop_input, out_key)
+        elif test_mode:
+            data_dict = self.Fusion(data_dict, in_key, "init_seg", out_key)
+        else:
+            data_dict = self.Fusion(data_dict, in_key, "gt_recon", out_key)
+        data_dict["seg_recon"], _, _ = self.Vae(data_dict["init_seg"].detach(), if_random=False, scale=0, mid_input=False)
+        return data_dict
