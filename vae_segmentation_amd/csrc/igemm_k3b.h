@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     // ---- first stage in flight before anything else; the statistics tables meanwhile ----------------------------------
     // XCD-aware walk: consecutive workgroup ids land on different XCDs (8, each with its own L2), so workgroup b starts at
     // tile (b % 8) * (G / 8) + b / 8 — the workgroups of one XCD then work on one contiguous run of tiles at any time and find
-    // their neighbours' halos in that XCD's L2 (G is a multiple of 8 whenever it is >= 8, see k3b_launch)
+    // their neighbours' halos in that XCD's L2 (identity walk when G is not a multiple of 8)
     const int G = (int)gridDim.x;
     int t = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     Coord cur = tile_coord(t), nxt = cur;
@@ -455,8 +455,9 @@ static int k3b_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipS
     static const int per_cu = getenv("VS_K3_WGS_PER_CU") ? atoi(getenv("VS_K3_WGS_PER_CU")) : 4;   // tuning knob
     int wg = 256 * per_cu / (row_tiles < per_cu ? row_tiles : per_cu);
     if (wg < 256) wg = 256;
-    int gx = tiles_total < wg ? tiles_total : wg;
-    if (gx >= 8) gx &= ~7;                               // multiple of the XCD count (kernel: XCD-aware tile walk)
+    // one workgroup per tile while the tiles fit; the persistent cap `wg` is a multiple of 8 (kernel: XCD-aware walk).  Never round a
+    // small grid down to a multiple of 8: the workgroups that then take two tiles double the latency of the whole launch.
+    const int gx = tiles_total < wg ? tiles_total : wg;
     hipLaunchKernelGGL(kern, dim3(gx, row_tiles), dim3(256), lds, stream, p);
     VS_CHECK_LAUNCH();
     return VS_OK;
