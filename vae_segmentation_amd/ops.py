@@ -44,11 +44,19 @@ def _pick_mt(rows16, tiles):
     return 16
 
 
-def _k3_kid(tname, ck, mt, sums=False):
-    """kernel instantiation name of a 3x3x3 launch (mirrors g1_dispatch_k3_* in csrc; rocprof prints the same string)."""
+def _k3_kid(tname, ck, mt, sums=False, geom=None):
+    """kernel instantiation name of a 3x3x3 launch (mirrors g1_dispatch_k3_* / k3b_use_tall in csrc; rocprof prints the same
+    string).  geom = (n, d, h, w) of the convolution's grid."""
     if tname == "float":
         return "k3_kernel<float,%d,%d,0>" % (ck, mt)
-    return "k3b_kernel<%d,%d,0,%s>" % (ck, min(mt, 32), "true" if sums else "false")
+    yt = 4
+    if geom is not None and ck < 32 and mt == 16 and os.environ.get("VS_K3_TALL", "") != "0":
+        n, d, h, w = geom
+        tiles = n * ((d + 3) // 4) * ((h + 3) // 4) * ((w + 15) // 16)
+        tall = n * ((d + 3) // 4) * ((h + 7) // 8) * ((w + 15) // 16)
+        if os.environ.get("VS_K3_TALL", "") == "1" or (tall >= 256 and tiles <= 2048):
+            yt = 8
+    return "k3b_kernel<%d,%d,0,%s,%d>" % (ck, min(mt, 32), "true" if sums else "false", yt)
 
 
 PROFILE_PRIME_US = 80
@@ -336,7 +344,7 @@ def conv_gather(x, xs, wp, bias, m_out, kind, want_stats, real_channels=None):
         rows16 = (m_out + 15) // 16 * 16
         tname = "float" if x.dtype == torch.float32 else "unsigned short"
         if kind == VS_CONV_K3:
-            kid = _k3_kid(tname, ck, _pick_mt(rows16, tiles))
+            kid = _k3_kid(tname, ck, _pick_mt(rows16, tiles), geom=(n, d, h, w))
         else:
             kid = "g1_kernel<%s,%d,%d,%d,0>" % (tname, ck, kind, _pick_mt(rows16, tiles))
         cr = real_channels[0] if real_channels else c
@@ -396,7 +404,7 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
                 tiles = n * ((g.numel() // (n * c) + 255) // 256)
             tname = "float" if x.dtype == torch.float32 else "unsigned short"
             if kind == VS_CONV_K3:
-                kid = _k3_kid(tname, min(gc, 32), _pick_mt((c + 15) // 16 * 16, tiles), sums=True)
+                kid = _k3_kid(tname, min(gc, 32), _pick_mt((c + 15) // 16 * 16, tiles), sums=True, geom=(gn, gd, gh, gw))
             else:
                 kid = "g1_kernel<%s,%d,%d,%d,0>" % (tname, min(gc, 32), kind, _pick_mt((c + 15) // 16 * 16, tiles))
             cr = real_channels[0] if real_channels else gc
