@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--detail", action="store_true", help="print the slowest individual launches (stderr)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="testing aid: every rank uses cuda:0")
+    ap.add_argument("--force-dist", action="store_true", help="testing aid: initialise the process group and run the gradient "
+                    "all-reduce path even with one rank (exercises RCCL on a 1-GPU box)")
     return ap.parse_args()
 
 
@@ -120,8 +122,12 @@ def main():
     if a.share_gpu:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -134,7 +140,7 @@ def main():
     opt = optim.SGD([{"params": joint.Seg.parameters(), "lr": 1e-2}, {"params": joint.Vae.parameters(), "lr": 0.0}],
                     lr=1e-2, momentum=0.9, weight_decay=0.0)
     seg_params = [p for p in joint.Seg.parameters()]
-    sync = ddp.FlatGradSync(seg_params) if world > 1 else None
+    sync = ddp.FlatGradSync(seg_params) if use_dist else None
     if sync is not None:
         sync.broadcast_parameters(0)
 
@@ -172,7 +178,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -182,7 +188,7 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -197,7 +203,7 @@ def main():
             print("timed launches: %.3f ms per step over %d launches" % (tot, len(profiling.LAST_LAUNCHES) // 2), file=sys.stderr)
             for ms, kid, det, nb, fl in profiling.LAST_LAUNCHES[:60]:
                 print("%8.1f us  %-42s %-52s %7.1f GB/s %8.2f TF/s" % (ms * 1e3, kid, det, nb / ms / 1e6, fl / ms / 1e9), file=sys.stderr)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.side, a.cpu_steps)
@@ -216,7 +222,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
