@@ -451,8 +451,8 @@ static int k3b_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipS
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
-    // persistent grid: a few workgroups per CU, each walking a strided slice of the tile list
-    static const int per_cu = getenv("VS_K3_WGS_PER_CU") ? atoi(getenv("VS_K3_WGS_PER_CU")) : 4;   // tuning knob
+    // persistent grid: three workgroups per CU, each walking a strided slice of the tile list
+    static const int per_cu = getenv("VS_K3_WGS_PER_CU") ? atoi(getenv("VS_K3_WGS_PER_CU")) : 3;   // tuning knob (measured: 8->8 @96^3 36.6 / 40.1 / 44.9 / 51.5 us at 3 / 4 / 5 / 6)
     int wg = 256 * per_cu / (row_tiles < per_cu ? row_tiles : per_cu);
     if (wg < 256) wg = 256;
     // one workgroup per tile while the tiles fit; the persistent cap `wg` is a multiple of 8 (kernel: XCD-aware walk).  Never round a
