@@ -172,9 +172,39 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                         for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
                 }
             } else {
-                // wave-uniform tap; KPT k-groups per tap.  The A (weight) fragments come straight from global memory, so the
-                // loop is software-pipelined: fragments for k-group kg+PD are requested while k-group kg is multiplied.
+                // wave-uniform tap; KPT k-groups per tap.
                 constexpr int NK = NTAPS * KPT;
+                if constexpr (NK * (4 + RB) <= 48) {
+                    // Whole chunk in flight: every A and B fragment of the chunk is requested before the first is used, so a chunk
+                    // costs one memory round trip (these layers have few workgroups — 2..100 — and nothing else hides the latency;
+                    // the 32-deep chain of dependent loads made the 3^3 / 6^3 stride-2 convs the slowest launches per FLOP).
+                    u32x4 aq[NK][RB], bq[NK][4];
+#pragma unroll
+                    for (int kg = 0; kg < NK; ++kg) {
+                        const int tap = kg / KPT, kk = kg - tap * KPT;
+                        const int dz = (tap >> 2) & 1, dy = (tap >> 1) & 1, dx = tap & 1;
+                        const long long toff_g = (((long long)dz * p.H + dy) * p.W + dx) * p.C + ch * CK + kk * KG + g * EPL;
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) aq[kg][rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg) bq[kg][cg] = *(const u32x4*)(xin + gofs[cg] + toff_g);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);       // keep the scheduler from sinking the requests back between the MFMAs
+#pragma unroll
+                    for (int kg = 0; kg < NK; ++kg) {
+                        const int cc = (kg % KPT) * KG + g * EPL;
+                        if (HS) {
+#pragma unroll
+                            for (int cg = 0; cg < 4; ++cg) bq[kg][cg] = act_transform<T, CK>(bq[kg][cg], s_mean, s_rstd, ch * CK + cc);
+                        }
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(aq[kg][rb], bq[kg][cg], acc[rb][cg], (T*)nullptr);
+                    }
+                } else {
+                // The A (weight) fragments come straight from global memory, so the
+                // loop is software-pipelined: fragments for k-group kg+PD are requested while k-group kg is multiplied.
                 constexpr int PD = RB <= 2 ? 9 : 3;          // prefetch distance in k-groups (register budget RB*PD*4 VGPRs)
                 u32x4 abuf[PD][RB];
 #pragma unroll
@@ -212,6 +242,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                                 for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
                         }
                     }
+                }
                 }
             }
         }
