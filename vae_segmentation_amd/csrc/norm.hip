@@ -118,24 +118,51 @@ __global__ __launch_bounds__(256) void in_relu_bwd_reduce_kernel(const T* __rest
     double* s_red = (double*)smem;
     __shared__ float s_m[NB_MAX_C], s_r[NB_MAX_C];
     const int n = blockIdx.y;
+    RowIter<T> it(c);
+    const bool act = it.active();
+    const size_t sample = (size_t)n * voxels * c + it.fx * EPL;
+    const long long stride = (long long)gridDim.x * it.rows_per_it;
+    long long v = (long long)blockIdx.x * it.rows_per_it + it.fy;
+    // as in the apply kernel below: UN (g, x) fragment pairs in flight per thread, the first batch requested before the tables
+    constexpr int UN = 4;
+    u32x4 gq[UN], xq[UN];
+    auto request = [&](long long v0) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long long vv = v0 + u * stride;
+            const size_t e = (act && vv < voxels) ? sample + vv * c : sample - it.fx * EPL;
+            gq[u] = *(const u32x4*)(g + e);
+            xq[u] = *(const u32x4*)(x + e);
+        }
+    };
+    request(v);
     load_mean_rstd(xs, n, c, inv_count, eps, s_m, s_r);
     __syncthreads();
-    RowIter<T> it(c);
     double part[EPL][2];
 #pragma unroll
     for (int j = 0; j < EPL; ++j) part[j][0] = part[j][1] = 0.0;
-    if (it.active()) {
-        const size_t sample = (size_t)n * voxels * c + it.fx * EPL;
-        for (long long v = (long long)blockIdx.x * it.rows_per_it + it.fy; v < voxels; v += (long long)gridDim.x * it.rows_per_it) {
-            float fg[EPL], fx_[EPL];
-            frag_unpack(*(const u32x4*)(g + sample + v * c), fg, (T*)nullptr);
-            frag_unpack(*(const u32x4*)(x + sample + v * c), fx_, (T*)nullptr);
+    if (act) {
+        float m[EPL], r[EPL];
 #pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-                const float xh = (fx_[j] - s_m[it.fx * EPL + j]) * s_r[it.fx * EPL + j];
-                const float gm = xh > 0.f ? fg[j] : 0.f;
-                part[j][0] += gm;
-                part[j][1] += (double)gm * xh;
+        for (int j = 0; j < EPL; ++j) { m[j] = s_m[it.fx * EPL + j]; r[j] = s_r[it.fx * EPL + j]; }
+        for (; v < voxels; v += UN * stride) {
+            u32x4 gc[UN], xc[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) { gc[u] = gq[u]; xc[u] = xq[u]; }
+            request(v + UN * stride);
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (v + u * stride >= voxels) break;
+                float fg[EPL], fx_[EPL];
+                frag_unpack(gc[u], fg, (T*)nullptr);
+                frag_unpack(xc[u], fx_, (T*)nullptr);
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) {
+                    const float xh = (fx_[j] - m[j]) * r[j];
+                    const float gm = xh > 0.f ? fg[j] : 0.f;
+                    part[j][0] += gm;
+                    part[j][1] += (double)gm * xh;
+                }
             }
         }
     }
