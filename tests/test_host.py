@@ -41,6 +41,15 @@ def test_argument_validation_without_gpu():
     assert lib.vs_packed_weight_bytes(8, 8, 27, 1) == 1 * 1 * 7 * 64 * 8 * 2
     assert lib.vs_packed_weight_bytes(64, 64, 27, 0) == 4 * 2 * 54 * 64 * 4 * 4
     assert lib.vs_conv_wgrad_workspace_bytes(2, 96, 96, 96, 8, 8, 0) > 0
+    # maximum sizes: shapes the 32-bit offsets of the kernels cannot address are refused (VS_ESHAPE = -2), never mis-computed.
+    # (fake, aligned, never dereferenced pointers: the check precedes every launch)
+    fake = 0x10000
+    assert lib.vs_conv_gather_fwd(fake, None, fake, None, fake, None, 1, 2048, 1024, 1024, 8, 8, 0, 1, 1e-5, None) == -2     # >= 2^31 elements
+    assert lib.vs_conv_gather_fwd(fake, None, fake, None, fake, None, 1, 512, 512, 512, 8, 8, 0, 1, 1e-5, None) == -2        # bf16 3x3x3: >= 2 GiB
+    assert lib.vs_conv_gather_fwd(fake, None, fake, None, fake, None, 1, 5, 5, 5, 8, 8, 1, 1, 1e-5, None) == -2              # stride-2 conv on odd sizes
+    assert lib.vs_conv_gather_fwd(fake, None, fake, None, fake, None, 1, 4, 4, 4, 24, 8, 0, 1, 1e-5, None) == -2             # channel count not 8 / 16 / 32k
+    assert lib.vs_conv_gather_fwd(fake + 4, None, fake, None, fake, None, 1, 4, 4, 4, 8, 8, 0, 1, 1e-5, None) == -5          # VS_EALIGN
+    assert lib.vs_conv_gather_fwd(fake, None, fake, None, fake, None, 0, 4, 4, 4, 8, 8, 0, 1, 1e-5, None) == -2              # empty batch
 
 
 def test_host_helpers():
