@@ -96,6 +96,19 @@ __device__ __forceinline__ void stats_to_mean_rstd(const double* st, double inv_
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// same for the bf16-storage kernels: the cancellation-prone part (variance) stays fp64, the reciprocal square root is v_rsq_f32 plus
+// one Newton step (~1e-7 relative) instead of an fp64 sqrt + divide (~60 dependent instructions in every kernel prologue)
+__device__ __forceinline__ void stats_to_mean_rstd_fast(const double* st, double inv_count, float eps, float& mean, float& rstd) {
+    const double m = st[0] * inv_count;
+    double var = st[1] * inv_count - m * m;
+    if (var < 0.0) var = 0.0;
+    const float v = (float)(var + (double)eps);
+    float r = rsqrtf(v);
+    r = r * (1.5f - 0.5f * v * r * r);
+    mean = (float)m;
+    rstd = r;
+}
+
 // counter-based Bernoulli(keep) for dropout: splitmix64 finaliser of (seed, index) -> uniform in [0,1)
 __device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx) {
     unsigned long long x = idx * 0x9E3779B97F4A7C15ull + seed;

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         double st[2] = {st_pre[0], st_pre[1]};
         if (i != tid) { st[0] = st_src[(size_t)i * 2]; st[1] = st_src[(size_t)i * 2 + 1]; }
         float m, r;
-        stats_to_mean_rstd(st, SUMS ? p.inv_count_out : p.inv_count_in, p.eps, m, r);
+        stats_to_mean_rstd_fast(st, SUMS ? p.inv_count_out : p.inv_count_in, p.eps, m, r);
         if constexpr (SUMS) { s_mkm[i] = m; s_mkr[i] = r; }
         else { s_scale[i] = r; s_shift[i] = -m * r; }
     }
