@@ -87,15 +87,6 @@ int vs_conv_gather_fwd(const void* x, const double* x_stats, const void* w_packe
 int vs_conv_scatter_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                         void* y, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);
 
-/* Backward-data of a 3x3x3 conv whose incoming gradient is still "lazy": g = dL/d relu(InstanceNorm(yl)) as the layer above wrote
- * it, WITHOUT that layer's InstanceNorm+ReLU backward (autograd of joint_model.py:41-48 between two convs of a DoubleConv).  The
- * kernel applies it while staging — rstd*(g*[xh>0] - S1/N - xh*S2/N), xh = (yl-mean)*rstd, from yl, its statistics and the (S1,S2)
- * sums the layer above accumulated — so the separate vs_instnorm_relu_bwd_apply pass over (g, yl) disappears.  Everything else as
- * vs_conv_gather_bwd_data (VS_CONV_K3, VS_BF16 only); mask_x / mask_stats / sums may all be NULL when this conv's own input is not lazy. */
-int vs_conv_gather_bwd_data_lazyg(const void* g, const void* gy_layer_y, const double* gy_layer_stats, const double* gy_layer_sums,
-                                  const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,
-                                  int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);
-
 /* Backward-data forms of the two calls above with the InstanceNorm+ReLU-backward REDUCTION fused into the epilogue:
  * y here is g = dL/da of a lazy activation a = relu(instnorm(mask_x)) (mask_x: raw tensor shaped like y, mask_stats
  * its (sum,sumsq)); besides writing g the kernel ACCUMULATES sums[n][m] = (sum g*[xhat>0], sum g*[xhat>0]*xhat)

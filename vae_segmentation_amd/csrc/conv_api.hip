@@ -30,8 +30,7 @@ static int check_common(const void* x, const void* w, int n, int d, int h, int w
 
 static int gather_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                        void* y, double* y_stats, const void* mask_x, const double* mask_stats, double* sums,
-                       int n, int d, int h, int w, int c_in, int m_out, int kind, int dtype, float eps, void* stream,
-                       const void* lz_y = nullptr, const double* lz_stats = nullptr, const double* lz_sums = nullptr) {
+                       int n, int d, int h, int w, int c_in, int m_out, int kind, int dtype, float eps, void* stream) {
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
     if (!y || m_out <= 0 || m_out % 8 || ((uintptr_t)y & 15)) return VS_EINVAL;
@@ -41,8 +40,6 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = y; p.y_stats = y_stats; p.prob = nullptr;
     p.mask_x = mask_x; p.mask_stats = mask_stats; p.sums = sums;
     if (sums && (!mask_x || !mask_stats || y_stats)) return VS_EINVAL;
-    p.lz_y = lz_y; p.lz_stats = lz_stats; p.lz_sums = lz_sums;
-    if (lz_y && (kind != VS_CONV_K3 || dtype != VS_BF16 || x_stats || !lz_stats || !lz_sums || ((uintptr_t)lz_y & 15))) return VS_EINVAL;
     p.N = n; p.D = d; p.H = h; p.W = w;
     p.C = c_in; p.M = m_out;
     p.rb_total = (m_out + 15) / 16;
@@ -83,14 +80,6 @@ extern "C" int vs_conv_gather_bwd_data(const void* x, const void* w_packed, void
                                        int m_out, int kind, int dtype, float eps, void* stream) {
     if (!mask_x || !mask_stats || !sums) return VS_EINVAL;
     return gather_impl(x, nullptr, w_packed, nullptr, y, nullptr, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, kind, dtype, eps, stream);
-}
-
-extern "C" int vs_conv_gather_bwd_data_lazyg(const void* g, const void* gy_layer_y, const double* gy_layer_stats, const double* gy_layer_sums,
-                                             const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,
-                                             int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream) {
-    if (!gy_layer_y || (sums != nullptr) != (mask_x != nullptr) || (sums != nullptr) != (mask_stats != nullptr)) return VS_EINVAL;
-    return gather_impl(g, nullptr, w_packed, nullptr, y, nullptr, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, VS_CONV_K3, dtype, eps, stream,
-                       gy_layer_y, gy_layer_stats, gy_layer_sums);
 }
 
 static int scatter_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias, void* y,

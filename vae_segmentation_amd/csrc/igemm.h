@@ -40,11 +40,6 @@ struct G1Params {
     int tyn, txn;         // K3 tiling: tiles along y and x
     float eps;
     double inv_count_in;  // 1 / (D*H*W) of the input grid
-    // k3b_kernel, lazy-gradient input (backward-data inside a DoubleConv): x holds g = dL/d relu(IN(y)) as written by the layer above,
-    // still without that layer's InstanceNorm+ReLU backward; it is applied while staging from y, y's statistics and the (S1, S2) sums
-    const void* lz_y;
-    const double* lz_stats;
-    const double* lz_sums;
     unsigned int fd_m[3], fd_s[3];   // k3b_kernel: multiply-shift pairs for / tiles_per_sample, / (txn*tyn), / txn (k3b_launch fills them)
 };
 

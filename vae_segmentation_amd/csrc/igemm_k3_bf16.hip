@@ -9,17 +9,6 @@
 // bf16 3x3x3 convolutions run k3b_kernel with 16- or 32-row tiles (a 64-row weight block does not fit LDS next to the halo
 // tile): a 64-row request from pick_mt() is served as twice as many 32-row workgroups.
 int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s) {
-    if (p.lz_y) {                                           // lazy-gradient input (backward-data inside a DoubleConv)
-        if (epi != EPI_RAW || p.x_stats) return VS_EINVAL;
-        if (mt == 64) { mt = 32; row_tiles *= 2; }
-#define K3B_LZ(CKV, MTV)                                                                                  \
-    if (ck == CKV && mt == MTV)                                                                            \
-        return p.sums ? k3b_launch<CKV, MTV, EPI_RAW, true, 4, true>(p, tiles, row_tiles, s)               \
-                      : k3b_launch<CKV, MTV, EPI_RAW, false, 4, true>(p, tiles, row_tiles, s);
-        K3B_LZ(8, 16) K3B_LZ(8, 32) K3B_LZ(16, 16) K3B_LZ(16, 32) K3B_LZ(32, 16) K3B_LZ(32, 32)
-#undef K3B_LZ
-        return VS_ESHAPE;
-    }
     const bool tall = mt == 16 && ck < 32 && k3b_use_tall(p);
     if (epi == EPI_SOFTMAX2) {
         if (ck == 8 && mt == 16)

@@ -52,18 +52,15 @@ struct K3BGeom {
 
 // register budget: 4 workgroups per CU (one wave per SIMD each) for the small-channel kernels, 2 for the 32-channel chunks
 // SUMS: backward-data use (input = a materialised gradient, no statistics; epilogue accumulates the fused IN-backward sums)
-// LZ (with SUMS): the input gradient is lazy — see G1Params::lz_y — and gets its InstanceNorm+ReLU backward while it is staged:
-// staged = rstd*(g*[xh>0] - S1/N - xh*S2/N), xh = (y-mean)*rstd.  Removes the separate apply pass between two convs of a DoubleConv.
-template <int CK, int MT, int EPI, bool SUMS, int YT = 4, bool LZ = false>
+template <int CK, int MT, int EPI, bool SUMS, int YT = 4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
-    LZ ? (CK == 32 ? 1 : (MT == 32 ? 2 : 3)) : YT == 8 ? 2 : (CK == 32 ? (MT == 32 ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : (CK == 16 && SUMS ? 3 : 4))), 8))) void k3b_kernel(const G1Params p) {
+    YT == 8 ? 2 : (CK == 32 ? (MT == 32 ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : (CK == 16 && SUMS ? 3 : 4))), 8))) void k3b_kernel(const G1Params p) {
     typedef unsigned short T;
     K3_TICK_INIT
     using GEO = K3BGeom<CK, MT, YT>;
     static_assert(YT == 4 || (YT == 8 && CK < 32 && MT == 16), "tall tiles: single-chunk layers, 16 rows");
     constexpr int TV = GEO::TV, PLANE = (YT + 2) * 18;
     static_assert(CK == 8 || CK == 16 || CK == 32, "chunk width");
-    static_assert(!LZ || EPI == EPI_RAW, "lazy-gradient input: backward-data kernels only");
     constexpr int RB = GEO::RB, NKGC = GEO::NKGC, CKB = GEO::CKB, NWF = GEO::NWF;
     constexpr bool SMALLC = GEO::SMALLC;
     constexpr int U = CKB / 16;                          // 16-byte fragments per staged voxel
@@ -79,8 +76,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     float* s_shift = s_scale + p.N * p.C;
     float* s_mkm = s_shift + p.N * p.C;                  // mean / rstd of the mask tensor's channels (fused IN-bwd sums)
     float* s_mkr = s_mkm + p.N * p.M;
-    float* s_nla = SUMS ? s_mkr + p.N * p.M : s_mkm;     // LZ: -rstd*S1/N and -rstd*S2/N of the lazy gradient's layer, [N*C] each
-    float* s_nlb = s_nla + p.N * p.C;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int rb0 = blockIdx.y * RB;
@@ -123,8 +118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         w_off[i] = (rb0 + rb) * (p.nch * NKGC * 64) + r;                                   // + ch * NKGC * 64
     }
 
-    u32x4 xv[NIT], wv[NWI], yv[LZ ? NIT : 1];
-    const i32x4 lzrsrc = make_rsrc(LZ ? p.lz_y : p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.C * 2));
+    u32x4 xv[NIT], wv[NWI];
     unsigned int okbits = 0;
     struct Coord { int n, z0, y0, x0; };
     auto tile_coord = [&](int t) {                        // scalar: t is workgroup-uniform
@@ -151,43 +145,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
             const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             okbits |= ok ? (1u << b) : 0u;
             xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, ok ? base + rel_off[b] : -1, 0, 0));
-            if constexpr (LZ) yv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(lzrsrc, ok ? base + rel_off[b] : -1, 0, 0));
         }
     };
     auto write_x = [&](int n, int ch) {
         f32x2 sc[4], sh[4];
-        if constexpr (LZ) {
-            f32x2 nla[4], nlb[4];
-            const int c0 = n * p.C + ch * CK + part * 8;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sc[i] = *(const f32x2*)(s_scale + c0 + 2 * i);
-                sh[i] = *(const f32x2*)(s_shift + c0 + 2 * i);
-                nla[i] = *(const f32x2*)(s_nla + c0 + 2 * i);
-                nlb[i] = *(const f32x2*)(s_nlb + c0 + 2 * i);
-            }
-#pragma unroll
-            for (int b = 0; b < NIT; ++b) {
-                u32x4 v;
-                const bool ok = (okbits >> b) & 1u;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    f32x2 gg, yy;
-                    gg[0] = __uint_as_float(xv[b][i] << 16); gg[1] = __uint_as_float(xv[b][i] & 0xffff0000u);
-                    yy[0] = __uint_as_float(yv[b][i] << 16); yy[1] = __uint_as_float(yv[b][i] & 0xffff0000u);
-                    const f32x2 xh = yy * sc[i] + sh[i];
-                    f32x2 gm;
-                    gm[0] = xh[0] > 0.f ? gg[0] : 0.f;
-                    gm[1] = xh[1] > 0.f ? gg[1] : 0.f;
-                    const f32x2 o = gm * sc[i] + (xh * nlb[i] + nla[i]);
-                    const unsigned int pk = __builtin_bit_cast(unsigned int, __builtin_convertvector(o, bf16x2));
-                    v[i] = ok ? pk : 0u;                 // zero padding applies to the transformed gradient
-                }
-                const int pw = CK == 32 ? (part ^ (int)(((swzbits >> b) & 1u) << 1)) : part;
-                if (b < NIT - 1 || tid + b * 256 < NU) *(u32x4*)(s_tile + lds_w0 + b * 4096 + pw * 16) = v;
-            }
-            return;
-        }
         if (has_stats) {
             const int c0 = n * p.C + ch * CK + part * 8;
 #pragma unroll
@@ -242,16 +203,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         stats_to_mean_rstd_fast(st, SUMS ? p.inv_count_out : p.inv_count_in, p.eps, m, r);
         if constexpr (SUMS) { s_mkm[i] = m; s_mkr[i] = r; }
         else { s_scale[i] = r; s_shift[i] = -m * r; }
-    }
-    if constexpr (LZ) {
-        for (int i = tid; i < p.N * p.C; i += 256) {
-            float m, r;
-            stats_to_mean_rstd_fast(p.lz_stats + (size_t)i * 2, p.inv_count_in, p.eps, m, r);
-            s_scale[i] = r;
-            s_shift[i] = -m * r;
-            s_nla[i] = -r * (float)(p.lz_sums[(size_t)i * 2 + 0] * p.inv_count_in);
-            s_nlb[i] = -r * (float)(p.lz_sums[(size_t)i * 2 + 1] * p.inv_count_in);
-        }
     }
 
     // ---- LDS read addresses ---------------------------------------------------------------------------------------------
@@ -477,10 +428,10 @@ static inline void k3b_fastdiv(int d, unsigned int& m, unsigned int& s) {
     m = (unsigned int)((((1ull << (32 + s)) + (unsigned long long)d - 1) / (unsigned long long)d) - (1ull << 32));
 }
 
-template <int CK, int MT, int EPI, bool SUMS, int YT = 4, bool LZ = false>
+template <int CK, int MT, int EPI, bool SUMS, int YT = 4>
 static int k3b_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
     using GEO = K3BGeom<CK, MT, YT>;
-    const size_t tables = (size_t)(LZ ? 4 : 2) * p_in.N * p_in.C * sizeof(float) + (p_in.sums ? (size_t)2 * p_in.N * p_in.M * sizeof(float) : 0);
+    const size_t tables = (size_t)2 * p_in.N * p_in.C * sizeof(float) + (p_in.sums ? (size_t)2 * p_in.N * p_in.M * sizeof(float) : 0);
     const size_t lds = K3B_LDS_TILE + (size_t)GEO::TILE_BYTES + GEO::W_BYTES + tables;
     if (lds > 160 * 1024) return VS_ESHAPE;
     G1Params p = p_in;
@@ -495,8 +446,7 @@ static int k3b_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipS
     k3b_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3b_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
     if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr)) return VS_EINVAL;
-    if (LZ != (p.lz_y != nullptr) || (LZ && (!p.lz_stats || !p.lz_sums))) return VS_EINVAL;
-    auto kern = k3b_kernel<CK, MT, EPI, SUMS, YT, LZ>;
+    auto kern = k3b_kernel<CK, MT, EPI, SUMS, YT>;
     // idempotent one-time opt-in to the full 160 KiB of dynamic LDS (not a stream operation)
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -90,16 +90,8 @@ class DoubleConv(nn.Module):
 
     def forward(self, x):
         a, wrapped = _as_act(x, self.kernel_dtype)
-        convs = [self.conv[i] for i in (0, 3, 6)]
-        if a.raw.dtype == torch.bfloat16 and not any(c.weight.requires_grad for c in convs[:-1]):
-            # frozen first two convs (the VAE under joint_train / domain adaptation): one autograd node, lazy gradients inside
-            wb = []
-            for c in convs:
-                wb += [c.weight, c.bias]
-            a = Act(*ops.ConvK3Chain.apply(a.raw, a.stats, *wb))
-        else:
-            for c in convs:
-                a = _conv3(c, a)
+        for i in (0, 3, 6):
+            a = _conv3(self.conv[i], a)
         return _as_tensor(a, self.out_ch) if wrapped else a
 
 

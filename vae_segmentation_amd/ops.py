@@ -534,90 +534,6 @@ class ConvK3(torch.autograd.Function):
         return gx, None, gw, gb
 
 
-def _bwd_data_k3(gy, lazy_g, wpb, x, xs, m_out):
-    """3x3x3 backward-data.  gy is the materialised gradient, or — with lazy_g = (yl, yl_stats, yl_sums) — the lazy one that
-    still lacks the InstanceNorm+ReLU backward of its layer (applied inside the kernel).  With a lazy input (x, xs) of the conv
-    the fused (S1, S2) sums are produced as well.  -> (g, sums or None); nothing is applied to g."""
-    n, d, h, w, gc = gy.shape
-    g = torch.empty((n, d, h, w, m_out), dtype=gy.dtype, device=gy.device)
-    sums = _new_stats(n, m_out, gy.device) if xs is not None else None
-    dt = vs_dtype(gy)
-    if lazy_g is None:
-        if xs is None:
-            g, _ = conv_gather(gy, None, wpb, None, m_out, VS_CONV_K3, False)
-        else:
-            check(lib.vs_conv_gather_bwd_data(gy.data_ptr(), wpb.data_ptr(), g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(),
-                                              n, d, h, w, gc, m_out, VS_CONV_K3, dt, EPS_IN, _stream()), "conv_gather_bwd_data")
-    else:
-        yl, yls, ylsums = lazy_g
-        check(lib.vs_conv_gather_bwd_data_lazyg(gy.data_ptr(), yl.data_ptr(), yls.data_ptr(), ylsums.data_ptr(), wpb.data_ptr(), g.data_ptr(),
-                                                _p(x if xs is not None else None), _p(xs), _p(sums), n, d, h, w, gc, m_out, dt, EPS_IN,
-                                                _stream()), "conv_gather_bwd_data_lazyg")
-    return g, sums
-
-
-class ConvK3Chain(torch.autograd.Function):
-    """A chain of 3x3x3 convs on lazy activations (DoubleConv, joint_model.py:35-52) as ONE autograd node: the gradient between two
-    convs of the chain stays lazy — the backward-data kernel of conv i applies the InstanceNorm+ReLU backward of conv i's output while it
-    stages it (vs_conv_gather_bwd_data_lazyg) — so the per-layer apply passes inside the chain disappear.  bf16 storage; every conv but
-    the last must be frozen (its weight gradient would need the materialised gradient).  Arguments: x, xs, then (weight, bias) per conv."""
-
-    @staticmethod
-    def forward(ctx, x, xs, *wb):
-        weights = wb[0::2]
-        _require_cuda(x, *weights)
-        acts = [(x, xs)]
-        for wgt in weights:
-            a, a_s = acts[-1]
-            wp = pack_weight_cached(wgt, VS_PACK_ROWS_D0, a.shape[-1], a.dtype)
-            acts.append(conv_gather(a, a_s, wp, None, cpad(wgt.shape[0]), VS_CONV_K3, True, real_channels=(wgt.shape[1], wgt.shape[0])))
-        y, ys = acts[-1]
-        flat = []
-        for a, a_s in acts[:-1]:
-            flat += [a, a_s]
-        ctx.save_for_backward(*flat, *weights)
-        ctx.n_conv = len(weights)
-        ctx.xs_none = xs is None
-        ctx.bias_shapes = [None if b is None else b.shape for b in wb[1::2]]
-        ctx.mark_non_differentiable(ys)
-        ctx.set_materialize_grads(False)
-        return y, ys
-
-    @staticmethod
-    def backward(ctx, gy, _gys):
-        k = ctx.n_conv
-        saved = ctx.saved_tensors
-        acts = [(saved[2 * i], saved[2 * i + 1]) for i in range(k)]          # input (raw, stats) of conv i
-        weights = saved[2 * k:]
-        grads = [None, None] + [None] * (2 * k)
-        if gy is None:
-            return tuple(grads)
-        g, lazy = _contig(gy), None                      # gradient w.r.t. conv i's raw output; lazy = (y_i, stats_i, sums_i) when pending
-        for i in range(k - 1, -1, -1):
-            x, xs = acts[i]
-            wgt = weights[i]
-            cout, cin = wgt.shape[0], wgt.shape[1]
-            if ctx.needs_input_grad[2 + 2 * i]:
-                if lazy is not None:
-                    raise RuntimeError("ConvK3Chain: only the last conv of the chain may be trainable")
-                grads[2 + 2 * i], _ = _side_grads(wgt, (g, x, xs), (g, None, x, xs, cout, cin, VS_CONV_K3), None)
-            if ctx.bias_shapes[i] is not None and ctx.needs_input_grad[3 + 2 * i]:
-                grads[3 + 2 * i] = _new_stats(1, (ctx.bias_shapes[i][0] + 1) // 2, g.device, width=1).view(-1).view(torch.float32)[:ctx.bias_shapes[i][0]]
-            if i == 0 and not ctx.needs_input_grad[0]:
-                break
-            wpb = pack_weight_cached(wgt, VS_PACK_ROWS_D1_FLIP, g.shape[-1], g.dtype)
-            gn, sums = _bwd_data_k3(g, lazy, wpb, x, xs, x.shape[-1])
-            g, lazy = gn, ((x, xs, sums) if xs is not None else None)
-        else:
-            if lazy is not None:                         # the chain's own input is lazy: its producer is outside, apply here
-                x, xs, sums = lazy
-                n, c = x.shape[0], x.shape[-1]
-                check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), g.data_ptr(), n,
-                                                     x.numel() // (n * c), c, vs_dtype(x), EPS_IN, _stream()), "instnorm_relu_bwd_apply")
-            grads[0] = g
-        return tuple(grads)
-
-
 class ConvK3Softmax(torch.autograd.Function):
     """out_block (3x3x3 conv, live bias) + Softmax(dim=1) over 2 classes -> planar fp32 probabilities
     (joint_model.py:224-225,265-266 / 366-367,386-388)."""
