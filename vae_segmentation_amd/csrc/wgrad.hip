@@ -7,6 +7,7 @@
 // Each wave accumulates over its share of voxels in registers and writes one partial slab; a second
 // kernel sums the slabs in a fixed order (bitwise reproducible) straight into the reference's
 // [m][c][tap] fp32 layout.
+#include <stdlib.h>
 #include "common.h"
 
 enum { G3_K3 = 0, G3_K2S2 = 1 };
@@ -437,7 +438,8 @@ static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind,
     tyn = (hp + 3) / 4; txn = (wp + 15) / 16;
     tiles_per_sample = ((dp + 3) / 4) * tyn * txn;
     const long long total = (long long)tiles_per_sample * n;
-    long long want = (512 + (long long)mbn * cbn - 1) / ((long long)mbn * cbn);   // ~2 workgroups per CU overall
+    static const long long wg_target = getenv("VS_WGRAD_WGS") ? atoll(getenv("VS_WGRAD_WGS")) : 512;   // tuning knob: ~2 workgroups per CU overall
+    long long want = (wg_target + (long long)mbn * cbn - 1) / ((long long)mbn * cbn);
     // fp32 (parity) mode: at most two tiles per workgroup, so an fp32 MFMA accumulator never chains more than 128
     // products before the fp64 slab reduction
     if (short_chains && (total + 1) / 2 > want) want = (total + 1) / 2;
