@@ -149,7 +149,7 @@ def main():
 
     if a.no_graph:
         from vae_segmentation_amd import ops as _ops
-        _ops.set_overlap(True)
+        _ops.set_overlap(False)
 
         def step():
             for p in seg_params:

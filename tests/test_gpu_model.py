@@ -239,9 +239,11 @@ def test_bf16_mode_joint96_close_to_fp32_reference():
     assert all(np.isfinite(G.flat64(p.grad)).all() for p in joint.Seg.parameters())
 
 
-def test_sgd_step_and_graph_replay_match_eager():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_sgd_step_and_graph_replay_match_eager(overlap):
     """Three SGD(momentum) steps: native multi-tensor kernel vs torch.optim.SGD on the oracle (CPU), then a
-    HIP-graph replayed step against the eager step (bitwise on the loss)."""
+    HIP-graph replayed step against the eager step (bitwise on the loss) — serial graph and with the weight-gradient
+    kernels on the side-stream branch."""
     M, O, T = _mods()
     from vae_segmentation_amd import optim
     side, bs = 32, 2
@@ -265,7 +267,7 @@ def test_sgd_step_and_graph_replay_match_eager():
     ig, lg = img.cuda(), lab.cuda()
     opt_a = optim.SGD(seg_a.parameters(), lr=1e-2, momentum=0.9)
     opt_b = optim.SGD(seg_b.parameters(), lr=1e-2, momentum=0.9)
-    gs = T.GraphedStep(lambda: T.seg_train_losses(seg_b, ig, lg), seg_b.parameters(), opt_b, warmup=1)
+    gs = T.GraphedStep(lambda: T.seg_train_losses(seg_b, ig, lg), seg_b.parameters(), opt_b, warmup=1, overlap=overlap)
     for _ in range(2):
         opt_a.zero_grad()
         la, _ = T.seg_train_losses(seg_a, ig, lg)
@@ -275,6 +277,8 @@ def test_sgd_step_and_graph_replay_match_eager():
         assert abs(la.item() - lb.item()) < 1e-5
     for (n1, p1), (_, p2) in zip(seg_a.named_parameters(), seg_b.named_parameters()):
         assert G.rel_l2(p1.detach().cpu(), p2.detach().cpu()) < 1e-4, n1
+    from vae_segmentation_amd import ops
+    ops.set_overlap(False)
 
 
 # ---- Encoder / Fusion / Joint2 / Embed on the native kernels (goldens: oracle/make_golden.py gold_rank4) ----

@@ -165,6 +165,17 @@ __device__ __forceinline__ u32x4 act8(const u32x4 raw, const f32x2 (&sc)[4], con
     return r;
 }
 
+// Zeroing as a kernel, never hipMemsetAsync: inside a replayed HIP graph a memset node was observed to run out of order with the
+// kernel nodes around it after a host-side D2H copy (second test-time-training case, nondeterministic bias gradients); kernel nodes
+// are ordered.  One workgroup is enough for the few hundred bytes zeroed here.
+__global__ static void vs_zero_kernel(unsigned int* p, long long words) {
+    for (long long i = threadIdx.x; i < words; i += blockDim.x) p[i] = 0u;
+}
+static inline hipError_t vs_zero_async(void* p, size_t bytes, hipStream_t stream) {
+    hipLaunchKernelGGL(vs_zero_kernel, dim3(1), dim3(256), 0, stream, (unsigned int*)p, (long long)(bytes / 4));
+    return hipGetLastError();
+}
+
 #define VS_CHECK_LAUNCH()                                  \
     do {                                                   \
         hipError_t e__ = hipGetLastError();                \

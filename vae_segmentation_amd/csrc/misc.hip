@@ -432,7 +432,7 @@ extern "C" int vs_dice_fwd(const float* s, const float* t, double* sums, float* 
                            int channels, long long voxels, int bot, int top, float eps, void* stream) {
     if (!s || !t || !sums || batch <= 0 || batch > 64 || channels <= 0 || voxels <= 0 || bot < 0 || top > channels || bot >= top) return VS_EINVAL;
     if (((uintptr_t)s & 15) || ((uintptr_t)t & 15) || (voxels & 3)) return VS_EALIGN;
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 3 * batch * channels, (hipStream_t)stream);
+    hipError_t e = vs_zero_async(sums, sizeof(double) * 3 * batch * channels, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     long long blocks = (voxels / 4 + 256 * 8 - 1) / (256 * 8);
     if (blocks < 1) blocks = 1;
@@ -502,7 +502,7 @@ __global__ void bce_bwd_kernel(const float* __restrict__ p, const float* __restr
 }
 extern "C" int vs_bce_fwd(const float* p, const float* t, float* out, double* scratch, long long count, void* stream) {
     if (!p || !t || !out || !scratch || count <= 0) return VS_EINVAL;
-    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double), (hipStream_t)stream);
+    hipError_t e = vs_zero_async(scratch, sizeof(double), (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     long long blocks = (count + 256 * 16 - 1) / (256 * 16);
     if (blocks > 1024) blocks = 1024;

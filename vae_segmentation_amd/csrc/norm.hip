@@ -346,7 +346,7 @@ extern "C" int vs_bias_grad(const void* g, float* db, long long rows, int c_ch, 
     int rc = check_cl(g, 1, rows, c_ch, dtype);
     if (rc) return rc;
     if (!db || c_real <= 0 || c_real > c_ch) return VS_EINVAL;
-    hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * c_real, (hipStream_t)stream);
+    hipError_t e = vs_zero_async(db, sizeof(float) * c_real, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     dim3 grid(row_blocks(rows, c_ch, dtype));
     DISPATCH_T(dtype,

@@ -213,7 +213,7 @@ def run(args, side="source"):
     sync = ddp.FlatGradSync(params) if world > 1 else None
     if sync is not None:
         sync.broadcast_parameters(0)
-    ops.set_overlap(True)
+    ops.set_overlap(False)          # serial launch order: measured 1-2 % faster than the side-stream branch (train.GraphedStep)
 
     runner = None
     if method == "domain_adaptation" and getattr(args, "val_finetune", 0) and rank == 0:
