@@ -117,6 +117,26 @@ size_t vs_conv_wgrad_workspace_bytes(int n, int dp, int hp, int wp, int m_ch, in
 int vs_conv_wgrad(const void* p, const double* p_stats, const void* q, const double* q_stats, float* dw,
                   void* workspace, size_t workspace_bytes, int n, int dp, int hp, int wp, int m_ch, int c_ch,
                   int m_real, int c_real, int kind, int dtype, float eps, void* stream);
+/* The weight (and bias) gradients of MANY conv layers in a handful of launches.  They are leaves of backward — nothing in
+ * the pass reads them (the optimiser step of main_source.py:660-661 does, after backward) — so the host side collects one
+ * descriptor per layer while autograd walks the graph and issues them together when the pass ends: layers of the same
+ * kernel instantiation share one grid, all slab reductions share one.  Per layer the arguments mean what they mean in
+ * vs_conv_wgrad; bias_g != NULL additionally requests db[c] = sum over bias_rows of bias_g[bias_rows][bias_c_ch],
+ * c < bias_c_real (fixed summation order: bitwise reproducible, unlike vs_bias_grad's float atomics).
+ * workspace: vs_conv_wgrad_multi_workspace_bytes() bytes for the same (descs, count, dtype), contents undefined. */
+typedef struct vs_wgrad_desc {
+    const void* p; const double* p_stats;
+    const void* q; const double* q_stats;
+    float* dw;
+    const void* bias_g; float* db;
+    long long bias_rows;
+    int bias_c_ch, bias_c_real;
+    int n, dp, hp, wp, m_ch, c_ch, m_real, c_real, kind;
+    int reserved_;
+} vs_wgrad_desc;
+size_t vs_conv_wgrad_multi_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype);
+int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
+                        float eps, void* stream);
 /* db[c] = sum over rows of g[rows][c_ch], c < c_real (bias gradient of a conv whose bias is live). */
 int vs_bias_grad(const void* g, float* db, long long rows, int c_ch, int c_real, int dtype, void* stream);
 

@@ -367,3 +367,85 @@ def test_segmentation_and_vae_with_dropout_run_and_stay_normalised():
     vae = O.deterministic_fill_(M.VAE(2, 2, norm_type=1, dim=128, spatial=64), seed=0).cuda()
     r, m, s = vae(O.one_hot(O.synthetic_label(1, 64, 3)).cuda(), dropout=0.1)
     assert float((r.sum(1) - 1).abs().max()) < 1e-5 and torch.isfinite(r).all()
+
+
+GROUP_LAYERS = [  # (kind, N, Cin, Cout, D, H, W) — one backward pass over all of them: every (CB, KIND) bucket of the grouped weight-gradient
+    # launch gets several layers of different sizes, more than G3_GROUP_MAX (16) in the largest bucket
+    ("k3", 2, 16, 16, 12, 12, 20), ("k3", 2, 32, 32, 6, 6, 6), ("k3", 2, 64, 32, 5, 4, 7), ("k3", 2, 32, 64, 3, 3, 3),
+    ("k3", 2, 128, 128, 3, 3, 3), ("k3", 2, 16, 8, 9, 16, 33), ("k3", 2, 8, 8, 16, 16, 32), ("k3", 2, 8, 16, 7, 9, 18),
+    ("k3", 2, 1, 8, 8, 8, 16), ("k3", 2, 16, 32, 8, 8, 8), ("k3", 2, 32, 16, 8, 8, 8), ("k3", 2, 64, 64, 4, 4, 4),
+    ("k3", 2, 16, 16, 4, 4, 4), ("k3", 2, 16, 16, 5, 5, 5), ("k3", 2, 16, 16, 6, 6, 6), ("k3", 2, 32, 32, 4, 4, 4),
+    ("k3", 2, 32, 32, 5, 5, 5), ("k3", 2, 64, 64, 3, 3, 3), ("k3", 2, 64, 64, 5, 5, 5), ("k3", 2, 128, 64, 3, 3, 3),
+    ("k3", 2, 256, 256, 2, 2, 2), ("k3", 2, 16, 16, 20, 24, 40),
+    ("k2", 2, 8, 8, 8, 8, 16), ("k2", 2, 16, 16, 4, 6, 10), ("k2", 2, 64, 64, 2, 2, 6), ("k2", 2, 32, 32, 6, 6, 6),
+    ("t2", 2, 16, 16, 4, 4, 8), ("t2", 2, 32, 32, 3, 5, 7), ("t2", 2, 128, 128, 3, 3, 3), ("t2", 2, 8, 8, 4, 4, 4),
+]
+
+
+def _group_layers_backward(ops, dtype):
+    """-> (list of (weight grad, bias grad or None) on the GPU, list of CPU references)"""
+    outs, refs, total = [], [], None
+    for i, (kind, n, cin, cout, d, h, w) in enumerate(GROUP_LAYERS):
+        x = rnd(n, cin, d, h, w, seed=10 + i)
+        xq = q(x, dtype)
+        a = in_relu(xq)
+        x_cl = to_cl(x, ops.cpad(cin), dtype)
+        xs = ops.instnorm_stats(x_cl)
+        if kind == "k3":
+            wt = q(rnd(cout, cin, 3, 3, 3, seed=40 + i, scale=(3.0 / (27 * cin)) ** 0.5), dtype).requires_grad_(True)
+            y_ref = F.conv3d(a, wt, None, padding=1)
+            gy = rnd(*y_ref.shape, seed=70 + i)
+            w_gpu, b_gpu = wt.detach().cuda().requires_grad_(True), None
+            y, _ = ops.ConvK3.apply(x_cl, xs, w_gpu, None)
+        elif kind == "k2":
+            wt = q(rnd(cout, cin, 2, 2, 2, seed=40 + i, scale=(3.0 / (8 * cin)) ** 0.5), dtype).requires_grad_(True)
+            bt = rnd(cout, seed=90 + i).requires_grad_(True)
+            y_ref = F.conv3d(a, wt, bt, stride=2)
+            gy = rnd(*y_ref.shape, seed=70 + i)
+            w_gpu, b_gpu = wt.detach().cuda().requires_grad_(True), bt.detach().cuda().requires_grad_(True)
+            y = ops.ConvK2S2.apply(x_cl, xs, w_gpu, b_gpu)
+        else:
+            wt = q(rnd(cin, cout, 2, 2, 2, seed=40 + i, scale=(3.0 / (8 * cin)) ** 0.5), dtype).requires_grad_(True)
+            bt = rnd(cout, seed=90 + i).requires_grad_(True)
+            y_ref = F.conv_transpose3d(a, wt, bt, stride=2)
+            gy = rnd(*y_ref.shape, seed=70 + i)
+            w_gpu, b_gpu = wt.detach().cuda().requires_grad_(True), bt.detach().cuda().requires_grad_(True)
+            y = ops.ConvT2S2.apply(x_cl, xs, w_gpu, b_gpu)
+        gq = q(gy, dtype)
+        (y_ref * gq).sum().backward()
+        refs.append((wt.grad.clone(), None if kind == "k3" else bt.grad.clone()))
+        term = (y.float() * to_cl(gy, ops.cpad(cout), dtype).float()).sum()
+        total = term if total is None else total + term
+        outs.append((w_gpu, b_gpu))
+    total.backward()                              # ONE pass: the engine callback at its end issues the grouped launches
+    torch.cuda.synchronize()
+    return [(wg.grad.clone(), None if bg is None else bg.grad.clone()) for wg, bg in outs], refs
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_grouped_weight_gradients_many_layers(dtype):
+    """vs_conv_wgrad_multi (main_source.py:660: the gradients the optimiser step reads): 30 layers of all conv kinds deferred to the end of ONE
+    backward pass and issued as grouped launches — each against F.conv3d / F.conv_transpose3d autograd on the CPU, against the
+    per-layer launches (vs_conv_wgrad), and bitwise reproducible."""
+    ops = _ops()
+    assert ops._GROUP["enabled"]
+    got, refs = _group_layers_backward(ops, dtype)
+    tol = TOL[dtype] * 4
+    for (gw, gb), (rw, rb), case in zip(got, refs, GROUP_LAYERS):
+        assert relerr(gw.cpu(), rw) < tol, case
+        if rb is not None:
+            assert relerr(gb.cpu(), rb) < tol, case
+    again, _ = _group_layers_backward(ops, dtype)
+    for (gw, gb), (aw, ab) in zip(got, again):
+        assert torch.equal(gw, aw)
+        if gb is not None and dtype == torch.bfloat16:     # fp32 mode keeps vs_bias_grad (float atomics)
+            assert torch.equal(gb, ab)
+    ops.set_wgrad_grouping(False)
+    try:
+        single, _ = _group_layers_backward(ops, dtype)
+    finally:
+        ops.set_wgrad_grouping(True)
+    for (gw, gb), (sw, sb), case in zip(got, single, GROUP_LAYERS):
+        assert relerr(gw, sw) < 2e-6, case
+        if gb is not None:
+            assert relerr(gb, sb) < 1e-5, case

@@ -61,7 +61,7 @@ __device__ __forceinline__ void g3_finish(f32x4 (&acc)[NCB], float* s_buf, float
 }
 
 template <typename T, int CB, int KIND>
-__global__ __launch_bounds__(256) void g3_kernel(const G3Params p) {
+__device__ __forceinline__ void g3_body(const G3Params& p, const int bx, const int ks) {
     using GEO = G3Geo<CB, KIND>;
     constexpr int NTAPS = GEO::NTAPS, NCB = GEO::NCB, QY = GEO::QY, QX = GEO::QX, QV = GEO::QV;
     constexpr int EPL = ET<T>::EPL;
@@ -74,8 +74,7 @@ __global__ __launch_bounds__(256) void g3_kernel(const G3Params p) {
     float* s_q = (float*)(smem + G3_LDS_Q);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
-    const int mb = blockIdx.x / p.cbn, cb = blockIdx.x - mb * p.cbn;
-    const int ks = blockIdx.y;
+    const int mb = bx / p.cbn, cb = bx - mb * p.cbn;
     const T* __restrict__ Pp = (const T*)p.P;
     const T* __restrict__ Qp = (const T*)p.Q;
     const bool p_stats = p.P_stats != nullptr, q_stats = p.Q_stats != nullptr;
@@ -184,8 +183,11 @@ __global__ __launch_bounds__(256) void g3_kernel(const G3Params p) {
     }
 
     const size_t slab_elems = (size_t)p.mbn * p.cbn * NCB * 256;
-    g3_finish<NCB>(acc, s_p, p.ws + (size_t)ks * slab_elems + ((size_t)blockIdx.x * NCB) * 256, wave, col, g);
+    g3_finish<NCB>(acc, s_p, p.ws + (size_t)ks * slab_elems + ((size_t)bx * NCB) * 256, wave, col, g);
 }
+
+template <typename T, int CB, int KIND>
+__global__ __launch_bounds__(256) void g3_kernel(const G3Params p) { g3_body<T, CB, KIND>(p, blockIdx.x, blockIdx.y); }
 
 // ---------------------------------------------------------------------------------------------------
 // bf16 storage: the same GEMM on v_mfma_f32_16x16x32_bf16.  The MFMA wants 8 consecutive k (= voxels) per lane
@@ -213,7 +215,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* s_base, int off0, int off1
 // no branches) right after tile t went to LDS, so their latency is covered by tile t's MFMA phase; the lazy operands'
 // normalise+ReLU runs as packed fma / packed max (common.h act8).
 template <int CB, int KIND>
-__global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) {
+__device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const int ks) {
     using GEO = G3Geo<CB, KIND>;
     constexpr int NTAPS = GEO::NTAPS, NCB = GEO::NCB, QY = GEO::QY, QX = GEO::QX, QV = GEO::QV;
     constexpr int QROW = CB * 2;                 // bytes per Q-tile voxel
@@ -230,8 +232,7 @@ __global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int q4 = col >> 2, p4 = col & 3;       // tr-read addressing: this lane supplies row q4, columns 4*p4..4*p4+3
-    const int mb = blockIdx.x / p.cbn, cb = blockIdx.x - mb * p.cbn;
-    const int ks = blockIdx.y;
+    const int mb = bx / p.cbn, cb = bx - mb * p.cbn;
     const bool p_stats = p.P_stats != nullptr, q_stats = p.Q_stats != nullptr;
     const i32x4 prsrc = make_rsrc(p.P, (unsigned int)((long long)p.N * p.Dp * p.Hp * p.Wp * p.Mch * 2));
     const i32x4 qrsrc = make_rsrc(p.Q, (unsigned int)((long long)p.N * p.Dq * p.Hq * p.Wq * p.Cch * 2));
@@ -383,7 +384,34 @@ __global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) {
     }
 
     const size_t slab_elems = (size_t)p.mbn * p.cbn * NCB * 256;
-    g3_finish<NCB>(acc, (float*)s_p, p.ws + (size_t)ks * slab_elems + ((size_t)blockIdx.x * NCB) * 256, wave, col, g);
+    g3_finish<NCB>(acc, (float*)s_p, p.ws + (size_t)ks * slab_elems + ((size_t)bx * NCB) * 256, wave, col, g);
+}
+
+template <int CB, int KIND>
+__global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) { g3b_body<CB, KIND>(p, blockIdx.x, blockIdx.y); }
+
+// Grouped launch: the weight gradients of up to G3_GROUP_MAX layers of one (CB, KIND) instantiation in ONE grid.  Weight
+// gradients are leaves of backward, so the host defers them to the end of the pass and issues them together: the small
+// layers (tens of workgroups each, start-up bound) then share the chip instead of queueing behind one another.
+// Workgroup b belongs to layer l with wg_start[l] <= b < wg_start[l+1]; inside the layer it is (pair, k-split) as in g3b_kernel.
+#define G3_GROUP_MAX 24
+struct G3Group {
+    G3Params p[G3_GROUP_MAX];
+    int wg_start[G3_GROUP_MAX + 1];
+    int n;
+};
+
+template <int CB, int KIND>
+__global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
+    const int b = blockIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < G3_GROUP_MAX; ++i) l += (i < grp.n && b >= grp.wg_start[i]) ? 1 : 0;
+    const G3Params p = grp.p[l];
+    const int local = b - grp.wg_start[l];
+    const int pairs = p.mbn * p.cbn;
+    const int ks = local / pairs;
+    g3b_body<CB, KIND>(p, local - ks * pairs, ks);
 }
 
 // Sum the partial slabs (fixed order, fp64) into the reference's [m][c][tap] layout.  A block = 64 consecutive slab
@@ -530,3 +558,352 @@ extern "C" int vs_conv_wgrad(const void* P, const double* p_stats, const void* Q
     return cbsz == 16 ? g3b_run<16, G3_K2S2>(p, dw, m_real, c_real, st) : g3b_run<8, G3_K2S2>(p, dw, m_real, c_real, st);
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Grouped path (vs_conv_wgrad_multi): see include/vaeseg.h.
+// ---------------------------------------------------------------------------------------------------
+#include <algorithm>
+#include <vector>
+
+// One reduce launch for every layer: weight slabs (kind 0, runtime geometry of g3_reduce_kernel) and bias partials (kind 1).
+struct G3RedDesc {
+    const float* ws; float* dw;
+    int m_real, c_real, mbn, cbn, nslabs, cb, ntaps, ncb;
+    int kind, parts;         // parts: slab partitions summed in parallel (power of two <= 16); a block covers 64 * 16 / parts elements
+};
+#define G3_RED_MAX 40
+struct G3RedGroup {
+    G3RedDesc d[G3_RED_MAX];
+    int blk_start[G3_RED_MAX + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(1024) void g3_reduce_group_kernel(const G3RedGroup grp) {
+    __shared__ double red[16][64];
+    const int b = blockIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < G3_RED_MAX; ++i) l += (i < grp.n && b >= grp.blk_start[i]) ? 1 : 0;
+    const G3RedDesc d = grp.d[l];
+    const int lb = b - grp.blk_start[l];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    if (d.kind == 1) {                            // bias partials: double [nslabs][c_real]
+        const double* src = (const double*)d.ws;
+        const int c = lb * 64 + lane;
+        double s = 0.0;
+        if (c < d.c_real) {
+            int sl = part;
+            for (; sl + 112 < d.nslabs; sl += 128) {      // 8 loads in flight
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(sl + 16 * j) * d.c_real + c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[j];
+            }
+            for (; sl < d.nslabs; sl += 16) s += src[(size_t)sl * d.c_real + c];
+        }
+        red[part][lane] = s;
+        __syncthreads();
+        if (part == 0 && c < d.c_real) {
+            double tot = 0.0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) tot += red[q][lane];
+            d.dw[c] = (float)tot;
+        }
+        return;
+    }
+    // weight slabs: the 16 rows of the block are (element group, slab partition) pairs — a layer with one slab (deep layers
+    // of a grouped launch) spends no threads on partitions it does not have
+    const int parts = d.parts, egrp = part / parts, sp = part - egrp * parts;
+    const size_t slab_elems = (size_t)d.mbn * d.cbn * d.ncb * 256;
+    const size_t e = ((size_t)lb * (16 / parts) + egrp) * 64 + lane;
+    double s = 0.0;
+    if (e < slab_elems) {
+        const float* src = d.ws + e;
+        int sl = sp;
+        for (; sl + 7 * parts < d.nslabs; sl += 8 * parts) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(sl + parts * j) * slab_elems];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (double)v[j];
+        }
+        for (; sl < d.nslabs; sl += parts) s += (double)src[(size_t)sl * slab_elems];
+    }
+    red[part][lane] = s;
+    __syncthreads();
+    if (sp == 0 && e < slab_elems) {
+        double tot = 0.0;
+        for (int q = 0; q < parts; ++q) tot += red[egrp * parts + q][lane];
+        const int row = (int)(e & 15), col = (int)((e >> 4) & 15);
+        const int k = (int)((e >> 8) % d.ncb);
+        const int pair = (int)(e / ((size_t)d.ncb * 256));
+        const int mb = pair / d.cbn, cb = pair - mb * d.cbn;
+        const int m = mb * 16 + row;
+        int c, tap;
+        if (d.cb == 16) { c = cb * 16 + col; tap = k; }
+        else { c = cb * 8 + (col & 7); tap = 2 * k + (col >> 3); }
+        if (m < d.m_real && c < d.c_real && tap < d.ntaps) d.dw[((size_t)m * d.c_real + c) * d.ntaps + tap] = (float)tot;
+    }
+}
+
+// Bias-gradient partials of several layers in one launch (bf16 rows of c_ch channels): block lb of a layer sums rows
+// lb*rpi + fy + i*nblk*rpi and writes one double per channel; the grouped reduce adds the blocks in a fixed order.
+struct G3BiasDesc { const unsigned short* g; double* part; long long rows; int c_ch, c_real, nblk, pad_; };
+#define G3_BIAS_MAX 16
+struct G3BiasGroup {
+    G3BiasDesc d[G3_BIAS_MAX];
+    int blk_start[G3_BIAS_MAX + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void bias_partial_group_kernel(const G3BiasGroup grp) {
+    __shared__ float s_red[256 * 8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < G3_BIAS_MAX; ++i) l += (i < grp.n && b >= grp.blk_start[i]) ? 1 : 0;
+    const G3BiasDesc d = grp.d[l];
+    const int lb = b - grp.blk_start[l];
+    const int frags = d.c_ch >> 3, fx = tid % frags, fy = tid / frags, rpi = 256 / frags;
+    float part[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[j] = 0.f;
+    for (long long v = (long long)lb * rpi + fy; v < d.rows; v += (long long)d.nblk * rpi) {
+        float f[8];
+        frag_unpack(*(const u32x4*)(d.g + v * d.c_ch + fx * 8), f, (unsigned short*)nullptr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = part[j];
+    __syncthreads();
+    for (int ch = tid; ch < d.c_real; ch += 256) {
+        const int cx = ch >> 3, j = ch & 7;
+        double tot = 0.0;
+        for (int y = 0; y < rpi; ++y) tot += (double)s_red[(y * frags + cx) * 8 + j];
+        d.part[(size_t)lb * d.c_real + ch] = tot;
+    }
+}
+
+namespace {
+struct MultiLayer {
+    G3Params p;
+    int cbsz, ncb, kind, m_real, c_real;
+    float* dw;
+    size_t ws_off;           // byte offset of this layer's slabs
+    long long work;          // tiles per workgroup (sort key)
+    // bias
+    int bias_nblk;
+    size_t bias_off;
+};
+struct MultiPlan {
+    std::vector<MultiLayer> layers;
+    size_t bytes = 0;
+};
+
+static int multi_validate(const vs_wgrad_desc& d) {
+    if (!d.p || !d.q || !d.dw) return VS_EINVAL;
+    if (d.n <= 0 || d.n > G3_MAXN || d.dp <= 0 || d.hp <= 0 || d.wp <= 0) return VS_ESHAPE;
+    if (d.m_ch % 8 || d.c_ch % 8 || d.m_real > d.m_ch || d.c_real > d.c_ch || d.m_real <= 0 || d.c_real <= 0) return VS_ESHAPE;
+    if (d.kind != VS_CONV_K3 && d.kind != VS_CONV_K2S2) return VS_EINVAL;
+    if (d.bias_g) {
+        if (!d.db || d.bias_rows <= 0 || d.bias_c_real <= 0 || d.bias_c_real > d.bias_c_ch) return VS_EINVAL;
+        if (d.bias_c_ch <= 0 || d.bias_c_ch % 8 || d.bias_c_ch > 2048 || 256 % (d.bias_c_ch / 8)) return VS_ESHAPE;
+    }
+    return VS_OK;
+}
+
+// bf16 plan: every layer gets its own slab region; k-splits are chosen per (CB, KIND) bucket so that the bucket's ONE grid has
+// about `target` workgroups of about equal tile counts.
+static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPlan& plan) {
+    static const long long target = getenv("VS_WGRAD_GROUP_WGS") ? atoll(getenv("VS_WGRAD_GROUP_WGS")) : 512;     // measured best of 384..2560 (two workgroups per CU are resident)
+    plan.layers.resize(count);
+    long long bucket_work[4] = {0, 0, 0, 0};
+    for (int i = 0; i < count; ++i) {
+        const vs_wgrad_desc& d = descs[i];
+        int rc = multi_validate(d);
+        if (rc) return rc;
+        MultiLayer& L = plan.layers[i];
+        G3Params& p = L.p;
+        p = G3Params{};
+        int ks_unused;
+        g3_plan(d.n, d.dp, d.hp, d.wp, d.m_ch, d.c_ch, d.kind, L.cbsz, p.mbn, p.cbn, L.ncb, p.tiles_per_sample, p.tyn, p.txn, ks_unused, false);
+        p.P = d.p; p.P_stats = d.p_stats; p.Q = d.q; p.Q_stats = d.q_stats;
+        p.N = d.n; p.Dp = d.dp; p.Hp = d.hp; p.Wp = d.wp;
+        const int s = d.kind == VS_CONV_K3 ? 1 : 2;
+        p.Dq = d.dp * s; p.Hq = d.hp * s; p.Wq = d.wp * s;
+        p.Mch = d.m_ch; p.Cch = d.c_ch;
+        p.total_tiles = p.tiles_per_sample * d.n;
+        p.eps = eps;
+        p.inv_cnt_p = 1.0 / ((double)d.dp * d.hp * d.wp);
+        p.inv_cnt_q = 1.0 / ((double)p.Dq * p.Hq * p.Wq);
+        if ((long long)d.n * d.dp * d.hp * d.wp * d.m_ch * 2 >= 2147483648ll || (long long)d.n * p.Dq * p.Hq * p.Wq * d.c_ch * 2 >= 2147483648ll) return VS_ESHAPE;
+        L.kind = d.kind; L.m_real = d.m_real; L.c_real = d.c_real; L.dw = d.dw;
+        bucket_work[(L.cbsz == 16 ? 0 : 1) + (d.kind == VS_CONV_K3 ? 0 : 2)] += (long long)p.mbn * p.cbn * p.total_tiles;
+    }
+    size_t off = 0;
+    for (int i = 0; i < count; ++i) {
+        MultiLayer& L = plan.layers[i];
+        G3Params& p = L.p;
+        const long long w = bucket_work[(L.cbsz == 16 ? 0 : 1) + (L.kind == VS_CONV_K3 ? 0 : 2)];
+        long long tpw = (w + target - 1) / target;            // tiles per workgroup
+        if (tpw < 1) tpw = 1;
+        long long ks = (p.total_tiles + tpw - 1) / tpw;
+        const double slab_bytes = (double)p.mbn * p.cbn * L.ncb * 256 * 4;
+        while (ks > 1 && ks * slab_bytes > 64.0 * 1024 * 1024) --ks;
+        p.ksplit = (int)ks;
+        L.work = (p.total_tiles + ks - 1) / ks;
+        L.ws_off = off;
+        off += (size_t)ks * p.mbn * p.cbn * L.ncb * 256 * 4;
+        const vs_wgrad_desc& d = descs[i];
+        L.bias_nblk = 0; L.bias_off = 0;
+        if (d.bias_g) {
+            const int rpi = 256 / (d.bias_c_ch / 8);
+            long long nb = (d.bias_rows + (long long)rpi * 32 - 1) / ((long long)rpi * 32);
+            L.bias_nblk = (int)std::min<long long>(std::max<long long>(nb, 1), 256);     // <= 2 rounds of the reduce's 16 x 8 loads
+            L.bias_off = off;
+            off += ((size_t)L.bias_nblk * d.bias_c_real * sizeof(double) + 255) / 256 * 256;
+        }
+    }
+    plan.bytes = off;
+    return VS_OK;
+}
+
+template <int CB, int KIND>
+static int g3b_group_run(const G3Group& grp, hipStream_t s) {
+    using GEO = G3Geo<CB, KIND>;
+    constexpr size_t lds = G3B_LDS_Q + (size_t)GEO::QV * CB * 2;
+    auto kern = g3b_group_kernel<CB, KIND>;
+    if (lds > 64 * 1024) {
+        static const hipError_t attr_err =
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr_err != hipSuccess) return (int)attr_err;
+    }
+    hipLaunchKernelGGL(kern, dim3(grp.wg_start[grp.n]), dim3(256), lds, s, grp);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+}  // namespace
+
+extern "C" size_t vs_conv_wgrad_multi_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype) {
+    if (!descs || count <= 0) return 0;
+    if (dtype == VS_F32) {                        // serial per-layer launches share one region
+        size_t mx = 0;
+        for (int i = 0; i < count; ++i)
+            mx = std::max(mx, vs_conv_wgrad_workspace_bytes(descs[i].n, descs[i].dp, descs[i].hp, descs[i].wp, descs[i].m_ch, descs[i].c_ch, descs[i].kind));
+        return mx;
+    }
+    MultiPlan plan;
+    if (multi_plan(descs, count, 0.f, plan)) return 0;
+    return plan.bytes;
+}
+
+extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
+                                   float eps, void* stream) {
+    if (!descs || count <= 0 || !workspace) return VS_EINVAL;
+    if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VS_F32) {
+        // parity mode is not launch-bound: the per-layer kernels, one after the other on the same stream
+        for (int i = 0; i < count; ++i) {
+            const vs_wgrad_desc& d = descs[i];
+            int rc = multi_validate(d);
+            if (rc) return rc;
+            rc = vs_conv_wgrad(d.p, d.p_stats, d.q, d.q_stats, d.dw, workspace, workspace_bytes, d.n, d.dp, d.hp, d.wp, d.m_ch, d.c_ch,
+                               d.m_real, d.c_real, d.kind, dtype, eps, stream);
+            if (rc) return rc;
+            if (d.bias_g) {
+                rc = vs_bias_grad(d.bias_g, d.db, d.bias_rows, d.bias_c_ch, d.bias_c_real, dtype, stream);
+                if (rc) return rc;
+            }
+        }
+        return VS_OK;
+    }
+    MultiPlan plan;
+    int rc = multi_plan(descs, count, eps, plan);
+    if (rc) return rc;
+    if (workspace_bytes < plan.bytes) return VS_EWORKSPACE;
+    if ((uintptr_t)workspace % 16) return VS_EINVAL;
+    char* ws = (char*)workspace;
+
+    // ---- the four (CB, KIND) buckets, heaviest workgroups first, G3_GROUP_MAX layers per grid ----
+    for (int bucket = 0; bucket < 4; ++bucket) {
+        const int cbsz = (bucket & 1) ? 8 : 16, kind = (bucket & 2) ? VS_CONV_K2S2 : VS_CONV_K3;
+        std::vector<int> idx;
+        for (int i = 0; i < count; ++i)
+            if (plan.layers[i].cbsz == cbsz && plan.layers[i].kind == kind) idx.push_back(i);
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return plan.layers[a].work > plan.layers[b].work; });
+        for (size_t at = 0; at < idx.size(); at += G3_GROUP_MAX) {
+            G3Group grp{};
+            grp.n = (int)std::min<size_t>(G3_GROUP_MAX, idx.size() - at);
+            long long wg = 0;
+            for (int j = 0; j < grp.n; ++j) {
+                MultiLayer& L = plan.layers[idx[at + j]];
+                grp.p[j] = L.p;
+                grp.p[j].ws = (float*)(ws + L.ws_off);
+                grp.wg_start[j] = (int)wg;
+                wg += (long long)L.p.mbn * L.p.cbn * L.p.ksplit;
+            }
+            if (wg >= 2147483647ll) return VS_ESHAPE;
+            for (int j = grp.n; j <= G3_GROUP_MAX; ++j) grp.wg_start[j] = (int)wg;
+            if (kind == VS_CONV_K3) rc = cbsz == 16 ? g3b_group_run<16, G3_K3>(grp, st) : g3b_group_run<8, G3_K3>(grp, st);
+            else rc = cbsz == 16 ? g3b_group_run<16, G3_K2S2>(grp, st) : g3b_group_run<8, G3_K2S2>(grp, st);
+            if (rc) return rc;
+        }
+    }
+    // ---- bias partials ----
+    {
+        std::vector<int> idx;
+        for (int i = 0; i < count; ++i) if (descs[i].bias_g) idx.push_back(i);
+        for (size_t at = 0; at < idx.size(); at += G3_BIAS_MAX) {
+            G3BiasGroup grp{};
+            grp.n = (int)std::min<size_t>(G3_BIAS_MAX, idx.size() - at);
+            int blk = 0;
+            for (int j = 0; j < grp.n; ++j) {
+                const int i = idx[at + j];
+                const vs_wgrad_desc& d = descs[i];
+                grp.d[j] = G3BiasDesc{(const unsigned short*)d.bias_g, (double*)(ws + plan.layers[i].bias_off), d.bias_rows, d.bias_c_ch,
+                                      d.bias_c_real, plan.layers[i].bias_nblk, 0};
+                grp.blk_start[j] = blk;
+                blk += plan.layers[i].bias_nblk;
+            }
+            for (int j = grp.n; j <= G3_BIAS_MAX; ++j) grp.blk_start[j] = blk;
+            hipLaunchKernelGGL(bias_partial_group_kernel, dim3(blk), dim3(256), 0, st, grp);
+            VS_CHECK_LAUNCH();
+        }
+    }
+    // ---- every reduction in one grid (G3_RED_MAX entries per launch) ----
+    {
+        std::vector<G3RedDesc> red;
+        std::vector<int> blocks;
+        for (int i = 0; i < count; ++i) {
+            const MultiLayer& L = plan.layers[i];
+            const long long slab_elems = (long long)L.p.mbn * L.p.cbn * L.ncb * 256;
+            int parts = 1;
+            while (parts < 16 && parts < L.p.ksplit) parts *= 2;
+            red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.p.ksplit, L.cbsz,
+                                    L.kind == VS_CONV_K3 ? 27 : 8, L.ncb, 0, parts});
+            blocks.push_back(vs_ceil_div(slab_elems, 64 * (16 / parts)));
+            if (descs[i].bias_g) {
+                red.push_back(G3RedDesc{(const float*)(ws + L.bias_off), descs[i].db, 0, descs[i].bias_c_real, 0, 0, L.bias_nblk, 0, 0, 0, 1, 16});
+                blocks.push_back(vs_ceil_div(descs[i].bias_c_real, 64));
+            }
+        }
+        for (size_t at = 0; at < red.size(); at += G3_RED_MAX) {
+            G3RedGroup grp{};
+            grp.n = (int)std::min<size_t>(G3_RED_MAX, red.size() - at);
+            long long blk = 0;
+            for (int j = 0; j < grp.n; ++j) {
+                grp.d[j] = red[at + j];
+                grp.blk_start[j] = (int)blk;
+                blk += blocks[at + j];
+            }
+            if (blk >= 2147483647ll) return VS_ESHAPE;
+            for (int j = grp.n; j <= G3_RED_MAX; ++j) grp.blk_start[j] = (int)blk;
+            hipLaunchKernelGGL(g3_reduce_group_kernel, dim3((unsigned)blk), dim3(1024), 0, st, grp);
+            VS_CHECK_LAUNCH();
+        }
+    }
+    return VS_OK;
+}
