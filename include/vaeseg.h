@@ -213,6 +213,19 @@ int vs_dice_fwd(const float* s, const float* t, double* sums, float* per_sample,
  * gout_is_mean == 1: w[b] = gout[0]/B (upstream gradient of mean_out). */
 int vs_dice_bwd(const float* s, const float* t, const double* sums, const float* gout, int gout_is_mean, float* gs,
                 float* gt, int batch, int channels, long long voxels, int bot, int top, float eps, void* stream);
+/* A weighted sum of soft-Dice LOSSES of one source against k <= 4 targets in one pass over the source — the loss line of
+ * every train method, e.g. main_source.py:469-471  final = lambda*(1-Dice(pred,recon)) + (1-Dice(pred,gt)):
+ *   terms[j] = 1 - mean_b mean_{c in [bot,top)} 2*I_j/(S+T_j+eps);   final = ((w[0]*terms[0]) + w[1]*terms[1]) + ...   (fp32, that order)
+ * t, w (and gt below) are HOST arrays of k entries.  scratch: vs_dice_loss_multi_scratch_doubles() doubles, contents undefined
+ * on entry (per-block partials summed in a fixed order: no atomics, bitwise reproducible); the forward leaves the sums the
+ * backward needs in its first 3*k*B*C entries.  The backward writes gs = d final/d s * gout[0] and,
+ * for every non-NULL gt[j], d final/d t_j * gout[0]; channels outside [bot,top) get 0. */
+size_t vs_dice_loss_multi_scratch_doubles(int k, int batch, int channels);
+int vs_dice_loss_multi_fwd(const float* s, const float* const* t, const float* w, int k, double* scratch, float* terms,
+                           float* final_out, int batch, int channels, long long voxels, int bot, int top, float eps, void* stream);
+int vs_dice_loss_multi_bwd(const float* s, const float* const* t, const float* w, int k, const double* scratch,
+                           const float* gout, float* gs, float* const* gt, int batch, int channels, long long voxels,
+                           int bot, int top, float eps, void* stream);
 /* nn.BCELoss() mean reduction (utils/evaluation.py:29-39), log clamped at -100 like torch */
 int vs_bce_fwd(const float* p, const float* t, float* out, double* scratch, long long count, void* stream);
 int vs_bce_bwd(const float* p, const float* t, const float* gout, float* gp, long long count, void* stream);

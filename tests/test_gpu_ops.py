@@ -449,3 +449,49 @@ def test_grouped_weight_gradients_many_layers(dtype):
         assert relerr(gw, sw) < 2e-6, case
         if gb is not None:
             assert relerr(gb, sb) < 1e-5, case
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_dice_loss_sum_matches_reference_spelling(k):
+    """ops.dice_loss_sum (one launch each way) against the reference's spelling — 1 - avg_dsc per term, torch scalar arithmetic
+    (main_source.py:469-471) — on the CPU, and against the unfused GPU path: value, terms, gradients of source and targets."""
+    ops = _ops()
+    b, c, side = 2, 2, 12
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(b, c, side, side, side, generator=g)
+    src = torch.softmax(logits, 1)
+    tgts = [torch.softmax(torch.randn(b, c, side, side, side, generator=g), 1) for _ in range(k)]
+    ws = [0.1, 1.0, 0.37][:k]
+    eps = 1e-4
+
+    def ref_dice(s, t):
+        s1, t1 = s[:, 1:2].reshape(b, 1, -1), t[:, 1:2].reshape(b, 1, -1)
+        return (2 * (s1 * t1).sum(2) / (s1.sum(2) + t1.sum(2) + eps)).mean()
+
+    s_ref = src.clone().requires_grad_(True)
+    t_ref = [t.clone().requires_grad_(True) for t in tgts]
+    terms_ref = [1 - ref_dice(s_ref, t) for t in t_ref]
+    final_ref = sum(w * tr for w, tr in zip(ws, terms_ref))
+    final_ref.backward()
+
+    outs = {}
+    for fused in (True, False):
+        ops.FUSED_LOSS[0] = fused
+        try:
+            s_g = src.cuda().requires_grad_(True)
+            t_g = [t.cuda().requires_grad_(True) for t in tgts]
+            ops.stats_arena_begin(s_g.device)
+            final, terms = ops.dice_loss_sum(s_g, list(zip(t_g, ws)), botindex=1, topindex=2, eps=eps)
+            final.backward()
+            torch.cuda.synchronize()
+            outs[fused] = (final.item(), [float(t) for t in terms], s_g.grad.cpu(), [t.grad.cpu() for t in t_g])
+        finally:
+            ops.FUSED_LOSS[0] = True
+    for fused, (fv, tv, gs, gts) in outs.items():
+        assert abs(fv - final_ref.item()) < 2e-6, fused
+        for a, r in zip(tv, terms_ref):
+            assert abs(a - r.item()) < 2e-6
+        assert relerr(gs, s_ref.grad) < 2e-5
+        for a, r in zip(gts, t_ref):
+            assert relerr(a, r.grad) < 2e-5
+    assert abs(outs[True][0] - outs[False][0]) < 1e-6

@@ -259,34 +259,77 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[rb][r] = 0.f; ssq[rb][r] = 0.f; mk_mean[rb][r] = 0.f; mk_rstd[rb][r] = 1.f; }
 
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
+    // element offset of every (row block, column group) fragment this lane stores
+    auto out_elem = [&](int rb, int cg, int& m_out, bool& valid) -> size_t {
         const int row = (rb0 + rb) * 16 + 4 * g;          // first of this lane's 4 consecutive rows
         int m = row, tap = 0;
         if constexpr (EPI == EPI_SCATTER) { tap = row / p.M; m = row - tap * p.M; }
         const bool rvalid = EPI == EPI_SCATTER ? (tap < 8) : (row < p.M);
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && rvalid) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = p.bias[m + r];
+        m_out = m;
+        valid = rvalid && cvalid[cg];
+        if constexpr (EPI == EPI_SCATTER) {
+            const int dz = (tap >> 2) & 1, dy = (tap >> 1) & 1, dx = tap & 1;
+            return ((((size_t)n * (2 * p.D) + 2 * oz[cg] + dz) * (2 * p.H) + 2 * oy[cg] + dy) * (2 * p.W) + 2 * ox[cg] + dx) * p.M + m;
+        } else {
+            return ((((size_t)n * p.Do + oz[cg]) * p.Ho + oy[cg]) * p.Wo + ox[cg]) * p.M + m;
         }
+    };
+    // backward-data use: ALL mask fragments are requested before the first store (a load issued between the stores of the
+    // loop below cannot be hoisted over them by the compiler — the tensors may alias for all it knows — and each would cost a
+    // full memory round trip: 16 in a row for a 64-row scatter workgroup)
+    constexpr int MKW = sizeof(T) == 4 ? 4 : 2;
+    unsigned int mkv[RB][4][MKW];
+    if (p.sums != nullptr) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) {
+                int m; bool ok;
+                const size_t e = out_elem(rb, cg, m, ok);
+#pragma unroll
+                for (int i = 0; i < MKW; ++i) mkv[rb][cg][i] = 0u;
+                if (ok) {
+                    if constexpr (sizeof(T) == 4) {
+                        const u32x4 xx = *(const u32x4*)((const float*)p.mask_x + e);
+                        mkv[rb][cg][0] = xx[0]; mkv[rb][cg][1] = xx[1]; mkv[rb][cg][2] = xx[2]; mkv[rb][cg][3] = xx[3];
+                    } else {
+                        const u32x2 xx = *(const u32x2*)((const unsigned short*)p.mask_x + e);
+                        mkv[rb][cg][0] = xx[0]; mkv[rb][cg][1] = xx[1];
+                    }
+                }
+            }
+    }
+
+    float bvq[RB][4];                            // bias rows, requested up front for the same reason
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        int m; bool ok0;
+        (void)out_elem(rb, 0, m, ok0);
+        const int row = (rb0 + rb) * 16 + 4 * g;
+        const bool rvalid = EPI == EPI_SCATTER ? (row / p.M < 8) : (row < p.M);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bvq[rb][r] = (p.bias && rvalid) ? p.bias[m + r] : 0.f;
+    }
+
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        int m; bool ok0;
+        (void)out_elem(rb, 0, m, ok0);
+        const int row = (rb0 + rb) * 16 + 4 * g;
+        const bool rvalid = EPI == EPI_SCATTER ? (row / p.M < 8) : (row < p.M);
+        float bv[4] = {bvq[rb][0], bvq[rb][1], bvq[rb][2], bvq[rb][3]};
         if (p.sums != nullptr && rvalid) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { mk_mean[rb][r] = s_mean[m + r]; mk_rstd[rb][r] = s_rstd[m + r]; }
         }
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) {
-            if (!(rvalid && cvalid[cg])) continue;
+            int m2; bool ok;
+            const size_t e = out_elem(rb, cg, m2, ok);
+            if (!ok) continue;
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = E::rnd(acc[rb][cg][r] + bv[r]);
-            size_t e;
-            if constexpr (EPI == EPI_SCATTER) {
-                const int dz = (tap >> 2) & 1, dy = (tap >> 1) & 1, dx = tap & 1;
-                e = ((((size_t)n * (2 * p.D) + 2 * oz[cg] + dz) * (2 * p.H) + 2 * oy[cg] + dy) * (2 * p.W) + 2 * ox[cg] + dx) * p.M + m;
-            } else {
-                e = ((((size_t)n * p.Do + oz[cg]) * p.Ho + oy[cg]) * p.Wo + ox[cg]) * p.M + m;
-            }
             if constexpr (sizeof(T) == 4) {
                 *(f32x4*)((float*)yout + e) = f32x4{v[0], v[1], v[2], v[3]};
             } else {
@@ -298,12 +341,11 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
             if (p.sums != nullptr) {
                 float xv[4];
                 if constexpr (sizeof(T) == 4) {
-                    const f32x4 xx = *(const f32x4*)((const float*)p.mask_x + e);
-                    xv[0] = xx[0]; xv[1] = xx[1]; xv[2] = xx[2]; xv[3] = xx[3];
+                    xv[0] = __uint_as_float(mkv[rb][cg][0]); xv[1] = __uint_as_float(mkv[rb][cg][1]);
+                    xv[2] = __uint_as_float(mkv[rb][cg][2]); xv[3] = __uint_as_float(mkv[rb][cg][3]);
                 } else {
-                    const u32x2 xx = *(const u32x2*)((const unsigned short*)p.mask_x + e);
-                    xv[0] = __uint_as_float(xx[0] << 16); xv[1] = __uint_as_float(xx[0] & 0xffff0000u);
-                    xv[2] = __uint_as_float(xx[1] << 16); xv[3] = __uint_as_float(xx[1] & 0xffff0000u);
+                    xv[0] = __uint_as_float(mkv[rb][cg][0] << 16); xv[1] = __uint_as_float(mkv[rb][cg][0] & 0xffff0000u);
+                    xv[2] = __uint_as_float(mkv[rb][cg][1] << 16); xv[3] = __uint_as_float(mkv[rb][cg][1] & 0xffff0000u);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {

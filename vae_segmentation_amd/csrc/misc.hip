@@ -479,6 +479,214 @@ extern "C" int vs_dice_bwd(const float* s, const float* t, const double* sums, c
     return VS_OK;
 }
 
+// ---- weighted sum of Dice losses, one source against k targets (one launch forward, one backward) -----------------
+#define DICE_MULTI_MAX 4
+struct DiceMulti {
+    const float* s;
+    const float* t[DICE_MULTI_MAX];
+    float* gt[DICE_MULTI_MAX];
+    float w[DICE_MULTI_MAX];
+    int k;
+};
+// scratch layout: sums[(j*B + b)*C + c][3] = (I_j, S, T_j), written by the finish kernel (the backward reads them); then
+// the per-block partials part[((b*nc + ci)*NQ + q)*nblk + blk], q = 0: S, 1+2j: I_j, 2+2j: T_j.  No atomics: 27 ns per
+// same-line fp64 atomic made a 432-block single-launch version (atomics + last-block ticket) cost 58 us; two small launches
+// cost 12, and the fixed summation order makes the loss bitwise reproducible.
+#define DICE_MULTI_BLOCKS 256
+__global__ __launch_bounds__(256) void dice_multi_partial_kernel(const DiceMulti a, double* __restrict__ part, int channels, long long voxels, int bot) {
+    const int c = bot + blockIdx.y, b = blockIdx.z, K = a.k;
+    const size_t plane = ((size_t)b * channels + c) * voxels;
+    const float* sp = a.s + plane;
+    double aS = 0.0, aI[DICE_MULTI_MAX], aT[DICE_MULTI_MAX];
+#pragma unroll
+    for (int j = 0; j < DICE_MULTI_MAX; ++j) { aI[j] = 0.0; aT[j] = 0.0; }
+    const long long v4 = voxels / 4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v4; i += (long long)gridDim.x * 256) {
+        const f32x4 x = *(const f32x4*)(sp + i * 4);
+        aS += (double)(x[0] + x[1]) + (double)(x[2] + x[3]);
+#pragma unroll
+        for (int j = 0; j < DICE_MULTI_MAX; ++j) {
+            if (j < K) {
+                const f32x4 y = *(const f32x4*)(a.t[j] + plane + i * 4);
+                aI[j] += (double)(x[0] * y[0] + x[1] * y[1]) + (double)(x[2] * y[2] + x[3] * y[3]);
+                aT[j] += (double)(y[0] + y[1]) + (double)(y[2] + y[3]);
+            }
+        }
+    }
+    __shared__ double red[4][1 + 2 * DICE_MULTI_MAX];
+    const int wave = threadIdx.x >> 6;
+    aS = wave_sum_d(aS);
+#pragma unroll
+    for (int j = 0; j < DICE_MULTI_MAX; ++j) { aI[j] = wave_sum_d(aI[j]); aT[j] = wave_sum_d(aT[j]); }
+    if ((threadIdx.x & 63) == 0) {
+        red[wave][0] = aS;
+#pragma unroll
+        for (int j = 0; j < DICE_MULTI_MAX; ++j) { red[wave][1 + 2 * j] = aI[j]; red[wave][2 + 2 * j] = aT[j]; }
+    }
+    __syncthreads();
+    const int NQ = 1 + 2 * K;
+    if (threadIdx.x < NQ) {
+        const int q = threadIdx.x;
+        part[(((size_t)b * gridDim.y + blockIdx.y) * NQ + q) * gridDim.x + blockIdx.x] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+    }
+}
+
+__global__ __launch_bounds__(256) void dice_multi_finish_kernel(const DiceMulti a, const double* __restrict__ part, double* __restrict__ sums,
+                                                               float* __restrict__ terms, float* __restrict__ final_out, int batch,
+                                                               int channels, int bot, int top, int nblk, float eps) {
+    const int K = a.k, NQ = 1 + 2 * K, nc = top - bot;
+    __shared__ double s_tot[64 * 2 * (1 + 2 * DICE_MULTI_MAX)];      // [b][ci][q], batch*nc <= 128 checked on the host
+    for (int i = threadIdx.x; i < batch * nc * NQ; i += 256) {
+        const double* src = part + (size_t)i * nblk;
+        double t = 0.0;
+        int blk = 0;
+        for (; blk + 8 <= nblk; blk += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[blk + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; blk < nblk; ++blk) t += src[blk];
+        s_tot[i] = t;
+        const int q = i % NQ, bc = i / NQ, ci = bc % nc, b = bc / nc;
+        if (q == 0) {
+            for (int j = 0; j < K; ++j) sums[(((size_t)j * batch + b) * channels + bot + ci) * 3 + 1] = t;
+        } else {
+            const int j = (q - 1) >> 1;
+            sums[(((size_t)j * batch + b) * channels + bot + ci) * 3 + (((q - 1) & 1) ? 2 : 0)] = t;
+        }
+    }
+    __syncthreads();
+    __shared__ float s_term[DICE_MULTI_MAX];
+    if (threadIdx.x < K) {
+        const int j = threadIdx.x;
+        float m = 0.f;
+        for (int b = 0; b < batch; ++b) {
+            float v = 0.f;
+            for (int ci = 0; ci < nc; ++ci) {
+                const double* q = s_tot + (b * nc + ci) * NQ;
+                // fp32 arithmetic as torch does on the fp32 sums
+                const float I = (float)q[1 + 2 * j], S = (float)q[0], T = (float)q[2 + 2 * j];
+                v += 2.f * I / (S + T + eps);
+            }
+            m += v / (float)nc;
+        }
+        const float term = 1.f - m / (float)batch;
+        terms[j] = term;
+        s_term[j] = term;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float f = __fmul_rn(a.w[0], s_term[0]);
+        for (int j = 1; j < K; ++j) f = __fadd_rn(f, __fmul_rn(a.w[j], s_term[j]));
+        final_out[0] = f;
+    }
+}
+
+static int dice_multi_args(DiceMulti& a, const float* s, const float* const* t, const float* w, float* const* gt, int k) {
+    if (!s || !t || !w || k <= 0 || k > DICE_MULTI_MAX) return VS_EINVAL;
+    a = DiceMulti{};
+    a.s = s; a.k = k;
+    if ((uintptr_t)s & 15) return VS_EALIGN;
+    for (int j = 0; j < k; ++j) {
+        if (!t[j]) return VS_EINVAL;
+        if (((uintptr_t)t[j] & 15) || (gt && gt[j] && ((uintptr_t)gt[j] & 15))) return VS_EALIGN;
+        a.t[j] = t[j]; a.w[j] = w[j]; a.gt[j] = gt ? gt[j] : nullptr;
+    }
+    return VS_OK;
+}
+
+extern "C" size_t vs_dice_loss_multi_scratch_doubles(int k, int batch, int channels) {
+    if (k <= 0 || batch <= 0 || channels <= 0) return 0;
+    return (size_t)3 * k * batch * channels + (size_t)batch * channels * (1 + 2 * k) * DICE_MULTI_BLOCKS;
+}
+
+extern "C" int vs_dice_loss_multi_fwd(const float* s, const float* const* t, const float* w, int k, double* scratch, float* terms,
+                                      float* final_out, int batch, int channels, long long voxels, int bot, int top, float eps, void* stream) {
+    DiceMulti a;
+    int rc = dice_multi_args(a, s, t, w, nullptr, k);
+    if (rc) return rc;
+    if (!scratch || !terms || !final_out || batch <= 0 || batch > 64 || channels <= 0 || voxels <= 0 || bot < 0 || top > channels || bot >= top) return VS_EINVAL;
+    if (voxels & 3) return VS_EALIGN;
+    if ((long long)batch * (top - bot) > 128) return VS_ESHAPE;
+    long long blocks = (voxels / 4 + 256 * 2 - 1) / (256 * 2);       // short loops: the launch is latency-, not bandwidth-bound
+    if (blocks < 1) blocks = 1;
+    if (blocks > DICE_MULTI_BLOCKS) blocks = DICE_MULTI_BLOCKS;
+    double* part = scratch + (size_t)3 * k * batch * channels;
+    hipLaunchKernelGGL(dice_multi_partial_kernel, dim3((unsigned)blocks, top - bot, batch), dim3(256), 0, (hipStream_t)stream, a, part, channels,
+                       voxels, bot);
+    VS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dice_multi_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, part, scratch, terms, final_out, batch, channels,
+                       bot, top, (int)blocks, eps);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// final = sum_j w_j (1 - mean_{b,c} 2 I_j/(S+T_j+eps))  =>  d/ds_i = -sum_j w_j/(B*nc) (2 t_ji/den_j - 2 I_j/den_j^2), d/dt_ji symmetric
+__global__ __launch_bounds__(256) void dice_multi_bwd_kernel(const DiceMulti a, const double* __restrict__ sums, const float* __restrict__ gout,
+                                                            float* __restrict__ gs, int batch, int channels, long long voxels, int bot,
+                                                            int top, float eps) {
+    const int c = blockIdx.y, b = blockIdx.z, K = a.k;
+    const size_t plane = ((size_t)b * channels + c) * voxels;
+    const long long v4 = voxels / 4;
+    if (c < bot || c >= top) {
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v4; i += (long long)gridDim.x * 256) {
+            if (gs) *(f32x4*)(gs + plane + i * 4) = z;
+#pragma unroll
+            for (int j = 0; j < DICE_MULTI_MAX; ++j)
+                if (j < K && a.gt[j]) *(f32x4*)(a.gt[j] + plane + i * 4) = z;
+        }
+        return;
+    }
+    float k1[DICE_MULTI_MAX], k2[DICE_MULTI_MAX], k2sum = 0.f;
+    const float g0 = -gout[0] / ((float)batch * (float)(top - bot));
+#pragma unroll
+    for (int j = 0; j < DICE_MULTI_MAX; ++j) {
+        k1[j] = 0.f; k2[j] = 0.f;
+        if (j < K) {
+            const double* q = sums + (((size_t)j * batch + b) * channels + c) * 3;
+            const float I = (float)q[0], den = (float)q[1] + (float)q[2] + eps;
+            const float g = g0 * a.w[j];
+            k1[j] = g * 2.f / den;
+            k2[j] = g * 2.f * I / (den * den);
+            k2sum += k2[j];
+        }
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < v4; i += (long long)gridDim.x * 256) {
+        const f32x4 x = *(const f32x4*)(a.s + plane + i * 4);
+        f32x4 acc = f32x4{-k2sum, -k2sum, -k2sum, -k2sum};
+#pragma unroll
+        for (int j = 0; j < DICE_MULTI_MAX; ++j) {
+            if (j < K) {
+                if (gs) {
+                    const f32x4 y = *(const f32x4*)(a.t[j] + plane + i * 4);
+                    acc[0] += k1[j] * y[0]; acc[1] += k1[j] * y[1]; acc[2] += k1[j] * y[2]; acc[3] += k1[j] * y[3];
+                }
+                if (a.gt[j]) *(f32x4*)(a.gt[j] + plane + i * 4) = f32x4{k1[j] * x[0] - k2[j], k1[j] * x[1] - k2[j], k1[j] * x[2] - k2[j], k1[j] * x[3] - k2[j]};
+            }
+        }
+        if (gs) *(f32x4*)(gs + plane + i * 4) = acc;
+    }
+}
+
+extern "C" int vs_dice_loss_multi_bwd(const float* s, const float* const* t, const float* w, int k, const double* scratch, const float* gout,
+                                      float* gs, float* const* gt, int batch, int channels, long long voxels, int bot, int top, float eps,
+                                      void* stream) {
+    DiceMulti a;
+    int rc = dice_multi_args(a, s, t, w, gt, k);
+    if (rc) return rc;
+    if (!scratch || !gout || batch <= 0 || channels <= 0 || voxels <= 0 || (voxels & 3) || bot < 0 || top > channels || bot >= top) return VS_EINVAL;
+    if (gs && ((uintptr_t)gs & 15)) return VS_EALIGN;
+    long long blocks = (voxels / 4 + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(dice_multi_bwd_kernel, dim3((unsigned)blocks, channels, batch), dim3(256), 0, (hipStream_t)stream, a, scratch, gout, gs,
+                       batch, channels, voxels, bot, top, eps);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
 // ---- BCE ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bce_sum_kernel(const float* __restrict__ p, const float* __restrict__ t, double* __restrict__ acc, long long count) {
     double s = 0.0;

@@ -979,6 +979,73 @@ class Dice(torch.autograd.Function):
         return gs, gt, None, None, None, None
 
 
+class DiceLossSum(torch.autograd.Function):
+    """final = sum_j w[j] * (1 - avg_dsc(s, t_j))  — the loss line of every train method (main_source.py:469-471,
+    main_target.py:588-592) — in TWO forward launches (per-block partials, finish) and ONE backward launch: the source is read once
+    for all targets, no atomics, fixed summation order (the unfused spelling costs ~18 launches of 4.7 us for two terms).  -> (final, terms[k]); terms are the individual (1 - Dice) values, not differentiable."""
+
+    @staticmethod
+    def forward(ctx, s, bot, top, eps, weights, *targets):
+        _require_cuda(s, *targets)
+        k = len(targets)
+        s = _contig(s.float())
+        ts = [_contig(t.float()) for t in targets]
+        b, c = s.shape[0], s.shape[1]
+        voxels = s.numel() // (b * c)
+        scratch = torch.empty(lib.vs_dice_loss_multi_scratch_doubles(k, b, c), dtype=torch.float64, device=s.device)
+        terms = torch.empty(k, dtype=torch.float32, device=s.device)
+        final = torch.empty((), dtype=torch.float32, device=s.device)
+        tp = (_ct.c_void_p * k)(*[t.data_ptr() for t in ts])
+        wp = (_ct.c_float * k)(*[float(w) for w in weights])
+        check(lib.vs_dice_loss_multi_fwd(s.data_ptr(), _ct.addressof(tp), _ct.addressof(wp), k, scratch.data_ptr(), terms.data_ptr(),
+                                         final.data_ptr(), b, c, voxels, bot, top, float(eps), _stream()), "dice_loss_multi_fwd")
+        ctx.save_for_backward(s, scratch, *ts)
+        ctx.cfg = (bot, top, float(eps), [float(w) for w in weights])
+        ctx.mark_non_differentiable(terms)
+        ctx.set_materialize_grads(False)      # no zero-fill launch for the terms' gradient
+        return final, terms
+
+    @staticmethod
+    def backward(ctx, g, _gterms):
+        s, scratch = ctx.saved_tensors[:2]
+        ts = ctx.saved_tensors[2:]
+        bot, top, eps, weights = ctx.cfg
+        if g is None:
+            return (None,) * (5 + len(ts))
+        k = len(ts)
+        b, c = s.shape[0], s.shape[1]
+        voxels = s.numel() // (b * c)
+        g = _contig(g.float())
+        gs = torch.empty_like(s) if ctx.needs_input_grad[0] else None
+        gts = [torch.empty_like(t) if ctx.needs_input_grad[5 + j] else None for j, t in enumerate(ts)]
+        if gs is not None or any(x is not None for x in gts):
+            tp = (_ct.c_void_p * k)(*[t.data_ptr() for t in ts])
+            gp = (_ct.c_void_p * k)(*[_p(x) for x in gts])
+            wp = (_ct.c_float * k)(*weights)
+            check(lib.vs_dice_loss_multi_bwd(s.data_ptr(), _ct.addressof(tp), _ct.addressof(wp), k, scratch.data_ptr(), g.data_ptr(), _p(gs),
+                                             _ct.addressof(gp), b, c, voxels, bot, top, eps, _stream()), "dice_loss_multi_bwd")
+        return (gs, None, None, None, None) + tuple(gts)
+
+
+FUSED_LOSS = [os.environ.get("VS_FUSED_LOSS", "1") != "0"]
+
+
+def dice_loss_sum(source, targets_and_weights, botindex=0, topindex=2, eps=1e-6):
+    """sum_j w_j * (1 - avg_dsc(source, target_j, botindex, topindex)) -> (final, [1 - Dice_j ...]); channel selection as
+    utils/evaluation.py:66-70.  VS_FUSED_LOSS=0 spells it with Dice.apply and torch scalar arithmetic, as the reference does."""
+    channels = source.shape[1]
+    bot, top = (botindex, min(topindex, channels)) if channels > 1 else (0, 1)
+    if not FUSED_LOSS[0] or len(targets_and_weights) > 4:
+        terms = [1 - Dice.apply(source, t, bot, top, eps, True) for t, _ in targets_and_weights]
+        final = None
+        for term, (_, w) in zip(terms, targets_and_weights):
+            part = term if w == 1 else w * term
+            final = part if final is None else final + part
+        return final, terms
+    final, terms = DiceLossSum.apply(source, bot, top, eps, [w for _, w in targets_and_weights], *[t for t, _ in targets_and_weights])
+    return final, list(terms.unbind(0))
+
+
 class BCE(torch.autograd.Function):
     """nn.BCELoss() (mean) — utils/evaluation.py:29-39."""
 

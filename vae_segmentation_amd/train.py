@@ -18,17 +18,17 @@ from .evaluation import EPS_EVALUATION, EPS_MAIN_SOURCE, KLloss, avg_dsc, binari
 def joint_train_losses(joint, img, label, lambda_vae=0.1, eps=EPS_MAIN_SOURCE, n_class=2):
     batch = {"img": img, "gt": ops.onehot(label, n_class)}
     batch = joint(batch, "img", "pred", "recon")
-    recon_loss = 1 - avg_dsc(batch, "pred", "recon", botindex=1, topindex=n_class, eps=eps)
-    dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=eps)
-    final = lambda_vae * recon_loss + dsc_loss
+    # final = lambda_vae * (1 - avg_dsc(pred, recon)) + (1 - avg_dsc(pred, gt))        (main_source.py:469-471), one launch each way
+    final, (recon_loss, dsc_loss) = ops.dice_loss_sum(batch["pred"], [(batch["recon"], lambda_vae), (batch["gt"], 1.0)],
+                                                      botindex=1, topindex=n_class, eps=eps)
     return final, {"recon_loss": recon_loss, "dice_loss": dsc_loss, "batch": batch}
 
 
 def seg_train_losses(seg, img, label, eps=EPS_MAIN_SOURCE, n_class=2):
     batch = {"img": img, "gt": ops.onehot(label, n_class)}
     batch = seg(batch, "img", "pred")
-    dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=eps)
-    return dsc_loss, {"dice_loss": dsc_loss, "batch": batch}
+    final, (dsc_loss,) = ops.dice_loss_sum(batch["pred"], [(batch["gt"], 1.0)], botindex=1, topindex=n_class, eps=eps)
+    return final, {"dice_loss": dsc_loss, "batch": batch}
 
 
 def vae_train_losses(vae, label, scale=0.35, noise=None, eps=EPS_MAIN_SOURCE, n_class=2):
