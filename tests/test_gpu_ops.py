@@ -59,8 +59,10 @@ CONV_CASES = [  # (N, Cin, Cout, D, H, W)
 # shapes that make the persistent 3x3x3 kernels walk several tiles per workgroup (more tiles than the grid), cross a sample
 # boundary mid-walk (statistics flush), use 32-row weight blocks, two channel chunks, and ragged edges in all three axes
 # the last two take the tall-tile (4x8x16) variant of the bf16 kernel (one wave of 256..1024 workgroups), one with a ragged y edge
+# the 8 -> 8 channel cases run the Toeplitz kernel (igemm_k3t.h, 4x8x32 tiles): ragged in all three axes with three samples; more tiles
+# (576, four samples) than the persistent grid (512); 2 real input channels of 8
 CONV_CASES_LARGE = [(2, 8, 8, 48, 48, 64), (2, 32, 32, 16, 32, 64), (1, 16, 32, 37, 30, 50), (3, 64, 32, 9, 10, 21),
-                    (2, 16, 16, 32, 64, 64), (1, 8, 8, 32, 100, 48)]
+                    (2, 16, 16, 32, 64, 64), (1, 8, 8, 32, 100, 48), (3, 8, 8, 7, 9, 37), (4, 8, 8, 24, 48, 128), (2, 2, 8, 12, 20, 70)]
 
 
 @pytest.mark.parametrize("dtype", DT)

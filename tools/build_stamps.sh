@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../vae_segmentation_amd/csrc"
 mkdir -p ../../tools/_dbg/obj
 for f in igemm_k3_f32 igemm_k3_bf16 igemm_k2s2 igemm_pw conv_api wgrad pack norm misc; do
-  /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -DVS_STAMPS -Wno-unused-variable -c $f.hip -o ../../tools/_dbg/obj/$f.o &
+  /opt/rocm/bin/hipcc -O3 -fPIC -std=c++17 --offload-arch=gfx950 -D${VS_STAMPS_DEF:-VS_STAMPS} -Wno-unused-variable -c $f.hip -o ../../tools/_dbg/obj/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_dbg/libvaeseg_stamps.so ../../tools/_dbg/obj/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/_dbg/${VS_STAMPS_OUT:-libvaeseg_stamps.so} ../../tools/_dbg/obj/*.o

@@ -27,10 +27,21 @@ TICK_NS = 1.0 / 2.2   # s_memtime ticks at ~2.2 GHz under this load (calibrated 
 nwg = 2048
 buf = np.zeros(nwg * 8, dtype=np.uint64)
 dbg.vs_debug_read_k3_stamps(buf.ctypes.data, nwg * 8)
-st = buf.reshape(nwg, 8).astype(np.int64)
-st = st[st.sum(1) > 0]
+raw = buf.reshape(nwg, 8)
+raw = raw[raw[:, :7].sum(1) > 0]
+# slot 7: (start << 32) | end of the workgroup on the 100 MHz s_memrealtime clock -> dispatch timeline
+t_start = (raw[:, 7] >> np.uint64(32)).astype(np.int64) & 0xffffffff
+t_end = (raw[:, 7] & np.uint64(0xffffffff)).astype(np.int64)
+t0 = t_start.min()
+print("workgroup starts (us after the first): percentiles 5/50/95/100:", [round(float(v) * 0.01, 2) for v in np.percentile(t_start - t0, [5, 50, 95, 100])],
+      " ends: 5/50/95/100:", [round(float(v) * 0.01, 2) for v in np.percentile(t_end - t0, [5, 50, 95, 100])])
+late = (t_start - t0) > 300
+print("workgroups starting > 3 us after the first: %d of %d" % (int(late.sum()), len(raw)))
+st = raw.astype(np.int64)
+st[:, 7] = 0
 names = ["prologue (tables, first loads)", "barrier 1 (prev stage read by all) + tile setup", "vmcnt wait + transform + LDS write", "barrier 2", "next-stage load issue", "MFMA phase", "epilogue", "-"]
 tot = st.sum(1)
+print("total ticks/WG percentiles 5/25/50/75/95/100:", [int(v) for v in np.percentile(tot, [5, 25, 50, 75, 95, 100])], " (%.1f us max)" % (tot.max() * TICK_NS * 1e-3))
 print("workgroups with stamps:", len(st), " median total ticks/WG:", int(np.median(tot)))
 for i, nm in enumerate(names[:7]):
     print("%-50s median %8d ticks  %5.1f %%  (%.1f us)" % (nm, np.median(st[:, i]), 100 * np.median(st[:, i]) / np.median(tot), np.median(st[:, i]) * TICK_NS * 1e-3))

@@ -165,6 +165,13 @@ __device__ __forceinline__ u32x4 act8(const u32x4 raw, const f32x2 (&sc)[4], con
     return r;
 }
 
+// (bf16, 3x3x3, 8 stored k-side channels, <= 8 rows) weights — the 8-channel full-resolution layers — are packed in the Toeplitz
+// fragment order of k3t_kernel (igemm_k3t.h): [k-group (tz,ty)][lane][8], row (lane & 15) = (dx2, co), k = (xpos = lane >> 4, ci),
+// value W[co][ci][tz][ty][xpos - dx2] or 0.  pack.hip (image) and igemm_k3_bf16.hip (dispatch) both key on this predicate.
+static __host__ __device__ inline bool vs_k3_toeplitz(int rows, int c_pad, int ntaps, int dtype) {
+    return dtype == VS_BF16 && ntaps == 27 && c_pad == 8 && rows <= 8;
+}
+
 // Zeroing as a kernel, never hipMemsetAsync: inside a replayed HIP graph a memset node was observed to run out of order with the
 // kernel nodes around it after a host-side D2H copy (second test-time-training case, nondeterministic bias gradients); kernel nodes
 // are ordered.  One workgroup is enough for the few hundred bytes zeroed here.

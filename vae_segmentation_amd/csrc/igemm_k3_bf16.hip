@@ -1,5 +1,6 @@
 #include "igemm_dispatch.h"
 #include "igemm_k3b.h"
+#include "igemm_k3t.h"
 
 #define K3B_CASE(CKV, MTV)                                                                              \
     if (ck == CKV && mt == MTV)                                                                          \
@@ -9,12 +10,12 @@
 // bf16 3x3x3 convolutions run k3b_kernel with 16- or 32-row tiles (a 64-row weight block does not fit LDS next to the halo
 // tile): a 64-row request from pick_mt() is served as twice as many 32-row workgroups.
 int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s) {
-    const bool tall = mt == 16 && ck < 32 && k3b_use_tall(p);
-    if (epi == EPI_SOFTMAX2) {
-        if (ck == 8 && mt == 16)
-            return tall ? k3b_launch<8, 16, EPI_SOFTMAX2, false, 8>(p, tiles, row_tiles, s) : k3b_launch<8, 16, EPI_SOFTMAX2, false>(p, tiles, row_tiles, s);
-        return VS_ESHAPE;
+    if (ck == 8 && p.C == 8 && p.M == 8) {                // the 8-channel full-resolution layers: Toeplitz kernel (weights packed to match)
+        if (epi == EPI_SOFTMAX2) return k3t_launch<EPI_SOFTMAX2, false, 8>(p, s);
+        return p.sums ? k3t_launch<EPI_RAW, true, 8>(p, s) : k3t_launch<EPI_RAW, false, 8>(p, s);
     }
+    const bool tall = mt == 16 && ck < 32 && k3b_use_tall(p);
+    if (epi == EPI_SOFTMAX2) return VS_ESHAPE;           // out_block is an 8-channel layer (above)
     if (tall) {
         if (ck == 8) return p.sums ? k3b_launch<8, 16, EPI_RAW, true, 8>(p, tiles, row_tiles, s) : k3b_launch<8, 16, EPI_RAW, false, 8>(p, tiles, row_tiles, s);
         return p.sums ? k3b_launch<16, 16, EPI_RAW, true, 8>(p, tiles, row_tiles, s) : k3b_launch<16, 16, EPI_RAW, false, 8>(p, tiles, row_tiles, s);

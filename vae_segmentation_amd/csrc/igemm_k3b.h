@@ -24,8 +24,16 @@ extern "C" int vs_debug_read_k3_stamps(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k3_stamps), sizeof(unsigned long long) * n);
 }
 #define K3_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk_acc[i] += now_ - tk_last; tk_last = now_; } while (0)
-#define K3_TICK_INIT unsigned long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk_last = __builtin_amdgcn_s_memtime();
-#define K3_TICK_FLUSH do { if (threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) g_k3_stamps[((blockIdx.y * gridDim.x + blockIdx.x) & 2047) * 8 + i_] = tk_acc[i_]; } } while (0)
+#define K3_TICK_INIT unsigned long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk_last = __builtin_amdgcn_s_memtime(); tk_acc[7] = __builtin_amdgcn_s_memrealtime();
+#define K3_TICK_FLUSH do { if (threadIdx.x == 0) { tk_acc[7] = (tk_acc[7] << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull); for (int i_ = 0; i_ < 8; ++i_) g_k3_stamps[((blockIdx.y * gridDim.x + blockIdx.x) & 2047) * 8 + i_] = tk_acc[i_]; } } while (0)
+#elif defined(VS_STAMPS_LITE)   // only the workgroup's start / end on the 100 MHz clock (no extra VGPRs: the occupancy of the release build)
+__device__ unsigned long long g_k3_stamps[2048 * 8];
+extern "C" int vs_debug_read_k3_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k3_stamps), sizeof(unsigned long long) * n);
+}
+#define K3_TICK(i)
+#define K3_TICK_INIT const unsigned long long tk_rt0 = __builtin_amdgcn_s_memrealtime();
+#define K3_TICK_FLUSH do { if (threadIdx.x == 0) { unsigned long long* d_ = g_k3_stamps + ((blockIdx.y * gridDim.x + blockIdx.x) & 2047) * 8; d_[0] = 1; d_[7] = (tk_rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull); } } while (0)
 #else
 #define K3_TICK(i)
 #define K3_TICK_INIT
@@ -177,11 +185,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     };
 
     // ---- first stage in flight before anything else; the statistics tables meanwhile ----------------------------------
-    // XCD-aware walk: consecutive workgroup ids land on different XCDs (8, each with its own L2), so workgroup b starts at
-    // tile (b % 8) * (G / 8) + b / 8 — the workgroups of one XCD then work on one contiguous run of tiles at any time and find
-    // their neighbours' halos in that XCD's L2 (identity walk when G is not a multiple of 8)
-    const int G = (int)gridDim.x;
-    int t = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    // XCD-aware walk: consecutive workgroup ids land on different XCDs (8, each with its own L2); the workgroups of one XCD work
+    // on one contiguous run of tiles and find their neighbours' halos in that XCD's L2 (identity walk when the grid is not a
+    // multiple of 8).
+    // XCD x owns the contiguous run [x*T/8, (x+1)*T/8) of the tile list and deals it round-robin to its workgroups: every XCD gets
+    // the same number of tiles (striding the whole list by the grid left the remainder T mod G to XCD 0 and 1).
+    int t, t_end, G;
+    if (((int)gridDim.x & 7) == 0) {
+        const int xcd = (int)blockIdx.x & 7;
+        G = (int)gridDim.x >> 3;
+        t = (int)(((long long)total_tiles * xcd) >> 3) + ((int)blockIdx.x >> 3);
+        t_end = (int)(((long long)total_tiles * (xcd + 1)) >> 3);
+    } else { G = (int)gridDim.x; t = (int)blockIdx.x; t_end = total_tiles; }
     Coord cur = tile_coord(t), nxt = cur;
     load_w(0);
     load_x(cur, 0);
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     __syncthreads();                                     // tables visible
     K3_TICK(0);                                          // prologue
 
-    for (; t < total_tiles; t += gridDim.x) {
+    for (; t < t_end; t += G) {
         const int n = cur.n, z0 = cur.z0, y0 = cur.y0, x0 = cur.x0;
         const int oz = z0 + wave;
         // byte offset of output voxel (n, oz, y0 + cg, x0 + col), row 4g of row block rb: ebase + cg * W*M*2 + rb * 32; -1 = dropped
@@ -280,9 +295,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
                 }
             }
             {
-                const int tn = last_ch ? t + (int)gridDim.x : t;
+                const int tn = last_ch ? t + G : t;
                 if (last_ch) nxt = tile_coord(tn);
-                if (tn < total_tiles) {
+                if (tn < t_end) {
                     if constexpr (restage_w) load_w(last_ch ? 0 : ch + 1);
                     load_x(last_ch ? nxt : cur, last_ch ? 0 : ch + 1);
                 }
@@ -385,7 +400,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
             }
             double* const red_dst = has_sums ? p.sums : p.y_stats;
             if (red_dst != nullptr) {
-                const bool flush = t + (int)gridDim.x >= total_tiles || nxt.n != n;       // workgroup-uniform
+                const bool flush = t + G >= t_end || nxt.n != n;       // workgroup-uniform
                 if (flush) {
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
                             atomicAdd(red_dst + ((size_t)n * p.M + row) * 2 + st, tot);
                         }
                     }
-                    if (t + (int)gridDim.x < total_tiles) __syncthreads();     // s_red is reused by a later flush
+                    if (t + G < t_end) __syncthreads();     // s_red is reused by a later flush
                 }
             }
         }

@@ -8,6 +8,19 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ src, T* __res
                                          int c_pad, int form, long long total, long long i) {
     constexpr int EPL = ET<T>::EPL, KG = ET<T>::KG;
     if (i >= total) return;
+    if (sizeof(T) == 2 && form != VS_PACK_SCATTER_D1 && vs_k3_toeplitz(form == VS_PACK_ROWS_D0 ? d0 : d1, c_pad, ntaps, VS_BF16)) {
+        // Toeplitz image of the 8-channel 3x3x3 layers (common.h vs_k3_toeplitz, igemm_k3t.h): [kg = tz*3+ty][lane][ci]
+        const int ci = (int)(i & 7), lane = (int)((i >> 3) & 63), kg = (int)(i >> 9);
+        const int row = lane & 15, dx2 = row >> 3, co = row & 7, tx = (lane >> 4) - dx2;
+        float v = 0.f;
+        if (tx >= 0 && tx <= 2) {
+            const int tap = kg * 3 + tx;
+            if (form == VS_PACK_ROWS_D0) { if (co < d0 && ci < d1) v = src[((size_t)co * d1 + ci) * 27 + tap]; }
+            else { if (co < d1 && ci < d0) v = src[((size_t)ci * d1 + co) * 27 + (26 - tap)]; }
+        }
+        ET<T>::st(dst + i, v);
+        return;
+    }
     const int CK = c_pad < 32 ? c_pad : 32;
     const int nch = c_pad / CK;
     const int gemm_taps = form == VS_PACK_SCATTER_D1 ? 1 : ntaps;
@@ -61,6 +74,7 @@ extern "C" int vs_pack_weight_multi(const vs_pack_desc* descs, int n_desc, int t
 }
 
 static long long packed_elems(int rows, int c_pad, int gemm_taps, int dtype) {
+    if (vs_k3_toeplitz(rows, c_pad, gemm_taps, dtype)) return 9 * 64 * 8;
     const int EPL = dtype == VS_F32 ? 4 : 8, KG = 4 * EPL;
     const int CK = c_pad < 32 ? c_pad : 32;
     const int nch = c_pad / CK;

@@ -44,11 +44,13 @@ def _pick_mt(rows16, tiles):
     return 16
 
 
-def _k3_kid(tname, ck, mt, sums=False, geom=None):
+def _k3_kid(tname, ck, mt, sums=False, geom=None, m=None):
     """kernel instantiation name of a 3x3x3 launch (mirrors g1_dispatch_k3_* / k3b_use_tall in csrc; rocprof prints the same
-    string).  geom = (n, d, h, w) of the convolution's grid."""
+    string).  geom = (n, d, h, w) of the convolution's grid, m = stored output channels."""
     if tname == "float":
         return "k3_kernel<float,%d,%d,0>" % (ck, mt)
+    if ck == 8 and m == 8:
+        return "k3t_kernel<0,%s,8>" % ("true" if sums else "false")
     yt = 4
     if geom is not None and ck < 32 and mt == 16 and os.environ.get("VS_K3_TALL", "") != "0":
         n, d, h, w = geom
@@ -346,7 +348,7 @@ def conv_gather(x, xs, wp, bias, m_out, kind, want_stats, real_channels=None):
         rows16 = (m_out + 15) // 16 * 16
         tname = "float" if x.dtype == torch.float32 else "unsigned short"
         if kind == VS_CONV_K3:
-            kid = _k3_kid(tname, ck, _pick_mt(rows16, tiles), geom=(n, d, h, w))
+            kid = _k3_kid(tname, ck, _pick_mt(rows16, tiles), geom=(n, d, h, w), m=m_out)
         else:
             kid = "g1_kernel<%s,%d,%d,%d,0>" % (tname, ck, kind, _pick_mt(rows16, tiles))
         cr = real_channels[0] if real_channels else c
@@ -406,7 +408,7 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
                 tiles = n * ((g.numel() // (n * c) + 255) // 256)
             tname = "float" if x.dtype == torch.float32 else "unsigned short"
             if kind == VS_CONV_K3:
-                kid = _k3_kid(tname, min(gc, 32), _pick_mt((c + 15) // 16 * 16, tiles), sums=True, geom=(gn, gd, gh, gw))
+                kid = _k3_kid(tname, min(gc, 32), _pick_mt((c + 15) // 16 * 16, tiles), sums=True, geom=(gn, gd, gh, gw), m=c)
             else:
                 kid = "g1_kernel<%s,%d,%d,%d,0>" % (tname, min(gc, 32), kind, _pick_mt((c + 15) // 16 * 16, tiles))
             cr = real_channels[0] if real_channels else gc
