@@ -37,8 +37,11 @@ def test_argument_validation_without_gpu():
     assert lib.vs_conv_gather_fwd(None, None, None, None, None, None, 1, 4, 4, 4, 8, 8, 0, 0, 1e-5, None) == -1
     assert lib.vs_pack_weight(None, None, 8, 8, 27, 8, 0, 0, None) == -1
     assert lib.vs_dice_fwd(None, None, None, None, None, 1, 2, 64, 1, 2, 1e-4, None) == -1
-    # packed-weight sizing is pure host arithmetic: 16 rows x (27 taps x 8 ch -> 7 k-groups of 32) bf16 fragments
-    assert lib.vs_packed_weight_bytes(8, 8, 27, 1) == 1 * 1 * 7 * 64 * 8 * 2
+    # packed-weight sizing is pure host arithmetic: 16 rows x (27 taps x 8 ch -> 7 k-groups of 32) bf16 fragments ...
+    assert lib.vs_packed_weight_bytes(16, 8, 27, 1) == 1 * 1 * 7 * 64 * 8 * 2
+    # ... except the 8-channel 3x3x3 layers (<= 8 rows, bf16), packed as 9 Toeplitz k-groups (tz, ty) for k3t_kernel
+    assert lib.vs_packed_weight_bytes(8, 8, 27, 1) == 9 * 64 * 8 * 2
+    assert lib.vs_packed_weight_bytes(8, 8, 27, 0) == 1 * 1 * 14 * 64 * 4 * 4        # fp32 keeps the standard order
     assert lib.vs_packed_weight_bytes(64, 64, 27, 0) == 4 * 2 * 54 * 64 * 4 * 4
     assert lib.vs_conv_wgrad_workspace_bytes(2, 96, 96, 96, 8, 8, 0) > 0
     # maximum sizes: shapes the 32-bit offsets of the kernels cannot address are refused (VS_ESHAPE = -2), never mis-computed.
