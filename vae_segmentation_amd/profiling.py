@@ -104,8 +104,21 @@ def dominant_kernel_roofline(fwd_bwd, params, dtype, steps=2, kernel=None):
     else:
         ach, peak, unit, bound = a["flops"] / sec / 1e12, mfma_peak, "TFLOP/s", "mfma"
     top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:6]
+
+    def bound_of(v):
+        peak_tf = MFMA_PEAK_TFLOPS["f32"] if "float" in v[0] else MFMA_PEAK_TFLOPS["bf16"]
+        s = v[1]["ms"] * 1e-3
+        if v[1]["bytes"] / (HBM_PEAK_GBS * 1e9) >= v[1]["flops"] / (peak_tf * 1e12):
+            return {"kernel": v[0], "bound": "hbm", "achieved": round(v[1]["bytes"] / s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(v[1]["bytes"] / s / 1e9 / HBM_PEAK_GBS, 4), "launches_per_step": v[1]["launches"],
+                    "avg_launch_us": round(1e3 * v[1]["ms"] / v[1]["launches"], 2), "traffic": measured_traffic(v[0])}
+        return {"kernel": v[0], "bound": "mfma", "achieved": round(v[1]["flops"] / s / 1e12, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                "frac": round(v[1]["flops"] / s / 1e12 / peak_tf, 4), "launches_per_step": v[1]["launches"],
+                "avg_launch_us": round(1e3 * v[1]["ms"] / v[1]["launches"], 2), "traffic": measured_traffic(v[0])}
     return {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "traffic": measured_traffic(kid),
             "kernel": kid, "launches_per_step": a["launches"], "avg_launch_us": 1e3 * a["ms"] / a["launches"],
             "share_of_timed_kernel_time": a["ms"] / total_ms, "event_bracket_overhead_us_subtracted": round(LAST_EVENT_OVERHEAD_US, 2),
             "algorithmic_bytes_per_launch": a["bytes"] / a["launches"], "algorithmic_flops_per_launch": a["flops"] / a["launches"],
-            "top_kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in top}}
+            "top_kernels_ms_per_step": {k: round(v["ms"], 4) for k, v in top},
+            # the same figures for the other heavy kernels, each against the roofline that bounds it (algorithmic bytes or flops)
+            "other_kernels": [bound_of(v) for v in top if v[0] != kid]}
