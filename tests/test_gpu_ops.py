@@ -337,13 +337,14 @@ def test_dropout_forward_backward_share_the_mask(dtype):
     """F.dropout(training=True) semantics with a counter-based mask: kept fraction ~ 1-p, kept values scaled by 1/(1-p),
     the backward applies the SAME mask, a different seed gives a different mask."""
     ops = _ops()
+    torch.manual_seed(1234)                       # the mask seed derives from torch's seed: fixed here, so the 2.8-sigma bound below cannot flake
     x = (rnd(2, 16, 8, 8, 8, seed=40).abs() + 0.5)
     x_cl = to_cl(x, 16, dtype).requires_grad_(True)
     p, seed = 0.3, ops.next_dropout_seed()
     y = ops.Dropout.apply(x_cl, p, seed)
     keep = (y != 0)
     frac = keep.float().mean().item()
-    assert abs(frac - (1 - p)) < 0.01
+    assert abs(frac - (1 - p)) < 0.015             # 16384 draws: sigma = 0.0036
     ratio = (y.float()[keep] / x_cl.detach().float()[keep])
     assert float((ratio - 1 / (1 - p)).abs().max()) < (2e-2 if dtype == torch.bfloat16 else 1e-5)
     g = to_cl(rnd(2, 16, 8, 8, 8, seed=41).abs() + 0.5, 16, dtype)

@@ -148,28 +148,33 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
             const u32x4* wch = wp + (size_t)ch * NKG * 64 + lane;
             const size_t rb_stride = (size_t)p.nch * NKG * 64;
             if constexpr (KG > CK) {
-                // several taps per k-group: per-lane tap = kg*TPK + (g*EPL)/CK
+                // several taps per k-group: per-lane tap = kg*TPK + (g*EPL)/CK.  Every A and B fragment of the chunk (NKG <= 4 k-groups)
+                // is requested before the first MFMA: issued inside the k-group loop each load was used at once and a 16-channel
+                // stride-2 conv at 96^3 paid four memory round trips in a row.
                 const int sub = (g * EPL) / CK;
+                u32x4 aq[NKG][RB], bq[NKG][4];
 #pragma unroll
                 for (int kg = 0; kg < NKG; ++kg) {
-                    u32x4 a[RB];
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb) a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
-                    u32x4 b[4];
+                    for (int rb = 0; rb < RB; ++rb) aq[kg][rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
                     const int tap = kg * TPK + sub;
                     const int tt = tap < NTAPS ? tap : 0;
                     const int dz = (tt >> 2) & 1, dy = (tt >> 1) & 1, dx = tt & 1;
                     const long long toff = (((long long)dz * p.H + dy) * p.W + dx) * p.C + ch * CK + (g * EPL) % CK;
 #pragma unroll
-                    for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(xin + gofs[cg] + toff);
+                    for (int cg = 0; cg < 4; ++cg) bq[kg][cg] = *(const u32x4*)(xin + gofs[cg] + toff);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kg = 0; kg < NKG; ++kg) {
                     if (HS) {
 #pragma unroll
-                        for (int cg = 0; cg < 4; ++cg) b[cg] = act_transform<T, CK>(b[cg], s_mean, s_rstd, ch * CK + (g * EPL) % CK);
+                        for (int cg = 0; cg < 4; ++cg) bq[kg][cg] = act_transform<T, CK>(bq[kg][cg], s_mean, s_rstd, ch * CK + (g * EPL) % CK);
                     }
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                        for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
+                        for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(aq[kg][rb], bq[kg][cg], acc[rb][cg], (T*)nullptr);
                 }
             } else {
                 // wave-uniform tap; KPT k-groups per tap.
