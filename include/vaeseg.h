@@ -257,6 +257,10 @@ int vs_scale_copy(const float* src, float* dst, long long count, float scale, vo
  * queued when it retires; without it every packet of an eager step meets an idle queue and the bracket measures the
  * command processor's wake-up latency (2-7 us) on top of the kernel. */
 int vs_spin(int microseconds, void* stream);
+/* Measurement aid: `n_wg` (<= 1024, all resident) workgroups pass `iters` device-wide barriers (one release store per workgroup into
+ * flags[n_wg], every workgroup polls all flags); ticks[n_wg] receives each workgroup's 100 MHz-clock ticks for the whole loop.
+ * mode 1: one shared counter (fetch-add + poll) instead.  flags must be zero on entry.  Answers "what would fusing two dependent launches into one cost?" (profiles/README.md). */
+int vs_debug_grid_barrier_probe(unsigned int* flags, unsigned long long* ticks, int n_wg, int iters, int mode, void* stream);
 
 #ifdef __cplusplus
 }

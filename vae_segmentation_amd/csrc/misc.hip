@@ -139,10 +139,13 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const void* __restrict_
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
     const float* wr = w + (size_t)j * k_in;
-    for (int k0 = threadIdx.x; k0 < k_in; k0 += 256 * 4) {
-        float wv[4], xv[4][NB];
+    // LU k-steps per round: the 6912-wide bottleneck layers finish in two rounds of independent loads (with 4 per round the seven
+    // dependent rounds made this 22 us for 3.5 MB of weights)
+    constexpr int LU = NB <= 2 ? 16 : (NB <= 4 ? 8 : 4);
+    for (int k0 = threadIdx.x; k0 < k_in; k0 += 256 * LU) {
+        float wv[LU], xv[LU][NB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < LU; ++u) {
             const int k = k0 + u * 256;
             const bool ok = k < k_in;
             wv[u] = ok ? wr[k] : 0.f;
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const void* __restrict_
             for (int b = 0; b < NB; ++b) xv[u][b] = ld_any(x, x_dtype, (long long)(b < batch ? b : batch - 1) * k_in + ph);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < LU; ++u)
 #pragma unroll
             for (int b = 0; b < NB; ++b) acc[b] += wv[u] * xv[u][b];
     }
@@ -842,6 +845,46 @@ __global__ void spin_kernel(unsigned long long ticks) {
 extern "C" int vs_spin(int microseconds, void* stream) {
     if (microseconds < 0 || microseconds > 1000) return VS_EINVAL;
     hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// ---- measurement aid: cost of a device-wide barrier between resident workgroups ------------------------------------------
+__global__ __launch_bounds__(256) void grid_barrier_probe_kernel(unsigned int* flags, unsigned long long* ticks, int n_wg, int iters, int mode) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    __shared__ int s_fail;
+    if (threadIdx.x == 0) s_fail = 0;
+    __syncthreads();
+    if (mode == 1) {
+        // one counter: every workgroup adds 1 and its thread 0 polls the counter (n serialized atomics + n pollers of one word)
+        for (int it = 1; it <= iters; ++it) {
+            if (threadIdx.x == 0) {
+                __hip_atomic_fetch_add(flags, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                while (__hip_atomic_load(flags, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)it * (unsigned int)n_wg && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(2);
+                if (spins >= (1 << 20)) s_fail = 1;
+            }
+            __syncthreads();
+            if (s_fail) break;
+        }
+        if (threadIdx.x == 0) ticks[blockIdx.x] = s_fail ? ~0ull : __builtin_amdgcn_s_memrealtime() - t0;
+        return;
+    }
+    for (int it = 1; it <= iters; ++it) {
+        if (threadIdx.x == 0) __hip_atomic_store(flags + blockIdx.x, (unsigned int)it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = threadIdx.x; i < n_wg; i += 256) {
+            int spins = 0;                               // bounded: a workgroup that is not resident must not hang the others
+            while (__hip_atomic_load(flags + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)it && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+            if (spins >= (1 << 20)) s_fail = 1;
+        }
+        __syncthreads();
+        if (s_fail) break;
+    }
+    if (threadIdx.x == 0) ticks[blockIdx.x] = s_fail ? ~0ull : __builtin_amdgcn_s_memrealtime() - t0;
+}
+extern "C" int vs_debug_grid_barrier_probe(unsigned int* flags, unsigned long long* ticks, int n_wg, int iters, int mode, void* stream) {
+    if (!flags || !ticks || n_wg <= 0 || n_wg > 1024 || iters <= 0 || iters > 100000) return VS_EINVAL;
+    hipLaunchKernelGGL(grid_barrier_probe_kernel, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, flags, ticks, n_wg, iters, mode);
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
