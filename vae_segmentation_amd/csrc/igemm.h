@@ -111,6 +111,11 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         }
     }
     // ---- column geometry: 256 output voxels per workgroup, 64 per wave ----
+    // Small volumes (<= 64 output voxels per sample: the 3^3 level, where only wave 0 would have real columns and the four waves would
+    // each walk all C/32 chunks — one memory round trip per chunk — on padding): the waves share wave 0's columns and SPLIT the channel
+    // chunks (wave w takes chunks w, w+4, ...); the partial accumulators are summed through LDS in wave order before the epilogue.
+    const bool splitw = KIND == G1_K2S2 && CK == 32 && p.Do * p.Ho * p.Wo <= 64 && p.nch >= 2;
+    const int cwave = splitw ? 0 : wave;
     long long gofs[4];                          // element offset of the column's input voxel (tap 0)
     bool cvalid[4];
     int oz[4], oy[4], ox[4];
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         const int vcol = p.Do * p.Ho * p.Wo;             // < 2^31 (host check); 32-bit divisions: the 64-bit ones cost ~100 instructions each
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) {
-            int v = tile * 256 + wave * 64 + cg * 16 + col;
+            int v = tile * 256 + cwave * 64 + cg * 16 + col;
             cvalid[cg] = v < vcol;
             if (!cvalid[cg]) v = 0;
             ox[cg] = v % p.Wo;
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     // round trips per chunk).
     auto chunk_loop = [&](auto hs_tag) {
         constexpr bool HS = decltype(hs_tag)::value;
-        for (int ch = 0; ch < p.nch; ++ch) {
+        for (int ch = splitw ? wave : 0; ch < p.nch; ch += splitw ? 4 : 1) {
             const u32x4* wch = wp + (size_t)ch * NKG * 64 + lane;
             const size_t rb_stride = (size_t)p.nch * NKG * 64;
             if constexpr (KG > CK) {
@@ -253,6 +258,30 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         }
     };
     if (has_stats) chunk_loop(std::true_type{}); else chunk_loop(std::false_type{});
+    if (splitw) {
+        // fixed order w0 + w1 + w2 + w3 (bitwise reproducible); waves 1-3 then hold no columns of their own
+        f32x4* s_part = (f32x4*)(smem + G1_LDS_BYTES);   // [3 waves][RB][4][64 lanes]
+        if (wave > 0) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) s_part[(((wave - 1) * RB + rb) * 4 + cg) * 64 + lane] = acc[rb][cg];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 0; w < 3; ++w)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) {
+                        const f32x4 o = s_part[((w * RB + rb) * 4 + cg) * 64 + lane];
+                        acc[rb][cg][0] += o[0]; acc[rb][cg][1] += o[1]; acc[rb][cg][2] += o[2]; acc[rb][cg][3] += o[3];
+                    }
+        } else {
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) cvalid[cg] = false;
+        }
+    }
 
     // ------------------------------------------------------------------------------------------
     // epilogues
@@ -404,7 +433,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
 
 template <typename T, int CK, int KIND, int MT, int EPI>
 static int g1_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
-    constexpr size_t lds = G1_LDS_BYTES;
+    constexpr size_t lds = G1_LDS_BYTES + (KIND == G1_K2S2 && CK == 32 ? (size_t)3 * (MT / 16) * 4 * 64 * 16 : 0);   // + the wave-split partials
     auto kern = g1_kernel<T, CK, KIND, MT, EPI>;
     hipLaunchKernelGGL(kern, dim3(tiles_total, row_tiles), dim3(256), lds, stream, p);
     VS_CHECK_LAUNCH();
