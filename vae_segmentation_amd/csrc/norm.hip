@@ -268,12 +268,15 @@ static int check_cl(const void* a, int n, long long voxels, int c, int dtype) {
     if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
     return VS_OK;
 }
-static int row_blocks(long long voxels, int c, int dtype) {
+static int row_blocks(long long voxels, int c, int dtype, bool atomics = true) {
     const int frags = c / (dtype == VS_F32 ? 4 : 8);
     const int rpi = 256 / frags;
     long long b = (voxels + rpi - 1) / rpi;
-    // each block should stream >= ~16 iterations; cap at 8 blocks per CU overall
-    long long cap = (voxels + (long long)rpi * 16 - 1) / ((long long)rpi * 16);
+    // each block should stream >= ~16 iterations; cap at 8 blocks per CU overall.  Small tensors (the 24^3 / 48^3 skip merges: 28-108 blocks
+    // of 16 dependent rounds = 21 us for 2.6 MB) are latency-bound instead: 4 rounds per block, four times the blocks.
+    // (kernels that end in fp64 atomics keep 16: more blocks cost more same-address atomics than the shorter loop saves)
+    const int rounds = (!atomics && (double)voxels * c <= 2097152.0) ? 4 : 16;
+    long long cap = (voxels + (long long)rpi * rounds - 1) / ((long long)rpi * rounds);
     if (cap < 1) cap = 1;
     if (cap > 2048) cap = 2048;
     return (int)(b < cap ? b : cap);
@@ -300,7 +303,7 @@ extern "C" int vs_instnorm_relu_fwd(const void* x, const double* x_stats, const 
     int rc = check_cl(x, n, voxels, c, dtype);
     if (rc) return rc;
     if (!out) return VS_EINVAL;
-    dim3 grid(row_blocks(voxels, c, dtype), n);
+    dim3 grid(row_blocks(voxels, c, dtype, false), n);
     const double inv = 1.0 / (double)voxels;
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(in_relu_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, x_stats, (const float*)x2, x2_stats, (float*)out, voxels, c, inv, eps),
