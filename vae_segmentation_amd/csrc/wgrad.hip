@@ -880,8 +880,9 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
         for (int i = 0; i < count; ++i) {
             const MultiLayer& L = plan.layers[i];
             const long long slab_elems = (long long)L.p.mbn * L.p.cbn * L.ncb * 256;
+            // a partition sums up to 8 slabs in one round of independent loads: no more partitions (= threads, waves) than that needs
             int parts = 1;
-            while (parts < 16 && parts < L.p.ksplit) parts *= 2;
+            while (parts < 16 && parts * 8 < L.p.ksplit) parts *= 2;
             red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.p.ksplit, L.cbsz,
                                     L.kind == VS_CONV_K3 ? 27 : 8, L.ncb, 0, parts});
             blocks.push_back(vs_ceil_div(slab_elems, 64 * (16 / parts)));
