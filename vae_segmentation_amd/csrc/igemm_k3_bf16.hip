@@ -1,6 +1,7 @@
 #include "igemm_dispatch.h"
 #include "igemm_k3b.h"
 #include "igemm_k3t.h"
+#include "igemm_k3s.h"
 
 #define K3B_CASE(CKV, MTV)                                                                              \
     if (ck == CKV && mt == MTV)                                                                          \
@@ -14,6 +15,8 @@ int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, i
         if (epi == EPI_SOFTMAX2) return k3t_launch<EPI_SOFTMAX2, false, 8>(p, s);
         return p.sums ? k3t_launch<EPI_RAW, true, 8>(p, s) : k3t_launch<EPI_RAW, false, 8>(p, s);
     }
+    if (epi == EPI_RAW && k3s_takes(p, ck))                 // the small volumes of the deep levels: flattened columns, waves split the taps
+        return p.sums ? k3s_launch<true>(p, s) : k3s_launch<false>(p, s);
     const bool tall = mt == 16 && ck < 32 && k3b_use_tall(p);
     if (epi == EPI_SOFTMAX2) return VS_ESHAPE;           // out_block is an 8-channel layer (above)
     if (tall) {

@@ -51,6 +51,9 @@ def _k3_kid(tname, ck, mt, sums=False, geom=None, m=None):
         return "k3_kernel<float,%d,%d,0>" % (ck, mt)
     if ck == 8 and m == 8:
         return "k3t_kernel<0,%s,8>" % ("true" if sums else "false")
+    if ck == 32 and geom is not None and max(geom[1:]) <= 8 and os.environ.get("VS_K3_SMALL", "") != "0":
+        tv = (geom[1] + 2) * (geom[2] + 2) * (geom[3] + 2)
+        return "k3s_kernel<%s,%d>" % ("true" if sums else "false", 128 if tv <= 128 else (512 if tv <= 512 else 1024))
     yt = 4
     if geom is not None and ck < 32 and mt == 16 and os.environ.get("VS_K3_TALL", "") != "0":
         n, d, h, w = geom
