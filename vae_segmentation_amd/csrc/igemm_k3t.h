@@ -24,11 +24,12 @@
 template <int YT>
 struct K3TGeom {
     static constexpr int PX = 34, PY = YT + 2, PLANE = PX * PY, TV = 6 * PLANE;
-    static constexpr int TILE_BYTES = TV * 16;
+    static constexpr int TILE_BYTES = ((TV + 255) / 256) * 256 * 16;     // every thread stores all its NIT fragments (no exec-masked tail)
     static constexpr int NIT = (TV + 255) / 256;
 };
 
-template <int EPI, bool SUMS, int YT>
+// HS: lazy input (normalise + ReLU while staging), compile-time like every condition on the staging path
+template <int EPI, bool SUMS, int YT, bool HS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k3t_kernel(const G1Params p) {
     K3_TICK_INIT
     using GEO = K3TGeom<YT>;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int dx2 = g >> 1, c4 = 4 * (g & 1);            // this lane's accumulator rows: output voxel x = 2*col + dx2, channels c4..c4+3
-    const bool has_stats = !SUMS && p.x_stats != nullptr;
+    constexpr bool has_stats = HS;
     const int total_tiles = p.tiles_per_sample * p.N;
     const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * 16));
 
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
             }
-            if (b < NIT - 1 || tid + b * 256 < TV) *(u32x4*)(s_tile + (tid + b * 256) * 16) = v;
+            *(u32x4*)(s_tile + (tid + b * 256) * 16) = v;      // fragments beyond TV are zeros in the padded tail of the tile region
         }
     };
 
@@ -288,8 +289,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     K3_TICK_FLUSH;
 }
 
-template <int EPI, bool SUMS, int YT>
-static int k3t_launch(const G1Params& p_in, hipStream_t stream) {
+template <int EPI, bool SUMS, int YT, bool HS>
+static int k3t_launch_t(const G1Params& p_in, hipStream_t stream) {
     using GEO = K3TGeom<YT>;
     G1Params p = p_in;
     if (p.C != 8 || p.M != 8) return VS_ESHAPE;
@@ -305,7 +306,7 @@ static int k3t_launch(const G1Params& p_in, hipStream_t stream) {
     k3b_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3b_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
     if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr)) return VS_EINVAL;
-    auto kern = k3t_kernel<EPI, SUMS, YT>;
+    auto kern = k3t_kernel<EPI, SUMS, YT, HS>;
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
@@ -318,4 +319,10 @@ static int k3t_launch(const G1Params& p_in, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, stream, p);
     VS_CHECK_LAUNCH();
     return VS_OK;
+}
+
+template <int EPI, bool SUMS, int YT>
+static int k3t_launch(const G1Params& p, hipStream_t stream) {
+    if (!SUMS && p.x_stats != nullptr) return k3t_launch_t<EPI, SUMS, YT, !SUMS>(p, stream);
+    return k3t_launch_t<EPI, SUMS, YT, false>(p, stream);
 }
