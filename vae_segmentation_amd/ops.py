@@ -44,16 +44,17 @@ def _pick_mt(rows16, tiles):
     return 16
 
 
-def _k3_kid(tname, ck, mt, sums=False, geom=None, m=None):
+def _k3_kid(tname, ck, mt, sums=False, geom=None, m=None, lazy=False):
     """kernel instantiation name of a 3x3x3 launch (mirrors g1_dispatch_k3_* / k3b_use_tall in csrc; rocprof prints the same
     string).  geom = (n, d, h, w) of the convolution's grid, m = stored output channels."""
     if tname == "float":
         return "k3_kernel<float,%d,%d,0>" % (ck, mt)
+    hs = "true" if (lazy and not sums) else "false"
     if ck == 8 and m == 8:
-        return "k3t_kernel<0,%s,8>" % ("true" if sums else "false")
+        return "k3t_kernel<0,%s,8,%s>" % ("true" if sums else "false", hs)
     if ck == 32 and geom is not None and max(geom[1:]) <= 8 and os.environ.get("VS_K3_SMALL", "") != "0":
         tv = (geom[1] + 2) * (geom[2] + 2) * (geom[3] + 2)
-        return "k3s_kernel<%s,%d>" % ("true" if sums else "false", 128 if tv <= 128 else (512 if tv <= 512 else 1024))
+        return "k3s_kernel<%s,%d,%s>" % ("true" if sums else "false", 128 if tv <= 128 else (512 if tv <= 512 else 1024), hs)
     yt = 4
     if geom is not None and ck < 32 and mt == 16 and os.environ.get("VS_K3_TALL", "") != "0":
         n, d, h, w = geom
@@ -351,7 +352,7 @@ def conv_gather(x, xs, wp, bias, m_out, kind, want_stats, real_channels=None):
         rows16 = (m_out + 15) // 16 * 16
         tname = "float" if x.dtype == torch.float32 else "unsigned short"
         if kind == VS_CONV_K3:
-            kid = _k3_kid(tname, ck, _pick_mt(rows16, tiles), geom=(n, d, h, w), m=m_out)
+            kid = _k3_kid(tname, ck, _pick_mt(rows16, tiles), geom=(n, d, h, w), m=m_out, lazy=xs is not None)
         else:
             kid = "g1_kernel<%s,%d,%d,%d,0>" % (tname, ck, kind, _pick_mt(rows16, tiles))
         cr = real_channels[0] if real_channels else c
