@@ -53,14 +53,16 @@ struct K3BGeom {
     static constexpr bool SMALLC = CK < 32;                                  // several taps per 32-wide k-group, one chunk
     static constexpr int NKGC = SMALLC ? (27 * CK + 31) / 32 : 27;           // k-groups per channel chunk
     static constexpr int CKB = CK * 2;
-    static constexpr int TILE_BYTES = TV * CKB;
+    static constexpr int TILE_BYTES = ((TV * (CKB / 16) + 255) / 256) * 256 * 16;     // padded: every thread stores all its fragments
     static constexpr int NWF = RB * NKGC * 64;                               // 16-byte weight fragments per chunk per workgroup
-    static constexpr int W_BYTES = NWF * 16;
+    static constexpr int W_BYTES = ((NWF + 255) / 256) * 256 * 16;                     // padded likewise
 };
 
 // register budget: 4 workgroups per CU (one wave per SIMD each) for the small-channel kernels, 2 for the 32-channel chunks
 // SUMS: backward-data use (input = a materialised gradient, no statistics; epilogue accumulates the fused IN-backward sums)
-template <int CK, int MT, int EPI, bool SUMS, int YT = 4>
+// HS: the input is a lazy activation — compile-time, like every condition on the staging path (a run-time test between a load and its
+// use, or an exec-masked tail store, makes the compiler drain vmcnt(0): it then waits for the prefetched stage as well)
+template <int CK, int MT, int EPI, bool SUMS, int YT = 4, bool HS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     YT == 8 ? 2 : (CK == 32 ? (MT == 32 ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : (CK == 16 && SUMS ? 3 : 4))), 8))) void k3b_kernel(const G1Params p) {
     typedef unsigned short T;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int rb0 = blockIdx.y * RB;
-    const bool has_stats = !SUMS && p.x_stats != nullptr;
+    constexpr bool has_stats = HS;
     constexpr bool has_sums = SUMS;
     const int total_tiles = p.tiles_per_sample * p.N;
     const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.C * 2));
@@ -175,13 +177,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
             }
             const int pw = CK == 32 ? (part ^ (int)(((swzbits >> b) & 1u) << 1)) : part;
-            if (b < NIT - 1 || tid + b * 256 < NU) *(u32x4*)(s_tile + lds_w0 + b * 4096 + pw * 16) = v;
+            *(u32x4*)(s_tile + lds_w0 + b * 4096 + pw * 16) = v;      // fragments beyond the tile are zeros in the padded tail
         }
     };
     auto write_w = [&]() {
 #pragma unroll
         for (int i = 0; i < NWI; ++i)
-            if (i < NWI - 1 || tid + i * 256 < NWF) *(u32x4*)(s_w + (tid + i * 256) * 16) = wv[i];
+            *(u32x4*)(s_w + (tid + i * 256) * 16) = wv[i];
     };
 
     // ---- first stage in flight before anything else; the statistics tables meanwhile ----------------------------------
@@ -443,8 +445,8 @@ static inline void k3b_fastdiv(int d, unsigned int& m, unsigned int& s) {
     m = (unsigned int)((((1ull << (32 + s)) + (unsigned long long)d - 1) / (unsigned long long)d) - (1ull << 32));
 }
 
-template <int CK, int MT, int EPI, bool SUMS, int YT = 4>
-static int k3b_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
+template <int CK, int MT, int EPI, bool SUMS, int YT, bool HS>
+static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
     using GEO = K3BGeom<CK, MT, YT>;
     const size_t tables = (size_t)2 * p_in.N * p_in.C * sizeof(float) + (p_in.sums ? (size_t)2 * p_in.N * p_in.M * sizeof(float) : 0);
     const size_t lds = K3B_LDS_TILE + (size_t)GEO::TILE_BYTES + GEO::W_BYTES + tables;
@@ -461,7 +463,7 @@ static int k3b_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipS
     k3b_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3b_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
     if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr)) return VS_EINVAL;
-    auto kern = k3b_kernel<CK, MT, EPI, SUMS, YT>;
+    auto kern = k3b_kernel<CK, MT, EPI, SUMS, YT, HS>;
     // idempotent one-time opt-in to the full 160 KiB of dynamic LDS (not a stream operation)
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -476,6 +478,12 @@ static int k3b_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipS
     hipLaunchKernelGGL(kern, dim3(gx, row_tiles), dim3(256), lds, stream, p);
     VS_CHECK_LAUNCH();
     return VS_OK;
+}
+
+template <int CK, int MT, int EPI, bool SUMS, int YT = 4>
+static int k3b_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
+    if (!SUMS && p.x_stats != nullptr) return k3b_launch_t<CK, MT, EPI, SUMS, YT, !SUMS>(p, tiles_total, row_tiles, stream);
+    return k3b_launch_t<CK, MT, EPI, SUMS, YT, false>(p, tiles_total, row_tiles, stream);
 }
 
 // Tall (4x8x16) tiles: measured faster (16->16 @48^3: 19.4 -> 15.4 us) where the layer is one wave of workgroups anyway — fewer,
