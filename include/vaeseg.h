@@ -155,6 +155,11 @@ int vs_instnorm_relu_bwd_reduce(const void* g, const void* x, const double* x_st
                                 int n, long long voxels, int c, int dtype, float eps, void* stream);
 int vs_instnorm_relu_bwd_apply(const void* g, const void* x, const double* x_stats, const double* sums,
                                void* gx, int n, long long voxels, int c, int dtype, float eps, void* stream);
+/* The backward of the additive skip a = relu(instnorm(x1)) + relu(instnorm(x2)) (joint_model.py:380,382): one gradient g, both
+ * operands' reduce in one launch and both applies in one (sums1 / sums2 ACCUMULATED: caller zeroes; gx1 / gx2 distinct from g). */
+int vs_instnorm_relu_bwd_pair(const void* g, const void* x1, const double* x1_stats, double* sums1, void* gx1,
+                              const void* x2, const double* x2_stats, double* sums2, void* gx2, int n, long long voxels,
+                              int c, int dtype, float eps, void* stream);
 
 /* F.dropout(x, p, training=True) on a channels-last tensor (joint_model.py:256-264,379-385): out = x * keep / (1-p),
  * keep ~ Bernoulli(1-p) from a counter-based hash of (seed, element index) — the same call with the same seed applied to

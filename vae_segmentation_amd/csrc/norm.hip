@@ -110,9 +110,9 @@ __global__ __launch_bounds__(256) void in_relu_fwd_kernel(const T* __restrict__ 
 
 // ---- backward: reductions ------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void in_relu_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ x, const double* xs,
-                                                                 double* __restrict__ sums, long long voxels, int c,
-                                                                 double inv_count, float eps) {
+__device__ __forceinline__ void in_relu_bwd_reduce_body(const T* __restrict__ g, const T* __restrict__ x, const double* xs,
+                                                        double* __restrict__ sums, long long voxels, int c,
+                                                        double inv_count, float eps) {
     constexpr int EPL = ET<T>::EPL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* s_red = (double*)smem;
@@ -168,12 +168,27 @@ __global__ __launch_bounds__(256) void in_relu_bwd_reduce_kernel(const T* __rest
     }
     reduce_and_atomic<T, 2>(it, part, sums, n, c, s_red);
 }
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ x, const double* xs,
+                                                                 double* __restrict__ sums, long long voxels, int c,
+                                                                 double inv_count, float eps) {
+    in_relu_bwd_reduce_body<T>(g, x, xs, sums, voxels, c, inv_count, eps);
+}
+// The additive U-Net skip (joint_model.py:380,382) sends ONE gradient g to two lazy operands: blockIdx.z picks the operand, so the
+// reduce and the apply of both are one launch each instead of two.
+struct InBwdPair { const void* x[2]; const double* xs[2]; double* sums[2]; void* gx[2]; };
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_bwd_reduce2_kernel(const T* __restrict__ g, const InBwdPair a, long long voxels, int c,
+                                                                  double inv_count, float eps) {
+    const int op = blockIdx.z;
+    in_relu_bwd_reduce_body<T>(g, (const T*)a.x[op], a.xs[op], a.sums[op], voxels, c, inv_count, eps);
+}
 
 // ---- backward: apply -----------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void in_relu_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x, const double* xs,
-                                                                const double* __restrict__ sums, T* __restrict__ gx,
-                                                                long long voxels, int c, double inv_count, float eps) {
+__device__ __forceinline__ void in_relu_bwd_apply_body(const T* __restrict__ g, const T* __restrict__ x, const double* xs,
+                                                       const double* __restrict__ sums, T* __restrict__ gx,
+                                                       long long voxels, int c, double inv_count, float eps) {
     // Streaming pass, 3 tensors: a thread keeps UN (g, x) fragment pairs in flight and requests the next batch before it
     // works on the current one; the first batch is requested before the statistics tables are built, so the kernel's
     // start-up is one memory round trip, not two (most of its 58 launches per step are small and start-up bound).
@@ -231,6 +246,18 @@ __global__ __launch_bounds__(256) void in_relu_bwd_apply_kernel(const T* __restr
             *(u32x4*)(gx + sample + vv * c) = frag_pack(o, (T*)nullptr);
         }
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x, const double* xs,
+                                                                const double* __restrict__ sums, T* __restrict__ gx,
+                                                                long long voxels, int c, double inv_count, float eps) {
+    in_relu_bwd_apply_body<T>(g, x, xs, sums, gx, voxels, c, inv_count, eps);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void in_relu_bwd_apply2_kernel(const T* __restrict__ g, const InBwdPair a, long long voxels, int c,
+                                                                 double inv_count, float eps) {
+    const int op = blockIdx.z;
+    in_relu_bwd_apply_body<T>(g, (const T*)a.x[op], a.xs[op], a.sums[op], (T*)a.gx[op], voxels, c, inv_count, eps);
 }
 
 // ---- bias gradient ---------------------------------------------------------------------------------
@@ -341,6 +368,32 @@ extern "C" int vs_instnorm_relu_bwd_apply(const void* g, const void* x, const do
     DISPATCH_T(dtype,
         hipLaunchKernelGGL(in_relu_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)x, x_stats, sums, (float*)gx, voxels, c, inv, eps),
         hipLaunchKernelGGL(in_relu_bwd_apply_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)g, (const unsigned short*)x, x_stats, sums, (unsigned short*)gx, voxels, c, inv, eps));
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_instnorm_relu_bwd_pair(const void* g, const void* x1, const double* x1_stats, double* sums1, void* gx1,
+                                         const void* x2, const double* x2_stats, double* sums2, void* gx2, int n, long long voxels,
+                                         int c, int dtype, float eps, void* stream) {
+    int rc = check_cl(x1, n, voxels, c, dtype);
+    if (rc) return rc;
+    if (!g || !x2 || !x1_stats || !x2_stats || !sums1 || !sums2 || !gx1 || !gx2) return VS_EINVAL;
+    InBwdPair a;
+    a.x[0] = x1; a.x[1] = x2; a.xs[0] = x1_stats; a.xs[1] = x2_stats; a.sums[0] = sums1; a.sums[1] = sums2; a.gx[0] = gx1; a.gx[1] = gx2;
+    const double inv = 1.0 / (double)voxels;
+    dim3 grid(row_blocks(voxels, c, dtype), n, 2);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(in_relu_bwd_reduce2_kernel<float>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const float*)g, a, voxels, c, inv, eps),
+        hipLaunchKernelGGL(in_relu_bwd_reduce2_kernel<unsigned short>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const unsigned short*)g, a, voxels, c, inv, eps));
+    VS_CHECK_LAUNCH();
+    const int rpi = 256 / (c / (dtype == VS_F32 ? 4 : 8));
+    long long gb = (voxels + (long long)rpi * 4 - 1) / ((long long)rpi * 4);
+    const long long gcap = 2048 / (2 * n) > 0 ? 2048 / (2 * n) : 1;
+    if (gb > gcap) gb = gcap;
+    dim3 grid2((unsigned)gb, n, 2);
+    DISPATCH_T(dtype,
+        hipLaunchKernelGGL(in_relu_bwd_apply2_kernel<float>, grid2, dim3(256), 0, (hipStream_t)stream, (const float*)g, a, voxels, c, inv, eps),
+        hipLaunchKernelGGL(in_relu_bwd_apply2_kernel<unsigned short>, grid2, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)g, a, voxels, c, inv, eps));
     VS_CHECK_LAUNCH();
     return VS_OK;
 }

@@ -756,6 +756,16 @@ class Materialize(torch.autograd.Function):
         x, xs, x2, x2s = ctx.saved_tensors
         g = _contig(g)
         g1 = g2 = None
+        if (x2 is not None and xs is not None and x2s is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[2] and PROFILE is None):
+            # both operands lazy (the U-Net skips): reduce and apply of the two in one launch each
+            n, c = x.shape[0], x.shape[-1]
+            voxels = x.numel() // (n * c)
+            s1, s2 = _new_stats(n, c, x.device), _new_stats(n, c, x.device)
+            g1, g2 = torch.empty_like(g), torch.empty_like(g)
+            check(lib.vs_instnorm_relu_bwd_pair(g.data_ptr(), x.data_ptr(), xs.data_ptr(), s1.data_ptr(), g1.data_ptr(), x2.data_ptr(),
+                                                x2s.data_ptr(), s2.data_ptr(), g2.data_ptr(), n, voxels, c, vs_dtype(x), EPS_IN, _stream()),
+                  "instnorm_relu_bwd_pair")
+            return g1, None, g2, None
         if ctx.needs_input_grad[0]:
             g1 = in_relu_bwd(g, x, xs, inplace=False) if xs is not None else g
         if x2 is not None and ctx.needs_input_grad[2]:
