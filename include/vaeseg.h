@@ -188,6 +188,9 @@ int vs_binarize(const float* a, float* out, long long count, int mode, float lo,
  * (k = c*pv + v); pc == 0 means x is a plain float[B][K].  x_dtype applies to x; y, W, bias are fp32. */
 int vs_linear_fwd(const void* x, int x_dtype, const float* wgt, const float* bias, float* y, int batch, int k_in,
                   int j_out, int pc, int pv, int relu, void* stream);
+/* two layers on the same input (fc_mean and fc_std, joint_model.py:216-217,241-243) in one launch; arguments as vs_linear_fwd */
+int vs_linear_fwd_pair(const void* x, int x_dtype, const float* w1, const float* b1, float* y1, int relu1, const float* w2,
+                       const float* b2, float* y2, int relu2, int batch, int k_in, int j_out, int pc, int pv, void* stream);
 /* y[b][phys(j)] = bias[j] + sum_k W[j][k] * z[b][k]   — fc2: fp32 latent in, channels-last activation out. */
 int vs_linear_fwd_perm_out(const float* z, const float* wgt, const float* bias, void* y, int y_dtype, int batch,
                            int k_in, int j_out, int pc, int pv, void* stream);

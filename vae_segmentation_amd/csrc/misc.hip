@@ -131,9 +131,9 @@ __device__ __forceinline__ void st_any(void* p, int dtype, long long i, float v)
 // time (padding rows re-read row batch-1 and are dropped), k unrolled by 4: 4 weight + 4*NB activation loads are in flight per
 // thread instead of one dependent load per FMA (the bottleneck GEMV is latency-, not bandwidth-bound: 27 k-steps per thread).
 template <int NB>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const void* __restrict__ x, int x_dtype, const float* __restrict__ w,
-                                                         const float* __restrict__ bias, float* __restrict__ y, int batch, int k_in,
-                                                         int j_out, int pc, int pv, int relu) {
+__device__ __forceinline__ void linear_fwd_body(const void* __restrict__ x, int x_dtype, const float* __restrict__ w,
+                                                const float* __restrict__ bias, float* __restrict__ y, int batch, int k_in,
+                                                int j_out, int pc, int pv, int relu) {
     const int j = blockIdx.x;
     float acc[NB];
 #pragma unroll
@@ -171,6 +171,20 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const void* __restrict_
         y[(size_t)threadIdx.x * j_out + j] = s;
     }
 }
+template <int NB>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const void* __restrict__ x, int x_dtype, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int batch, int k_in,
+                                                         int j_out, int pc, int pv, int relu) {
+    linear_fwd_body<NB>(x, x_dtype, w, bias, y, batch, k_in, j_out, pc, pv, relu);
+}
+// fc_mean and fc_std read the same bottleneck activation (joint_model.py:241-243): blockIdx.y picks the layer, one launch for both
+struct LinearPair { const float* w[2]; const float* bias[2]; float* y[2]; int relu[2]; };
+template <int NB>
+__global__ __launch_bounds__(256) void linear_fwd_pair_kernel(const void* __restrict__ x, int x_dtype, const LinearPair a, int batch, int k_in,
+                                                              int j_out, int pc, int pv) {
+    const int op = blockIdx.y;
+    linear_fwd_body<NB>(x, x_dtype, a.w[op], a.bias[op], a.y[op], batch, k_in, j_out, pc, pv, a.relu[op]);
+}
 
 extern "C" int vs_linear_fwd(const void* x, int x_dtype, const float* wgt, const float* bias, float* y, int batch, int k_in,
                              int j_out, int pc, int pv, int relu, void* stream) {
@@ -179,6 +193,19 @@ extern "C" int vs_linear_fwd(const void* x, int x_dtype, const float* wgt, const
 #define LIN_FWD(NB) hipLaunchKernelGGL(linear_fwd_kernel<NB>, dim3(j_out), dim3(256), 0, (hipStream_t)stream, x, x_dtype, wgt, bias, y, batch, k_in, j_out, pc, pv, relu)
     if (batch == 1) LIN_FWD(1); else if (batch == 2) LIN_FWD(2); else if (batch <= 4) LIN_FWD(4); else if (batch <= 8) LIN_FWD(8); else LIN_FWD(16);
 #undef LIN_FWD
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_linear_fwd_pair(const void* x, int x_dtype, const float* w1, const float* b1, float* y1, int relu1, const float* w2,
+                                  const float* b2, float* y2, int relu2, int batch, int k_in, int j_out, int pc, int pv, void* stream) {
+    if (!x || !w1 || !w2 || !y1 || !y2 || batch <= 0 || batch > LIN_MAXB || k_in <= 0 || j_out <= 0) return VS_EINVAL;
+    if (pc > 0 && (long long)pc * pv != k_in) return VS_ESHAPE;
+    LinearPair a;
+    a.w[0] = w1; a.w[1] = w2; a.bias[0] = b1; a.bias[1] = b2; a.y[0] = y1; a.y[1] = y2; a.relu[0] = relu1; a.relu[1] = relu2;
+#define LIN_FWD2(NB) hipLaunchKernelGGL(linear_fwd_pair_kernel<NB>, dim3(j_out, 2), dim3(256), 0, (hipStream_t)stream, x, x_dtype, a, batch, k_in, j_out, pc, pv)
+    if (batch == 1) LIN_FWD2(1); else if (batch == 2) LIN_FWD2(2); else if (batch <= 4) LIN_FWD2(4); else if (batch <= 8) LIN_FWD2(8); else LIN_FWD2(16);
+#undef LIN_FWD2
     VS_CHECK_LAUNCH();
     return VS_OK;
 }

@@ -206,8 +206,8 @@ class VAE(nn.Module):
             for blk in (self.down1, self.down2, self.down3, self.down4, self.down5):
                 a = blk(a)
             feat = ops.Materialize.apply(a.raw, a.stats, None, None)
-            x_mean = ops.LinearCL.apply(feat, self.fc_mean.weight, self.fc_mean.bias, False)
-            x_std = ops.LinearCL.apply(feat, self.fc_std.weight, self.fc_std.bias, True)
+            x_mean, x_std = ops.LinearCLPair.apply(feat, self.fc_mean.weight, self.fc_mean.bias, False,
+                                                   self.fc_std.weight, self.fc_std.bias, True)
             if if_random:
                 if noise is None:
                     noise = torch.randn(x_mean.shape, device=x_mean.device, dtype=torch.float32)

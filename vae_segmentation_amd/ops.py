@@ -881,6 +881,49 @@ class LinearCL(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class LinearCLPair(torch.autograd.Function):
+    """(act1(W1 x + b1), act2(W2 x + b2)) for two layers of equal shape on the same channels-last input — fc_mean and fc_std
+    (joint_model.py:241-243) — in one forward launch; the backward runs LinearCL's kernels for the outputs that received a gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, relu1, w2, b2, relu2):
+        _require_cuda(x, w1, w2)
+        if w1.shape != w2.shape:
+            raise ValueError("LinearCLPair needs two layers of the same shape")
+        n, d, h, w, c = x.shape
+        k_in, j_out = c * d * h * w, w1.shape[0]
+        y1 = torch.empty((n, j_out), dtype=torch.float32, device=x.device)
+        y2 = torch.empty((n, j_out), dtype=torch.float32, device=x.device)
+        check(lib.vs_linear_fwd_pair(x.data_ptr(), vs_dtype(x), w1.data_ptr(), _p(b1), y1.data_ptr(), 1 if relu1 else 0, w2.data_ptr(), _p(b2),
+                                     y2.data_ptr(), 1 if relu2 else 0, n, k_in, j_out, c, d * h * w, _stream()), "linear_fwd_pair")
+        ctx.save_for_backward(x, w1, w2, y1 if relu1 else None, y2 if relu2 else None)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.set_materialize_grads(False)
+        return y1, y2
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        x, w1, w2, r1, r2 = ctx.saved_tensors
+        n, d, h, w, c = x.shape
+        k_in, j_out = c * d * h * w, w1.shape[0]
+        out = [None] * 7
+        gx_total = None
+        for gy, wt, yrelu, iw, ib, hb in ((g1, w1, r1, 1, 2, ctx.has_bias[0]), (g2, w2, r2, 4, 5, ctx.has_bias[1])):
+            if gy is None:
+                continue
+            gy = _contig(gy.float())
+            gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            gw = torch.empty_like(wt) if ctx.needs_input_grad[iw] else None
+            gb = torch.empty(j_out, dtype=torch.float32, device=x.device) if (hb and ctx.needs_input_grad[ib]) else None
+            check(lib.vs_linear_bwd(x.data_ptr(), vs_dtype(x), wt.data_ptr(), gy.data_ptr(), _p(yrelu), _p(gx), _p(gw), _p(gb), n, k_in,
+                                    j_out, c, d * h * w, _stream()), "linear_bwd")
+            out[iw], out[ib] = gw, gb
+            if gx is not None:
+                gx_total = gx if gx_total is None else gx_total + gx
+        out[0] = gx_total
+        return tuple(out)
+
+
 class LinearToCL(torch.autograd.Function):
     """fc2 (joint_model.py:248-253): fp32 latent (B, K) -> channels-last activation (B, s, s, s, C) holding
     view(B, C, s, s, s) of the reference's output."""
