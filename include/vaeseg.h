@@ -106,6 +106,12 @@ int vs_conv_k3_softmax2_fwd(const void* x, const double* x_stats, const void* w_
 int vs_conv_k3_softmax2_dropout_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                                     float* prob, int n, int d, int h, int w, int c_in, int dtype, float eps, float drop_p,
                                     unsigned long long drop_seed, void* stream);
+/* same, additionally writing the probabilities as a channels-last bf16 tensor prob_cl[n][v][8] (2 real channels) — the input layout of the
+ * network that consumes them next (Joint.forward feeds Segmentation's prediction to the VAE, joint_model.py:447-450): saves the
+ * vs_pack_planar launch and its re-read.  prob_cl may be NULL (then this is the call above); bf16 only. */
+int vs_conv_k3_softmax2_cl_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                               float* prob, void* prob_cl, int n, int d, int h, int w, int c_in, int dtype, float eps, float drop_p,
+                               unsigned long long drop_seed, void* stream);
 
 /* weight gradient of all three conv kinds:
  *   dW[m][c][tap] = sum_{n,v} actP(P)[n,v,m] * actQ(Q)[n, v*s + off(tap) - p, c]        (fp32, reference layout)
@@ -177,6 +183,10 @@ int vs_softmax2_bwd(const float* prob, const float* gprob, void* glogit, int n, 
 /* same, followed by the backward of the logit dropout of vs_conv_k3_softmax2_dropout_fwd (same p / seed) */
 int vs_softmax2_dropout_bwd(const float* prob, const float* gprob, void* glogit, int n, long long voxels, int c_pad, int dtype,
                             float drop_p, unsigned long long drop_seed, void* stream);
+/* same with the upstream gradient arriving in two parts: gprob (planar fp32, may be NULL) and gprob_cl (channels-last [n][v][c_pad] in
+ * `dtype`, channels 0..1 used, may be NULL) — the gradients of prob and of its channels-last copy (vs_conv_k3_softmax2_cl_fwd). */
+int vs_softmax2_cl_bwd(const float* prob, const float* gprob, const void* gprob_cl, void* glogit, int n, long long voxels,
+                       int c_pad, int dtype, float drop_p, unsigned long long drop_seed, void* stream);
 /* label (float, values 0..n_class-1) [N][1][V] -> one-hot planar fp32 [N][n_class][V]   (main_source.py:449-451) */
 int vs_onehot(const float* label, float* out, int n, long long voxels, int n_class, void* stream);
 /* mode 0: (a >= 0.5) ; mode 1: a>hi -> 1, a<lo -> 0, else a        (utils/evaluation.py:9-18) */

@@ -129,12 +129,20 @@ extern "C" int vs_conv_k3_softmax2_fwd(const void* x, const double* x_stats, con
 extern "C" int vs_conv_k3_softmax2_dropout_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                                                float* prob, int n, int d, int h, int w, int c_in, int dtype, float eps,
                                                float drop_p, unsigned long long drop_seed, void* stream) {
+    return vs_conv_k3_softmax2_cl_fwd(x, x_stats, w_packed, bias, prob, nullptr, n, d, h, w, c_in, dtype, eps, drop_p, drop_seed, stream);
+}
+
+extern "C" int vs_conv_k3_softmax2_cl_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,
+                                          float* prob, void* prob_cl, int n, int d, int h, int w, int c_in, int dtype, float eps,
+                                          float drop_p, unsigned long long drop_seed, void* stream) {
     if (drop_p < 0.f || drop_p >= 1.f) return VS_EINVAL;
+    if (prob_cl && dtype != VS_BF16) return VS_EDTYPE;
+    if (prob_cl && ((uintptr_t)prob_cl & 15)) return VS_EALIGN;
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
     if (!prob || c_in != 8) return VS_ESHAPE;
     G1Params p{};
-    p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = nullptr; p.y_stats = nullptr; p.prob = prob;
+    p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = prob_cl; p.y_stats = nullptr; p.prob = prob;
     p.mask_x = nullptr; p.mask_stats = nullptr; p.sums = nullptr; p.inv_count_out = 1.0 / ((double)d * h * w);
     p.drop_p = drop_p; p.drop_seed = drop_seed;
     p.N = n; p.D = d; p.H = h; p.W = w;

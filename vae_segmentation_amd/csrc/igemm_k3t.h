@@ -197,23 +197,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // ---- epilogue ----
         K3_TICK(5);
         if constexpr (EPI == EPI_SOFTMAX2) {
-            if ((g & 1) == 0) {
-                const size_t V = (size_t)p.D * p.H * p.W;
+            const size_t V = (size_t)p.D * p.H * p.W;
 #pragma unroll
-                for (int cg = 0; cg < YT; ++cg) {
-                    const int oy = y0 + cg;
-                    if (!(zx_ok && oy < p.H)) continue;
-                    float l0 = acc[cg][0] + bv[0], l1 = acc[cg][1] + bv[1];
-                    const size_t v = ((size_t)oz * p.H + oy) * p.W + ox;
-                    if (p.drop_p > 0.f) {
-                        l0 *= dropout_scale(p.drop_seed, ((unsigned long long)n * 2 + 0) * V + v, p.drop_p);
-                        l1 *= dropout_scale(p.drop_seed, ((unsigned long long)n * 2 + 1) * V + v, p.drop_p);
-                    }
-                    const float mx = fmaxf(l0, l1);
-                    const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx);
-                    const float inv = 1.f / (e0 + e1);
+            for (int cg = 0; cg < YT; ++cg) {
+                const int oy = y0 + cg;
+                const bool valid = zx_ok && oy < p.H;
+                float l0 = acc[cg][0] + bv[0], l1 = acc[cg][1] + bv[1];
+                const size_t v = ((size_t)oz * p.H + oy) * p.W + ox;
+                if (p.drop_p > 0.f) {
+                    l0 *= dropout_scale(p.drop_seed, ((unsigned long long)n * 2 + 0) * V + v, p.drop_p);
+                    l1 *= dropout_scale(p.drop_seed, ((unsigned long long)n * 2 + 1) * V + v, p.drop_p);
+                }
+                const float mx = fmaxf(l0, l1);
+                const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx);
+                const float inv = 1.f / (e0 + e1);
+                if (valid && (g & 1) == 0) {
                     p.prob[((size_t)n * 2 + 0) * V + v] = e0 * inv;
                     p.prob[((size_t)n * 2 + 1) * V + v] = e1 * inv;
+                }
+                if (p.y != nullptr) {
+                    // the same probabilities as the next network's channels-last bf16 input (8 stored channels, 2 real): what
+                    // vs_pack_planar(prob) would write, without the extra launch and the re-read
+                    f32x2 pr;
+                    pr[0] = e0 * inv; pr[1] = e1 * inv;
+                    i32x2 pk;
+                    pk[0] = (g & 1) == 0 ? __builtin_bit_cast(int, __builtin_convertvector(pr, bf16x2)) : 0;
+                    pk[1] = 0;
+                    vs_raw_buffer_store_b64(pk, yrsrc, valid ? ebase + cg * p.W * 16 : -1, 0, 0);
                 }
             }
         } else {

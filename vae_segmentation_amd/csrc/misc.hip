@@ -44,12 +44,18 @@ extern "C" int vs_dropout(const void* x, void* out, long long count, float p, un
 }
 
 template <typename T>
-__global__ void softmax2_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ gprob, T* __restrict__ gl,
+__global__ void softmax2_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ gprob, const T* __restrict__ gcl, T* __restrict__ gl,
                                     long long voxels, int c_pad, long long total, float drop_p, unsigned long long drop_seed) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long n = i / voxels, v = i - n * voxels;
         const float p0 = prob[(n * 2 + 0) * voxels + v], p1 = prob[(n * 2 + 1) * voxels + v];
-        const float g0 = gprob[(n * 2 + 0) * voxels + v], g1 = gprob[(n * 2 + 1) * voxels + v];
+        float g0 = 0.f, g1 = 0.f;
+        if (gprob) { g0 = gprob[(n * 2 + 0) * voxels + v]; g1 = gprob[(n * 2 + 1) * voxels + v]; }
+        if (gcl) {                  // + the gradient that arrived through the channels-last copy of the probabilities
+            float f2[ET<T>::EPL];
+            frag_unpack(*(const u32x4*)(gcl + i * c_pad), f2, (T*)nullptr);
+            g0 += f2[0]; g1 += f2[1];
+        }
         const float dot = p0 * g0 + p1 * g1;
         float f[ET<T>::EPL];
 #pragma unroll
@@ -74,12 +80,18 @@ extern "C" int vs_softmax2_bwd(const float* prob, const float* gprob, void* glog
 
 extern "C" int vs_softmax2_dropout_bwd(const float* prob, const float* gprob, void* glogit, int n, long long voxels, int c_pad,
                                        int dtype, float drop_p, unsigned long long drop_seed, void* stream) {
-    if (!prob || !gprob || !glogit || n <= 0 || voxels <= 0 || c_pad % 8 || c_pad <= 0) return VS_EINVAL;
+    if (!gprob) return VS_EINVAL;
+    return vs_softmax2_cl_bwd(prob, gprob, nullptr, glogit, n, voxels, c_pad, dtype, drop_p, drop_seed, stream);
+}
+
+extern "C" int vs_softmax2_cl_bwd(const float* prob, const float* gprob, const void* gprob_cl, void* glogit, int n, long long voxels,
+                                  int c_pad, int dtype, float drop_p, unsigned long long drop_seed, void* stream) {
+    if (!prob || (!gprob && !gprob_cl) || !glogit || n <= 0 || voxels <= 0 || c_pad % 8 || c_pad <= 0) return VS_EINVAL;
     const long long total = (long long)n * voxels;
     if (dtype == VS_F32)
-        hipLaunchKernelGGL(softmax2_bwd_kernel<float>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (float*)glogit, voxels, c_pad, total, drop_p, drop_seed);
+        hipLaunchKernelGGL(softmax2_bwd_kernel<float>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (const float*)gprob_cl, (float*)glogit, voxels, c_pad, total, drop_p, drop_seed);
     else if (dtype == VS_BF16)
-        hipLaunchKernelGGL(softmax2_bwd_kernel<unsigned short>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (unsigned short*)glogit, voxels, c_pad, total, drop_p, drop_seed);
+        hipLaunchKernelGGL(softmax2_bwd_kernel<unsigned short>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (const unsigned short*)gprob_cl, (unsigned short*)glogit, voxels, c_pad, total, drop_p, drop_seed);
     else return VS_EDTYPE;
     VS_CHECK_LAUNCH();
     return VS_OK;

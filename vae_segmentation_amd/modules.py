@@ -201,7 +201,7 @@ class VAE(nn.Module):
             if x.shape[-1] != self.spatial:
                 raise ValueError("VAE built for spatial=%d got input side %d" % (self.spatial, x.shape[-1]))
             ops.stats_arena_begin(x.device)
-            a = Act(ops.PackPlanar.apply(x, self.kernel_dtype), None)
+            a = Act(ops.planar_input(x, self.kernel_dtype), None)     # Segmentation's prediction arrives with its channels-last copy
             a = self.in_block(a)
             for blk in (self.down1, self.down2, self.down3, self.down4, self.down5):
                 a = blk(a)
@@ -268,10 +268,10 @@ class Segmentation(nn.Module):
         u = _dropout(Act(ops.Materialize.apply(u.raw, u.stats, x2.raw, x2.stats), None), dropout)
         u = _dropout(self.up5(u), dropout)
         if dropout:     # the reference also drops the two logits before the softmax (joint_model.py:386-388): fused epilogue
-            data_dict[out_key] = ops.ConvK3Softmax.apply(u.raw, u.stats, self.out_block.weight, self.out_block.bias,
-                                                         float(dropout), ops.next_dropout_seed())
+            data_dict[out_key] = ops.out_block_softmax(u.raw, u.stats, self.out_block.weight, self.out_block.bias,
+                                                       float(dropout), ops.next_dropout_seed())
         else:
-            data_dict[out_key] = ops.ConvK3Softmax.apply(u.raw, u.stats, self.out_block.weight, self.out_block.bias)
+            data_dict[out_key] = ops.out_block_softmax(u.raw, u.stats, self.out_block.weight, self.out_block.bias)
         return data_dict
 
 

@@ -671,6 +671,74 @@ class ConvK3Softmax(torch.autograd.Function):
         return gx, None, gw, gb, None, None
 
 
+class ConvK3SoftmaxCL(torch.autograd.Function):
+    """ConvK3Softmax that ALSO returns the probabilities as the channels-last bf16 tensor the next network reads
+    (Joint.forward: Segmentation's prediction is the VAE's input, joint_model.py:447-450) -> (prob, prob_cl).  Saves the
+    vs_pack_planar launch in forward and, in backward, vs_unpack_planar and autograd's add of the two gradients of prob:
+    the softmax backward takes both parts (vs_softmax2_cl_bwd).  bf16 kernels only."""
+
+    @staticmethod
+    def forward(ctx, x, xs, weight, bias, drop_p=0.0, drop_seed=0):
+        _require_cuda(x, weight)
+        if weight.shape[0] != 2 or x.dtype != torch.bfloat16:
+            raise NotImplementedError("fused out_block+softmax with a channels-last copy: n_class == 2, bf16")
+        n, d, h, w, c = x.shape
+        wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, c, x.dtype)
+        prob = torch.empty((n, 2, d, h, w), dtype=torch.float32, device=x.device)
+        prob_cl = torch.empty((n, d, h, w, 8), dtype=x.dtype, device=x.device)
+        check(lib.vs_conv_k3_softmax2_cl_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), prob.data_ptr(), prob_cl.data_ptr(), n, d, h, w, c,
+                                             vs_dtype(x), EPS_IN, float(drop_p), drop_seed, _stream()), "conv_k3_softmax2_cl_fwd")
+        ctx.save_for_backward(x, xs, weight, prob)
+        ctx.has_bias = bias is not None
+        ctx.drop = (float(drop_p), drop_seed)
+        ctx.set_materialize_grads(False)
+        return prob, prob_cl
+
+    @staticmethod
+    def backward(ctx, gprob, gcl):
+        x, xs, weight, prob = ctx.saved_tensors
+        if gprob is None and gcl is None:
+            return None, None, None, None, None, None
+        n, d, h, w, c = x.shape
+        gprob = None if gprob is None else _contig(gprob.float())
+        gcl = None if gcl is None else _contig(gcl)
+        gl = torch.empty((n, d, h, w, 8), dtype=x.dtype, device=x.device)
+        check(lib.vs_softmax2_cl_bwd(prob.data_ptr(), _p(gprob), _p(gcl), gl.data_ptr(), n, d * h * w, 8, vs_dtype(x), ctx.drop[0], ctx.drop[1],
+                                     _stream()), "softmax2_cl_bwd")
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, x.dtype)
+            if xs is not None:
+                gx = conv_bwd_data_lazy(gl, wpb, x, xs, VS_CONV_K3, real_channels=(2, weight.shape[1]))
+            else:
+                gx, _ = conv_gather(gl, None, wpb, None, c, VS_CONV_K3, False)
+        if ctx.needs_input_grad[2]:
+            gw, gb = _side_grads(weight, (gl, x, xs), (gl, None, x, xs, 2, weight.shape[1], VS_CONV_K3),
+                                 (gl, 2) if ctx.has_bias and ctx.needs_input_grad[3] else None)
+        elif ctx.has_bias and ctx.needs_input_grad[3]:
+            gb = bias_grad(gl, 2)
+        return gx, None, gw, gb, None, None
+
+
+def out_block_softmax(x, xs, weight, bias, drop_p=0.0, drop_seed=0):
+    """out_block + softmax -> planar fp32 probabilities; in bf16 mode the tensor carries its channels-last copy as `_vs_cl`, which a
+    network that takes it as input (VAE / Joint) uses instead of re-packing it (set VS_SOFTMAX_CL=0 to disable)."""
+    if x.dtype == torch.bfloat16 and weight.shape[0] == 2 and os.environ.get("VS_SOFTMAX_CL", "1") != "0":
+        prob, prob_cl = ConvK3SoftmaxCL.apply(x, xs, weight, bias, drop_p, drop_seed)
+        prob._vs_cl = prob_cl
+        return prob
+    return ConvK3Softmax.apply(x, xs, weight, bias, drop_p, drop_seed)
+
+
+def planar_input(x, dtype):
+    """channels-last kernel-dtype view of a planar (N, C, D, H, W) input: the producer's own channels-last copy when it left one
+    (out_block_softmax), vs_pack_planar otherwise."""
+    cl = getattr(x, "_vs_cl", None)
+    if cl is not None and cl.dtype == dtype and cl.shape[0] == x.shape[0] and tuple(cl.shape[1:4]) == tuple(x.shape[2:]):
+        return cl
+    return PackPlanar.apply(x, dtype)
+
+
 class ConvK2S2(torch.autograd.Function):
     """Conv3d(C, C, 2, stride 2) with live bias on a lazy input; output is final (feeds a conv directly)
     — joint_model.py:130."""
