@@ -239,6 +239,31 @@ def test_bf16_mode_joint96_close_to_fp32_reference():
     assert all(np.isfinite(G.flat64(p.grad)).all() for p in joint.Seg.parameters())
 
 
+def test_bf16_joint_step_same_with_and_without_the_channels_last_prediction(monkeypatch):
+    """Joint.forward (joint_model.py:447-450) feeds Segmentation's prediction to the VAE.  In bf16 mode out_block writes the channels-last copy
+    the VAE reads and the softmax backward takes the two gradient parts itself; VS_SOFTMAX_CL=0 spells it with vs_pack_planar,
+    vs_unpack_planar and autograd's add.  Same arithmetic: the step must not change (statistics atomics reorder, hence a tolerance)."""
+    M, O, T = _mods()
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VS_SOFTMAX_CL", flag)
+        joint = _build_joint(M, O, 64)
+        M.set_kernel_dtype(joint, torch.bfloat16)
+        final, aux = T.joint_train_losses(joint, O.synthetic_image(2, 64, 2).cuda(), O.synthetic_label(2, 64, 3).cuda())
+        final.backward()
+        torch.cuda.synchronize()
+        assert (getattr(aux["batch"]["pred"], "_vs_cl", None) is not None) == (flag == "1")
+        out[flag] = (final.item(), aux["recon_loss"].item(), aux["batch"]["recon"].detach().float().cpu(),
+                     {n: p.grad.detach().float().cpu() for n, p in joint.Seg.named_parameters()})
+    assert abs(out["1"][0] - out["0"][0]) < 1e-5 and abs(out["1"][1] - out["0"][1]) < 1e-5
+    assert float((out["1"][2] - out["0"][2]).abs().max()) < 1e-3
+    for n in out["1"][3]:
+        a, b = out["1"][3][n], out["0"][3][n]
+        if G.is_dead_bias(n):
+            continue
+        assert float((a - b).norm() / b.norm().clamp_min(1e-20)) < 2e-2, n
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_sgd_step_and_graph_replay_match_eager(overlap):
     """Three SGD(momentum) steps: native multi-tensor kernel vs torch.optim.SGD on the oracle (CPU), then a
