@@ -62,7 +62,7 @@ def _k3_kid(tname, ck, mt, sums=False, geom=None, m=None, lazy=False):
         tall = n * ((d + 3) // 4) * ((h + 7) // 8) * ((w + 15) // 16)
         if os.environ.get("VS_K3_TALL", "") == "1" or (tall >= 256 and tiles <= 2048):
             yt = 8
-    return "k3b_kernel<%d,%d,0,%s,%d>" % (ck, min(mt, 32), "true" if sums else "false", yt)
+    return "k3b_kernel<%d,%d,0,%s,%d,%s>" % (ck, min(mt, 32), "true" if sums else "false", yt, hs)
 
 
 PROFILE_PRIME_US = 80
