@@ -56,11 +56,17 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
         p.Do = d / 2; p.Ho = h / 2; p.Wo = w / 2;
         p.tyn = p.txn = 0;
         p.tiles_per_sample = vs_ceil_div((long long)p.Do * p.Ho * p.Wo, 256);
+        // few workgroups and several 32-channel chunks (the deep stride-2 convs: 8-32 workgroups, one memory round trip per chunk each):
+        // 64-voxel column tiles whose four waves split the chunks (g1_kernel, splitw)
+        if (ck == 32 && p.nch >= 2 && (long long)p.tiles_per_sample * n * p.rb_total <= 64) {
+            p.tiles_per_sample = vs_ceil_div((long long)p.Do * p.Ho * p.Wo, 64);
+            p.tyn = 64;
+        }
     }
     tiles = (long long)p.tiles_per_sample * n;
     p.inv_count_out = 1.0 / ((double)p.Do * p.Ho * p.Wo);
     const int rows16 = p.rb_total * 16;
-    const int mt = pick_mt(rows16, tiles);
+    const int mt = (kind != VS_CONV_K3 && p.tyn == 64) ? 16 : pick_mt(rows16, tiles);
     const int row_tiles = rows16 / mt;
     if (kind == VS_CONV_K3) {
         return dtype == VS_F32 ? g1_dispatch_k3_f32(p, ck, mt, EPI_RAW, (int)tiles, row_tiles, (hipStream_t)stream)

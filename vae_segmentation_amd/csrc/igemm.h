@@ -114,8 +114,11 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     // Small volumes (<= 64 output voxels per sample: the 3^3 level, where only wave 0 would have real columns and the four waves would
     // each walk all C/32 chunks — one memory round trip per chunk — on padding): the waves share wave 0's columns and SPLIT the channel
     // chunks (wave w takes chunks w, w+4, ...); the partial accumulators are summed through LDS in wave order before the epilogue.
-    const bool splitw = KIND == G1_K2S2 && CK == 32 && p.Do * p.Ho * p.Wo <= 64 && p.nch >= 2;
+    // (The host picks this mode — 64-voxel column tiles, p.tyn == 64 — for every stride-2 conv with few workgroups and >= 2 chunks: four
+    // times the workgroups, each walking a quarter of the chunks.)
+    const bool splitw = KIND == G1_K2S2 && CK == 32 && p.tyn == 64;
     const int cwave = splitw ? 0 : wave;
+    const int ctile = splitw ? 64 : 256;
     long long gofs[4];                          // element offset of the column's input voxel (tap 0)
     bool cvalid[4];
     int oz[4], oy[4], ox[4];
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         const int vcol = p.Do * p.Ho * p.Wo;             // < 2^31 (host check); 32-bit divisions: the 64-bit ones cost ~100 instructions each
 #pragma unroll
         for (int cg = 0; cg < 4; ++cg) {
-            int v = tile * 256 + cwave * 64 + cg * 16 + col;
+            int v = tile * ctile + cwave * 64 + cg * 16 + col;
             cvalid[cg] = v < vcol;
             if (!cvalid[cg]) v = 0;
             ox[cg] = v % p.Wo;
