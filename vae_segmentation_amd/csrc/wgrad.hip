@@ -569,17 +569,21 @@ extern "C" int vs_conv_wgrad(const void* P, const double* p_stats, const void* Q
 struct G3RedDesc {
     const float* ws; float* dw;
     int m_real, c_real, mbn, cbn, nslabs, cb, ntaps, ncb;
-    int kind, parts;         // parts: slab partitions summed in parallel (power of two <= 16); a block covers 64 * 16 / parts elements
+    int kind, parts;         // parts: slab partitions summed in parallel (power of two <= G3_RED_ROWS); a block covers 256 * G3_RED_ROWS / parts elements
 };
-#define G3_RED_MAX 40
+#define G3_RED_MAX 56
 struct G3RedGroup {
     G3RedDesc d[G3_RED_MAX];
     int blk_start[G3_RED_MAX + 1];
     int n;
 };
 
-__global__ __launch_bounds__(1024) void g3_reduce_group_kernel(const G3RedGroup grp) {
-    __shared__ double red[16][64];
+// RR rows of 64 lanes per block; a row = (element group, slab partition).  256-thread blocks: the 10k blocks of this launch were bound by the
+// rate at which 1024-thread workgroups can be started, not by their 40 MB of slabs.
+#define G3_RED_ROWS 4
+__global__ __launch_bounds__(64 * G3_RED_ROWS) void g3_reduce_group_kernel(const G3RedGroup grp) {
+    __shared__ double red[G3_RED_ROWS][64];
+    __shared__ double red4[4][G3_RED_ROWS][64];
     const int b = blockIdx.x;
     int l = 0;
 #pragma unroll
@@ -593,57 +597,66 @@ __global__ __launch_bounds__(1024) void g3_reduce_group_kernel(const G3RedGroup 
         double s = 0.0;
         if (c < d.c_real) {
             int sl = part;
-            for (; sl + 112 < d.nslabs; sl += 128) {      // 8 loads in flight
+            for (; sl + 7 * G3_RED_ROWS < d.nslabs; sl += 8 * G3_RED_ROWS) {      // 8 loads in flight
                 double v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(sl + 16 * j) * d.c_real + c];
+                for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(sl + G3_RED_ROWS * j) * d.c_real + c];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += v[j];
             }
-            for (; sl < d.nslabs; sl += 16) s += src[(size_t)sl * d.c_real + c];
+            for (; sl < d.nslabs; sl += G3_RED_ROWS) s += src[(size_t)sl * d.c_real + c];
         }
         red[part][lane] = s;
         __syncthreads();
         if (part == 0 && c < d.c_real) {
             double tot = 0.0;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) tot += red[q][lane];
+            for (int q = 0; q < G3_RED_ROWS; ++q) tot += red[q][lane];
             d.dw[c] = (float)tot;
         }
         return;
     }
-    // weight slabs: the 16 rows of the block are (element group, slab partition) pairs — a layer with one slab (deep layers
+    // weight slabs: the rows of the block are (element group, slab partition) pairs — a layer with one slab (deep layers
     // of a grouped launch) spends no threads on partitions it does not have
     const int parts = d.parts, egrp = part / parts, sp = part - egrp * parts;
     const size_t slab_elems = (size_t)d.mbn * d.cbn * d.ncb * 256;
-    const size_t e = ((size_t)lb * (16 / parts) + egrp) * 64 + lane;
-    double s = 0.0;
+    // four consecutive slab elements per lane (= rows 4q..4q+3 of one (k, col)): 1 KiB per wave request instead of 256 B
+    const size_t e = (((size_t)lb * (G3_RED_ROWS / parts) + egrp) * 64 + lane) * 4;
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
     if (e < slab_elems) {
         const float* src = d.ws + e;
         int sl = sp;
         for (; sl + 7 * parts < d.nslabs; sl += 8 * parts) {
-            float v[8];
+            f32x4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(sl + parts * j) * slab_elems];
+            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(src + (size_t)(sl + parts * j) * slab_elems);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (double)v[j];
+            for (int j = 0; j < 8; ++j) { s4[0] += (double)v[j][0]; s4[1] += (double)v[j][1]; s4[2] += (double)v[j][2]; s4[3] += (double)v[j][3]; }
         }
-        for (; sl < d.nslabs; sl += parts) s += (double)src[(size_t)sl * slab_elems];
+        for (; sl < d.nslabs; sl += parts) {
+            const f32x4 v = *(const f32x4*)(src + (size_t)sl * slab_elems);
+            s4[0] += (double)v[0]; s4[1] += (double)v[1]; s4[2] += (double)v[2]; s4[3] += (double)v[3];
+        }
     }
-    red[part][lane] = s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red4[i][part][lane] = s4[i];
     __syncthreads();
     if (sp == 0 && e < slab_elems) {
-        double tot = 0.0;
-        for (int q = 0; q < parts; ++q) tot += red[egrp * parts + q][lane];
-        const int row = (int)(e & 15), col = (int)((e >> 4) & 15);
-        const int k = (int)((e >> 8) % d.ncb);
-        const int pair = (int)(e / ((size_t)d.ncb * 256));
-        const int mb = pair / d.cbn, cb = pair - mb * d.cbn;
-        const int m = mb * 16 + row;
-        int c, tap;
-        if (d.cb == 16) { c = cb * 16 + col; tap = k; }
-        else { c = cb * 8 + (col & 7); tap = 2 * k + (col >> 3); }
-        if (m < d.m_real && c < d.c_real && tap < d.ntaps) d.dw[((size_t)m * d.c_real + c) * d.ntaps + tap] = (float)tot;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double tot = 0.0;
+            for (int q = 0; q < parts; ++q) tot += red4[i][egrp * parts + q][lane];
+            const size_t ee = e + i;
+            const int row = (int)(ee & 15), col = (int)((ee >> 4) & 15);
+            const int k = (int)((ee >> 8) % d.ncb);
+            const int pair = (int)(ee / ((size_t)d.ncb * 256));
+            const int mb = pair / d.cbn, cb = pair - mb * d.cbn;
+            const int m = mb * 16 + row;
+            int c, tap;
+            if (d.cb == 16) { c = cb * 16 + col; tap = k; }
+            else { c = cb * 8 + (col & 7); tap = 2 * k + (col >> 3); }
+            if (m < d.m_real && c < d.c_real && tap < d.ntaps) d.dw[((size_t)m * d.c_real + c) * d.ntaps + tap] = (float)tot;
+        }
     }
 }
 
@@ -882,12 +895,12 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
             const long long slab_elems = (long long)L.p.mbn * L.p.cbn * L.ncb * 256;
             // a partition sums up to 8 slabs in one round of independent loads: no more partitions (= threads, waves) than that needs
             int parts = 1;
-            while (parts < 16 && parts * 8 < L.p.ksplit) parts *= 2;
+            while (parts < G3_RED_ROWS && parts * 8 < L.p.ksplit) parts *= 2;
             red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.p.ksplit, L.cbsz,
                                     L.kind == VS_CONV_K3 ? 27 : 8, L.ncb, 0, parts});
-            blocks.push_back(vs_ceil_div(slab_elems, 64 * (16 / parts)));
+            blocks.push_back(vs_ceil_div(slab_elems, 256 * (G3_RED_ROWS / parts)));
             if (descs[i].bias_g) {
-                red.push_back(G3RedDesc{(const float*)(ws + L.bias_off), descs[i].db, 0, descs[i].bias_c_real, 0, 0, L.bias_nblk, 0, 0, 0, 1, 16});
+                red.push_back(G3RedDesc{(const float*)(ws + L.bias_off), descs[i].db, 0, descs[i].bias_c_real, 0, 0, L.bias_nblk, 0, 0, 0, 1, G3_RED_ROWS});
                 blocks.push_back(vs_ceil_div(descs[i].bias_c_real, 64));
             }
         }
@@ -902,7 +915,7 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
             }
             if (blk >= 2147483647ll) return VS_ESHAPE;
             for (int j = grp.n; j <= G3_RED_MAX; ++j) grp.blk_start[j] = (int)blk;
-            hipLaunchKernelGGL(g3_reduce_group_kernel, dim3((unsigned)blk), dim3(1024), 0, st, grp);
+            hipLaunchKernelGGL(g3_reduce_group_kernel, dim3((unsigned)blk), dim3(64 * G3_RED_ROWS), 0, st, grp);
             VS_CHECK_LAUNCH();
         }
     }
