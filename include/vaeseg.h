@@ -62,7 +62,7 @@ typedef struct vs_pack_desc {
     const float* src;      /* float[d0][d1][ntaps] */
     void* dst;             /* packed image, vs_packed_weight_bytes() bytes */
     int d0, d1, ntaps, c_pad, form, dtype;
-    int first_block;       /* index of this weight's first 256-thread block in the launch */
+    int first_block;       /* index of this weight's first 256-thread block in the launch; a thread packs one 16-byte fragment (8 bf16 / 4 fp32 elements) */
     int pad_;
     long long total;       /* packed elements of this weight */
 } vs_pack_desc;

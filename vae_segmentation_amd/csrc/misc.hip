@@ -780,11 +780,25 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* params, co
     float* m = bufs[ti];
     const long long n = sizes[ti];
     const long long end = (long long)start + MT_CHUNK < n ? (long long)start + MT_CHUNK : n;
-    for (long long i = start + threadIdx.x; i < end; i += 256) {
-        float gi = g[i] + wd * p[i];
-        float bi = first ? gi : momentum * m[i] + gi;
-        m[i] = bi;
-        p[i] -= lr * (momentum != 0.f ? bi : gi);
+    // every operand of the chunk is requested before the first store: the compiler cannot move a load over a store that may alias, and
+    // sixteen dependent load -> store rounds made this 2.3 M-parameter update 25 us
+    constexpr int R = MT_CHUNK / 256;
+    float gv[R], pv[R], mv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long i = start + threadIdx.x + r * 256;
+        const bool ok = i < end;
+        gv[r] = ok ? g[i] : 0.f; pv[r] = ok ? p[i] : 0.f; mv[r] = (ok && !first) ? m[i] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long i = start + threadIdx.x + r * 256;
+        if (i < end) {
+            const float gi = gv[r] + wd * pv[r];
+            const float bi = first ? gi : momentum * mv[r] + gi;
+            m[i] = bi;
+            p[i] = pv[r] - lr * (momentum != 0.f ? bi : gi);
+        }
     }
 }
 extern "C" int vs_sgd_momentum_multi(float* const* params, const float* const* grads, float* const* bufs, const long long* sizes,
@@ -808,13 +822,25 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(float* const* params, c
     const long long end = (long long)start + MT_CHUNK < n ? (long long)start + MT_CHUNK : n;
     const float step_size = lr / bc1;
     const float bc2s = sqrtf(bc2);
-    for (long long i = start + threadIdx.x; i < end; i += 256) {
-        const float gi = g[i] + wd * p[i];
-        const float ai = b1 * a[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-        a[i] = ai; v[i] = vi;
-        const float denom = sqrtf(vi) / bc2s + eps;
-        p[i] -= step_size * ai / denom;
+    constexpr int R = MT_CHUNK / 256;                    // all loads of the chunk before the first store (see sgd_multi_kernel)
+    float gv[R], pv[R], av[R], vv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long i = start + threadIdx.x + r * 256;
+        const bool ok = i < end;
+        gv[r] = ok ? g[i] : 0.f; pv[r] = ok ? p[i] : 0.f; av[r] = ok ? a[i] : 0.f; vv[r] = ok ? v[i] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long i = start + threadIdx.x + r * 256;
+        if (i < end) {
+            const float gi = gv[r] + wd * pv[r];
+            const float ai = b1 * av[r] + (1.f - b1) * gi;
+            const float vi = b2 * vv[r] + (1.f - b2) * gi * gi;
+            a[i] = ai; v[i] = vi;
+            const float denom = sqrtf(vi) / bc2s + eps;
+            p[i] = pv[r] - step_size * ai / denom;
+        }
     }
 }
 extern "C" int vs_adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,

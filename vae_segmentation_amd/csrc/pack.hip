@@ -3,48 +3,57 @@
 
 // Packed image: [row-block rb][channel chunk ch][k-group kg][lane][EPL elements]
 //   row = rb*16 + (lane & 15);  k within the chunk = kg*KG + (lane >> 4)*EPL + j;  tap = k / CK, c = ch*CK + k % CK
+// One thread packs one 16-byte FRAGMENT (EPL consecutive k-side channels of one row / tap): EPL independent gathers, one vector
+// store (one element per thread meant 2-byte stores and eight times the threads: 27 us for the step's 136 images).
 template <typename T>
 __device__ __forceinline__ void pack_one(const float* __restrict__ src, T* __restrict__ dst, int d0, int d1, int ntaps,
-                                         int c_pad, int form, long long total, long long i) {
+                                         int c_pad, int form, long long total, long long frag) {
     constexpr int EPL = ET<T>::EPL, KG = ET<T>::KG;
+    const long long i = frag * EPL;                      // first element of the fragment
     if (i >= total) return;
+    float v[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) v[j] = 0.f;
     if (sizeof(T) == 2 && form != VS_PACK_SCATTER_D1 && vs_k3_toeplitz(form == VS_PACK_ROWS_D0 ? d0 : d1, c_pad, ntaps, VS_BF16)) {
         // Toeplitz image of the 8-channel 3x3x3 layers (common.h vs_k3_toeplitz, igemm_k3t.h): [kg = tz*3+ty][lane][ci]
-        const int ci = (int)(i & 7), lane = (int)((i >> 3) & 63), kg = (int)(i >> 9);
+        const int lane = (int)(frag & 63), kg = (int)(frag >> 6);
         const int row = lane & 15, dx2 = row >> 3, co = row & 7, tx = (lane >> 4) - dx2;
-        float v = 0.f;
         if (tx >= 0 && tx <= 2) {
             const int tap = kg * 3 + tx;
-            if (form == VS_PACK_ROWS_D0) { if (co < d0 && ci < d1) v = src[((size_t)co * d1 + ci) * 27 + tap]; }
-            else { if (co < d1 && ci < d0) v = src[((size_t)ci * d1 + co) * 27 + (26 - tap)]; }
+#pragma unroll
+            for (int ci = 0; ci < EPL; ++ci) {
+                if (form == VS_PACK_ROWS_D0) { if (co < d0 && ci < d1) v[ci] = src[((size_t)co * d1 + ci) * 27 + tap]; }
+                else { if (co < d1 && ci < d0) v[ci] = src[((size_t)ci * d1 + co) * 27 + (26 - tap)]; }
+            }
         }
-        ET<T>::st(dst + i, v);
-        return;
+    } else {
+        const int CK = c_pad < 32 ? c_pad : 32;
+        const int nch = c_pad / CK;
+        const int gemm_taps = form == VS_PACK_SCATTER_D1 ? 1 : ntaps;
+        const int nkg = (gemm_taps * CK + KG - 1) / KG;
+        long long r = frag;
+        const int lane = (int)(r % 64); r /= 64;
+        const int kg = (int)(r % nkg); r /= nkg;
+        const int ch = (int)(r % nch);
+        const int rb = (int)(r / nch);
+        const int row = rb * 16 + (lane & 15);
+        const int kk0 = kg * KG + (lane >> 4) * EPL;     // EPL divides CK: the fragment stays inside one tap
+        const int tap = kk0 / CK;
+        const int c0 = ch * CK + kk0 % CK;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int c = c0 + j;
+            if (form == VS_PACK_ROWS_D0) {
+                if (row < d0 && tap < ntaps && c < d1) v[j] = src[((size_t)row * d1 + c) * ntaps + tap];
+            } else if (form == VS_PACK_ROWS_D1_FLIP) {
+                if (row < d1 && tap < ntaps && c < d0) v[j] = src[((size_t)c * d1 + row) * ntaps + (ntaps - 1 - tap)];
+            } else {  // VS_PACK_SCATTER_D1: rows (t, m = d1 index), k = c = d0 index
+                const int t = row / d1, m = row - t * d1;
+                if (t < ntaps && tap < 1 && c < d0) v[j] = src[((size_t)c * d1 + m) * ntaps + t];
+            }
+        }
     }
-    const int CK = c_pad < 32 ? c_pad : 32;
-    const int nch = c_pad / CK;
-    const int gemm_taps = form == VS_PACK_SCATTER_D1 ? 1 : ntaps;
-    const int nkg = (gemm_taps * CK + KG - 1) / KG;
-    const int j = (int)(i % EPL);
-    long long r = i / EPL;
-    const int lane = (int)(r % 64); r /= 64;
-    const int kg = (int)(r % nkg); r /= nkg;
-    const int ch = (int)(r % nch);
-    const int rb = (int)(r / nch);
-    const int row = rb * 16 + (lane & 15);
-    const int kk = kg * KG + (lane >> 4) * EPL + j;
-    const int tap = kk / CK;
-    const int c = ch * CK + kk % CK;
-    float v = 0.f;
-    if (form == VS_PACK_ROWS_D0) {
-        if (row < d0 && tap < ntaps && c < d1) v = src[((size_t)row * d1 + c) * ntaps + tap];
-    } else if (form == VS_PACK_ROWS_D1_FLIP) {
-        if (row < d1 && tap < ntaps && c < d0) v = src[((size_t)c * d1 + row) * ntaps + (ntaps - 1 - tap)];
-    } else {  // VS_PACK_SCATTER_D1: rows (t, m = d1 index), k = c = d0 index
-        const int t = row / d1, m = row - t * d1;
-        if (t < ntaps && tap < 1 && c < d0) v = src[((size_t)c * d1 + m) * ntaps + t];
-    }
-    ET<T>::st(dst + i, v);
+    *(u32x4*)(dst + i) = frag_pack(v, (T*)nullptr);
 }
 
 template <typename T>
@@ -53,6 +62,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict_
     pack_one<T>(src, dst, d0, d1, ntaps, c_pad, form, total, (long long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// descs[].first_block counts 256-thread blocks of FRAGMENTS (vs_pack_desc::total / EPL of them per image)
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const vs_pack_desc* __restrict__ descs, int n_desc) {
     // binary search: last descriptor whose first_block <= blockIdx.x
     int lo = 0, hi = n_desc - 1;
@@ -100,7 +110,7 @@ extern "C" int vs_pack_weight(const float* src, void* dst, int d0, int d1, int n
     if (kc > c_pad) return VS_ESHAPE;
     if (!(ntaps == 27 || ntaps == 8)) return VS_ESHAPE;
     const long long total = packed_elems(rows, c_pad, gemm_taps, dtype);
-    const int blocks = vs_ceil_div(total, 256);
+    const int blocks = vs_ceil_div(total / (dtype == VS_F32 ? 4 : 8), 256);      // one thread per 16-byte fragment
     if (dtype == VS_F32)
         hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (float*)dst,
                            d0, d1, ntaps, c_pad, form, total);

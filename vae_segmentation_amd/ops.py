@@ -278,7 +278,7 @@ def repack_trainable():
                 total = ent[0].numel() // (4 if dt == VS_F32 else 2)
                 recs.append(struct.pack("<QQiiiiiiiiq", p.data_ptr(), ent[0].data_ptr(), d0, d1, ntaps, c_pad, form, dt, blocks, 0, total))
                 entries.append((p, ent))
-                blocks += (total + 255) // 256
+                blocks += (total // (4 if dt == VS_F32 else 8) + 255) // 256        # 256-thread blocks of 16-byte fragments
         raw = torch.frombuffer(bytearray(b"".join(recs)), dtype=torch.uint8)
         r["descs"] = raw.to(live[0].device)
         r["blocks"], r["n"], r["entries"], r["dirty"] = blocks, len(recs), entries, False
