@@ -860,7 +860,18 @@ __global__ __launch_bounds__(256) void ema_multi_kernel(float* const* teacher, c
     const float* s = student[ti];
     const long long n = sizes[ti];
     const long long end = (long long)start + MT_CHUNK < n ? (long long)start + MT_CHUNK : n;
-    for (long long i = start + threadIdx.x; i < end; i += 256) t[i] = alpha * t[i] + (1.f - alpha) * s[i];
+    constexpr int R = MT_CHUNK / 256;                    // all loads of the chunk before the first store (see sgd_multi_kernel)
+    float tv[R], sv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long i = start + threadIdx.x + r * 256;
+        tv[r] = i < end ? t[i] : 0.f; sv[r] = i < end ? s[i] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long i = start + threadIdx.x + r * 256;
+        if (i < end) t[i] = alpha * tv[r] + (1.f - alpha) * sv[r];
+    }
 }
 extern "C" int vs_ema_multi(float* const* teacher, const float* const* student, const long long* sizes, const int* block_map,
                             int n_blocks, float alpha, void* stream) {
@@ -877,7 +888,18 @@ __global__ __launch_bounds__(256) void copy_scale_multi_kernel(const float* cons
     float* d = dsts[ti];
     const long long n = sizes[ti];
     const long long end = (long long)start + MT_CHUNK < n ? (long long)start + MT_CHUNK : n;
-    for (long long i = start + threadIdx.x; i < end; i += 256) d[i] = s[i] * scale;
+    constexpr int R = MT_CHUNK / 256;                    // all loads of the chunk before the first store (see sgd_multi_kernel)
+    float sv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long i = start + threadIdx.x + r * 256;
+        sv[r] = i < end ? s[i] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long i = start + threadIdx.x + r * 256;
+        if (i < end) d[i] = sv[r] * scale;
+    }
 }
 extern "C" int vs_copy_scale_multi(const float* const* srcs, float* const* dsts, const long long* sizes, const int* block_map,
                                    int n_blocks, float scale, void* stream) {
