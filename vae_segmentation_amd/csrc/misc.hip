@@ -578,19 +578,37 @@ __global__ __launch_bounds__(256) void dice_multi_finish_kernel(const DiceMulti 
                                                                int channels, int bot, int top, int nblk, float eps) {
     const int K = a.k, NQ = 1 + 2 * K, nc = top - bot;
     __shared__ double s_tot[64 * 2 * (1 + 2 * DICE_MULTI_MAX)];      // [b][ci][q], batch*nc <= 128 checked on the host
-    for (int i = threadIdx.x; i < batch * nc * NQ; i += 256) {
-        const double* src = part + (size_t)i * nblk;
+    __shared__ double s_p16[16][17];
+    // 16 threads per statistic, each summing every 16th block (fixed order: reproducible), 16 statistics per round: the usual 10
+    // statistics x 256 blocks are two rounds of 8 loads per thread instead of 32 dependent rounds in one thread
+    const int sl = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    for (int i0 = 0; i0 < batch * nc * NQ; i0 += 16) {
+        const int i = i0 + sg;
         double t = 0.0;
-        int blk = 0;
-        for (; blk + 8 <= nblk; blk += 8) {
-            double v[8];
+        if (i < batch * nc * NQ) {
+            const double* src = part + (size_t)i * nblk;
+            int blk = sl;
+            for (; blk + 7 * 16 < nblk; blk += 8 * 16) {
+                double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = src[blk + u];
+                for (int u = 0; u < 8; ++u) v[u] = src[blk + 16 * u];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t += v[u];
+                for (int u = 0; u < 8; ++u) t += v[u];
+            }
+            for (; blk < nblk; blk += 16) t += src[blk];
         }
-        for (; blk < nblk; ++blk) t += src[blk];
-        s_tot[i] = t;
+        s_p16[sg][sl] = t;
+        __syncthreads();
+        if (sl == 0 && i < batch * nc * NQ) {
+            double tt = 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tt += s_p16[sg][u];
+            s_tot[i] = tt;
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < batch * nc * NQ; i += 256) {
+        const double t = s_tot[i];
         const int q = i % NQ, bc = i / NQ, ci = bc % nc, b = bc / nc;
         if (q == 0) {
             for (int j = 0; j < K; ++j) sums[(((size_t)j * batch + b) * channels + bot + ci) * 3 + 1] = t;
