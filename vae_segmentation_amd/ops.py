@@ -295,6 +295,29 @@ def clear_pack_cache():
     _PACK_EPOCH[0] += 1
 
 
+def frozen_linear_layout(param, kind, c, v):
+    """Frozen fc weights re-laid ONCE for contiguous access (cached on the tensor like the packed conv images; trainable weights keep the
+    reference layout and the permuting kernels).  The reference flattens NCDHW (k = c*V + v) while activations are channels-last
+    (ph = v*C + c), so read in k order the activation is a 2-byte gather and fc2's backward walks a weight column with a 512-byte stride.
+      "cols_cl"  : (J, K) -> the K columns in channels-last order          (fc_mean / fc_std forward, backward w.r.t. x)
+      "rows_cl_t": (J, K) -> (K, J) transposed, the J rows in channels-last order   (fc2 backward w.r.t. z)"""
+    key = ("lin", kind, c, v)
+    cache = getattr(param, "_vs_pack_cache", None)
+    if cache is None or cache[0] != (param._version, param.data_ptr(), _PACK_EPOCH[0]):
+        cache = ((param._version, param.data_ptr(), _PACK_EPOCH[0]), {})
+        param._vs_pack_cache = cache
+    hit = cache[1].get(key)
+    if hit is None:
+        w = param.detach()
+        with torch.no_grad():
+            if kind == "cols_cl":
+                hit = w.view(w.shape[0], c, v).permute(0, 2, 1).contiguous().view(w.shape[0], c * v)
+            else:
+                hit = w.view(c, v, w.shape[1]).permute(2, 1, 0).contiguous().view(w.shape[1], c * v)
+        cache[1][key] = hit
+    return hit
+
+
 def weights_changed():
     """Called by the native optimisers after they updated parameters through raw pointers (torch's version counters do
     not see that): start a new epoch and refresh all registered trainable images in one launch."""
@@ -929,8 +952,10 @@ class LinearCL(torch.autograd.Function):
         n, d, h, w, c = x.shape
         k_in, j_out = c * d * h * w, weight.shape[0]
         y = torch.empty((n, j_out), dtype=torch.float32, device=x.device)
-        check(lib.vs_linear_fwd(x.data_ptr(), vs_dtype(x), weight.data_ptr(), _p(bias), y.data_ptr(), n, k_in, j_out, c,
-                                d * h * w, 1 if relu else 0, _stream()), "linear_fwd")
+        ctx.cl = (not weight.requires_grad) and d * h * w > 1       # frozen: contiguous channels-last copy of the weight, no permutation
+        wt = frozen_linear_layout(weight, "cols_cl", c, d * h * w) if ctx.cl else weight
+        check(lib.vs_linear_fwd(x.data_ptr(), vs_dtype(x), wt.data_ptr(), _p(bias), y.data_ptr(), n, k_in, j_out, 0 if ctx.cl else c,
+                                0 if ctx.cl else d * h * w, 1 if relu else 0, _stream()), "linear_fwd")
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.has_bias = bias is not None
         return y
@@ -944,8 +969,10 @@ class LinearCL(torch.autograd.Function):
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
         gb = torch.empty(j_out, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        check(lib.vs_linear_bwd(x.data_ptr(), vs_dtype(x), weight.data_ptr(), gy.data_ptr(), _p(yrelu), _p(gx), _p(gw),
-                                _p(gb), n, k_in, j_out, c, d * h * w, _stream()), "linear_bwd")
+        cl = ctx.cl and gw is None
+        wt = frozen_linear_layout(weight, "cols_cl", c, d * h * w) if cl else weight
+        check(lib.vs_linear_bwd(x.data_ptr(), vs_dtype(x), wt.data_ptr(), gy.data_ptr(), _p(yrelu), _p(gx), _p(gw),
+                                _p(gb), n, k_in, j_out, 0 if cl else c, 0 if cl else d * h * w, _stream()), "linear_bwd")
         return gx, gw, gb, None
 
 
@@ -962,8 +989,12 @@ class LinearCLPair(torch.autograd.Function):
         k_in, j_out = c * d * h * w, w1.shape[0]
         y1 = torch.empty((n, j_out), dtype=torch.float32, device=x.device)
         y2 = torch.empty((n, j_out), dtype=torch.float32, device=x.device)
-        check(lib.vs_linear_fwd_pair(x.data_ptr(), vs_dtype(x), w1.data_ptr(), _p(b1), y1.data_ptr(), 1 if relu1 else 0, w2.data_ptr(), _p(b2),
-                                     y2.data_ptr(), 1 if relu2 else 0, n, k_in, j_out, c, d * h * w, _stream()), "linear_fwd_pair")
+        ctx.cl = (not w1.requires_grad) and (not w2.requires_grad) and d * h * w > 1
+        wa = frozen_linear_layout(w1, "cols_cl", c, d * h * w) if ctx.cl else w1
+        wb = frozen_linear_layout(w2, "cols_cl", c, d * h * w) if ctx.cl else w2
+        check(lib.vs_linear_fwd_pair(x.data_ptr(), vs_dtype(x), wa.data_ptr(), _p(b1), y1.data_ptr(), 1 if relu1 else 0, wb.data_ptr(), _p(b2),
+                                     y2.data_ptr(), 1 if relu2 else 0, n, k_in, j_out, 0 if ctx.cl else c, 0 if ctx.cl else d * h * w, _stream()),
+              "linear_fwd_pair")
         ctx.save_for_backward(x, w1, w2, y1 if relu1 else None, y2 if relu2 else None)
         ctx.has_bias = (b1 is not None, b2 is not None)
         ctx.set_materialize_grads(False)
@@ -983,8 +1014,10 @@ class LinearCLPair(torch.autograd.Function):
             gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
             gw = torch.empty_like(wt) if ctx.needs_input_grad[iw] else None
             gb = torch.empty(j_out, dtype=torch.float32, device=x.device) if (hb and ctx.needs_input_grad[ib]) else None
-            check(lib.vs_linear_bwd(x.data_ptr(), vs_dtype(x), wt.data_ptr(), gy.data_ptr(), _p(yrelu), _p(gx), _p(gw), _p(gb), n, k_in,
-                                    j_out, c, d * h * w, _stream()), "linear_bwd")
+            cl = ctx.cl and gw is None
+            wuse = frozen_linear_layout(wt, "cols_cl", c, d * h * w) if cl else wt
+            check(lib.vs_linear_bwd(x.data_ptr(), vs_dtype(x), wuse.data_ptr(), gy.data_ptr(), _p(yrelu), _p(gx), _p(gw), _p(gb), n, k_in,
+                                    j_out, 0 if cl else c, 0 if cl else d * h * w, _stream()), "linear_bwd")
             out[iw], out[ib] = gw, gb
             if gx is not None:
                 gx_total = gx if gx_total is None else gx_total + gx
@@ -1020,6 +1053,13 @@ class LinearToCL(torch.autograd.Function):
         gz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
         gw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
         gb = torch.empty(j_out, dtype=torch.float32, device=z.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if gz is not None and gw is None and gb is None and not weight.requires_grad and side > 1:
+            # frozen fc2: gz[b][k] = sum_ph W2T[k][ph] * gy[b][ph] with the transposed, channels-last-ordered copy — the plain GEMV kernel,
+            # every access contiguous (the permuting kernel walks a weight column with a 512-byte stride)
+            wt = frozen_linear_layout(weight, "rows_cl_t", c, side ** 3)
+            check(lib.vs_linear_fwd(gy.data_ptr(), vs_dtype(gy), wt.data_ptr(), None, gz.data_ptr(), b, j_out, k_in, 0, 0, 0, _stream()),
+                  "linear_fwd (fc2 backward)")
+            return gz, None, None, None, None, None
         check(lib.vs_linear_perm_out_bwd(z.data_ptr(), weight.data_ptr(), gy.data_ptr(), vs_dtype(gy), _p(gz), _p(gw),
                                          _p(gb), b, k_in, j_out, c, side ** 3, _stream()), "linear_perm_out_bwd")
         return gz, gw, gb, None, None, None
