@@ -154,11 +154,12 @@ __device__ __forceinline__ void linear_fwd_body(const void* __restrict__ x, int 
     // LU k-steps per round: the 6912-wide bottleneck layers finish in two rounds of independent loads (with 4 per round the seven
     // dependent rounds made this 22 us for 3.5 MB of weights)
     constexpr int LU = NB <= 2 ? 16 : (NB <= 4 ? 8 : 4);
-    for (int k0 = threadIdx.x; k0 < k_in; k0 += 256 * LU) {
+    const int nt = (int)blockDim.x;                       // 256, or 1024 for the wide layers (one round of loads instead of several)
+    for (int k0 = threadIdx.x; k0 < k_in; k0 += nt * LU) {
         float wv[LU], xv[LU][NB];
 #pragma unroll
         for (int u = 0; u < LU; ++u) {
-            const int k = k0 + u * 256;
+            const int k = k0 + u * nt;
             const bool ok = k < k_in;
             wv[u] = ok ? wr[k] : 0.f;
             const long long ph = phys_index(ok ? k : 0, pc, pv);
@@ -170,7 +171,7 @@ __device__ __forceinline__ void linear_fwd_body(const void* __restrict__ x, int 
 #pragma unroll
             for (int b = 0; b < NB; ++b) acc[b] += wv[u] * xv[u][b];
     }
-    __shared__ float red[4][NB];
+    __shared__ float red[16][NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const float s = wave_sum(acc[b]);
@@ -178,13 +179,14 @@ __device__ __forceinline__ void linear_fwd_body(const void* __restrict__ x, int 
     }
     __syncthreads();
     if (threadIdx.x < batch) {
-        float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x] + (bias ? bias[j] : 0.f);
+        float s = bias ? bias[j] : 0.f;
+        for (int w2 = 0; w2 < (nt >> 6); ++w2) s += red[w2][threadIdx.x];
         if (relu && s < 0.f) s = 0.f;
         y[(size_t)threadIdx.x * j_out + j] = s;
     }
 }
 template <int NB>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const void* __restrict__ x, int x_dtype, const float* __restrict__ w,
+__global__ __launch_bounds__(1024) void linear_fwd_kernel(const void* __restrict__ x, int x_dtype, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int batch, int k_in,
                                                          int j_out, int pc, int pv, int relu) {
     linear_fwd_body<NB>(x, x_dtype, w, bias, y, batch, k_in, j_out, pc, pv, relu);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const void* __restrict_
 // fc_mean and fc_std read the same bottleneck activation (joint_model.py:241-243): blockIdx.y picks the layer, one launch for both
 struct LinearPair { const float* w[2]; const float* bias[2]; float* y[2]; int relu[2]; };
 template <int NB>
-__global__ __launch_bounds__(256) void linear_fwd_pair_kernel(const void* __restrict__ x, int x_dtype, const LinearPair a, int batch, int k_in,
+__global__ __launch_bounds__(1024) void linear_fwd_pair_kernel(const void* __restrict__ x, int x_dtype, const LinearPair a, int batch, int k_in,
                                                               int j_out, int pc, int pv) {
     const int op = blockIdx.y;
     linear_fwd_body<NB>(x, x_dtype, a.w[op], a.bias[op], a.y[op], batch, k_in, j_out, pc, pv, a.relu[op]);
@@ -202,7 +204,8 @@ extern "C" int vs_linear_fwd(const void* x, int x_dtype, const float* wgt, const
                              int j_out, int pc, int pv, int relu, void* stream) {
     if (!x || !wgt || !y || batch <= 0 || batch > LIN_MAXB || k_in <= 0 || j_out <= 0) return VS_EINVAL;
     if (pc > 0 && (long long)pc * pv != k_in) return VS_ESHAPE;
-#define LIN_FWD(NB) hipLaunchKernelGGL(linear_fwd_kernel<NB>, dim3(j_out), dim3(256), 0, (hipStream_t)stream, x, x_dtype, wgt, bias, y, batch, k_in, j_out, pc, pv, relu)
+    const int lin_threads = k_in >= 4096 ? 1024 : 256;
+#define LIN_FWD(NB) hipLaunchKernelGGL(linear_fwd_kernel<NB>, dim3(j_out), dim3(lin_threads), 0, (hipStream_t)stream, x, x_dtype, wgt, bias, y, batch, k_in, j_out, pc, pv, relu)
     if (batch == 1) LIN_FWD(1); else if (batch == 2) LIN_FWD(2); else if (batch <= 4) LIN_FWD(4); else if (batch <= 8) LIN_FWD(8); else LIN_FWD(16);
 #undef LIN_FWD
     VS_CHECK_LAUNCH();
@@ -215,7 +218,8 @@ extern "C" int vs_linear_fwd_pair(const void* x, int x_dtype, const float* w1, c
     if (pc > 0 && (long long)pc * pv != k_in) return VS_ESHAPE;
     LinearPair a;
     a.w[0] = w1; a.w[1] = w2; a.bias[0] = b1; a.bias[1] = b2; a.y[0] = y1; a.y[1] = y2; a.relu[0] = relu1; a.relu[1] = relu2;
-#define LIN_FWD2(NB) hipLaunchKernelGGL(linear_fwd_pair_kernel<NB>, dim3(j_out, 2), dim3(256), 0, (hipStream_t)stream, x, x_dtype, a, batch, k_in, j_out, pc, pv)
+    const int lin_threads = k_in >= 4096 ? 1024 : 256;
+#define LIN_FWD2(NB) hipLaunchKernelGGL(linear_fwd_pair_kernel<NB>, dim3(j_out, 2), dim3(lin_threads), 0, (hipStream_t)stream, x, x_dtype, a, batch, k_in, j_out, pc, pv)
     if (batch == 1) LIN_FWD2(1); else if (batch == 2) LIN_FWD2(2); else if (batch <= 4) LIN_FWD2(4); else if (batch <= 8) LIN_FWD2(8); else LIN_FWD2(16);
 #undef LIN_FWD2
     VS_CHECK_LAUNCH();
