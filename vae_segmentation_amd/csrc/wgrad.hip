@@ -682,11 +682,22 @@ __global__ __launch_bounds__(256) void bias_partial_group_kernel(const G3BiasGro
     float part[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) part[j] = 0.f;
-    for (long long v = (long long)lb * rpi + fy; v < d.rows; v += (long long)d.nblk * rpi) {
-        float f[8];
-        frag_unpack(*(const u32x4*)(d.g + v * d.c_ch + fx * 8), f, (unsigned short*)nullptr);
+    // 8 rows in flight per thread (one load per iteration made the ~32 rounds of a 96^3 layer a dependent chain: 26 us for 100 MB)
+    const long long vstep = (long long)d.nblk * rpi;
+    for (long long v = (long long)lb * rpi + fy; v < d.rows; v += 8 * vstep) {
+        u32x4 q[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) part[j] += f[j];
+        for (int u = 0; u < 8; ++u) {
+            const long long vv = v + u * vstep;
+            q[u] = vv < d.rows ? *(const u32x4*)(d.g + vv * d.c_ch + fx * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float f[8];
+            frag_unpack(q[u], f, (unsigned short*)nullptr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[j] += f[j];
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = part[j];
