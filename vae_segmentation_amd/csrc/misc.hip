@@ -997,3 +997,21 @@ extern "C" int vs_debug_grid_barrier_probe(unsigned int* flags, unsigned long lo
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
+
+// ---- measurement aid: what a kernel's stores add to the cost of a dependent graph node (tools/launch_floor.py) -------------------------
+__global__ void store_probe_kernel(float* p, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == 0) p[i] = 1.f;
+    else if (mode == 1) __builtin_nontemporal_store(1.f, p + i);
+    else if (mode == 2) __hip_atomic_store(p + i, 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (mode == 3) __hip_atomic_store(p + i, 1.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (mode == 4) { const float v = p[i]; if (v == 123.f) p[i + 1] = v; }       // load only
+    else if (mode == 5) p[i] = p[i] + 1.f;                                              // read-modify-write: depends on the previous node's stores
+    else if (mode == 6) p[i] = p[(i * 1031 + 7) % (gridDim.x * blockDim.x)] + 1.f;      // reads what OTHER workgroups (other XCDs) of the previous node wrote
+}
+extern "C" int vs_debug_store_probe(float* p, int n_wg, int mode, void* stream) {
+    if (!p || n_wg <= 0 || n_wg > 65536) return VS_EINVAL;
+    hipLaunchKernelGGL(store_probe_kernel, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, p, mode);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
