@@ -53,9 +53,9 @@ CONV_CASES = [  # (N, Cin, Cout, D, H, W)
     (1, 16, 32, 4, 8, 16), (1, 32, 32, 3, 3, 3), (1, 64, 32, 4, 4, 4), (1, 32, 64, 6, 6, 6), (1, 64, 128, 3, 3, 3),
     (1, 128, 64, 3, 3, 3), (2, 256, 256, 3, 3, 3), (1, 2, 8, 8, 8, 8), (1, 1, 8, 4, 4, 16),
     (1, 128, 128, 8, 8, 8), (1, 64, 64, 16, 16, 16), (2, 128, 64, 8, 8, 8),
-    # small-volume kernel (igemm_k3s.h): ragged box, three samples; two voxels;
-    # the largest volume it takes next to the first one it leaves to k3b
-    (3, 64, 32, 5, 7, 8), (2, 64, 64, 1, 1, 2), (1, 32, 64, 8, 8, 8), (1, 32, 32, 9, 8, 8),
+    # small-volume kernel (igemm_k3s.h, padded volume <= 512 voxels): ragged box, three samples; two voxels;
+    # the largest cube it takes (6^3) next to volumes it leaves to k3b
+    (3, 64, 32, 5, 6, 6), (2, 64, 64, 1, 1, 2), (1, 32, 64, 6, 6, 6), (1, 32, 64, 8, 8, 8), (1, 32, 32, 7, 6, 6),
 ]
 
 
@@ -116,7 +116,7 @@ def test_conv_k3_fwd_bwd(case, lazy, dtype, stat_tol=1.0):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("case", [(3, 96, 32, 5, 7, 8), (2, 160, 96, 2, 3, 4)])
+@pytest.mark.parametrize("case", [(3, 96, 32, 5, 6, 6), (2, 160, 96, 2, 3, 4)])
 def test_conv_k3_small_volume_odd_chunk_counts(case, dtype):
     """3 and 5 chunks of 32 channels: the small-volume kernel keeps two stages in flight, the last stage of an odd count runs alone.
     (Materialised input: the statistics kernels only take the model's channel counts.)"""

@@ -1,4 +1,4 @@
-// 3x3x3 (pad 1) convolution of the SMALL volumes (3^3 ... 8^3: the deep levels, C >= 32), bf16: forward and backward-data.
+// 3x3x3 (pad 1) convolution of the SMALL volumes (up to 6^3: the deep levels, C >= 32), bf16: forward and backward-data.
 //
 // k3b_kernel's 4x4x16 tile is mostly padding there (6^3: 28 % of the tile's columns are voxels, 3^3: 14 %), every wave re-reads the
 // whole weight block from LDS, and the measured bound of those launches is the LDS read bandwidth of the MFMA phase (1.25 KB of
@@ -19,7 +19,7 @@
 #define K3S_LDS_TILE (512 + 28 * 1024)     // 7 fragments x 256 threads: the staging stores are unconditional
 // then: padded sample chunk [TV][64 B] (at least 16 KB: the cross-wave partials alias it), scale / shift tables [C] each
 
-// TVC: compile-time bound of the padded voxel count (128: up to 3x3x3 ... 1024: up to 8x8x8) -> staging fragments per thread
+// TVC: compile-time bound of the padded voxel count (128: up to 3x3x3, 512: up to 6x6x6) -> staging fragments per thread
 // HS: the input is a lazy activation (normalise + ReLU while staging) — compile-time, like every other condition on the staging path: a
 // run-time test between a load and its use makes the compiler drain vmcnt(0), i.e. wait for the prefetched stages as well
 template <bool SUMS, int TVC, bool HS>
@@ -278,10 +278,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     K3_TICK_FLUSH;
 }
 
-// volumes this kernel takes: up to 8 x 8 x 8 (padded sample chunk <= 64 KB of LDS), C a multiple of 32
+// volumes this kernel takes (C a multiple of 32):
 static inline bool k3s_takes(const G1Params& p, int ck) {
     static const int on = getenv("VS_K3_SMALL") ? atoi(getenv("VS_K3_SMALL")) : 1;
-    return on && ck == 32 && p.C % 32 == 0 && p.D <= 8 && p.H <= 8 && p.W <= 8 && p.C <= 1024;
+    // up to 6x6x6 (padded sample chunk <= 512 voxels): at 8^3 (128^3 inputs) the 64 KB chunk and its 16 fragments per thread made this kernel
+    // no faster than k3b_kernel (4.51 vs 4.47 ms per 128^3 domain-adaptation step)
+    return on && ck == 32 && p.C % 32 == 0 && (p.D + 2) * (p.H + 2) * (p.W + 2) <= 512 && p.C <= 1024;
 }
 
 template <bool SUMS, int TVC, bool HS>
@@ -307,6 +309,6 @@ static int k3s_launch(const G1Params& p_in, hipStream_t stream) {
 #define K3S_GO(TVC) return hs ? k3s_launch_t<SUMS, TVC, !SUMS>(p, ctiles, stream) : k3s_launch_t<SUMS, TVC, false>(p, ctiles, stream)
     if (TV <= 128) K3S_GO(128);
     if (TV <= 512) K3S_GO(512);
-    K3S_GO(1024);
+    return VS_ESHAPE;
 #undef K3S_GO
 }

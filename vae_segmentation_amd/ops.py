@@ -52,9 +52,9 @@ def _k3_kid(tname, ck, mt, sums=False, geom=None, m=None, lazy=False):
     hs = "true" if (lazy and not sums) else "false"
     if ck == 8 and m == 8:
         return "k3t_kernel<0,%s,8,%s>" % ("true" if sums else "false", hs)
-    if ck == 32 and geom is not None and max(geom[1:]) <= 8 and os.environ.get("VS_K3_SMALL", "") != "0":
+    if ck == 32 and geom is not None and (geom[1] + 2) * (geom[2] + 2) * (geom[3] + 2) <= 512 and os.environ.get("VS_K3_SMALL", "") != "0":
         tv = (geom[1] + 2) * (geom[2] + 2) * (geom[3] + 2)
-        return "k3s_kernel<%s,%d,%s>" % ("true" if sums else "false", 128 if tv <= 128 else (512 if tv <= 512 else 1024), hs)
+        return "k3s_kernel<%s,%d,%s>" % ("true" if sums else "false", 128 if tv <= 128 else 512, hs)
     yt = 4
     if geom is not None and ck < 32 and mt == 16 and os.environ.get("VS_K3_TALL", "") != "0":
         n, d, h, w = geom
