@@ -145,7 +145,13 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
-    __syncthreads();
+    // The barrier that publishes the statistics tables is taken AFTER the first chunk's loads have been issued (each wave exactly once: in
+    // its first chunk, or after the loop if it has none), so the statistics round trip and the first data round trip overlap instead of
+    // following one another (2 dependent rounds -> 1 at the head of all 36 launches of this kernel per step).
+    bool tables_published = false;
+    auto publish_tables = [&]() {
+        if (!tables_published) { __syncthreads(); tables_published = true; }
+    };
 
     // The chunk loop is instantiated twice, with has_stats a compile-time constant: as a run-time flag its branch sat between
     // every direct-from-global B load and its use, and the compiler drained vmcnt(0) after each load (32 serialized memory
@@ -173,6 +179,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                     for (int cg = 0; cg < 4; ++cg) bq[kg][cg] = *(const u32x4*)(xin + gofs[cg] + toff);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                publish_tables();
 #pragma unroll
                 for (int kg = 0; kg < NKG; ++kg) {
                     if (HS) {
@@ -203,6 +210,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                         for (int cg = 0; cg < 4; ++cg) bq[kg][cg] = *(const u32x4*)(xin + gofs[cg] + toff_g);
                     }
                     __builtin_amdgcn_sched_barrier(0);       // keep the scheduler from sinking the requests back between the MFMAs
+                    publish_tables();
 #pragma unroll
                     for (int kg = 0; kg < NK; ++kg) {
                         const int cc = (kg % KPT) * KG + g * EPL;
@@ -225,6 +233,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
                         abuf[j][rb] = j < NK ? wch[(size_t)(rb0 + rb) * rb_stride + j * 64] : u32x4{0u, 0u, 0u, 0u};
+                publish_tables();
 #pragma unroll 1
                 for (int kgb = 0; kgb < NK; kgb += PD) {
 #pragma unroll
@@ -261,6 +270,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         }
     };
     if (has_stats) chunk_loop(std::true_type{}); else chunk_loop(std::false_type{});
+    publish_tables();
     if (splitw) {
         // fixed order w0 + w1 + w2 + w3 (bitwise reproducible); waves 1-3 then hold no columns of their own
         f32x4* s_part = (f32x4*)(smem + G1_LDS_BYTES);   // [3 waves][RB][4][64 lanes]
