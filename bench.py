@@ -1,51 +1,75 @@
 #!/usr/bin/env python3
 """Headline benchmark: joint VAE+seg train-step throughput (volumes/s) on synthetic 96^3 volumes, batch 2 per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A step = zero_grad -> Segmentation fwd -> frozen VAE fwd -> Dice losses -> backward -> [RCCL all-reduce] -> SGD(momentum)
-(the `joint_train` method of the reference, main_source.py:449-471,660-661), bf16 activations / fp32 accumulate,
-inputs resident in HBM.  Rank 0 prints ONE JSON line with the whole-job volumes/s, plus
-  roofline      live HIP-event timing of the dominant kernel's launches inside real steps vs its roofline bound
-  cpu_baseline  the same step on the host cores with the CPU oracle (plain eager PyTorch fp32), bounded sample.
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (one rank per GPU), or as
+plain `python bench.py --gpus N`, in which case this process spawns that launcher itself — before it touches the GPU — and
+relays rank 0's single JSON line.
+
+A step = zero_grad -> Segmentation fwd -> frozen VAE fwd -> Dice losses -> backward -> [RCCL all-reduces, overlapped with the
+weight-gradient kernels] -> SGD(momentum)  (the `joint_train` method of the reference, main_source.py:449-471,660-661),
+bf16 activations / fp32 accumulate, inputs resident in HBM, HIP-graph replay.  Rank 0 prints ONE JSON line:
+  value/ms_per_step  whole-job volumes/s over all ranks (barrier + synchronize on both sides, max over ranks)
+  roofline           the WHOLE STEP against its binding roofline: algorithmic bytes per step (1.28 GB per volume,
+                     every activation touched once per pass) / ms_per_step against HBM peak — recomputable from this line alone;
+                     `families` lists the per-kernel-family figures from live HIP-event timing (or --no-families)
+  fp32_parity_mode   the same step with the fp32 kernels (the mode that meets the 1e-3 parity gate), N=1 only
+  cpu_baseline       the same step on the host cores with the CPU oracle (plain eager PyTorch fp32), bounded sample, N=1 only.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
 
 SIDE, BATCH, DIM = 96, 2, 128
-# algorithmic work per volume per joint_train step at 96^3 (SURVEY.md §8a/§8d): 3 Seg passes + 2 VAE passes
+# algorithmic work per volume per joint_train step at 96^3 (SURVEY.md §8a/§8d, BASELINE.md §3): 3 Seg passes + 2 VAE passes
 FLOPS_PER_VOLUME = 164.0e9
+BYTES_PER_VOLUME = {"bf16": 1.28e9, "fp16": 1.28e9, "fp32": 2.56e9}
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--side", type=int, default=SIDE)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 (parity-mode) timing entry")
+    ap.add_argument("--no-families", action="store_true", help="skip the live per-kernel-family timing pass")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--detail", action="store_true", help="print the slowest individual launches (stderr)")
+    ap.add_argument("--dump-launches", default=None, help="write every live-timed launch (kernel, detail, us, bytes, flops) to this JSON file")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 path on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="testing aid: every rank uses cuda:0")
     ap.add_argument("--force-dist", action="store_true", help="testing aid: initialise the process group and run the gradient "
                     "all-reduce path even with one rank (exercises RCCL on a 1-GPU box)")
+    ap.add_argument("--master-port", type=int, default=29533)
     return ap.parse_args()
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (this process has not
+    initialised the GPU and never will) and relay its output; rank 0 of the child job prints the JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(a.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def build(side, dtype, rank):
+    import torch
     import joint_model as M
     from oracle import ref_cpu as O      # only for the RNG-free weight fill / synthetic inputs shared with the tests
     seg = M.Segmentation(n_channels=1, n_class=2, norm_type=1)
@@ -56,7 +80,7 @@ def build(side, dtype, rank):
     for p in joint.Vae.parameters():
         p.requires_grad = False
     joint.Vae.eval()
-    M.set_kernel_dtype(joint, torch.bfloat16 if dtype == "bf16" else torch.float32)
+    M.set_kernel_dtype(joint, {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype])
     img = O.synthetic_image(BATCH, side, seed=2 + 10 * rank).cuda()
     lab = O.synthetic_label(BATCH, side, seed=3 + 10 * rank).cuda()
     return joint, img, lab
@@ -88,6 +112,7 @@ def usable_cores():
 
 def cpu_baseline(side, steps, budget_s=40.0):
     """The oracle's joint_train step (stock eager PyTorch fp32) on the host cores; 1 warm-up + `steps` timed."""
+    import torch
     from oracle import ref_cpu as O
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -111,32 +136,11 @@ def cpu_baseline(side, steps, budget_s=40.0):
                       "median, %d threads" % (len(timed), side, BATCH, cores)}
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (a.gpus, a.gpus))
-    if a.share_gpu:
-        local = 0
-    torch.cuda.set_device(local)
-    use_dist = world > 1 or a.force_dist
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(a.backend)
-
-    from vae_segmentation_amd import ddp, optim, profiling
+def make_step(a, dtype, rank, use_dist):
+    """-> (step(), loss_fn, seg_params, closer): one train step of configs[1] in the given kernel dtype."""
+    from vae_segmentation_amd import ddp, optim
     from vae_segmentation_amd import train as T
-
-    joint, img, lab = build(a.side, a.dtype, rank)
+    joint, img, lab = build(a.side, dtype, rank)
     opt = optim.SGD([{"params": joint.Seg.parameters(), "lr": 1e-2}, {"params": joint.Vae.parameters(), "lr": 0.0}],
                     lr=1e-2, momentum=0.9, weight_decay=0.0)
     seg_params = [p for p in joint.Seg.parameters()]
@@ -157,24 +161,77 @@ def main():
             loss, _ = loss_fn()
             loss.backward()
             if sync is not None:
-                opt.step_with(seg_params, sync())
+                opt.step_with(sync.params, sync())
             else:
                 opt.step()
             return loss
     else:
-        gs = T.GraphedStep(loss_fn, seg_params, opt, warmup=2)
-        graph_grads = [p.grad for p in seg_params]
+        gs = T.GraphedStep(loss_fn, seg_params, opt, grad_sync=sync, warmup=2)
+        step = gs.step
 
-        def step():
-            gs.graph.replay()
-            if sync is not None:
-                opt.step_with(seg_params, sync(graph_grads))
-            else:
-                opt.step()
-            return gs.loss
+    def closer():
+        if sync is not None:
+            sync.close()
+    return step, loss_fn, seg_params, closer
 
-    for _ in range(a.warmup):
+
+def timed_steps(step, steps, warmup, fence):
+    for _ in range(warmup):
         step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    fence()
+    return time.perf_counter() - t0, loss
+
+
+def step_roofline(dtype, ms_per_step, families):
+    """Whole-step roofline: the step is HBM-bound by the algorithm (2.56 GB -> 0.32 ms at 8 TB/s against
+    328 GF -> 0.13 ms at the bf16 MFMA peak), so `achieved` = algorithmic bytes per step / measured step time."""
+    from vae_segmentation_amd import profiling
+    nbytes = BYTES_PER_VOLUME[dtype] * BATCH
+    flops = FLOPS_PER_VOLUME * BATCH
+    sec = ms_per_step * 1e-3
+    t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_PEAK_TFLOPS[dtype] * 1e12)
+    out = {"scope": "whole step (one HIP-graph replay + optimiser launches)",
+           "algorithmic_bytes_per_step": nbytes, "algorithmic_flops_per_step": flops,
+           "mfma": {"achieved": flops / sec / 1e12, "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": flops / sec / 1e12 / MFMA_PEAK_TFLOPS[dtype]},
+           "hbm": {"achieved": nbytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS}}
+    lead = "hbm" if t_hbm >= t_mfma else "mfma"
+    out.update({"bound": lead, "achieved": out[lead]["achieved"], "peak": out[lead]["peak"], "unit": out[lead]["unit"], "frac": out[lead]["frac"],
+                "traffic": profiling.measured_step_traffic()})
+    if families is not None:
+        out["families"] = families
+    return out
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(a))        # nothing in this process has touched the GPU
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.share_gpu:
+        local = 0
+    torch.cuda.set_device(local)
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(a.master_port))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
+
+    from vae_segmentation_amd import profiling
 
     def fence():
         torch.cuda.synchronize()
@@ -182,22 +239,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
+    step, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, use_dist)
+    dt, loss = timed_steps(step, a.steps, a.warmup, fence)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    ms_per_step = 1e3 * dt / a.steps
 
-    roof, cpu = None, None
-    if rank == 0:
-        # dominant-kernel timing: HIP events around every launch of that kernel inside real (eager) steps
-        roof = profiling.dominant_kernel_roofline(lambda: (loss_fn()[0]).backward(), seg_params, a.dtype, steps=2)
+    families, fp32_mode, cpu = None, None, None
+    if rank == 0 and not a.no_families:
+        # per-kernel-family timing: HIP events around every launch inside real (eager) forward+backward passes
+        closer()                                 # gradients back to ordinary tensors for the eager profiling pass
+        families = profiling.kernel_families(lambda: (loss_fn()[0]).backward(), seg_params, a.dtype, steps=2)
+        if a.dump_launches:
+            with open(a.dump_launches, "w") as f:
+                json.dump([{"us": round(ms * 1e3, 3), "kernel": kid, "detail": det, "bytes": nb, "flops": fl}
+                           for ms, kid, det, nb, fl in profiling.LAST_LAUNCHES], f)
         if a.detail:
             tot = sum(r[0] for r in profiling.LAST_LAUNCHES) / 2
             print("timed launches: %.3f ms per step over %d launches" % (tot, len(profiling.LAST_LAUNCHES) // 2), file=sys.stderr)
@@ -205,6 +264,15 @@ def main():
                 print("%8.1f us  %-42s %-52s %7.1f GB/s %8.2f TF/s" % (ms * 1e3, kid, det, nb / ms / 1e6, fl / ms / 1e9), file=sys.stderr)
     if use_dist:
         dist.barrier()
+    if rank == 0 and world == 1 and not a.no_fp32_mode and a.dtype != "fp32":
+        del step, loss_fn, seg_params
+        torch.cuda.empty_cache()
+        step32, _, _, closer32 = make_step(a, "fp32", rank, False)
+        n32 = max(5, min(a.steps, 10))
+        dt32, _ = timed_steps(step32, n32, 2, lambda: torch.cuda.synchronize())
+        fp32_mode = {"ms_per_step": 1e3 * dt32 / n32, "value": BATCH * n32 / dt32, "unit": "volumes/s", "steps": n32,
+                     "note": "fp32 storage + exact-f32 MFMA: the mode that meets the 1e-3 parity gate (tests/test_gpu_model.py)"}
+        del step32
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.side, a.cpu_steps)
 
@@ -212,14 +280,16 @@ def main():
         vols = world * BATCH * a.steps / dt
         out = {
             "metric": "3D train-step volumes/sec at 96^3 batch=2 (joint VAE+seg)", "value": vols, "unit": "volumes/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if a.dtype == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[a.dtype], "data": "synthetic",
             "config": {"workload": "configs[1]: %d^3 joint VAE+seg training step (joint_train), batch=%d/GPU, %s activations + fp32 accumulate, "
                                    "SGD momentum 0.9, VAE frozen, HIP-graph replay" % (a.side, BATCH, a.dtype),
                        "global_batch": world * BATCH, "parallelism": "dp%d" % world, "final_loss": final_loss,
-                       "step_flops_fraction_of_mfma_peak": FLOPS_PER_VOLUME * BATCH * a.steps / dt / (MFMA_PEAK_TFLOPS["bf16" if a.dtype == "bf16" else "f32"] * 1e12)},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "grad_exchange": ("2-bucket RCCL all-reduce, bucket 0 under the full-resolution weight-gradient kernels"
+                                         if use_dist else "none (1 rank)")},
+            "roofline": step_roofline(a.dtype, ms_per_step / 1.0, families) if a.side == SIDE else None,
+            "fp32_parity_mode": fp32_mode, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if use_dist:

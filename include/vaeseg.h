@@ -9,7 +9,7 @@
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); nothing is allocated, freed or
  *     synchronised inside; every launch goes to `stream` (a hipStream_t passed as void*).
  *   - activations are channels-last: [N][D][H][W][C], C a multiple of 8, element type `dtype`
- *     (VS_F32 or VS_BF16).  "planar" tensors are the reference's NCDHW fp32: [N][C][D*H*W].
+ *     (VS_F32, VS_BF16 or VS_F16; accumulation is always fp32).  "planar" tensors are the reference's NCDHW fp32: [N][C][D*H*W].
  *   - a *lazy* activation is a raw conv output plus `stats`: double[N][C][2] = (sum, sum of squares)
  *     over the D*H*W voxels of each (n,c), accumulated by the producing kernel.  Passing `stats` to a
  *     consumer makes it read relu((x-mean)*rstd) — InstanceNorm3d(affine=False, eps) + ReLU
@@ -29,7 +29,7 @@ extern "C" {
 
 #define VS_VERSION 100
 
-enum { VS_F32 = 0, VS_BF16 = 1 };
+enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2 };   /* storage type of activations: fp32 (parity mode), bf16, IEEE fp16 (needs loss scaling, see vs_loss_scale_*) */
 enum { VS_OK = 0, VS_EINVAL = -1, VS_ESHAPE = -2, VS_EDTYPE = -3, VS_EWORKSPACE = -4, VS_EALIGN = -5 };
 
 /* geometry of an implicit-GEMM convolution */
@@ -171,6 +171,10 @@ int vs_instnorm_relu_bwd_pair(const void* g, const void* x1, const double* x1_st
  * keep ~ Bernoulli(1-p) from a counter-based hash of (seed, element index) — the same call with the same seed applied to
  * the incoming gradient is the backward.  (The reference draws from torch's Philox stream; only the distribution matches.) */
 int vs_dropout(const void* x, void* out, long long count, float p, unsigned long long seed, int dtype, void* stream);
+/* The multiplier vs_dropout (and the fused logit dropout of vs_conv_k3_softmax2_dropout_fwd) applies to element i, i < count:
+ * mask[i] = 0 or 1/(1-p).  Element order: the tensor's own memory order — channels-last [N][V][C] for vs_dropout, planar [N][2][V]
+ * for the logits.  Lets a checker feed the SAME mask to the reference arithmetic (F.dropout replaced by a multiply). */
+int vs_dropout_mask(float* mask, long long count, float p, unsigned long long seed, void* stream);
 
 /* ---- layout glue at the NCDHW boundary ----------------------------------------------------------- */
 /* planar fp32 [N][c_src][V] -> channels-last [N][V][c_pad] (zero-filled channels >= c_src) */
@@ -267,7 +271,7 @@ int vs_ema_multi(float* const* teacher, const float* const* student, const long 
  * (main_source.py:354). */
 int vs_copy_scale_multi(const float* const* srcs, float* const* dsts, const long long* sizes, const int* block_map,
                         int n_blocks, float scale, void* stream);
-/* flat helper: dst[i] = src[i]*scale */
+/* flat helper: dst[i] = src[i]*scale (dst may equal src: the 1/world scale after a sum all-reduce when the collective has no average) */
 int vs_scale_copy(const float* src, float* dst, long long count, float scale, void* stream);
 
 /* Measurement aid (no reference counterpart): one wave idles on the stream for `microseconds` (<= 1000).  bench.py's live

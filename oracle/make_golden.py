@@ -179,6 +179,54 @@ def _seg32(dt):
     return d
 
 
+def gold_seg96():
+    """seg_train step (main_source.py:421-441, eps 1e-4) at the BASELINE size: 96^3, batch 2.  Segmentation alone is ~30 layers deep
+    instead of the joint step's ~60, so the reference's own fp32-vs-fp64 gradient distance is small here and the 2e-3 floor of the
+    gradient check binds at the real layer shapes."""
+    save("seg96", both_precisions(_seg96))
+
+
+def _seg96(dt):
+    d = {}
+    seg = RM.Segmentation(n_channels=1, n_class=2, norm_type=1)
+    O.deterministic_fill_(seg, seed=0)
+    seg = seg.to(dt)
+    img, lab = O.synthetic_image(2, 96, seed=2).to(dt), O.synthetic_label(2, 96, seed=3)
+    batch = {"img": img, "gt": O.one_hot(lab).to(dt)}
+    batch = seg(batch, "img", "pred")
+    dsc = 1 - main_source_avg_dsc(batch["pred"], batch["gt"], 1, 2)
+    dsc.backward()
+    d["dice_loss"] = dsc.detach().numpy()
+    put(d, "pred", batch["pred"], 512)
+    put_grads(d, "seg", seg)
+    return d
+
+
+def gold_joint160_fwd():
+    """BASELINE configs[4] geometry: the joint forward at 160^3, batch 2 (reference Segmentation + the reference VAE's own blocks composed
+    around fc layers of width 256*5^3, as for 96^3), no gradients (the fp64 run of a 160^3 backward does not fit this container)."""
+    save("joint160_fwd", both_precisions(_joint160_fwd))
+
+
+def _joint160_fwd(dt):
+    d = {}
+    joint, fwd = joint_case(160, False, dt)
+    img, lab = O.synthetic_image(2, 160, seed=2).to(dt), O.synthetic_label(2, 160, seed=3)
+    t0 = time.time()
+    with torch.no_grad():
+        batch = {"img": img, "gt": O.one_hot(lab).to(dt)}
+        batch = joint.Seg(batch, "img", "pred")
+        batch["recon"], batch["mean"], batch["std"] = fwd(batch["pred"])
+        recon_loss = 1 - main_source_avg_dsc(batch["pred"], batch["recon"], 1, 2)
+        dsc_loss = 1 - main_source_avg_dsc(batch["pred"], batch["gt"], 1, 2)
+    print("  joint160 fwd %s %.1fs" % (dt, time.time() - t0))
+    d["recon_loss"], d["dice_loss"], d["final"] = recon_loss.numpy(), dsc_loss.numpy(), (0.1 * recon_loss + dsc_loss).numpy()
+    d["mean"], d["std"] = batch["mean"].numpy(), batch["std"].numpy()
+    put(d, "pred", batch["pred"], 512)
+    put(d, "recon", batch["recon"], 512)
+    return d
+
+
 def composed_vae(ref_vae, side):
     """The reference VAE's own sub-modules around fc layers of width 256*side^3: the
     reference forward hard-codes 16384 / view(256,4,4,4) (joint_model.py:241,253), so for S != 128
@@ -304,10 +352,15 @@ def _da128(dt):
     dsc_loss = 1 - REV.avg_dsc(batch, "pred", "gt", botindex=1, topindex=2)
     fake_loss = 1 - REV.avg_dsc(batch, "pred", "fake", botindex=1, topindex=2)
     final0 = 1.0 * recon_loss + fake_loss
-    final0.backward()
+    final0.backward(retain_graph=True)
+    put_grads(d, "seg", student.Seg)
     cur = O.lambda_schedule(recon_loss, 1.0)
     final8 = (recon_loss + 1 / cur * fake_loss) if cur > 1 else (cur * recon_loss + fake_loss)
     final9 = (cur * recon_loss + fake_loss) / (1 + cur)
+    for p in student.Seg.parameters():
+        p.grad = None
+    final8.backward()                               # domain_loss_type 8 (main_target.py:550-560): its own gradient set, keys "seg8.grad.*"
+    put_grads(d, "seg8", student.Seg)
     for k, v in (("recon_loss", recon_loss), ("kl", klloss), ("dice_loss", dsc_loss), ("fake_loss", fake_loss),
                  ("final0", final0), ("final8", final8), ("final9", final9)):
         d[k] = v.detach().numpy()
@@ -318,7 +371,6 @@ def _da128(dt):
     d["fake.sum"] = batch["fake"].double().sum().numpy()
     cb = REV.confident_binarize(fake_soft)
     d["cfake.sum"] = cb.double().sum().numpy()
-    put_grads(d, "seg", student.Seg)
     return d
 
 
@@ -498,6 +550,8 @@ CASES = {
     "vae128_train": gold_vae128_native,
     "ft128": gold_ft128,
     "rank4": gold_rank4,
+    "seg96": gold_seg96,
+    "joint160_fwd": gold_joint160_fwd,
 }
 
 if __name__ == "__main__":

@@ -28,9 +28,15 @@ def test_main_source_joint_train_then_main_target_domain_adaptation(tmp_path):
     assert set(blob) == {"epoch", "model_state_dict", "optimizer_state_dict"}
     assert any(k.startswith("Seg.in_block.conv.0.") for k in blob["model_state_dict"])
     assert json.load(open(tmp_path / "tensorboard" / "src" / "score_0.json"))
+    assert "graph replay" in out and "train step captured as a HIP graph" in out          # the entry point runs the benchmarked (graph-replayed) path
     out = _run([os.path.join(REPO, "main_target.py"), "tgt", "-M", "domain_adaptation", "--load_prefix_joint", "src",
-                "--checkpoint_name", "model_epoch1.ckpt", "--domain_loss_type", "8"] + common, str(tmp_path))
-    assert "Finished Training" in out
+                "--checkpoint_name", "model_epoch1.ckpt", "--domain_loss_type", "8", "--train_first_epoch", "--pseudo_save_epoch", "1",
+                "--update_every_iteration"] + common, str(tmp_path))
+    assert "Finished Training" in out and "graph replay" in out
+    # epoch 0 of domain_adaptation only validates in the reference (main_target.py:506); dropout > 0 falls back to eager launches
+    out = _run([os.path.join(REPO, "main_target.py"), "tgt_do", "-M", "domain_adaptation", "--load_prefix_joint", "src",
+                "--checkpoint_name", "model_epoch1.ckpt", "--seg_dropout", "0.1", "--train_first_epoch"] + common, str(tmp_path))
+    assert "Finished Training" in out and "(eager)" in out
     # test-time training of each validation case (main_target.py --val_finetune, scripts/target/domain_msd_dh_ft1.bash)
     out = _run([os.path.join(REPO, "main_target.py"), "tgt_ft", "-M", "domain_adaptation", "--load_prefix_joint", "src",
                 "--checkpoint_name", "model_epoch1.ckpt", "--domain_loss_type", "8", "--val_finetune", "1", "--test_only"] + common,

@@ -1,0 +1,171 @@
+"""GPU parity at the REAL layer shapes of BASELINE configs[1] (96^3, B=2) and configs[3] (128^3, B=1): every distinct 3x3x3, stride-2 and
+transposed convolution of Segmentation / VAE (joint_model.py:204-226,349-367), forward + backward-data (with the fused
+InstanceNorm+ReLU-backward sums and the apply pass) + weight / bias gradient, lazy (InstanceNorm+ReLU-on-load) input, against
+F.conv3d / F.conv_transpose3d autograd in fp32 on the CPU — the same tolerances as the small-shape tests in test_gpu_ops.py
+(fp32 kernels 2e-5, x4 for quantities behind the lazy input; bf16 / fp16 1.5e-2, x4).
+
+The model-level goldens at 96^3 / 128^3 bound gradients only loosely (the reference's own fp32 gradients sit 1e-2..1e-1 from fp64
+there, tests/golden_util.py); this file is what pins the backward kernels at the sizes the benchmark runs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_gpu_ops import TOL, from_cl, in_relu, q, relerr, rnd, to_cl
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+# (N, Cin, Cout, side) — configs[1]: B=2 at 96^3; configs[3]: B=1 at 128^3 (levels 128, 64; the deeper levels of 128^3 are the 96^3
+# shapes with other sides, covered by the ragged cases of test_gpu_ops.py)
+K3_LAYERS = [
+    (2, 1, 8, 96), (2, 2, 8, 96), (2, 8, 8, 96), (2, 16, 8, 96),                      # in_block (Seg / VAE), up5
+    (2, 8, 16, 48), (2, 16, 16, 48), (2, 32, 16, 48),                                 # down1, up4
+    (2, 16, 32, 24), (2, 32, 32, 24), (2, 64, 32, 24),                                # down2, up3
+    (2, 32, 64, 12), (2, 64, 64, 12), (2, 128, 64, 12),                               # down3, up2
+    (2, 64, 128, 6), (2, 128, 128, 6), (2, 256, 128, 6),                              # down4, up1 (VAE)
+    (2, 128, 256, 3), (2, 256, 256, 3),                                               # down5 (VAE)
+    (1, 8, 8, 128), (1, 16, 8, 128), (1, 16, 16, 64), (1, 32, 16, 64), (1, 32, 32, 32), (1, 128, 128, 8), (1, 256, 256, 4),
+]
+K2_LAYERS = [(2, 8, 96), (2, 16, 48), (2, 32, 24), (2, 64, 12), (2, 128, 6), (1, 8, 128), (1, 16, 64)]           # Down: Conv3d(C, C, 2, stride 2)
+T2_LAYERS = [(2, 16, 48), (2, 32, 24), (2, 64, 12), (2, 128, 6), (2, 256, 3), (1, 16, 64), (1, 32, 32)]          # Up: ConvTranspose3d(C, C, 2, stride 2), input side
+
+
+def _ops():
+    from vae_segmentation_amd import ops
+    return ops
+
+
+def _report(tag, errs, lims):
+    bad = {k: (errs[k], lims[k]) for k in errs if not errs[k] < lims[k]}
+    print("\n%s: %s" % (tag, ", ".join("%s %.2e (<%.1e)" % (k, errs[k], lims[k]) for k in errs)))
+    assert not bad, "%s: %s" % (tag, bad)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", K3_LAYERS)
+def test_k3_layer_shapes(case, dtype):
+    ops = _ops()
+    n, cin, cout, s = case
+    x = rnd(n, cin, s, s, s, seed=1)
+    wt = rnd(cout, cin, 3, 3, 3, seed=2, scale=(3.0 / (27 * cin)) ** 0.5)
+    gy = rnd(n, cout, s, s, s, seed=3)
+    xq, wq, gq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), q(gy, dtype)
+    y_ref = F.conv3d(in_relu(xq), wq, None, padding=1)
+    (y_ref * gq).sum().backward()
+
+    x_cl = to_cl(x, ops.cpad(cin), dtype).requires_grad_(True)
+    xs = ops.instnorm_stats(x_cl.detach())
+    w_gpu = q(wt, dtype).cuda().requires_grad_(True)
+    ops.stats_arena_begin(x_cl.device)
+    y, ys = ops.ConvK3.apply(x_cl, xs, w_gpu, None)
+    y.backward(to_cl(gy, ops.cpad(cout), dtype))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    yr = q(y_ref.detach(), dtype).double()
+    st = ys.cpu()[:, :cout]
+    ref_sum, ref_sq = yr.sum((2, 3, 4)), (yr * yr).sum((2, 3, 4))
+    errs = {"y": relerr(from_cl(y, cout), y_ref.detach()),
+            "stat_sum": float((st[..., 0] - ref_sum).abs().max() / ref_sq.sqrt().max()),
+            "stat_sq": float((st[..., 1] - ref_sq).abs().max() / ref_sq.max()),
+            "gx": relerr(from_cl(x_cl.grad, cin), xq.grad), "gw": relerr(w_gpu.grad.cpu(), wq.grad)}
+    lims = {"y": tol, "stat_sum": 4 * tol, "stat_sq": 4 * tol, "gx": 4 * tol, "gw": 4 * tol}
+    _report("k3 %s %s" % (case, dtype), errs, lims)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", K2_LAYERS)
+def test_k2s2_layer_shapes(case, dtype):
+    ops = _ops()
+    n, c, s = case
+    x = rnd(n, c, s, s, s, seed=4)
+    wt = rnd(c, c, 2, 2, 2, seed=5, scale=(3.0 / (8 * c)) ** 0.5)
+    b = rnd(c, seed=6, scale=0.1)
+    gy = rnd(n, c, s // 2, s // 2, s // 2, seed=7)
+    xq, wq, bq, gq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), b.clone().requires_grad_(True), q(gy, dtype)
+    y_ref = F.conv3d(in_relu(xq), wq, bq, stride=2)
+    (y_ref * gq).sum().backward()
+    x_cl = to_cl(x, c, dtype).requires_grad_(True)
+    xs = ops.instnorm_stats(x_cl.detach())
+    w_gpu, b_gpu = q(wt, dtype).cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    ops.stats_arena_begin(x_cl.device)
+    y = ops.ConvK2S2.apply(x_cl, xs, w_gpu, b_gpu)
+    y.backward(to_cl(gy, c, dtype))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    errs = {"y": relerr(from_cl(y, c), y_ref.detach()), "gx": relerr(from_cl(x_cl.grad, c), xq.grad),
+            "gw": relerr(w_gpu.grad.cpu(), wq.grad), "gb": relerr(b_gpu.grad.cpu(), bq.grad)}
+    _report("k2s2 %s %s" % (case, dtype), errs, {"y": tol, "gx": 4 * tol, "gw": 4 * tol, "gb": 4 * tol})
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", T2_LAYERS)
+def test_transposed_layer_shapes(case, dtype):
+    ops = _ops()
+    n, c, s = case
+    x = rnd(n, c, s, s, s, seed=8)
+    wt = rnd(c, c, 2, 2, 2, seed=9, scale=(3.0 / c) ** 0.5)
+    b = rnd(c, seed=10, scale=0.1)
+    gy = rnd(n, c, 2 * s, 2 * s, 2 * s, seed=11)
+    xq, wq, bq, gq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), b.clone().requires_grad_(True), q(gy, dtype)
+    y_ref = F.conv_transpose3d(in_relu(xq), wq, bq, stride=2)
+    (y_ref * gq).sum().backward()
+    x_cl = to_cl(x, c, dtype).requires_grad_(True)
+    xs = ops.instnorm_stats(x_cl.detach())
+    w_gpu, b_gpu = q(wt, dtype).cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    ops.stats_arena_begin(x_cl.device)
+    y = ops.ConvT2S2.apply(x_cl, xs, w_gpu, b_gpu)
+    y.backward(to_cl(gy, c, dtype))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    errs = {"y": relerr(from_cl(y, c), y_ref.detach()), "gx": relerr(from_cl(x_cl.grad, c), xq.grad),
+            "gw": relerr(w_gpu.grad.cpu(), wq.grad), "gb": relerr(b_gpu.grad.cpu(), bq.grad)}
+    _report("convT %s %s" % (case, dtype), errs, {"y": tol, "gx": 4 * tol, "gw": 4 * tol, "gb": 4 * tol})
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [(2, 96), (1, 128)])
+def test_out_block_softmax_layer_shapes(case, dtype):
+    """out_block (8 -> 2, live bias) + Softmax at full resolution, with the backward through the softmax, the fused IN-backward sums and
+    the weight / bias gradients (joint_model.py:366-367,386-388)."""
+    ops = _ops()
+    n, s = case
+    x = rnd(n, 8, s, s, s, seed=12)
+    wt = rnd(2, 8, 3, 3, 3, seed=13, scale=0.3)
+    b = rnd(2, seed=14, scale=0.2)
+    gp = rnd(n, 2, s, s, s, seed=15)
+    xq, wq, bq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), b.clone().requires_grad_(True)
+    p_ref = torch.softmax(F.conv3d(in_relu(xq), wq, bq, padding=1), dim=1)
+    (p_ref * gp).sum().backward()
+    x_cl = to_cl(x, 8, dtype).requires_grad_(True)
+    xs = ops.instnorm_stats(x_cl.detach())
+    w_gpu, b_gpu = q(wt, dtype).cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    ops.stats_arena_begin(x_cl.device)
+    p = ops.ConvK3Softmax.apply(x_cl, xs, w_gpu, b_gpu)
+    p.backward(gp.cuda())
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    errs = {"p": relerr(p.cpu(), p_ref.detach()), "gx": relerr(from_cl(x_cl.grad, 8), xq.grad),
+            "gw": relerr(w_gpu.grad.cpu(), wq.grad), "gb": relerr(b_gpu.grad.cpu(), bq.grad)}
+    _report("out_block %s %s" % (case, dtype), errs, {"p": tol, "gx": 4 * tol, "gw": 4 * tol, "gb": 4 * tol})
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [(2, 16, 48), (2, 32, 24), (1, 16, 64)])
+def test_skip_merge_layer_shapes(case, dtype):
+    """The additive U-Net skips at up3 / up4 (joint_model.py:380,382) at their real sizes: relu(IN(a)) + relu(IN(b)) and its pair backward."""
+    ops = _ops()
+    n, c, s = case
+    x1, x2 = rnd(n, c, s, s, s, seed=16), rnd(n, c, s, s, s, seed=17) * 2 + 0.3
+    g = rnd(n, c, s, s, s, seed=18)
+    a1, a2 = q(x1, dtype).requires_grad_(True), q(x2, dtype).requires_grad_(True)
+    ref = in_relu(a1) + in_relu(a2)
+    (ref * q(g, dtype)).sum().backward()
+    c1, c2 = to_cl(x1, c, dtype).requires_grad_(True), to_cl(x2, c, dtype).requires_grad_(True)
+    ops.stats_arena_begin(c1.device)
+    out = ops.Materialize.apply(c1, ops.instnorm_stats(c1.detach()), c2, ops.instnorm_stats(c2.detach()))
+    out.backward(to_cl(g, c, dtype))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    errs = {"out": relerr(from_cl(out, c), ref.detach()), "g1": relerr(from_cl(c1.grad, c), a1.grad), "g2": relerr(from_cl(c2.grad, c), a2.grad)}
+    _report("skip %s %s" % (case, dtype), errs, {"out": tol, "g1": 2 * tol, "g2": 2 * tol})

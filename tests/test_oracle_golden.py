@@ -74,6 +74,16 @@ def test_seg32():
     assert l4.item() == pytest.approx(float(g["dice_loss_eps1e4"]), rel=1e-6)
 
 
+def test_seg96():
+    g = G.load("seg96")
+    seg = O.deterministic_fill_(O.Segmentation(1, 2, norm_type=1), seed=0)
+    loss, aux = O.seg_train_losses(seg, O.synthetic_image(2, 96, 2), O.synthetic_label(2, 96, 3))
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["dice_loss"]), rel=1e-6)
+    G.check_tensor(g, "pred", aux["batch"]["pred"], k=512, rtol=1e-5)
+    G.check_grads(g, "seg", [(n, p.grad) for n, p in seg.named_parameters()], rtol=1e-4)
+
+
 def test_vae64_train():
     g = G.load("vae64_train")
     vae = O.deterministic_fill_(O.VAE(2, 2, norm_type=1, dim=128, spatial=64), seed=0)
@@ -126,6 +136,12 @@ def test_domain_adaptation128():
     f8 = (r + f / cur) if cur > 1 else (cur * r + f)
     assert f8 == pytest.approx(float(g["final8"]), rel=1e-5)
     assert (cur * r + f) / (1 + cur) == pytest.approx(float(g["final9"]), rel=1e-5)
+    for p in student.Seg.parameters():
+        p.grad = None
+    f8t, _ = O.domain_adaptation_losses(student, teacher, img, lab, lambda_vae=1.0, domain_loss_type=8)
+    f8t.backward()
+    assert f8t.item() == pytest.approx(float(g["final8"]), rel=1e-5)
+    G.check_grads(g, "seg8", [(n, p.grad) for n, p in student.Seg.named_parameters()], rtol=1e-4)
 
 
 def test_test_time_finetune128():

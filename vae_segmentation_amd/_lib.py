@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vaeseg.h")
 LIB_PATH = os.path.join(_HERE, "libvaeseg.so")
 
-VS_F32, VS_BF16 = 0, 1
+VS_F32, VS_BF16, VS_F16 = 0, 1, 2
 VS_CONV_K3, VS_CONV_K2S2, VS_CONV_T2S2 = 0, 1, 2
 VS_PACK_ROWS_D0, VS_PACK_ROWS_D1_FLIP, VS_PACK_SCATTER_D1 = 0, 1, 2
 

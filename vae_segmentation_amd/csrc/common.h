@@ -5,6 +5,9 @@
 #include "../../include/vaeseg.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef _Float16 vs_half;                                   // IEEE fp16 storage type (VS_F16); bf16 storage is carried as `unsigned short` bits (VS_BF16)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -20,7 +23,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 }
 __device__ __forceinline__ float round_bf(float f) { return bf2f(f2bf(f)); }
 
-// element type traits: T = float or unsigned short (bf16 bits)
+// element type traits: T = float, unsigned short (bf16 bits) or vs_half (fp16)
 template <typename T> struct ET;
 template <> struct ET<float> {
     static constexpr int EPL = 4;   // elements per 16-byte lane fragment
@@ -36,6 +39,22 @@ template <> struct ET<unsigned short> {
     __device__ static __forceinline__ void st(unsigned short* p, float v) { *p = f2bf(v); }
     __device__ static __forceinline__ float rnd(float v) { return round_bf(v); }
 };
+
+template <> struct ET<vs_half> {
+    static constexpr int EPL = 8;
+    static constexpr int KG = 32;
+    __device__ static __forceinline__ float ld(const vs_half* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(vs_half* p, float v) { *p = (vs_half)v; }              // v_cvt_f16_f32: RNE
+    __device__ static __forceinline__ float rnd(float v) { return (float)(vs_half)v; }
+};
+
+// VS_* dtype enum of a storage type, element size
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int vs = VS_F32; };
+template <> struct DT<unsigned short> { static constexpr int vs = VS_BF16; };
+template <> struct DT<vs_half> { static constexpr int vs = VS_F16; };
+static inline int vs_esize(int dtype) { return dtype == VS_F32 ? 4 : 2; }
+static inline bool vs_dtype_ok(int dtype) { return dtype == VS_F32 || dtype == VS_BF16 || dtype == VS_F16; }
 
 // unpack a 16-byte fragment into EPL floats / pack back
 __device__ __forceinline__ void frag_unpack(const u32x4& r, float (&v)[4], float*) {
@@ -62,11 +81,33 @@ __device__ __forceinline__ u32x4 frag_pack(const float (&v)[8], unsigned short*)
     return r;
 }
 
+__device__ __forceinline__ void frag_unpack(const u32x4& r, float (&v)[8], vs_half*) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f16x2 h = __builtin_bit_cast(f16x2, r[i]);
+        v[2 * i] = (float)h[0];
+        v[2 * i + 1] = (float)h[1];
+    }
+}
+__device__ __forceinline__ u32x4 frag_pack(const float (&v)[8], vs_half*) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f16x2 h;
+        h[0] = (vs_half)v[2 * i]; h[1] = (vs_half)v[2 * i + 1];
+        r[i] = __builtin_bit_cast(unsigned int, h);
+    }
+    return r;
+}
+
 // ---- MFMA: one 16-byte A fragment x one 16-byte B fragment -> 16x16 f32 tile ---------------------
 // bf16: one v_mfma_f32_16x16x32_bf16 (k = 8*(lane>>4)+j, j = 0..7).
 // f32 : four v_mfma_f32_16x16x4_f32; MFMA j covers k = 4*(lane>>4)+j, so a lane's four k's are contiguous.
 __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c, unsigned short*) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c, vs_half*) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c, float*) {
 #pragma unroll
@@ -148,18 +189,32 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned int bytes)
     return r;
 }
 
-// relu(x * scale + shift) on one 16-byte fragment of 8 bf16 channels
+// The two 16-bit storage formats of the throughput kernels (k3b / k3t / k3s / g3b are templated on T = unsigned short | vs_half):
+// one dword = two elements; pack2 rounds to nearest even in both formats, lo / hi widen exactly.
+template <typename T> struct H16;
+template <> struct H16<unsigned short> {
+    __device__ static __forceinline__ unsigned int pack2(f32x2 v) { return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2)); }
+    __device__ static __forceinline__ float lo(unsigned int w) { return __uint_as_float(w << 16); }
+    __device__ static __forceinline__ float hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+};
+template <> struct H16<vs_half> {
+    __device__ static __forceinline__ unsigned int pack2(f32x2 v) { return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2)); }
+    __device__ static __forceinline__ float lo(unsigned int w) { return (float)__builtin_bit_cast(f16x2, w)[0]; }
+    __device__ static __forceinline__ float hi(unsigned int w) { return (float)__builtin_bit_cast(f16x2, w)[1]; }
+};
+
+// relu(x * scale + shift) on one 16-byte fragment of 8 channels (bf16 or fp16)
+template <typename T>
 __device__ __forceinline__ u32x4 act8(const u32x4 raw, const f32x2 (&sc)[4], const f32x2 (&sh)[4]) {
     u32x4 r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         f32x2 v;
-        v[0] = __uint_as_float(raw[i] << 16);
-        v[1] = __uint_as_float(raw[i] & 0xffff0000u);
+        v[0] = H16<T>::lo(raw[i]);
+        v[1] = H16<T>::hi(raw[i]);
         v = v * sc[i] + sh[i];
-        const bf16x2 h = __builtin_convertvector(v, bf16x2);
-        i16x2 s = __builtin_bit_cast(i16x2, h);
-        s = __builtin_elementwise_max(s, i16x2{0, 0});  // ReLU on the bf16 bit patterns: negative floats are negative int16
+        i16x2 s = __builtin_bit_cast(i16x2, H16<T>::pack2(v));
+        s = __builtin_elementwise_max(s, i16x2{0, 0});  // ReLU on the bit patterns: in both formats negative values (and -0) are negative int16
         r[i] = __builtin_bit_cast(unsigned int, s);
     }
     return r;
@@ -169,7 +224,7 @@ __device__ __forceinline__ u32x4 act8(const u32x4 raw, const f32x2 (&sc)[4], con
 // fragment order of k3t_kernel (igemm_k3t.h): [k-group (tz,ty)][lane][8], row (lane & 15) = (dx2, co), k = (xpos = lane >> 4, ci),
 // value W[co][ci][tz][ty][xpos - dx2] or 0.  pack.hip (image) and igemm_k3_bf16.hip (dispatch) both key on this predicate.
 static __host__ __device__ inline bool vs_k3_toeplitz(int rows, int c_pad, int ntaps, int dtype) {
-    return dtype == VS_BF16 && ntaps == 27 && c_pad == 8 && rows <= 8;
+    return (dtype == VS_BF16 || dtype == VS_F16) && ntaps == 27 && c_pad == 8 && rows <= 8;
 }
 
 // Zeroing as a kernel, never hipMemsetAsync: inside a replayed HIP graph a memset node was observed to run out of order with the

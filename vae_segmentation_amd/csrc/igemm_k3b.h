@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         for (int b = 0; b < NIT; ++b) {
             u32x4 v = xv[b];
             if (has_stats) {
-                const u32x4 a = act8(v, sc, sh);
+                const u32x4 a = act8<unsigned short>(v, sc, sh);
                 const bool ok = (okbits >> b) & 1u;       // zero padding applies to the normalised activation
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;

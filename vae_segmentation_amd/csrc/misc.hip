@@ -43,6 +43,17 @@ extern "C" int vs_dropout(const void* x, void* out, long long count, float p, un
     return VS_OK;
 }
 
+__global__ void dropout_mask_kernel(float* __restrict__ mask, long long count, float p, unsigned long long seed) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
+        mask[i] = dropout_scale(seed, (unsigned long long)i, p);
+}
+extern "C" int vs_dropout_mask(float* mask, long long count, float p, unsigned long long seed, void* stream) {
+    if (!mask || count <= 0 || p < 0.f || p >= 1.f) return VS_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, GRID1D(count), dim3(256), 0, (hipStream_t)stream, mask, count, p, seed);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
 template <typename T>
 __global__ void softmax2_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ gprob, const T* __restrict__ gcl, T* __restrict__ gl,
                                     long long voxels, int c_pad, long long total, float drop_p, unsigned long long drop_seed) {
@@ -931,7 +942,7 @@ extern "C" int vs_copy_scale_multi(const float* const* srcs, float* const* dsts,
     return VS_OK;
 }
 
-__global__ void scale_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, float scale) {
+__global__ void scale_copy_kernel(const float* src, float* dst, long long n, float scale) {     // src may equal dst (in-place scale)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i] * scale;
 }
 extern "C" int vs_scale_copy(const float* src, float* dst, long long count, float scale, void* stream) {

@@ -298,7 +298,7 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         for (int b = 0; b < 2; ++b) {
             u32x4 v = pv[b];
             if (p_stats) {
-                const u32x4 a = act8(v, sc, sh);
+                const u32x4 a = act8<unsigned short>(v, sc, sh);
                 const bool ok = (okbits >> b) & 1u;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
@@ -316,7 +316,7 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         for (int b = 0; b < NITQ; ++b) {
             u32x4 v = qv[b];
             if (q_stats) {
-                const u32x4 a = act8(v, sc, sh);
+                const u32x4 a = act8<unsigned short>(v, sc, sh);
                 const bool ok = (okbits >> (2 + b)) & 1u;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;

@@ -1,11 +1,22 @@
-"""Data parallelism for the train step: one process per GPU, replicated parameters, ONE exchange per step —
-an RCCL all-reduce (torch.distributed backend "nccl" is RCCL on ROCm) of the trainable gradients in a flat fp32
-bucket.  This replaces the reference's single-process nn.DataParallel (main_source.py:354, main_target.py:436):
+"""Data parallelism for the train step: one process per GPU, replicated parameters, ONE exchange step per train step —
+RCCL all-reduces (torch.distributed backend "nccl" is RCCL on ROCm) of the trainable gradients, which live in one flat
+fp32 buffer.  This replaces the reference's single-process nn.DataParallel (main_source.py:354, main_target.py:436):
 its per-forward parameter broadcast and output gather disappear (replicas stay bit-identical because every rank
 applies the same averaged gradient), and its gradient reduce-to-GPU0 becomes the all-reduce.
 
 InstanceNorm is per-sample and the Dice/KL losses are per-sample means, so with equal per-rank batch the mean of
-the per-rank losses equals the reference's global-batch loss and the averaged gradient equals its gradient."""
+the per-rank losses equals the reference's global-batch loss and the averaged gradient equals its gradient.
+
+Layout and overlap (MI355X: xGMI is point-to-point, the 9.1 MB exchange is latency- not bandwidth-bound, and the step is
+2-3 ms, so what matters is that the exchange is not serialised behind the pass):
+  * the grouped weight-gradient launches write dW / db STRAIGHT into the parameters' slices of the flat buffer
+    (``param._vs_grad_view``; autograd adopts the slice as ``.grad``) — no gather launch, no second copy of the gradients;
+  * the buffer is ordered in two buckets.  Bucket 0 holds the large tensors (>= ``split_numel`` elements: the 12^3 .. 3^3
+    levels, 98 % of the bytes, whose weight gradients are cheap), bucket 1 the small ones (the 96^3 / 48^3 layers, whose
+    weight gradients are the expensive ones, plus all biases).  At the end of backward the bucket-0 gradients are computed
+    first (ops.set_wgrad_split), their all-reduce starts on a communication stream, and the bucket-1 weight-gradient kernels
+    — about half of the step's weight-gradient time — run underneath it; bucket 1 (a few hundred KB) follows.
+"""
 import torch
 import torch.distributed as dist
 
@@ -14,39 +25,127 @@ from .optim import _Tables
 
 
 class FlatGradSync:
-    """gather grads (x 1/world) into a flat bucket -> all_reduce(sum) -> expose flat views as the grads to apply."""
+    """Flat gradient buffer + bucketed all-reduce.  Use:
 
-    def __init__(self, params, process_group=None):
+        sync = FlatGradSync(params)                  # registers the gradient slots, switches ops to two-phase weight gradients
+        ... forward, backward (ends with the bucket-0 weight gradients) ...
+        views = sync()                               # start(0) -> remaining weight gradients -> start(1) -> wait
+        optimizer.step_with(sync.params, views)
+
+    train.GraphedStep drives the same phases around two captured graphs.  ``direct=False`` keeps the classic form: gradients
+    wherever autograd put them, one gather launch (vs_copy_scale_multi), one all-reduce."""
+
+    def __init__(self, params, process_group=None, direct=True, split_numel=8192):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
+        self.direct = bool(direct) and dev.type == "cuda"
+        big = [p for p in self.params if p.numel() >= split_numel] if self.direct else list(self.params)
+        small = [p for p in self.params if p.numel() < split_numel] if self.direct else []
+        order = big + small
+        total = sum(p.numel() for p in order)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.views, off = [], 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+        slot, off = {}, 0
+        for p in order:
+            slot[id(p)] = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
-        self._tab = _Tables()
+        n0 = sum(p.numel() for p in big)
+        self.buckets = [self.flat[:n0], self.flat[n0:]] if small else [self.flat]
+        self.views = [slot[id(p)] for p in self.params]                 # aligned with self.params
+        self._first_ids = {id(p) for p in big}
+        self._tab, self._tab0 = _Tables(), _Tables()
+        self._comm = torch.cuda.Stream() if dev.type == "cuda" else None
+        self._avg = True
+        if self.direct:
+            from . import ops
+            for p, v in zip(self.params, self.views):
+                p._vs_grad_view = v
+            if len(self.buckets) > 1:
+                ops.set_wgrad_split(lambda w: id(w) in self._first_ids)
+
+    def close(self):
+        """Unregister the gradient slots (parameters go back to ordinary .grad tensors, weight gradients to one phase)."""
+        if self.direct:
+            from . import ops
+            for p in self.params:
+                if getattr(p, "_vs_grad_view", None) is not None:
+                    p._vs_grad_view = None
+            ops.set_wgrad_split(None)
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:
             for p in self.params:
                 dist.broadcast(p.data, src, group=self.group)
 
-    def __call__(self, grads=None):
-        """grads: tensors aligned with self.params (default: p.grad).  Returns the averaged-gradient views."""
+    # -- phases ---------------------------------------------------------------------------------------------------
+    def _stragglers(self, grads):
+        """Gradients that did not land in their slot (accumulation into an existing .grad, hooks, direct=False): gathered by
+        one multi-tensor copy.  In the steady state of the direct mode this list is empty and nothing is launched."""
+        src, dst = [], []
+        for g, v in zip(grads, self.views):
+            if g is None:
+                continue
+            if g.data_ptr() != v.data_ptr():
+                src.append(g)
+                dst.append(v)
+        return src, dst
+
+    def gather(self, grads=None, tab=None):
         grads = [p.grad for p in self.params] if grads is None else grads
+        src, dst = self._stragglers(grads)
+        if not src:
+            return
         if self.flat.is_cuda:
-            from . import ops
-            ops.join_side()
-            (sp, dp, sizes, bm), nb = self._tab.get([grads, self.views], self.flat.device)
-            check(lib.vs_copy_scale_multi(sp.data_ptr(), dp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb,
-                                          1.0 / self.world, torch.cuda.current_stream().cuda_stream), "copy_scale_multi")
+            (sp, dp, sizes, bm), nb = (tab or self._tab).get([src, dst], self.flat.device)
+            check(lib.vs_copy_scale_multi(sp.data_ptr(), dp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb, 1.0,
+                                          torch.cuda.current_stream().cuda_stream), "copy_scale_multi")
         else:   # gloo / CPU tensors: host-side staging for the multi-process CPU tests of the exchange logic
-            for v, g in zip(self.views, grads):
+            for v, g in zip(dst, src):
                 v.copy_(g)
-            self.flat.mul_(1.0 / self.world)
-        if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def start(self, i):
+        """All-reduce bucket i on the communication stream, after everything issued so far on the current stream."""
+        if self.world == 1 and not dist.is_initialized():
+            return
+        b = self.buckets[i]
+        if self._comm is None:                                       # CPU tensors (gloo tests)
+            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+            b.mul_(1.0 / self.world)
+            return
+        self._comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm):
+            if self._avg and dist.get_backend(self.group) == "nccl":
+                try:
+                    dist.all_reduce(b, op=dist.ReduceOp.AVG, group=self.group)   # RCCL averages in the reduction itself
+                    return
+                except (RuntimeError, ValueError):                               # a build without ncclAvg: sum, then scale
+                    self._avg = False
+            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1:
+                check(lib.vs_scale_copy(b.data_ptr(), b.data_ptr(), b.numel(), 1.0 / self.world, self._comm.cuda_stream), "scale_copy")
+
+    def wait(self):
+        if self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
+
+    def __call__(self, grads=None):
+        """Whole exchange after a backward pass.  grads: tensors aligned with self.params (default: p.grad).  Returns the
+        averaged-gradient views (aligned with self.params)."""
+        from . import ops
+        grads = [p.grad for p in self.params] if grads is None else grads
+        if self.flat.is_cuda and ops._SIDE["enabled"]:
+            ops.join_side()
+        if len(self.buckets) == 1:
+            if self.flat.is_cuda:
+                ops.flush_wgrads()
+            self.gather(grads)
+            self.start(0)
+        else:
+            self.gather([g if id(p) in self._first_ids else None for g, p in zip(grads, self.params)], self._tab0)
+            self.start(0)
+            ops.flush_wgrads()                                       # bucket-1 weight gradients run under bucket 0's all-reduce
+            self.gather(grads)
+            self.start(1)
+        self.wait()
         return self.views

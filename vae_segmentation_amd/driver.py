@@ -168,7 +168,7 @@ def run(args, side="source"):
     assert args.save_epoch % args.eval_epoch == 0
     nc = n_class_of(args)
     method = args.method
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
     eps = EPS_MAIN_SOURCE if side == "source" else EPS_EVALUATION          # the two scripts use different epsilons
 
     teacher = None
@@ -198,7 +198,15 @@ def run(args, side="source"):
         freeze(model.Vae)                                                   # main_source.py:343-346
     if teacher is not None:
         teacher = teacher.cuda()
-        teacher.load_state_dict(model.state_dict())                         # main_target.py:420-423
+        if getattr(args, "only_pseudo", False):
+            # main_target.py:421-425: the loaded network becomes the frozen pseudo-label teacher, a freshly initialised one is trained
+            model, teacher = teacher, model
+            freeze(model.Vae)
+            trainable = model.Seg
+        elif not args.test_only:
+            teacher.load_state_dict(model.state_dict())                     # main_target.py:426-427
+        else:
+            teacher.load_state_dict(model.state_dict())                     # main_target.py:379-380
         freeze(teacher)
         set_kernel_dtype(teacher, dtype)
     set_kernel_dtype(model, dtype)
@@ -226,40 +234,76 @@ def run(args, side="source"):
 
     train_loader, val_loader, sampler = make_loaders(args, rank, world)
     lambda_vae = args.lambda_vae
+    turn_epoch, warmup_epochs = getattr(args, "turn_epoch", -1), getattr(args, "lambda_vae_warmup", 0)
+    has_dropout = bool(getattr(args, "seg_dropout", 0.0) or getattr(args, "vae_decoder_dropout", 0.0))
+    use_graph = not getattr(args, "no_graph", False) and not has_dropout      # dropout draws fresh masks per call: eager (train.GraphedStep)
+    bs, side_ = args.batch_size, args.size
+    img_buf = torch.zeros(bs, 1, side_, side_, side_, device="cuda")         # fixed-address inputs of the captured step
+    lab_buf = torch.zeros(bs, 1, side_, side_, side_, device="cuda")
+    cur = {"epoch": 0}
+
+    def loss_fn():
+        if method == "vae_train":
+            return T.vae_train_losses(model, lab_buf, scale=0.35, eps=eps, n_class=nc)
+        if method == "seg_train":
+            return T.seg_train_losses(model, img_buf, lab_buf, eps=eps, n_class=nc)
+        if method == "joint_train":
+            return T.joint_train_losses(model, img_buf, lab_buf, lambda_vae=lambda_vae, eps=eps, n_class=nc)
+        return T.domain_adaptation_losses(model, teacher, img_buf, lab_buf, lambda_vae=lambda_vae,
+                                          domain_loss_type=getattr(args, "domain_loss_type", 0), kl=getattr(args, "kl", False),
+                                          use_confident_binarize=getattr(args, "use_confident_binarize", False), eps=eps, n_class=nc,
+                                          only_pseudo=getattr(args, "only_pseudo", False), epoch=cur["epoch"], turn_epoch=turn_epoch,
+                                          lambda_vae_warmup=warmup_epochs, host_schedule=not use_graph)
+
+    def loss_key(epoch):
+        """what of the loss expression depends on the epoch (main_target.py:583-592): a captured step is rebuilt when it changes"""
+        if method != "domain_adaptation" or getattr(args, "domain_loss_type", 0) != 0 or getattr(args, "only_pseudo", False):
+            return 0
+        if turn_epoch != -1:
+            return (epoch // turn_epoch) % 2
+        return min(epoch, warmup_epochs)
+
+    stepper, stepper_key = None, None
     best, n_outer = 0.0, max(1, args.max_epoch // args.eval_epoch)
     for epoch in range(n_outer):
+        cur["epoch"] = epoch
         if sampler is not None:
             sampler.set_epoch(epoch)
-        if not args.test_only:
+        skip_da = method == "domain_adaptation" and epoch == 0 and not getattr(args, "train_first_epoch", False)    # main_target.py:506: `if epoch == 0: continue`
+        if not args.test_only and not skip_da:
             model.train()
             if hasattr(model, "Vae"):
                 model.Vae.eval()
+            if use_graph and (stepper is None or stepper_key != loss_key(epoch)):
+                stepper = None                                        # release the old capture's memory pool first
+                stepper = T.GraphedStep(loss_fn, params, optimizer, grad_sync=sync, warmup=1)
+                stepper_key = loss_key(epoch)
+                if rank == 0:
+                    print("train step captured as a HIP graph (%s)" % ("2 graphs + bucketed all-reduce" if stepper.graph2 is not None else "1 graph"))
             t0, seen = time.time(), 0
+            n_iter = len(train_loader)
             for idx, batch in enumerate(train_loader):
-                img = batch[IMG_KEY].cuda(non_blocking=True)
-                lab = batch[LABEL_KEY].cuda(non_blocking=True)
-                for p in params:
-                    p.grad = None
-                if method == "vae_train":
-                    loss, aux = T.vae_train_losses(model, lab, scale=0.35, eps=eps, n_class=nc)
-                elif method == "seg_train":
-                    loss, aux = T.seg_train_losses(model, img, lab, eps=eps, n_class=nc)
-                elif method == "joint_train":
-                    loss, aux = T.joint_train_losses(model, img, lab, lambda_vae=lambda_vae, eps=eps, n_class=nc)
+                img_buf.copy_(batch[IMG_KEY], non_blocking=True)
+                lab_buf.copy_(batch[LABEL_KEY], non_blocking=True)
+                if method == "domain_adaptation" and getattr(args, "pseudo_save_epoch", 0):
+                    # EMA teacher (main_target.py:508-518): every `pseudo_save_epoch` epochs, at the first iteration of an epoch slice or
+                    # every iteration; never in epoch 0
+                    every = max(1, args.pseudo_save_epoch // args.eval_epoch)
+                    if epoch != 0 and epoch % every == 0 and (getattr(args, "update_every_iteration", False) or idx % max(1, n_iter // args.eval_epoch) == 0):
+                        optim.ema_update(teacher.Seg, model.Seg, args.alpha)
+                if stepper is not None:
+                    stepper.step()
+                    aux = stepper.aux
                 else:
-                    if getattr(args, "pseudo_save_epoch", 0) and getattr(args, "update_every_iteration", False):
-                        optim.ema_update(teacher.Seg, model.Seg, args.alpha)      # main_target.py:508-518
-                    loss, aux = T.domain_adaptation_losses(model, teacher, img, lab, lambda_vae=lambda_vae,
-                                                           domain_loss_type=getattr(args, "domain_loss_type", 0),
-                                                           kl=getattr(args, "kl", False),
-                                                           use_confident_binarize=getattr(args, "use_confident_binarize", False),
-                                                           eps=eps, n_class=nc)
-                loss.backward()
-                if sync is not None:
-                    optimizer.step_with(params, sync())
-                else:
-                    optimizer.step()
-                seen += img.shape[0]
+                    for p in params:
+                        p.grad = None
+                    loss, aux = loss_fn()
+                    loss.backward()
+                    if sync is not None:
+                        optimizer.step_with(sync.params, sync())
+                    else:
+                        optimizer.step()
+                seen += bs
                 if rank == 0 and idx % args.display_freq == 0:              # logging syncs the host every display_freq steps only
                     parts = ", ".join("%s %.4f" % (k, v.item()) for k, v in aux.items() if k != "batch")
                     print("[%3d, %3d] loss: %s" % ((epoch + 1) * args.eval_epoch, idx + 1, parts))
@@ -267,7 +311,8 @@ def run(args, side="source"):
                     break
             torch.cuda.synchronize()
             if rank == 0:
-                print("epoch %d: %.2f volumes/s per rank" % (epoch + 1, seen / max(time.time() - t0, 1e-9)))
+                print("epoch %d: %.2f volumes/s per rank (%s)" % (epoch + 1, seen / max(time.time() - t0, 1e-9),
+                                                                   "graph replay" if stepper is not None else "eager"))
         if rank == 0:
             model.eval()
             if runner is not None and (epoch != 0 or args.test_only):             # main_target.py:811
@@ -298,8 +343,11 @@ def add_native_flags(parser):
     g = parser.add_argument_group("native (MI355X) additions")
     g.add_argument("--synthetic", action="store_true", default=True, help="synthetic volumes (the only data source in this build)")
     g.add_argument("--size", type=int, default=128, help="cubic patch side (reference: patch_size 128, main_source.py:117)")
-    g.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"], help="kernel storage dtype")
+    g.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"], help="kernel storage dtype")
     g.add_argument("--synthetic_train", type=int, default=16)
     g.add_argument("--synthetic_val", type=int, default=2)
     g.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many steps (0 = whole loader)")
     g.add_argument("--display_freq", type=int, default=10)
+    g.add_argument("--no_graph", action="store_true", help="eager launches instead of the HIP-graph replayed step")
+    g.add_argument("--train_first_epoch", action="store_true", help="domain_adaptation: also train in epoch 0 (the reference only "
+                   "validates there, main_target.py:506)")

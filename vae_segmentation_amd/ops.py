@@ -14,8 +14,20 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (VS_BF16, VS_CONV_K2S2, VS_CONV_K3, VS_F32, VS_PACK_ROWS_D0, VS_PACK_ROWS_D1_FLIP,
+from ._lib import (VS_BF16, VS_CONV_K2S2, VS_CONV_K3, VS_F16, VS_F32, VS_PACK_ROWS_D0, VS_PACK_ROWS_D1_FLIP,
                    VS_PACK_SCATTER_D1, check, lib)
+
+_DT_TORCH = {VS_F32: torch.float32, VS_BF16: torch.bfloat16, VS_F16: torch.float16}
+_DT_VS = {v: k for k, v in _DT_TORCH.items()}
+KERNEL_DTYPES = tuple(_DT_VS)
+
+
+def vs_of(dtype):
+    """torch dtype -> VS_* enum of include/vaeseg.h"""
+    try:
+        return _DT_VS[dtype]
+    except KeyError:
+        raise TypeError("kernel dtype must be float32, bfloat16 or float16, got %s" % (dtype,)) from None
 
 EPS_IN = 1e-5       # nn.InstanceNorm3d default eps (joint_model.py:11)
 
@@ -96,11 +108,7 @@ def _p(t):
 
 
 def vs_dtype(t):
-    if t.dtype == torch.float32:
-        return VS_F32
-    if t.dtype == torch.bfloat16:
-        return VS_BF16
-    raise TypeError("kernel dtype must be float32 or bfloat16, got %s" % t.dtype)
+    return vs_of(t.dtype)
 
 
 def _require_cuda(*ts):
@@ -199,15 +207,15 @@ def join_side():
 # ------------------------------------------------------------------------------------------------
 
 
-def pack_weight(w, form, c_pad, dtype):
-    """w: (d0, d1, k, k, k) fp32 parameter -> uint8 buffer holding the MFMA-fragment image."""
+def pack_weight(w, form, c_pad, dtype, out=None):
+    """w: (d0, d1, k, k, k) fp32 parameter -> uint8 buffer holding the MFMA-fragment image (written into `out` when given)."""
     _require_cuda(w)
     w = w.detach()
     if not w.is_contiguous():
         w = w.contiguous()
     d0, d1 = w.shape[0], w.shape[1]
     ntaps = w[0, 0].numel()
-    dt = VS_F32 if dtype == torch.float32 else VS_BF16
+    dt = vs_of(dtype)
     if form == VS_PACK_ROWS_D0:
         rows, gemm_taps = d0, ntaps
     elif form == VS_PACK_ROWS_D1_FLIP:
@@ -215,7 +223,9 @@ def pack_weight(w, form, c_pad, dtype):
     else:
         rows, gemm_taps = ntaps * d1, 1
     nbytes = lib.vs_packed_weight_bytes(rows, c_pad, gemm_taps, dt)
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device) if out is None else out
+    if buf.numel() != nbytes:
+        raise ValueError("pack_weight: out buffer holds %d bytes, image needs %d" % (buf.numel(), nbytes))
     check(lib.vs_pack_weight(w.data_ptr(), buf.data_ptr(), d0, d1, ntaps, c_pad, form, dt, _stream()), "pack_weight")
     return buf
 
@@ -228,7 +238,7 @@ def pack_weight_cached(param, form, c_pad, dtype):
     `repack_trainable()` — called by the native optimisers right after their update kernel — refreshes EVERY registered
     image in one multi-tensor launch, so a training step issues no per-layer pack launches.  An image is trusted only if
     it was packed at the parameter's current (version, epoch); otherwise it is re-packed on the spot."""
-    dt = VS_F32 if dtype == torch.float32 else VS_BF16
+    dt = vs_of(dtype)
     key = (form, c_pad, dt)
     if param.requires_grad:
         plan = getattr(param, "_vs_pack_plan", None)
@@ -244,18 +254,49 @@ def pack_weight_cached(param, form, c_pad, dtype):
             _REPACK["dirty"] = True
             return buf
         if ent[1] != stamp:
-            ent[0].copy_(pack_weight(param, form, c_pad, dtype))
+            pack_weight(param, form, c_pad, dtype, out=ent[0])
             ent[1] = stamp
         return ent[0]
+    cache = _frozen_cache(param)
+    stamp = (param._version, param.data_ptr(), _PACK_EPOCH[0])
+    ent = cache.get(key)
+    if ent is None:
+        cache[key] = [pack_weight(param, form, c_pad, dtype), stamp]
+        return cache[key][0]
+    if ent[1] != stamp:
+        # re-pack INTO the existing buffer: a captured HIP graph holds this address (GraphedStep / TestTimeFinetune replay the
+        # frozen VAE / teacher with pointer arguments only), so an invalidated image must be refreshed in place, never re-allocated
+        pack_weight(param, form, c_pad, dtype, out=ent[0])
+        ent[1] = stamp
+    return ent[0]
+
+
+def _frozen_cache(param):
+    """{key: [buffer, stamp]} living on the tensor object itself: it dies with the tensor, so a recycled device address can
+    never alias another weight; buffers are never replaced once handed out (see pack_weight_cached)."""
     cache = getattr(param, "_vs_pack_cache", None)
-    if cache is None or cache[0] != (param._version, param.data_ptr(), _PACK_EPOCH[0]):
-        cache = ((param._version, param.data_ptr(), _PACK_EPOCH[0]), {})
+    if cache is None:
+        cache = {}
         param._vs_pack_cache = cache
-    hit = cache[1].get(key)
-    if hit is None:
-        hit = pack_weight(param, form, c_pad, dtype)
-        cache[1][key] = hit
-    return hit
+    return cache
+
+
+def refresh_frozen_packs(module):
+    """Re-pack, in place and now, every cached image of `module`'s frozen weights (call after writing them through raw
+    pointers — optim.ema_update, load_state_dict on a network a captured graph replays): graph replays that follow read the
+    new weights without an eager forward in between."""
+    for prm in module.parameters():
+        cache = getattr(prm, "_vs_pack_cache", None)
+        if not cache:
+            continue
+        stamp = (prm._version, prm.data_ptr(), _PACK_EPOCH[0])
+        for key, ent in cache.items():
+            if key[0] == "lin":
+                ent[0].copy_(_linear_layout(prm, key[1], key[2], key[3]))
+            else:
+                form, c_pad, dt = key
+                pack_weight(prm, form, c_pad, _DT_TORCH[dt], out=ent[0])
+            ent[1] = stamp
 
 
 _TRAIN_EPOCH = [0]
@@ -302,20 +343,24 @@ def frozen_linear_layout(param, kind, c, v):
       "cols_cl"  : (J, K) -> the K columns in channels-last order          (fc_mean / fc_std forward, backward w.r.t. x)
       "rows_cl_t": (J, K) -> (K, J) transposed, the J rows in channels-last order   (fc2 backward w.r.t. z)"""
     key = ("lin", kind, c, v)
-    cache = getattr(param, "_vs_pack_cache", None)
-    if cache is None or cache[0] != (param._version, param.data_ptr(), _PACK_EPOCH[0]):
-        cache = ((param._version, param.data_ptr(), _PACK_EPOCH[0]), {})
-        param._vs_pack_cache = cache
-    hit = cache[1].get(key)
-    if hit is None:
-        w = param.detach()
-        with torch.no_grad():
-            if kind == "cols_cl":
-                hit = w.view(w.shape[0], c, v).permute(0, 2, 1).contiguous().view(w.shape[0], c * v)
-            else:
-                hit = w.view(c, v, w.shape[1]).permute(2, 1, 0).contiguous().view(w.shape[1], c * v)
-        cache[1][key] = hit
-    return hit
+    cache = _frozen_cache(param)
+    stamp = (param._version, param.data_ptr(), _PACK_EPOCH[0])
+    ent = cache.get(key)
+    if ent is None:
+        cache[key] = [_linear_layout(param, kind, c, v), stamp]
+        return cache[key][0]
+    if ent[1] != stamp:
+        ent[0].copy_(_linear_layout(param, kind, c, v))         # in place: see pack_weight_cached
+        ent[1] = stamp
+    return ent[0]
+
+
+def _linear_layout(param, kind, c, v):
+    w = param.detach()
+    with torch.no_grad():
+        if kind == "cols_cl":
+            return w.view(w.shape[0], c, v).permute(0, 2, 1).contiguous().view(w.shape[0], c * v)
+        return w.view(c, v, w.shape[1]).permute(2, 1, 0).contiguous().view(w.shape[1], c * v)
 
 
 def weights_changed():
@@ -337,6 +382,7 @@ _ARENA = {"buf": None, "off": 0, "used": 0, "need": 1 << 14}
 
 def stats_arena_begin(device):
     """Start a new zeroed arena (call at the top of a forward pass; backward keeps carving from the same one)."""
+    drop_stale_wgrads()
     a = _ARENA
     a["need"] = max(a["need"], a["used"])
     a["buf"] = torch.zeros(a["need"] + (a["need"] >> 2), dtype=torch.float64, device=device)
@@ -505,13 +551,31 @@ class WgradDesc(_ct.Structure):
 
 
 _GROUP = {"enabled": os.environ.get("VS_WGRAD_GROUP", "1") != "0", "descs": [], "keep": [], "callback": False, "dtype": None,
-          "bytes": 0.0, "flops": 0.0}
+          "bytes": 0.0, "flops": 0.0, "split": None}
 
 
 def set_wgrad_grouping(enabled=True):
     """Defer weight/bias gradients to the end of backward and issue them as grouped launches (default on)."""
     flush_wgrads()
     _GROUP["enabled"] = bool(enabled)
+
+
+def set_wgrad_split(first=None):
+    """Two-phase issue for the data-parallel step (ddp.FlatGradSync): with `first` = a predicate on a parameter, the launches at the end
+    of backward cover only the layers whose weight satisfies it; the caller issues the rest with flush_wgrads() after it has started the
+    all-reduce of the first bucket, so that the exchange runs under the remaining weight-gradient kernels.  None: one phase."""
+    flush_wgrads()
+    _GROUP["split"] = first
+
+
+def drop_stale_wgrads():
+    """Forget deferred descriptors left behind by a backward pass that raised before its end-of-pass callback ran (their raw pointers
+    may be recycled by now).  Called at the top of every forward (stats_arena_begin)."""
+    g = _GROUP
+    if g["descs"] and not g["callback"]:
+        return                                  # a caller-managed second phase (set_wgrad_split) is pending: not stale
+    if g["descs"] or g["callback"]:
+        g["descs"], g["keep"], g["callback"], g["bytes"], g["flops"] = [], [], False, 0.0, 0.0
 
 
 def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb):
@@ -527,12 +591,12 @@ def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb):
         bg = bias_args[0]
         d.bias_g, d.db, d.bias_rows, d.bias_c_ch, d.bias_c_real = bg.data_ptr(), gb.data_ptr(), bg.numel() // bg.shape[-1], bg.shape[-1], bias_args[1]
         g["keep"].append(bg)
-    g["descs"].append(d)
+    taps = 27 if kind == VS_CONV_K3 else 8
+    nb = (p.numel() // m_ch * m_real + q.numel() // q.shape[-1] * c_real) * _esize(p) + m_real * c_real * taps * 4
+    fl = 2.0 * (p.numel() // m_ch) * taps * m_real * c_real
+    first = g["split"] is None or bool(g["split"](weight))
+    g["descs"].append((d, first, nb, fl))
     g["keep"].extend(t for t in keep if t is not None)
-    if PROFILE is not None:
-        taps = 27 if kind == VS_CONV_K3 else 8
-        g["bytes"] += (p.numel() // m_ch * m_real + q.numel() // q.shape[-1] * c_real) * _esize(p) + m_real * c_real * taps * 4
-        g["flops"] += 2.0 * (p.numel() // m_ch) * taps * m_real * c_real
     if not g["callback"]:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_group_backward_done)
@@ -543,37 +607,63 @@ def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb):
 
 def _group_backward_done():
     _GROUP["callback"] = False
-    flush_wgrads()
+    flush_wgrads(first_only=_GROUP["split"] is not None)
 
 
-def flush_wgrads():
-    """Issue every deferred weight/bias gradient on the current stream (vs_conv_wgrad_multi)."""
+def pending_wgrads():
+    return len(_GROUP["descs"])
+
+
+def flush_wgrads(first_only=False):
+    """Issue the deferred weight/bias gradients on the current stream (vs_conv_wgrad_multi): all of them, or — under
+    set_wgrad_split — only the first phase."""
     g = _GROUP
-    descs = g["descs"]
-    if not descs:
+    if not g["descs"]:
         return
+    now = [e for e in g["descs"] if e[1]] if first_only else g["descs"]
+    later = [e for e in g["descs"] if not e[1]] if first_only else []
+    g["descs"] = later
+    if not now:
+        return
+    descs = [e[0] for e in now]
     arr = (WgradDesc * len(descs))(*descs)
-    dt = VS_F32 if g["dtype"] == torch.float32 else VS_BF16
+    dt = vs_of(g["dtype"])
     dev = g["keep"][0].device
     nbytes = lib.vs_conv_wgrad_multi_workspace_bytes(_ct.addressof(arr), len(descs), dt)
     if nbytes == 0:
         g["descs"], g["keep"] = [], []
         raise _lib.VaesegError("vs_conv_wgrad_multi: unsupported layer in the deferred weight-gradient list")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    nb, fl = g["bytes"], g["flops"]
-    g["descs"], g["keep_now"], g["keep"], g["bytes"], g["flops"] = [], g["keep"], [], 0.0, 0.0
+    nb, fl = sum(e[2] for e in now), sum(e[3] for e in now)
     with _timed("wgrad_multi(%d layers)" % len(descs), nb, fl):
         check(lib.vs_conv_wgrad_multi(_ct.addressof(arr), len(descs), ws.data_ptr(), nbytes, dt, EPS_IN, _stream()), "conv_wgrad_multi")
-    g["keep_now"] = None                        # launched on the current stream: the allocator may recycle the inputs now
+    if not later:
+        g["keep"] = []                          # launched on the current stream: the allocator may recycle the inputs now
 
 
-def _side_grads(weight, keep, wgrad_args, bias_args):
+def _grad_slot(param, shape):
+    """Where a parameter's gradient is written: its slice of the data-parallel flat bucket when ddp.FlatGradSync registered one
+    (the all-reduce then needs no gather launch; autograd adopts the view as .grad), a fresh tensor otherwise."""
+    view = getattr(param, "_vs_grad_view", None)
+    if view is not None and param.grad is None:
+        return view.detach()                    # a fresh alias: AccumulateGrad adopts a gradient only if nobody else holds the tensor object
+    return torch.empty(shape, dtype=torch.float32, device=param.device)
+
+
+def _has_hooks(t):
+    return bool(getattr(t, "_backward_hooks", None)) or bool(getattr(t, "_post_accumulate_grad_hooks", None))
+
+
+def _side_grads(weight, keep, wgrad_args, bias_args, bias=None):
     """Allocate dW (and db) now; their kernels are deferred — grouped at the end of backward (default) or queued for the side
-    stream (set_overlap) — or run at once when the parameter already holds a gradient to accumulate into; -> (gw, gb)."""
-    dev = keep[0].device
-    gw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
-    gb = torch.empty(bias_args[1], dtype=torch.float32, device=dev) if bias_args is not None else None
-    if _GROUP["enabled"] and not _SIDE["enabled"] and weight.grad is None:
+    stream (set_overlap) — or run at once when the parameter already holds a gradient to accumulate into, carries hooks, or
+    grad mode is on (autograd would then clone the still-unwritten tensor); -> (gw, gb)."""
+    gw = _grad_slot(weight, weight.shape)
+    gb = None
+    if bias_args is not None:
+        gb = _grad_slot(bias, (bias_args[1],)) if bias is not None else torch.empty(bias_args[1], dtype=torch.float32, device=keep[0].device)
+    deferrable = weight.grad is None and not _has_hooks(weight) and not torch.is_grad_enabled() and (bias is None or not _has_hooks(bias))
+    if _GROUP["enabled"] and not _SIDE["enabled"] and deferrable:
         # the descriptor holds raw pointers only: AccumulateGrad must find gw / gb unshared to adopt them as .grad without a copy
         _group_submit(weight, keep, wgrad_args, bias_args, gw, gb)
         return gw, gb
@@ -583,8 +673,20 @@ def _side_grads(weight, keep, wgrad_args, bias_args):
         conv_wgrad(*wgrad_args, weight.shape, out_ptr=gw_ptr)
         if bias_args is not None:
             bias_grad(bias_args[0], bias_args[1], out_ptr=gb_ptr)
-    side_submit(weight, keep, launch)
+    if deferrable:
+        side_submit(weight, keep, launch)
+    else:
+        launch()
     return gw, gb
+
+
+def _dead_bias_grad(bias, n, device):
+    """Gradient of a conv bias that feeds InstanceNorm (exactly zero): the parameter's (never written, zero) slot of
+    the flat bucket when one is registered, else zeros carved from the statistics arena (no fill launch)."""
+    view = getattr(bias, "_vs_grad_view", None) if bias is not None else None
+    if view is not None and bias.grad is None:
+        return view.detach()
+    return _new_stats(1, (n + 1) // 2, device, width=1).view(-1).view(torch.float32)[:n]
 
 
 def in_relu_bwd(g, x, xs, inplace=True):
@@ -626,7 +728,7 @@ class ConvK3(torch.autograd.Function):
         y, ys = conv_gather(x, xs, wp, None, cpad(cout), VS_CONV_K3, True, real_channels=(cin, cout))
         ctx.save_for_backward(x, xs, weight)
         ctx.has_bias = bias is not None
-        ctx.bias_shape = None if bias is None else bias.shape
+        ctx.bias_ref = bias                   # a Parameter (long-lived leaf): only its gradient slot is looked up in backward
         ctx.mark_non_differentiable(ys)
         ctx.set_materialize_grads(False)      # otherwise autograd zero-fills a gradient for the stats output every backward
         return y, ys
@@ -648,7 +750,7 @@ class ConvK3(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gw, _ = _side_grads(weight, (gy, x, xs), (gy, None, x, xs, cout, cin, VS_CONV_K3), None)
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            gb = _new_stats(1, (ctx.bias_shape[0] + 1) // 2, gy.device, width=1).view(-1).view(torch.float32)[:ctx.bias_shape[0]]
+            gb = _dead_bias_grad(ctx.bias_ref, ctx.bias_ref.shape[0], gy.device)
         return gx, None, gw, gb
 
 
@@ -668,6 +770,7 @@ class ConvK3Softmax(torch.autograd.Function):
                                                   vs_dtype(x), EPS_IN, float(drop_p), drop_seed, _stream()), "conv_k3_softmax2_fwd")
         ctx.save_for_backward(x, xs, weight, prob)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.drop = (float(drop_p), drop_seed)
         return prob
 
@@ -688,7 +791,7 @@ class ConvK3Softmax(torch.autograd.Function):
                 gx, _ = conv_gather(gl, None, wpb, None, c, VS_CONV_K3, False)
         if ctx.needs_input_grad[2]:
             gw, gb = _side_grads(weight, (gl, x, xs), (gl, None, x, xs, 2, weight.shape[1], VS_CONV_K3),
-                                 (gl, 2) if ctx.has_bias and ctx.needs_input_grad[3] else None)
+                                 (gl, 2) if ctx.has_bias and ctx.needs_input_grad[3] else None, ctx.bias_ref)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gl, 2)
         return gx, None, gw, gb, None, None
@@ -713,6 +816,7 @@ class ConvK3SoftmaxCL(torch.autograd.Function):
                                              vs_dtype(x), EPS_IN, float(drop_p), drop_seed, _stream()), "conv_k3_softmax2_cl_fwd")
         ctx.save_for_backward(x, xs, weight, prob)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.drop = (float(drop_p), drop_seed)
         ctx.set_materialize_grads(False)
         return prob, prob_cl
@@ -737,7 +841,7 @@ class ConvK3SoftmaxCL(torch.autograd.Function):
                 gx, _ = conv_gather(gl, None, wpb, None, c, VS_CONV_K3, False)
         if ctx.needs_input_grad[2]:
             gw, gb = _side_grads(weight, (gl, x, xs), (gl, None, x, xs, 2, weight.shape[1], VS_CONV_K3),
-                                 (gl, 2) if ctx.has_bias and ctx.needs_input_grad[3] else None)
+                                 (gl, 2) if ctx.has_bias and ctx.needs_input_grad[3] else None, ctx.bias_ref)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gl, 2)
         return gx, None, gw, gb, None, None
@@ -773,6 +877,7 @@ class ConvK2S2(torch.autograd.Function):
         y, _ = conv_gather(x, xs, wp, bias, cpad(weight.shape[0]), VS_CONV_K2S2, False)
         ctx.save_for_backward(x, xs, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -789,7 +894,7 @@ class ConvK2S2(torch.autograd.Function):
                 gx = conv_scatter(gy, None, wpb, None, x.shape[-1])
         if ctx.needs_input_grad[2]:
             gw, gb = _side_grads(weight, (gy, x, xs), (gy, None, x, xs, cout, cin, VS_CONV_K2S2),
-                                 (gy, cout) if ctx.has_bias and ctx.needs_input_grad[3] else None)
+                                 (gy, cout) if ctx.has_bias and ctx.needs_input_grad[3] else None, ctx.bias_ref)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gy, cout)
         return gx, None, gw, gb
@@ -805,6 +910,7 @@ class ConvT2S2(torch.autograd.Function):
         y = conv_scatter(x, xs, wp, bias, cpad(weight.shape[1]))
         ctx.save_for_backward(x, xs, weight)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         return y
 
     @staticmethod
@@ -821,7 +927,7 @@ class ConvT2S2(torch.autograd.Function):
                 gx, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K2S2, False)
         if ctx.needs_input_grad[2]:
             gw, gb = _side_grads(weight, (gy, x, xs), (x, xs, gy, None, cin, cout, VS_CONV_K2S2),
-                                 (gy, cout) if ctx.has_bias and ctx.needs_input_grad[3] else None)
+                                 (gy, cout) if ctx.has_bias and ctx.needs_input_grad[3] else None, ctx.bias_ref)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gy, cout)
         return gx, None, gw, gb
@@ -869,9 +975,20 @@ _DROPOUT_CALLS = [0]
 
 def next_dropout_seed():
     """A fresh 64-bit seed per dropout site per call, a pure function of torch's seed and a call counter (host side: no
-    device sync).  Under HIP-graph replay the captured seeds repeat, so GraphedStep refuses models with dropout > 0."""
+    device sync).  Under HIP-graph replay the captured seeds would repeat, so drawing one during capture raises; TestTimeFinetune
+    runs models with dropout > 0 eagerly."""
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("dropout > 0 inside HIP-graph capture: the host-side mask seed would be baked into the graph and every replay "
+                           "would reuse the same masks (the reference draws fresh ones per call) — run this model eagerly (graph=False)")
     _DROPOUT_CALLS[0] += 1
     return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _DROPOUT_CALLS[0] * 0xD1B54A32D192ED03) % (1 << 64)
+
+
+def dropout_mask(count, p, seed, device="cuda"):
+    """The multipliers (0 or 1/(1-p)) a dropout site with this (p, seed) applies, in the site tensor's memory order (vs_dropout_mask)."""
+    mask = torch.empty(count, dtype=torch.float32, device=device)
+    check(lib.vs_dropout_mask(mask.data_ptr(), count, float(p), seed, _stream()), "dropout_mask")
+    return mask
 
 
 class Dropout(torch.autograd.Function):

@@ -131,4 +131,5 @@ def ema_update(teacher, student, alpha):
     tab = _EMA_TABLES.setdefault((id(teacher), id(student)), _Tables())
     (tp, sp, sizes, bm), nb = tab.get([ts, ss], ts[0].device)
     check(lib.vs_ema_multi(tp.data_ptr(), sp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb, float(alpha), _stream()), "ema_multi")
-    ops.clear_pack_cache()      # the teacher's cached packed weights are stale now
+    ops.clear_pack_cache()      # the teacher's cached packed weights are stale now ...
+    ops.refresh_frozen_packs(teacher)   # ... and are re-packed in place at once: captured graphs that replay the teacher hold these addresses

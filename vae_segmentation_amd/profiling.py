@@ -6,7 +6,7 @@ from . import ops
 
 LAST_LAUNCHES = []
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3}
 
 
 LAST_EVENT_OVERHEAD_US = 0.0
@@ -65,6 +65,70 @@ def collect(fwd_bwd, params, steps=2):
     return agg
 
 
+def _traffic_path():
+    import glob
+    import os
+    cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r*_hbm_traffic.json")))
+    return cands[-1] if cands else ""
+
+
+def measured_step_traffic(path=None):
+    """HBM bytes per train step summed over all kernels, from the newest committed PMC summary (profiles/rNN_hbm_traffic.json:
+    per-kernel FETCH_SIZE x2 + WRITE_SIZE per launch x launches per step); None when there is none."""
+    import json
+    try:
+        table = json.load(open(path or _traffic_path()))
+    except Exception:
+        return None
+    if "_step_total_bytes" in table:
+        return table["_step_total_bytes"]
+    try:
+        return float(sum(rec["hbm_bytes_per_launch"] * rec.get("launches_per_step", 0) for rec in table.values() if isinstance(rec, dict)))
+    except Exception:
+        return None
+
+
+FAMILIES = (
+    ("conv3x3x3, C>=32 levels (k3b<32,..>, k3s)", lambda k: k.startswith("k3b_kernel<32") or k.startswith("k3s_kernel") or k.startswith("chain")),
+    ("conv3x3x3, 16-channel layers (k3b<16|8,..>)", lambda k: k.startswith("k3b_kernel<16") or k.startswith("k3b_kernel<8")),
+    ("conv3x3x3, 8-channel full-resolution layers (k3t)", lambda k: k.startswith("k3t_kernel")),
+    ("conv3x3x3, fp32 kernels (k3_kernel<float>)", lambda k: k.startswith("k3_kernel")),
+    ("stride-2 / transposed convs (g1)", lambda k: k.startswith("g1_kernel")),
+    ("weight gradients (grouped)", lambda k: k.startswith("wgrad_multi") or k.startswith("g3")),
+    ("InstanceNorm+ReLU backward apply", lambda k: k.startswith("in_relu_bwd")),
+)
+
+
+def kernel_families(fwd_bwd, params, dtype, steps=2):
+    """Per-kernel-family summary of live HIP-event timing inside real eager passes: launches, time, algorithmic bytes / FLOPs and the
+    fraction of the roofline that bounds the family (HBM for byte-bound families, dense MFMA peak of the dtype otherwise)."""
+    agg = collect(fwd_bwd, params, steps)
+    peak_tf = MFMA_PEAK_TFLOPS["f32" if dtype == "fp32" else dtype]
+    fam = {}
+    for kid, a in agg.items():
+        name = next((n for n, pred in FAMILIES if pred(kid)), "other timed launches")
+        f = fam.setdefault(name, {"launches_per_step": 0.0, "ms_per_step": 0.0, "bytes": 0.0, "flops": 0.0, "kernels": []})
+        f["launches_per_step"] += a["launches"]
+        f["ms_per_step"] += a["ms"]
+        f["bytes"] += a["bytes"]
+        f["flops"] += a["flops"]
+        f["kernels"].append(kid)
+    out = []
+    for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+        sec = f["ms_per_step"] * 1e-3
+        hbm_bound = f["bytes"] / (HBM_PEAK_GBS * 1e9) >= f["flops"] / (peak_tf * 1e12)
+        ach = f["bytes"] / sec / 1e9 if hbm_bound else f["flops"] / sec / 1e12
+        peak = HBM_PEAK_GBS if hbm_bound else peak_tf
+        out.append({"family": name, "bound": "hbm" if hbm_bound else "mfma", "achieved": round(ach, 2), "peak": peak,
+                    "unit": "GB/s" if hbm_bound else "TFLOP/s", "frac": round(ach / peak, 4),
+                    "launches_per_step": round(f["launches_per_step"], 1), "ms_per_step": round(f["ms_per_step"], 4),
+                    "avg_launch_us": round(1e3 * f["ms_per_step"] / max(f["launches_per_step"], 1e-9), 2),
+                    "algorithmic_bytes_per_step": f["bytes"], "algorithmic_flops_per_step": f["flops"],
+                    "kernels": sorted(set(f["kernels"]))})
+    return {"method": "HIP events around every launch of real eager passes, bracket overhead %.2f us subtracted" % LAST_EVENT_OVERHEAD_US,
+            "timed_ms_per_step": round(sum(f["ms_per_step"] for f in fam.values()), 4), "entries": out}
+
+
 def _norm_name(name):
     name = name.replace("void ", "").split("(")[0]
     return name.replace(" ", "")
@@ -75,7 +139,7 @@ def measured_traffic(kid, path=None):
     passes, FETCH_SIZE doubled per MI355X_MICROARCH.md); None when no summary covers this kernel."""
     import json
     import os
-    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_hbm_traffic.json")
+    path = path or _traffic_path()
     try:
         table = json.load(open(path))
     except Exception:

@@ -54,7 +54,13 @@ def lambda_schedule(recon_loss, lambda_vae):
 
 
 def domain_adaptation_losses(student, teacher, img, label, lambda_vae=1.0, domain_loss_type=0, kl=False,
-                             use_confident_binarize=False, eps=EPS_EVALUATION, n_class=2):
+                             use_confident_binarize=False, eps=EPS_EVALUATION, n_class=2, only_pseudo=False, epoch=0,
+                             turn_epoch=-1, lambda_vae_warmup=0, host_schedule=True):
+    """main_target.py:520-596.  The branch order is the reference's: only_pseudo (:548-549), domain_loss_type 8 / 15 / 16 (:550-560),
+    9 (:561-566), 11 - 14 (:571-582), --turn_epoch alternation (:583-587), then the default with its --lambda_vae_warmup ramp (:588-592).
+    Type 10 reads a tensor of the validation loop that does not exist at that point of the reference (`val_batch`, :568) and raises there too.
+    host_schedule=False evaluates the `if recon_loss < 0.15 ...` ladder of types 8 / 9 on the device (lambda_schedule_device) instead of
+    reading the loss on the host as the reference does: same value, no sync — the form a captured HIP graph needs."""
     batch = {"img": img, "gt": ops.onehot(label, n_class)}
     batch = student(batch, "img", "pred", "recon", dropout=True)
     with torch.no_grad():
@@ -64,7 +70,11 @@ def domain_adaptation_losses(student, teacher, img, label, lambda_vae=1.0, domai
     klloss = KLloss(batch)
     dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=eps)
     fake_loss = 1 - avg_dsc(batch, "pred", "fake", botindex=1, topindex=n_class, eps=eps)
-    if domain_loss_type == 8:
+    if only_pseudo:
+        final = fake_loss
+    elif domain_loss_type in (8, 15, 16, 9) and not host_schedule:
+        final = finetune_loss(recon_loss, fake_loss, klloss, lambda_vae, 9 if domain_loss_type == 9 else 8, kl, False)
+    elif domain_loss_type in (8, 15, 16):
         cur = lambda_schedule(recon_loss.detach(), lambda_vae)
         if cur > 1:
             final = recon_loss + (klloss if kl else 0) + 1 / cur * fake_loss
@@ -73,31 +83,52 @@ def domain_adaptation_losses(student, teacher, img, label, lambda_vae=1.0, domai
     elif domain_loss_type == 9:
         cur = lambda_schedule(recon_loss.detach(), lambda_vae)
         final = (cur * recon_loss + fake_loss) / (1 + cur)
-    elif domain_loss_type == 0:
+    elif domain_loss_type == 11:
+        final = lambda_vae * recon_loss + fake_loss + recon_loss * fake_loss
+    elif domain_loss_type == 12:
+        final = lambda_vae * recon_loss + fake_loss - recon_loss * fake_loss
+    elif domain_loss_type == 13:
+        recon_loss = torch.clamp(recon_loss - 0.15, min=0)        # `recon_loss -= 0.15; recon_loss[recon_loss < 0] = 0`
+        final = lambda_vae * recon_loss
+    elif domain_loss_type == 14:
+        recon_loss = torch.clamp(recon_loss - 0.1, min=0)
+        final = lambda_vae * recon_loss + fake_loss
+    elif domain_loss_type == 10:
+        raise NotImplementedError("domain_loss_type 10 reads `val_batch`, undefined in the reference's training loop (main_target.py:568)")
+    elif domain_loss_type != 0:
+        raise NotImplementedError("domain_loss_type %r" % (domain_loss_type,))
+    elif turn_epoch != -1:
+        final = lambda_vae * recon_loss if (epoch // turn_epoch) % 2 == 0 else lambda_vae * recon_loss + fake_loss
+    elif epoch >= lambda_vae_warmup:
         final = lambda_vae * recon_loss + fake_loss
         if kl:
             final = final + 0.00002 * lambda_vae * klloss
     else:
-        raise NotImplementedError("domain_loss_type %r" % (domain_loss_type,))
+        final = lambda_vae * epoch / lambda_vae_warmup * recon_loss + fake_loss
     return final, {"recon_loss": recon_loss, "kl_loss": klloss, "dice_loss": dsc_loss, "dice_loss_fake": fake_loss,
                    "batch": batch}
 
 
 class GraphedStep:
     """zero_grad -> forward -> losses -> backward captured once into a HIP graph and replayed per step; the
-    optimiser (one multi-tensor kernel) and, under DDP, the gradient all-reduce run eagerly after each replay.
+    optimiser (one multi-tensor kernel) and, under data parallelism, the gradient all-reduces run eagerly around the replays.
 
     ``loss_fn()`` must read its inputs from tensors that stay at fixed addresses (copy new data into them).
+    ``grad_sync``: a ddp.FlatGradSync.  With its two buckets the pass is captured as TWO graphs — [forward, backward, bucket-0
+    weight gradients] and [bucket-1 weight gradients] — and a step is: replay 1, start the all-reduce of bucket 0 on the
+    communication stream, replay 2 underneath it, all-reduce bucket 1, wait, optimiser on the averaged views.
     ``overlap``: issue the weight-gradient kernels on a side stream (a parallel branch of the graph).  Off by default: with the
     current kernels the serial graph is 1-2 % faster (3.87 vs 3.94 ms) — the branch's forks/joins and the contention for CUs cost
-    more than the concurrency returns."""
+    more than the concurrency returns.
+    Models with dropout > 0 cannot be captured (ops.next_dropout_seed raises during capture): run them eagerly."""
 
     def __init__(self, loss_fn, params, optimizer, grad_sync=None, warmup=2, overlap=False):
         ops.set_overlap(overlap and os.environ.get("VS_OVERLAP", "1") != "0")       # VS_OVERLAP=0: measurement aid
         self.loss_fn, self.params, self.optimizer, self.grad_sync = loss_fn, list(params), optimizer, grad_sync
-        self.graph = None
+        self.graph = self.graph2 = None
         self.loss = None
         self.aux = None
+        two_phase = grad_sync is not None and len(grad_sync.buckets) > 1
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -109,20 +140,37 @@ class GraphedStep:
         for p in self.params:
             p.grad = None
         with torch.cuda.graph(self.graph):
-            self._eager_fwd_bwd()
+            self._eager_fwd_bwd(rest=not two_phase)
+        if two_phase:
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+                ops.flush_wgrads()
+        self.grads = [p.grad for p in self.params]
 
-    def _eager_fwd_bwd(self):
+    def _eager_fwd_bwd(self, rest=True):
         for p in self.params:
             p.grad = None
         self.loss, self.aux = self.loss_fn()
         self.loss.backward()
-        ops.join_side()          # weight-gradient kernels run on a side stream (a parallel branch of the captured graph)
+        if rest:
+            ops.join_side()      # side-stream weight gradients (a parallel branch of the captured graph) / the second weight-gradient phase
 
     def step(self):
         self.graph.replay()
-        if self.grad_sync is not None:
-            self.grad_sync()
-        self.optimizer.step()
+        s = self.grad_sync
+        if s is None:
+            self.optimizer.step()
+            return self.loss
+        if self.graph2 is not None:
+            s.start(0)
+            self.graph2.replay()
+            s.gather(self.grads)
+            s.start(1)
+        else:
+            s.gather(self.grads)
+            s.start(0)
+        s.wait()
+        self.optimizer.step_with(s.params, s.views)
         return self.loss
 
 
@@ -195,6 +243,9 @@ class TestTimeFinetune:
             p.requires_grad = False
         model_ft.Vae.eval()
         ops.clear_pack_cache()
+        if graph and (getattr(model_ft, "seg_dropout", 0.0) or getattr(model_ft, "vae_decoder_dropout", 0.0)):
+            graph = False       # dropout > 0: a captured graph would replay the same masks every iteration; the reference draws fresh ones
+        self.graph = bool(graph)
         self.params = [p for p in model_ft.Seg.parameters() if p.requires_grad]
         self.src = [p for p in model.Seg.parameters()][:len(self.params)]
         self.img = torch.zeros(1, 1, spatial, spatial, spatial, device=device)
