@@ -144,6 +144,8 @@ def make_step(a, dtype, rank, use_dist):
     opt = optim.SGD([{"params": joint.Seg.parameters(), "lr": 1e-2}, {"params": joint.Vae.parameters(), "lr": 0.0}],
                     lr=1e-2, momentum=0.9, weight_decay=0.0)
     seg_params = [p for p in joint.Seg.parameters()]
+    scaler = optim.LossScaler() if dtype == "fp16" else None          # fp16 storage: dynamic loss scale, on the device
+    kw = {} if scaler is None else {"scaler": scaler}
     sync = ddp.FlatGradSync(seg_params) if use_dist else None
     if sync is not None:
         sync.broadcast_parameters(0)
@@ -159,14 +161,17 @@ def make_step(a, dtype, rank, use_dist):
             for p in seg_params:
                 p.grad = None
             loss, _ = loss_fn()
-            loss.backward()
-            if sync is not None:
-                opt.step_with(sync.params, sync())
+            if scaler is not None:
+                loss.backward(gradient=scaler.seed)
             else:
-                opt.step()
+                loss.backward()
+            if sync is not None:
+                opt.step_with(sync.params, sync(), **kw)
+            else:
+                opt.step(**kw)
             return loss
     else:
-        gs = T.GraphedStep(loss_fn, seg_params, opt, grad_sync=sync, warmup=2)
+        gs = T.GraphedStep(loss_fn, seg_params, opt, grad_sync=sync, warmup=2, scaler=scaler)
         step = gs.step
 
     def closer():
@@ -211,6 +216,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(a))        # nothing in this process has touched the GPU
+    # fd 1 carries the JSON line and nothing else: native libraries (RCCL prints a version banner to stdout at init) get fd 2
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -291,7 +300,8 @@ def main():
             "roofline": step_roofline(a.dtype, ms_per_step / 1.0, families) if a.side == SIDE else None,
             "fp32_parity_mode": fp32_mode, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

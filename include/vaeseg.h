@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VS_VERSION 100
+#define VS_VERSION 200
 
 enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2 };   /* storage type of activations: fp32 (parity mode), bf16, IEEE fp16 (needs loss scaling, see vs_loss_scale_*) */
 enum { VS_OK = 0, VS_EINVAL = -1, VS_ESHAPE = -2, VS_EDTYPE = -3, VS_EWORKSPACE = -4, VS_EALIGN = -5 };
@@ -259,10 +259,28 @@ int vs_bce_bwd(const float* p, const float* t, const float* gout, float* gp, lon
 int vs_sgd_momentum_multi(float* const* params, const float* const* grads, float* const* bufs, const long long* sizes,
                           const int* block_map, int n_blocks, float lr, float momentum, float weight_decay,
                           int first_step, void* stream);
-/* Adam (torch.optim.Adam, betas (b1,b2), eps 1e-8, L2 weight decay; main_source.py:292-294); step >= 1 */
+/* Adam (torch.optim.Adam, betas (b1,b2), eps 1e-8, L2 weight decay; main_source.py:292-294); step >= 1.  The betas are doubles
+ * (python floats): 1 - beta and the bias corrections 1 - beta^step are formed in double, exactly as torch.optim.Adam forms them. */
 int vs_adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                  const long long* sizes, const int* block_map, int n_blocks, float lr, float beta1, float beta2,
+                  const long long* sizes, const int* block_map, int n_blocks, float lr, double beta1, double beta2,
                   float eps, float weight_decay, int step, void* stream);
+/* ---- dynamic loss scaling: VS_F16 storage (BASELINE configs[4]; no counterpart in the reference, which trains in fp32) ------------
+ * The soft-Dice gradients are O(1e-6): stored as fp16 they fall below the normal range.  The loss is therefore differentiated with
+ * an upstream gradient of S = loss_scale[0] (a DEVICE scalar, so that a captured graph follows it), every gradient comes out S times
+ * too large, and the optimiser divides by S.  Overflow protocol (torch.cuda.amp.GradScaler's, all on the device, no host sync):
+ *   vs_grad_finite_multi      found_inf[0] = 1 if any gradient element is inf / nan (caller zero-initialises once)
+ *   vs_*_scaled_multi         the update with g / S; the WHOLE step is skipped when found_inf[0] != 0  (NULL, NULL = the plain call)
+ *   vs_loss_scale_update      found_inf ? S *= backoff, tracker = 0 : (++tracker == interval ? S *= growth, tracker = 0); found_inf = 0 */
+int vs_sgd_momentum_scaled_multi(float* const* params, const float* const* grads, float* const* bufs, const long long* sizes,
+                                 const int* block_map, int n_blocks, float lr, float momentum, float weight_decay,
+                                 int first_step, const float* loss_scale, const float* found_inf, void* stream);
+int vs_adam_scaled_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                         const long long* sizes, const int* block_map, int n_blocks, float lr, double beta1, double beta2,
+                         float eps, float weight_decay, int step, const float* loss_scale, const float* found_inf, void* stream);
+int vs_grad_finite_multi(const float* const* grads, const long long* sizes, const int* block_map, int n_blocks,
+                         float* found_inf, void* stream);
+int vs_loss_scale_update(float* scale, int* growth_tracker, float* found_inf, float growth_factor, float backoff_factor,
+                         int growth_interval, void* stream);
 /* EMA teacher: t = alpha*t + (1-alpha)*s       (main_target.py:512-516) */
 int vs_ema_multi(float* const* teacher, const float* const* student, const long long* sizes, const int* block_map,
                  int n_blocks, float alpha, void* stream);

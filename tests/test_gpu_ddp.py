@@ -63,8 +63,9 @@ torch.cuda.synchronize()
 direct = sum(1 for p, v in zip(params, views) if p.grad is not None and p.grad.data_ptr() == v.data_ptr())
 assert direct == len(params), "only %%d of %%d gradients were written straight into the flat bucket" %% (direct, len(params))
 avg = [v.detach().cpu().clone() for v in views]
-losses = [torch.zeros(1) for _ in range(world)]
-dist.all_gather(losses, loss.detach().cpu().reshape(1))
+losses = [torch.zeros(1, device="cuda") for _ in range(world)]
+dist.all_gather(losses, loss.detach().reshape(1))
+losses = [float(v.item()) for v in losses]
 
 if rank == 0:
     # (a) same network, GLOBAL batch, one process, no exchange
@@ -118,11 +119,12 @@ with torch.no_grad():                                          # the capture's w
 for _ in range(3):
     gs.step()
 torch.cuda.synchronize()
-flat = torch.cat([p.detach().reshape(-1) for p in params2]).cpu()
-gathered = [torch.zeros_like(flat) for _ in range(world)]
-dist.all_gather(gathered, flat)
+flat_dev = torch.cat([p.detach().reshape(-1) for p in params2])
+gathered = [torch.zeros_like(flat_dev) for _ in range(world)]
+dist.all_gather(gathered, flat_dev)
 for g in gathered[1:]:
     assert torch.equal(gathered[0], g), "replicas diverged"
+flat = flat_dev.cpu()
 if rank == 0:
     sync2.close()
     seg3 = make()

@@ -462,7 +462,11 @@ def test_seg32_dropout_with_exported_masks_vs_oracle(monkeypatch):
             continue
         mine = float((prm.grad.double().cpu() - g64[n]).norm() / g64[n].norm())
         theirs = float((g32[n] - g64[n]).norm() / g64[n].norm())
-        lim = max(RTOL_GRAD_FP32, 8 * theirs)
+        # the bias of a stride-2 / transposed conv in front of an InstanceNorm'd DoubleConv acts only through the zero padding of the
+        # next 3x3x3 conv: its exact gradient is a near-cancelling sum over the voxels (|sum| ~ 1e-3 of sum |.|), so fp32 rounding of the
+        # terms shows up amplified ~1e3 times in the relative error — floor 1e-2 for these 8 vectors
+        floor = 1e-2 if n.endswith(".conv.0.bias") else RTOL_GRAD_FP32
+        lim = max(floor, 8 * theirs)
         over += lim > 1e-2
         assert mine <= lim, (n, mine, lim, theirs)
     print("\nseg32 dropout: %d gradient tensors had a limit above 1e-2" % over)

@@ -115,6 +115,18 @@ def test_joint_train(side, bs, name):
     assert all(p.grad is None for p in joint.Vae.parameters()) and bool(g["vae_grads_none"])
 
 
+def test_joint160_forward():
+    """BASELINE configs[4] geometry (160^3, B=2), forward only: the oracle against the reference modules' golden."""
+    g = G.load("joint160_fwd")
+    joint = O.build_joint(160)
+    with torch.no_grad():
+        final, aux = O.joint_train_losses(joint, O.synthetic_image(2, 160, 2), O.synthetic_label(2, 160, 3))
+    assert final.item() == pytest.approx(float(g["final"]), rel=1e-6)
+    assert aux["recon_loss"].item() == pytest.approx(float(g["recon_loss"]), rel=1e-5)
+    G.check_tensor(g, "pred", aux["batch"]["pred"], k=512, rtol=1e-5)
+    G.check_tensor(g, "recon", aux["batch"]["recon"], k=512, rtol=1e-5)
+
+
 def test_domain_adaptation128():
     g = G.load("da128")
     student, teacher = O.build_joint(128), O.build_joint(128)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/vaeseg.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -203,6 +204,27 @@ template <> struct H16<vs_half> {
     __device__ static __forceinline__ float hi(unsigned int w) { return (float)__builtin_bit_cast(f16x2, w)[1]; }
 };
 
+// four consecutive channels of one voxel: store rounded to T / widen what was loaded as dwords (4 for fp32, 2 for the 16-bit formats)
+template <typename T>
+__device__ __forceinline__ void store4(T* p, const float (&v)[4]) {
+    if constexpr (sizeof(T) == 4) {
+        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+        u32x2 pk;
+        pk[0] = H16<T>::pack2(f32x2{v[0], v[1]});
+        pk[1] = H16<T>::pack2(f32x2{v[2], v[3]});
+        *(u32x2*)p = pk;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void widen4(const unsigned int* w, float (&v)[4]) {
+    if constexpr (sizeof(T) == 4) {
+        v[0] = __uint_as_float(w[0]); v[1] = __uint_as_float(w[1]); v[2] = __uint_as_float(w[2]); v[3] = __uint_as_float(w[3]);
+    } else {
+        v[0] = H16<T>::lo(w[0]); v[1] = H16<T>::hi(w[0]); v[2] = H16<T>::lo(w[1]); v[3] = H16<T>::hi(w[1]);
+    }
+}
+
 // relu(x * scale + shift) on one 16-byte fragment of 8 channels (bf16 or fp16)
 template <typename T>
 __device__ __forceinline__ u32x4 act8(const u32x4 raw, const f32x2 (&sc)[4], const f32x2 (&sh)[4]) {
@@ -243,5 +265,14 @@ static inline hipError_t vs_zero_async(void* p, size_t bytes, hipStream_t stream
         hipError_t e__ = hipGetLastError();                \
         if (e__ != hipSuccess) return (int)e__;            \
     } while (0)
+
+// run f with a null pointer of the storage type as tag: f((float*)0) / f((unsigned short*)0) [bf16 bits] / f((vs_half*)0) [fp16]
+template <typename F>
+static inline void dispatch_t(int dtype, F&& f) {
+    if (dtype == VS_F32) f((float*)nullptr);
+    else if (dtype == VS_BF16) f((unsigned short*)nullptr);
+    else f((vs_half*)nullptr);
+}
+#define TAG_T(tag) typename std::remove_pointer<decltype(tag)>::type
 
 static inline int vs_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

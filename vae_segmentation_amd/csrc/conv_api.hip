@@ -4,6 +4,13 @@
 
 int g1_dispatch_k3_f32(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
+int g1_dispatch_k3_f16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
+
+static int dispatch_k3(const G1Params& p, int dtype, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s) {
+    if (dtype == VS_F32) return g1_dispatch_k3_f32(p, ck, mt, epi, tiles, row_tiles, s);
+    if (dtype == VS_BF16) return g1_dispatch_k3_bf16(p, ck, mt, epi, tiles, row_tiles, s);
+    return g1_dispatch_k3_f16(p, ck, mt, epi, tiles, row_tiles, s);
+}
 
 static int pick_mt(int rows16, long long tiles) {
     // largest row tile that still leaves >= VS_MT_MIN_WGS workgroups; 16 when the layer is too small for that.
@@ -22,7 +29,7 @@ static int check_common(const void* x, const void* w, int n, int d, int h, int w
     if (!x || !w) return VS_EINVAL;
     if (n <= 0 || d <= 0 || h <= 0 || w_ <= 0) return VS_ESHAPE;
     if (!(c_in == 8 || c_in == 16 || (c_in % 32 == 0 && c_in > 0 && c_in <= 256))) return VS_ESHAPE;
-    if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
+    if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return VS_EALIGN;
     if ((double)n * d * h * w_ * c_in >= 2147483648.0) return VS_ESHAPE;      // kernels index activations with 32-bit element offsets
     return VS_OK;
@@ -69,8 +76,7 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     const int mt = (kind != VS_CONV_K3 && p.tyn == 64) ? 16 : pick_mt(rows16, tiles);
     const int row_tiles = rows16 / mt;
     if (kind == VS_CONV_K3) {
-        return dtype == VS_F32 ? g1_dispatch_k3_f32(p, ck, mt, EPI_RAW, (int)tiles, row_tiles, (hipStream_t)stream)
-                               : g1_dispatch_k3_bf16(p, ck, mt, EPI_RAW, (int)tiles, row_tiles, (hipStream_t)stream);
+        return dispatch_k3(p, dtype, ck, mt, EPI_RAW, (int)tiles, row_tiles, (hipStream_t)stream);
     }
     return g1_dispatch_k2s2(p, dtype, ck, mt, (int)tiles, row_tiles, (hipStream_t)stream);
 }
@@ -142,7 +148,7 @@ extern "C" int vs_conv_k3_softmax2_cl_fwd(const void* x, const double* x_stats, 
                                           float* prob, void* prob_cl, int n, int d, int h, int w, int c_in, int dtype, float eps,
                                           float drop_p, unsigned long long drop_seed, void* stream) {
     if (drop_p < 0.f || drop_p >= 1.f) return VS_EINVAL;
-    if (prob_cl && dtype != VS_BF16) return VS_EDTYPE;
+    if (prob_cl && dtype == VS_F32) return VS_EDTYPE;
     if (prob_cl && ((uintptr_t)prob_cl & 15)) return VS_EALIGN;
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
@@ -161,6 +167,5 @@ extern "C" int vs_conv_k3_softmax2_cl_fwd(const void* x, const double* x_stats, 
     p.tyn = (h + 3) / 4; p.txn = (w + 15) / 16;
     p.tiles_per_sample = ((d + 3) / 4) * p.tyn * p.txn;
     const long long tiles = (long long)p.tiles_per_sample * n;
-    return dtype == VS_F32 ? g1_dispatch_k3_f32(p, 8, 16, EPI_SOFTMAX2, (int)tiles, 1, (hipStream_t)stream)
-                           : g1_dispatch_k3_bf16(p, 8, 16, EPI_SOFTMAX2, (int)tiles, 1, (hipStream_t)stream);
+    return dispatch_k3(p, dtype, 8, 16, EPI_SOFTMAX2, (int)tiles, 1, (hipStream_t)stream);
 }

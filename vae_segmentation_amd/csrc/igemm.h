@@ -1,12 +1,12 @@
 // Implicit-GEMM convolution: shared parameter block and fragment conventions of every conv kernel, and g1_kernel — the
 // direct-from-global kernel of the 2x2x2 stride-2 convolution (K2S2) and the pointwise + 2x scatter = transposed convolution (PW).
-// The 3x3x3 kernels (LDS-staged halo tiles) are igemm_k3b.h (bf16) and igemm_k3.h (fp32).
+// The 3x3x3 kernels (LDS-staged halo tiles) are igemm_k3b.h / igemm_k3t.h / igemm_k3s.h (bf16, fp16) and igemm_k3.h (fp32).
 //
 // GEMM orientation: D[row = output channel m][col = voxel] = sum_k A[m][k] * B[k][voxel]
 //   A = packed weights (fragment order, see pack.hip), 16 B/lane
 //   B = activations: k runs over (tap, channel); a lane's 16-byte fragment is EPL contiguous channels of one input voxel
 // The accumulator layout (col = lane&15, row = 4*(lane>>4)+reg) gives every lane 4 consecutive output
-// channels of one voxel, i.e. one 16-byte (f32) / 8-byte (bf16) channels-last store.
+// channels of one voxel, i.e. one 16-byte (f32) / 8-byte (bf16, fp16) channels-last store.
 #pragma once
 #include <type_traits>
 #include "common.h"
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                         const u32x4 xx = *(const u32x4*)((const float*)p.mask_x + e);
                         mkv[rb][cg][0] = xx[0]; mkv[rb][cg][1] = xx[1]; mkv[rb][cg][2] = xx[2]; mkv[rb][cg][3] = xx[3];
                     } else {
-                        const u32x2 xx = *(const u32x2*)((const unsigned short*)p.mask_x + e);
+                        const u32x2 xx = *(const u32x2*)((const T*)p.mask_x + e);
                         mkv[rb][cg][0] = xx[0]; mkv[rb][cg][1] = xx[1];
                     }
                 }
@@ -377,23 +377,10 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = E::rnd(acc[rb][cg][r] + bv[r]);
-            if constexpr (sizeof(T) == 4) {
-                *(f32x4*)((float*)yout + e) = f32x4{v[0], v[1], v[2], v[3]};
-            } else {
-                u32x2 pk;
-                pk[0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
-                pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
-                *(u32x2*)((unsigned short*)yout + e) = pk;
-            }
+            store4<T>(yout + e, v);
             if (p.sums != nullptr) {
                 float xv[4];
-                if constexpr (sizeof(T) == 4) {
-                    xv[0] = __uint_as_float(mkv[rb][cg][0]); xv[1] = __uint_as_float(mkv[rb][cg][1]);
-                    xv[2] = __uint_as_float(mkv[rb][cg][2]); xv[3] = __uint_as_float(mkv[rb][cg][3]);
-                } else {
-                    xv[0] = __uint_as_float(mkv[rb][cg][0] << 16); xv[1] = __uint_as_float(mkv[rb][cg][0] & 0xffff0000u);
-                    xv[2] = __uint_as_float(mkv[rb][cg][1] << 16); xv[3] = __uint_as_float(mkv[rb][cg][1] & 0xffff0000u);
-                }
+                widen4<T>(mkv[rb][cg], xv);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float xh = (xv[r] - mk_mean[rb][r]) * mk_rstd[rb][r];

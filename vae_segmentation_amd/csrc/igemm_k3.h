@@ -301,23 +301,16 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = E::rnd(acc[rb][cg][r] + bv[r]);
                     const size_t e = ((((size_t)n * p.D + oz) * p.H + oy) * p.W + ox) * p.M + row;
-                    if constexpr (sizeof(T) == 4) {
-                        *(f32x4*)((float*)yout + e) = f32x4{v[0], v[1], v[2], v[3]};
-                    } else {
-                        u32x2 pk;
-                        pk[0] = (unsigned int)f2bf(v[0]) | ((unsigned int)f2bf(v[1]) << 16);
-                        pk[1] = (unsigned int)f2bf(v[2]) | ((unsigned int)f2bf(v[3]) << 16);
-                        *(u32x2*)((unsigned short*)yout + e) = pk;
-                    }
+                    store4<T>(yout + e, v);
                     if (p.sums != nullptr) {
                         float xv[4];
                         if constexpr (sizeof(T) == 4) {
                             const f32x4 xx = *(const f32x4*)((const float*)p.mask_x + e);
                             xv[0] = xx[0]; xv[1] = xx[1]; xv[2] = xx[2]; xv[3] = xx[3];
                         } else {
-                            const u32x2 xx = *(const u32x2*)((const unsigned short*)p.mask_x + e);
-                            xv[0] = __uint_as_float(xx[0] << 16); xv[1] = __uint_as_float(xx[0] & 0xffff0000u);
-                            xv[2] = __uint_as_float(xx[1] << 16); xv[3] = __uint_as_float(xx[1] & 0xffff0000u);
+                            const u32x2 xx = *(const u32x2*)((const T*)p.mask_x + e);
+                            const unsigned int w2[2] = {xx[0], xx[1]};
+                            widen4<T>(w2, xv);
                         }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {

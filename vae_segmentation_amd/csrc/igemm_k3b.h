@@ -1,4 +1,4 @@
-// 3x3x3 (pad 1) implicit-GEMM convolution, bf16 operands / fp32 accumulate: forward and backward-data.
+// 3x3x3 (pad 1) implicit-GEMM convolution, bf16 or fp16 operands / fp32 accumulate: forward and backward-data.
 //
 // Second-generation kernel for the bf16 path (the fp32 path keeps k3_kernel, igemm_k3.h).  Phase stamps of k3_kernel
 // (tools/stamps_k3.py) showed that no phase was bound by MFMA or HBM; every phase paid a memory round trip instead:
@@ -62,10 +62,11 @@ struct K3BGeom {
 // SUMS: backward-data use (input = a materialised gradient, no statistics; epilogue accumulates the fused IN-backward sums)
 // HS: the input is a lazy activation — compile-time, like every condition on the staging path (a run-time test between a load and its
 // use, or an exec-masked tail store, makes the compiler drain vmcnt(0): it then waits for the prefetched stage as well)
-template <int CK, int MT, int EPI, bool SUMS, int YT = 4, bool HS = false>
+// T: unsigned short (bf16 bits) or vs_half (fp16) — same fragment shapes, same MFMA rate; last template argument so that the profiler's
+// kernel names keep their prefix
+template <int CK, int MT, int EPI, bool SUMS, int YT = 4, bool HS = false, typename T = unsigned short>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     YT == 8 ? 2 : (CK == 32 ? (MT == 32 ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : (CK == 16 && SUMS ? 3 : 4))), 8))) void k3b_kernel(const G1Params p) {
-    typedef unsigned short T;
     K3_TICK_INIT
     using GEO = K3BGeom<CK, MT, YT>;
     static_assert(YT == 4 || (YT == 8 && CK < 32 && MT == 16), "tall tiles: single-chunk layers, 16 rows");
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         for (int b = 0; b < NIT; ++b) {
             u32x4 v = xv[b];
             if (has_stats) {
-                const u32x4 a = act8<unsigned short>(v, sc, sh);
+                const u32x4 a = act8<T>(v, sc, sh);
                 const bool ok = (okbits >> b) & 1u;       // zero padding applies to the normalised activation
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
@@ -371,23 +372,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                 for (int cg = 0; cg < YT; ++cg) {
                     const bool valid = rvalid && zx_ok && y0 + cg < p.H;
-                    // round once to bf16; the statistics are those of the stored values
+                    // round once to T; the statistics are those of the stored values
                     f32x2 lo, hi;
                     lo[0] = acc[rb][cg][0] + bv[rb][0]; lo[1] = acc[rb][cg][1] + bv[rb][1];
                     hi[0] = acc[rb][cg][2] + bv[rb][2]; hi[1] = acc[rb][cg][3] + bv[rb][3];
                     i32x2 pk;
-                    pk[0] = __builtin_bit_cast(int, __builtin_convertvector(lo, bf16x2));
-                    pk[1] = __builtin_bit_cast(int, __builtin_convertvector(hi, bf16x2));
+                    pk[0] = (int)H16<T>::pack2(lo);
+                    pk[1] = (int)H16<T>::pack2(hi);
                     vs_raw_buffer_store_b64(pk, yrsrc, valid ? ebase + cg * p.W * p.M * 2 + rb * 32 : -1, 0, 0);
                     float v[4];
-                    v[0] = __uint_as_float((unsigned int)pk[0] << 16); v[1] = __uint_as_float((unsigned int)pk[0] & 0xffff0000u);
-                    v[2] = __uint_as_float((unsigned int)pk[1] << 16); v[3] = __uint_as_float((unsigned int)pk[1] & 0xffff0000u);
+                    v[0] = H16<T>::lo((unsigned int)pk[0]); v[1] = H16<T>::hi((unsigned int)pk[0]);
+                    v[2] = H16<T>::lo((unsigned int)pk[1]); v[3] = H16<T>::hi((unsigned int)pk[1]);
                     if (!valid) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
                     if (has_sums) {
                         const u32x2 xx = mk[rb][cg];
                         float xv4[4];
-                        xv4[0] = __uint_as_float(xx[0] << 16); xv4[1] = __uint_as_float(xx[0] & 0xffff0000u);
-                        xv4[2] = __uint_as_float(xx[1] << 16); xv4[3] = __uint_as_float(xx[1] & 0xffff0000u);
+                        xv4[0] = H16<T>::lo(xx[0]); xv4[1] = H16<T>::hi(xx[0]);
+                        xv4[2] = H16<T>::lo(xx[1]); xv4[3] = H16<T>::hi(xx[1]);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float xh = (xv4[r] - mm[r]) * mr[r];
@@ -445,7 +446,7 @@ static inline void k3b_fastdiv(int d, unsigned int& m, unsigned int& s) {
     m = (unsigned int)((((1ull << (32 + s)) + (unsigned long long)d - 1) / (unsigned long long)d) - (1ull << 32));
 }
 
-template <int CK, int MT, int EPI, bool SUMS, int YT, bool HS>
+template <typename T, int CK, int MT, int EPI, bool SUMS, int YT, bool HS>
 static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
     using GEO = K3BGeom<CK, MT, YT>;
     const size_t tables = (size_t)2 * p_in.N * p_in.C * sizeof(float) + (p_in.sums ? (size_t)2 * p_in.N * p_in.M * sizeof(float) : 0);
@@ -463,7 +464,7 @@ static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     k3b_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3b_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
     if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr)) return VS_EINVAL;
-    auto kern = k3b_kernel<CK, MT, EPI, SUMS, YT, HS>;
+    auto kern = k3b_kernel<CK, MT, EPI, SUMS, YT, HS, T>;
     // idempotent one-time opt-in to the full 160 KiB of dynamic LDS (not a stream operation)
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -480,10 +481,10 @@ static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     return VS_OK;
 }
 
-template <int CK, int MT, int EPI, bool SUMS, int YT = 4>
+template <typename T, int CK, int MT, int EPI, bool SUMS, int YT = 4>
 static int k3b_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
-    if (!SUMS && p.x_stats != nullptr) return k3b_launch_t<CK, MT, EPI, SUMS, YT, !SUMS>(p, tiles_total, row_tiles, stream);
-    return k3b_launch_t<CK, MT, EPI, SUMS, YT, false>(p, tiles_total, row_tiles, stream);
+    if (!SUMS && p.x_stats != nullptr) return k3b_launch_t<T, CK, MT, EPI, SUMS, YT, !SUMS>(p, tiles_total, row_tiles, stream);
+    return k3b_launch_t<T, CK, MT, EPI, SUMS, YT, false>(p, tiles_total, row_tiles, stream);
 }
 
 // Tall (4x8x16) tiles: measured faster (16->16 @48^3: 19.4 -> 15.4 us) where the layer is one wave of workgroups anyway — fewer,

@@ -1,4 +1,4 @@
-// 3x3x3 (pad 1) convolution of the SMALL volumes (up to 6^3: the deep levels, C >= 32), bf16: forward and backward-data.
+// 3x3x3 (pad 1) convolution of the SMALL volumes (up to 6^3: the deep levels, C >= 32), bf16 / fp16: forward and backward-data.
 //
 // k3b_kernel's 4x4x16 tile is mostly padding there (6^3: 28 % of the tile's columns are voxels, 3^3: 14 %), every wave re-reads the
 // whole weight block from LDS, and the measured bound of those launches is the LDS read bandwidth of the MFMA phase (1.25 KB of
@@ -22,7 +22,8 @@
 // TVC: compile-time bound of the padded voxel count (128: up to 3x3x3, 512: up to 6x6x6) -> staging fragments per thread
 // HS: the input is a lazy activation (normalise + ReLU while staging) — compile-time, like every other condition on the staging path: a
 // run-time test between a load and its use makes the compiler drain vmcnt(0), i.e. wait for the prefetched stages as well
-template <bool SUMS, int TVC, bool HS>
+// T: unsigned short (bf16 bits) or vs_half (fp16); last template argument (kernel-name prefix unchanged)
+template <bool SUMS, int TVC, bool HS, typename T = unsigned short>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k3s_kernel(const G1Params p) {
     K3_TICK_INIT
     constexpr int NIT = TVC * 4 / 256;                   // 16-byte fragments per thread per stage
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         for (int b = 0; b < NIT; ++b) {
             u32x4 v = xv[b];
             if (has_stats) {
-                const u32x4 a = act8<unsigned short>(v, sc, sh);
+                const u32x4 a = act8<T>(v, sc, sh);
                 const bool ok = goff[b] >= 0;             // zero padding applies to the normalised activation
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
             for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + boff[i][cg]);
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) acc[cg] = mfma16(a, b[cg], acc[cg], (unsigned short*)nullptr);
+            for (int cg = 0; cg < 4; ++cg) acc[cg] = mfma16(a, b[cg], acc[cg], (T*)nullptr);
         }
     };
     for (int ch = 0; ch < p.nch; ch += 2) {
@@ -230,18 +231,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     lo[0] = o[0] + bv[0]; lo[1] = o[1] + bv[1];
     hi[0] = o[2] + bv[2]; hi[1] = o[3] + bv[3];
     i32x2 pk;
-    pk[0] = __builtin_bit_cast(int, __builtin_convertvector(lo, bf16x2));
-    pk[1] = __builtin_bit_cast(int, __builtin_convertvector(hi, bf16x2));
+    pk[0] = (int)H16<T>::pack2(lo);
+    pk[1] = (int)H16<T>::pack2(hi);
     vs_raw_buffer_store_b64(pk, yrsrc, valid ? e : -1, 0, 0);
-    float sv[4];                                         // round once to bf16; the statistics are those of the stored values
-    sv[0] = __uint_as_float((unsigned int)pk[0] << 16); sv[1] = __uint_as_float((unsigned int)pk[0] & 0xffff0000u);
-    sv[2] = __uint_as_float((unsigned int)pk[1] << 16); sv[3] = __uint_as_float((unsigned int)pk[1] & 0xffff0000u);
+    float sv[4];                                         // round once to T; the statistics are those of the stored values
+    sv[0] = H16<T>::lo((unsigned int)pk[0]); sv[1] = H16<T>::hi((unsigned int)pk[0]);
+    sv[2] = H16<T>::lo((unsigned int)pk[1]); sv[3] = H16<T>::hi((unsigned int)pk[1]);
     if (!valid) { sv[0] = 0.f; sv[1] = 0.f; sv[2] = 0.f; sv[3] = 0.f; }
     float ssum[4], ssq[4];
     if constexpr (SUMS) {
         float xv4[4];
-        xv4[0] = __uint_as_float(mk[0] << 16); xv4[1] = __uint_as_float(mk[0] & 0xffff0000u);
-        xv4[2] = __uint_as_float(mk[1] << 16); xv4[3] = __uint_as_float(mk[1] & 0xffff0000u);
+        xv4[0] = H16<T>::lo(mk[0]); xv4[1] = H16<T>::hi(mk[0]);
+        xv4[2] = H16<T>::lo(mk[1]); xv4[3] = H16<T>::hi(mk[1]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float xh = (xv4[r] - mm[r]) * mr[r];
@@ -286,11 +287,11 @@ static inline bool k3s_takes(const G1Params& p, int ck) {
     return on && ck == 32 && p.C % 32 == 0 && (p.D + 2) * (p.H + 2) * (p.W + 2) <= 512 && p.C <= 1024;
 }
 
-template <bool SUMS, int TVC, bool HS>
+template <typename T, bool SUMS, int TVC, bool HS>
 static int k3s_launch_t(const G1Params& p, int ctiles, hipStream_t stream) {
     const size_t lds = K3S_LDS_TILE + (size_t)(TVC * 64 > 16384 ? TVC * 64 : 16384) + (size_t)2 * p.C * sizeof(float);
     if (lds > 160 * 1024) return VS_ESHAPE;
-    auto kern = k3s_kernel<SUMS, TVC, HS>;
+    auto kern = k3s_kernel<SUMS, TVC, HS, T>;
     static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
     hipLaunchKernelGGL(kern, dim3(ctiles * p.N, (p.M + 15) / 16), dim3(256), lds, stream, p);
@@ -298,7 +299,7 @@ static int k3s_launch_t(const G1Params& p, int ctiles, hipStream_t stream) {
     return VS_OK;
 }
 
-template <bool SUMS>
+template <typename T, bool SUMS>
 static int k3s_launch(const G1Params& p_in, hipStream_t stream) {
     G1Params p = p_in;
     if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr)) return VS_EINVAL;
@@ -306,7 +307,7 @@ static int k3s_launch(const G1Params& p_in, hipStream_t stream) {
     const int ctiles = (V + 63) / 64;
     p.tiles_per_sample = ctiles;
     const bool hs = !SUMS && p.x_stats != nullptr;
-#define K3S_GO(TVC) return hs ? k3s_launch_t<SUMS, TVC, !SUMS>(p, ctiles, stream) : k3s_launch_t<SUMS, TVC, false>(p, ctiles, stream)
+#define K3S_GO(TVC) return hs ? k3s_launch_t<T, SUMS, TVC, !SUMS>(p, ctiles, stream) : k3s_launch_t<T, SUMS, TVC, false>(p, ctiles, stream)
     if (TV <= 128) K3S_GO(128);
     if (TV <= 512) K3S_GO(512);
     return VS_ESHAPE;

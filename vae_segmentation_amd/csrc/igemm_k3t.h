@@ -1,4 +1,4 @@
-// 3x3x3 (pad 1) convolution of the 8-channel full-resolution layers (in_block, up5, out_block and their backward-data), bf16.
+// 3x3x3 (pad 1) convolution of the 8-channel full-resolution layers (in_block, up5, out_block and their backward-data), bf16 / fp16.
 //
 // These layers are HBM-bound by the algorithm (8 -> 8 channels at 96^3, B = 2: 57 MB in + out, 7 us at 8 TB/s) and ran
 // instruction-issue bound in k3b_kernel<8,...> (31 us): per 64 output voxels a wave spent ~277 VALU, ~129 SALU, 59 LDS and
@@ -29,7 +29,8 @@ struct K3TGeom {
 };
 
 // HS: lazy input (normalise + ReLU while staging), compile-time like every condition on the staging path
-template <int EPI, bool SUMS, int YT, bool HS>
+// T: unsigned short (bf16 bits) or vs_half (fp16); last template argument (kernel-name prefix unchanged)
+template <int EPI, bool SUMS, int YT, bool HS, typename T = unsigned short>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k3t_kernel(const G1Params p) {
     K3_TICK_INIT
     using GEO = K3TGeom<YT>;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int b = 0; b < NIT; ++b) {
             u32x4 v = xv[b];
             if (has_stats) {
-                const u32x4 a = act8<unsigned short>(v, sc, sh);
+                const u32x4 a = act8<T>(v, sc, sh);
                 const bool ok = (okbits >> b) & 1u;       // zero padding applies to the normalised activation
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int ty = 0; ty < 3; ++ty)
 #pragma unroll
-                for (int cg = 0; cg < YT; ++cg) acc[cg] = mfma16(wa[tz * 3 + ty], fb[cg + ty], acc[cg], (unsigned short*)nullptr);
+                for (int cg = 0; cg < YT; ++cg) acc[cg] = mfma16(wa[tz * 3 + ty], fb[cg + ty], acc[cg], (T*)nullptr);
             __builtin_amdgcn_sched_barrier(0);
         }
 
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     f32x2 pr;
                     pr[0] = e0 * inv; pr[1] = e1 * inv;
                     i32x2 pk;
-                    pk[0] = (g & 1) == 0 ? __builtin_bit_cast(int, __builtin_convertvector(pr, bf16x2)) : 0;
+                    pk[0] = (g & 1) == 0 ? (int)H16<T>::pack2(pr) : 0;
                     pk[1] = 0;
                     vs_raw_buffer_store_b64(pk, yrsrc, valid ? ebase + cg * p.W * 16 : -1, 0, 0);
                 }
@@ -235,23 +236,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int cg = 0; cg < YT; ++cg) {
                 const bool valid = zx_ok && y0 + cg < p.H;
-                // round once to bf16; the statistics are those of the stored values
+                // round once to T; the statistics are those of the stored values
                 f32x2 lo, hi;
                 lo[0] = acc[cg][0] + bv[0]; lo[1] = acc[cg][1] + bv[1];
                 hi[0] = acc[cg][2] + bv[2]; hi[1] = acc[cg][3] + bv[3];
                 i32x2 pk;
-                pk[0] = __builtin_bit_cast(int, __builtin_convertvector(lo, bf16x2));
-                pk[1] = __builtin_bit_cast(int, __builtin_convertvector(hi, bf16x2));
+                pk[0] = (int)H16<T>::pack2(lo);
+                pk[1] = (int)H16<T>::pack2(hi);
                 vs_raw_buffer_store_b64(pk, yrsrc, valid ? ebase + cg * p.W * 16 : -1, 0, 0);
                 float v[4];
-                v[0] = __uint_as_float((unsigned int)pk[0] << 16); v[1] = __uint_as_float((unsigned int)pk[0] & 0xffff0000u);
-                v[2] = __uint_as_float((unsigned int)pk[1] << 16); v[3] = __uint_as_float((unsigned int)pk[1] & 0xffff0000u);
+                v[0] = H16<T>::lo((unsigned int)pk[0]); v[1] = H16<T>::hi((unsigned int)pk[0]);
+                v[2] = H16<T>::lo((unsigned int)pk[1]); v[3] = H16<T>::hi((unsigned int)pk[1]);
                 if (!valid) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
                 if constexpr (SUMS) {
                     const u32x2 xx = mk[cg];
                     float xv4[4];
-                    xv4[0] = __uint_as_float(xx[0] << 16); xv4[1] = __uint_as_float(xx[0] & 0xffff0000u);
-                    xv4[2] = __uint_as_float(xx[1] << 16); xv4[3] = __uint_as_float(xx[1] & 0xffff0000u);
+                    xv4[0] = H16<T>::lo(xx[0]); xv4[1] = H16<T>::hi(xx[0]);
+                    xv4[2] = H16<T>::lo(xx[1]); xv4[3] = H16<T>::hi(xx[1]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float xh = (xv4[r] - mm[r]) * mr[r];
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     K3_TICK_FLUSH;
 }
 
-template <int EPI, bool SUMS, int YT, bool HS>
+template <typename T, int EPI, bool SUMS, int YT, bool HS>
 static int k3t_launch_t(const G1Params& p_in, hipStream_t stream) {
     using GEO = K3TGeom<YT>;
     G1Params p = p_in;
@@ -316,7 +317,7 @@ static int k3t_launch_t(const G1Params& p_in, hipStream_t stream) {
     k3b_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3b_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
     if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr)) return VS_EINVAL;
-    auto kern = k3t_kernel<EPI, SUMS, YT, HS>;
+    auto kern = k3t_kernel<EPI, SUMS, YT, HS, T>;
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
@@ -331,8 +332,8 @@ static int k3t_launch_t(const G1Params& p_in, hipStream_t stream) {
     return VS_OK;
 }
 
-template <int EPI, bool SUMS, int YT>
+template <typename T, int EPI, bool SUMS, int YT>
 static int k3t_launch(const G1Params& p, hipStream_t stream) {
-    if (!SUMS && p.x_stats != nullptr) return k3t_launch_t<EPI, SUMS, YT, !SUMS>(p, stream);
-    return k3t_launch_t<EPI, SUMS, YT, false>(p, stream);
+    if (!SUMS && p.x_stats != nullptr) return k3t_launch_t<T, EPI, SUMS, YT, !SUMS>(p, stream);
+    return k3t_launch_t<T, EPI, SUMS, YT, false>(p, stream);
 }

@@ -8,7 +8,7 @@ extern "C" const char* vs_strerror(int code) {
         case VS_OK: return "ok";
         case VS_EINVAL: return "invalid argument (null pointer or non-positive size)";
         case VS_ESHAPE: return "unsupported shape (channels must be 8, 16 or a multiple of 32 up to 256; even dims for stride 2; batch <= 16 for wgrad)";
-        case VS_EDTYPE: return "unsupported dtype (VS_F32 or VS_BF16)";
+        case VS_EDTYPE: return "unsupported dtype (VS_F32, VS_BF16 or VS_F16)";
         case VS_EWORKSPACE: return "workspace too small";
         case VS_EALIGN: return "pointer not 16-byte aligned";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown libvaeseg error";
@@ -31,14 +31,14 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ out, lon
 }
 extern "C" int vs_dropout(const void* x, void* out, long long count, float p, unsigned long long seed, int dtype, void* stream) {
     if (!x || !out || count <= 0 || p < 0.f || p >= 1.f) return VS_EINVAL;
+    if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
     const int epl = dtype == VS_F32 ? 4 : 8;
     if (count % epl) return VS_ESHAPE;
     const long long frags = count / epl;
-    if (dtype == VS_F32)
-        hipLaunchKernelGGL(dropout_kernel<float>, GRID1D(frags), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, frags, p, seed);
-    else if (dtype == VS_BF16)
-        hipLaunchKernelGGL(dropout_kernel<unsigned short>, GRID1D(frags), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (unsigned short*)out, frags, p, seed);
-    else return VS_EDTYPE;
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(dropout_kernel<T>, GRID1D(frags), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, frags, p, seed);
+    });
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -99,11 +99,11 @@ extern "C" int vs_softmax2_cl_bwd(const float* prob, const float* gprob, const v
                                   int c_pad, int dtype, float drop_p, unsigned long long drop_seed, void* stream) {
     if (!prob || (!gprob && !gprob_cl) || !glogit || n <= 0 || voxels <= 0 || c_pad % 8 || c_pad <= 0) return VS_EINVAL;
     const long long total = (long long)n * voxels;
-    if (dtype == VS_F32)
-        hipLaunchKernelGGL(softmax2_bwd_kernel<float>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (const float*)gprob_cl, (float*)glogit, voxels, c_pad, total, drop_p, drop_seed);
-    else if (dtype == VS_BF16)
-        hipLaunchKernelGGL(softmax2_bwd_kernel<unsigned short>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (const unsigned short*)gprob_cl, (unsigned short*)glogit, voxels, c_pad, total, drop_p, drop_seed);
-    else return VS_EDTYPE;
+    if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(softmax2_bwd_kernel<T>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (const T*)gprob_cl, (T*)glogit, voxels, c_pad, total, drop_p, drop_seed);
+    });
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -143,10 +143,14 @@ extern "C" int vs_binarize(const float* a, float* out, long long count, int mode
 // ---- fully connected --------------------------------------------------------------------------------
 __device__ __forceinline__ long long phys_index(int k, int pc, int pv) { return pc > 0 ? (long long)(k % pv) * pc + k / pv : k; }
 __device__ __forceinline__ float ld_any(const void* p, int dtype, long long i) {
-    return dtype == VS_F32 ? ((const float*)p)[i] : bf2f(((const unsigned short*)p)[i]);
+    if (dtype == VS_F32) return ((const float*)p)[i];
+    if (dtype == VS_BF16) return bf2f(((const unsigned short*)p)[i]);
+    return (float)((const vs_half*)p)[i];
 }
 __device__ __forceinline__ void st_any(void* p, int dtype, long long i, float v) {
-    if (dtype == VS_F32) ((float*)p)[i] = v; else ((unsigned short*)p)[i] = f2bf(v);
+    if (dtype == VS_F32) ((float*)p)[i] = v;
+    else if (dtype == VS_BF16) ((unsigned short*)p)[i] = f2bf(v);
+    else ((vs_half*)p)[i] = (vs_half)v;
 }
 #define LIN_MAXB 16
 
@@ -806,7 +810,10 @@ extern "C" int vs_bce_bwd(const float* p, const float* t, const float* gout, flo
 #define MT_CHUNK 4096
 __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* params, const float* const* grads, float* const* bufs,
                                                         const long long* sizes, const int* block_map, float lr, float momentum,
-                                                        float wd, int first) {
+                                                        float wd, int first, const float* __restrict__ loss_scale,
+                                                        const float* __restrict__ found_inf) {
+    if (found_inf != nullptr && found_inf[0] != 0.f) return;          // a non-finite gradient somewhere: the whole step is skipped
+    const float inv_scale = loss_scale != nullptr ? 1.f / loss_scale[0] : 1.f;
     const int ti = block_map[2 * blockIdx.x], start = block_map[2 * blockIdx.x + 1];
     float* p = params[ti];
     const float* g = grads[ti];
@@ -827,7 +834,7 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* params, co
     for (int r = 0; r < R; ++r) {
         const long long i = start + threadIdx.x + r * 256;
         if (i < end) {
-            const float gi = gv[r] + wd * pv[r];
+            const float gi = gv[r] * inv_scale + wd * pv[r];
             const float bi = first ? gi : momentum * mv[r] + gi;
             m[i] = bi;
             p[i] = pv[r] - lr * (momentum != 0.f ? bi : gi);
@@ -837,15 +844,24 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* params, co
 extern "C" int vs_sgd_momentum_multi(float* const* params, const float* const* grads, float* const* bufs, const long long* sizes,
                                      const int* block_map, int n_blocks, float lr, float momentum, float weight_decay,
                                      int first_step, void* stream) {
+    return vs_sgd_momentum_scaled_multi(params, grads, bufs, sizes, block_map, n_blocks, lr, momentum, weight_decay, first_step, nullptr, nullptr, stream);
+}
+extern "C" int vs_sgd_momentum_scaled_multi(float* const* params, const float* const* grads, float* const* bufs, const long long* sizes,
+                                            const int* block_map, int n_blocks, float lr, float momentum, float weight_decay,
+                                            int first_step, const float* loss_scale, const float* found_inf, void* stream) {
     if (!params || !grads || !bufs || !sizes || !block_map || n_blocks <= 0) return VS_EINVAL;
-    hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, params, grads, bufs, sizes, block_map, lr, momentum, weight_decay, first_step);
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, params, grads, bufs, sizes, block_map, lr, momentum,
+                       weight_decay, first_step, loss_scale, found_inf);
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(float* const* params, const float* const* grads, float* const* m1, float* const* m2,
                                                          const long long* sizes, const int* block_map, float lr, float b1, float b2,
-                                                         float eps, float wd, float bc1, float bc2) {
+                                                         float omb1, float omb2, float eps, float wd, float bc1, float bc2,
+                                                         const float* __restrict__ loss_scale, const float* __restrict__ found_inf) {
+    if (found_inf != nullptr && found_inf[0] != 0.f) return;
+    const float inv_scale = loss_scale != nullptr ? 1.f / loss_scale[0] : 1.f;
     const int ti = block_map[2 * blockIdx.x], start = block_map[2 * blockIdx.x + 1];
     float* p = params[ti];
     const float* g = grads[ti];
@@ -867,9 +883,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(float* const* params, c
     for (int r = 0; r < R; ++r) {
         const long long i = start + threadIdx.x + r * 256;
         if (i < end) {
-            const float gi = gv[r] + wd * pv[r];
-            const float ai = b1 * av[r] + (1.f - b1) * gi;
-            const float vi = b2 * vv[r] + (1.f - b2) * gi * gi;
+            const float gi = gv[r] * inv_scale + wd * pv[r];
+            const float ai = b1 * av[r] + omb1 * gi;                 // omb = 1 - beta formed in double on the host, as torch forms it
+            const float vi = b2 * vv[r] + omb2 * gi * gi;
             a[i] = ai; v[i] = vi;
             const float denom = sqrtf(vi) / bc2s + eps;
             p[i] = pv[r] - step_size * ai / denom;
@@ -877,11 +893,64 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(float* const* params, c
     }
 }
 extern "C" int vs_adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
-                             const long long* sizes, const int* block_map, int n_blocks, float lr, float beta1, float beta2,
+                             const long long* sizes, const int* block_map, int n_blocks, float lr, double beta1, double beta2,
                              float eps, float weight_decay, int step, void* stream) {
+    return vs_adam_scaled_multi(params, grads, exp_avg, exp_avg_sq, sizes, block_map, n_blocks, lr, beta1, beta2, eps, weight_decay, step, nullptr, nullptr, stream);
+}
+extern "C" int vs_adam_scaled_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                    const long long* sizes, const int* block_map, int n_blocks, float lr, double beta1, double beta2,
+                                    float eps, float weight_decay, int step, const float* loss_scale, const float* found_inf, void* stream) {
     if (!params || !grads || !exp_avg || !exp_avg_sq || !sizes || !block_map || n_blocks <= 0 || step < 1) return VS_EINVAL;
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes, block_map, lr, beta1, beta2, eps, weight_decay, bc1, bc2);
+    // betas arrive as doubles (python floats): 1 - beta and the bias corrections are formed in double, as torch.optim.Adam forms them
+    const float bc1 = (float)(1.0 - pow(beta1, (double)step)), bc2 = (float)(1.0 - pow(beta2, (double)step));
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, sizes, block_map, lr,
+                       (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), eps, weight_decay, bc1, bc2, loss_scale, found_inf);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// ---- dynamic loss scaling (fp16 storage: Dice gradients are O(1e-6), below fp16's normal range) ---------------------------------------
+__global__ __launch_bounds__(256) void grad_finite_multi_kernel(const float* const* grads, const long long* sizes, const int* block_map,
+                                                                float* __restrict__ found_inf) {
+    const int ti = block_map[2 * blockIdx.x], start = block_map[2 * blockIdx.x + 1];
+    const float* g = grads[ti];
+    const long long n = sizes[ti];
+    const long long end = (long long)start + MT_CHUNK < n ? (long long)start + MT_CHUNK : n;
+    constexpr int R = MT_CHUNK / 256;
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long i = start + threadIdx.x + r * 256;
+        const float v = i < end ? g[i] : 0.f;
+        bad |= !(fabsf(v) <= 3.402823466e+38f);         // inf or nan
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) found_inf[0] = 1.f;       // same value from every writer: a benign race
+}
+extern "C" int vs_grad_finite_multi(const float* const* grads, const long long* sizes, const int* block_map, int n_blocks,
+                                    float* found_inf, void* stream) {
+    if (!grads || !sizes || !block_map || n_blocks <= 0 || !found_inf) return VS_EINVAL;
+    hipLaunchKernelGGL(grad_finite_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, grads, sizes, block_map, found_inf);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+__global__ void loss_scale_update_kernel(float* scale, int* growth_tracker, float* found_inf, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (found_inf[0] != 0.f) {
+        scale[0] *= backoff;
+        growth_tracker[0] = 0;
+    } else {
+        const int t = growth_tracker[0] + 1;
+        if (t >= interval) { scale[0] *= growth; growth_tracker[0] = 0; }
+        else growth_tracker[0] = t;
+    }
+    found_inf[0] = 0.f;
+}
+extern "C" int vs_loss_scale_update(float* scale, int* growth_tracker, float* found_inf, float growth_factor, float backoff_factor,
+                                    int growth_interval, void* stream) {
+    if (!scale || !growth_tracker || !found_inf || growth_factor < 1.f || backoff_factor <= 0.f || backoff_factor > 1.f || growth_interval < 1)
+        return VS_EINVAL;
+    hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scale, growth_tracker, found_inf, growth_factor,
+                       backoff_factor, growth_interval);
     VS_CHECK_LAUNCH();
     return VS_OK;
 }

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ g,
 static int check_cl(const void* a, int n, long long voxels, int c, int dtype) {
     if (!a || n <= 0 || voxels <= 0) return VS_EINVAL;
     if (c <= 0 || c % 8 || c > NB_MAX_C || (256 % (c / 8)) ) return VS_ESHAPE;
-    if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
+    if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
     return VS_OK;
 }
 static int row_blocks(long long voxels, int c, int dtype, bool atomics = true) {
@@ -310,17 +310,16 @@ static int row_blocks(long long voxels, int c, int dtype, bool atomics = true) {
 }
 static size_t red_lds(int dtype, int ns) { return (size_t)256 * (dtype == VS_F32 ? 4 : 8) * ns * sizeof(double); }
 
-#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
-    if ((dtype) == VS_F32) { CALL_F32; } else { CALL_BF16; }
 
 extern "C" int vs_instnorm_stats(const void* x, double* stats, int n, long long voxels, int c, int dtype, void* stream) {
     int rc = check_cl(x, n, voxels, c, dtype);
     if (rc) return rc;
     if (!stats) return VS_EINVAL;
     dim3 grid(row_blocks(voxels, c, dtype), n);
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(stats_kernel<float>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const float*)x, stats, voxels, c),
-        hipLaunchKernelGGL(stats_kernel<unsigned short>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const unsigned short*)x, stats, voxels, c));
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(stats_kernel<T>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const T*)x, stats, voxels, c);
+    });
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -332,9 +331,10 @@ extern "C" int vs_instnorm_relu_fwd(const void* x, const double* x_stats, const 
     if (!out) return VS_EINVAL;
     dim3 grid(row_blocks(voxels, c, dtype, false), n);
     const double inv = 1.0 / (double)voxels;
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(in_relu_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, x_stats, (const float*)x2, x2_stats, (float*)out, voxels, c, inv, eps),
-        hipLaunchKernelGGL(in_relu_fwd_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, x_stats, (const unsigned short*)x2, x2_stats, (unsigned short*)out, voxels, c, inv, eps));
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(in_relu_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, x_stats, (const T*)x2, x2_stats, (T*)out, voxels, c, inv, eps);
+    });
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -346,9 +346,10 @@ extern "C" int vs_instnorm_relu_bwd_reduce(const void* g, const void* x, const d
     if (!g || !x_stats || !sums) return VS_EINVAL;
     dim3 grid(row_blocks(voxels, c, dtype), n);
     const double inv = 1.0 / (double)voxels;
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(in_relu_bwd_reduce_kernel<float>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const float*)g, (const float*)x, x_stats, sums, voxels, c, inv, eps),
-        hipLaunchKernelGGL(in_relu_bwd_reduce_kernel<unsigned short>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const unsigned short*)g, (const unsigned short*)x, x_stats, sums, voxels, c, inv, eps));
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(in_relu_bwd_reduce_kernel<T>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const T*)g, (const T*)x, x_stats, sums, voxels, c, inv, eps);
+    });
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -365,9 +366,10 @@ extern "C" int vs_instnorm_relu_bwd_apply(const void* g, const void* x, const do
     if (gb > gcap) gb = gcap;
     dim3 grid((unsigned)gb, n);
     const double inv = 1.0 / (double)voxels;
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(in_relu_bwd_apply_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)x, x_stats, sums, (float*)gx, voxels, c, inv, eps),
-        hipLaunchKernelGGL(in_relu_bwd_apply_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)g, (const unsigned short*)x, x_stats, sums, (unsigned short*)gx, voxels, c, inv, eps));
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(in_relu_bwd_apply_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g, (const T*)x, x_stats, sums, (T*)gx, voxels, c, inv, eps);
+    });
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -382,18 +384,20 @@ extern "C" int vs_instnorm_relu_bwd_pair(const void* g, const void* x1, const do
     a.x[0] = x1; a.x[1] = x2; a.xs[0] = x1_stats; a.xs[1] = x2_stats; a.sums[0] = sums1; a.sums[1] = sums2; a.gx[0] = gx1; a.gx[1] = gx2;
     const double inv = 1.0 / (double)voxels;
     dim3 grid(row_blocks(voxels, c, dtype), n, 2);
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(in_relu_bwd_reduce2_kernel<float>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const float*)g, a, voxels, c, inv, eps),
-        hipLaunchKernelGGL(in_relu_bwd_reduce2_kernel<unsigned short>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const unsigned short*)g, a, voxels, c, inv, eps));
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(in_relu_bwd_reduce2_kernel<T>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const T*)g, a, voxels, c, inv, eps);
+    });
     VS_CHECK_LAUNCH();
     const int rpi = 256 / (c / (dtype == VS_F32 ? 4 : 8));
     long long gb = (voxels + (long long)rpi * 4 - 1) / ((long long)rpi * 4);
     const long long gcap = 2048 / (2 * n) > 0 ? 2048 / (2 * n) : 1;
     if (gb > gcap) gb = gcap;
     dim3 grid2((unsigned)gb, n, 2);
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(in_relu_bwd_apply2_kernel<float>, grid2, dim3(256), 0, (hipStream_t)stream, (const float*)g, a, voxels, c, inv, eps),
-        hipLaunchKernelGGL(in_relu_bwd_apply2_kernel<unsigned short>, grid2, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)g, a, voxels, c, inv, eps));
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(in_relu_bwd_apply2_kernel<T>, grid2, dim3(256), 0, (hipStream_t)stream, (const T*)g, a, voxels, c, inv, eps);
+    });
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -405,9 +409,10 @@ extern "C" int vs_bias_grad(const void* g, float* db, long long rows, int c_ch, 
     hipError_t e = vs_zero_async(db, sizeof(float) * c_real, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     dim3 grid(row_blocks(rows, c_ch, dtype));
-    DISPATCH_T(dtype,
-        hipLaunchKernelGGL(bias_grad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)g, db, rows, c_ch, c_real),
-        hipLaunchKernelGGL(bias_grad_kernel<unsigned short>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned short*)g, db, rows, c_ch, c_real));
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(bias_grad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g, db, rows, c_ch, c_real);
+    });
     VS_CHECK_LAUNCH();
     return VS_OK;
 }

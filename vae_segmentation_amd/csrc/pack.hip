@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const vs_pack_de
     const vs_pack_desc d = descs[lo];
     const long long i = (long long)(blockIdx.x - d.first_block) * 256 + threadIdx.x;
     if (d.dtype == VS_F32) pack_one<float>(d.src, (float*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
-    else pack_one<unsigned short>(d.src, (unsigned short*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
+    else if (d.dtype == VS_BF16) pack_one<unsigned short>(d.src, (unsigned short*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
+    else pack_one<vs_half>(d.src, (vs_half*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
 }
 
 extern "C" int vs_pack_weight_multi(const vs_pack_desc* descs, int n_desc, int total_blocks, void* stream) {
@@ -101,7 +102,7 @@ extern "C" int vs_pack_weight(const float* src, void* dst, int d0, int d1, int n
                               void* stream) {
     if (!src || !dst || d0 <= 0 || d1 <= 0) return VS_EINVAL;
     if (!(c_pad == 8 || c_pad == 16 || (c_pad % 32 == 0 && c_pad > 0))) return VS_ESHAPE;
-    if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
+    if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
     int rows, kc, gemm_taps;
     if (form == VS_PACK_ROWS_D0) { rows = d0; kc = d1; gemm_taps = ntaps; }
     else if (form == VS_PACK_ROWS_D1_FLIP) { rows = d1; kc = d0; gemm_taps = ntaps; }
@@ -111,12 +112,10 @@ extern "C" int vs_pack_weight(const float* src, void* dst, int d0, int d1, int n
     if (!(ntaps == 27 || ntaps == 8)) return VS_ESHAPE;
     const long long total = packed_elems(rows, c_pad, gemm_taps, dtype);
     const int blocks = vs_ceil_div(total / (dtype == VS_F32 ? 4 : 8), 256);      // one thread per 16-byte fragment
-    if (dtype == VS_F32)
-        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (float*)dst,
-                           d0, d1, ntaps, c_pad, form, total);
-    else
-        hipLaunchKernelGGL(pack_weight_kernel<unsigned short>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src,
-                           (unsigned short*)dst, d0, d1, ntaps, c_pad, form, total);
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, d0, d1, ntaps, c_pad, form, total);
+    });
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -159,13 +158,11 @@ extern "C" int vs_pack_planar(const float* src, void* dst, int n, long long voxe
                               void* stream) {
     if (!src || !dst || n <= 0 || voxels <= 0 || c_src <= 0 || c_src > c_pad || c_pad % 8) return VS_EINVAL;
     const long long tv = (long long)n * voxels;
-    if (dtype == VS_F32)
-        hipLaunchKernelGGL(pack_planar_kernel<float>, dim3(vs_ceil_div(tv, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                           (float*)dst, voxels, c_src, c_pad, tv);
-    else if (dtype == VS_BF16)
-        hipLaunchKernelGGL(pack_planar_kernel<unsigned short>, dim3(vs_ceil_div(tv, 256)), dim3(256), 0,
-                           (hipStream_t)stream, src, (unsigned short*)dst, voxels, c_src, c_pad, tv);
-    else return VS_EDTYPE;
+    if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(pack_planar_kernel<T>, dim3(vs_ceil_div(tv, 256)), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, voxels, c_src, c_pad, tv);
+    });
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -174,13 +171,11 @@ extern "C" int vs_unpack_planar(const void* src, float* dst, int n, long long vo
                                 void* stream) {
     if (!src || !dst || n <= 0 || voxels <= 0 || c_dst <= 0 || c_dst > c_pad || c_pad % 8) return VS_EINVAL;
     const long long tv = (long long)n * voxels;
-    if (dtype == VS_F32)
-        hipLaunchKernelGGL(unpack_planar_kernel<float>, dim3(vs_ceil_div(tv, 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)src, dst, voxels, c_dst, c_pad, tv);
-    else if (dtype == VS_BF16)
-        hipLaunchKernelGGL(unpack_planar_kernel<unsigned short>, dim3(vs_ceil_div(tv, 256)), dim3(256), 0,
-                           (hipStream_t)stream, (const unsigned short*)src, dst, voxels, c_dst, c_pad, tv);
-    else return VS_EDTYPE;
+    if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(unpack_planar_kernel<T>, dim3(vs_ceil_div(tv, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)src, dst, voxels, c_dst, c_pad, tv);
+    });
     VS_CHECK_LAUNCH();
     return VS_OK;
 }

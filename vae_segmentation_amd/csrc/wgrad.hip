@@ -200,12 +200,12 @@ __global__ __launch_bounds__(256) void g3_kernel(const G3Params p) { g3_body<T, 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-__device__ __forceinline__ bf16x8 tr_pair(const char* s_base, int off0, int off1) {
+__device__ __forceinline__ u32x4 tr_pair(const char* s_base, int off0, int off1) {       // eight 16-bit k-values of one row / column
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s_base + off0));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s_base + off1));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(u32x4, v);
 }
 
 #define G3B_LDS_P (4 * G3_MAXN * 16 * 4)
@@ -214,7 +214,8 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* s_base, int off0, int off1
 // Tile t+ksplit's P and Q fragments are requested (bounds-checked buffer loads: out-of-volume fragments read as zero,
 // no branches) right after tile t went to LDS, so their latency is covered by tile t's MFMA phase; the lazy operands'
 // normalise+ReLU runs as packed fma / packed max (common.h act8).
-template <int CB, int KIND>
+// T: unsigned short (bf16 bits) or vs_half (fp16) — the transposing LDS read moves 16-bit words, whatever they encode
+template <typename T, int CB, int KIND>
 __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const int ks) {
     using GEO = G3Geo<CB, KIND>;
     constexpr int NTAPS = GEO::NTAPS, NCB = GEO::NCB, QY = GEO::QY, QX = GEO::QX, QV = GEO::QV;
@@ -298,7 +299,7 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         for (int b = 0; b < 2; ++b) {
             u32x4 v = pv[b];
             if (p_stats) {
-                const u32x4 a = act8<unsigned short>(v, sc, sh);
+                const u32x4 a = act8<T>(v, sc, sh);
                 const bool ok = (okbits >> b) & 1u;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
@@ -316,7 +317,7 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         for (int b = 0; b < NITQ; ++b) {
             u32x4 v = qv[b];
             if (q_stats) {
-                const u32x4 a = act8<unsigned short>(v, sc, sh);
+                const u32x4 a = act8<T>(v, sc, sh);
                 const bool ok = (okbits >> (2 + b)) & 1u;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
@@ -366,7 +367,7 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         for (int s = 0; s < 2; ++s) {
             const int xr = 4 * g + q4;                                   // this lane's tr-read row: voxel x
             const int pa0 = (((wave * 4 + 2 * s) * 16 + xr) * 32) + p4 * 8;
-            const bf16x8 a = tr_pair(s_p, pa0, pa0 + 16 * 32);
+            const u32x4 a = tr_pair(s_p, pa0, pa0 + 16 * 32);
             int qb0, qb1;
             if (KIND == G3_K3) {
                 qb0 = ((wave * QY + 2 * s) * QX + xr) * QROW;
@@ -377,8 +378,8 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
             }
 #pragma unroll
             for (int k = 0; k < NCB; ++k) {
-                const bf16x8 b = tr_pair(s_q, qb0 + qoff[k], qb1 + qoff[k]);
-                acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[k], 0, 0, 0);
+                const u32x4 b = tr_pair(s_q, qb0 + qoff[k], qb1 + qoff[k]);
+                acc[k] = mfma16(a, b, acc[k], (T*)nullptr);
             }
         }
     }
@@ -387,8 +388,8 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
     g3_finish<NCB>(acc, (float*)s_p, p.ws + (size_t)ks * slab_elems + ((size_t)bx * NCB) * 256, wave, col, g);
 }
 
-template <int CB, int KIND>
-__global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) { g3b_body<CB, KIND>(p, blockIdx.x, blockIdx.y); }
+template <int CB, int KIND, typename T = unsigned short>
+__global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) { g3b_body<T, CB, KIND>(p, blockIdx.x, blockIdx.y); }
 
 // Grouped launch: the weight gradients of up to G3_GROUP_MAX layers of one (CB, KIND) instantiation in ONE grid.  Weight
 // gradients are leaves of backward, so the host defers them to the end of the pass and issues them together: the small
@@ -401,7 +402,7 @@ struct G3Group {
     int n;
 };
 
-template <int CB, int KIND>
+template <int CB, int KIND, typename T = unsigned short>
 __global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
     const int b = blockIdx.x;
     int l = 0;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
     const int local = b - grp.wg_start[l];
     const int pairs = p.mbn * p.cbn;
     const int ks = local / pairs;
-    g3b_body<CB, KIND>(p, local - ks * pairs, ks);
+    g3b_body<T, CB, KIND>(p, local - ks * pairs, ks);
 }
 
 // Sum the partial slabs (fixed order, fp64) into the reference's [m][c][tap] layout.  A block = 64 consecutive slab
@@ -486,11 +487,11 @@ extern "C" size_t vs_conv_wgrad_workspace_bytes(int n, int dp, int hp, int wp, i
     return (size_t)ksplit * mbn * cbn * ncb * 256 * 4;
 }
 
-template <int CB, int KIND>
+template <typename T, int CB, int KIND>
 static int g3b_run(const G3Params& p, float* dw, int m_real, int c_real, hipStream_t s) {
     using GEO = G3Geo<CB, KIND>;
     constexpr size_t lds = G3B_LDS_Q + (size_t)GEO::QV * CB * 2;
-    auto kern = g3b_kernel<CB, KIND>;
+    auto kern = g3b_kernel<CB, KIND, T>;
     if (lds > 64 * 1024) {
         static const hipError_t attr_err =
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -531,7 +532,7 @@ extern "C" int vs_conv_wgrad(const void* P, const double* p_stats, const void* Q
     if (n <= 0 || n > G3_MAXN || dp <= 0 || hp <= 0 || wp <= 0) return VS_ESHAPE;
     if (m_ch % 8 || c_ch % 8 || m_real > m_ch || c_real > c_ch || m_real <= 0 || c_real <= 0) return VS_ESHAPE;
     if (kind != VS_CONV_K3 && kind != VS_CONV_K2S2) return VS_EINVAL;
-    if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
+    if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
     G3Params p{};
     int cbsz, ncb;
     g3_plan(n, dp, hp, wp, m_ch, c_ch, kind, cbsz, p.mbn, p.cbn, ncb, p.tiles_per_sample, p.tyn, p.txn, p.ksplit, dtype == VS_F32);
@@ -554,8 +555,12 @@ extern "C" int vs_conv_wgrad(const void* P, const double* p_stats, const void* Q
 #undef G3_GO
     // g3b_kernel addresses P and Q with signed 32-bit byte offsets
     if ((long long)n * dp * hp * wp * m_ch * 2 >= 2147483648ll || (long long)n * p.Dq * p.Hq * p.Wq * c_ch * 2 >= 2147483648ll) return VS_ESHAPE;
-    if (kind == VS_CONV_K3) return cbsz == 16 ? g3b_run<16, G3_K3>(p, dw, m_real, c_real, st) : g3b_run<8, G3_K3>(p, dw, m_real, c_real, st);
-    return cbsz == 16 ? g3b_run<16, G3_K2S2>(p, dw, m_real, c_real, st) : g3b_run<8, G3_K2S2>(p, dw, m_real, c_real, st);
+#define G3B_GO(T) \
+    if (kind == VS_CONV_K3) return cbsz == 16 ? g3b_run<T, 16, G3_K3>(p, dw, m_real, c_real, st) : g3b_run<T, 8, G3_K3>(p, dw, m_real, c_real, st); \
+    return cbsz == 16 ? g3b_run<T, 16, G3_K2S2>(p, dw, m_real, c_real, st) : g3b_run<T, 8, G3_K2S2>(p, dw, m_real, c_real, st);
+    if (dtype == VS_BF16) { G3B_GO(unsigned short) }
+    G3B_GO(vs_half)
+#undef G3B_GO
 }
 
 
@@ -662,7 +667,7 @@ __global__ __launch_bounds__(64 * G3_RED_ROWS) void g3_reduce_group_kernel(const
 
 // Bias-gradient partials of several layers in one launch (bf16 rows of c_ch channels): block lb of a layer sums rows
 // lb*rpi + fy + i*nblk*rpi and writes one double per channel; the grouped reduce adds the blocks in a fixed order.
-struct G3BiasDesc { const unsigned short* g; double* part; long long rows; int c_ch, c_real, nblk, pad_; };
+struct G3BiasDesc { const void* g; double* part; long long rows; int c_ch, c_real, nblk, pad_; };
 #define G3_BIAS_MAX 16
 struct G3BiasGroup {
     G3BiasDesc d[G3_BIAS_MAX];
@@ -670,6 +675,7 @@ struct G3BiasGroup {
     int n;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void bias_partial_group_kernel(const G3BiasGroup grp) {
     __shared__ float s_red[256 * 8];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -689,12 +695,12 @@ __global__ __launch_bounds__(256) void bias_partial_group_kernel(const G3BiasGro
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const long long vv = v + u * vstep;
-            q[u] = vv < d.rows ? *(const u32x4*)(d.g + vv * d.c_ch + fx * 8) : u32x4{0u, 0u, 0u, 0u};
+            q[u] = vv < d.rows ? *(const u32x4*)((const T*)d.g + vv * d.c_ch + fx * 8) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             float f[8];
-            frag_unpack(q[u], f, (unsigned short*)nullptr);
+            frag_unpack(q[u], f, (T*)nullptr);
 #pragma unroll
             for (int j = 0; j < 8; ++j) part[j] += f[j];
         }
@@ -794,11 +800,11 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
     return VS_OK;
 }
 
-template <int CB, int KIND>
+template <typename T, int CB, int KIND>
 static int g3b_group_run(const G3Group& grp, hipStream_t s) {
     using GEO = G3Geo<CB, KIND>;
     constexpr size_t lds = G3B_LDS_Q + (size_t)GEO::QV * CB * 2;
-    auto kern = g3b_group_kernel<CB, KIND>;
+    auto kern = g3b_group_kernel<CB, KIND, T>;
     if (lds > 64 * 1024) {
         static const hipError_t attr_err =
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -826,7 +832,8 @@ extern "C" size_t vs_conv_wgrad_multi_workspace_bytes(const vs_wgrad_desc* descs
 extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
                                    float eps, void* stream) {
     if (!descs || count <= 0 || !workspace) return VS_EINVAL;
-    if (dtype != VS_F32 && dtype != VS_BF16) return VS_EDTYPE;
+    if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
+    const bool f16 = dtype == VS_F16;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VS_F32) {
         // parity mode is not launch-bound: the per-layer kernels, one after the other on the same stream
@@ -871,8 +878,13 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
             }
             if (wg >= 2147483647ll) return VS_ESHAPE;
             for (int j = grp.n; j <= G3_GROUP_MAX; ++j) grp.wg_start[j] = (int)wg;
-            if (kind == VS_CONV_K3) rc = cbsz == 16 ? g3b_group_run<16, G3_K3>(grp, st) : g3b_group_run<8, G3_K3>(grp, st);
-            else rc = cbsz == 16 ? g3b_group_run<16, G3_K2S2>(grp, st) : g3b_group_run<8, G3_K2S2>(grp, st);
+            if (f16) {
+                if (kind == VS_CONV_K3) rc = cbsz == 16 ? g3b_group_run<vs_half, 16, G3_K3>(grp, st) : g3b_group_run<vs_half, 8, G3_K3>(grp, st);
+                else rc = cbsz == 16 ? g3b_group_run<vs_half, 16, G3_K2S2>(grp, st) : g3b_group_run<vs_half, 8, G3_K2S2>(grp, st);
+            } else {
+                if (kind == VS_CONV_K3) rc = cbsz == 16 ? g3b_group_run<unsigned short, 16, G3_K3>(grp, st) : g3b_group_run<unsigned short, 8, G3_K3>(grp, st);
+                else rc = cbsz == 16 ? g3b_group_run<unsigned short, 16, G3_K2S2>(grp, st) : g3b_group_run<unsigned short, 8, G3_K2S2>(grp, st);
+            }
             if (rc) return rc;
         }
     }
@@ -887,13 +899,14 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
             for (int j = 0; j < grp.n; ++j) {
                 const int i = idx[at + j];
                 const vs_wgrad_desc& d = descs[i];
-                grp.d[j] = G3BiasDesc{(const unsigned short*)d.bias_g, (double*)(ws + plan.layers[i].bias_off), d.bias_rows, d.bias_c_ch,
+                grp.d[j] = G3BiasDesc{d.bias_g, (double*)(ws + plan.layers[i].bias_off), d.bias_rows, d.bias_c_ch,
                                       d.bias_c_real, plan.layers[i].bias_nblk, 0};
                 grp.blk_start[j] = blk;
                 blk += plan.layers[i].bias_nblk;
             }
             for (int j = grp.n; j <= G3_BIAS_MAX; ++j) grp.blk_start[j] = blk;
-            hipLaunchKernelGGL(bias_partial_group_kernel, dim3(blk), dim3(256), 0, st, grp);
+            if (f16) hipLaunchKernelGGL(bias_partial_group_kernel<vs_half>, dim3(blk), dim3(256), 0, st, grp);
+            else hipLaunchKernelGGL(bias_partial_group_kernel<unsigned short>, dim3(blk), dim3(256), 0, st, grp);
             VS_CHECK_LAUNCH();
         }
     }

@@ -17,6 +17,8 @@ Layout and overlap (MI355X: xGMI is point-to-point, the 9.1 MB exchange is laten
     first (ops.set_wgrad_split), their all-reduce starts on a communication stream, and the bucket-1 weight-gradient kernels
     — about half of the step's weight-gradient time — run underneath it; bucket 1 (a few hundred KB) follows.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -41,6 +43,8 @@ class FlatGradSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         dev = self.params[0].device
         self.direct = bool(direct) and dev.type == "cuda"
+        if os.environ.get("VS_DDP_SPLIT", "1") == "0":          # measurement aid: one bucket, one phase
+            split_numel = 0
         big = [p for p in self.params if p.numel() >= split_numel] if self.direct else list(self.params)
         small = [p for p in self.params if p.numel() < split_numel] if self.direct else []
         order = big + small
@@ -56,6 +60,7 @@ class FlatGradSync:
         self._first_ids = {id(p) for p in big}
         self._tab, self._tab0 = _Tables(), _Tables()
         self._comm = torch.cuda.Stream() if dev.type == "cuda" else None
+        self._own_stream = os.environ.get("VS_DDP_COMM_STREAM", "1") != "0"      # measurement aid: 0 = collectives on the launching stream
         self._avg = True
         if self.direct:
             from . import ops
@@ -113,8 +118,9 @@ class FlatGradSync:
             dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
             b.mul_(1.0 / self.world)
             return
-        self._comm.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._comm):
+        if self._own_stream:
+            self._comm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._comm if self._own_stream else torch.cuda.current_stream()):
             if self._avg and dist.get_backend(self.group) == "nccl":
                 try:
                     dist.all_reduce(b, op=dist.ReduceOp.AVG, group=self.group)   # RCCL averages in the reduction itself
@@ -123,10 +129,10 @@ class FlatGradSync:
                     self._avg = False
             dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
             if self.world > 1:
-                check(lib.vs_scale_copy(b.data_ptr(), b.data_ptr(), b.numel(), 1.0 / self.world, self._comm.cuda_stream), "scale_copy")
+                check(lib.vs_scale_copy(b.data_ptr(), b.data_ptr(), b.numel(), 1.0 / self.world, torch.cuda.current_stream().cuda_stream), "scale_copy")
 
     def wait(self):
-        if self._comm is not None:
+        if self._comm is not None and self._own_stream:
             torch.cuda.current_stream().wait_stream(self._comm)
 
     def __call__(self, grads=None):

@@ -20,16 +20,16 @@ _DEFAULT_DTYPE = torch.float32
 
 
 def set_default_kernel_dtype(dtype):
-    """fp32 (parity mode, exact-f32 MFMA) or bf16 (throughput mode, fp32 accumulate)."""
+    """fp32 (parity mode, exact-f32 MFMA), bf16 or fp16 (throughput modes, fp32 accumulate; fp16 needs optim.LossScaler)."""
     global _DEFAULT_DTYPE
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError("kernel dtype must be torch.float32 or torch.bfloat16")
+    if dtype not in ops.KERNEL_DTYPES:
+        raise TypeError("kernel dtype must be torch.float32, torch.bfloat16 or torch.float16")
     _DEFAULT_DTYPE = dtype
 
 
 def set_kernel_dtype(module, dtype):
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError("kernel dtype must be torch.float32 or torch.bfloat16")
+    if dtype not in ops.KERNEL_DTYPES:
+        raise TypeError("kernel dtype must be torch.float32, torch.bfloat16 or torch.float16")
     for m in module.modules():
         if hasattr(m, "kernel_dtype"):
             m.kernel_dtype = dtype

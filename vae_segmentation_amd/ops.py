@@ -58,15 +58,16 @@ def _pick_mt(rows16, tiles):
 
 def _k3_kid(tname, ck, mt, sums=False, geom=None, m=None, lazy=False):
     """kernel instantiation name of a 3x3x3 launch (mirrors g1_dispatch_k3_* / k3b_use_tall in csrc; rocprof prints the same
-    string).  geom = (n, d, h, w) of the convolution's grid, m = stored output channels."""
+    string).  geom = (n, d, h, w) of the convolution's grid, m = stored output channels.  The 16-bit kernels carry their storage
+    type as the LAST template argument."""
     if tname == "float":
         return "k3_kernel<float,%d,%d,0>" % (ck, mt)
     hs = "true" if (lazy and not sums) else "false"
     if ck == 8 and m == 8:
-        return "k3t_kernel<0,%s,8,%s>" % ("true" if sums else "false", hs)
+        return "k3t_kernel<0,%s,8,%s,%s>" % ("true" if sums else "false", hs, tname)
     if ck == 32 and geom is not None and (geom[1] + 2) * (geom[2] + 2) * (geom[3] + 2) <= 512 and os.environ.get("VS_K3_SMALL", "") != "0":
         tv = (geom[1] + 2) * (geom[2] + 2) * (geom[3] + 2)
-        return "k3s_kernel<%s,%d,%s>" % ("true" if sums else "false", 128 if tv <= 128 else 512, hs)
+        return "k3s_kernel<%s,%d,%s,%s>" % ("true" if sums else "false", 128 if tv <= 128 else 512, hs, tname)
     yt = 4
     if geom is not None and ck < 32 and mt == 16 and os.environ.get("VS_K3_TALL", "") != "0":
         n, d, h, w = geom
@@ -74,7 +75,7 @@ def _k3_kid(tname, ck, mt, sums=False, geom=None, m=None, lazy=False):
         tall = n * ((d + 3) // 4) * ((h + 7) // 8) * ((w + 15) // 16)
         if os.environ.get("VS_K3_TALL", "") == "1" or (tall >= 256 and tiles <= 2048):
             yt = 8
-    return "k3b_kernel<%d,%d,0,%s,%d,%s>" % (ck, min(mt, 32), "true" if sums else "false", yt, hs)
+    return "k3b_kernel<%d,%d,0,%s,%d,%s,%s>" % (ck, min(mt, 32), "true" if sums else "false", yt, hs, tname)
 
 
 PROFILE_PRIME_US = 80
@@ -105,6 +106,11 @@ class _timed:
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+def _tname(t):
+    """the storage type as it appears in the profiler's kernel names"""
+    return {torch.float32: "float", torch.bfloat16: "unsigned short", torch.float16: "_Float16"}[t.dtype]
 
 
 def vs_dtype(t):
@@ -419,7 +425,7 @@ def conv_gather(x, xs, wp, bias, m_out, kind, want_stats, real_channels=None):
         else:
             tiles = n * ((y.numel() // (n * m_out) + 255) // 256)
         rows16 = (m_out + 15) // 16 * 16
-        tname = "float" if x.dtype == torch.float32 else "unsigned short"
+        tname = _tname(x)
         if kind == VS_CONV_K3:
             kid = _k3_kid(tname, ck, _pick_mt(rows16, tiles), geom=(n, d, h, w), m=m_out, lazy=xs is not None)
         else:
@@ -442,7 +448,7 @@ def conv_scatter(x, xs, wp, bias, m_out):
     if PROFILE is not None:
         tiles = n * ((d * h * w + 255) // 256)
         rows16 = (8 * m_out + 15) // 16 * 16
-        kid = "g1_kernel<%s,%d,2,%d,2>" % ("float" if x.dtype == torch.float32 else "unsigned short", min(c, 32), _pick_mt(rows16, tiles))
+        kid = "g1_kernel<%s,%d,2,%d,2>" % (_tname(x), min(c, 32), _pick_mt(rows16, tiles))
         nb = (x.numel() + y.numel()) * _esize(x) + 8 * c * m_out * _esize(x)
         fl = 2.0 * (x.numel() // c) * 8 * c * m_out
     with _timed(kid, nb, fl, "x%s->m%d" % (tuple(x.shape), m_out)):
@@ -464,7 +470,7 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
         kid = nb = fl = None
         if PROFILE is not None:
             tiles = gn * ((gd * gh * gw + 255) // 256)
-            kid = "g1_kernel<%s,%d,2,%d,2>" % ("float" if x.dtype == torch.float32 else "unsigned short", min(gc, 32),
+            kid = "g1_kernel<%s,%d,2,%d,2>" % (_tname(x), min(gc, 32),
                                                _pick_mt((8 * c + 15) // 16 * 16, tiles))
             nb = (gy.numel() + 2 * g.numel()) * _esize(x) + 8 * gc * c * _esize(x)
             fl = 2.0 * (gy.numel() // gc) * 8 * gc * c
@@ -479,7 +485,7 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
                 tiles = gn * ((gd + 3) // 4) * ((gh + 3) // 4) * ((gw + 15) // 16)
             else:
                 tiles = n * ((g.numel() // (n * c) + 255) // 256)
-            tname = "float" if x.dtype == torch.float32 else "unsigned short"
+            tname = _tname(x)
             if kind == VS_CONV_K3:
                 kid = _k3_kid(tname, min(gc, 32), _pick_mt((c + 15) // 16 * 16, tiles), sums=True, geom=(gn, gd, gh, gw), m=c)
             else:
@@ -493,7 +499,7 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
             check(lib.vs_conv_gather_bwd_data(gy.data_ptr(), wpb.data_ptr(), g.data_ptr(), x.data_ptr(), xs.data_ptr(),
                                               sums.data_ptr(), gn, gd, gh, gw, gc, c, kind, dt, EPS_IN, _stream()), "conv_gather_bwd_data")
     voxels = x.numel() // (n * c)
-    tname = "float" if x.dtype == torch.float32 else "unsigned short"
+    tname = _tname(x)
     with _timed("in_relu_bwd_apply_kernel<%s>" % tname, 3 * x.numel() * _esize(x), 6.0 * x.numel(), str(tuple(x.shape))):
         check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), g.data_ptr(), n, voxels,
                                              c, dt, EPS_IN, _stream()), "instnorm_relu_bwd_apply")
@@ -697,7 +703,7 @@ def in_relu_bwd(g, x, xs, inplace=True):
     voxels = x.numel() // (n * c)
     sums = _new_stats(n, c, x.device)
     dt = vs_dtype(x)
-    tname = "float" if x.dtype == torch.float32 else "unsigned short"
+    tname = _tname(x)
     with _timed("in_relu_bwd_reduce_kernel<%s>" % tname, 2 * x.numel() * _esize(x), 4.0 * x.numel(), str(tuple(x.shape))):
         check(lib.vs_instnorm_relu_bwd_reduce(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), n, voxels, c, dt,
                                               EPS_IN, _stream()), "instnorm_relu_bwd_reduce")
@@ -806,8 +812,8 @@ class ConvK3SoftmaxCL(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, xs, weight, bias, drop_p=0.0, drop_seed=0):
         _require_cuda(x, weight)
-        if weight.shape[0] != 2 or x.dtype != torch.bfloat16:
-            raise NotImplementedError("fused out_block+softmax with a channels-last copy: n_class == 2, bf16")
+        if weight.shape[0] != 2 or x.dtype == torch.float32:
+            raise NotImplementedError("fused out_block+softmax with a channels-last copy: n_class == 2, 16-bit storage")
         n, d, h, w, c = x.shape
         wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, c, x.dtype)
         prob = torch.empty((n, 2, d, h, w), dtype=torch.float32, device=x.device)
@@ -850,7 +856,7 @@ class ConvK3SoftmaxCL(torch.autograd.Function):
 def out_block_softmax(x, xs, weight, bias, drop_p=0.0, drop_seed=0):
     """out_block + softmax -> planar fp32 probabilities; in bf16 mode the tensor carries its channels-last copy as `_vs_cl`, which a
     network that takes it as input (VAE / Joint) uses instead of re-packing it (set VS_SOFTMAX_CL=0 to disable)."""
-    if x.dtype == torch.bfloat16 and weight.shape[0] == 2 and os.environ.get("VS_SOFTMAX_CL", "1") != "0":
+    if x.dtype != torch.float32 and weight.shape[0] == 2 and os.environ.get("VS_SOFTMAX_CL", "1") != "0":
         prob, prob_cl = ConvK3SoftmaxCL.apply(x, xs, weight, bias, drop_p, drop_seed)
         prob._vs_cl = prob_cl
         return prob

@@ -39,6 +39,35 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class LossScaler:
+    """Dynamic loss scaling for fp16 storage (BASELINE configs[4]) with torch.cuda.amp.GradScaler's protocol, entirely on the device:
+    the scale, the overflow flag and the growth counter are device scalars, so a captured HIP graph follows them and nothing syncs.
+
+        loss.backward(gradient=scaler.seed)        # every gradient comes out `scale` times too large
+        optimizer.step(scaler=scaler)              # checks the gradients, divides by the scale, skips the step on inf / nan, updates the scale
+    """
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, device="cuda"):
+        self.scale = torch.full((1,), float(init_scale), dtype=torch.float32, device=device)
+        self.found_inf = torch.zeros(1, dtype=torch.float32, device=device)
+        self.tracker = torch.zeros(1, dtype=torch.int32, device=device)
+        self.cfg = (float(growth_factor), float(backoff_factor), int(growth_interval))
+        self._tab = _Tables()
+
+    @property
+    def seed(self):
+        """0-dim view of the scale: pass it as the upstream gradient of the (scalar) loss"""
+        return self.scale.view(())
+
+    def check(self, grads):
+        (gp, sizes, bm), nb = self._tab.get([grads], grads[0].device)
+        check(lib.vs_grad_finite_multi(gp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb, self.found_inf.data_ptr(), _stream()), "grad_finite_multi")
+
+    def update(self):
+        g, b, i = self.cfg
+        check(lib.vs_loss_scale_update(self.scale.data_ptr(), self.tracker.data_ptr(), self.found_inf.data_ptr(), g, b, i, _stream()), "loss_scale_update")
+
+
 class SGD(torch.optim.Optimizer):
     """torch.optim.SGD(lr, momentum, weight_decay) — dampening 0, no nesterov — as one kernel per group."""
 
@@ -47,13 +76,14 @@ class SGD(torch.optim.Optimizer):
         self._tables = {}
 
     @torch.no_grad()
-    def step_with(self, params, grads):
+    def step_with(self, params, grads, scaler=None):
         """step() with explicit gradient tensors (e.g. the views of a DDP flat bucket) instead of p.grad."""
-        return self.step(_override={id(p): g for p, g in zip(params, grads)})
+        return self.step(_override={id(p): g for p, g in zip(params, grads)}, scaler=scaler)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, _override=None):
+    def step(self, closure=None, grad_scale=1.0, _override=None, scaler=None):
         ops.join_side()
+        todo = []
         for gi, group in enumerate(self.param_groups):
             if _override is not None:
                 ps = [p for p in group["params"] if id(p) in _override]
@@ -76,9 +106,17 @@ class SGD(torch.optim.Optimizer):
                 bufs.append(st["momentum_buffer"])
             tab = self._tables.setdefault(gi, _Tables())
             (pp, gp, bp, sizes, bm), nb = tab.get([ps, grads, bufs], ps[0].device)
-            check(lib.vs_sgd_momentum_multi(pp.data_ptr(), gp.data_ptr(), bp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb,
-                                            float(group["lr"]) * float(grad_scale), float(group["momentum"]),
-                                            float(group["weight_decay"]), 0, _stream()), "sgd_momentum_multi")
+            todo.append((group, grads, pp, gp, bp, sizes, bm, nb))
+        if scaler is not None:
+            for t in todo:                                   # every group is checked before any group is updated
+                scaler.check(t[1])
+        sp, fp = (scaler.scale.data_ptr(), scaler.found_inf.data_ptr()) if scaler is not None else (None, None)
+        for group, grads, pp, gp, bp, sizes, bm, nb in todo:
+            check(lib.vs_sgd_momentum_scaled_multi(pp.data_ptr(), gp.data_ptr(), bp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb,
+                                                   float(group["lr"]) * float(grad_scale), float(group["momentum"]),
+                                                   float(group["weight_decay"]), 0, sp, fp, _stream()), "sgd_momentum_multi")
+        if scaler is not None:
+            scaler.update()
         ops.weights_changed()
         return None
 
@@ -91,13 +129,22 @@ class Adam(torch.optim.Optimizer):
         self._tables = {}
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step_with(self, params, grads, scaler=None):
+        return self.step(_override={id(p): g for p, g in zip(params, grads)}, scaler=scaler)
+
+    @torch.no_grad()
+    def step(self, closure=None, _override=None, scaler=None):
         ops.join_side()
+        todo = []
         for gi, group in enumerate(self.param_groups):
-            ps = [p for p in group["params"] if p.grad is not None]
+            if _override is not None:
+                ps = [p for p in group["params"] if id(p) in _override]
+                grads = [_override[id(p)] for p in ps]
+            else:
+                ps = [p for p in group["params"] if p.grad is not None]
+                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
             if not ps:
                 continue
-            grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in ps]
             m1, m2 = [], []
             for p in ps:
                 st = self.state[p]
@@ -111,10 +158,18 @@ class Adam(torch.optim.Optimizer):
             step = int(self.state[ps[0]]["step"])
             tab = self._tables.setdefault(gi, _Tables())
             (pp, gp, ap, vp, sizes, bm), nb = tab.get([ps, grads, m1, m2], ps[0].device)
+            todo.append((group, grads, pp, gp, ap, vp, sizes, bm, nb, step))
+        if scaler is not None:
+            for t in todo:
+                scaler.check(t[1])
+        sp, fp = (scaler.scale.data_ptr(), scaler.found_inf.data_ptr()) if scaler is not None else (None, None)
+        for group, grads, pp, gp, ap, vp, sizes, bm, nb, step in todo:
             b1, b2 = group["betas"]
-            check(lib.vs_adam_multi(pp.data_ptr(), gp.data_ptr(), ap.data_ptr(), vp.data_ptr(), sizes.data_ptr(), bm.data_ptr(),
-                                    nb, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                    float(group["weight_decay"]), step, _stream()), "adam_multi")
+            check(lib.vs_adam_scaled_multi(pp.data_ptr(), gp.data_ptr(), ap.data_ptr(), vp.data_ptr(), sizes.data_ptr(), bm.data_ptr(),
+                                           nb, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                           float(group["weight_decay"]), step, sp, fp, _stream()), "adam_multi")
+        if scaler is not None:
+            scaler.update()
         ops.weights_changed()
         return None
 

@@ -120,11 +120,13 @@ class GraphedStep:
     ``overlap``: issue the weight-gradient kernels on a side stream (a parallel branch of the graph).  Off by default: with the
     current kernels the serial graph is 1-2 % faster (3.87 vs 3.94 ms) — the branch's forks/joins and the contention for CUs cost
     more than the concurrency returns.
+    ``scaler``: an optim.LossScaler (fp16 storage) — backward is seeded with its device-resident scale, the optimiser unscales / skips.
     Models with dropout > 0 cannot be captured (ops.next_dropout_seed raises during capture): run them eagerly."""
 
-    def __init__(self, loss_fn, params, optimizer, grad_sync=None, warmup=2, overlap=False):
+    def __init__(self, loss_fn, params, optimizer, grad_sync=None, warmup=2, overlap=False, scaler=None):
         ops.set_overlap(overlap and os.environ.get("VS_OVERLAP", "1") != "0")       # VS_OVERLAP=0: measurement aid
         self.loss_fn, self.params, self.optimizer, self.grad_sync = loss_fn, list(params), optimizer, grad_sync
+        self.scaler = scaler                     # optim.LossScaler for fp16 storage: its scale is a device scalar the captured backward reads
         self.graph = self.graph2 = None
         self.loss = None
         self.aux = None
@@ -151,15 +153,19 @@ class GraphedStep:
         for p in self.params:
             p.grad = None
         self.loss, self.aux = self.loss_fn()
-        self.loss.backward()
+        if self.scaler is not None:
+            self.loss.backward(gradient=self.scaler.seed)
+        else:
+            self.loss.backward()
         if rest:
             ops.join_side()      # side-stream weight gradients (a parallel branch of the captured graph) / the second weight-gradient phase
 
     def step(self):
         self.graph.replay()
         s = self.grad_sync
+        kw = {} if self.scaler is None else {"scaler": self.scaler}
         if s is None:
-            self.optimizer.step()
+            self.optimizer.step(**kw)
             return self.loss
         if self.graph2 is not None:
             s.start(0)
@@ -170,7 +176,7 @@ class GraphedStep:
             s.gather(self.grads)
             s.start(0)
         s.wait()
-        self.optimizer.step_with(s.params, s.views)
+        self.optimizer.step_with(s.params, s.views, **kw)
         return self.loss
 
 
