@@ -85,7 +85,8 @@ __device__ __forceinline__ u32x4 frag_pack(const float (&v)[8], unsigned short*)
 __device__ __forceinline__ void frag_unpack(const u32x4& r, float (&v)[8], vs_half*) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const f16x2 h = __builtin_bit_cast(f16x2, r[i]);
+        const unsigned int w = r[i];             // a scalar copy first: __builtin_bit_cast applied to the vector ELEMENT r[i] was compiled as a
+        const f16x2 h = __builtin_bit_cast(f16x2, w);   // cast of the vector's first dword for every i (hipcc 7.2; seen in the ISA and on the GPU)
         v[2 * i] = (float)h[0];
         v[2 * i + 1] = (float)h[1];
     }
@@ -96,7 +97,8 @@ __device__ __forceinline__ u32x4 frag_pack(const float (&v)[8], vs_half*) {
     for (int i = 0; i < 4; ++i) {
         f16x2 h;
         h[0] = (vs_half)v[2 * i]; h[1] = (vs_half)v[2 * i + 1];
-        r[i] = __builtin_bit_cast(unsigned int, h);
+        const unsigned int w = __builtin_bit_cast(unsigned int, h);
+        r[i] = w;
     }
     return r;
 }

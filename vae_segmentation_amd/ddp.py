@@ -14,8 +14,10 @@ Layout and overlap (MI355X: xGMI is point-to-point, the 9.1 MB exchange is laten
   * the buffer is ordered in two buckets.  Bucket 0 holds the large tensors (>= ``split_numel`` elements: the 12^3 .. 3^3
     levels, 98 % of the bytes, whose weight gradients are cheap), bucket 1 the small ones (the 96^3 / 48^3 layers, whose
     weight gradients are the expensive ones, plus all biases).  At the end of backward the bucket-0 gradients are computed
-    first (ops.set_wgrad_split), their all-reduce starts on a communication stream, and the bucket-1 weight-gradient kernels
-    — about half of the step's weight-gradient time — run underneath it; bucket 1 (a few hundred KB) follows.
+    first (ops.set_wgrad_split), their all-reduce is started asynchronously (the process group's own RCCL stream), and the
+    bucket-1 weight-gradient kernels — about half of the step's weight-gradient time — run underneath it; bucket 1 (a few
+    hundred KB) follows.  Measured on one MI355X with one rank through RCCL (bench.py --force-dist, profiles/README.md):
+    +0.01 ms per step for a single bucket after the pass, +0.06 ms for the two-phase form (the second graph launch).
 """
 import os
 
@@ -59,8 +61,8 @@ class FlatGradSync:
         self.views = [slot[id(p)] for p in self.params]                 # aligned with self.params
         self._first_ids = {id(p) for p in big}
         self._tab, self._tab0 = _Tables(), _Tables()
-        self._comm = torch.cuda.Stream() if dev.type == "cuda" else None
-        self._own_stream = os.environ.get("VS_DDP_COMM_STREAM", "1") != "0"      # measurement aid: 0 = collectives on the launching stream
+        self._async = os.environ.get("VS_DDP_ASYNC", "1") != "0"          # measurement aid: 0 = blocking collectives
+        self._works = []
         self._avg = True
         if self.direct:
             from . import ops
@@ -110,30 +112,33 @@ class FlatGradSync:
                 v.copy_(g)
 
     def start(self, i):
-        """All-reduce bucket i on the communication stream, after everything issued so far on the current stream."""
+        """Start the all-reduce of bucket i, ordered after everything issued so far on the current stream, WITHOUT blocking that stream:
+        torch's RCCL process group runs collectives on its own stream (async_op=True), so kernels launched next — the bucket-1
+        weight gradients — run underneath it.  (A communication stream of our own was measured and dropped: its extra cross-stream
+        edges cost 0.14 ms per step on top of the collective's.)"""
         if self.world == 1 and not dist.is_initialized():
             return
         b = self.buckets[i]
-        if self._comm is None:                                       # CPU tensors (gloo tests)
+        if not b.is_cuda:                                            # CPU tensors (gloo tests)
             dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
             b.mul_(1.0 / self.world)
             return
-        if self._own_stream:
-            self._comm.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._comm if self._own_stream else torch.cuda.current_stream()):
-            if self._avg and dist.get_backend(self.group) == "nccl":
-                try:
-                    dist.all_reduce(b, op=dist.ReduceOp.AVG, group=self.group)   # RCCL averages in the reduction itself
-                    return
-                except (RuntimeError, ValueError):                               # a build without ncclAvg: sum, then scale
-                    self._avg = False
-            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
-            if self.world > 1:
-                check(lib.vs_scale_copy(b.data_ptr(), b.data_ptr(), b.numel(), 1.0 / self.world, torch.cuda.current_stream().cuda_stream), "scale_copy")
+        if self._avg and dist.get_backend(self.group) == "nccl":
+            try:
+                self._works.append((dist.all_reduce(b, op=dist.ReduceOp.AVG, group=self.group, async_op=self._async), None))   # RCCL averages in the reduction
+                return
+            except (RuntimeError, ValueError):                       # a build without ncclAvg: sum, then scale
+                self._avg = False
+        self._works.append((dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=self._async), b if self.world > 1 else None))
 
     def wait(self):
-        if self._comm is not None and self._own_stream:
-            torch.cuda.current_stream().wait_stream(self._comm)
+        """Make the current stream wait for the started collectives (and apply the 1/world scale where the collective only sums)."""
+        for work, b in self._works:
+            if work is not None:
+                work.wait()
+            if b is not None:
+                check(lib.vs_scale_copy(b.data_ptr(), b.data_ptr(), b.numel(), 1.0 / self.world, torch.cuda.current_stream().cuda_stream), "scale_copy")
+        self._works = []
 
     def __call__(self, grads=None):
         """Whole exchange after a backward pass.  grads: tensors aligned with self.params (default: p.grad).  Returns the
