@@ -295,7 +295,9 @@ def main():
             "config": {"workload": "configs[1]: %d^3 joint VAE+seg training step (joint_train), batch=%d/GPU, %s activations + fp32 accumulate, "
                                    "SGD momentum 0.9, VAE frozen, HIP-graph replay" % (a.side, BATCH, a.dtype),
                        "global_batch": world * BATCH, "parallelism": "dp%d" % world, "final_loss": final_loss,
-                       "grad_exchange": ("2-bucket RCCL all-reduce, bucket 0 under the full-resolution weight-gradient kernels"
+                       "grad_exchange": (("2-bucket RCCL all-reduce, bucket 0 under the full-resolution weight-gradient kernels"
+                                          if os.environ.get("VS_DDP_OVERLAP", "0") == "1" else
+                                          "one RCCL all-reduce of the flat gradient buffer (written in place by the weight-gradient kernels) after the pass")
                                          if use_dist else "none (1 rank)")},
             "roofline": step_roofline(a.dtype, ms_per_step / 1.0, families) if a.side == SIDE else None,
             "fp32_parity_mode": fp32_mode, "cpu_baseline": cpu,

@@ -1,7 +1,8 @@
 """GPU: the data-parallel exchange path (BASELINE configs[2]; replaces nn.DataParallel at main_source.py:354, main_target.py:436-438).
 
-  * one rank through RCCL (backend "nccl"): GraphedStep + FlatGradSync — gradients written straight into the flat bucket, the two
-    captured graphs, bucketed all-reduce on the communication stream — must reproduce the plain single-process step;
+  * one rank through RCCL (backend "nccl"): GraphedStep + FlatGradSync — gradients written straight into the flat bucket; the default
+    single all-reduce after the pass and the overlapped form (two captured graphs, bucket 0 under the remaining weight-gradient
+    kernels) — must reproduce the plain single-process step;
   * two ranks (gloo, sharing the one GPU of the box): the average of the per-rank micro-batch gradients must equal the gradient of
     the GLOBAL batch — checked against the same network on the global batch in one process, and against the CPU oracle run in fp64
     on the global batch (the fp64 yardstick of tests/golden_util.py, floor 2e-3) — and replicas must stay bit-identical over steps;
@@ -51,12 +52,16 @@ if rank == 1:
     with torch.no_grad():
         for p in seg.parameters(): p.add_(0.5)                 # replicas start different: the broadcast must fix that
 params = list(seg.parameters())
-sync = ddp.FlatGradSync(params)
+OVERLAP = os.environ["VS_TEST_OVERLAP"] == "1"
+sync = ddp.FlatGradSync(params, overlap=OVERLAP)
 sync.broadcast_parameters(0)
-assert len(sync.buckets) == 2 and sync.buckets[0].numel() > 10 * sync.buckets[1].numel()
 loss, _ = T.seg_train_losses(seg, img_g, lab_g, eps=1e-6)
 loss.backward()
-assert ops.pending_wgrads() > 0                               # second weight-gradient phase still queued (runs under bucket 0's all-reduce)
+if OVERLAP:
+    assert len(sync.buckets) == 2 and sync.buckets[0].numel() > 10 * sync.buckets[1].numel()
+    assert ops.pending_wgrads() > 0                           # second weight-gradient phase still queued (runs under bucket 0's all-reduce)
+else:
+    assert len(sync.buckets) == 1 and ops.pending_wgrads() == 0
 views = sync()
 assert ops.pending_wgrads() == 0
 torch.cuda.synchronize()
@@ -110,10 +115,10 @@ dist.barrier()
 seg2 = make()
 params2 = list(seg2.parameters())
 opt2 = optim.SGD(params2, lr=1e-2, momentum=0.9)
-sync2 = ddp.FlatGradSync(params2)
+sync2 = ddp.FlatGradSync(params2, overlap=OVERLAP)
 sync2.broadcast_parameters(0)
 gs = T.GraphedStep(lambda: T.seg_train_losses(seg2, img_g, lab_g, eps=1e-6), params2, opt2, grad_sync=sync2, warmup=1)
-assert gs.graph2 is not None
+assert (gs.graph2 is not None) == OVERLAP
 with torch.no_grad():                                          # the capture's warm-up moved nothing (no optimiser step), start is the fill
     pass
 for _ in range(3):
@@ -147,11 +152,11 @@ print("rank %%d ok" %% rank)
 """
 
 
-def _launch(tmp_path, world, backend, port):
+def _launch(tmp_path, world, backend, port, overlap=False):
     script = tmp_path / "ddp_worker.py"
     script.write_text(WORKER % {"repo": REPO})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), VS_TEST_BACKEND=backend,
-               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", VS_TEST_OVERLAP="1" if overlap else "0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
@@ -161,12 +166,14 @@ def _launch(tmp_path, world, backend, port):
     print("\n".join(line for o in outs for line in o.splitlines() if line.startswith("rank")))
 
 
-def test_one_rank_rccl_graphed_step_with_flat_grad_sync(tmp_path):
-    _launch(tmp_path, 1, "nccl", 29551)
+@pytest.mark.parametrize("overlap", [False, True])
+def test_one_rank_rccl_graphed_step_with_flat_grad_sync(tmp_path, overlap):
+    _launch(tmp_path, 1, "nccl", 29551 + 10 * overlap, overlap)
 
 
-def test_two_rank_average_equals_global_batch_gradient(tmp_path):
-    _launch(tmp_path, 2, "gloo", 29552)
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_average_equals_global_batch_gradient(tmp_path, overlap):
+    _launch(tmp_path, 2, "gloo", 29552 + 10 * overlap, overlap)
 
 
 def test_bench_spawns_its_own_ranks(tmp_path):

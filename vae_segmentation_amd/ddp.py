@@ -31,21 +31,28 @@ from .optim import _Tables
 class FlatGradSync:
     """Flat gradient buffer + bucketed all-reduce.  Use:
 
-        sync = FlatGradSync(params)                  # registers the gradient slots, switches ops to two-phase weight gradients
-        ... forward, backward (ends with the bucket-0 weight gradients) ...
-        views = sync()                               # start(0) -> remaining weight gradients -> start(1) -> wait
+        sync = FlatGradSync(params)                  # registers the gradient slots (overlap=True: and two-phase weight gradients)
+        ... forward, backward ...
+        views = sync()                               # all-reduce (overlap=True: start(0) -> remaining weight gradients -> start(1) -> wait)
         optimizer.step_with(sync.params, views)
 
     train.GraphedStep drives the same phases around two captured graphs.  ``direct=False`` keeps the classic form: gradients
     wherever autograd put them, one gather launch (vs_copy_scale_multi), one all-reduce."""
 
-    def __init__(self, params, process_group=None, direct=True, split_numel=8192):
+    def __init__(self, params, process_group=None, direct=True, split_numel=8192, overlap=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         dev = self.params[0].device
         self.direct = bool(direct) and dev.type == "cuda"
-        if os.environ.get("VS_DDP_SPLIT", "1") == "0":          # measurement aid: one bucket, one phase
+        # overlap=False (default): ONE bucket, all-reduced on the launching stream right after the pass — measured cheapest at this step
+        # size (one rank through RCCL on one MI355X: +0.01 ms per step, against +0.06 .. +0.2 ms for the two-phase overlapped forms,
+        # whose second graph launch and cross-stream edges cost more than the ~9 MB collective they hide; profiles/README.md).
+        # overlap=True / VS_DDP_OVERLAP=1: the two-bucket form described above.
+        if overlap is None:
+            overlap = os.environ.get("VS_DDP_OVERLAP", "0") == "1"
+        self.overlap = bool(overlap)
+        if not self.overlap:
             split_numel = 0
         big = [p for p in self.params if p.numel() >= split_numel] if self.direct else list(self.params)
         small = [p for p in self.params if p.numel() < split_numel] if self.direct else []
@@ -61,7 +68,7 @@ class FlatGradSync:
         self.views = [slot[id(p)] for p in self.params]                 # aligned with self.params
         self._first_ids = {id(p) for p in big}
         self._tab, self._tab0 = _Tables(), _Tables()
-        self._async = os.environ.get("VS_DDP_ASYNC", "1") != "0"          # measurement aid: 0 = blocking collectives
+        self._async = self.overlap
         self._works = []
         self._avg = True
         if self.direct:
