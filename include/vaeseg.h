@@ -161,6 +161,13 @@ int vs_instnorm_relu_bwd_reduce(const void* g, const void* x, const double* x_st
                                 int n, long long voxels, int c, int dtype, float eps, void* stream);
 int vs_instnorm_relu_bwd_apply(const void* g, const void* x, const double* x_stats, const double* sums,
                                void* gx, int n, long long voxels, int c, int dtype, float eps, void* stream);
+/* apply with a second gradient of the same raw tensor summed in: gx = round(apply(g)) + add — an activation that feeds both the next
+ * encoder level and a U-Net skip (joint_model.py:380,382) receives two gradients; autograd would add them with a kernel of its own. */
+int vs_instnorm_relu_bwd_apply_add(const void* g, const void* x, const double* x_stats, const double* sums, const void* add,
+                                   void* gx, int n, long long voxels, int c, int dtype, float eps, void* stream);
+/* p[0 .. bytes) = 0 (16-byte aligned, bytes a multiple of 16): the per-forward statistics arena (every (sum, sumsq) / IN-backward-sums
+ * buffer of a pass is carved from ONE zeroed allocation). */
+int vs_zero_fill(void* p, long long bytes, void* stream);
 /* The backward of the additive skip a = relu(instnorm(x1)) + relu(instnorm(x2)) (joint_model.py:380,382): one gradient g, both
  * operands' reduce in one launch and both applies in one (sums1 / sums2 ACCUMULATED: caller zeroes; gx1 / gx2 distinct from g). */
 int vs_instnorm_relu_bwd_pair(const void* g, const void* x1, const double* x1_stats, double* sums1, void* gx1,

@@ -1023,6 +1023,21 @@ extern "C" int vs_scale_copy(const float* src, float* dst, long long count, floa
     return VS_OK;
 }
 
+// ---- zero fill (statistics arenas): a kernel of this library, not a memset node (common.h: vs_zero_async) -------------------------
+__global__ __launch_bounds__(256) void zero_fill_kernel(u32x4* __restrict__ p, long long frags) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < frags; i += (long long)gridDim.x * 256) p[i] = u32x4{0u, 0u, 0u, 0u};
+}
+extern "C" int vs_zero_fill(void* p, long long bytes, void* stream) {
+    if (!p || bytes <= 0) return VS_EINVAL;
+    if (((uintptr_t)p & 15) || (bytes & 15)) return VS_EALIGN;
+    const long long frags = bytes / 16;
+    long long blocks = (frags + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (u32x4*)p, frags);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
 // ---- measurement aid: keep the queue busy for a given time (see include/vaeseg.h) -------------------------------------
 __global__ void spin_kernel(unsigned long long ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz

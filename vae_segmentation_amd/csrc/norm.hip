@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void in_relu_bwd_reduce2_kernel(const T* __res
 template <typename T>
 __device__ __forceinline__ void in_relu_bwd_apply_body(const T* __restrict__ g, const T* __restrict__ x, const double* xs,
                                                        const double* __restrict__ sums, T* __restrict__ gx,
-                                                       long long voxels, int c, double inv_count, float eps) {
+                                                       long long voxels, int c, double inv_count, float eps, const T* __restrict__ add = nullptr) {
     // Streaming pass, 3 tensors: a thread keeps UN (g, x) fragment pairs in flight and requests the next batch before it
     // works on the current one; the first batch is requested before the statistics tables are built, so the kernel's
     // start-up is one memory round trip, not two (most of its 58 launches per step are small and start-up bound).
@@ -201,7 +201,7 @@ __device__ __forceinline__ void in_relu_bwd_apply_body(const T* __restrict__ g, 
     const size_t sample = (size_t)n * voxels * c + it.fx * EPL;
     const long long stride = (long long)gridDim.x * it.rows_per_it;
     long long v = (long long)blockIdx.x * it.rows_per_it + it.fy;
-    u32x4 gq[UN], xq[UN];
+    u32x4 gq[UN], xq[UN], aq[UN];
     auto request = [&](long long v0) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -209,6 +209,7 @@ __device__ __forceinline__ void in_relu_bwd_apply_body(const T* __restrict__ g, 
             const size_t e = (act && vv < voxels) ? sample + vv * c : sample - it.fx * EPL;     // clamped lanes re-read voxel 0
             gq[u] = *(const u32x4*)(g + e);
             xq[u] = *(const u32x4*)(x + e);
+            if (add != nullptr) aq[u] = *(const u32x4*)(add + e);                               // uniform branch: a second gradient of x to sum in
         }
     };
     request(v);
@@ -226,9 +227,9 @@ __device__ __forceinline__ void in_relu_bwd_apply_body(const T* __restrict__ g, 
         m[j] = s_m[ch]; r[j] = s_r[ch]; a[j] = s_a[ch]; b[j] = s_b[ch];
     }
     for (; v < voxels; v += UN * stride) {
-        u32x4 gc[UN], xc[UN];
+        u32x4 gc[UN], xc[UN], ac[UN];
 #pragma unroll
-        for (int u = 0; u < UN; ++u) { gc[u] = gq[u]; xc[u] = xq[u]; }
+        for (int u = 0; u < UN; ++u) { gc[u] = gq[u]; xc[u] = xq[u]; if (add != nullptr) ac[u] = aq[u]; }
         request(v + UN * stride);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -243,6 +244,12 @@ __device__ __forceinline__ void in_relu_bwd_apply_body(const T* __restrict__ g, 
                 const float gm = xh > 0.f ? fg[j] : 0.f;
                 o[j] = r[j] * (gm - a[j] - xh * b[j]);
             }
+            if (add != nullptr) {
+                float fa[EPL];
+                frag_unpack(ac[u], fa, (T*)nullptr);
+#pragma unroll
+                for (int j = 0; j < EPL; ++j) o[j] = ET<T>::rnd(o[j]) + fa[j];      // what autograd's add of the two stored gradients gives
+            }
             *(u32x4*)(gx + sample + vv * c) = frag_pack(o, (T*)nullptr);
         }
     }
@@ -250,8 +257,8 @@ __device__ __forceinline__ void in_relu_bwd_apply_body(const T* __restrict__ g, 
 template <typename T>
 __global__ __launch_bounds__(256) void in_relu_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x, const double* xs,
                                                                 const double* __restrict__ sums, T* __restrict__ gx,
-                                                                long long voxels, int c, double inv_count, float eps) {
-    in_relu_bwd_apply_body<T>(g, x, xs, sums, gx, voxels, c, inv_count, eps);
+                                                                long long voxels, int c, double inv_count, float eps, const T* __restrict__ add) {
+    in_relu_bwd_apply_body<T>(g, x, xs, sums, gx, voxels, c, inv_count, eps, add);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void in_relu_bwd_apply2_kernel(const T* __restrict__ g, const InBwdPair a, long long voxels, int c,
@@ -356,6 +363,11 @@ extern "C" int vs_instnorm_relu_bwd_reduce(const void* g, const void* x, const d
 
 extern "C" int vs_instnorm_relu_bwd_apply(const void* g, const void* x, const double* x_stats, const double* sums,
                                           void* gx, int n, long long voxels, int c, int dtype, float eps, void* stream) {
+    return vs_instnorm_relu_bwd_apply_add(g, x, x_stats, sums, nullptr, gx, n, voxels, c, dtype, eps, stream);
+}
+
+extern "C" int vs_instnorm_relu_bwd_apply_add(const void* g, const void* x, const double* x_stats, const double* sums, const void* add,
+                                              void* gx, int n, long long voxels, int c, int dtype, float eps, void* stream) {
     int rc = check_cl(x, n, voxels, c, dtype);
     if (rc) return rc;
     if (!g || !x_stats || !sums || !gx) return VS_EINVAL;
@@ -368,7 +380,7 @@ extern "C" int vs_instnorm_relu_bwd_apply(const void* g, const void* x, const do
     const double inv = 1.0 / (double)voxels;
     dispatch_t(dtype, [&](auto* tag) {
         using T = TAG_T(tag);
-        hipLaunchKernelGGL(in_relu_bwd_apply_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g, (const T*)x, x_stats, sums, (T*)gx, voxels, c, inv, eps);
+        hipLaunchKernelGGL(in_relu_bwd_apply_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g, (const T*)x, x_stats, sums, (T*)gx, voxels, c, inv, eps, (const T*)add);
     });
     VS_CHECK_LAUNCH();
     return VS_OK;

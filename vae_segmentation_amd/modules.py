@@ -263,9 +263,11 @@ class Segmentation(nn.Module):
         x5 = self.down4(x4)
         u = _dropout(self.up2(x5), dropout)
         u = self.up3(u)
-        u = _dropout(Act(ops.Materialize.apply(u.raw, u.stats, x3.raw, x3.stats), None), dropout)
+        # skips (joint_model.py:380,382).  x3 / x2 also feed down3 / down2's strided conv: their skip gradient is parked for that conv's
+        # backward to sum in (ops._park_gradient) instead of an add launch of autograd's
+        u = _dropout(Act(ops.Materialize.apply(u.raw, u.stats, x3.raw, x3.stats, True), None), dropout)
         u = self.up4(u)
-        u = _dropout(Act(ops.Materialize.apply(u.raw, u.stats, x2.raw, x2.stats), None), dropout)
+        u = _dropout(Act(ops.Materialize.apply(u.raw, u.stats, x2.raw, x2.stats, True), None), dropout)
         u = _dropout(self.up5(u), dropout)
         if dropout:     # the reference also drops the two logits before the softmax (joint_model.py:386-388): fused epilogue
             data_dict[out_key] = ops.out_block_softmax(u.raw, u.stats, self.out_block.weight, self.out_block.bias,
@@ -287,14 +289,15 @@ class Joint(nn.Module):
         self.seg_dropout = seg_dropout
 
     def forward(self, data_dict, in_key, out_key, out_key_recon, dropout=False):
-        if dropout:
-            data_dict = self.Seg(data_dict, in_key, out_key, dropout=self.seg_dropout)
-            data_dict[out_key_recon], _, _ = self.Vae(data_dict[out_key], if_random=False, scale=self.vae_forward_scale,
-                                                      dropout=self.vae_decoder_dropout)
-        else:
-            data_dict = self.Seg(data_dict, in_key, out_key)
-            data_dict[out_key_recon], data_dict["mean"], data_dict["std"] = self.Vae(
-                data_dict[out_key], if_random=False, scale=self.vae_forward_scale)
+        with ops.arena_scope(data_dict[in_key].device):          # Seg and Vae share one statistics arena: one zero fill per forward
+            if dropout:
+                data_dict = self.Seg(data_dict, in_key, out_key, dropout=self.seg_dropout)
+                data_dict[out_key_recon], _, _ = self.Vae(data_dict[out_key], if_random=False, scale=self.vae_forward_scale,
+                                                          dropout=self.vae_decoder_dropout)
+            else:
+                data_dict = self.Seg(data_dict, in_key, out_key)
+                data_dict[out_key_recon], data_dict["mean"], data_dict["std"] = self.Vae(
+                    data_dict[out_key], if_random=False, scale=self.vae_forward_scale)
         return data_dict
 
 

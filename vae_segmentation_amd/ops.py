@@ -383,17 +383,38 @@ def weights_changed():
 # one ~4 us fill launch per layer (~170 per step).  Instead the top-level modules open an arena per forward: ONE zeroed
 # fp64 buffer sized from the previous step's use, from which the per-layer buffers are carved as views (the views keep
 # the arena's storage alive for backward; a new forward gets a new arena, so nothing is ever re-zeroed under a reader).
-_ARENA = {"buf": None, "off": 0, "used": 0, "need": 1 << 14}
+_ARENA = {"buf": None, "off": 0, "used": 0, "need": 1 << 14, "depth": 0}
 
 
 def stats_arena_begin(device):
-    """Start a new zeroed arena (call at the top of a forward pass; backward keeps carving from the same one)."""
+    """Start a new zeroed arena (call at the top of a forward pass; backward keeps carving from the same one).  Inside an
+    arena_scope (Joint.forward: Segmentation then VAE) the inner forwards share the scope's arena: one zero-fill launch per step."""
     drop_stale_wgrads()
     a = _ARENA
+    if a["depth"] > 0 and a["buf"] is not None and a["buf"].device == torch.device(device):
+        return
     a["need"] = max(a["need"], a["used"])
-    a["buf"] = torch.zeros(a["need"] + (a["need"] >> 2), dtype=torch.float64, device=device)
+    n = (a["need"] + (a["need"] >> 2) + 1) // 2 * 2                  # doubles, a multiple of 16 bytes
+    a["buf"] = torch.empty(n, dtype=torch.float64, device=device)
+    check(lib.vs_zero_fill(a["buf"].data_ptr(), n * 8, _stream()), "zero_fill")
     a["off"] = 0
     a["used"] = 0
+
+
+class arena_scope:
+    """with arena_scope(device): every forward inside shares one statistics arena (one zero fill)."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        if _ARENA["depth"] == 0:
+            stats_arena_begin(self.device)
+        _ARENA["depth"] += 1
+
+    def __exit__(self, *exc):
+        _ARENA["depth"] -= 1
+        return False
 
 
 def _new_stats(n, c, device, width=2):
@@ -457,6 +478,35 @@ def conv_scatter(x, xs, wp, bias, m_out):
     return y
 
 
+# An activation that feeds both the next encoder level (a lazy conv) and an additive U-Net skip (joint_model.py:380,382) receives two
+# gradients.  The skip's (Materialize.backward, which runs first: the decoder is differentiated before the encoder) is parked here, keyed
+# by the raw tensor, and summed in by the apply pass of the conv's backward (vs_instnorm_relu_bwd_apply_add) instead of by an ATen add
+# launch of autograd's.  A gradient nobody collected by the end of the pass is an error (it would be lost), checked by an engine callback.
+_PENDING = {"grads": {}, "callback": False}
+
+
+def _park_gradient(x, g):
+    _PENDING["grads"][(x.data_ptr(), tuple(x.shape))] = g
+    if not _PENDING["callback"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_pending_done)
+            _PENDING["callback"] = True
+        except RuntimeError:
+            pass
+
+
+def _collect_gradient(x):
+    return _PENDING["grads"].pop((x.data_ptr(), tuple(x.shape)), None)
+
+
+def _pending_done():
+    _PENDING["callback"] = False
+    left = len(_PENDING["grads"])
+    _PENDING["grads"].clear()
+    if left:
+        raise RuntimeError("%d parked skip gradient(s) were never collected by the conv that shares their input: gradients lost" % left)
+
+
 def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
     """Gradient w.r.t. the raw tensor x of a lazy activation a = relu(instnorm(x)) that fed a conv:
     g = conv-backward-data(gy) with the InstanceNorm+ReLU-backward sums accumulated in the same kernel's epilogue,
@@ -500,9 +550,10 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
                                               sums.data_ptr(), gn, gd, gh, gw, gc, c, kind, dt, EPS_IN, _stream()), "conv_gather_bwd_data")
     voxels = x.numel() // (n * c)
     tname = _tname(x)
-    with _timed("in_relu_bwd_apply_kernel<%s>" % tname, 3 * x.numel() * _esize(x), 6.0 * x.numel(), str(tuple(x.shape))):
-        check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), g.data_ptr(), n, voxels,
-                                             c, dt, EPS_IN, _stream()), "instnorm_relu_bwd_apply")
+    add = _collect_gradient(x)                 # the skip's gradient of the same tensor, if one was parked
+    with _timed("in_relu_bwd_apply_kernel<%s>" % tname, (3 if add is None else 4) * x.numel() * _esize(x), 6.0 * x.numel(), str(tuple(x.shape))):
+        check(lib.vs_instnorm_relu_bwd_apply_add(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), _p(add), g.data_ptr(), n, voxels,
+                                                 c, dt, EPS_IN, _stream()), "instnorm_relu_bwd_apply")
     return g
 
 
@@ -944,8 +995,9 @@ class Materialize(torch.autograd.Function):
     With two operands this is the additive U-Net skip (joint_model.py:380,382)."""
 
     @staticmethod
-    def forward(ctx, x, xs, x2, x2s):
+    def forward(ctx, x, xs, x2, x2s, park_second=False):
         _require_cuda(x)
+        ctx.park_second = bool(park_second)
         n, c = x.shape[0], x.shape[-1]
         voxels = x.numel() // (n * c)
         out = torch.empty_like(x)
@@ -968,12 +1020,15 @@ class Materialize(torch.autograd.Function):
             check(lib.vs_instnorm_relu_bwd_pair(g.data_ptr(), x.data_ptr(), xs.data_ptr(), s1.data_ptr(), g1.data_ptr(), x2.data_ptr(),
                                                 x2s.data_ptr(), s2.data_ptr(), g2.data_ptr(), n, voxels, c, vs_dtype(x), EPS_IN, _stream()),
                   "instnorm_relu_bwd_pair")
-            return g1, None, g2, None
+            if ctx.park_second and not torch.is_grad_enabled():
+                _park_gradient(x2, g2)          # the encoder conv that shares x2 sums it into its own gradient (no autograd add launch)
+                return g1, None, None, None, None
+            return g1, None, g2, None, None
         if ctx.needs_input_grad[0]:
             g1 = in_relu_bwd(g, x, xs, inplace=False) if xs is not None else g
         if x2 is not None and ctx.needs_input_grad[2]:
             g2 = in_relu_bwd(g, x2, x2s, inplace=False) if x2s is not None else g
-        return g1, None, g2, None
+        return g1, None, g2, None, None
 
 
 _DROPOUT_CALLS = [0]

@@ -126,6 +126,7 @@ class GraphedStep:
     def __init__(self, loss_fn, params, optimizer, grad_sync=None, warmup=2, overlap=False, scaler=None):
         ops.set_overlap(overlap and os.environ.get("VS_OVERLAP", "1") != "0")       # VS_OVERLAP=0: measurement aid
         self.loss_fn, self.params, self.optimizer, self.grad_sync = loss_fn, list(params), optimizer, grad_sync
+        self._one = None
         self.scaler = scaler                     # optim.LossScaler for fp16 storage: its scale is a device scalar the captured backward reads
         self.graph = self.graph2 = None
         self.loss = None
@@ -156,7 +157,9 @@ class GraphedStep:
         if self.scaler is not None:
             self.loss.backward(gradient=self.scaler.seed)
         else:
-            self.loss.backward()
+            if self._one is None or self._one.device != self.loss.device:
+                self._one = torch.ones((), dtype=self.loss.dtype, device=self.loss.device)
+            self.loss.backward(gradient=self._one)     # a constant seed: autograd's own ones_like would be a fill launch in every replay
         if rest:
             ops.join_side()      # side-stream weight gradients (a parallel branch of the captured graph) / the second weight-gradient phase
 
