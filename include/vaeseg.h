@@ -10,8 +10,10 @@
  *     synchronised inside; every launch goes to `stream` (a hipStream_t passed as void*).
  *   - activations are channels-last: [N][D][H][W][C], C a multiple of 8, element type `dtype`
  *     (VS_F32, VS_BF16 or VS_F16; accumulation is always fp32).  "planar" tensors are the reference's NCDHW fp32: [N][C][D*H*W].
- *   - a *lazy* activation is a raw conv output plus `stats`: double[N][C][2] = (sum, sum of squares)
- *     over the D*H*W voxels of each (n,c), accumulated by the producing kernel.  Passing `stats` to a
+ *   - a *lazy* activation is a raw conv output plus `stats`: double[VS_STAT_SLOTS][N][C][2] = VS_STAT_SLOTS partial copies of
+ *     (sum, sum of squares) over the D*H*W voxels of each (n,c): a producing workgroup accumulates (fp64 atomics) into copy
+ *     (workgroup id mod VS_STAT_SLOTS), consumers add the copies — same-address atomics retire ~20 ns apart, and hundreds of
+ *     workgroups finish together at the full-resolution levels.  The IN-backward `sums` buffers have the same shape.  Passing `stats` to a
  *     consumer makes it read relu((x-mean)*rstd) — InstanceNorm3d(affine=False, eps) + ReLU
  *     (joint_model.py:11,41-48,107-108) — without that tensor ever being materialised.  stats == NULL
  *     means "use x as is".
@@ -30,6 +32,9 @@ extern "C" {
 #define VS_VERSION 200
 
 enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2 };   /* storage type of activations: fp32 (parity mode), bf16, IEEE fp16 (needs loss scaling, see vs_loss_scale_*) */
+#ifndef VS_STAT_SLOTS
+#define VS_STAT_SLOTS 4        /* measured on one MI355X, 96^3 step: 1 copy 2.908 ms, 2: 2.820, 4: 2.797, 8: 3.021 (consumers read every copy) */
+#endif
 enum { VS_OK = 0, VS_EINVAL = -1, VS_ESHAPE = -2, VS_EDTYPE = -3, VS_EWORKSPACE = -4, VS_EALIGN = -5 };
 
 /* geometry of an implicit-GEMM convolution */
@@ -48,6 +53,8 @@ enum {
 };
 
 int vs_version(void);
+int vs_stat_slots(void);        /* VS_STAT_SLOTS the library was built with (callers size statistics buffers by it) */
+int vs_stat_interleaved(void);  /* 0: double[slot][N][C][2]   1: double[N][C][slot][2] */
 const char* vs_strerror(int code);
 
 /* ---- weights ---------------------------------------------------------------------------------- */

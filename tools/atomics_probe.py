@@ -37,7 +37,7 @@ for (n, cin, cout, side) in [(2, 8, 8, 96), (2, 16, 8, 96), (2, 8, 16, 48), (2, 
     w = torch.randn(cout, cin, 3, 3, 3, device="cuda") * 0.05
     wp = ops.pack_weight(w, VS_PACK_ROWS_D0, cin, dt)
     y = torch.empty(n, side, side, side, cout, device="cuda", dtype=dt)
-    ys = torch.zeros(n, cout, 2, dtype=torch.float64, device="cuda")
+    ys = torch.zeros(ops.STAT_SLOTS, n, cout, 2, dtype=torch.float64, device="cuda")
     res = []
     for stats in (ys.data_ptr(), None):
         res.append(time_graph(lambda: check(lib.vs_conv_gather_fwd(x.data_ptr(), xs.data_ptr(), wp.data_ptr(), None, y.data_ptr(), stats, n, side, side, side,

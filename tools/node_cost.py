@@ -31,7 +31,7 @@ for side, c in ((6, 128), (12, 64), (24, 32)):
     x = torch.randn(n, side, side, side, c, device="cuda").to(dt)
     g = torch.randn_like(x)
     xs = ops.instnorm_stats(x)
-    sums = torch.zeros(n, c, 2, dtype=torch.float64, device="cuda")
+    sums = torch.zeros(ops.STAT_SLOTS, n, c, 2, dtype=torch.float64, device="cuda")
     gx = torch.empty_like(x)
     vox = side ** 3
     st = lambda: torch.cuda.current_stream().cuda_stream
@@ -39,7 +39,7 @@ for side, c in ((6, 128), (12, 64), (24, 32)):
     w = torch.randn(c, c, 3, 3, 3, device="cuda") * 0.05
     wp = ops.pack_weight(w, VS_PACK_ROWS_D0, c, dt)
     y = torch.empty_like(x)
-    ys = torch.zeros(n, c, 2, dtype=torch.float64, device="cuda")
+    ys = torch.zeros(ops.STAT_SLOTS, n, c, 2, dtype=torch.float64, device="cuda")
     t_conv = time_graph(lambda: check(lib.vs_conv_gather_fwd(x.data_ptr(), xs.data_ptr(), wp.data_ptr(), None, y.data_ptr(), ys.data_ptr(), n, side, side, side, c, c, VS_CONV_K3, VS_BF16, 1e-5, st()), "c"))
     wpb = ops.pack_weight(w, VS_PACK_ROWS_D1_FLIP, c, dt)
     t_bwd = time_graph(lambda: check(lib.vs_conv_gather_bwd_data(g.data_ptr(), wpb.data_ptr(), gx.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), n, side, side, side, c, c, VS_CONV_K3, VS_BF16, 1e-5, st()), "b"))

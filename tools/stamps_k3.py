@@ -16,7 +16,7 @@ xs = ops.instnorm_stats(x)
 y = torch.empty(n, s, s, s, m, device="cuda", dtype=torch.bfloat16)
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for it in range(int(os.environ.get('VS_ITERS', 3))):
-    ys = torch.zeros(n, m, 2, dtype=torch.float64, device="cuda")
+    ys = torch.zeros(ops.STAT_SLOTS, n, m, 2, dtype=torch.float64, device="cuda")
     ev0.record()
     rc = dbg.vs_conv_gather_fwd(x.data_ptr(), xs.data_ptr(), wp.data_ptr(), None, y.data_ptr(), ys.data_ptr(), n, s, s, s, c, m, 0, 1, 1e-5, None)
     ev1.record()

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vaeseg.h")
-LIB_PATH = os.path.join(_HERE, "libvaeseg.so")
+LIB_PATH = os.environ.get("VS_LIBVAESEG") or os.path.join(_HERE, "libvaeseg.so")      # VS_LIBVAESEG: an alternative build (A/B measurements)
 
 VS_F32, VS_BF16, VS_F16 = 0, 1, 2
 VS_CONV_K3, VS_CONV_K2S2, VS_CONV_T2S2 = 0, 1, 2

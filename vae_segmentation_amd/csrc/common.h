@@ -131,18 +131,51 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// ---- per-(n,c) statistics: double[VS_STAT_SLOTS][pairs][2] --------------------------------------------------------------------------
+// A statistics buffer holds VS_STAT_SLOTS partial copies of its (sum, sumsq) [or IN-backward (sum g*mask, sum g*mask*xhat)] pairs.  A
+// producing workgroup accumulates into copy (blockIdx.x mod VS_STAT_SLOTS); consumers add the copies (fixed order) when they build their
+// tables.  Why: the accumulation is one fp64 atomic per (workgroup, channel, statistic), device-scope atomics on ONE address retire
+// ~20 ns apart, and in the one-wave kernels of the 48^3 / 96^3 levels 200-400 workgroups finish together — measured 3.5-4.4 us of a
+// 10-16 us launch (tools/atomics_probe.py).  More copies shorten that chain but every consuming workgroup reads all of them while it builds
+// its tables: 4 copies measured best (step time with 1 / 2 / 4 / 8 copies: 2.908 / 2.820 / 2.797 / 3.021 ms).  Copies of one pair placed in
+// the same cache line (VS_STAT_INTERLEAVE 1) gain nothing (2.92 ms): the atomics of one line retire one after another, whatever the address.
+#ifndef VS_STAT_INTERLEAVE
+#define VS_STAT_INTERLEAVE 0       // 0: double[slot][pair][2] (copies far apart)   1: double[pair][slot][2] (a pair's copies in one cache line)
+#endif
+__device__ __forceinline__ size_t stat_index(size_t pair, size_t pairs, int slot) {
+    return VS_STAT_INTERLEAVE ? (pair * VS_STAT_SLOTS + slot) * 2 : ((size_t)slot * pairs + pair) * 2;
+}
+__device__ __forceinline__ void stat_load(const double* __restrict__ st, size_t pair, size_t pairs, double (&out)[2]) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int s = 0; s < VS_STAT_SLOTS; ++s) {
+        a += st[stat_index(pair, pairs, s)];
+        b += st[stat_index(pair, pairs, s) + 1];
+    }
+    out[0] = a; out[1] = b;
+}
+// where this workgroup accumulates statistic `which` (0 / 1) of `pair`
+__device__ __forceinline__ double* stat_ptr(double* st, size_t pair, size_t pairs, int which) {
+    return st + stat_index(pair, pairs, (int)(blockIdx.x & (VS_STAT_SLOTS - 1))) + which;
+}
+
 // mean / rstd of one (n,c) from the fp64 (sum, sumsq) pair a producer accumulated
-__device__ __forceinline__ void stats_to_mean_rstd(const double* st, double inv_count, float eps, float& mean, float& rstd) {
+__device__ __forceinline__ void pair_to_mean_rstd(const double (&st)[2], double inv_count, float eps, float& mean, float& rstd) {
     double m = st[0] * inv_count;
     double var = st[1] * inv_count - m * m;
     if (var < 0.0) var = 0.0;
     mean = (float)m;
     rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
+__device__ __forceinline__ void stats_to_mean_rstd(const double* st, size_t pair, size_t pairs, double inv_count, float eps, float& mean, float& rstd) {
+    double v[2];
+    stat_load(st, pair, pairs, v);
+    pair_to_mean_rstd(v, inv_count, eps, mean, rstd);
+}
 
-// same for the bf16-storage kernels: the cancellation-prone part (variance) stays fp64, the reciprocal square root is v_rsq_f32 plus
+// same for the 16-bit-storage kernels: the cancellation-prone part (variance) stays fp64, the reciprocal square root is v_rsq_f32 plus
 // one Newton step (~1e-7 relative) instead of an fp64 sqrt + divide (~60 dependent instructions in every kernel prologue)
-__device__ __forceinline__ void stats_to_mean_rstd_fast(const double* st, double inv_count, float eps, float& mean, float& rstd) {
+__device__ __forceinline__ void stats_to_mean_rstd_fast(const double* st, double inv_count, float eps, float& mean, float& rstd) {     // st: an already summed pair
     const double m = st[0] * inv_count;
     double var = st[1] * inv_count - m * m;
     if (var < 0.0) var = 0.0;
@@ -151,6 +184,11 @@ __device__ __forceinline__ void stats_to_mean_rstd_fast(const double* st, double
     r = r * (1.5f - 0.5f * v * r * r);
     mean = (float)m;
     rstd = r;
+}
+__device__ __forceinline__ void stats_to_mean_rstd_fast(const double* st, size_t pair, size_t pairs, double inv_count, float eps, float& mean, float& rstd) {
+    double v[2];
+    stat_load(st, pair, pairs, v);
+    stats_to_mean_rstd_fast(v, inv_count, eps, mean, rstd);
 }
 
 // counter-based Bernoulli(keep) for dropout: splitmix64 finaliser of (seed, index) -> uniform in [0,1)

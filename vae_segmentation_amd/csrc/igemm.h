@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     if (has_stats) {
         for (int c = tid; c < p.C; c += 256) {
             float m, r;
-            stats_to_mean_rstd(p.x_stats + ((size_t)n * p.C + c) * 2, p.inv_count_in, p.eps, m, r);
+            stats_to_mean_rstd(p.x_stats, (size_t)n * p.C + c, (size_t)p.N * p.C, p.inv_count_in, p.eps, m, r);
             s_mean[c] = m;
             s_rstd[c] = r;
         }
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         // mask tensor's channels of this sample
         for (int c = tid; c < p.M; c += 256) {
             float m, r;
-            stats_to_mean_rstd(p.mask_stats + ((size_t)n * p.M + c) * 2, p.inv_count_out, p.eps, m, r);
+            stats_to_mean_rstd(p.mask_stats, (size_t)n * p.M + c, (size_t)p.N * p.M, p.inv_count_out, p.eps, m, r);
             s_mean[c] = m;
             s_rstd[c] = r;
         }
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         }
     }
 
-    double* const red_dst = p.sums != nullptr ? p.sums : p.y_stats;
+    double* const red_dst0 = p.sums != nullptr ? p.sums : p.y_stats;
+    double* const red_dst = red_dst0;
     if ((EPI == EPI_RAW || EPI == EPI_SCATTER) && red_dst != nullptr) {
         // reduce over the 16 columns held by lanes with equal g, then over waves, then one fp64 atomic per (m, stat)
 #pragma unroll
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                            (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
                 }
             }
-            if (ch_out >= 0) atomicAdd(red_dst + ((size_t)n * p.M + ch_out) * 2 + st, tot);
+            if (ch_out >= 0) atomicAdd(stat_ptr(red_dst, (size_t)n * p.M + ch_out, (size_t)p.N * p.M, st), tot);
         }
     }
 }

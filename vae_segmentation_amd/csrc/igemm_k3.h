@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     if (has_stats) {
         for (int i = tid; i < p.N * p.C; i += 256) {
             float m, r;
-            stats_to_mean_rstd(p.x_stats + (size_t)i * 2, p.inv_count_in, p.eps, m, r);
+            stats_to_mean_rstd(p.x_stats, (size_t)i, (size_t)p.N * p.C, p.inv_count_in, p.eps, m, r);
             s_mean[i] = m;
             s_rstd[i] = r;
         }
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     if (p.sums != nullptr) {
         for (int i = tid; i < p.N * p.M; i += 256) {
             float m, r;
-            stats_to_mean_rstd(p.mask_stats + (size_t)i * 2, p.inv_count_out, p.eps, m, r);
+            stats_to_mean_rstd(p.mask_stats, (size_t)i, (size_t)p.N * p.M, p.inv_count_out, p.eps, m, r);
             s_mkm[i] = m;
             s_mkr[i] = r;
         }
@@ -324,7 +324,8 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                     }
                 }
             }
-            double* const red_dst = p.sums != nullptr ? p.sums : p.y_stats;
+            double* const red_dst0 = p.sums != nullptr ? p.sums : p.y_stats;
+            double* const red_dst = red_dst0;
             if (red_dst != nullptr) {
                 const int tn = t + (int)gridDim.x;
                 const bool flush = tn >= total_tiles || tn / p.tiles_per_sample != n;     // workgroup-uniform
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                         if (row < p.M) {
                             const double tot = (double)s_red[(0 * 64 + lr) * 2 + st] + (double)s_red[(1 * 64 + lr) * 2 + st] +
                                                (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
-                            atomicAdd(red_dst + ((size_t)n * p.M + row) * 2 + st, tot);
+                            atomicAdd(stat_ptr(red_dst, (size_t)n * p.M + row, (size_t)p.N * p.M, st), tot);
                         }
                     }
                     __syncthreads();                     // s_red is reused by a later flush

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     const double* st_src = SUMS ? p.mask_stats : p.x_stats;
     const int st_n = SUMS ? p.N * p.M : (has_stats ? p.N * p.C : 0);
     double st_pre[2] = {0.0, 1.0};
-    if (tid < st_n) { st_pre[0] = st_src[(size_t)tid * 2]; st_pre[1] = st_src[(size_t)tid * 2 + 1]; }
+    if (tid < st_n) stat_load(st_src, (size_t)tid, (size_t)st_n, st_pre);
 
     // ---- per-thread stage geometry (tile independent) -----------------------------------------------------------------
     // fragment b of this thread is 16-byte part `part` (the same for every b: 256 % U == 0) of tile voxel tv_b
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     const i32x4 mrsrc = make_rsrc(p.mask_x, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.M * 2));
     for (int i = tid; i < st_n; i += 256) {
         double st[2] = {st_pre[0], st_pre[1]};
-        if (i != tid) { st[0] = st_src[(size_t)i * 2]; st[1] = st_src[(size_t)i * 2 + 1]; }
+        if (i != tid) stat_load(st_src, (size_t)i, (size_t)st_n, st);
         float m, r;
         stats_to_mean_rstd_fast(st, SUMS ? p.inv_count_out : p.inv_count_in, p.eps, m, r);
         if constexpr (SUMS) { s_mkm[i] = m; s_mkr[i] = r; }
@@ -401,7 +401,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
                     }
                 }
             }
-            double* const red_dst = has_sums ? p.sums : p.y_stats;
+            double* const red_dst0 = has_sums ? p.sums : p.y_stats;
+            double* const red_dst = red_dst0;
             if (red_dst != nullptr) {
                 const bool flush = t + G >= t_end || nxt.n != n;       // workgroup-uniform
                 if (flush) {
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
                         if (row < p.M) {
                             const double tot = (double)s_red[(0 * 64 + lr) * 2 + st] + (double)s_red[(1 * 64 + lr) * 2 + st] +
                                                (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
-                            atomicAdd(red_dst + ((size_t)n * p.M + row) * 2 + st, tot);
+                            atomicAdd(stat_ptr(red_dst, (size_t)n * p.M + row, (size_t)p.N * p.M, st), tot);
                         }
                     }
                     if (t + G < t_end) __syncthreads();     // s_red is reused by a later flush

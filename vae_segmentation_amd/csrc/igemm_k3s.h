@@ -108,9 +108,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (p.nch > 1) load_stage(1, xv1, wv1);
     if (has_stats) {
         for (int c = tid; c < p.C; c += 256) {
-            double st[2] = {p.x_stats[((size_t)n * p.C + c) * 2], p.x_stats[((size_t)n * p.C + c) * 2 + 1]};
             float m, r;
-            stats_to_mean_rstd_fast(st, p.inv_count_in, p.eps, m, r);
+            stats_to_mean_rstd_fast(p.x_stats, (size_t)n * p.C + c, (size_t)p.N * p.C, p.inv_count_in, p.eps, m, r);
             s_scale[c] = r; s_shift[c] = -m * r;
         }
     }
@@ -120,8 +119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (row0 + r < p.M) {
-                double st[2] = {p.mask_stats[((size_t)n * p.M + row0 + r) * 2], p.mask_stats[((size_t)n * p.M + row0 + r) * 2 + 1]};
-                stats_to_mean_rstd_fast(st, p.inv_count_out, p.eps, mm[r], mr[r]);
+                stats_to_mean_rstd_fast(p.mask_stats, (size_t)n * p.M + row0 + r, (size_t)p.N * p.M, p.inv_count_out, p.eps, mm[r], mr[r]);
             }
     }
     if (p.bias != nullptr) {
@@ -253,7 +251,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[r] = sv[r]; ssq[r] = sv[r] * sv[r]; }
     }
-    double* const red_dst = SUMS ? p.sums : p.y_stats;
+    double* const red_dst0 = SUMS ? p.sums : p.y_stats;
+    double* const red_dst = red_dst0;
     if (red_dst != nullptr) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             if (row < p.M) {
                 const double tot = (double)s_red[(0 * 16 + lr) * 2 + st] + (double)s_red[(1 * 16 + lr) * 2 + st] +
                                    (double)s_red[(2 * 16 + lr) * 2 + st] + (double)s_red[(3 * 16 + lr) * 2 + st];
-                atomicAdd(red_dst + ((size_t)n * p.M + row) * 2 + st, tot);
+                atomicAdd(stat_ptr(red_dst, (size_t)n * p.M + row, (size_t)p.N * p.M, st), tot);
             }
         }
     }

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const double* st_src = SUMS ? p.mask_stats : p.x_stats;
     const int st_n = SUMS ? p.N * 8 : (has_stats ? p.N * 8 : 0);
     double st_pre[2] = {0.0, 1.0};
-    if (tid < st_n) { st_pre[0] = st_src[(size_t)tid * 2]; st_pre[1] = st_src[(size_t)tid * 2 + 1]; }
+    if (tid < st_n) stat_load(st_src, (size_t)tid, (size_t)st_n, st_pre);
 
     // ---- per-thread staging geometry: fragment b = halo voxel tid + 256 b -------------------------------------------------
     int rel_off[NIT], tzyx[NIT];
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const i32x4 mrsrc = make_rsrc(p.mask_x, (unsigned int)((long long)p.N * p.D * p.H * p.W * 16));
     for (int i = tid; i < st_n; i += 256) {
         double st[2] = {st_pre[0], st_pre[1]};
-        if (i != tid) { st[0] = st_src[(size_t)i * 2]; st[1] = st_src[(size_t)i * 2 + 1]; }
+        if (i != tid) stat_load(st_src, (size_t)i, (size_t)st_n, st);
         float m, r;
         stats_to_mean_rstd_fast(st, SUMS ? p.inv_count_out : p.inv_count_in, p.eps, m, r);
         if constexpr (SUMS) { s_mkm[i] = m; s_mkr[i] = r; }
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int r = 0; r < 4; ++r) { ssum[r] += v[r]; ssq[r] += v[r] * v[r]; }
                 }
             }
-            double* const red_dst = SUMS ? p.sums : p.y_stats;
+            double* const red_dst0 = SUMS ? p.sums : p.y_stats;
+            double* const red_dst = red_dst0;
             if (red_dst != nullptr) {
                 const bool flush = t + G >= t_end || nxt.n != n;       // workgroup-uniform
                 if (flush) {
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         if (ch < p.M) {
                             const double tot = (double)s_red[(0 * 8 + ch) * 2 + st] + (double)s_red[(1 * 8 + ch) * 2 + st] +
                                                (double)s_red[(2 * 8 + ch) * 2 + st] + (double)s_red[(3 * 8 + ch) * 2 + st];
-                            atomicAdd(red_dst + ((size_t)n * 8 + ch) * 2 + st, tot);
+                            atomicAdd(stat_ptr(red_dst, (size_t)n * 8 + ch, (size_t)p.N * 8, st), tot);
                         }
                     }
                     // s_red is rewritten only after the two barriers at the top of the next tile

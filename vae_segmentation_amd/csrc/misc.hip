@@ -3,6 +3,8 @@
 #include "common.h"
 
 extern "C" int vs_version(void) { return VS_VERSION; }
+extern "C" int vs_stat_slots(void) { return VS_STAT_SLOTS; }
+extern "C" int vs_stat_interleaved(void) { return VS_STAT_INTERLEAVE; }
 extern "C" const char* vs_strerror(int code) {
     switch (code) {
         case VS_OK: return "ok";

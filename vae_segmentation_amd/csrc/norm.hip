@@ -21,9 +21,10 @@ struct RowIter {
 
 __device__ __forceinline__ void load_mean_rstd(const double* stats, int n, int c, double inv_count, float eps,
                                                float* s_mean, float* s_rstd) {
+    const size_t pairs = (size_t)gridDim.y * c;          // every kernel of this file runs blockIdx.y = sample over all N samples
     for (int i = threadIdx.x; i < c; i += blockDim.x) {
         float m = 0.f, r = 1.f;
-        if (stats) stats_to_mean_rstd(stats + ((size_t)n * c + i) * 2, inv_count, eps, m, r);
+        if (stats) stats_to_mean_rstd(stats, (size_t)n * c + i, pairs, inv_count, eps, m, r);
         s_mean[i] = m;
         s_rstd[i] = r;
     }
@@ -45,7 +46,8 @@ __device__ __forceinline__ void reduce_and_atomic(const RowIter<T>& it, double (
         const int fx = ch / EPL, j = ch - fx * EPL;
         double tot = 0.0;
         for (int fy = 0; fy < it.rows_per_it; ++fy) tot += s_red[(fy * it.frags + fx) * (EPL * NS) + j * NS + s];
-        atomicAdd(out + ((size_t)n * c + ch) * NS + s, tot);
+        static_assert(NS == 2, "statistics come in pairs");
+        atomicAdd(stat_ptr(out, (size_t)n * c + ch, (size_t)gridDim.y * c, s), tot);
     }
 }
 
@@ -215,8 +217,10 @@ __device__ __forceinline__ void in_relu_bwd_apply_body(const T* __restrict__ g, 
     request(v);
     load_mean_rstd(xs, n, c, inv_count, eps, s_m, s_r);
     for (int i = threadIdx.x; i < c; i += 256) {
-        s_a[i] = (float)(sums[((size_t)n * c + i) * 2 + 0] * inv_count);
-        s_b[i] = (float)(sums[((size_t)n * c + i) * 2 + 1] * inv_count);
+        double sv[2];
+        stat_load(sums, (size_t)n * c + i, (size_t)gridDim.y * c, sv);
+        s_a[i] = (float)(sv[0] * inv_count);
+        s_b[i] = (float)(sv[1] * inv_count);
     }
     __syncthreads();
     if (!act) return;

@@ -84,11 +84,11 @@ __device__ __forceinline__ void g3_body(const G3Params& p, const int bx, const i
         const int n = i >> 4, c = i & 15;
         float m = 0.f, r = 1.f;
         const int pc = mb * 16 + c;
-        if (p_stats && pc < p.Mch) stats_to_mean_rstd(p.P_stats + ((size_t)n * p.Mch + pc) * 2, p.inv_cnt_p, p.eps, m, r);
+        if (p_stats && pc < p.Mch) stats_to_mean_rstd(p.P_stats, (size_t)n * p.Mch + pc, (size_t)p.N * p.Mch, p.inv_cnt_p, p.eps, m, r);
         s_pm[i] = m; s_pr[i] = r;
         m = 0.f; r = 1.f;
         const int qc = cb * CB + c;
-        if (q_stats && c < CB && qc < p.Cch) stats_to_mean_rstd(p.Q_stats + ((size_t)n * p.Cch + qc) * 2, p.inv_cnt_q, p.eps, m, r);
+        if (q_stats && c < CB && qc < p.Cch) stats_to_mean_rstd(p.Q_stats, (size_t)n * p.Cch + qc, (size_t)p.N * p.Cch, p.inv_cnt_q, p.eps, m, r);
         s_qm[i] = m; s_qr[i] = r;
     }
 
@@ -333,11 +333,11 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         const int n = i >> 4, c = i & 15;
         float m = 0.f, r = 1.f;
         const int pc = mb * 16 + c;
-        if (p_stats && pc < p.Mch) stats_to_mean_rstd_fast(p.P_stats + ((size_t)n * p.Mch + pc) * 2, p.inv_cnt_p, p.eps, m, r);
+        if (p_stats && pc < p.Mch) stats_to_mean_rstd_fast(p.P_stats, (size_t)n * p.Mch + pc, (size_t)p.N * p.Mch, p.inv_cnt_p, p.eps, m, r);
         s_psc[i] = r; s_psh[i] = -m * r;
         m = 0.f; r = 1.f;
         const int qc = cb * CB + c;
-        if (q_stats && c < CB && qc < p.Cch) stats_to_mean_rstd_fast(p.Q_stats + ((size_t)n * p.Cch + qc) * 2, p.inv_cnt_q, p.eps, m, r);
+        if (q_stats && c < CB && qc < p.Cch) stats_to_mean_rstd_fast(p.Q_stats, (size_t)n * p.Cch + qc, (size_t)p.N * p.Cch, p.inv_cnt_q, p.eps, m, r);
         s_qsc[i] = r; s_qsh[i] = -m * r;
     }
 

@@ -383,7 +383,7 @@ def weights_changed():
 # one ~4 us fill launch per layer (~170 per step).  Instead the top-level modules open an arena per forward: ONE zeroed
 # fp64 buffer sized from the previous step's use, from which the per-layer buffers are carved as views (the views keep
 # the arena's storage alive for backward; a new forward gets a new arena, so nothing is ever re-zeroed under a reader).
-_ARENA = {"buf": None, "off": 0, "used": 0, "need": 1 << 14, "depth": 0}
+_ARENA = {"buf": None, "off": 0, "used": 0, "need": 1 << 17, "depth": 0}
 
 
 def stats_arena_begin(device):
@@ -417,17 +417,30 @@ class arena_scope:
         return False
 
 
+STAT_SLOTS = lib.vs_stat_slots()      # VS_STAT_SLOTS of the loaded library: partial copies of every statistics buffer; consumers add them
+
+
 def _new_stats(n, c, device, width=2):
+    """A zeroed statistics buffer double[STAT_SLOTS][n][c][2] (width 2), carved from the arena; width 1 = plain zeroed scratch [1][n][c][1]."""
     a = _ARENA
-    cnt = n * c * width
+    slots = STAT_SLOTS if width == 2 else 1
+    cnt = slots * n * c * width
     a["used"] += cnt
     buf = a["buf"]
     if buf is None or buf.device != device or a["off"] + cnt > buf.numel():
         a["fallbacks"] = a.get("fallbacks", 0) + 1
-        return torch.zeros(n, c, width, dtype=torch.float64, device=device)
-    out = buf[a["off"]:a["off"] + cnt].view(n, c, width)
+        return torch.zeros(slots, n, c, width, dtype=torch.float64, device=device)
+    out = buf[a["off"]:a["off"] + cnt].view(slots, n, c, width)
     a["off"] += cnt
     return out
+
+
+def stats_total(stats):
+    """(n, c, 2) totals of a statistics buffer (sum over its partial copies) — for tests / inspection"""
+    if lib.vs_stat_interleaved():
+        s, n, c, w = stats.shape
+        return stats.reshape(n, c, s, w).sum(2)
+    return stats.sum(0)
 
 
 def conv_gather(x, xs, wp, bias, m_out, kind, want_stats, real_channels=None):
