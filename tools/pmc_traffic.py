@@ -1,6 +1,7 @@
 """Per-kernel HBM traffic from two rocprofv3 passes (--pmc FETCH_SIZE and --pmc WRITE_SIZE), as MI355X_MICROARCH.md §HBM
 prescribes: counters are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream, so it is doubled.
-usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> [out.json]"""
+usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <step_equivalents_in_the_run> [out.json]
+(step equivalents: bench.py's 2 eager warm-up passes + --warmup + --steps; launches per step = sampled launches / that)"""
 import collections, csv, glob, json, sys
 
 
@@ -14,13 +15,19 @@ def per_kernel(d, counter):
 
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {}
+steps = float(sys.argv[3])
+out, total = {}, 0.0
 for k in fetch:
     f, n = fetch[k]
     w = write.get(k, (0.0, 0))[0]
-    out[k] = {"launches_sampled": n, "fetch_kib_raw": f, "write_kib": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
-for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:12]:
-    print("%-70s n=%5d  %10.2f MB/launch (fetch x2 %.2f MB, write %.2f MB)" % (k[:70], v["launches_sampled"], v["hbm_bytes_per_launch"] / 1e6,
-                                                                             2 * v["fetch_kib_raw"] * 1024 / 1e6, v["write_kib"] * 1024 / 1e6))
-if len(sys.argv) > 3:
-    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    b = (2.0 * f + w) * 1024.0
+    out[k] = {"launches_sampled": n, "launches_per_step": n / steps, "fetch_kib_raw": f, "write_kib": w, "hbm_bytes_per_launch": b}
+    if "spin_kernel" not in k:
+        total += b * n / steps
+out["_step_total_bytes"] = total
+print("HBM traffic per step (FETCH_SIZE x2 + WRITE_SIZE over all kernels): %.3f GB" % (total / 1e9))
+for k, v in sorted(((k, v) for k, v in out.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:14]:
+    print("%-72s %6.1f/step %9.2f MB/launch (fetch x2 %.2f MB, write %.2f MB)" % (k[:72], v["launches_per_step"], v["hbm_bytes_per_launch"] / 1e6,
+                                                                                  2 * v["fetch_kib_raw"] * 1024 / 1e6, v["write_kib"] * 1024 / 1e6))
+if len(sys.argv) > 4:
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
