@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Source-domain trainer — same flags as the reference's main_source.py (argparse block main_source.py:25-57), native step.
 
-Methods with native kernels: vae_train, seg_train, joint_train (the ones the reference's scripts/source/*.bash use).
+Methods (all native): vae_train, seg_train, joint_train (the ones the reference's scripts/source/*.bash use), sep_joint_train, embed_train,
+refine_vae (main_source.py:546-659).
 Data: --synthetic volumes (see vae_segmentation_amd/driver.py).  Multi-GPU: `python -m torch.distributed.run
 --nproc-per-node N main_source.py ...` (one process per GPU, RCCL gradient all-reduce) instead of -G/nn.DataParallel."""
 import argparse

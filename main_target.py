@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Target-domain trainer — the flags of the reference's main_target.py that its launch scripts (scripts/target/*.bash) use,
-native step.  Methods with native kernels: vae_train, domain_adaptation (student/teacher Joint nets, binarised or
-confident pseudo-labels, domain_loss_type 0 / 8 / 9, optional KL term, optional EMA teacher).  Uses the
+native step.  Methods (all native): vae_train, domain_adaptation (student/teacher Joint nets, binarised or confident pseudo-labels,
+domain_loss_type 0 / 8 / 9 / 11-16, --only_pseudo, --turn_epoch, --lambda_vae_warmup, optional KL term, optional EMA teacher, test-time
+training with --val_finetune), discriminator_train, domain_adaptation_dis.  Uses the
 utils/evaluation.py epsilon (1e-6), as main_target.py does (it imports avg_dsc from there, main_target.py:23)."""
 import argparse
 

@@ -503,6 +503,129 @@ def _embed128(dt):
     return d
 
 
+def gold_methods():
+    """The loss bodies of the remaining train methods on the reference's own modules:
+    embed_train (main_source.py:546-590), refine_vae (:591-628), sep_joint_train (:629-659), domain_adaptation_dis (main_target.py:696-732)
+    and discriminator_train (:491-501).  Scalars + gradient summaries, fp32 and fp64."""
+    save("embed_train128", both_precisions(_embed_train128))
+    save("sep_joint128", both_precisions(_sep_joint128))
+    save("da_dis128", both_precisions(_da_dis128))
+
+
+def _embed_train128(dt):
+    d = {}
+    enc = RM.Encoder(n_channels=1, dim=128, norm_type=1)
+    vae = RM.VAE(n_channels=2, n_class=2, norm_type=1, dim=128)
+    fus = RM.Fusion(n_channels_img=1, n_channels_mask=2, n_class=2, norm_type=1)
+    emb = RM.Embed(models=[enc, vae, fus])
+    O.deterministic_fill_(emb, seed=8)
+    emb.to(dt)
+    img = O.synthetic_image(1, 128, seed=2).to(dt)
+    gt = O.one_hot(O.synthetic_label(1, 128, seed=3)).to(dt)
+    torch.manual_seed(123)
+    z = torch.randn(1, 128)
+    torch.manual_seed(123)
+    if dt == torch.float64:
+        torch.cuda.FloatTensor = torch.DoubleTensor
+    try:
+        batch = emb({"img": img, "venous_pancreas_only": gt}, "img", "pred", test_mode=True)        # main_source.py:555
+    finally:
+        torch.cuda.FloatTensor = torch.FloatTensor
+    dsc = lambda key: 1 - main_source_avg_dsc(batch[key], gt, 1, 2)
+    dsc1, dsc2, recon, inpaint = dsc("pred"), dsc("init_seg"), dsc("gt_recon"), dsc("seg_recon")
+    kl = REV.KLloss(batch, mean_key="latent_code_gt", std_key="latent_code_std")
+    mse = torch.nn.MSELoss()(batch["latent_code"], batch["latent_code_gt"])
+    final = (dsc1 + dsc2 + inpaint) / 3 + mse / 10 + 0.00002 * kl + recon                            # :581
+    refine = inpaint + 0.00002 * kl + recon                                                           # :618 (refine_vae)
+    final.backward(retain_graph=True)
+    d["z"] = z.numpy()
+    for k, v in (("dice_loss1", dsc1), ("dice_loss2", dsc2), ("recon_loss", recon), ("inpaint_loss", inpaint), ("kl", kl), ("mse", mse),
+                 ("final", final), ("refine_final", refine)):
+        d[k] = v.detach().numpy()
+    put_grads(d, "enc", enc)
+    put_grads(d, "vae", vae)
+    put_grads(d, "fus", fus)
+    for m in (enc, vae, fus):
+        for p in m.parameters():
+            p.grad = None
+    for p in enc.parameters():                       # refine_vae freezes the Encoder (:596-597)
+        p.requires_grad = False
+    refine.backward()
+    put_grads(d, "rvae", vae)
+    put_grads(d, "rfus", fus)
+    return d
+
+
+def _sep_joint128(dt):
+    d = {}
+    student, _ = joint_case(128, True, dt)
+    teacher, _ = joint_case(128, True, dt)
+    O.deterministic_fill_(teacher.Seg.float(), seed=1)
+    teacher.to(dt)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    teacher.eval()
+    img, lab = O.synthetic_image(1, 128, seed=2).to(dt), O.synthetic_label(1, 128, seed=3)
+    batch = {"img": img, "gt": O.one_hot(lab).to(dt)}
+    batch = student(batch, "img", "pred", "recon")                                                    # main_source.py:634
+    batch = teacher(batch, "img", "pred_tea", "recon_tea")                                            # :635
+
+    def per_sample(s, t):                                                                             # main_source.py:150-182, return_mean=False
+        dd = 2 * torch.sum(s * t, (2, 3, 4)) / (torch.sum(s, (2, 3, 4)) + torch.sum(t, (2, 3, 4)) + 1e-4)
+        return torch.mean(dd[:, 1:2], 1)
+    recon = per_sample(batch["pred"], batch["recon"])
+    recon_tea = per_sample(batch["pred_tea"], batch["recon_tea"])
+    dsc = per_sample(batch["pred"], batch["pred_tea"])
+    final = 0.1 * (1 - torch.mean(recon)) + 1 - torch.mean(dsc * (recon_tea ** 2))                    # :650
+    final.backward()
+    for k, v in (("recon", recon), ("recon_tea", recon_tea), ("dsc", dsc), ("final", final)):
+        d[k] = v.detach().numpy()
+    put_grads(d, "seg", student.Seg)
+    return d
+
+
+def _da_dis128(dt):
+    d = {}
+    seg = RM.Segmentation(n_channels=1, n_class=2, norm_type=1)
+    dis = RM.Encoder(n_channels=1, dim=1, norm_type=1)
+    j2 = RM.Joint2(models=[seg, dis])
+    O.deterministic_fill_(j2.Seg, seed=0)
+    O.deterministic_fill_(j2.Dis, seed=4)
+    j2.to(dt)
+    for p in j2.Dis.parameters():                                                                     # main_target.py:407-411
+        p.requires_grad = False
+    teacher = RM.Segmentation(n_channels=1, n_class=2, norm_type=1)
+    O.deterministic_fill_(teacher, seed=1)
+    teacher.to(dt)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    img, lab = O.synthetic_image(1, 128, seed=2).to(dt), O.synthetic_label(1, 128, seed=3)
+    batch = {"img": img, "gt": O.one_hot(lab).to(dt)}
+    batch = j2(batch, "img", "pred", "score", dropout=True)                                           # :701 (seg_dropout 0)
+    with torch.no_grad():
+        batch = teacher(batch, "img", "fake")                                                         # :702
+    batch["fake"] = REV.binarize(batch["fake"])
+    dsc_loss = 1 - REV.avg_dsc(batch, "pred", "gt", botindex=1, topindex=2)
+    fake_loss = 1 - REV.avg_dsc(batch, "pred", "fake", botindex=1, topindex=2)
+    dis_loss = 1 - batch["score"].mean()
+    final = 1.0 * dis_loss + fake_loss                                                                # :718-720, lambda_vae 1, past warm-up
+    final.backward()
+    # discriminator_train on the same Encoder (main_target.py:491-501): regress a score of 0.7 from the label mask
+    dis2 = RM.Encoder(n_channels=1, dim=1, norm_type=1)
+    O.deterministic_fill_(dis2, seed=4)
+    dis2.to(dt)
+    mask = lab.to(dt)
+    out = dis2(mask)
+    dl = torch.square(torch.tensor([[0.7]], dtype=dt) - out).mean()
+    dl.backward()
+    for k, v in (("dice_loss", dsc_loss), ("fake_loss", fake_loss), ("dis_loss", dis_loss), ("final", final), ("score", batch["score"]),
+                 ("dtrain_loss", dl), ("dtrain_out", out)):
+        d[k] = v.detach().numpy()
+    put_grads(d, "seg", j2.Seg)
+    put_grads(d, "dis", dis2)
+    return d
+
+
 def gold_vae128_native():
     """vae_train step on the NATIVE reference VAE (main_source.py:389-413): z is the reference's own
     torch.randn draw under torch.manual_seed(123), recorded so the oracle / HIP path can inject it."""
@@ -552,6 +675,7 @@ CASES = {
     "rank4": gold_rank4,
     "seg96": gold_seg96,
     "joint160_fwd": gold_joint160_fwd,
+    "methods": gold_methods,
 }
 
 if __name__ == "__main__":

@@ -466,6 +466,68 @@ def finetune_loss(recon_loss, fake_loss, klloss, lambda_vae=1.0, domain_loss_typ
     raise ValueError("oracle restates the finetune loss for only_pseudo and domain_loss_type 0, 8, 9")
 
 
+def embed_train_losses(embed, img, label, eps=EPS_MAIN_SOURCE, n_class=2, noise=None):
+    """main_source.py:546-590."""
+    gt = one_hot(label, n_class).to(img.dtype)
+    batch = embed({"img": img, "venous_pancreas_only": gt}, "img", "pred", test_mode=True, noise=noise)
+    batch["gt"] = gt
+    d = lambda key: 1 - avg_dsc(batch, key, "gt", botindex=1, topindex=n_class, eps=eps)
+    dsc1, dsc2, recon, inpaint = d("pred"), d("init_seg"), d("gt_recon"), d("seg_recon")
+    kl = KLloss(batch, mean_key="latent_code_gt", std_key="latent_code_std")
+    mse = torch.nn.functional.mse_loss(batch["latent_code"], batch["latent_code_gt"])
+    final = (dsc1 + dsc2 + inpaint) / 3 + mse / 10 + 0.00002 * kl + recon
+    return final, {"dice_loss1": dsc1, "dice_loss2": dsc2, "mse_loss": mse, "kl_loss": kl, "recon_loss": recon, "inpaint_loss": inpaint, "batch": batch}
+
+
+def refine_vae_losses(embed, img, label, eps=EPS_MAIN_SOURCE, n_class=2, noise=None):
+    """main_source.py:591-628."""
+    gt = one_hot(label, n_class).to(img.dtype)
+    batch = embed({"img": img, "venous_pancreas_only": gt}, "img", "pred", test_mode=True, noise=noise)
+    batch["gt"] = gt
+    d = lambda key: 1 - avg_dsc(batch, key, "gt", botindex=1, topindex=n_class, eps=eps)
+    recon, inpaint = d("gt_recon"), d("seg_recon")
+    kl = KLloss(batch, mean_key="latent_code_gt", std_key="latent_code_std")
+    final = inpaint + 0.00002 * kl + recon
+    return final, {"recon_loss": recon, "inpaint_loss": inpaint, "kl_loss": kl, "batch": batch}
+
+
+def sep_joint_train_losses(joint, teacher, img, label, eps=EPS_MAIN_SOURCE, n_class=2):
+    """main_source.py:629-659."""
+    batch = {"img": img, "gt": one_hot(label, n_class).to(img.dtype)}
+    batch = joint(batch, "img", "pred", "recon")
+    with torch.no_grad():
+        tb = teacher({"img": img}, "img", "pred_tea", "recon_tea")
+    batch["pred_tea"], batch["recon_tea"] = tb["pred_tea"], tb["recon_tea"]
+    kw = dict(botindex=1, topindex=n_class, return_mean=False, eps=eps)
+    recon = avg_dsc(batch, "pred", "recon", **kw)
+    recon_tea = avg_dsc(batch, "pred_tea", "recon_tea", **kw)
+    dsc = avg_dsc(batch, "pred", "pred_tea", **kw)
+    final = 0.1 * (1 - torch.mean(recon)) + 1 - torch.mean(dsc * recon_tea ** 2)
+    return final, {"recon_loss": 1 - torch.mean(recon), "dice_loss": 1 - torch.mean(dsc), "batch": batch}
+
+
+def discriminator_train_loss(dis, mask, score):
+    """main_target.py:491-501."""
+    out = dis(mask)
+    final = torch.square(score.to(out) - out).mean()
+    return final, {"final_loss": final, "score_out": out}
+
+
+def domain_adaptation_dis_losses(student, teacher_seg, img, label, lambda_vae=1.0, epoch=1, lambda_vae_warmup=0, eps=EPS_EVALUATION, n_class=2):
+    """main_target.py:696-732."""
+    batch = {"img": img, "gt": one_hot(label, n_class).to(img.dtype)}
+    batch = student(batch, "img", "pred", "score", dropout=True)
+    with torch.no_grad():
+        batch = teacher_seg(batch, "img", "fake")
+    batch["fake"] = binarize(batch["fake"])
+    dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=eps)
+    fake_loss = 1 - avg_dsc(batch, "pred", "fake", botindex=1, topindex=n_class, eps=eps)
+    dis_loss = 1 - batch["score"].mean()
+    lam = lambda_vae if epoch >= lambda_vae_warmup else lambda_vae * epoch / lambda_vae_warmup
+    final = lam * dis_loss + fake_loss
+    return final, {"discriminator_loss": dis_loss, "dice_loss_fake": fake_loss, "dice_loss": dsc_loss, "batch": batch}
+
+
 def test_time_finetune(model, model_ft, teacher, img, label, steps, lr=1e-2, weight_decay=0.0, lambda_vae=1.0,
                        domain_loss_type=0, kl=False, only_pseudo=False, use_confident_binarize=False, n_class=2):
     """Per-case test-time training, main_target.py:809-900: model_ft starts from model's weights (:811), then `steps`

@@ -43,3 +43,15 @@ def test_main_source_joint_train_then_main_target_domain_adaptation(tmp_path):
                str(tmp_path))
     assert "validation result without finetuning" in out and "Finished Training" in out
     assert json.load(open(tmp_path / "tensorboard" / "tgt_ft" / "score_0.json"))
+
+
+def test_remaining_methods_run_end_to_end(tmp_path):
+    """sep_joint_train / embed_train / refine_vae (main_source.py) and discriminator_train / domain_adaptation_dis
+    (main_target.py) through the native entry points on synthetic volumes."""
+    common = ["--size", "64", "-b", "1", "-E", "1", "--eval_epoch", "1", "--save_epoch", "1", "--synthetic_train", "2",
+              "--synthetic_val", "1", "--max_iters", "2", "--display_freq", "1"]
+    for script, method, extra in (("main_source.py", "sep_joint_train", []), ("main_source.py", "embed_train", []),
+                                  ("main_source.py", "refine_vae", []), ("main_target.py", "discriminator_train", []),
+                                  ("main_target.py", "domain_adaptation_dis", ["--train_first_epoch"])):
+        out = _run([os.path.join(REPO, script), "m_" + method, "-M", method] + common + extra, str(tmp_path))
+        assert "Finished Training" in out and "loss:" in out, (method, out[-1500:])

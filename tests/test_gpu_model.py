@@ -470,3 +470,78 @@ def test_seg32_dropout_with_exported_masks_vs_oracle(monkeypatch):
         over += lim > 1e-2
         assert mine <= lim, (n, mine, lim, theirs)
     print("\nseg32 dropout: %d gradient tensors had a limit above 1e-2" % over)
+
+
+# ---- remaining train methods on the native modules (goldens: oracle/make_golden.py gold_methods) ---------------------------------------
+def _embed_native(M, O):
+    emb = M.Embed(models=[M.Encoder(1, 128, norm_type=1), M.VAE(2, 2, norm_type=1, dim=128), M.Fusion(1, 2, 2, norm_type=1)])
+    O.deterministic_fill_(emb, seed=8)
+    return emb.cuda()
+
+
+def test_embed_train_and_refine_vae128_vs_reference_golden():
+    """main_source.py:546-628: the embed_train and refine_vae loss bodies (train.embed_train_losses / refine_vae_losses) on the native Embed."""
+    M, O, T = _mods()
+    g = G.load("embed_train128")
+    emb = _embed_native(M, O)
+    img, lab = O.synthetic_image(1, 128, seed=2).cuda(), O.synthetic_label(1, 128, seed=3).cuda()
+    z = torch.from_numpy(g["z"]).cuda()
+    final, aux = T.embed_train_losses(emb, img, lab, noise=z)
+    final.backward()
+    for k_o, k_g in (("dice_loss1", "dice_loss1"), ("dice_loss2", "dice_loss2"), ("recon_loss", "recon_loss"), ("inpaint_loss", "inpaint_loss"),
+                     ("kl_loss", "kl"), ("mse_loss", "mse")):
+        G.scalar_close(g, k_g, aux[k_o].item(), RTOL_FP32)
+    G.scalar_close(g, "final", final.item(), RTOL_FP32)
+    for pre, mod in (("enc", emb.Encoder), ("vae", emb.Vae), ("fus", emb.Fusion)):
+        G.vacuity(G.check_grads_f64(g, pre, [(n, p.grad) for n, p in mod.named_parameters()], floor=RTOL_GRAD_FP32), "embed_train " + pre)
+    emb2 = _embed_native(M, O)
+    for p in emb2.Encoder.parameters():
+        p.requires_grad = False
+    rfinal, _ = T.refine_vae_losses(emb2, img, lab, noise=z)
+    rfinal.backward()
+    G.scalar_close(g, "refine_final", rfinal.item(), RTOL_FP32)
+    G.check_grads_f64(g, "rvae", [(n, p.grad) for n, p in emb2.Vae.named_parameters()], floor=RTOL_GRAD_FP32)
+    G.check_grads_f64(g, "rfus", [(n, p.grad) for n, p in emb2.Fusion.named_parameters()], floor=RTOL_GRAD_FP32)
+    assert all(p.grad is None for p in emb2.Encoder.parameters())
+
+
+def test_sep_joint_train128_vs_reference_golden():
+    """main_source.py:629-659: per-sample Dice scores, the teacher's squared reconstruction score as weight."""
+    M, O, T = _mods()
+    g = G.load("sep_joint128")
+    student, teacher = _build_joint(M, O, 128), _build_joint(M, O, 128)
+    O.deterministic_fill_(teacher.Seg, seed=1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    final, aux = T.sep_joint_train_losses(student, teacher, O.synthetic_image(1, 128, 2).cuda(), O.synthetic_label(1, 128, 3).cuda())
+    final.backward()
+    G.scalar_close(g, "final", final.item(), RTOL_FP32)
+    G.vacuity(G.check_grads_f64(g, "seg", [(n, p.grad) for n, p in student.Seg.named_parameters()], floor=RTOL_GRAD_FP32), "sep_joint128")
+
+
+def test_domain_adaptation_dis_and_discriminator_train128_vs_reference_golden():
+    """main_target.py:696-732 (Joint2 student, frozen discriminator and pseudo-label teacher) and :491-501 (score regression)."""
+    M, O, T = _mods()
+    g = G.load("da_dis128")
+    seg, dis = _fill(M.Segmentation(1, 2, norm_type=1), 0, O), _fill(M.Encoder(1, 1, norm_type=1), 4, O)
+    j2 = M.Joint2(models=[seg, dis])
+    for p in j2.Dis.parameters():
+        p.requires_grad = False
+    teacher = _fill(M.Segmentation(1, 2, norm_type=1), 1, O)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    img, lab = O.synthetic_image(1, 128, 2).cuda(), O.synthetic_label(1, 128, 3).cuda()
+    final, aux = T.domain_adaptation_dis_losses(j2, teacher, img, lab, lambda_vae=1.0, epoch=1, lambda_vae_warmup=0)
+    final.backward()
+    G.scalar_close(g, "final", final.item(), RTOL_FP32)
+    for k_o, k_g in (("dice_loss", "dice_loss"), ("dice_loss_fake", "fake_loss"), ("discriminator_loss", "dis_loss")):
+        G.scalar_close(g, k_g, aux[k_o].item(), RTOL_FP32)
+    G.vacuity(G.check_grads_f64(g, "seg", [(n, p.grad) for n, p in j2.Seg.named_parameters()], floor=RTOL_GRAD_FP32), "da_dis128")
+    dis2 = _fill(M.Encoder(1, 1, norm_type=1), 4, O)
+    dl, daux = T.discriminator_train_loss(dis2, lab.float(), torch.tensor([[0.7]]).cuda())
+    dl.backward()
+    G.scalar_close(g, "dtrain_loss", dl.item(), RTOL_FP32)
+    tight = [(n, p.grad) for n, p in dis2.named_parameters() if n.startswith(("fc", "down5."))]
+    loose = [(n, p.grad) for n, p in dis2.named_parameters() if not n.startswith(("fc", "down5."))]
+    G.check_grads_f64(g, "dis", tight, floor=RTOL_GRAD_FP32)
+    G.check_grads_f64(g, "dis", loose, floor=3e-2)          # see test_encoder128: one ReLU-threshold voxel can move the upstream gradients ~1e-2

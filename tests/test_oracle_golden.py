@@ -240,3 +240,70 @@ def test_embed128():
         G.check_tensor(g, k, batch[k], k=512, rtol=1e-4)
     for pre, mod in (("enc", emb.Encoder), ("vae", emb.Vae), ("fus", emb.Fusion)):
         G.check_grads(g, pre, [(n, p.grad) for n, p in mod.named_parameters()], rtol=2e-4)
+
+
+# ---- remaining train methods (oracle/make_golden.py: gold_methods) --------------------------------------------------------------------
+def _embed(spatial=128):
+    emb = O.Embed([O.Encoder(1, 128, norm_type=1, spatial=spatial), O.VAE(2, 2, norm_type=1, dim=128, spatial=spatial), O.Fusion(1, 2, 2, norm_type=1)])
+    return O.deterministic_fill_(emb, seed=8)
+
+
+def test_embed_train_and_refine_vae128():
+    """main_source.py:546-628: embed_train's and refine_vae's loss bodies restated in the oracle, against the reference modules."""
+    g = G.load("embed_train128")
+    emb = _embed()
+    img, lab = O.synthetic_image(1, 128, seed=2), O.synthetic_label(1, 128, seed=3)
+    z = torch.from_numpy(g["z"])
+    final, aux = O.embed_train_losses(emb, img, lab, noise=z)
+    final.backward()
+    for k_o, k_g in (("dice_loss1", "dice_loss1"), ("dice_loss2", "dice_loss2"), ("recon_loss", "recon_loss"), ("inpaint_loss", "inpaint_loss"),
+                     ("kl_loss", "kl"), ("mse_loss", "mse")):
+        assert aux[k_o].item() == pytest.approx(float(g[k_g]), rel=1e-5), k_o
+    assert final.item() == pytest.approx(float(g["final"]), rel=1e-6)
+    for pre, mod in (("enc", emb.Encoder), ("vae", emb.Vae), ("fus", emb.Fusion)):
+        G.check_grads(g, pre, [(n, p.grad) for n, p in mod.named_parameters()], rtol=2e-4, dead=G.is_dead_bias)
+    emb2 = _embed()
+    for p in emb2.Encoder.parameters():
+        p.requires_grad = False
+    rfinal, _ = O.refine_vae_losses(emb2, img, lab, noise=z)
+    rfinal.backward()
+    assert rfinal.item() == pytest.approx(float(g["refine_final"]), rel=1e-6)
+    G.check_grads(g, "rvae", [(n, p.grad) for n, p in emb2.Vae.named_parameters()], rtol=2e-4, dead=G.is_dead_bias)
+    G.check_grads(g, "rfus", [(n, p.grad) for n, p in emb2.Fusion.named_parameters()], rtol=2e-4, dead=G.is_dead_bias)
+
+
+def test_sep_joint_train128():
+    g = G.load("sep_joint128")
+    student, teacher = O.build_joint(128), O.build_joint(128)
+    O.deterministic_fill_(teacher.Seg, seed=1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    final, aux = O.sep_joint_train_losses(student, teacher, O.synthetic_image(1, 128, 2), O.synthetic_label(1, 128, 3))
+    final.backward()
+    assert final.item() == pytest.approx(float(g["final"]), rel=1e-6)
+    assert aux["recon_loss"].item() == pytest.approx(1 - float(g["recon"].mean()), rel=1e-5)
+    G.check_grads(g, "seg", [(n, p.grad) for n, p in student.Seg.named_parameters()], rtol=1e-4, dead=G.is_dead_bias)
+
+
+def test_domain_adaptation_dis_and_discriminator_train128():
+    g = G.load("da_dis128")
+    seg = O.deterministic_fill_(O.Segmentation(1, 2, norm_type=1), seed=0)
+    dis = O.deterministic_fill_(O.Encoder(1, 1, norm_type=1), seed=4)
+    j2 = O.Joint2([seg, dis])
+    for p in j2.Dis.parameters():
+        p.requires_grad = False
+    teacher = O.deterministic_fill_(O.Segmentation(1, 2, norm_type=1), seed=1)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    img, lab = O.synthetic_image(1, 128, 2), O.synthetic_label(1, 128, 3)
+    final, aux = O.domain_adaptation_dis_losses(j2, teacher, img, lab, lambda_vae=1.0, epoch=1, lambda_vae_warmup=0)
+    final.backward()
+    assert final.item() == pytest.approx(float(g["final"]), rel=1e-6)
+    for k_o, k_g in (("dice_loss", "dice_loss"), ("dice_loss_fake", "fake_loss"), ("discriminator_loss", "dis_loss")):
+        assert aux[k_o].item() == pytest.approx(float(g[k_g]), rel=1e-5), k_o
+    G.check_grads(g, "seg", [(n, p.grad) for n, p in j2.Seg.named_parameters()], rtol=1e-4, dead=G.is_dead_bias)
+    dis2 = O.deterministic_fill_(O.Encoder(1, 1, norm_type=1), seed=4)
+    dl, daux = O.discriminator_train_loss(dis2, lab.float(), torch.tensor([[0.7]]))
+    dl.backward()
+    assert dl.item() == pytest.approx(float(g["dtrain_loss"]), rel=1e-5)
+    G.check_grads(g, "dis", [(n, p.grad) for n, p in dis2.named_parameters()], rtol=2e-4, dead=G.is_dead_bias)

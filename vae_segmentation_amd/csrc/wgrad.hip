@@ -403,7 +403,10 @@ struct G3Group {
 };
 
 template <int CB, int KIND, typename T = unsigned short>
-__global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
+#ifndef VS_G3B_WAVES
+#define VS_G3B_WAVES 2
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CB == 8 ? VS_G3B_WAVES : 2, CB == 8 ? VS_G3B_WAVES : 2))) void g3b_group_kernel(const G3Group grp) {
     const int b = blockIdx.x;
     int l = 0;
 #pragma unroll

@@ -21,7 +21,7 @@ import torch.distributed as dist
 from . import ddp, ops, optim
 from . import train as T
 from .evaluation import EPS_EVALUATION, EPS_MAIN_SOURCE, avg_dsc
-from .modules import Joint, Segmentation, VAE, set_kernel_dtype
+from .modules import Embed, Encoder, Fusion, Joint, Joint2, Segmentation, VAE, set_kernel_dtype
 
 LABEL_KEY, IMG_KEY = "venous_pancreas", "venous"          # main_source.py:355-356
 
@@ -134,6 +134,12 @@ def validate(method, model, loader, nc):
         gt = ops.onehot(batch[LABEL_KEY].cuda(non_blocking=True), nc)
         if method == "vae_train":
             pred, _, _ = model(gt, if_random=False)
+        elif method == "discriminator_train":                              # no segmentation to score: report 1 - squared error of the score
+            tgt = batch[LABEL_KEY].float().mean((1, 2, 3, 4)).view(-1, 1).cuda() * 4
+            scores[i] = float(1 - ((model(batch[LABEL_KEY].cuda().float()) - tgt) ** 2).mean().item())
+            continue
+        elif method in ("embed_train", "refine_vae"):                      # main_source.py:735-745: Embed in test mode
+            pred = model({IMG_KEY: batch[IMG_KEY].cuda(non_blocking=True), "venous_pancreas_only": gt}, IMG_KEY, "pred", test_mode=True)["pred"]
         else:
             seg = model.Seg if hasattr(model, "Seg") else model
             pred = seg({IMG_KEY: batch[IMG_KEY].cuda(non_blocking=True)}, IMG_KEY, "pred")["pred"]
@@ -178,15 +184,26 @@ def run(args, side="source"):
     elif method == "seg_train":
         model = Segmentation(n_channels=1, n_class=nc, norm_type=1)
         trainable = model
-    elif method in ("joint_train", "domain_adaptation"):
+    elif method in ("joint_train", "domain_adaptation", "sep_joint_train"):
         model = build_joint(args)
         trainable = model.Seg
-        if method == "domain_adaptation":
-            teacher = build_joint(args)
+        if method in ("domain_adaptation", "sep_joint_train"):
+            teacher = build_joint(args)                                     # main_target.py:323-328 / main_source.py:270-273 (tea_model)
+    elif method in ("embed_train", "refine_vae"):                          # main_source.py:259-264
+        model = Embed(models=[Encoder(n_channels=1, dim=128, norm_type=1, spatial=args.size),
+                              VAE(n_channels=nc, n_class=nc, norm_type=1, dim=128, spatial=args.size),
+                              Fusion(n_channels_img=1, n_channels_mask=nc, n_class=nc, norm_type=1)])
+        trainable = model
+    elif method == "discriminator_train":                                  # main_target.py:318-319
+        model = Encoder(n_channels=1, dim=1, norm_type=1, spatial=args.size)
+        trainable = model
+    elif method == "domain_adaptation_dis":                                # main_target.py:337-342
+        model = Joint2(models=[Segmentation(n_channels=1, n_class=nc, norm_type=1), Encoder(n_channels=1, dim=1, norm_type=1, spatial=args.size)],
+                       seg_dropout=getattr(args, "seg_dropout", 0.0))
+        trainable = model.Seg
+        teacher = Segmentation(n_channels=1, n_class=nc, norm_type=1)
     else:
-        raise NotImplementedError("method %r: native kernels cover vae_train, seg_train, joint_train and domain_adaptation "
-                                  "(the methods the reference's launch scripts use, SURVEY.md §2.1); embed_train / refine_vae / "
-                                  "sep_joint_train / discriminator methods are listed as next in SURVEY.md §8f" % method)
+        raise ValueError("Try a valid method.")                           # main_source.py:275 / main_target.py:343
     model = model.cuda()
     if args.load_prefix:
         load_prefix(model.Seg if hasattr(model, "Seg") else model, args.load_prefix, args.checkpoint_name)
@@ -194,9 +211,21 @@ def run(args, side="source"):
         load_prefix(model.Vae, args.load_prefix_vae)
     if args.load_prefix_joint and hasattr(model, "Seg"):
         load_prefix(model, args.load_prefix_joint, args.checkpoint_name)
-    if hasattr(model, "Vae"):
+    if hasattr(model, "Vae") and method != "refine_vae":
         freeze(model.Vae)                                                   # main_source.py:343-346
-    if teacher is not None:
+    if method == "refine_vae":                                              # main_source.py:347-353: VAE encoder half frozen, decoder trained
+        for name, prm in model.Vae.named_parameters():
+            prm.requires_grad = name.split(".")[0] not in ("in_block", "down1", "down2", "down3", "down4", "down5", "fc_mean", "fc_std")
+        for prm in model.Encoder.parameters():                              # :596-597
+            prm.requires_grad = False
+    if method == "domain_adaptation_dis":
+        freeze(model.Dis)                                                   # main_target.py:407-411
+    if teacher is not None and method in ("sep_joint_train", "domain_adaptation_dis"):
+        teacher = teacher.cuda()
+        teacher.load_state_dict(model.state_dict() if method == "sep_joint_train" else model.Seg.state_dict())   # main_source.py:330-340 / main_target.py:366
+        freeze(teacher)
+        set_kernel_dtype(teacher, dtype)
+    elif teacher is not None:
         teacher = teacher.cuda()
         if getattr(args, "only_pseudo", False):
             # main_target.py:421-425: the loaded network becomes the frozen pseudo-label teacher, a freshly initialised one is trained
@@ -211,7 +240,7 @@ def run(args, side="source"):
         set_kernel_dtype(teacher, dtype)
     set_kernel_dtype(model, dtype)
 
-    if hasattr(model, "Seg"):
+    if hasattr(model, "Seg") and hasattr(model, "Vae"):
         groups = [{"params": list(model.Seg.parameters()), "lr": args.lr_seg, "model": "Seg"},
                   {"params": list(model.Vae.parameters()), "lr": args.lr_vae, "model": "Vae"}]
     else:
@@ -240,7 +269,11 @@ def run(args, side="source"):
     bs, side_ = args.batch_size, args.size
     img_buf = torch.zeros(bs, 1, side_, side_, side_, device="cuda")         # fixed-address inputs of the captured step
     lab_buf = torch.zeros(bs, 1, side_, side_, side_, device="cuda")
+    score_buf = torch.zeros(bs, 1, device="cuda")                           # discriminator_train's regression target (venous_score)
     cur = {"epoch": 0}
+    # the Embed methods draw VAE noise per call on the device and embed_train toggles requires_grad by epoch: launched eagerly
+    if method in ("embed_train", "refine_vae", "vae_train"):
+        use_graph = False
 
     def loss_fn():
         if method == "vae_train":
@@ -249,6 +282,18 @@ def run(args, side="source"):
             return T.seg_train_losses(model, img_buf, lab_buf, eps=eps, n_class=nc)
         if method == "joint_train":
             return T.joint_train_losses(model, img_buf, lab_buf, lambda_vae=lambda_vae, eps=eps, n_class=nc)
+        if method == "sep_joint_train":
+            return T.sep_joint_train_losses(model, teacher, img_buf, lab_buf, eps=eps, n_class=nc)
+        if method == "embed_train":
+            return T.embed_train_losses(model, img_buf, lab_buf, eps=eps, n_class=nc)
+        if method == "refine_vae":
+            return T.refine_vae_losses(model, img_buf, lab_buf, eps=eps, n_class=nc)
+        if method == "discriminator_train":
+            return T.discriminator_train_loss(model, lab_buf, score_buf)
+        if method == "domain_adaptation_dis":
+            return T.domain_adaptation_dis_losses(model, teacher, img_buf, lab_buf, lambda_vae=lambda_vae, epoch=cur["epoch"],
+                                                  lambda_vae_warmup=warmup_epochs,
+                                                  use_confident_binarize=getattr(args, "use_confident_binarize", False), eps=eps, n_class=nc)
         return T.domain_adaptation_losses(model, teacher, img_buf, lab_buf, lambda_vae=lambda_vae,
                                           domain_loss_type=getattr(args, "domain_loss_type", 0), kl=getattr(args, "kl", False),
                                           use_confident_binarize=getattr(args, "use_confident_binarize", False), eps=eps, n_class=nc,
@@ -269,7 +314,11 @@ def run(args, side="source"):
         cur["epoch"] = epoch
         if sampler is not None:
             sampler.set_epoch(epoch)
-        skip_da = method == "domain_adaptation" and epoch == 0 and not getattr(args, "train_first_epoch", False)    # main_target.py:506: `if epoch == 0: continue`
+        skip_da = method in ("domain_adaptation", "domain_adaptation_dis") and epoch == 0 and not getattr(args, "train_first_epoch", False)    # main_target.py:506,697: `if epoch == 0: continue`
+        if method == "embed_train":                                         # main_source.py:550-554: the image encoder trains on odd epochs only
+            for prm in model.Encoder.parameters():
+                prm.requires_grad = epoch % 2 == 1
+            params = [p for p in trainable.parameters() if p.requires_grad]
         if not args.test_only and not skip_da:
             model.train()
             if hasattr(model, "Vae"):
@@ -285,6 +334,8 @@ def run(args, side="source"):
             for idx, batch in enumerate(train_loader):
                 img_buf.copy_(batch[IMG_KEY], non_blocking=True)
                 lab_buf.copy_(batch[LABEL_KEY], non_blocking=True)
+                if method == "discriminator_train":          # synthetic stand-in for the venous_score field: a function of the mask
+                    score_buf.copy_(batch[LABEL_KEY].float().mean((1, 2, 3, 4)).view(-1, 1) * 4, non_blocking=True)
                 if method == "domain_adaptation" and getattr(args, "pseudo_save_epoch", 0):
                     # EMA teacher (main_target.py:508-518): every `pseudo_save_epoch` epochs, at the first iteration of an epoch slice or
                     # every iteration; never in epoch 0

@@ -6,6 +6,8 @@ HIP-graph replayed step.  Each *_losses function mirrors the loss arithmetic of 
   vae_train_losses          main_source.py:389-413     (1-Dice(recon,gt)) + 2e-5*KL, z = mean + noise*std*0.35
   domain_adaptation_losses  main_target.py:520-596     student/teacher, domain_loss_type 0 / 8 / 9, eps 1e-6
   finetune_losses / TestTimeFinetune   main_target.py:809-953   per-case test-time training + hard-Dice validation
+  embed_train_losses / refine_vae_losses / sep_joint_train_losses    main_source.py:546-659
+  discriminator_train_loss / domain_adaptation_dis_losses            main_target.py:491-501, 696-732
 """
 import os
 
@@ -107,6 +109,79 @@ def domain_adaptation_losses(student, teacher, img, label, lambda_vae=1.0, domai
         final = lambda_vae * epoch / lambda_vae_warmup * recon_loss + fake_loss
     return final, {"recon_loss": recon_loss, "kl_loss": klloss, "dice_loss": dsc_loss, "dice_loss_fake": fake_loss,
                    "batch": batch}
+
+
+# ----------------------------------------------------------------------------------------------------
+# remaining train methods of the reference: loss bodies on the native modules
+# ----------------------------------------------------------------------------------------------------
+def embed_train_losses(embed, img, label, eps=EPS_MAIN_SOURCE, n_class=2, noise=None):
+    """main_source.py:546-590 (`embed_train`): Embed(Encoder, VAE, Fusion) in test_mode; the caller toggles the Encoder's requires_grad by
+    epoch parity (:550-554).  final = (dsc1 + dsc2 + inpaint) / 3 + mse / 10 + 2e-5 * KL + recon."""
+    gt = ops.onehot(label, n_class)
+    batch = embed({"img": img, "venous_pancreas_only": gt}, "img", "pred", test_mode=True, noise=noise)
+    batch["gt"] = gt
+    d = lambda key: 1 - avg_dsc(batch, key, "gt", botindex=1, topindex=n_class, eps=eps)
+    dsc1, dsc2, recon, inpaint = d("pred"), d("init_seg"), d("gt_recon"), d("seg_recon")
+    kl = KLloss(batch, mean_key="latent_code_gt", std_key="latent_code_std")
+    mse = torch.mean((batch["latent_code"] - batch["latent_code_gt"]) ** 2)                    # nn.MSELoss() on two (B, dim) codes
+    final = (dsc1 + dsc2 + inpaint) / 3 + mse / 10 + 0.00002 * kl + recon
+    return final, {"dice_loss1": dsc1, "dice_loss2": dsc2, "mse_loss": mse, "kl_loss": kl, "recon_loss": recon, "inpaint_loss": inpaint,
+                   "batch": batch}
+
+
+def refine_vae_losses(embed, img, label, eps=EPS_MAIN_SOURCE, n_class=2, noise=None):
+    """main_source.py:591-628 (`refine_vae`): Encoder frozen by the caller (:596-597); final = inpaint + 2e-5 * KL + recon."""
+    gt = ops.onehot(label, n_class)
+    batch = embed({"img": img, "venous_pancreas_only": gt}, "img", "pred", test_mode=True, noise=noise)
+    batch["gt"] = gt
+    d = lambda key: 1 - avg_dsc(batch, key, "gt", botindex=1, topindex=n_class, eps=eps)
+    recon, inpaint, init = d("gt_recon"), d("seg_recon"), d("init_seg")
+    kl = KLloss(batch, mean_key="latent_code_gt", std_key="latent_code_std")
+    final = inpaint + 0.00002 * kl + recon
+    return final, {"recon_loss": recon, "inpaint_loss": inpaint, "kl_loss": kl, "init_loss": init, "batch": batch}
+
+
+def sep_joint_train_losses(joint, teacher, img, label, eps=EPS_MAIN_SOURCE, n_class=2):
+    """main_source.py:629-659 (`sep_joint_train`): per-sample Dice scores (return_mean=False) of the student against its own VAE
+    reconstruction, of the teacher against its reconstruction, and of the student against the teacher's prediction, the latter weighted by
+    the teacher's squared reconstruction score:  final = 0.1 * (1 - mean(recon)) + 1 - mean(dsc * recon_tea^2).
+    (The reference leaves autograd on for the teacher pass; its parameters are frozen and its inputs carry no gradient, so no_grad here
+    changes nothing but memory.)"""
+    batch = {"img": img, "gt": ops.onehot(label, n_class)}
+    batch = joint(batch, "img", "pred", "recon")
+    with torch.no_grad():
+        tb = teacher({"img": img}, "img", "pred_tea", "recon_tea")
+    batch["pred_tea"], batch["recon_tea"] = tb["pred_tea"], tb["recon_tea"]
+    kw = dict(botindex=1, topindex=n_class, return_mean=False, eps=eps)
+    recon = avg_dsc(batch, "pred", "recon", **kw)
+    recon_tea = avg_dsc(batch, "pred_tea", "recon_tea", **kw)
+    dsc = avg_dsc(batch, "pred", "pred_tea", **kw)
+    final = 0.1 * (1 - torch.mean(recon)) + 1 - torch.mean(dsc * recon_tea ** 2)
+    return final, {"recon_loss": 1 - torch.mean(recon), "dice_loss": 1 - torch.mean(dsc), "batch": batch}
+
+
+def discriminator_train_loss(dis, mask, score):
+    """main_target.py:491-501 (`discriminator_train`): the Encoder regresses a quality score of a (B,1,D,H,W) mask; mean squared error."""
+    out = dis(mask)
+    final = torch.mean((score.to(out) - out) ** 2)
+    return final, {"final_loss": final, "score_out": out}
+
+
+def domain_adaptation_dis_losses(student, teacher_seg, img, label, lambda_vae=1.0, epoch=1, lambda_vae_warmup=0,
+                                 use_confident_binarize=False, eps=EPS_EVALUATION, n_class=2):
+    """main_target.py:696-732 (`domain_adaptation_dis`): student = Joint2(Seg, Dis) with dropout flag on, teacher = a frozen Segmentation
+    giving the pseudo-label; final = lambda * (1 - mean(score)) + (1 - Dice(pred, pseudo)), lambda ramped over lambda_vae_warmup epochs."""
+    batch = {"img": img, "gt": ops.onehot(label, n_class)}
+    batch = student(batch, "img", "pred", "score", dropout=True)
+    with torch.no_grad():
+        batch = teacher_seg(batch, "img", "fake")
+    batch["fake"] = confident_binarize(batch["fake"]) if use_confident_binarize else binarize(batch["fake"])
+    dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=eps)
+    fake_loss = 1 - avg_dsc(batch, "pred", "fake", botindex=1, topindex=n_class, eps=eps)
+    dis_loss = 1 - batch["score"].mean()
+    lam = lambda_vae if epoch >= lambda_vae_warmup else lambda_vae * epoch / lambda_vae_warmup
+    final = lam * dis_loss + fake_loss
+    return final, {"discriminator_loss": dis_loss, "dice_loss_fake": fake_loss, "dice_loss": dsc_loss, "batch": batch}
 
 
 class GraphedStep:
