@@ -136,6 +136,9 @@ int vs_conv_wgrad(const void* p, const double* p_stats, const void* q, const dou
  * kernel instantiation share one grid, all slab reductions share one.  Per layer the arguments mean what they mean in
  * vs_conv_wgrad; bias_g != NULL additionally requests db[c] = sum over bias_rows of bias_g[bias_rows][bias_c_ch],
  * c < bias_c_real (fixed summation order: bitwise reproducible, unlike vs_bias_grad's float atomics).
+ * Descriptors that share `dw` (and `db`) are the uses of ONE weight in this backward pass (a network applied several times, e.g. the VAE
+ * inside Embed, joint_model.py:469-500): their contributions are summed — the slabs of all uses feed one reduction — as autograd's
+ * accumulation would, without an add launch per use.
  * workspace: vs_conv_wgrad_multi_workspace_bytes() bytes for the same (descs, count, dtype), contents undefined. */
 typedef struct vs_wgrad_desc {
     const void* p; const double* p_stats;
@@ -152,6 +155,8 @@ int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* workspace, 
                         float eps, void* stream);
 /* db[c] = sum over rows of g[rows][c_ch], c < c_real (bias gradient of a conv whose bias is live). */
 int vs_bias_grad(const void* g, float* db, long long rows, int c_ch, int c_real, int dtype, void* stream);
+/* same; accumulate != 0 adds to db instead of overwriting it (a bias used several times in one backward pass) */
+int vs_bias_grad_acc(const void* g, float* db, long long rows, int c_ch, int c_real, int dtype, int accumulate, void* stream);
 
 /* ---- InstanceNorm3d + ReLU ---------------------------------------------------------------------- */
 /* (sum,sumsq) per (n,c) of x, accumulated into stats (caller zeroes) — only needed when the producer

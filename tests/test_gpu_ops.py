@@ -510,3 +510,41 @@ def test_dice_loss_sum_matches_reference_spelling(k):
         for a, r in zip(gts, t_ref):
             assert relerr(a, r.grad) < 2e-5
     assert abs(outs[True][0] - outs[False][0]) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_weight_used_several_times_in_one_backward(dtype):
+    """A network applied more than once per forward (the VAE inside Embed runs three times, joint_model.py:469-500) uses each weight
+    several times in one backward pass: the deferred grouped launches must SUM the uses (descriptors sharing their destination are
+    reduced together) — all three conv kinds, live biases included, against autograd on the CPU."""
+    ops = _ops()
+    n, c = 2, 16
+    xs_ = [rnd(n, c, 8, 8, 16, seed=50), rnd(n, c, 4, 6, 8, seed=51), rnd(n, c, 12, 4, 8, seed=52)]         # three uses, three sizes
+    w3 = q(rnd(c, c, 3, 3, 3, seed=53, scale=0.05), dtype)
+    w2, b2 = q(rnd(c, c, 2, 2, 2, seed=54, scale=0.1), dtype), rnd(c, seed=55, scale=0.1)
+    wt, bt = q(rnd(c, c, 2, 2, 2, seed=56, scale=0.1), dtype), rnd(c, seed=57, scale=0.1)
+    ref = [t.clone().requires_grad_(True) for t in (w3, w2, b2, wt, bt)]
+    gpu = [t.clone().cuda().requires_grad_(True) for t in (w3, w2, b2, wt, bt)]
+    total_ref, total = 0.0, None
+    ops.stats_arena_begin(torch.device("cuda", 0))
+    for i, x in enumerate(xs_):
+        xq = q(x, dtype)
+        a = in_relu(xq)
+        y3 = F.conv3d(a, ref[0], None, padding=1)
+        y2 = F.conv3d(a, ref[1], ref[2], stride=2)
+        yt = F.conv_transpose3d(a, ref[3], ref[4], stride=2)
+        g3, g2, gt_ = rnd(*y3.shape, seed=60 + i), rnd(*y2.shape, seed=70 + i), rnd(*yt.shape, seed=80 + i)
+        total_ref = total_ref + (y3 * q(g3, dtype)).sum() + (y2 * q(g2, dtype)).sum() + (yt * q(gt_, dtype)).sum()
+        x_cl = to_cl(x, c, dtype)
+        st = ops.instnorm_stats(x_cl)
+        o3, _ = ops.ConvK3.apply(x_cl, st, gpu[0], None)
+        o2 = ops.ConvK2S2.apply(x_cl, st, gpu[1], gpu[2])
+        ot = ops.ConvT2S2.apply(x_cl, st, gpu[3], gpu[4])
+        term = (o3.float() * to_cl(g3, c, dtype).float()).sum() + (o2.float() * to_cl(g2, c, dtype).float()).sum() + (ot.float() * to_cl(gt_, c, dtype).float()).sum()
+        total = term if total is None else total + term
+    total_ref.backward()
+    total.backward()
+    torch.cuda.synchronize()
+    tol = TOL[dtype] * 4
+    for name, r, gq_ in zip(("k3 weight", "k2s2 weight", "k2s2 bias", "convT weight", "convT bias"), ref, gpu):
+        assert relerr(gq_.grad.cpu(), r.grad) < tol, name

@@ -64,10 +64,14 @@ def test_grouped_weight_gradient_planning_without_gpu():
     assert ctypes.sizeof(ops.WgradDesc) == 112
     fake = 0x10000
 
-    def desc(n, d, h, w, m_ch, c_ch, kind, m_real=None, c_real=None, bias=False):
-        x = ops.WgradDesc(fake, None, fake, None, fake, None, None, 0, 0, 0, n, d, h, w, m_ch, c_ch, m_real or m_ch, c_real or c_ch, kind, 0)
+    counter = [0]
+
+    def desc(n, d, h, w, m_ch, c_ch, kind, m_real=None, c_real=None, bias=False, dw=None):
+        counter[0] += 1
+        dst = dw if dw is not None else fake + 0x100000 * counter[0]          # a destination of its own: descriptors sharing dw are parts of one gradient
+        x = ops.WgradDesc(fake, None, fake, None, dst, None, None, 0, 0, 0, n, d, h, w, m_ch, c_ch, m_real or m_ch, c_real or c_ch, kind, 0)
         if bias:
-            x.bias_g, x.db, x.bias_rows, x.bias_c_ch, x.bias_c_real = fake, fake, n * d * h * w, m_ch, m_real or m_ch
+            x.bias_g, x.db, x.bias_rows, x.bias_c_ch, x.bias_c_real = fake, dst + 0x80000, n * d * h * w, m_ch, m_real or m_ch
         return x
 
     layers = [desc(2, 96, 96, 96, 8, 8, VS_CONV_K3), desc(2, 48, 48, 48, 16, 16, VS_CONV_K3), desc(2, 6, 6, 6, 128, 128, VS_CONV_K3),
@@ -81,6 +85,14 @@ def test_grouped_weight_gradient_planning_without_gpu():
     assert lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(arr), len(layers), VS_F32) == max(single)
     assert lib.vs_conv_wgrad_multi(ctypes.addressof(arr), len(layers), None, 0, VS_BF16, 1e-5, None) == -1      # no workspace
     assert lib.vs_conv_wgrad_multi(ctypes.addressof(arr), len(layers), fake, 16, VS_BF16, 1e-5, None) == -4      # VS_EWORKSPACE
+    # a weight used several times in one pass: descriptors with the same destination are summed — their slabs lie side by side
+    one = (ops.WgradDesc * 1)(desc(1, 24, 24, 24, 32, 32, VS_CONV_K3, dw=fake))
+    two = (ops.WgradDesc * 2)(desc(1, 24, 24, 24, 32, 32, VS_CONV_K3, dw=fake), desc(1, 12, 12, 12, 32, 32, VS_CONV_K3, dw=fake))
+    for dt in (VS_BF16, VS_F32):
+        assert lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(two), 2, dt) > lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(one), 1, dt) > 0
+    mixed = (ops.WgradDesc * 2)(desc(1, 8, 8, 8, 32, 32, VS_CONV_K3, dw=fake), desc(1, 8, 8, 8, 32, 16, VS_CONV_K3, dw=fake))   # same destination, other layer
+    assert lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(mixed), 2, VS_BF16) == 0
+    assert lib.vs_conv_wgrad_multi(ctypes.addressof(mixed), 2, fake, 1 << 24, VS_BF16, 1e-5, None) == -1
     bad = (ops.WgradDesc * 1)(desc(2, 8, 8, 8, 12, 8, VS_CONV_K3))                                               # channels not a multiple of 8
     assert lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(bad), 1, VS_BF16) == 0
     assert lib.vs_conv_wgrad_multi(ctypes.addressof(bad), 1, fake, 1 << 20, VS_BF16, 1e-5, None) == -2

@@ -419,11 +419,17 @@ extern "C" int vs_instnorm_relu_bwd_pair(const void* g, const void* x1, const do
 }
 
 extern "C" int vs_bias_grad(const void* g, float* db, long long rows, int c_ch, int c_real, int dtype, void* stream) {
+    return vs_bias_grad_acc(g, db, rows, c_ch, c_real, dtype, 0, stream);
+}
+
+extern "C" int vs_bias_grad_acc(const void* g, float* db, long long rows, int c_ch, int c_real, int dtype, int accumulate, void* stream) {
     int rc = check_cl(g, 1, rows, c_ch, dtype);
     if (rc) return rc;
     if (!db || c_real <= 0 || c_real > c_ch) return VS_EINVAL;
-    hipError_t e = vs_zero_async(db, sizeof(float) * c_real, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    if (!accumulate) {
+        hipError_t e = vs_zero_async(db, sizeof(float) * c_real, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
     dim3 grid(row_blocks(rows, c_ch, dtype));
     dispatch_t(dtype, [&](auto* tag) {
         using T = TAG_T(tag);

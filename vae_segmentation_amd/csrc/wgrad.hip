@@ -403,10 +403,8 @@ struct G3Group {
 };
 
 template <int CB, int KIND, typename T = unsigned short>
-#ifndef VS_G3B_WAVES
-#define VS_G3B_WAVES 2
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CB == 8 ? VS_G3B_WAVES : 2, CB == 8 ? VS_G3B_WAVES : 2))) void g3b_group_kernel(const G3Group grp) {
+// (3 waves per SIMD for the 8-channel bucket — the compiler gets there without AGPRs — changed nothing: 2.814 vs 2.810 ms per step)
+__global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
     const int b = blockIdx.x;
     int l = 0;
 #pragma unroll
@@ -490,8 +488,19 @@ extern "C" size_t vs_conv_wgrad_workspace_bytes(int n, int dp, int hp, int wp, i
     return (size_t)ksplit * mbn * cbn * ncb * 256 * 4;
 }
 
+// reduce_slabs: how many slabs (starting at reduce_ws) the reduction that follows this layer's kernel sums; 0 = no reduction launch (a
+// later part of the same weight's gradient — a weight used several times in one backward pass — reduces all parts' slabs together)
+template <int CB, int KIND>
+static int g3_reduce_launch(const float* reduce_ws, float* dw, int m_real, int c_real, int mbn, int cbn, int slabs, hipStream_t s) {
+    using GEO = G3Geo<CB, KIND>;
+    const long long slab_elems = (long long)mbn * cbn * GEO::NCB * 256;
+    hipLaunchKernelGGL((g3_reduce_kernel<CB, KIND>), dim3(vs_ceil_div(slab_elems, 64)), dim3(1024), 0, s, reduce_ws, dw, m_real, c_real, mbn, cbn, slabs);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
 template <typename T, int CB, int KIND>
-static int g3b_run(const G3Params& p, float* dw, int m_real, int c_real, hipStream_t s) {
+static int g3b_run(const G3Params& p, float* dw, int m_real, int c_real, hipStream_t s, const float* reduce_ws, int reduce_slabs) {
     using GEO = G3Geo<CB, KIND>;
     constexpr size_t lds = G3B_LDS_Q + (size_t)GEO::QV * CB * 2;
     auto kern = g3b_kernel<CB, KIND, T>;
@@ -502,15 +511,11 @@ static int g3b_run(const G3Params& p, float* dw, int m_real, int c_real, hipStre
     }
     hipLaunchKernelGGL(kern, dim3(p.mbn * p.cbn, p.ksplit), dim3(256), lds, s, p);
     VS_CHECK_LAUNCH();
-    const long long slab_elems = (long long)p.mbn * p.cbn * GEO::NCB * 256;
-    hipLaunchKernelGGL((g3_reduce_kernel<CB, KIND>), dim3(vs_ceil_div(slab_elems, 64)), dim3(1024), 0, s, p.ws, dw, m_real,
-                       c_real, p.mbn, p.cbn, p.ksplit);
-    VS_CHECK_LAUNCH();
-    return VS_OK;
+    return reduce_slabs > 0 ? g3_reduce_launch<CB, KIND>(reduce_ws, dw, m_real, c_real, p.mbn, p.cbn, reduce_slabs, s) : VS_OK;
 }
 
 template <typename T, int CB, int KIND>
-static int g3_run(const G3Params& p, float* dw, int m_real, int c_real, hipStream_t s) {
+static int g3_run(const G3Params& p, float* dw, int m_real, int c_real, hipStream_t s, const float* reduce_ws, int reduce_slabs) {
     using GEO = G3Geo<CB, KIND>;
     constexpr size_t lds = G3_LDS_Q + (size_t)GEO::QV * CB * 4;
     auto kern = g3_kernel<T, CB, KIND>;
@@ -521,16 +526,24 @@ static int g3_run(const G3Params& p, float* dw, int m_real, int c_real, hipStrea
     }
     hipLaunchKernelGGL(kern, dim3(p.mbn * p.cbn, p.ksplit), dim3(256), lds, s, p);
     VS_CHECK_LAUNCH();
-    const long long slab_elems = (long long)p.mbn * p.cbn * GEO::NCB * 256;
-    hipLaunchKernelGGL((g3_reduce_kernel<CB, KIND>), dim3(vs_ceil_div(slab_elems, 64)), dim3(1024), 0, s, p.ws, dw, m_real,
-                       c_real, p.mbn, p.cbn, p.ksplit);
-    VS_CHECK_LAUNCH();
-    return VS_OK;
+    return reduce_slabs > 0 ? g3_reduce_launch<CB, KIND>(reduce_ws, dw, m_real, c_real, p.mbn, p.cbn, reduce_slabs, s) : VS_OK;
 }
+
+// One layer's kernel into `workspace`.  prior_slabs >= 0: reduce (prior_slabs + this layer's) slabs starting prior_slabs slabs BEFORE
+// `workspace` into dw; prior_slabs < 0: no reduction (an earlier part of a multi-use weight).  *slabs_out = this layer's slab count.
+static int wgrad_single(const void* P, const double* p_stats, const void* Q, const double* q_stats, float* dw,
+                        void* workspace, size_t workspace_bytes, int n, int dp, int hp, int wp, int m_ch, int c_ch,
+                        int m_real, int c_real, int kind, int dtype, float eps, void* stream, int prior_slabs, int* slabs_out);
 
 extern "C" int vs_conv_wgrad(const void* P, const double* p_stats, const void* Q, const double* q_stats, float* dw,
                              void* workspace, size_t workspace_bytes, int n, int dp, int hp, int wp, int m_ch, int c_ch,
                              int m_real, int c_real, int kind, int dtype, float eps, void* stream) {
+    return wgrad_single(P, p_stats, Q, q_stats, dw, workspace, workspace_bytes, n, dp, hp, wp, m_ch, c_ch, m_real, c_real, kind, dtype, eps, stream, 0, nullptr);
+}
+
+static int wgrad_single(const void* P, const double* p_stats, const void* Q, const double* q_stats, float* dw,
+                        void* workspace, size_t workspace_bytes, int n, int dp, int hp, int wp, int m_ch, int c_ch,
+                        int m_real, int c_real, int kind, int dtype, float eps, void* stream, int prior_slabs, int* slabs_out) {
     if (!P || !Q || !dw || !workspace) return VS_EINVAL;
     if (n <= 0 || n > G3_MAXN || dp <= 0 || hp <= 0 || wp <= 0) return VS_ESHAPE;
     if (m_ch % 8 || c_ch % 8 || m_real > m_ch || c_real > c_ch || m_real <= 0 || c_real <= 0) return VS_ESHAPE;
@@ -551,16 +564,20 @@ extern "C" int vs_conv_wgrad(const void* P, const double* p_stats, const void* Q
     p.inv_cnt_p = 1.0 / ((double)dp * hp * wp);
     p.inv_cnt_q = 1.0 / ((double)p.Dq * p.Hq * p.Wq);
     hipStream_t st = (hipStream_t)stream;
+    if (slabs_out) *slabs_out = p.ksplit;
+    const size_t slab_floats = (size_t)p.mbn * p.cbn * ncb * 256;
+    const float* rws = prior_slabs >= 0 ? (const float*)workspace - (size_t)prior_slabs * slab_floats : nullptr;
+    const int rsl = prior_slabs >= 0 ? prior_slabs + p.ksplit : 0;
 #define G3_GO(T) \
-    if (kind == VS_CONV_K3) return cbsz == 16 ? g3_run<T, 16, G3_K3>(p, dw, m_real, c_real, st) : g3_run<T, 8, G3_K3>(p, dw, m_real, c_real, st); \
-    return cbsz == 16 ? g3_run<T, 16, G3_K2S2>(p, dw, m_real, c_real, st) : g3_run<T, 8, G3_K2S2>(p, dw, m_real, c_real, st);
+    if (kind == VS_CONV_K3) return cbsz == 16 ? g3_run<T, 16, G3_K3>(p, dw, m_real, c_real, st, rws, rsl) : g3_run<T, 8, G3_K3>(p, dw, m_real, c_real, st, rws, rsl); \
+    return cbsz == 16 ? g3_run<T, 16, G3_K2S2>(p, dw, m_real, c_real, st, rws, rsl) : g3_run<T, 8, G3_K2S2>(p, dw, m_real, c_real, st, rws, rsl);
     if (dtype == VS_F32) { G3_GO(float) }
 #undef G3_GO
     // g3b_kernel addresses P and Q with signed 32-bit byte offsets
     if ((long long)n * dp * hp * wp * m_ch * 2 >= 2147483648ll || (long long)n * p.Dq * p.Hq * p.Wq * c_ch * 2 >= 2147483648ll) return VS_ESHAPE;
 #define G3B_GO(T) \
-    if (kind == VS_CONV_K3) return cbsz == 16 ? g3b_run<T, 16, G3_K3>(p, dw, m_real, c_real, st) : g3b_run<T, 8, G3_K3>(p, dw, m_real, c_real, st); \
-    return cbsz == 16 ? g3b_run<T, 16, G3_K2S2>(p, dw, m_real, c_real, st) : g3b_run<T, 8, G3_K2S2>(p, dw, m_real, c_real, st);
+    if (kind == VS_CONV_K3) return cbsz == 16 ? g3b_run<T, 16, G3_K3>(p, dw, m_real, c_real, st, rws, rsl) : g3b_run<T, 8, G3_K3>(p, dw, m_real, c_real, st, rws, rsl); \
+    return cbsz == 16 ? g3b_run<T, 16, G3_K2S2>(p, dw, m_real, c_real, st, rws, rsl) : g3b_run<T, 8, G3_K2S2>(p, dw, m_real, c_real, st, rws, rsl);
     if (dtype == VS_BF16) { G3B_GO(unsigned short) }
     G3B_GO(vs_half)
 #undef G3B_GO
@@ -723,6 +740,10 @@ namespace {
 struct MultiLayer {
     G3Params p;
     int cbsz, ncb, kind, m_real, c_real;
+    int primary;             // index of the first descriptor with the same dw (a weight used several times in one backward pass:
+                             // all uses write slabs into one contiguous region and ONE reduction sums them); == own index otherwise
+    int total_slabs;         // primary only: slabs of all its parts
+    int bias_primary, bias_total_blk;
     float* dw;
     size_t ws_off;           // byte offset of this layer's slabs
     long long work;          // tiles per workgroup (sort key)
@@ -775,8 +796,25 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         L.kind = d.kind; L.m_real = d.m_real; L.c_real = d.c_real; L.dw = d.dw;
         bucket_work[(L.cbsz == 16 ? 0 : 1) + (d.kind == VS_CONV_K3 ? 0 : 2)] += (long long)p.mbn * p.cbn * p.total_tiles;
     }
-    size_t off = 0;
+    // descriptors that share dw (db): parts of one gradient
     for (int i = 0; i < count; ++i) {
+        MultiLayer& L = plan.layers[i];
+        L.primary = i; L.bias_primary = i;
+        for (int j = 0; j < i; ++j) {
+            if (descs[j].dw == descs[i].dw && L.primary == i) {
+                const MultiLayer& F = plan.layers[j];
+                if (F.cbsz != L.cbsz || F.kind != L.kind || F.p.mbn != L.p.mbn || F.p.cbn != L.p.cbn || F.m_real != L.m_real || F.c_real != L.c_real)
+                    return VS_EINVAL;                     // same destination, different layer geometry
+                L.primary = F.primary;
+            }
+            if (descs[i].bias_g && descs[j].bias_g && descs[j].db == descs[i].db && L.bias_primary == i) {
+                if (descs[j].bias_c_real != descs[i].bias_c_real) return VS_EINVAL;
+                L.bias_primary = plan.layers[j].bias_primary;
+            }
+        }
+    }
+    size_t off = 0;
+    for (int i = 0; i < count; ++i) {                      // k-splits
         MultiLayer& L = plan.layers[i];
         G3Params& p = L.p;
         const long long w = bucket_work[(L.cbsz == 16 ? 0 : 1) + (L.kind == VS_CONV_K3 ? 0 : 2)];
@@ -787,17 +825,35 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         while (ks > 1 && ks * slab_bytes > 64.0 * 1024 * 1024) --ks;
         p.ksplit = (int)ks;
         L.work = (p.total_tiles + ks - 1) / ks;
-        L.ws_off = off;
-        off += (size_t)ks * p.mbn * p.cbn * L.ncb * 256 * 4;
+        L.total_slabs = 0; L.bias_total_blk = 0;
         const vs_wgrad_desc& d = descs[i];
         L.bias_nblk = 0; L.bias_off = 0;
         if (d.bias_g) {
             const int rpi = 256 / (d.bias_c_ch / 8);
             long long nb = (d.bias_rows + (long long)rpi * 32 - 1) / ((long long)rpi * 32);
             L.bias_nblk = (int)std::min<long long>(std::max<long long>(nb, 1), 256);     // <= 2 rounds of the reduce's 16 x 8 loads
-            L.bias_off = off;
-            off += ((size_t)L.bias_nblk * d.bias_c_real * sizeof(double) + 255) / 256 * 256;
         }
+    }
+    for (int i = 0; i < count; ++i) {                      // slab regions: the parts of one gradient lie back to back
+        if (plan.layers[i].primary != i) continue;
+        for (int j = i; j < count; ++j) {
+            MultiLayer& L = plan.layers[j];
+            if (L.primary != i) continue;
+            L.ws_off = off;
+            off += (size_t)L.p.ksplit * L.p.mbn * L.p.cbn * L.ncb * 256 * 4;
+            plan.layers[i].total_slabs += L.p.ksplit;
+        }
+    }
+    for (int i = 0; i < count; ++i) {                      // bias partial regions, likewise
+        if (!descs[i].bias_g || plan.layers[i].bias_primary != i) continue;
+        for (int j = i; j < count; ++j) {
+            MultiLayer& L = plan.layers[j];
+            if (!descs[j].bias_g || L.bias_primary != i) continue;
+            L.bias_off = off;
+            off += (size_t)L.bias_nblk * descs[j].bias_c_real * sizeof(double);
+            plan.layers[i].bias_total_blk += L.bias_nblk;
+        }
+        off = (off + 255) / 256 * 256;
     }
     plan.bytes = off;
     return VS_OK;
@@ -821,10 +877,18 @@ static int g3b_group_run(const G3Group& grp, hipStream_t s) {
 
 extern "C" size_t vs_conv_wgrad_multi_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype) {
     if (!descs || count <= 0) return 0;
-    if (dtype == VS_F32) {                        // serial per-layer launches share one region
+    if (dtype == VS_F32) {                        // serial per-layer launches share one region; the uses of one weight need theirs side by side
         size_t mx = 0;
-        for (int i = 0; i < count; ++i)
-            mx = std::max(mx, vs_conv_wgrad_workspace_bytes(descs[i].n, descs[i].dp, descs[i].hp, descs[i].wp, descs[i].m_ch, descs[i].c_ch, descs[i].kind));
+        for (int i = 0; i < count; ++i) {
+            bool first = true;
+            for (int j = 0; j < i; ++j) first = first && descs[j].dw != descs[i].dw;
+            if (!first) continue;
+            size_t sum = 0;
+            for (int j = i; j < count; ++j)
+                if (descs[j].dw == descs[i].dw)
+                    sum += vs_conv_wgrad_workspace_bytes(descs[j].n, descs[j].dp, descs[j].hp, descs[j].wp, descs[j].m_ch, descs[j].c_ch, descs[j].kind);
+            mx = std::max(mx, sum);
+        }
         return mx;
     }
     MultiPlan plan;
@@ -841,16 +905,39 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
     if (dtype == VS_F32) {
         // parity mode is not launch-bound: the per-layer kernels, one after the other on the same stream
         for (int i = 0; i < count; ++i) {
-            const vs_wgrad_desc& d = descs[i];
-            int rc = multi_validate(d);
+            int rc = multi_validate(descs[i]);
             if (rc) return rc;
-            rc = vs_conv_wgrad(d.p, d.p_stats, d.q, d.q_stats, d.dw, workspace, workspace_bytes, d.n, d.dp, d.hp, d.wp, d.m_ch, d.c_ch,
-                               d.m_real, d.c_real, d.kind, dtype, eps, stream);
-            if (rc) return rc;
-            if (d.bias_g) {
-                rc = vs_bias_grad(d.bias_g, d.db, d.bias_rows, d.bias_c_ch, d.bias_c_real, dtype, stream);
+        }
+        for (int i = 0; i < count; ++i) {
+            bool first = true;
+            for (int j = 0; j < i; ++j) first = first && descs[j].dw != descs[i].dw;
+            if (!first) continue;
+            int last = i;
+            for (int j = i + 1; j < count; ++j) if (descs[j].dw == descs[i].dw) last = j;
+            // the uses of this weight, slabs side by side; the last one's launch reduces them all
+            size_t off = 0;
+            int prior = 0;
+            for (int j = i; j <= last; ++j) {
+                const vs_wgrad_desc& d = descs[j];
+                if (d.dw != descs[i].dw) continue;
+                if (d.m_ch != descs[i].m_ch || d.c_ch != descs[i].c_ch || d.kind != descs[i].kind || d.m_real != descs[i].m_real || d.c_real != descs[i].c_real)
+                    return VS_EINVAL;
+                int slabs = 0;
+                int rc = wgrad_single(d.p, d.p_stats, d.q, d.q_stats, d.dw, (char*)workspace + off, workspace_bytes - off, d.n, d.dp, d.hp, d.wp,
+                                      d.m_ch, d.c_ch, d.m_real, d.c_real, d.kind, dtype, eps, stream, j == last ? prior : -1, &slabs);
                 if (rc) return rc;
+                off += vs_conv_wgrad_workspace_bytes(d.n, d.dp, d.hp, d.wp, d.m_ch, d.c_ch, d.kind) / 1;
+                // slabs of the next part start right behind this part's: its plan is the fp32 plan vs_conv_wgrad_workspace_bytes sizes
+                prior += slabs;
             }
+        }
+        for (int i = 0; i < count; ++i) {
+            const vs_wgrad_desc& d = descs[i];
+            if (!d.bias_g) continue;
+            bool first = true;
+            for (int j = 0; j < i; ++j) first = first && !(descs[j].bias_g && descs[j].db == d.db);
+            int rc = vs_bias_grad_acc(d.bias_g, d.db, d.bias_rows, d.bias_c_ch, d.bias_c_real, dtype, first ? 0 : 1, stream);
+            if (rc) return rc;
         }
         return VS_OK;
     }
@@ -903,7 +990,7 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
                 const int i = idx[at + j];
                 const vs_wgrad_desc& d = descs[i];
                 grp.d[j] = G3BiasDesc{d.bias_g, (double*)(ws + plan.layers[i].bias_off), d.bias_rows, d.bias_c_ch,
-                                      d.bias_c_real, plan.layers[i].bias_nblk, 0};
+                                      d.bias_c_real, plan.layers[i].bias_nblk, 0};      // parts of one bias gradient: adjacent partial regions
                 grp.blk_start[j] = blk;
                 blk += plan.layers[i].bias_nblk;
             }
@@ -919,15 +1006,17 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
         std::vector<int> blocks;
         for (int i = 0; i < count; ++i) {
             const MultiLayer& L = plan.layers[i];
-            const long long slab_elems = (long long)L.p.mbn * L.p.cbn * L.ncb * 256;
-            // a partition sums up to 8 slabs in one round of independent loads: no more partitions (= threads, waves) than that needs
-            int parts = 1;
-            while (parts < G3_RED_ROWS && parts * 8 < L.p.ksplit) parts *= 2;
-            red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.p.ksplit, L.cbsz,
-                                    L.kind == VS_CONV_K3 ? 27 : 8, L.ncb, 0, parts});
-            blocks.push_back(vs_ceil_div(slab_elems, 256 * (G3_RED_ROWS / parts)));
-            if (descs[i].bias_g) {
-                red.push_back(G3RedDesc{(const float*)(ws + L.bias_off), descs[i].db, 0, descs[i].bias_c_real, 0, 0, L.bias_nblk, 0, 0, 0, 1, G3_RED_ROWS});
+            if (L.primary == i) {                        // one reduction per gradient, over the slabs of all its parts
+                const long long slab_elems = (long long)L.p.mbn * L.p.cbn * L.ncb * 256;
+                // a partition sums up to 8 slabs in one round of independent loads: no more partitions (= threads, waves) than that needs
+                int parts = 1;
+                while (parts < G3_RED_ROWS && parts * 8 < L.total_slabs) parts *= 2;
+                red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.total_slabs, L.cbsz,
+                                        L.kind == VS_CONV_K3 ? 27 : 8, L.ncb, 0, parts});
+                blocks.push_back(vs_ceil_div(slab_elems, 256 * (G3_RED_ROWS / parts)));
+            }
+            if (descs[i].bias_g && L.bias_primary == i) {
+                red.push_back(G3RedDesc{(const float*)(ws + L.bias_off), descs[i].db, 0, descs[i].bias_c_real, 0, 0, L.bias_total_blk, 0, 0, 0, 1, G3_RED_ROWS});
                 blocks.push_back(vs_ceil_div(descs[i].bias_c_real, 64));
             }
         }

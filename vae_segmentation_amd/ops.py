@@ -621,7 +621,10 @@ class WgradDesc(_ct.Structure):
 
 
 _GROUP = {"enabled": os.environ.get("VS_WGRAD_GROUP", "1") != "0", "descs": [], "keep": [], "callback": False, "dtype": None,
-          "bytes": 0.0, "flops": 0.0, "split": None}
+          "bytes": 0.0, "flops": 0.0, "split": None, "slots": {}}
+# "slots": id(weight) -> (gw, gb) handed to autograd by the FIRST use of that weight in the current backward pass.  A weight used several
+# times (the VAE inside Embed runs three times per forward, joint_model.py:469-500) queues one descriptor per use, all with the first use's
+# destination: vs_conv_wgrad_multi sums the uses, and the later uses return None to autograd (nothing left to accumulate).
 
 
 def set_wgrad_grouping(enabled=True):
@@ -646,6 +649,7 @@ def drop_stale_wgrads():
         return                                  # a caller-managed second phase (set_wgrad_split) is pending: not stale
     if g["descs"] or g["callback"]:
         g["descs"], g["keep"], g["callback"], g["bytes"], g["flops"] = [], [], False, 0.0, 0.0
+    g["slots"] = {}
 
 
 def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb):
@@ -655,11 +659,13 @@ def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb):
         flush_wgrads()
     g["dtype"] = p.dtype
     n, dp, hp, wp_, m_ch = p.shape
-    d = WgradDesc(p.data_ptr(), _p(ps), q.data_ptr(), _p(qs), gw.data_ptr(), None, None, 0, 0, 0,
+    gw_ptr = gw if isinstance(gw, int) else gw.data_ptr()
+    d = WgradDesc(p.data_ptr(), _p(ps), q.data_ptr(), _p(qs), gw_ptr, None, None, 0, 0, 0,
                   n, dp, hp, wp_, m_ch, q.shape[-1], m_real, c_real, kind, 0)
     if bias_args is not None:
         bg = bias_args[0]
-        d.bias_g, d.db, d.bias_rows, d.bias_c_ch, d.bias_c_real = bg.data_ptr(), gb.data_ptr(), bg.numel() // bg.shape[-1], bg.shape[-1], bias_args[1]
+        gb_ptr = gb if isinstance(gb, int) else gb.data_ptr()
+        d.bias_g, d.db, d.bias_rows, d.bias_c_ch, d.bias_c_real = bg.data_ptr(), gb_ptr, bg.numel() // bg.shape[-1], bg.shape[-1], bias_args[1]
         g["keep"].append(bg)
     taps = 27 if kind == VS_CONV_K3 else 8
     nb = (p.numel() // m_ch * m_real + q.numel() // q.shape[-1] * c_real) * _esize(p) + m_real * c_real * taps * 4
@@ -678,6 +684,7 @@ def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb):
 def _group_backward_done():
     _GROUP["callback"] = False
     flush_wgrads(first_only=_GROUP["split"] is not None)
+    _GROUP["slots"] = {}
 
 
 def pending_wgrads():
@@ -728,12 +735,19 @@ def _side_grads(weight, keep, wgrad_args, bias_args, bias=None):
     """Allocate dW (and db) now; their kernels are deferred — grouped at the end of backward (default) or queued for the side
     stream (set_overlap) — or run at once when the parameter already holds a gradient to accumulate into, carries hooks, or
     grad mode is on (autograd would then clone the still-unwritten tensor); -> (gw, gb)."""
+    grouping = _GROUP["enabled"] and not _SIDE["enabled"]
+    slot = _GROUP["slots"].get(id(weight)) if grouping else None
+    if slot is not None:
+        # a later use of the same weight in this pass: one more descriptor with the first use's destination, nothing returned to autograd
+        _group_submit(weight, keep, wgrad_args, bias_args if slot[1] is not None else None, slot[0], slot[1])
+        return None, None
     gw = _grad_slot(weight, weight.shape)
     gb = None
     if bias_args is not None:
         gb = _grad_slot(bias, (bias_args[1],)) if bias is not None else torch.empty(bias_args[1], dtype=torch.float32, device=keep[0].device)
     deferrable = weight.grad is None and not _has_hooks(weight) and not torch.is_grad_enabled() and (bias is None or not _has_hooks(bias))
-    if _GROUP["enabled"] and not _SIDE["enabled"] and deferrable:
+    if grouping and deferrable:
+        _GROUP["slots"][id(weight)] = (gw.data_ptr(), None if gb is None else gb.data_ptr())      # addresses, not tensors: see below
         # the descriptor holds raw pointers only: AccumulateGrad must find gw / gb unshared to adopt them as .grad without a copy
         _group_submit(weight, keep, wgrad_args, bias_args, gw, gb)
         return gw, gb
@@ -752,7 +766,19 @@ def _side_grads(weight, keep, wgrad_args, bias_args, bias=None):
 
 def _dead_bias_grad(bias, n, device):
     """Gradient of a conv bias that feeds InstanceNorm (exactly zero): the parameter's (never written, zero) slot of
-    the flat bucket when one is registered, else zeros carved from the statistics arena (no fill launch)."""
+    the flat bucket when one is registered, else zeros carved from the statistics arena (no fill launch).  Later uses of the same
+    bias in one pass return None (nothing to accumulate)."""
+    if bias is not None and _GROUP["enabled"]:
+        key = ("dead", id(bias))
+        if key in _GROUP["slots"]:
+            return None
+        _GROUP["slots"][key] = True
+        if not _GROUP["callback"]:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_group_backward_done)
+                _GROUP["callback"] = True
+            except RuntimeError:
+                _GROUP["slots"].pop(key, None)
     view = getattr(bias, "_vs_grad_view", None) if bias is not None else None
     if view is not None and bias.grad is None:
         return view.detach()
