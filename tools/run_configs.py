@@ -1,42 +1,65 @@
-"""GPU-box aid: time the other BASELINE configs (eager + graph) — 128^3 domain_adaptation (configs[3]) and 160^3 joint_train."""
-import os, sys, time
+"""GPU-box aid: time the other BASELINE configs, HIP-graph replayed — configs[3] 128^3 domain_adaptation (types 0 and 8), configs[4]
+160^3 joint_train in fp16 with dynamic loss scaling (and in bf16), and the fp32 parity mode of configs[1].  Writes one JSON line per
+configuration.   usage: python tools/run_configs.py [all|da128|joint160|fp32] [out.jsonl]"""
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import joint_model as M
 from oracle import ref_cpu as O
 from vae_segmentation_amd import ops, optim, train as T
 
-def joint(side):
+DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+out_path = sys.argv[2] if len(sys.argv) > 2 else None
+records = []
+
+
+def joint(side, dtype):
     j = M.Joint([M.Segmentation(1, 2, norm_type=1), M.VAE(2, 2, norm_type=1, dim=128, spatial=side)])
     O.deterministic_fill_(j, 0); j = j.cuda()
     for p in j.Vae.parameters(): p.requires_grad = False
-    M.set_kernel_dtype(j, torch.bfloat16)
+    M.set_kernel_dtype(j, DT[dtype])
     return j
 
-def timeit(name, loss_fn, params, opt, vols, steps=10):
-    gs = T.GraphedStep(loss_fn, params, opt, warmup=2)
-    for _ in range(2): gs.step()
+
+def timeit(name, loss_fn, params, opt, vols, steps=20, scaler=None):
+    torch.cuda.reset_peak_memory_stats()
+    gs = T.GraphedStep(loss_fn, params, opt, warmup=2, scaler=scaler)
+    for _ in range(3): gs.step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): gs.step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    print("%-40s %.2f ms/step  %.1f volumes/s  peak mem %.2f GB  loss %.4f" % (name, dt * 1e3, vols / dt, torch.cuda.max_memory_allocated() / 2**30, gs.loss.item()))
+    rec = {"config": name, "ms_per_step": round(dt * 1e3, 3), "volumes_per_s": round(vols / dt, 1),
+           "peak_device_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "loss": round(float(gs.loss.item()), 5),
+           "loss_scale": None if scaler is None else float(scaler.scale.item())}
+    records.append(rec)
+    print(json.dumps(rec), flush=True)
+
 
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 if which in ("all", "da128"):
-    s, t = joint(128), joint(128)
-    O.deterministic_fill_(t.Seg, 1); t = t.cuda()
-    for p in t.parameters(): p.requires_grad = False
-    img, lab = O.synthetic_image(1, 128, 2).cuda(), O.synthetic_label(1, 128, 3).cuda()
-    params = list(s.Seg.parameters()); opt = optim.SGD(params, lr=1e-2, momentum=0.9)
-    timeit("128^3 domain_adaptation B=1 bf16", lambda: T.domain_adaptation_losses(s, t, img, lab, lambda_vae=1.0, domain_loss_type=0), params, opt, 1)
-    del s, t; torch.cuda.empty_cache()
+    for lt in (0, 8):
+        s, t = joint(128, "bf16"), joint(128, "bf16")
+        O.deterministic_fill_(t.Seg, 1); t = t.cuda()
+        for p in t.parameters(): p.requires_grad = False
+        img, lab = O.synthetic_image(1, 128, 2).cuda(), O.synthetic_label(1, 128, 3).cuda()
+        params = list(s.Seg.parameters()); opt = optim.SGD(params, lr=1e-2, momentum=0.9)
+        timeit("configs[3]: 128^3 domain_adaptation B=1 bf16, domain_loss_type %d" % lt,
+               lambda: T.domain_adaptation_losses(s, t, img, lab, lambda_vae=1.0, domain_loss_type=lt, host_schedule=False), params, opt, 1)
+        del s, t; torch.cuda.empty_cache()
 if which in ("all", "joint160"):
-    j = joint(160)
-    img, lab = O.synthetic_image(2, 160, 2).cuda(), O.synthetic_label(2, 160, 3).cuda()
-    params = list(j.Seg.parameters()); opt = optim.SGD(params, lr=1e-2, momentum=0.9)
-    timeit("160^3 joint_train B=2 bf16", lambda: T.joint_train_losses(j, img, lab), params, opt, 2)
+    for dtype in ("fp16", "bf16"):
+        j = joint(160, dtype)
+        img, lab = O.synthetic_image(2, 160, 2).cuda(), O.synthetic_label(2, 160, 3).cuda()
+        params = list(j.Seg.parameters()); opt = optim.SGD(params, lr=1e-2, momentum=0.9)
+        timeit("configs[4] (one GPU's share): 160^3 joint_train B=2 %s%s" % (dtype, " + dynamic loss scale" if dtype == "fp16" else ""),
+               lambda: T.joint_train_losses(j, img, lab), params, opt, 2, scaler=optim.LossScaler() if dtype == "fp16" else None)
+        del j; torch.cuda.empty_cache()
 if which in ("all", "fp32"):
-    j = joint(96); M.set_kernel_dtype(j, torch.float32)
+    j = joint(96, "fp32")
     img, lab = O.synthetic_image(2, 96, 2).cuda(), O.synthetic_label(2, 96, 3).cuda()
     params = list(j.Seg.parameters()); opt = optim.SGD(params, lr=1e-2, momentum=0.9)
-    timeit("96^3 joint_train B=2 fp32 (parity mode)", lambda: T.joint_train_losses(j, img, lab), params, opt, 2)
+    timeit("configs[1] in the fp32 parity mode: 96^3 joint_train B=2", lambda: T.joint_train_losses(j, img, lab), params, opt, 2)
+if out_path:
+    with open(out_path, "w") as f:
+        for r in records:
+            f.write(json.dumps(r) + "\n")
