@@ -83,9 +83,10 @@ def measured_step_traffic(path=None):
     if "_step_total_bytes" in table:
         return table["_step_total_bytes"]
     try:
-        return float(sum(rec["hbm_bytes_per_launch"] * rec.get("launches_per_step", 0) for rec in table.values() if isinstance(rec, dict)))
+        tot = float(sum(rec["hbm_bytes_per_launch"] * rec.get("launches_per_step", 0) for rec in table.values() if isinstance(rec, dict)))
     except Exception:
         return None
+    return tot if tot > 0 else None
 
 
 FAMILIES = (
