@@ -94,8 +94,12 @@ def _sample_err(s, ref, rms):
     return float(np.abs(s - ref).max() / max(np.abs(ref).max(), rms, 1e-30))
 
 
+def _f(x):
+    return float(np.asarray(x).reshape(-1)[0])
+
+
 def scalar_close(gold, key, val, floor=1e-3, factor=3.0):
-    f64, f32 = float(gold[key + "@f64"]), float(gold[key])
+    f64, f32 = _f(gold[key + "@f64"]), _f(gold[key])
     mine, theirs = abs(float(val) - f64), abs(f32 - f64)
     lim = max(floor * abs(f64), factor * theirs)
     assert mine <= lim, "%s: |%.9g - %.9g(f64)| = %.3g > %.3g (reference fp32 is off by %.3g)" % (key, float(val), f64, mine, lim, theirs)
