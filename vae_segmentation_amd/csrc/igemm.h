@@ -95,8 +95,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     if (has_stats) {
         for (int c = tid; c < p.C; c += 256) {
             float m, r;
-            if constexpr (sizeof(T) == 2) stats_to_mean_rstd_fast(p.x_stats, (size_t)n * p.C + c, (size_t)p.N * p.C, p.inv_count_in, p.eps, m, r);
-            else stats_to_mean_rstd(p.x_stats, (size_t)n * p.C + c, (size_t)p.N * p.C, p.inv_count_in, p.eps, m, r);
+            stats_to_mean_rstd(p.x_stats, (size_t)n * p.C + c, (size_t)p.N * p.C, p.inv_count_in, p.eps, m, r);
             s_mean[c] = m;
             s_rstd[c] = r;
         }
@@ -106,8 +105,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         // mask tensor's channels of this sample
         for (int c = tid; c < p.M; c += 256) {
             float m, r;
-            if constexpr (sizeof(T) == 2) stats_to_mean_rstd_fast(p.mask_stats, (size_t)n * p.M + c, (size_t)p.N * p.M, p.inv_count_out, p.eps, m, r);
-            else stats_to_mean_rstd(p.mask_stats, (size_t)n * p.M + c, (size_t)p.N * p.M, p.inv_count_out, p.eps, m, r);
+            stats_to_mean_rstd(p.mask_stats, (size_t)n * p.M + c, (size_t)p.N * p.M, p.inv_count_out, p.eps, m, r);
             s_mean[c] = m;
             s_rstd[c] = r;
         }

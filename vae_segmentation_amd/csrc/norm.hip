@@ -19,17 +19,12 @@ struct RowIter {
     __device__ bool active() const { return fy < rows_per_it; }
 };
 
-// FAST: the 16-bit kernels take the v_rsq_f32 + Newton reciprocal square root (common.h), the fp32 (parity) kernels the fp64 one
-template <bool FAST>
 __device__ __forceinline__ void load_mean_rstd(const double* stats, int n, int c, double inv_count, float eps,
                                                float* s_mean, float* s_rstd) {
     const size_t pairs = (size_t)gridDim.y * c;          // every kernel of this file runs blockIdx.y = sample over all N samples
     for (int i = threadIdx.x; i < c; i += blockDim.x) {
         float m = 0.f, r = 1.f;
-        if (stats) {
-            if constexpr (FAST) stats_to_mean_rstd_fast(stats, (size_t)n * c + i, pairs, inv_count, eps, m, r);
-            else stats_to_mean_rstd(stats, (size_t)n * c + i, pairs, inv_count, eps, m, r);
-        }
+        if (stats) stats_to_mean_rstd(stats, (size_t)n * c + i, pairs, inv_count, eps, m, r);
         s_mean[i] = m;
         s_rstd[i] = r;
     }
@@ -87,8 +82,8 @@ __global__ __launch_bounds__(256) void in_relu_fwd_kernel(const T* __restrict__ 
     constexpr int EPL = ET<T>::EPL;
     __shared__ float s_m[NB_MAX_C], s_r[NB_MAX_C], s_m2[NB_MAX_C], s_r2[NB_MAX_C];
     const int n = blockIdx.y;
-    load_mean_rstd<sizeof(T) == 2>(xs, n, c, inv_count, eps, s_m, s_r);
-    if (x2) load_mean_rstd<sizeof(T) == 2>(x2s, n, c, inv_count, eps, s_m2, s_r2);
+    load_mean_rstd(xs, n, c, inv_count, eps, s_m, s_r);
+    if (x2) load_mean_rstd(x2s, n, c, inv_count, eps, s_m2, s_r2);
     __syncthreads();
     RowIter<T> it(c);
     if (!it.active()) return;
@@ -143,7 +138,7 @@ __device__ __forceinline__ void in_relu_bwd_reduce_body(const T* __restrict__ g,
         }
     };
     request(v);
-    load_mean_rstd<sizeof(T) == 2>(xs, n, c, inv_count, eps, s_m, s_r);
+    load_mean_rstd(xs, n, c, inv_count, eps, s_m, s_r);
     __syncthreads();
     double part[EPL][2];
 #pragma unroll
@@ -220,7 +215,7 @@ __device__ __forceinline__ void in_relu_bwd_apply_body(const T* __restrict__ g, 
         }
     };
     request(v);
-    load_mean_rstd<sizeof(T) == 2>(xs, n, c, inv_count, eps, s_m, s_r);
+    load_mean_rstd(xs, n, c, inv_count, eps, s_m, s_r);
     for (int i = threadIdx.x; i < c; i += 256) {
         double sv[2];
         stat_load(sums, (size_t)n * c + i, (size_t)gridDim.y * c, sv);
