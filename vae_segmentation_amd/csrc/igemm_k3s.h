@@ -4,19 +4,17 @@
 // whole weight block from LDS, and the measured bound of those launches is the LDS read bandwidth of the MFMA phase (1.25 KB of
 // ds_read_b128 per MFMA; two chunks per stage changed nothing).  Here
 //   * columns are FLATTENED voxels of one sample: a workgroup owns 64 consecutive voxels (4 column groups, all real except the tail);
-//   * the four waves share those columns and SPLIT the 27 taps of a chunk (wave w: taps w, w+4, ...): a stage reads the weight
-//     block once per workgroup instead of once per wave and a quarter of the B fragments — 135 KB of LDS reads per stage
-//     instead of 540; the partial accumulators meet in LDS after the last stage and every wave finishes one column group;
+//   * the four waves share those columns and SPLIT the 27 taps of a chunk (wave w: taps w, w+4, ...): a wave's weight fragments are
+//     its own (global -> registers, no LDS) and it reads a quarter of the B fragments — 112 KB of LDS reads per stage instead of 540;
+//     the partial accumulators meet in LDS after the last stage and every wave finishes one column group;
 //   * the whole zero-padded sample chunk ((D+2)(H+2)(W+2) voxels x 32 channels: 32 KB at 6^3) is staged per chunk, whatever the tile.
-// Staging (buffer loads one stage ahead, normalise-on-load, swizzled parts), weights through LDS, statistics and fused IN-backward sums
-// follow k3b_kernel; results are summed in a fixed order (bitwise reproducible).
+// Staging (buffer loads two stages ahead, normalise-on-load, swizzled parts), statistics and fused IN-backward sums follow k3b_kernel; results are summed in a fixed order (bitwise reproducible).
 #pragma once
 #include <stdlib.h>
 #include "igemm.h"
 
 #define K3S_LDS_RED 0          // float[4][16][2]
-#define K3S_LDS_W 512          // weight block of the stage: [27][64 lanes] x 16 B
-#define K3S_LDS_TILE (512 + 28 * 1024)     // 7 fragments x 256 threads: the staging stores are unconditional
+#define K3S_LDS_TILE 512
 // then: padded sample chunk [TV][64 B] (at least 16 KB: the cross-wave partials alias it), scale / shift tables [C] each
 
 // TVC: compile-time bound of the padded voxel count (128: up to 3x3x3, 512: up to 6x6x6) -> staging fragments per thread
@@ -29,9 +27,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     constexpr int NIT = TVC * 4 / 256;                   // 16-byte fragments per thread per stage
     constexpr int NWI = 7;                               // weight fragments per thread per stage (27 * 64 / 256)
     constexpr int NKW = 7;                               // taps per wave per chunk (wave w: w, w + 4, ...)
+    constexpr int NCG = TVC == 128 ? 2 : 4;              // 16-column groups that can hold voxels: up to 3x3x3 = 27 voxels fill two (the other two were 4.5 of 13 us of MFMA phase on padding)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_red = (float*)(smem + K3S_LDS_RED);
-    char* s_w = smem + K3S_LDS_W;
     char* s_tile = smem + K3S_LDS_TILE;
     const int PX = p.W + 2, PY = p.H + 2, TV = (p.D + 2) * PY * PX, V = p.D * p.H * p.W;
     constexpr int tile_bytes = TVC * 64 > 16384 ? TVC * 64 : 16384;
@@ -61,12 +59,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         goff[b] = ok ? ((((n * p.D + pz - 1) * p.H + py - 1) * p.W + px - 1) * p.C + part * 8) * 2 : -1;
         swzbits |= (unsigned int)((px >> 2) & 1) << b;
     }
+    // weights: with the taps split over the waves, tap (wave + 4 i)'s A fragment is used by this wave only — it goes from global
+    // straight into the lane's registers (through LDS it cost 7 ds_write_b128 + 7 ds_read_b128 per thread and stage for no reuse)
     int w_off[NWI];
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
-        int f = tid + i * 256;
-        if (f > 27 * 64 - 1) f = 27 * 64 - 1;
-        w_off[i] = rb0 * (p.nch * 27 * 64) + f;          // + ch * 27 * 64
+        const int kg = (tid >> 6) + 4 * i < 27 ? (tid >> 6) + 4 * i : 26;
+        w_off[i] = rb0 * (p.nch * 27 * 64) + kg * 64 + (tid & 63);          // + ch * 27 * 64
     }
     // two stages in flight (registers): with the MFMA phase this short, a stage requested only one stage ahead arrived late every time
     u32x4 xv0[NIT], wv0[NWI], xv1[NIT], wv1[NWI];
@@ -99,8 +98,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             const int pw = part ^ (int)(((swzbits >> b) & 1u) << 1);
             *(u32x4*)(s_tile + pv * 64 + pw * 16) = v;
         }
-#pragma unroll
-        for (int i = 0; i < NWI; ++i) *(u32x4*)(s_w + (tid + i * 256) * 16) = wv[i];
     };
 
     // ---- first stage in flight; tables; per-lane read offsets ----------------------------------------------------------------
@@ -128,11 +125,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
     // B fragment of (tap kg = wave + 4 i, column group cg): padded voxel (z + dz, y + dy, x + dx) of column voxel (z, y, x), part g
     // stored at part ^ ((px >> 2) & 1) << 1
-    int boff[NKW][4];
+    int boff[NKW][NCG];
     {
-        int cz[4], cy[4], cx[4];
+        int cz[NCG], cy[NCG], cx[NCG];
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) {
+        for (int cg = 0; cg < NCG; ++cg) {
             int v = ct * 64 + cg * 16 + col;
             if (v >= V) v = 0;
             const int t2 = sdiv(v, inv_w);
@@ -146,35 +143,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             if (kg > 26) kg = 26;
             const int dz = kg / 9, dy = (kg / 3) % 3, dx = kg % 3;
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) {
+            for (int cg = 0; cg < NCG; ++cg) {
                 const int px = cx[cg] + dx;
                 boff[i][cg] = (((cz[cg] + dz) * PY + cy[cg] + dy) * PX + px) * 64 + ((g ^ (((px >> 2) & 1) << 1)) * 16);
             }
         }
     }
-    const char* s_wl = s_w + lane * 16;
-    f32x4 acc[4];
+    f32x4 acc[NCG];
 #pragma unroll
-    for (int cg = 0; cg < 4; ++cg) acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cg = 0; cg < NCG; ++cg) acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                     // tables visible
     K3_TICK(0);
 
+    u32x4 wa[NKW];                                       // the current stage's A fragments (the stage registers are re-requested before the MFMAs)
     auto multiply = [&]() {
         // no branches: a wave whose 7th tap does not exist (waves 3: taps 3, 7, ..., 27) multiplies a zeroed A fragment, so the
         // scheduler sees one block and keeps the next taps' LDS reads in flight under the MFMAs
 #pragma unroll
         for (int i = 0; i < NKW; ++i) {
-            const int kg = wave + 4 * i < 27 ? wave + 4 * i : 26;
-            u32x4 a = *(const u32x4*)(s_wl + kg * 1024);
+            u32x4 a = wa[i];
             if (i == NKW - 1) {
                 const unsigned int keep = wave + 4 * i < 27 ? 0xffffffffu : 0u;
                 a[0] &= keep; a[1] &= keep; a[2] &= keep; a[3] &= keep;
             }
-            u32x4 b[4];
+            u32x4 b[NCG];
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + boff[i][cg]);
+            for (int cg = 0; cg < NCG; ++cg) b[cg] = *(const u32x4*)(s_tile + boff[i][cg]);
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) acc[cg] = mfma16(a, b[cg], acc[cg], (T*)nullptr);
+            for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma16(a, b[cg], acc[cg], (T*)nullptr);
         }
     };
     for (int ch = 0; ch < p.nch; ch += 2) {
@@ -184,6 +180,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         K3_TICK(2);
         __syncthreads();
         K3_TICK(3);
+#pragma unroll
+        for (int i = 0; i < NKW; ++i) wa[i] = wv0[i];
         if (ch + 2 < p.nch) load_stage(ch + 2, xv0, wv0);
         K3_TICK(4);
         multiply();
@@ -195,6 +193,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             K3_TICK(2);
             __syncthreads();
             K3_TICK(3);
+#pragma unroll
+            for (int i = 0; i < NKW; ++i) wa[i] = wv1[i];
             if (ch + 3 < p.nch) load_stage(ch + 3, xv1, wv1);
             K3_TICK(4);
             multiply();
@@ -206,18 +206,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     __syncthreads();
     f32x4* s_part = (f32x4*)s_tile;                      // [wave][cg][lane]
 #pragma unroll
-    for (int cg = 0; cg < 4; ++cg) s_part[(wave * 4 + cg) * 64 + lane] = acc[cg];
+    for (int cg = 0; cg < NCG; ++cg) s_part[(wave * NCG + cg) * 64 + lane] = acc[cg];
     __syncthreads();
-    f32x4 o = s_part[(0 * 4 + wave) * 64 + lane];
+    const int fcg = wave < NCG ? wave : 0;               // waves beyond the last column group finish nothing (valid = false below)
+    f32x4 o = s_part[(0 * NCG + fcg) * 64 + lane];
 #pragma unroll
     for (int w = 1; w < 4; ++w) {
-        const f32x4 q = s_part[(w * 4 + wave) * 64 + lane];
+        const f32x4 q = s_part[(w * NCG + fcg) * 64 + lane];
         o[0] += q[0]; o[1] += q[1]; o[2] += q[2]; o[3] += q[3];
     }
 
     // ---- epilogue: column voxel v of sample n, rows row0 .. row0 + 3 ---------------------------------------------------------------------
     const int v = ct * 64 + wave * 16 + col;
-    const bool valid = v < V && row0 < p.M;
+    const bool valid = v < V && row0 < p.M && wave < NCG;
     const int e = ((n * V + v) * p.M + row0) * 2;        // byte offset in y (and in the mask tensor)
     const i32x4 yrsrc = make_rsrc(p.y, (unsigned int)((long long)p.N * V * p.M * 2));
     u32x2 mk = u32x2{0u, 0u};
@@ -307,7 +308,7 @@ static int k3s_launch(const G1Params& p_in, hipStream_t stream) {
     p.tiles_per_sample = ctiles;
     const bool hs = !SUMS && p.x_stats != nullptr;
 #define K3S_GO(TVC) return hs ? k3s_launch_t<T, SUMS, TVC, !SUMS>(p, ctiles, stream) : k3s_launch_t<T, SUMS, TVC, false>(p, ctiles, stream)
-    if (TV <= 128) K3S_GO(128);
+    if (TV <= 128 && V <= 32) K3S_GO(128);
     if (TV <= 512) K3S_GO(512);
     return VS_ESHAPE;
 #undef K3S_GO
