@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VS_VERSION 200
+#define VS_VERSION 201
 
 enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2 };   /* storage type of activations: fp32 (parity mode), bf16, IEEE fp16 (needs loss scaling, see vs_loss_scale_*) */
 #ifndef VS_STAT_SLOTS
@@ -185,6 +185,34 @@ int vs_zero_fill(void* p, long long bytes, void* stream);
 int vs_instnorm_relu_bwd_pair(const void* g, const void* x1, const double* x1_stats, double* sums1, void* gx1,
                               const void* x2, const double* x2_stats, double* sums2, void* gx2, int n, long long voxels,
                               int c, int dtype, float eps, void* stream);
+
+/* ---- general normalisation + activation ------------------------------------------------------------------------------------------
+ * The settings of joint_model.py's blocks that no entry point of the reference passes: norm_type=2 = nn.BatchNorm3d(C, momentum=0.1)
+ * (joint_model.py:12-13, the constructors' default) with its affine pair and running statistics, and soft=True = torch.nn.Softplus()
+ * (joint_model.py:38,58,93,104).  Not fused into the convs: the conv writes its raw output and (sum, sumsq) statistics as always and
+ * these streaming passes follow; the activation that leaves is a stored tensor.  u = xhat * gamma + beta, xhat = (x - mean) * rstd. */
+enum { VS_NORM_INSTANCE = 0, VS_NORM_BATCH = 1, VS_NORM_BATCH_EVAL = 2 };   /* per (n,c) | pooled over the batch (training) | running statistics */
+enum { VS_ACT_RELU = 0, VS_ACT_SOFTPLUS = 1 };                               /* Softplus: beta 1, threshold 20 (torch defaults) */
+/* mean / rstd tables float[n][c] from a conv epilogue's statistics (double[VS_STAT_SLOTS][n][c][2], `count` voxels per sample).
+ * VS_NORM_BATCH: batch mean and biased variance; running_mean / running_var (nullable pair, fp32 [c_real]) take
+ * (1-momentum) * old + momentum * (mean | unbiased variance) and *num_batches_tracked (nullable) is incremented — torch.nn.BatchNorm3d
+ * in training mode.  VS_NORM_BATCH_EVAL: the tables are the running pair (stats unused). */
+int vs_norm_tables(const double* stats, int n, int c, int c_real, double count, int mode, float eps, float momentum,
+                   float* running_mean, float* running_var, long long* num_batches_tracked, float* mean, float* rstd, void* stream);
+/* y = act(u); channels >= c_real (padding) are written as zeros.  gamma / beta: fp32 [c_real] or NULL (1 / 0). */
+int vs_norm_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y, int n,
+                    long long voxels, int c, int c_real, int act, int dtype, void* stream);
+/* backward, given g = dL/dy:  da = g * act'(u)
+ *   reduce: sums[n][c] = (sum da, sum da * xhat)          (double[VS_STAT_SLOTS][n][c][2], ACCUMULATED: caller zeroes)
+ *   finish: coef[n][c] = (k, m1, m2) with k = gamma * rstd and (m1, m2) = the means of (da, da * xhat) over the sample (INSTANCE),
+ *           over the batch (BATCH) or 0 (BATCH_EVAL);  dgamma[c] = sum_n sum da * xhat, dbeta[c] = sum_n sum da (nullable)
+ *   apply : dx = k * (da - m1 - xhat * m2) */
+int vs_norm_act_bwd_reduce(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           double* sums, int n, long long voxels, int c, int c_real, int act, int dtype, void* stream);
+int vs_norm_act_bwd_finish(const double* sums, int n, int c, int c_real, double count, int mode, const float* rstd, const float* gamma,
+                           float* coef, float* dgamma, float* dbeta, void* stream);
+int vs_norm_act_bwd_apply(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          const float* coef, void* dx, int n, long long voxels, int c, int c_real, int act, int dtype, void* stream);
 
 /* F.dropout(x, p, training=True) on a channels-last tensor (joint_model.py:256-264,379-385): out = x * keep / (1-p),
  * keep ~ Bernoulli(1-p) from a counter-based hash of (seed, element index) — the same call with the same seed applied to

@@ -158,6 +158,78 @@ def gold_blocks():
     save("blocks", d)
 
 
+def put_bn(d, tag, module):
+    """running statistics of every BatchNorm3d after the pass"""
+    for name, m in module.named_modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            d["%s.bn.%s.running_mean" % (tag, name)] = m.running_mean.detach().double().numpy()
+            d["%s.bn.%s.running_var" % (tag, name)] = m.running_var.detach().double().numpy()
+            d["%s.bn.%s.tracked" % (tag, name)] = np.asarray(int(m.num_batches_tracked))
+
+
+def gold_blocks_norm():
+    """The block settings no entry point passes: norm_type=2 (BatchNorm3d, joint_model.py:12-13) in training
+    and eval mode, soft=True (Softplus, joint_model.py:38,104), and both together — the reference's own blocks, fwd + bwd."""
+    save("blocks_norm", both_precisions(_blocks_norm))
+
+
+def _blocks_norm(dt):
+    d = {}
+
+    def case(tag, mod, shape, seed, eval_after_train=False):
+        O.bn_fill_(O.deterministic_fill_(mod, seed=seed))
+        mod = mod.to(dt)
+        n = int(np.prod(shape))
+        x = torch.from_numpy(2 * O.hashed_uniform(n, 7001, seed) - 1).to(dt).view(shape).requires_grad_(True)
+        if eval_after_train:                  # one training pass moves the running statistics, then the block is used in eval mode
+            mod.train()
+            with torch.no_grad():
+                mod(x)
+            mod.eval()
+        y = mod(x)
+        w = torch.from_numpy(2 * O.hashed_uniform(y.numel(), 7002, seed) - 1).to(dt).view_as(y)
+        (y * w).sum().backward()
+        d[tag + ".shape"] = np.asarray(shape)
+        d[tag + ".seed"] = np.asarray(seed)
+        put(d, tag + ".out", y)
+        put(d, tag + ".gin", x.grad)
+        put_grads(d, tag, mod)
+        put_bn(d, tag, mod)
+
+    case("conv_bn_2_8", RM.Conv(2, 8, norm_type=2), (2, 2, 16, 16, 16), 21)
+    case("dconv_bn_8_16", RM.DoubleConv(8, 16, norm_type=2), (2, 8, 16, 16, 16), 22)
+    case("down_bn_8_16", RM.Down(8, 16, norm_type=2), (2, 8, 16, 16, 16), 23)
+    case("up_bn_16_8", RM.Up(16, 8, norm_type=2), (2, 16, 8, 8, 8), 24)
+    case("down_bn_64_128", RM.Down(64, 128, norm_type=2), (2, 64, 8, 8, 8), 25)
+    case("conv_bn_eval_2_8", RM.Conv(2, 8, norm_type=2), (2, 2, 16, 16, 16), 26, eval_after_train=True)
+    case("dconv_soft_8_16", RM.DoubleConv(8, 16, norm_type=1, soft=True), (2, 8, 16, 16, 16), 27)
+    case("conv_soft_2_8", RM.Conv(2, 8, norm_type=1, soft=True), (2, 2, 16, 16, 16), 28)
+    case("dconv_bn_soft_8_16", RM.DoubleConv(8, 16, norm_type=2, soft=True), (2, 8, 16, 16, 16), 29)
+    return d
+
+
+def gold_seg32_bn():
+    """Segmentation with the constructors' default norm_type=2 (BatchNorm3d): seg_train's loss and gradients at 32^3, batch 2"""
+    save("seg32_bn", both_precisions(_seg32_bn))
+
+
+def _seg32_bn(dt):
+    d = {}
+    seg = RM.Segmentation(n_channels=1, n_class=2, norm_type=2)
+    O.bn_fill_(O.deterministic_fill_(seg, seed=0))
+    seg = seg.to(dt)
+    img, lab = O.synthetic_image(2, 32, seed=2).to(dt), O.synthetic_label(2, 32, seed=3)
+    batch = {"img": img, "gt": O.one_hot(lab).to(dt)}
+    batch = seg(batch, "img", "pred")
+    dsc = 1 - main_source_avg_dsc(batch["pred"], batch["gt"], 1, 2)
+    dsc.backward()
+    d["dice_loss"] = dsc.detach().numpy()
+    put(d, "pred", batch["pred"], 256)
+    put_grads(d, "seg", seg)
+    put_bn(d, "seg", seg)
+    return d
+
+
 def gold_seg32():
     save("seg32", both_precisions(_seg32))
 
@@ -676,6 +748,8 @@ CASES = {
     "seg96": gold_seg96,
     "joint160_fwd": gold_joint160_fwd,
     "methods": gold_methods,
+    "blocks_norm": gold_blocks_norm,
+    "seg32_bn": gold_seg32_bn,
 }
 
 if __name__ == "__main__":

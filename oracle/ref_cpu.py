@@ -598,6 +598,16 @@ def deterministic_fill_(module, seed=0, gain=1.0):
     return module
 
 
+def bn_fill_(module):
+    """After deterministic_fill_: BatchNorm3d scales become 1 + 3 * (their +-0.1 fill) = 0.7 .. 1.3 (a scale around 0 would test nothing);
+    shifts keep their +-0.1 fill, running statistics their defaults (0, 1).  Same call on the reference modules and the native ones."""
+    with torch.no_grad():
+        for m in module.modules():
+            if isinstance(m, nn.BatchNorm3d):
+                m.weight.mul_(3.0).add_(1.0)
+    return module
+
+
 def synthetic_image(batch, side, seed=2):
     """~ clip(N(0,1), -1, 1), shape (B,1,S,S,S); Box-Muller on the hashed uniforms."""
     n = batch * side ** 3

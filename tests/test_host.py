@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
                  "vs_conv_k3_softmax2_dropout_fwd", "vs_conv_wgrad_multi", "vs_conv_wgrad_multi_workspace_bytes",
                  "vs_dice_loss_multi_fwd", "vs_dice_loss_multi_bwd", "vs_dice_loss_multi_scratch_doubles"):
         assert must in protos, must
-    assert _lib.lib.vs_version() == 200
+    assert _lib.lib.vs_version() == 201
     assert b"dtype" in _lib.lib.vs_strerror(-3)
 
 
@@ -124,8 +124,10 @@ def test_module_surface_on_cpu_is_constructible_but_not_runnable():
     assert [n.split(".")[0] for n, _ in joint.named_parameters()][0] == "Seg"
     with pytest.raises(RuntimeError):
         joint({"x": torch.zeros(1, 1, 96, 96, 96)}, "x", "p", "r")
+    bn = M.Segmentation(1, 2)                                # the constructors' default norm_type=2: BatchNorm3d holders, reference state_dict keys
+    assert "in_block.conv.1.running_var" in bn.state_dict() and isinstance(M.DoubleConv(8, 8, norm_type=1, soft=True).conv[2], torch.nn.Softplus)
     with pytest.raises(NotImplementedError):
-        M.Segmentation(1, 2, norm_type=2)
+        M.Segmentation(1, 2, norm_type=3)                    # GSNorm3d: nothing in the reference instantiates it
     with pytest.raises(NotImplementedError):
         M.Segmentation(1, 3, norm_type=1)
 
@@ -167,3 +169,21 @@ def test_ddp_flat_grad_sync_gloo_world2(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
     assert all("ok" in o for o in outs)
+
+
+def test_capture_safe_accumulators_detects_graphs_of_earlier_passes():
+    """train.capture_safe_accumulators (GraphedStep's guard): gradient accumulators nobody owns are re-created under the caller's stream,
+    ones it tagged earlier are accepted, ones an older autograd graph keeps alive are reported instead of being captured over."""
+    import torch
+    from vae_segmentation_amd import train as T
+    ps = [torch.nn.Parameter(torch.randn(3)) for _ in range(3)] + [torch.nn.Parameter(torch.randn(2), requires_grad=False)]
+    a = T.capture_safe_accumulators(ps)
+    assert len(a) == 3
+    b = T.capture_safe_accumulators(ps)                      # the first call's nodes are alive and tagged
+    assert all(x is y for x, y in zip(a, b))
+    del a, b
+    loss = sum((p * 2).sum() for p in ps[:3])
+    with pytest.raises(RuntimeError, match="earlier eager pass"):
+        T.capture_safe_accumulators(ps)
+    del loss
+    assert len(T.capture_safe_accumulators(ps)) == 3

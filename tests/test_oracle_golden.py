@@ -62,6 +62,69 @@ def test_blocks(tag):
     G.check_grads(g, tag, [(n, p.grad) for n, p in mod.named_parameters()], rtol=1e-5, what=tag)
 
 
+BLOCKS_NORM = {
+    "conv_bn_2_8": lambda: O.Conv(2, 8, norm_type=2),
+    "dconv_bn_8_16": lambda: O.DoubleConv(8, 16, norm_type=2),
+    "down_bn_8_16": lambda: O.Down(8, 16, norm_type=2),
+    "up_bn_16_8": lambda: O.Up(16, 8, norm_type=2),
+    "down_bn_64_128": lambda: O.Down(64, 128, norm_type=2),
+    "conv_bn_eval_2_8": lambda: O.Conv(2, 8, norm_type=2),
+    "dconv_soft_8_16": lambda: O.DoubleConv(8, 16, norm_type=1, soft=True),
+    "conv_soft_2_8": lambda: O.Conv(2, 8, norm_type=1, soft=True),
+    "dconv_bn_soft_8_16": lambda: O.DoubleConv(8, 16, norm_type=2, soft=True),
+}
+
+
+def run_block_norm(mod, g, tag, device="cpu"):
+    """the case of oracle/make_golden.py:_blocks_norm on `mod` -> (out, input gradient)"""
+    seed = int(g[tag + ".seed"])
+    shape = tuple(int(v) for v in g[tag + ".shape"])
+    x = torch.from_numpy(2 * O.hashed_uniform(int(np.prod(shape)), 7001, seed) - 1).view(shape).to(device).requires_grad_(True)
+    if "_eval_" in tag:
+        mod.train()
+        with torch.no_grad():
+            mod(x)
+        mod.eval()
+    y = mod(x)
+    w = torch.from_numpy(2 * O.hashed_uniform(y.numel(), 7002, seed) - 1).view_as(y).to(device)
+    (y * w).sum().backward()
+    return y, x.grad
+
+
+def check_bn_buffers(g, tag, mod, rtol):
+    for name, m in mod.named_modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            for buf in ("running_mean", "running_var"):
+                ref = g["%s.bn.%s.%s" % (tag, name, buf)]
+                got = getattr(m, buf).detach().cpu().double().numpy()
+                assert np.abs(got - ref).max() <= rtol * max(np.abs(ref).max(), 1e-3), (tag, name, buf)
+            assert int(m.num_batches_tracked) == int(g["%s.bn.%s.tracked" % (tag, name)]), (tag, name)
+
+
+@pytest.mark.parametrize("tag", sorted(BLOCKS_NORM))
+def test_blocks_norm(tag):
+    """BatchNorm3d (training / eval) and Softplus blocks: the oracle against the reference's own blocks"""
+    g = G.load("blocks_norm")
+    mod = O.bn_fill_(O.deterministic_fill_(BLOCKS_NORM[tag](), seed=int(g[tag + ".seed"])))
+    y, gin = run_block_norm(mod, g, tag)
+    G.check_tensor(g, tag + ".out", y, rtol=1e-5, what=tag)
+    G.check_tensor(g, tag + ".gin", gin, rtol=1e-5, what=tag)
+    G.check_grads(g, tag, [(n, p.grad) for n, p in mod.named_parameters()], rtol=1e-5, what=tag)
+    check_bn_buffers(g, tag, mod, 1e-6)
+
+
+def test_seg32_bn():
+    g = G.load("seg32_bn")
+    seg = O.bn_fill_(O.deterministic_fill_(O.Segmentation(1, 2, norm_type=2), seed=0))
+    img, lab = O.synthetic_image(2, 32, seed=2), O.synthetic_label(2, 32, seed=3)
+    loss, aux = O.seg_train_losses(seg, img, lab)
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["dice_loss"]), rel=1e-5)
+    G.check_tensor(g, "pred", aux["batch"]["pred"], k=256, rtol=1e-4, what="seg32_bn")
+    G.check_grads(g, "seg", [(n, p.grad) for n, p in seg.named_parameters()], rtol=1e-3, what="seg32_bn")
+    check_bn_buffers(g, "seg", seg, 1e-5)
+
+
 def test_seg32():
     g = G.load("seg32")
     seg = O.deterministic_fill_(O.Segmentation(1, 2, norm_type=1), seed=0)

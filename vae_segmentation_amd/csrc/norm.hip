@@ -438,3 +438,278 @@ extern "C" int vs_bias_grad_acc(const void* g, float* db, long long rows, int c_
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// General normalisation + activation (vaeseg.h: vs_norm_*): BatchNorm3d (joint_model.py:13, norm_type=2 — the class default, which
+// no entry point passes) with its affine pair and running statistics, InstanceNorm3d, ReLU or Softplus (joint_model.py:38, soft=True).
+// No entry point of the reference reaches these settings, so they are NOT fused into the conv kernels: the conv writes its raw
+// output and (sum, sumsq) statistics as always, one tiny kernel turns the statistics into per-(n,c) mean / rstd tables (pooled over
+// the batch for BatchNorm, running statistics updated in the same kernel), and three streaming passes do forward, backward
+// reduction and backward apply.  The activation that leaves is a stored tensor (the next conv takes it as a non-lazy input).
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float na_act(float u, int act) {
+    if (act == VS_ACT_RELU) return u > 0.f ? u : 0.f;
+    return u > 20.f ? u : log1pf(expf(u));                 // torch.nn.Softplus(beta=1, threshold=20)
+}
+__device__ __forceinline__ float na_dact(float u, int act) {
+    if (act == VS_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+    return u > 20.f ? 1.f : 1.f / (1.f + expf(-u));
+}
+
+// one workgroup; tables float[n*c] each.  BatchNorm training: batch mean / biased variance normalise, the running pair takes the
+// unbiased variance (torch.nn.BatchNorm3d), num_batches_tracked is bumped.
+__global__ __launch_bounds__(256) void norm_tables_kernel(const double* __restrict__ stats, int n, int c, double count, int mode, float eps,
+                                                          float momentum, float* running_mean, float* running_var, long long* tracked,
+                                                          int c_real, float* __restrict__ mean, float* __restrict__ rstd) {
+    const size_t pairs = (size_t)n * c;
+    if (mode == VS_NORM_INSTANCE) {
+        for (int i = threadIdx.x; i < n * c; i += 256) {
+            double st[2];
+            stat_load(stats, (size_t)i, pairs, st);
+            float m, r;
+            pair_to_mean_rstd(st, 1.0 / count, eps, m, r);
+            mean[i] = m; rstd[i] = r;
+        }
+        return;
+    }
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        float m = 0.f, r = 1.f;
+        if (mode == VS_NORM_BATCH) {
+            double s = 0.0, q = 0.0;
+            for (int i = 0; i < n; ++i) {
+                double st[2];
+                stat_load(stats, (size_t)i * c + ch, pairs, st);
+                s += st[0]; q += st[1];
+            }
+            const double tot = count * n;
+            const double md = s / tot;
+            double var = q / tot - md * md;
+            if (var < 0.0) var = 0.0;
+            m = (float)md;
+            r = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean != nullptr && ch < c_real) {
+                running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * m;
+                running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)(tot > 1.0 ? var * tot / (tot - 1.0) : var);
+            }
+        } else if (ch < c_real) {                               // VS_NORM_BATCH_EVAL
+            m = running_mean[ch];
+            r = (float)(1.0 / sqrt((double)running_var[ch] + (double)eps));
+        }
+        for (int i = 0; i < n; ++i) { mean[i * c + ch] = m; rstd[i * c + ch] = r; }
+    }
+    if (mode == VS_NORM_BATCH && tracked != nullptr && threadIdx.x == 0) *tracked += 1;
+}
+
+// scale / shift of u = xhat * gamma + beta written as x * sc + sh; channels beyond c_real are padding and stay zero
+__device__ __forceinline__ void na_load_tables(const float* mean, const float* rstd, const float* gamma, const float* beta, int n, int c,
+                                               int c_real, float* s_m, float* s_r, float* s_g, float* s_b) {
+    for (int i = threadIdx.x; i < c; i += blockDim.x) {
+        s_m[i] = mean[n * c + i];
+        s_r[i] = rstd[n * c + i];
+        s_g[i] = i < c_real ? (gamma != nullptr ? gamma[i] : 1.f) : 0.f;
+        s_b[i] = (i < c_real && beta != nullptr) ? beta[i] : 0.f;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_fwd_kernel(const T* __restrict__ x, const float* mean, const float* rstd, const float* gamma,
+                                                           const float* beta, T* __restrict__ y, long long voxels, int c, int c_real, int act) {
+    constexpr int EPL = ET<T>::EPL;
+    __shared__ float s_m[NB_MAX_C], s_r[NB_MAX_C], s_g[NB_MAX_C], s_b[NB_MAX_C];
+    const int n = blockIdx.y;
+    na_load_tables(mean, rstd, gamma, beta, n, c, c_real, s_m, s_r, s_g, s_b);
+    __syncthreads();
+    RowIter<T> it(c);
+    if (!it.active()) return;
+    float m[EPL], r[EPL], ga[EPL], be[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) { const int ch = it.fx * EPL + j; m[j] = s_m[ch]; r[j] = s_r[ch]; ga[j] = s_g[ch]; be[j] = s_b[ch]; }
+    const size_t sample = (size_t)n * voxels * c + it.fx * EPL;
+    for (long long v = (long long)blockIdx.x * it.rows_per_it + it.fy; v < voxels; v += (long long)gridDim.x * it.rows_per_it) {
+        float f[EPL], o[EPL];
+        frag_unpack(*(const u32x4*)(x + sample + v * c), f, (T*)nullptr);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const float u = (f[j] - m[j]) * r[j] * ga[j] + be[j];
+            o[j] = it.fx * EPL + j < c_real ? na_act(u, act) : 0.f;
+        }
+        *(u32x4*)(y + sample + v * c) = frag_pack(o, (T*)nullptr);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ x, const float* mean,
+                                                                  const float* rstd, const float* gamma, const float* beta,
+                                                                  double* __restrict__ sums, long long voxels, int c, int c_real, int act) {
+    constexpr int EPL = ET<T>::EPL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* s_red = (double*)smem;
+    __shared__ float s_m[NB_MAX_C], s_r[NB_MAX_C], s_g[NB_MAX_C], s_b[NB_MAX_C];
+    const int n = blockIdx.y;
+    na_load_tables(mean, rstd, gamma, beta, n, c, c_real, s_m, s_r, s_g, s_b);
+    __syncthreads();
+    RowIter<T> it(c);
+    double part[EPL][2];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) part[j][0] = part[j][1] = 0.0;
+    if (it.active()) {
+        float m[EPL], r[EPL], ga[EPL], be[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) { const int ch = it.fx * EPL + j; m[j] = s_m[ch]; r[j] = s_r[ch]; ga[j] = s_g[ch]; be[j] = s_b[ch]; }
+        const size_t sample = (size_t)n * voxels * c + it.fx * EPL;
+        for (long long v = (long long)blockIdx.x * it.rows_per_it + it.fy; v < voxels; v += (long long)gridDim.x * it.rows_per_it) {
+            float fg[EPL], fx_[EPL];
+            frag_unpack(*(const u32x4*)(g + sample + v * c), fg, (T*)nullptr);
+            frag_unpack(*(const u32x4*)(x + sample + v * c), fx_, (T*)nullptr);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const float xh = (fx_[j] - m[j]) * r[j];
+                const float da = fg[j] * na_dact(xh * ga[j] + be[j], act);
+                part[j][0] += da;
+                part[j][1] += (double)da * xh;
+            }
+        }
+    }
+    reduce_and_atomic<T, 2>(it, part, sums, n, c, s_red);
+}
+
+// one workgroup: coef[n*c][3] = (k, m1, m2) of dx = k * (da - m1 - xhat * m2); dgamma / dbeta (fp32 [c_real], nullable)
+__global__ __launch_bounds__(256) void norm_act_bwd_finish_kernel(const double* __restrict__ sums, int n, int c, int c_real, double count, int mode,
+                                                                  const float* rstd, const float* gamma, float* __restrict__ coef,
+                                                                  float* dgamma, float* dbeta) {
+    const size_t pairs = (size_t)n * c;
+    for (int ch = threadIdx.x; ch < c; ch += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double st[2];
+            stat_load(sums, (size_t)i * c + ch, pairs, st);
+            s1 += st[0]; s2 += st[1];
+            if (mode == VS_NORM_INSTANCE) {
+                coef[((size_t)i * c + ch) * 3 + 1] = (float)(st[0] / count);
+                coef[((size_t)i * c + ch) * 3 + 2] = (float)(st[1] / count);
+            }
+        }
+        const float ga = ch < c_real ? (gamma != nullptr ? gamma[ch] : 1.f) : 0.f;
+        for (int i = 0; i < n; ++i) {
+            float* co = coef + ((size_t)i * c + ch) * 3;
+            co[0] = ga * rstd[i * c + ch];
+            if (mode == VS_NORM_BATCH) { co[1] = (float)(s1 / (count * n)); co[2] = (float)(s2 / (count * n)); }
+            else if (mode == VS_NORM_BATCH_EVAL) { co[1] = 0.f; co[2] = 0.f; }
+        }
+        if (ch < c_real) {
+            if (dgamma != nullptr) dgamma[ch] = (float)s2;
+            if (dbeta != nullptr) dbeta[ch] = (float)s1;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_act_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x, const float* mean,
+                                                                 const float* rstd, const float* gamma, const float* beta,
+                                                                 const float* __restrict__ coef, T* __restrict__ dx, long long voxels, int c,
+                                                                 int c_real, int act) {
+    constexpr int EPL = ET<T>::EPL;
+    __shared__ float s_m[NB_MAX_C], s_r[NB_MAX_C], s_g[NB_MAX_C], s_b[NB_MAX_C], s_k[NB_MAX_C], s_1[NB_MAX_C], s_2[NB_MAX_C];
+    const int n = blockIdx.y;
+    na_load_tables(mean, rstd, gamma, beta, n, c, c_real, s_m, s_r, s_g, s_b);
+    for (int i = threadIdx.x; i < c; i += 256) {
+        const float* co = coef + ((size_t)n * c + i) * 3;
+        s_k[i] = co[0]; s_1[i] = co[1]; s_2[i] = co[2];
+    }
+    __syncthreads();
+    RowIter<T> it(c);
+    if (!it.active()) return;
+    float m[EPL], r[EPL], ga[EPL], be[EPL], k[EPL], m1[EPL], m2[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const int ch = it.fx * EPL + j;
+        m[j] = s_m[ch]; r[j] = s_r[ch]; ga[j] = s_g[ch]; be[j] = s_b[ch]; k[j] = s_k[ch]; m1[j] = s_1[ch]; m2[j] = s_2[ch];
+    }
+    const size_t sample = (size_t)n * voxels * c + it.fx * EPL;
+    for (long long v = (long long)blockIdx.x * it.rows_per_it + it.fy; v < voxels; v += (long long)gridDim.x * it.rows_per_it) {
+        float fg[EPL], fx_[EPL], o[EPL];
+        frag_unpack(*(const u32x4*)(g + sample + v * c), fg, (T*)nullptr);
+        frag_unpack(*(const u32x4*)(x + sample + v * c), fx_, (T*)nullptr);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const float xh = (fx_[j] - m[j]) * r[j];
+            const float da = fg[j] * na_dact(xh * ga[j] + be[j], act);
+            o[j] = k[j] * (da - m1[j] - xh * m2[j]);
+        }
+        *(u32x4*)(dx + sample + v * c) = frag_pack(o, (T*)nullptr);
+    }
+}
+
+static int na_check(const void* x, const float* mean, const float* rstd, int n, long long voxels, int c, int c_real, int act, int dtype) {
+    int rc = check_cl(x, n, voxels, c, dtype);
+    if (rc) return rc;
+    if (!mean || !rstd || c_real <= 0 || c_real > c) return VS_EINVAL;
+    if (act != VS_ACT_RELU && act != VS_ACT_SOFTPLUS) return VS_EINVAL;
+    return VS_OK;
+}
+
+extern "C" int vs_norm_tables(const double* stats, int n, int c, int c_real, double count, int mode, float eps, float momentum,
+                              float* running_mean, float* running_var, long long* num_batches_tracked, float* mean, float* rstd, void* stream) {
+    if (!mean || !rstd || n <= 0 || c <= 0 || c_real <= 0 || c_real > c || count <= 0) return VS_EINVAL;
+    if (mode != VS_NORM_INSTANCE && mode != VS_NORM_BATCH && mode != VS_NORM_BATCH_EVAL) return VS_EINVAL;
+    if (mode != VS_NORM_BATCH_EVAL && !stats) return VS_EINVAL;
+    if (mode == VS_NORM_BATCH_EVAL && (!running_mean || !running_var)) return VS_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return VS_EINVAL;
+    hipLaunchKernelGGL(norm_tables_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, n, c, count, mode, eps, momentum, running_mean,
+                       running_var, num_batches_tracked, c_real, mean, rstd);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_norm_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta, void* y, int n,
+                               long long voxels, int c, int c_real, int act, int dtype, void* stream) {
+    int rc = na_check(x, mean, rstd, n, voxels, c, c_real, act, dtype);
+    if (rc) return rc;
+    if (!y) return VS_EINVAL;
+    dim3 grid(row_blocks(voxels, c, dtype, false), n);
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(norm_act_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, mean, rstd, gamma, beta, (T*)y, voxels, c, c_real, act);
+    });
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_norm_act_bwd_reduce(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                      double* sums, int n, long long voxels, int c, int c_real, int act, int dtype, void* stream) {
+    int rc = na_check(x, mean, rstd, n, voxels, c, c_real, act, dtype);
+    if (rc) return rc;
+    if (!g || !sums) return VS_EINVAL;
+    dim3 grid(row_blocks(voxels, c, dtype), n);
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(norm_act_bwd_reduce_kernel<T>, grid, dim3(256), red_lds(dtype, 2), (hipStream_t)stream, (const T*)g, (const T*)x, mean, rstd,
+                           gamma, beta, sums, voxels, c, c_real, act);
+    });
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_norm_act_bwd_finish(const double* sums, int n, int c, int c_real, double count, int mode, const float* rstd, const float* gamma,
+                                      float* coef, float* dgamma, float* dbeta, void* stream) {
+    if (!sums || !rstd || !coef || n <= 0 || c <= 0 || c_real <= 0 || c_real > c || count <= 0) return VS_EINVAL;
+    if (mode != VS_NORM_INSTANCE && mode != VS_NORM_BATCH && mode != VS_NORM_BATCH_EVAL) return VS_EINVAL;
+    hipLaunchKernelGGL(norm_act_bwd_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, n, c, c_real, count, mode, rstd, gamma, coef, dgamma, dbeta);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_norm_act_bwd_apply(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     const float* coef, void* dx, int n, long long voxels, int c, int c_real, int act, int dtype, void* stream) {
+    int rc = na_check(x, mean, rstd, n, voxels, c, c_real, act, dtype);
+    if (rc) return rc;
+    if (!g || !coef || !dx) return VS_EINVAL;
+    dim3 grid(row_blocks(voxels, c, dtype, false), n);
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(norm_act_bwd_apply_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g, (const T*)x, mean, rstd, gamma, beta,
+                           coef, (T*)dx, voxels, c, c_real, act);
+    });
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}

@@ -7,9 +7,12 @@ main_source.py / main_target.py loops keep working.  Parameters live in ordinary
 (InstanceNorm3d / ReLU entries are parameter-less there too), but ``forward`` never calls those holders:
 it launches the fused kernels through ``ops``.  There is no CPU path — inputs must be CUDA tensors.
 
-Only the configuration every entry point of the reference uses is implemented natively: ``norm_type=1``
-(InstanceNorm3d), ReLU (``soft=False``), two classes; dropout at the reference's sites is native too.
-Other settings raise NotImplementedError.
+The configuration every entry point of the reference uses — ``norm_type=1`` (InstanceNorm3d), ReLU (``soft=False``), two classes
+ — runs fused: normalisation and activation are applied inside the consuming conv kernels.  The constructors' other
+settings, ``norm_type=2`` (BatchNorm3d, the class default, with affine parameters and running statistics) and ``soft=True``
+(Softplus), run through ``ops.NormAct``: native too, but as separate streaming passes after each conv (nothing in the reference
+reaches them: main_source.py:250-272, main_target.py:317-342 pass norm_type=1, and every block receives soft=False).
+``norm_type=3`` (GSNorm3d) and the ``*_GS`` classes, which no reference code instantiates, raise NotImplementedError.
 """
 import torch
 import torch.nn as nn
@@ -46,16 +49,18 @@ class Act:
 
 
 def Normalization(norm_type, out_channels, num_group=1):
-    """joint_model.py:9-15 — parameter-less holder kept for Sequential index / repr parity."""
+    """joint_model.py:9-15 — the holder at the reference's Sequential index: parameter-less InstanceNorm3d, or BatchNorm3d whose
+    weight / bias / running_mean / running_var / num_batches_tracked are the state the native kernels read and update."""
     if norm_type == 1:
         return nn.InstanceNorm3d(out_channels)
-    raise NotImplementedError("native kernels implement norm_type=1 (InstanceNorm3d), the only value the "
-                              "reference's entry points use (main_source.py:250-272, main_target.py:317-342)")
+    if norm_type == 2:
+        return nn.BatchNorm3d(out_channels, momentum=0.1)
+    raise NotImplementedError("norm_type=3 (GSNorm3d, joint_model.py:17-33) has no native kernel; nothing in the reference instantiates it")
 
 
-def _check_soft(soft):
-    if soft:
-        raise NotImplementedError("Softplus variant (soft=True) has no native kernel; every entry point passes soft=False")
+def _activation(soft, inplace):
+    """joint_model.py:38,104 — the holder at the reference's Sequential index"""
+    return nn.Softplus() if soft else nn.ReLU(inplace=inplace)
 
 
 def _as_act(x, dtype):
@@ -75,15 +80,28 @@ def _conv3(conv, a):
     return Act(y, ys)
 
 
+def _conv_norm_act(seq, i, a):
+    """Sequential entries i, i+1, i+2 = conv3x3x3, normalisation, activation (joint_model.py:40-48,106-108).  InstanceNorm + ReLU stays
+    lazy (applied by the consuming kernels); BatchNorm and / or Softplus go through ops.NormAct and leave as a stored activation."""
+    conv, norm, actm = seq[i], seq[i + 1], seq[i + 2]
+    if isinstance(norm, nn.InstanceNorm3d) and isinstance(actm, nn.ReLU):
+        return _conv3(conv, a)
+    y, ys = ops.ConvK3.apply(a.raw, a.stats, conv.weight, conv.bias, True)
+    bn = norm if isinstance(norm, nn.BatchNorm3d) else None
+    act = ops.VS_ACT_SOFTPLUS if isinstance(actm, nn.Softplus) else ops.VS_ACT_RELU
+    out = ops.NormAct.apply(y, ys, bn.weight if bn is not None else None, bn.bias if bn is not None else None, bn, act, conv.weight.shape[0])
+    return Act(out, None)
+
+
 class DoubleConv(nn.Module):
     """joint_model.py:35-52 — three (conv3x3x3 -> norm -> act) triples, Sequential indices 0..8."""
 
     def __init__(self, in_ch, out_ch, norm_type=2, soft=False):
         super().__init__()
-        _check_soft(soft)
+        activation = _activation(soft, False)               # one module at indices 2, 5, 8, as in the reference
         layers = []
         for cin in (in_ch, out_ch, out_ch):
-            layers += [nn.Conv3d(cin, out_ch, 3, padding=1), Normalization(norm_type, out_ch), nn.ReLU(inplace=False)]
+            layers += [nn.Conv3d(cin, out_ch, 3, padding=1), Normalization(norm_type, out_ch), activation]
         self.conv = nn.Sequential(*layers)
         self.out_ch = out_ch
         self.kernel_dtype = _DEFAULT_DTYPE
@@ -91,7 +109,7 @@ class DoubleConv(nn.Module):
     def forward(self, x):
         a, wrapped = _as_act(x, self.kernel_dtype)
         for i in (0, 3, 6):
-            a = _conv3(self.conv[i], a)
+            a = _conv_norm_act(self.conv, i, a)
         return _as_tensor(a, self.out_ch) if wrapped else a
 
 
@@ -100,15 +118,14 @@ class Conv(nn.Module):
 
     def __init__(self, in_ch, out_ch, norm_type=2, num_group=1, activation=True, norm=True, soft=False):
         super().__init__()
-        _check_soft(soft)
         self.conv = nn.Sequential(nn.Conv3d(in_ch, out_ch, 3, padding=1), Normalization(norm_type, out_ch),
-                                  nn.ReLU(inplace=True))
+                                  _activation(soft, True))
         self.out_ch = out_ch
         self.kernel_dtype = _DEFAULT_DTYPE
 
     def forward(self, x):
         a, wrapped = _as_act(x, self.kernel_dtype)
-        a = _conv3(self.conv[0], a)
+        a = _conv_norm_act(self.conv, 0, a)
         return _as_tensor(a, self.out_ch) if wrapped else a
 
 

@@ -817,11 +817,13 @@ class ConvK3(torch.autograd.Function):
     nor differentiated (its gradient is returned as zeros, the reference's is ~1e-7 noise)."""
 
     @staticmethod
-    def forward(ctx, x, xs, weight, bias):
+    def forward(ctx, x, xs, weight, bias, live_bias=False):
         _require_cuda(x, weight)
         cout, cin = weight.shape[0], weight.shape[1]
         wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, x.shape[-1], x.dtype)
-        y, ys = conv_gather(x, xs, wp, None, cpad(cout), VS_CONV_K3, True, real_channels=(cin, cout))
+        # live_bias: the general norm path (NormAct) — under BatchNorm in eval mode the bias is not cancelled by the normalisation
+        ctx.live_bias = bool(live_bias) and bias is not None
+        y, ys = conv_gather(x, xs, wp, bias if ctx.live_bias else None, cpad(cout), VS_CONV_K3, True, real_channels=(cin, cout))
         ctx.save_for_backward(x, xs, weight)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias                   # a Parameter (long-lived leaf): only its gradient slot is looked up in backward
@@ -833,7 +835,7 @@ class ConvK3(torch.autograd.Function):
     def backward(ctx, gy, _gys):
         x, xs, weight = ctx.saved_tensors
         if gy is None:
-            return None, None, None, None
+            return None, None, None, None, None
         gy = _contig(gy)
         cout, cin = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
@@ -843,11 +845,15 @@ class ConvK3(torch.autograd.Function):
                 gx = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K3, real_channels=(cout, cin))
             else:
                 gx, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K3, False, real_channels=(cout, cin))
+        want_gb = ctx.has_bias and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[2]:
-            gw, _ = _side_grads(weight, (gy, x, xs), (gy, None, x, xs, cout, cin, VS_CONV_K3), None)
-        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gw, gb = _side_grads(weight, (gy, x, xs), (gy, None, x, xs, cout, cin, VS_CONV_K3),
+                                 (gy, cout) if want_gb and ctx.live_bias else None, ctx.bias_ref if ctx.live_bias else None)
+        elif want_gb and ctx.live_bias:
+            gb = bias_grad(gy, cout)
+        if want_gb and not ctx.live_bias:
             gb = _dead_bias_grad(ctx.bias_ref, ctx.bias_ref.shape[0], gy.device)
-        return gx, None, gw, gb
+        return gx, None, gw, gb, None
 
 
 class ConvK3Softmax(torch.autograd.Function):
@@ -1068,6 +1074,65 @@ class Materialize(torch.autograd.Function):
         if x2 is not None and ctx.needs_input_grad[2]:
             g2 = in_relu_bwd(g, x2, x2s, inplace=False) if x2s is not None else g
         return g1, None, g2, None, None
+
+
+VS_NORM_INSTANCE, VS_NORM_BATCH, VS_NORM_BATCH_EVAL = 0, 1, 2
+VS_ACT_RELU, VS_ACT_SOFTPLUS = 0, 1
+
+
+class NormAct(torch.autograd.Function):
+    """(raw conv output, its statistics) -> act(norm(raw) * gamma + beta) as a stored tensor: the block settings no entry point of the
+    reference uses — BatchNorm3d (joint_model.py:13, with running statistics), Softplus (joint_model.py:38) — and InstanceNorm with
+    either activation.  Unfused on purpose (vaeseg.h: general normalisation); the InstanceNorm + ReLU configuration of every entry point
+    never comes here (it stays lazy, fused into the convs).  bn = the nn.BatchNorm3d holder (running buffers, momentum, eps, training)
+    or None for InstanceNorm."""
+
+    @staticmethod
+    def forward(ctx, x, xs, gamma, beta, bn, act, c_real):
+        _require_cuda(x)
+        n, c = x.shape[0], x.shape[-1]
+        voxels = x.numel() // (n * c)
+        if bn is None:
+            mode, eps, mom, rm, rv, nbt = VS_NORM_INSTANCE, EPS_IN, 0.0, None, None, None
+        else:
+            track = bn.track_running_stats and bn.running_mean is not None
+            mode = VS_NORM_BATCH if (bn.training or not track) else VS_NORM_BATCH_EVAL
+            eps = float(bn.eps)
+            mom = 0.0 if bn.momentum is None else float(bn.momentum)
+            rm, rv, nbt = (bn.running_mean, bn.running_var, bn.num_batches_tracked) if track else (None, None, None)
+            if bn.momentum is None and track and mode == VS_NORM_BATCH:
+                raise NotImplementedError("BatchNorm3d(momentum=None) (cumulative average) has no native form; the reference uses momentum=0.1")
+        tab = torch.empty(2, n, c, dtype=torch.float32, device=x.device)
+        check(lib.vs_norm_tables(_p(xs), n, c, c_real, float(voxels), mode, eps, mom, _p(rm), _p(rv), _p(nbt), tab[0].data_ptr(), tab[1].data_ptr(),
+                                 _stream()), "norm_tables")
+        y = torch.empty_like(x)
+        check(lib.vs_norm_act_fwd(x.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), _p(gamma), _p(beta), y.data_ptr(), n, voxels, c, c_real, act,
+                                  vs_dtype(x), _stream()), "norm_act_fwd")
+        ctx.save_for_backward(x, tab, gamma, beta)
+        ctx.mode, ctx.act, ctx.c_real = mode, act, c_real
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, tab, gamma, beta = ctx.saved_tensors
+        g = _contig(g)
+        n, c = x.shape[0], x.shape[-1]
+        voxels = x.numel() // (n * c)
+        dt, st = vs_dtype(x), _stream()
+        sums = _new_stats(n, c, x.device)
+        check(lib.vs_norm_act_bwd_reduce(g.data_ptr(), x.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), _p(gamma), _p(beta), sums.data_ptr(), n,
+                                         voxels, c, ctx.c_real, ctx.act, dt, st), "norm_act_bwd_reduce")
+        coef = torch.empty(n, c, 3, dtype=torch.float32, device=x.device)
+        dgamma = torch.empty_like(gamma) if gamma is not None and ctx.needs_input_grad[2] else None
+        dbeta = torch.empty_like(beta) if beta is not None and ctx.needs_input_grad[3] else None
+        check(lib.vs_norm_act_bwd_finish(sums.data_ptr(), n, c, ctx.c_real, float(voxels), ctx.mode, tab[1].data_ptr(), _p(gamma), coef.data_ptr(),
+                                         _p(dgamma), _p(dbeta), st), "norm_act_bwd_finish")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.vs_norm_act_bwd_apply(g.data_ptr(), x.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), _p(gamma), _p(beta), coef.data_ptr(),
+                                            dx.data_ptr(), n, voxels, c, ctx.c_real, ctx.act, dt, st), "norm_act_bwd_apply")
+        return dx, None, dgamma, dbeta, None, None, None
 
 
 _DROPOUT_CALLS = [0]

@@ -184,6 +184,37 @@ def domain_adaptation_dis_losses(student, teacher_seg, img, label, lambda_vae=1.
     return final, {"discriminator_loss": dis_loss, "dice_loss_fake": fake_loss, "dice_loss": dsc_loss, "batch": batch}
 
 
+def capture_safe_accumulators(params):
+    """The AccumulateGrad node of every parameter, guaranteed to have been created under the CURRENT stream (call this under the side
+    stream the warm-up runs on) or by an earlier call of this function; the caller keeps the returned list alive through the capture.
+
+    Why: autograd creates a parameter's AccumulateGrad node lazily, records the stream that was current at that moment, and re-uses the
+    node for as long as any autograd graph references it.  A node born in an eager pass on the default stream — kept alive by a loss or
+    an output somebody still holds — makes the captured backward hop to the legacy default stream, which cannot join a stream capture:
+    hipStreamEndCapture then crashes the process (seen with a test that kept `loss, aux` of an eager step).  A node nobody else owns is
+    simply re-created here; one that survives without a reference of ours is reported."""
+    accs, stale = [], []
+    for p in params:
+        if not p.requires_grad:
+            continue
+        with torch.enable_grad():
+            acc = p.view_as(p).grad_fn.next_functions[0][0]
+            if not acc.metadata.get("vs_capture_safe"):
+                acc.metadata["vs_probe"] = True
+                del acc
+                acc = p.view_as(p).grad_fn.next_functions[0][0]          # the same node only if an older autograd graph owns it
+                if acc.metadata.get("vs_probe"):
+                    stale.append(p)
+                else:
+                    acc.metadata["vs_capture_safe"] = True
+        accs.append(acc)
+    if stale:
+        raise RuntimeError("GraphedStep: %d parameter(s) are still referenced by the autograd graph of an earlier eager pass (a loss or output "
+                           "that is still alive); their gradient accumulators belong to the default stream and a stream capture cannot "
+                           "include it.  Drop those tensors (del loss, aux) — or build the GraphedStep first — and try again." % len(stale))
+    return accs
+
+
 class GraphedStep:
     """zero_grad -> forward -> losses -> backward captured once into a HIP graph and replayed per step; the
     optimiser (one multi-tensor kernel) and, under data parallelism, the gradient all-reduces run eagerly around the replays.
@@ -210,6 +241,7 @@ class GraphedStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            self._accumulators = capture_safe_accumulators(self.params)      # kept: the capture must find these, not default-stream ones
             for _ in range(warmup):
                 self._eager_fwd_bwd()
         torch.cuda.current_stream().wait_stream(side)
