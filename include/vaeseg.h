@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VS_VERSION 201
+#define VS_VERSION 202
 
 enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2 };   /* storage type of activations: fp32 (parity mode), bf16, IEEE fp16 (needs loss scaling, see vs_loss_scale_*) */
 #ifndef VS_STAT_SLOTS
@@ -191,7 +191,7 @@ int vs_instnorm_relu_bwd_pair(const void* g, const void* x1, const double* x1_st
  * (joint_model.py:12-13, the constructors' default) with its affine pair and running statistics, and soft=True = torch.nn.Softplus()
  * (joint_model.py:38,58,93,104).  Not fused into the convs: the conv writes its raw output and (sum, sumsq) statistics as always and
  * these streaming passes follow; the activation that leaves is a stored tensor.  u = xhat * gamma + beta, xhat = (x - mean) * rstd. */
-enum { VS_NORM_INSTANCE = 0, VS_NORM_BATCH = 1, VS_NORM_BATCH_EVAL = 2 };   /* per (n,c) | pooled over the batch (training) | running statistics */
+enum { VS_NORM_INSTANCE = 0, VS_NORM_BATCH = 1, VS_NORM_BATCH_EVAL = 2, VS_NORM_NONE = 3 };   /* per (n,c) | pooled over the batch (training) | running statistics | no normalisation: mean 0, rstd 1 (conv -> activation of the *_GS blocks, joint_model.py:58-63) */
 enum { VS_ACT_RELU = 0, VS_ACT_SOFTPLUS = 1 };                               /* Softplus: beta 1, threshold 20 (torch defaults) */
 /* mean / rstd tables float[n][c] from a conv epilogue's statistics (double[VS_STAT_SLOTS][n][c][2], `count` voxels per sample).
  * VS_NORM_BATCH: batch mean and biased variance; running_mean / running_var (nullable pair, fp32 [c_real]) take
@@ -213,6 +213,19 @@ int vs_norm_act_bwd_finish(const double* sums, int n, int c, int c_real, double 
                            float* coef, float* dgamma, float* dbeta, void* stream);
 int vs_norm_act_bwd_apply(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                           const float* coef, void* dx, int n, long long voxels, int c, int c_real, int act, int dtype, void* stream);
+
+/* ---- the `*_GS` model family (joint_model.py:17-33, 54-99, 307-346; instantiated nowhere in the reference) ------------------------------
+ * GSNorm3d (joint_model.py:17-33): y[c] = x[c] / (sum of x over c's group of c / num_group consecutive channels + 1e-4), per voxel;
+ * rows = n * voxels channels-last rows of c channels.  bwd: dx[c] = g[c] / S - (sum_j g[j] x[j]) / S^2. */
+int vs_gsnorm_fwd(const void* x, void* y, long long rows, int c, int num_group, int dtype, void* stream);
+int vs_gsnorm_bwd(const void* g, const void* x, void* dx, long long rows, int c, int num_group, int dtype, void* stream);
+/* torch.nn.Upsample(scale_factor=scale, mode='trilinear') (joint_model.py:69,323-325; align_corners=False): x (n,d,h,w,c) -> y (n,d*s,h*s,w*s,c).
+ * bwd: g (upsampled grid) -> dx; scratch = n*d*h*w*c floats (16-byte aligned; zeroed and used for fp32 atomic accumulation by the call). */
+int vs_upsample_trilinear_fwd(const void* x, void* y, int n, int d, int h, int w, int c, int scale, int dtype, void* stream);
+int vs_upsample_trilinear_bwd(const void* g, void* dx, float* scratch, int n, int d, int h, int w, int c, int scale, int dtype, void* stream);
+/* nn.Softmax(dim=1) over two classes as its own pass (Segmentation_GS.final after the 1x1x1 out_block2, joint_model.py:326-327,343-344):
+ * channels 0, 1 of channels-last logits -> planar fp32 [n][2][voxels]; its backward is vs_softmax2_bwd. */
+int vs_softmax2_fwd(const void* logits, float* prob, int n, long long voxels, int c, int dtype, void* stream);
 
 /* F.dropout(x, p, training=True) on a channels-last tensor (joint_model.py:256-264,379-385): out = x * keep / (1-p),
  * keep ~ Bernoulli(1-p) from a counter-based hash of (seed, element index) — the same call with the same seed applied to

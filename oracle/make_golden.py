@@ -230,6 +230,55 @@ def _seg32_bn(dt):
     return d
 
 
+def gold_gs():
+    """The `*_GS` family (joint_model.py:17-33,54-99,140-202,307-346; instantiated nowhere in the reference): its blocks fwd + bwd and
+    Segmentation_GS with a Dice loss at 32^3."""
+    save("gs", both_precisions(_gs))
+
+
+def _gs(dt):
+    import warnings
+    warnings.filterwarnings("ignore", message=".*align_corners.*")
+    d = {}
+
+    def case(tag, mod, shape, seed, positive=False):
+        O.deterministic_fill_(mod, seed=seed)
+        mod = mod.to(dt)
+        n = int(np.prod(shape))
+        u = O.hashed_uniform(n, 7001, seed)
+        x = torch.from_numpy(u + 0.05 if positive else 2 * u - 1).to(dt).view(shape).requires_grad_(True)
+        y = mod(x)
+        w = torch.from_numpy(2 * O.hashed_uniform(y.numel(), 7002, seed) - 1).to(dt).view_as(y)
+        (y * w).sum().backward()
+        d[tag + ".shape"] = np.asarray(shape)
+        d[tag + ".seed"] = np.asarray(seed)
+        put(d, tag + ".out", y)
+        put(d, tag + ".gin", x.grad)
+        put_grads(d, tag, mod)
+
+    case("gsnorm_16_4", RM.GSNorm3d(16, num_group=4), (2, 16, 8, 8, 8), 31, positive=True)
+    case("conv_gs_2_8", RM.Conv_GS(2, 8), (2, 2, 16, 16, 16), 32)
+    case("dconv_gs_8_16", RM.DoubleConv_GS(8, 16), (2, 8, 16, 16, 16), 33)
+    case("down_gs_8_16", RM.Down_GS(8, 16), (2, 8, 16, 16, 16), 34)
+    case("up_gs_16_8", RM.Up_GS(16, 8), (2, 16, 8, 8, 8), 35)
+    case("gsconv_k3_8_16", RM.GSConv3d(8, 16, 3, num_group=2, padding=1), (2, 8, 8, 8, 8), 36)
+    case("gsconv_k2_8_8", RM.GSConv3d(8, 8, 2, num_group=2, stride=2), (2, 8, 8, 8, 8), 37)
+    case("sconv_k3_1_8", RM.SConv3d(1, 8, 3, padding=1), (2, 1, 8, 8, 8), 38)
+    case("gsconvt_k2_8_8", RM.GSConvTranspose3d(8, 8, 2, num_group=2, stride=2), (2, 8, 4, 4, 4), 39)
+    seg = RM.Segmentation_GS(n_channels=1, n_class=2)
+    O.deterministic_fill_(seg, seed=0)
+    seg = seg.to(dt)
+    img, lab = O.synthetic_image(2, 32, seed=2).to(dt), O.synthetic_label(2, 32, seed=3)
+    batch = {"img": img, "gt": O.one_hot(lab).to(dt)}
+    batch = seg(batch, "img", "pred")
+    dsc = 1 - main_source_avg_dsc(batch["pred"], batch["gt"], 1, 2)
+    dsc.backward()
+    d["seg.dice_loss"] = dsc.detach().numpy()
+    put(d, "seg.pred", batch["pred"], 256)
+    put_grads(d, "seg", seg)
+    return d
+
+
 def gold_seg32():
     save("seg32", both_precisions(_seg32))
 
@@ -750,6 +799,7 @@ CASES = {
     "methods": gold_methods,
     "blocks_norm": gold_blocks_norm,
     "seg32_bn": gold_seg32_bn,
+    "gs": gold_gs,
 }
 
 if __name__ == "__main__":

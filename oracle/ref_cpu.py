@@ -313,6 +313,134 @@ EPS_EVALUATION = 1e-6   # utils/evaluation.py:72-79
 EPS_MAIN_SOURCE = 1e-4  # main_source.py:174-181
 
 
+# --------------------------------------------------------------------------------------
+# the *_GS family (joint_model.py:17-33, 54-99, 140-202, 307-346) — instantiated nowhere in the reference; restated for completeness
+# --------------------------------------------------------------------------------------
+class GSNorm3d(nn.Module):
+    """joint_model.py:17-33: every channel divided by (the sum of its group's channels + 1e-4)"""
+
+    def __init__(self, out_ch, num_group=1):
+        super().__init__()
+        self.out_ch, self.num_group = out_ch, num_group
+
+    def forward(self, x):
+        n, c = x.shape[0], x.shape[1]
+        g = x.reshape(n, self.num_group, c // self.num_group, *x.shape[2:])
+        return (g / (g.sum(2, keepdim=True) + 0.0001)).reshape(x.shape)
+
+
+def _ca(cin, cout, soft, inplace):
+    return [nn.Conv3d(cin, cout, 3, padding=1), _act(soft, inplace)]
+
+
+class DoubleConv_GS(nn.Module):
+    def __init__(self, in_ch, out_ch, num_group=1, soft=False):
+        super().__init__()
+        act = _act(soft, False)
+        self.conv = nn.Sequential(nn.Conv3d(in_ch, out_ch, 3, padding=1), act, nn.Conv3d(out_ch, out_ch, 3, padding=1), act)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Up_GS(nn.Module):
+    def __init__(self, in_ch, out_ch, num_group=1, kernal_size=(2, 2, 2), stride=(2, 2, 2), soft=False):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Upsample(scale_factor=2, mode="trilinear"), DoubleConv_GS(in_ch, out_ch, num_group, soft=False))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Down_GS(nn.Module):
+    def __init__(self, in_ch, out_ch, num_group=1, kernal_size=(2, 2, 2), stride=(2, 2, 2), soft=False):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv3d(in_ch, in_ch, kernal_size, stride=stride, padding=0), DoubleConv_GS(in_ch, out_ch, num_group, soft=False))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Conv_GS(nn.Module):
+    def __init__(self, in_ch, out_ch, num_group=1, activation=True, norm=True, soft=False):
+        super().__init__()
+        self.conv = nn.Sequential(*_ca(in_ch, out_ch, soft, True))
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+def group_normalised_weight(weight, num_group):
+    """joint_model.py:154-161: |w| / (its sum over each group of input channels)"""
+    w = weight.abs()
+    o, i = w.shape[0], w.shape[1]
+    g = w.reshape(o, num_group, i // num_group, *w.shape[2:])
+    return (g / g.sum(2, keepdim=True)).reshape(w.shape)
+
+
+class GSConv3d(nn.Conv3d):
+    def __init__(self, in_channels, out_channels, kernel_size, num_group=1, stride=1, padding=0, dilation=1, groups=1, bias=True, if_sub=None,
+                 trainable=True):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        self.weight.requires_grad = bool(trainable)
+        self.num_group = num_group
+
+    def forward(self, x):
+        return F.conv3d(x, group_normalised_weight(self.weight, self.num_group), self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class GSConvTranspose3d(nn.ConvTranspose3d):
+    def __init__(self, in_channels, out_channels, kernel_size, num_group=1, stride=1, padding=0, dilation=1, output_padding=0, groups=1, bias=False,
+                 if_sub=None, trainable=True):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, output_padding, groups, bias, dilation)
+        self.weight.requires_grad = bool(trainable)
+        self.num_group = num_group
+
+    def forward(self, x, output_size=None):
+        return F.conv_transpose3d(x, group_normalised_weight(self.weight, self.num_group), self.bias, self.stride, self.padding,
+                                  self.output_padding, self.groups, self.dilation)
+
+
+class SConv3d(nn.Conv3d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True, if_sub=None, trainable=True):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        self.weight.requires_grad = bool(trainable)
+
+    def forward(self, x):
+        w = self.weight - self.weight.mean((2, 3, 4), keepdim=True)
+        return F.conv3d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class Segmentation_GS(nn.Module):
+    """joint_model.py:307-346"""
+
+    def __init__(self, n_channels, n_class, norm_type=2, n_fmaps=FMAPS):
+        super().__init__()
+        f = list(n_fmaps)
+        self.in_block = Conv_GS(n_channels, f[0], num_group=2)
+        self.down1 = Down_GS(f[0], f[1], num_group=2)
+        self.down2 = Down_GS(f[1], f[2], num_group=2)
+        self.down3 = Down_GS(f[2], f[3], num_group=4)
+        self.norm1, self.norm2 = GSNorm3d(f[0], 2), GSNorm3d(f[1], 4)
+        self.norm3, self.norm4 = GSNorm3d(f[2], 8), GSNorm3d(f[3], 8)
+        self.up2 = nn.Upsample(scale_factor=2, mode="trilinear")
+        self.up4 = nn.Upsample(scale_factor=4, mode="trilinear")
+        self.up8 = nn.Upsample(scale_factor=8, mode="trilinear")
+        self.out_block1 = Conv_GS(f[0] + f[1] + f[2] + f[3], 32)
+        self.out_block2 = nn.Conv3d(32, n_class, 1, padding=0)
+        self.final = nn.Softmax(dim=1)
+        self.n_class = n_class
+
+    def forward(self, data_dict, in_key, out_key):
+        x1 = self.in_block(data_dict[in_key])
+        x2 = self.down1(x1)
+        x3 = self.down2(x2)
+        x4 = self.down3(x3)
+        levels = (self.norm1(x1), self.up2(self.norm2(x2)), self.up4(self.norm3(x3)), self.up8(self.norm4(x4)))
+        data_dict[out_key] = self.final(self.out_block2(self.out_block1(torch.cat(levels, dim=1))))
+        return data_dict
+
+
 def one_hot(label, n_class=2):
     """(B,1,D,H,W) integer-valued labels -> (B,n_class,D,H,W) float one-hot."""
     lab = label.long()

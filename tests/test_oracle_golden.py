@@ -125,6 +125,56 @@ def test_seg32_bn():
     check_bn_buffers(g, "seg", seg, 1e-5)
 
 
+GS_BLOCKS = {
+    "gsnorm_16_4": lambda M: M.GSNorm3d(16, num_group=4),
+    "conv_gs_2_8": lambda M: M.Conv_GS(2, 8),
+    "dconv_gs_8_16": lambda M: M.DoubleConv_GS(8, 16),
+    "down_gs_8_16": lambda M: M.Down_GS(8, 16),
+    "up_gs_16_8": lambda M: M.Up_GS(16, 8),
+    "gsconv_k3_8_16": lambda M: M.GSConv3d(8, 16, 3, num_group=2, padding=1),
+    "gsconv_k2_8_8": lambda M: M.GSConv3d(8, 8, 2, num_group=2, stride=2),
+    "sconv_k3_1_8": lambda M: M.SConv3d(1, 8, 3, padding=1),
+    "gsconvt_k2_8_8": lambda M: M.GSConvTranspose3d(8, 8, 2, num_group=2, stride=2),
+}
+
+
+def run_gs_block(mod, g, tag, device="cpu"):
+    """the case of oracle/make_golden.py:_gs on `mod` -> (out, input gradient)"""
+    seed = int(g[tag + ".seed"])
+    shape = tuple(int(v) for v in g[tag + ".shape"])
+    u = O.hashed_uniform(int(np.prod(shape)), 7001, seed)
+    x = torch.from_numpy(u + 0.05 if tag.startswith("gsnorm") else 2 * u - 1).view(shape).to(device).requires_grad_(True)
+    y = mod(x)
+    w = torch.from_numpy(2 * O.hashed_uniform(y.numel(), 7002, seed) - 1).view_as(y).to(device)
+    (y * w).sum().backward()
+    return y, x.grad
+
+
+@pytest.mark.parametrize("tag", sorted(GS_BLOCKS))
+@pytest.mark.filterwarnings("ignore:.*align_corners.*")
+def test_gs_blocks(tag):
+    """the *_GS family: the oracle's restatement against the reference's own classes"""
+    g = G.load("gs")
+    mod = O.deterministic_fill_(GS_BLOCKS[tag](O), seed=int(g[tag + ".seed"]))
+    y, gin = run_gs_block(mod, g, tag)
+    G.check_tensor(g, tag + ".out", y, rtol=1e-5, what=tag)
+    G.check_tensor(g, tag + ".gin", gin, rtol=1e-5, what=tag)
+    G.check_grads(g, tag, [(n, p.grad) for n, p in mod.named_parameters()], rtol=2e-5, what=tag)
+
+
+@pytest.mark.filterwarnings("ignore:.*align_corners.*")
+def test_seg_gs32():
+    g = G.load("gs")
+    seg = O.deterministic_fill_(O.Segmentation_GS(1, 2), seed=0)
+    img, lab = O.synthetic_image(2, 32, seed=2), O.synthetic_label(2, 32, seed=3)
+    batch = seg({"img": img, "gt": O.one_hot(lab)}, "img", "pred")
+    loss = 1 - O.avg_dsc(batch, "pred", "gt", botindex=1, topindex=2, eps=1e-4)
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["seg.dice_loss"]), rel=1e-5)
+    G.check_tensor(g, "seg.pred", batch["pred"], k=256, rtol=1e-4, what="seg_gs32")
+    G.check_grads(g, "seg", [(n, p.grad) for n, p in seg.named_parameters()], rtol=1e-3, what="seg_gs32")
+
+
 def test_seg32():
     g = G.load("seg32")
     seg = O.deterministic_fill_(O.Segmentation(1, 2, norm_type=1), seed=0)

@@ -462,6 +462,10 @@ __global__ __launch_bounds__(256) void norm_tables_kernel(const double* __restri
                                                           float momentum, float* running_mean, float* running_var, long long* tracked,
                                                           int c_real, float* __restrict__ mean, float* __restrict__ rstd) {
     const size_t pairs = (size_t)n * c;
+    if (mode == VS_NORM_NONE) {
+        for (int i = threadIdx.x; i < n * c; i += 256) { mean[i] = 0.f; rstd[i] = 1.f; }
+        return;
+    }
     if (mode == VS_NORM_INSTANCE) {
         for (int i = threadIdx.x; i < n * c; i += 256) {
             double st[2];
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(256) void norm_act_bwd_finish_kernel(const double* 
             float* co = coef + ((size_t)i * c + ch) * 3;
             co[0] = ga * rstd[i * c + ch];
             if (mode == VS_NORM_BATCH) { co[1] = (float)(s1 / (count * n)); co[2] = (float)(s2 / (count * n)); }
-            else if (mode == VS_NORM_BATCH_EVAL) { co[1] = 0.f; co[2] = 0.f; }
+            else if (mode != VS_NORM_INSTANCE) { co[1] = 0.f; co[2] = 0.f; }        // running statistics / no normalisation: no batch terms
         }
         if (ch < c_real) {
             if (dgamma != nullptr) dgamma[ch] = (float)s2;
@@ -651,8 +655,8 @@ static int na_check(const void* x, const float* mean, const float* rstd, int n, 
 extern "C" int vs_norm_tables(const double* stats, int n, int c, int c_real, double count, int mode, float eps, float momentum,
                               float* running_mean, float* running_var, long long* num_batches_tracked, float* mean, float* rstd, void* stream) {
     if (!mean || !rstd || n <= 0 || c <= 0 || c_real <= 0 || c_real > c || count <= 0) return VS_EINVAL;
-    if (mode != VS_NORM_INSTANCE && mode != VS_NORM_BATCH && mode != VS_NORM_BATCH_EVAL) return VS_EINVAL;
-    if (mode != VS_NORM_BATCH_EVAL && !stats) return VS_EINVAL;
+    if (mode != VS_NORM_INSTANCE && mode != VS_NORM_BATCH && mode != VS_NORM_BATCH_EVAL && mode != VS_NORM_NONE) return VS_EINVAL;
+    if ((mode == VS_NORM_INSTANCE || mode == VS_NORM_BATCH) && !stats) return VS_EINVAL;
     if (mode == VS_NORM_BATCH_EVAL && (!running_mean || !running_var)) return VS_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return VS_EINVAL;
     hipLaunchKernelGGL(norm_tables_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, n, c, count, mode, eps, momentum, running_mean,
@@ -693,7 +697,7 @@ extern "C" int vs_norm_act_bwd_reduce(const void* g, const void* x, const float*
 extern "C" int vs_norm_act_bwd_finish(const double* sums, int n, int c, int c_real, double count, int mode, const float* rstd, const float* gamma,
                                       float* coef, float* dgamma, float* dbeta, void* stream) {
     if (!sums || !rstd || !coef || n <= 0 || c <= 0 || c_real <= 0 || c_real > c || count <= 0) return VS_EINVAL;
-    if (mode != VS_NORM_INSTANCE && mode != VS_NORM_BATCH && mode != VS_NORM_BATCH_EVAL) return VS_EINVAL;
+    if (mode != VS_NORM_INSTANCE && mode != VS_NORM_BATCH && mode != VS_NORM_BATCH_EVAL && mode != VS_NORM_NONE) return VS_EINVAL;
     hipLaunchKernelGGL(norm_act_bwd_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, n, c, c_real, count, mode, rstd, gamma, coef, dgamma, dbeta);
     VS_CHECK_LAUNCH();
     return VS_OK;

@@ -12,7 +12,7 @@ The configuration every entry point of the reference uses — ``norm_type=1`` (I
 settings, ``norm_type=2`` (BatchNorm3d, the class default, with affine parameters and running statistics) and ``soft=True``
 (Softplus), run through ``ops.NormAct``: native too, but as separate streaming passes after each conv (nothing in the reference
 reaches them: main_source.py:250-272, main_target.py:317-342 pass norm_type=1, and every block receives soft=False).
-``norm_type=3`` (GSNorm3d) and the ``*_GS`` classes, which no reference code instantiates, raise NotImplementedError.
+The ``*_GS`` classes, which no reference code instantiates, live in ``modules_gs.py``; ``norm_type=3`` inside these blocks raises.
 """
 import torch
 import torch.nn as nn

@@ -246,6 +246,10 @@ def pack_weight_cached(param, form, c_pad, dtype):
     it was packed at the parameter's current (version, epoch); otherwise it is re-packed on the spot."""
     dt = vs_of(dtype)
     key = (form, c_pad, dt)
+    if not param.is_leaf:
+        # a weight computed from a parameter in this very pass (GSConv3d's |w| / sum, the 1x1x1 conv embedded in a 3x3x3 one): a
+        # temporary — packed on the spot, never registered anywhere
+        return pack_weight(param, form, c_pad, dtype)
     if param.requires_grad:
         plan = getattr(param, "_vs_pack_plan", None)
         if plan is None:
@@ -736,7 +740,7 @@ def _side_grads(weight, keep, wgrad_args, bias_args, bias=None):
     stream (set_overlap) — or run at once when the parameter already holds a gradient to accumulate into, carries hooks, or
     grad mode is on (autograd would then clone the still-unwritten tensor); -> (gw, gb)."""
     grouping = _GROUP["enabled"] and not _SIDE["enabled"]
-    slot = _GROUP["slots"].get(id(weight)) if grouping else None
+    slot = _GROUP["slots"].get(id(weight)) if grouping and weight.is_leaf else None
     if slot is not None:
         # a later use of the same weight in this pass: one more descriptor with the first use's destination, nothing returned to autograd
         _group_submit(weight, keep, wgrad_args, bias_args if slot[1] is not None else None, slot[0], slot[1])
@@ -745,7 +749,10 @@ def _side_grads(weight, keep, wgrad_args, bias_args, bias=None):
     gb = None
     if bias_args is not None:
         gb = _grad_slot(bias, (bias_args[1],)) if bias is not None else torch.empty(bias_args[1], dtype=torch.float32, device=keep[0].device)
-    deferrable = weight.grad is None and not _has_hooks(weight) and not torch.is_grad_enabled() and (bias is None or not _has_hooks(bias))
+    # deferring hands autograd a still-unwritten tensor: only sound when its consumer is the parameter's AccumulateGrad (a leaf), which keeps it
+    # untouched until the pass ends; a non-leaf weight's gradient is read by the next backward node at once
+    deferrable = (weight.is_leaf and weight.grad is None and not _has_hooks(weight) and not torch.is_grad_enabled()
+                  and (bias is None or (bias.is_leaf and not _has_hooks(bias))))
     if grouping and deferrable:
         _GROUP["slots"][id(weight)] = (gw.data_ptr(), None if gb is None else gb.data_ptr())      # addresses, not tensors: see below
         # the descriptor holds raw pointers only: AccumulateGrad must find gw / gb unshared to adopt them as .grad without a copy
@@ -1076,7 +1083,7 @@ class Materialize(torch.autograd.Function):
         return g1, None, g2, None, None
 
 
-VS_NORM_INSTANCE, VS_NORM_BATCH, VS_NORM_BATCH_EVAL = 0, 1, 2
+VS_NORM_INSTANCE, VS_NORM_BATCH, VS_NORM_BATCH_EVAL, VS_NORM_NONE = 0, 1, 2, 3
 VS_ACT_RELU, VS_ACT_SOFTPLUS = 0, 1
 
 
@@ -1094,6 +1101,8 @@ class NormAct(torch.autograd.Function):
         voxels = x.numel() // (n * c)
         if bn is None:
             mode, eps, mom, rm, rv, nbt = VS_NORM_INSTANCE, EPS_IN, 0.0, None, None, None
+        elif isinstance(bn, str):             # "none": activation only (the conv -> ReLU pairs of the *_GS blocks, joint_model.py:58-63)
+            mode, eps, mom, rm, rv, nbt = VS_NORM_NONE, EPS_IN, 0.0, None, None, None
         else:
             track = bn.track_running_stats and bn.running_mean is not None
             mode = VS_NORM_BATCH if (bn.training or not track) else VS_NORM_BATCH_EVAL
@@ -1133,6 +1142,75 @@ class NormAct(torch.autograd.Function):
             check(lib.vs_norm_act_bwd_apply(g.data_ptr(), x.data_ptr(), tab[0].data_ptr(), tab[1].data_ptr(), _p(gamma), _p(beta), coef.data_ptr(),
                                             dx.data_ptr(), n, voxels, c, ctx.c_real, ctx.act, dt, st), "norm_act_bwd_apply")
         return dx, None, dgamma, dbeta, None, None, None
+
+
+class GSNorm(torch.autograd.Function):
+    """GSNorm3d (joint_model.py:17-33) on a channels-last tensor: every channel divided by the sum over its group (+1e-4)"""
+
+    @staticmethod
+    def forward(ctx, x, num_group):
+        _require_cuda(x)
+        c = x.shape[-1]
+        y = torch.empty_like(x)
+        check(lib.vs_gsnorm_fwd(x.data_ptr(), y.data_ptr(), x.numel() // c, c, num_group, vs_dtype(x), _stream()), "gsnorm_fwd")
+        ctx.save_for_backward(x)
+        ctx.num_group = num_group
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = _contig(g)
+        c = x.shape[-1]
+        dx = torch.empty_like(x)
+        check(lib.vs_gsnorm_bwd(g.data_ptr(), x.data_ptr(), dx.data_ptr(), x.numel() // c, c, ctx.num_group, vs_dtype(x), _stream()), "gsnorm_bwd")
+        return dx, None
+
+
+class UpsampleTrilinear(torch.autograd.Function):
+    """torch.nn.Upsample(scale_factor=s, mode='trilinear') (joint_model.py:69,323-325) on a channels-last tensor"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        _require_cuda(x)
+        n, d, h, w, c = x.shape
+        y = torch.empty((n, d * scale, h * scale, w * scale, c), dtype=x.dtype, device=x.device)
+        check(lib.vs_upsample_trilinear_fwd(x.data_ptr(), y.data_ptr(), n, d, h, w, c, scale, vs_dtype(x), _stream()), "upsample_trilinear_fwd")
+        ctx.shape, ctx.scale = (n, d, h, w, c), scale
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _contig(g)
+        n, d, h, w, c = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=g.dtype, device=g.device)
+        scratch = torch.empty((n * d * h * w * c + 3) // 4 * 4, dtype=torch.float32, device=g.device)
+        check(lib.vs_upsample_trilinear_bwd(g.data_ptr(), dx.data_ptr(), scratch.data_ptr(), n, d, h, w, c, ctx.scale, vs_dtype(g), _stream()),
+              "upsample_trilinear_bwd")
+        return dx, None
+
+
+class Softmax2(torch.autograd.Function):
+    """nn.Softmax(dim=1) over two classes as its own pass: channels-last logits (channels 0, 1) -> planar fp32 (N, 2, D, H, W)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        n, d, h, w, c = x.shape
+        prob = torch.empty((n, 2, d, h, w), dtype=torch.float32, device=x.device)
+        check(lib.vs_softmax2_fwd(x.data_ptr(), prob.data_ptr(), n, d * h * w, c, vs_dtype(x), _stream()), "softmax2_fwd")
+        ctx.save_for_backward(prob)
+        ctx.c, ctx.dtype = c, x.dtype
+        return prob
+
+    @staticmethod
+    def backward(ctx, gprob):
+        (prob,) = ctx.saved_tensors
+        gprob = _contig(gprob.float())
+        n, _, d, h, w = prob.shape
+        g = torch.empty((n, d, h, w, ctx.c), dtype=ctx.dtype, device=prob.device)
+        check(lib.vs_softmax2_bwd(prob.data_ptr(), gprob.data_ptr(), g.data_ptr(), n, d * h * w, ctx.c, vs_of(ctx.dtype), _stream()), "softmax2_bwd")
+        return g
 
 
 _DROPOUT_CALLS = [0]
