@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VS_VERSION 202
+#define VS_VERSION 203
 
 enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2 };   /* storage type of activations: fp32 (parity mode), bf16, IEEE fp16 (needs loss scaling, see vs_loss_scale_*) */
 #ifndef VS_STAT_SLOTS
@@ -103,6 +103,14 @@ int vs_conv_gather_bwd_data(const void* x, const void* w_packed, void* y, const 
                             void* stream);
 int vs_conv_scatter_bwd_data(const void* x, const void* w_packed, void* y, const void* mask_x, const double* mask_stats,
                              double* sums, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);
+/* vs_conv_gather_bwd_data (K3) whose INPUT gradient arrives un-applied: g = dL/da of the lazy activation a = relu(instnorm(act_x)), with
+ * that activation's statistics (act_stats) and IN-backward sums (act_sums, complete: produced by the backward-data launch that wrote g).
+ * The apply pass rstd * (g*[xhat>0] - m1 - xhat*m2) runs while the halo tile is staged — the standalone vs_instnorm_relu_bwd_apply launch
+ * between two backward-data launches of the 8-channel full-resolution layers (3 tensor passes at 96^3) disappears; dx_out (nullable)
+ * receives the applied gradient (what the weight gradient of this layer reads).  16-bit storage, c_in = m_out = 8 only (VS_ESHAPE). */
+int vs_conv_k3_bwd_data_fused_apply(const void* g, const void* act_x, const double* act_stats, const double* act_sums,
+                                    const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,
+                                    void* dx_out, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);
 
 /* out_block + Softmax(dim=1) fused (joint_model.py:224-225,265-266,366-367,386-388):
  * prob[n][k][v] (planar fp32, k < 2) = softmax_k( bias[k] + conv3x3x3(act(x))[k] ). */

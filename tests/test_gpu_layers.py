@@ -172,3 +172,53 @@ def test_skip_merge_layer_shapes(case, dtype):
     errs = {"out": relerr(from_cl(out, c).double(), ref.detach()), "g1": relerr(from_cl(c1.grad, c).double(), a1.grad),
             "g2": relerr(from_cl(c2.grad, c).double(), a2.grad)}
     _report("skip %s %s" % (case, dtype), errs, {"out": tol, "g1": 2 * tol, "g2": 2 * tol})
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 96, 96, 96), (1, 128, 128, 128), (2, 20, 12, 40), (3, 5, 9, 33), (1, 4, 8, 32)])
+@pytest.mark.parametrize("want_dx", [True, False])
+def test_k3_bwd_data_with_fused_apply(case, dtype, want_dx):
+    """vs_conv_k3_bwd_data_fused_apply (the 8 -> 8 full-resolution layers: apply pass of the incoming gradient fused into the staging of the
+    backward-data kernel) against the two launches it replaces — vs_instnorm_relu_bwd_apply, then vs_conv_gather_bwd_data — on the same
+    operands: the applied gradient it writes out, the gradient it produces and the IN-backward sums it accumulates.  Both forms do the apply
+    in fp32 and round once to the storage type; they differ in the association of one fma, i.e. by at most an ulp of the storage type
+    on isolated elements of dx."""
+    ops = _ops()
+    from vae_segmentation_amd._lib import check, lib
+    n, d, h, w = case
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(d * 7 + h)
+    ax = (torch.randn(n, d, h, w, 8, generator=gen) * 1.3 + 0.2).to(dtype).to(dev)           # raw output of this conv = the lazy activation
+    g = torch.randn(n, d, h, w, 8, generator=gen).to(dtype).to(dev)                           # un-applied gradient dL/da
+    mx = (torch.randn(n, d, h, w, 8, generator=gen) * 0.8 - 0.1).to(dtype).to(dev)            # the conv's own (lazy) input
+    wt = (torch.randn(8, 8, 3, 3, 3, generator=gen) * 0.1).to(dev)
+    ops.stats_arena_begin(ax.device)
+    axs, mxs = ops.instnorm_stats(ax), ops.instnorm_stats(mx)
+    vox, dt, st = d * h * w, ops.vs_dtype(ax), ops._stream()
+    asums = ops._new_stats(n, 8, ax.device)
+    check(lib.vs_instnorm_relu_bwd_reduce(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), n, vox, 8, dt, 1e-5, st), "reduce")
+    wpb = ops.pack_weight(wt, ops.VS_PACK_ROWS_D1_FLIP, 8, dtype)
+    # reference: standalone apply, then backward-data with fused sums
+    dx_ref = torch.empty_like(g)
+    check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), dx_ref.data_ptr(), n, vox, 8, dt, 1e-5, st), "apply")
+    y_ref, s_ref = torch.empty_like(g), ops._new_stats(n, 8, ax.device)
+    check(lib.vs_conv_gather_bwd_data(dx_ref.data_ptr(), wpb.data_ptr(), y_ref.data_ptr(), mx.data_ptr(), mxs.data_ptr(), s_ref.data_ptr(),
+                                      n, d, h, w, 8, 8, ops.VS_CONV_K3, dt, 1e-5, st), "bwd_data")
+    # fused
+    y, s2 = torch.empty_like(g), ops._new_stats(n, 8, ax.device)
+    dx = torch.full_like(g, 7.0) if want_dx else None
+    check(lib.vs_conv_k3_bwd_data_fused_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), y.data_ptr(),
+                                              mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(), None if dx is None else dx.data_ptr(),
+                                              n, d, h, w, 8, 8, dt, 1e-5, st), "fused")
+    torch.cuda.synchronize()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    if want_dx:
+        a, b = dx.float(), dx_ref.float()
+        assert float(((a - b).abs() / b.abs().clamp_min(1e-3)).max()) <= 2.1 * ulp                      # every element within an ulp of the storage type
+        assert float((a != b).float().mean()) < 0.02                                                    # and almost all identical
+    assert relerr(y.float().cpu(), y_ref.float().cpu()) < 4 * ulp
+    t2, tr = ops.stats_total(s2), ops.stats_total(s_ref)
+    assert float((t2 - tr).abs().max() / tr.abs().max()) < 4 * ulp
+    # shapes outside the 8 -> 8 class are refused, not mis-computed
+    assert lib.vs_conv_k3_bwd_data_fused_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), y.data_ptr(),
+                                               mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(), None, n, d, h, w, 16, 8, dt, 1e-5, st) == -2

@@ -37,7 +37,8 @@ static int check_common(const void* x, const void* w, int n, int d, int h, int w
 
 static int gather_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                        void* y, double* y_stats, const void* mask_x, const double* mask_stats, double* sums,
-                       int n, int d, int h, int w, int c_in, int m_out, int kind, int dtype, float eps, void* stream) {
+                       int n, int d, int h, int w, int c_in, int m_out, int kind, int dtype, float eps, void* stream,
+                       const void* fa_x = nullptr, const double* fa_sums = nullptr, void* fa_dx = nullptr) {
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
     if (!y || m_out <= 0 || m_out % 8 || ((uintptr_t)y & 15)) return VS_EINVAL;
@@ -46,6 +47,7 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     G1Params p{};
     p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = y; p.y_stats = y_stats; p.prob = nullptr;
     p.mask_x = mask_x; p.mask_stats = mask_stats; p.sums = sums;
+    p.fa_x = fa_x; p.fa_sums = fa_sums; p.fa_dx = fa_dx;
     if (sums && (!mask_x || !mask_stats || y_stats)) return VS_EINVAL;
     p.N = n; p.D = d; p.H = h; p.W = w;
     p.C = c_in; p.M = m_out;
@@ -92,6 +94,18 @@ extern "C" int vs_conv_gather_bwd_data(const void* x, const void* w_packed, void
                                        int m_out, int kind, int dtype, float eps, void* stream) {
     if (!mask_x || !mask_stats || !sums) return VS_EINVAL;
     return gather_impl(x, nullptr, w_packed, nullptr, y, nullptr, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, kind, dtype, eps, stream);
+}
+
+extern "C" int vs_conv_k3_bwd_data_fused_apply(const void* g, const void* act_x, const double* act_stats, const double* act_sums,
+                                               const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,
+                                               void* dx_out, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps,
+                                               void* stream) {
+    if (!g || !act_x || !act_stats || !act_sums || !mask_x || !mask_stats || !sums) return VS_EINVAL;
+    if (dtype == VS_F32) return VS_EDTYPE;
+    if (c_in != 8 || m_out != 8) return VS_ESHAPE;       // the Toeplitz kernel's shape class (igemm_k3t.h): the 8-channel full-resolution layers
+    if (((uintptr_t)act_x & 15) || (dx_out && ((uintptr_t)dx_out & 15))) return VS_EALIGN;
+    return gather_impl(g, act_stats, w_packed, nullptr, y, nullptr, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, VS_CONV_K3, dtype, eps,
+                       stream, act_x, act_sums, dx_out);
 }
 
 static int scatter_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias, void* y,

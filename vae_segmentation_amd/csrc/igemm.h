@@ -41,6 +41,11 @@ struct G1Params {
     float eps;
     double inv_count_in;  // 1 / (D*H*W) of the input grid
     unsigned int fd_m[3], fd_s[3];   // k3b_kernel: multiply-shift pairs for / tiles_per_sample, / (txn*tyn), / txn (k3b_launch fills them)
+    // k3t_kernel<FA>: backward-data with the IN-backward apply of its INPUT gradient fused into the staging: x = g (un-applied), x_stats = the
+    // statistics of the activation fa_x, fa_sums its IN-backward sums, fa_dx (nullable) receives the applied gradient
+    const void* fa_x;
+    const double* fa_sums;
+    void* fa_dx;
 };
 
 // LDS carve (bytes)

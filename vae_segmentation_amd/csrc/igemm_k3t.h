@@ -30,7 +30,11 @@ struct K3TGeom {
 
 // HS: lazy input (normalise + ReLU while staging), compile-time like every condition on the staging path
 // T: unsigned short (bf16 bits) or vs_half (fp16); last template argument (kernel-name prefix unchanged)
-template <int EPI, bool SUMS, int YT, bool HS, typename T = unsigned short>
+// FA (backward-data only): the input gradient arrives UN-applied — p.x = g = dL/da of the lazy activation a = relu(norm(p.fa_x)), with that
+// activation's statistics (p.x_stats) and IN-backward sums (p.fa_sums) — and the apply pass rstd * (g*[xhat>0] - m1 - xhat * m2) runs while the
+// halo tile is staged (the standalone vs_instnorm_relu_bwd_apply launch, 3 tensor passes at 96^3, disappears); centre voxels are also
+// written to p.fa_dx when given (the weight gradient of this layer reads the applied gradient).
+template <int EPI, bool SUMS, int YT, bool HS, typename T = unsigned short, bool FA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k3t_kernel(const G1Params p) {
     K3_TICK_INIT
     using GEO = K3TGeom<YT>;
@@ -42,29 +46,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* s_shift = s_scale + p.N * 8;
     float* s_mkm = s_shift + p.N * 8;                    // mean / rstd of the mask tensor's channels (fused IN-bwd sums)
     float* s_mkr = s_mkm + p.N * 8;
+    float* s_fa = s_mkr + p.N * 8;                       // FA: rstd, -mean*rstd, m1, m2 of the input gradient's activation, [N*8] each
+    static_assert(!FA || (SUMS && !HS && EPI == EPI_RAW), "fused apply: backward-data variant only");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int dx2 = g >> 1, c4 = 4 * (g & 1);            // this lane's accumulator rows: output voxel x = 2*col + dx2, channels c4..c4+3
     constexpr bool has_stats = HS;
     const int total_tiles = p.tiles_per_sample * p.N;
     const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * 16));
+    const i32x4 frsrc = make_rsrc(FA ? p.fa_x : p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * 16));
+    const i32x4 dxrsrc = make_rsrc(FA && p.fa_dx != nullptr ? p.fa_dx : p.y, (FA && p.fa_dx != nullptr) ? (unsigned int)((long long)p.N * p.D * p.H * p.W * 16) : 0u);
 
     // the (sum, sumsq) pair this thread turns into a table entry: oldest load in the queue
     const double* st_src = SUMS ? p.mask_stats : p.x_stats;
     const int st_n = SUMS ? p.N * 8 : (has_stats ? p.N * 8 : 0);
     double st_pre[2] = {0.0, 1.0};
     if (tid < st_n) stat_load(st_src, (size_t)tid, (size_t)st_n, st_pre);
+    double fa_pre[2][2] = {{0.0, 1.0}, {0.0, 0.0}};      // FA: wave 1 requests the activation's (sum, sumsq) and (sum g*mask, sum g*mask*xhat) pairs
+    if constexpr (FA) {
+        if (tid >= 64 && tid < 64 + p.N * 8) {
+            stat_load(p.x_stats, (size_t)(tid - 64), (size_t)p.N * 8, fa_pre[0]);
+            stat_load(p.fa_sums, (size_t)(tid - 64), (size_t)p.N * 8, fa_pre[1]);
+        }
+    }
 
     // ---- per-thread staging geometry: fragment b = halo voxel tid + 256 b -------------------------------------------------
     int rel_off[NIT], tzyx[NIT];
+    unsigned int cbits = 0;                              // FA: fragment b is a centre (non-halo) voxel of the tile
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
         const int tv = tid + b * 256;
         const int tx_ = tv % PX, ty_ = (tv / PX) % PY, tz_ = tv / PLANE;
         rel_off[b] = ((tz_ * p.H + ty_) * p.W + tx_) * 16;
         tzyx[b] = tv < TV ? (tz_ | (ty_ << 8) | (tx_ << 16)) : 0x00ffffff;
+        cbits |= (tv < TV && tz_ >= 1 && tz_ <= 4 && ty_ >= 1 && ty_ <= YT && tx_ >= 1 && tx_ <= 32) ? (1u << b) : 0u;
     }
-    u32x4 xv[NIT];
+    u32x4 xv[NIT], fv[FA ? NIT : 1];
     unsigned int okbits = 0;
     struct Coord { int n, z0, y0, x0; };
     auto tile_coord = [&](int t) {
@@ -86,6 +103,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             okbits |= ok ? (1u << b) : 0u;
             xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, ok ? base + rel_off[b] : -1, 0, 0));
+            if constexpr (FA) fv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(frsrc, ok ? base + rel_off[b] : -1, 0, 0));
+        }
+    };
+    auto write_x_fa = [&](const Coord& c) {             // FA: apply pass on the staged fragments, [+ the applied gradient of the centre voxels to fa_dx]
+        f32x2 r2[4], s2[4], a2[4], b2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r2[i] = *(const f32x2*)(s_fa + 0 * p.N * 8 + c.n * 8 + 2 * i);
+            s2[i] = *(const f32x2*)(s_fa + 1 * p.N * 8 + c.n * 8 + 2 * i);
+            a2[i] = *(const f32x2*)(s_fa + 2 * p.N * 8 + c.n * 8 + 2 * i);
+            b2[i] = *(const f32x2*)(s_fa + 3 * p.N * 8 + c.n * 8 + 2 * i);
+        }
+        const int base = (((c.n * p.D + c.z0 - 1) * p.H + c.y0 - 1) * p.W + c.x0 - 1) * 16;
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) {
+            u32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x2 g2, x2;
+                g2[0] = H16<T>::lo(xv[b][i]); g2[1] = H16<T>::hi(xv[b][i]);
+                x2[0] = H16<T>::lo(fv[b][i]); x2[1] = H16<T>::hi(fv[b][i]);
+                const f32x2 xh = x2 * r2[i] + s2[i];
+                f32x2 gm;
+                gm[0] = xh[0] > 0.f ? g2[0] : 0.f;
+                gm[1] = xh[1] > 0.f ? g2[1] : 0.f;
+                const f32x2 d = r2[i] * (gm - a2[i] - xh * b2[i]);
+                v[i] = H16<T>::pack2(d);
+            }
+            const bool ok = (okbits >> b) & 1u;           // out-of-volume halo voxels: the gradient is zero-padded
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ok ? v[i] : 0u;
+            *(u32x4*)(s_tile + (tid + b * 256) * 16) = v;
+            if (p.fa_dx != nullptr)                        // workgroup-uniform
+                vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), dxrsrc, (ok && ((cbits >> b) & 1u)) ? base + rel_off[b] : -1, 0, 0);
         }
     };
     auto write_x = [&](int n) {
@@ -143,6 +194,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (SUMS) { s_mkm[i] = m; s_mkr[i] = r; }
         else { s_scale[i] = r; s_shift[i] = -m * r; }
     }
+    if constexpr (FA) {
+        if (tid >= 64 && tid < 64 + p.N * 8) {
+            const int i = tid - 64;
+            float m, r;
+            stats_to_mean_rstd_fast(fa_pre[0], p.inv_count_in, p.eps, m, r);
+            s_fa[0 * p.N * 8 + i] = r;
+            s_fa[1 * p.N * 8 + i] = -m * r;
+            s_fa[2 * p.N * 8 + i] = (float)(fa_pre[1][0] * p.inv_count_in);
+            s_fa[3 * p.N * 8 + i] = (float)(fa_pre[1][1] * p.inv_count_in);
+        }
+    }
     const char* s_b = s_tile + ((wave * PY) * PX + 2 * col + g) * 16;     // B fragment of (tz, halo row yy): + ((tz * PY + yy) * PX) * 16
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -162,7 +224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (!first) __syncthreads();                     // every wave is done reading the previous tile
         first = false;
         K3_TICK(1);
-        write_x(n);
+        if constexpr (FA) write_x_fa(cur); else write_x(n);
         K3_TICK(2);
         __syncthreads();
         K3_TICK(3);
@@ -301,12 +363,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     K3_TICK_FLUSH;
 }
 
-template <typename T, int EPI, bool SUMS, int YT, bool HS>
+template <typename T, int EPI, bool SUMS, int YT, bool HS, bool FA = false>
 static int k3t_launch_t(const G1Params& p_in, hipStream_t stream) {
     using GEO = K3TGeom<YT>;
     G1Params p = p_in;
     if (p.C != 8 || p.M != 8) return VS_ESHAPE;
-    const size_t lds = K3T_LDS_TILE + (size_t)GEO::TILE_BYTES + (size_t)4 * p.N * 8 * sizeof(float);
+    if (FA && p.N * 8 > 192) return VS_ESHAPE;          // wave 1 .. 3 build the fused-apply tables
+    const size_t lds = K3T_LDS_TILE + (size_t)GEO::TILE_BYTES + (size_t)(FA ? 8 : 4) * p.N * 8 * sizeof(float);
     if (lds > 160 * 1024) return VS_ESHAPE;
     p.txn = (p.W + 31) / 32;
     p.tyn = (p.H + YT - 1) / YT;
@@ -317,8 +380,9 @@ static int k3t_launch_t(const G1Params& p_in, hipStream_t stream) {
     k3b_fastdiv(p.tiles_per_sample, p.fd_m[0], p.fd_s[0]);
     k3b_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3b_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
-    if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr)) return VS_EINVAL;
-    auto kern = k3t_kernel<EPI, SUMS, YT, HS, T>;
+    if (SUMS != (p.sums != nullptr) || (SUMS && !FA && p.x_stats != nullptr)) return VS_EINVAL;
+    if (FA && (!p.x_stats || !p.fa_x || !p.fa_sums)) return VS_EINVAL;
+    auto kern = k3t_kernel<EPI, SUMS, YT, HS, T, FA>;
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
@@ -335,6 +399,9 @@ static int k3t_launch_t(const G1Params& p_in, hipStream_t stream) {
 
 template <typename T, int EPI, bool SUMS, int YT>
 static int k3t_launch(const G1Params& p, hipStream_t stream) {
+    if constexpr (SUMS && EPI == EPI_RAW) {
+        if (p.fa_x != nullptr) return k3t_launch_t<T, EPI, SUMS, YT, false, true>(p, stream);
+    }
     if (!SUMS && p.x_stats != nullptr) return k3t_launch_t<T, EPI, SUMS, YT, !SUMS>(p, stream);
     return k3t_launch_t<T, EPI, SUMS, YT, false>(p, stream);
 }

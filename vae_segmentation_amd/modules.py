@@ -110,6 +110,8 @@ class DoubleConv(nn.Module):
         a, wrapped = _as_act(x, self.kernel_dtype)
         for i in (0, 3, 6):
             a = _conv_norm_act(self.conv, i, a)
+            if i < 6 and a.stats is not None:
+                ops.mark_defer_apply(a.raw, self.conv[i])      # consumed once, by the next 3x3x3 conv: its IN-backward apply can be fused (ops._LAZY_APPLY)
         return _as_tensor(a, self.out_ch) if wrapped else a
 
 
@@ -238,6 +240,8 @@ class VAE(nn.Module):
         a = Act(h, None)
         for blk in (self.up1, self.up2, self.up3, self.up4, self.up5):
             a = _dropout(blk(a), dropout)
+        if a.stats is not None:
+            ops.mark_defer_apply(a.raw, self.up5.conv[1].conv[6])           # up5's last conv feeds out_block only
         recon = ops.ConvK3Softmax.apply(a.raw, a.stats, self.out_block.weight, self.out_block.bias)
         if not mid_input:
             return recon, x_mean, x_std
@@ -286,6 +290,8 @@ class Segmentation(nn.Module):
         u = self.up4(u)
         u = _dropout(Act(ops.Materialize.apply(u.raw, u.stats, x2.raw, x2.stats, True), None), dropout)
         u = _dropout(self.up5(u), dropout)
+        if u.stats is not None:
+            ops.mark_defer_apply(u.raw, self.up5.conv[1].conv[6])           # up5's last conv feeds out_block only
         if dropout:     # the reference also drops the two logits before the softmax (joint_model.py:386-388): fused epilogue
             data_dict[out_key] = ops.out_block_softmax(u.raw, u.stats, self.out_block.weight, self.out_block.bias,
                                                        float(dropout), ops.next_dropout_seed())
@@ -399,6 +405,8 @@ class Fusion(nn.Module):
         u = self.up3(self.up2(x5))
         u = self.up4(Act(ops.Materialize.apply(u.raw, u.stats, x3.raw, x3.stats), None))
         u = self.up5(Act(ops.Materialize.apply(u.raw, u.stats, x2.raw, x2.stats), None))
+        if u.stats is not None:
+            ops.mark_defer_apply(u.raw, self.up5.conv[1].conv[6])
         data_dict[out_key] = ops.ConvK3Softmax.apply(u.raw, u.stats, self.out_block.weight, self.out_block.bias)
         return data_dict
 

@@ -524,15 +524,82 @@ def _pending_done():
         raise RuntimeError("%d parked skip gradient(s) were never collected by the conv that shares their input: gradients lost" % left)
 
 
-def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
+# Deferred IN-backward apply (the 8-channel full-resolution layers, igemm_k3t.h FA): where a lazy activation x is produced by an 8 -> 8 3x3x3
+# conv and consumed by exactly one 3x3x3 conv (the modules mark x: mark_defer_apply), the consumer's backward hands over the UN-applied
+# gradient g = dL/da together with (x, stats, sums) through this registry, and the producer's backward-data kernel applies
+# rstd * (g*mask - m1 - xhat*m2) while it stages its input — the standalone apply launch (3 tensor passes at 96^3) disappears.
+# An entry nobody took by the end of the pass means a consumer treated an un-applied gradient as applied: that is an error, not a fallback.
+FUSE_APPLY = os.environ.get("VS_FUSE_APPLY", "1") != "0"
+_LAZY_APPLY = {"grads": {}, "callback": False}
+
+
+def mark_defer_apply(x, producer):
+    """x: the raw output of `producer` (an nn.Conv3d holder run by ConvK3) about to be consumed, once, by a 3x3x3 conv op"""
+    if (FUSE_APPLY and x.dtype != torch.float32 and x.shape[-1] == 8 and tuple(producer.weight.shape[2:]) == (3, 3, 3)
+            and cpad(producer.weight.shape[1]) == 8 and producer.weight.shape[0] == 8):
+        x._vs_defer_apply = True
+    return x
+
+
+def _defer_register(g, x, xs, sums):
+    _LAZY_APPLY["grads"][(g.data_ptr(), tuple(g.shape))] = (x, xs, sums)
+    if not _LAZY_APPLY["callback"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_lazy_apply_done)
+            _LAZY_APPLY["callback"] = True
+        except RuntimeError:
+            pass
+
+
+def _take_lazy(g):
+    return _LAZY_APPLY["grads"].pop((g.data_ptr(), tuple(g.shape)), None) if _LAZY_APPLY["grads"] else None
+
+
+def _lazy_apply_done():
+    _LAZY_APPLY["callback"] = False
+    left = len(_LAZY_APPLY["grads"])
+    _LAZY_APPLY["grads"].clear()
+    if left:
+        raise RuntimeError("%d un-applied gradient(s) (deferred InstanceNorm-backward apply) were not taken by the producing conv: gradients wrong" % left)
+
+
+def apply_lazy(g, lazy):
+    """the standalone apply of a deferred gradient (a producer that cannot fuse it)"""
+    x, xs, sums = lazy
+    n, c = x.shape[0], x.shape[-1]
+    check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), g.data_ptr(), n, x.numel() // (n * c), c,
+                                         vs_dtype(x), EPS_IN, _stream()), "instnorm_relu_bwd_apply")
+    return g
+
+
+def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None, defer=False, lazy=None, want_dx=False):
     """Gradient w.r.t. the raw tensor x of a lazy activation a = relu(instnorm(x)) that fed a conv:
     g = conv-backward-data(gy) with the InstanceNorm+ReLU-backward sums accumulated in the same kernel's epilogue,
-    then the (in-place) apply pass.  kind / scatter select the backward-data form of the forward conv."""
+    then the (in-place) apply pass.  kind / scatter select the backward-data form of the forward conv.
+    lazy = (act_x, act_stats, act_sums): gy itself is an un-applied gradient (see _LAZY_APPLY) — its apply is fused into this launch's
+    staging and the call returns (g, applied gy or None [want_dx]).  defer: leave g un-applied and register it for x's producer."""
     n, c = x.shape[0], x.shape[-1]
     sums = _new_stats(n, c, x.device)
     g = torch.empty_like(x)
     gn, gd, gh, gw, gc = gy.shape
     dt = vs_dtype(x)
+    if lazy is not None:
+        ax, axs, asums = lazy
+        dx = torch.empty_like(gy) if want_dx else None
+        kid = nb = fl = None
+        if PROFILE is not None:
+            kid = _k3_kid(_tname(x), 8, 16, sums=True, geom=(gn, gd, gh, gw), m=c) + "+apply"
+            nb = (3 * gy.numel() + 2 * g.numel() + (gy.numel() if want_dx else 0)) * _esize(x) // 1 + 8 * 8 * 27 * _esize(x)
+            fl = 2.0 * (g.numel() // c) * 27 * 8 * 8
+        with _timed(kid, nb, fl, "bwd+apply gy%s->m%d" % (tuple(gy.shape), c)):
+            check(lib.vs_conv_k3_bwd_data_fused_apply(gy.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), g.data_ptr(),
+                                                      x.data_ptr(), xs.data_ptr(), sums.data_ptr(), _p(dx), gn, gd, gh, gw, gc, c, dt, EPS_IN,
+                                                      _stream()), "conv_k3_bwd_data_fused_apply")
+        if defer:
+            _defer_register(g, x, xs, sums)
+        else:
+            _apply_in_place(g, x, xs, sums)
+        return g, dx
     if scatter:
         kid = nb = fl = None
         if PROFILE is not None:
@@ -565,12 +632,20 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None):
         with _timed(kid, nb, fl, "bwd gy%s->m%d" % (tuple(gy.shape), c)):
             check(lib.vs_conv_gather_bwd_data(gy.data_ptr(), wpb.data_ptr(), g.data_ptr(), x.data_ptr(), xs.data_ptr(),
                                               sums.data_ptr(), gn, gd, gh, gw, gc, c, kind, dt, EPS_IN, _stream()), "conv_gather_bwd_data")
+    if defer:
+        _defer_register(g, x, xs, sums)
+        return g
+    return _apply_in_place(g, x, xs, sums)
+
+
+def _apply_in_place(g, x, xs, sums):
+    n, c = x.shape[0], x.shape[-1]
     voxels = x.numel() // (n * c)
     tname = _tname(x)
     add = _collect_gradient(x)                 # the skip's gradient of the same tensor, if one was parked
     with _timed("in_relu_bwd_apply_kernel<%s>" % tname, (3 if add is None else 4) * x.numel() * _esize(x), 6.0 * x.numel(), str(tuple(x.shape))):
         check(lib.vs_instnorm_relu_bwd_apply_add(g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), _p(add), g.data_ptr(), n, voxels,
-                                                 c, dt, EPS_IN, _stream()), "instnorm_relu_bwd_apply")
+                                                 c, vs_dtype(x), EPS_IN, _stream()), "instnorm_relu_bwd_apply")
     return g
 
 
@@ -834,6 +909,7 @@ class ConvK3(torch.autograd.Function):
         ctx.save_for_backward(x, xs, weight)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias                   # a Parameter (long-lived leaf): only its gradient slot is looked up in backward
+        ctx.defer = bool(getattr(x, "_vs_defer_apply", False)) and xs is not None     # see _LAZY_APPLY
         ctx.mark_non_differentiable(ys)
         ctx.set_materialize_grads(False)      # otherwise autograd zero-fills a gradient for the stats output every backward
         return y, ys
@@ -846,10 +922,16 @@ class ConvK3(torch.autograd.Function):
         gy = _contig(gy)
         cout, cin = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
+        lazy = _take_lazy(gy)                   # gy is an un-applied gradient handed over by the consumer of this conv's output
+        if lazy is not None and not (ctx.needs_input_grad[0] and xs is not None and x.shape[-1] == 8 and gy.shape[-1] == 8):
+            gy, lazy = apply_lazy(gy, lazy), None     # this conv cannot fuse it (not the 8 -> 8 shape class / no lazy input): apply now
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, gy.shape[-1], gy.dtype)
-            if xs is not None:
-                gx = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K3, real_channels=(cout, cin))
+            if lazy is not None:
+                gx, gy = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K3, real_channels=(cout, cin), defer=ctx.defer, lazy=lazy,
+                                            want_dx=ctx.needs_input_grad[2])
+            elif xs is not None:
+                gx = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K3, real_channels=(cout, cin), defer=ctx.defer)
             else:
                 gx, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K3, False, real_channels=(cout, cin))
         want_gb = ctx.has_bias and ctx.needs_input_grad[3]
@@ -859,7 +941,7 @@ class ConvK3(torch.autograd.Function):
         elif want_gb and ctx.live_bias:
             gb = bias_grad(gy, cout)
         if want_gb and not ctx.live_bias:
-            gb = _dead_bias_grad(ctx.bias_ref, ctx.bias_ref.shape[0], gy.device)
+            gb = _dead_bias_grad(ctx.bias_ref, ctx.bias_ref.shape[0], x.device)
         return gx, None, gw, gb, None
 
 
@@ -881,6 +963,7 @@ class ConvK3Softmax(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
         ctx.drop = (float(drop_p), drop_seed)
+        ctx.defer = bool(getattr(x, "_vs_defer_apply", False)) and xs is not None
         return prob
 
     @staticmethod
@@ -895,7 +978,7 @@ class ConvK3Softmax(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, x.dtype)
             if xs is not None:
-                gx = conv_bwd_data_lazy(gl, wpb, x, xs, VS_CONV_K3, real_channels=(2, weight.shape[1]))
+                gx = conv_bwd_data_lazy(gl, wpb, x, xs, VS_CONV_K3, real_channels=(2, weight.shape[1]), defer=ctx.defer)
             else:
                 gx, _ = conv_gather(gl, None, wpb, None, c, VS_CONV_K3, False)
         if ctx.needs_input_grad[2]:
@@ -927,6 +1010,7 @@ class ConvK3SoftmaxCL(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
         ctx.drop = (float(drop_p), drop_seed)
+        ctx.defer = bool(getattr(x, "_vs_defer_apply", False)) and xs is not None
         ctx.set_materialize_grads(False)
         return prob, prob_cl
 
@@ -945,7 +1029,7 @@ class ConvK3SoftmaxCL(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, x.dtype)
             if xs is not None:
-                gx = conv_bwd_data_lazy(gl, wpb, x, xs, VS_CONV_K3, real_channels=(2, weight.shape[1]))
+                gx = conv_bwd_data_lazy(gl, wpb, x, xs, VS_CONV_K3, real_channels=(2, weight.shape[1]), defer=ctx.defer)
             else:
                 gx, _ = conv_gather(gl, None, wpb, None, c, VS_CONV_K3, False)
         if ctx.needs_input_grad[2]:
