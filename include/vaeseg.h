@@ -107,7 +107,9 @@ int vs_conv_scatter_bwd_data(const void* x, const void* w_packed, void* y, const
  * that activation's statistics (act_stats) and IN-backward sums (act_sums, complete: produced by the backward-data launch that wrote g).
  * The apply pass rstd * (g*[xhat>0] - m1 - xhat*m2) runs while the halo tile is staged — the standalone vs_instnorm_relu_bwd_apply launch
  * between two backward-data launches of the 8-channel full-resolution layers (3 tensor passes at 96^3) disappears; dx_out (nullable)
- * receives the applied gradient (what the weight gradient of this layer reads).  16-bit storage, c_in = m_out = 8 only (VS_ESHAPE). */
+ * receives the applied gradient (what the weight gradient of this layer reads).  mask_x / mask_stats / sums: all three as in
+ * vs_conv_gather_bwd_data (the conv's own input is a lazy activation) or all NULL (it is a stored tensor: no sums to accumulate).
+ * 16-bit storage, c_in = m_out = 8 only (VS_ESHAPE). */
 int vs_conv_k3_bwd_data_fused_apply(const void* g, const void* act_x, const double* act_stats, const double* act_sums,
                                     const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,
                                     void* dx_out, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);

@@ -219,6 +219,14 @@ def test_k3_bwd_data_with_fused_apply(case, dtype, want_dx):
     assert relerr(y.float().cpu(), y_ref.float().cpu()) < 4 * ulp
     t2, tr = ops.stats_total(s2), ops.stats_total(s_ref)
     assert float((t2 - tr).abs().max() / tr.abs().max()) < 4 * ulp
+    # the same with a stored (non-lazy) conv input: no mask tensor, no sums (VAE.in_block on the prediction)
+    y_ref2 = torch.empty_like(g)
+    check(lib.vs_conv_gather_fwd(dx_ref.data_ptr(), None, wpb.data_ptr(), None, y_ref2.data_ptr(), None, n, d, h, w, 8, 8, ops.VS_CONV_K3, dt, 1e-5, st), "plain")
+    y3 = torch.empty_like(g)
+    check(lib.vs_conv_k3_bwd_data_fused_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), y3.data_ptr(),
+                                              None, None, None, None, n, d, h, w, 8, 8, dt, 1e-5, st), "fused, no sums")
+    torch.cuda.synchronize()
+    assert relerr(y3.float().cpu(), y_ref2.float().cpu()) < 4 * ulp
     # shapes outside the 8 -> 8 class are refused, not mis-computed
     assert lib.vs_conv_k3_bwd_data_fused_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), y.data_ptr(),
                                                mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(), None, n, d, h, w, 16, 8, dt, 1e-5, st) == -2

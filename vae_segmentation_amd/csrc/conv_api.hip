@@ -100,7 +100,8 @@ extern "C" int vs_conv_k3_bwd_data_fused_apply(const void* g, const void* act_x,
                                                const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,
                                                void* dx_out, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps,
                                                void* stream) {
-    if (!g || !act_x || !act_stats || !act_sums || !mask_x || !mask_stats || !sums) return VS_EINVAL;
+    if (!g || !act_x || !act_stats || !act_sums) return VS_EINVAL;
+    if ((mask_x == nullptr) != (sums == nullptr) || (mask_x == nullptr) != (mask_stats == nullptr)) return VS_EINVAL;    // all three (lazy conv input) or none
     if (dtype == VS_F32) return VS_EDTYPE;
     if (c_in != 8 || m_out != 8) return VS_ESHAPE;       // the Toeplitz kernel's shape class (igemm_k3t.h): the 8-channel full-resolution layers
     if (((uintptr_t)act_x & 15) || (dx_out && ((uintptr_t)dx_out & 15))) return VS_EALIGN;

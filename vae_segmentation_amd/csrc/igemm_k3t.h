@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float* s_mkm = s_shift + p.N * 8;                    // mean / rstd of the mask tensor's channels (fused IN-bwd sums)
     float* s_mkr = s_mkm + p.N * 8;
     float* s_fa = s_mkr + p.N * 8;                       // FA: rstd, -mean*rstd, m1, m2 of the input gradient's activation, [N*8] each
-    static_assert(!FA || (SUMS && !HS && EPI == EPI_RAW), "fused apply: backward-data variant only");
+    static_assert(!FA || (!HS && EPI == EPI_RAW), "fused apply: backward-data use (materialised gradient in), with or without the fused IN-backward sums");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int dx2 = g >> 1, c4 = 4 * (g & 1);            // this lane's accumulator rows: output voxel x = 2*col + dx2, channels c4..c4+3
@@ -399,7 +399,7 @@ static int k3t_launch_t(const G1Params& p_in, hipStream_t stream) {
 
 template <typename T, int EPI, bool SUMS, int YT>
 static int k3t_launch(const G1Params& p, hipStream_t stream) {
-    if constexpr (SUMS && EPI == EPI_RAW) {
+    if constexpr (EPI == EPI_RAW) {
         if (p.fa_x != nullptr) return k3t_launch_t<T, EPI, SUMS, YT, false, true>(p, stream);
     }
     if (!SUMS && p.x_stats != nullptr) return k3t_launch_t<T, EPI, SUMS, YT, !SUMS>(p, stream);

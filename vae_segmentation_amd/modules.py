@@ -222,6 +222,8 @@ class VAE(nn.Module):
             ops.stats_arena_begin(x.device)
             a = Act(ops.planar_input(x, self.kernel_dtype), None)     # Segmentation's prediction arrives with its channels-last copy
             a = self.in_block(a)
+            if a.stats is not None:
+                ops.mark_defer_apply(a.raw, self.in_block.conv[0])              # in_block's output feeds down1's strided conv only
             for blk in (self.down1, self.down2, self.down3, self.down4, self.down5):
                 a = blk(a)
             feat = ops.Materialize.apply(a.raw, a.stats, None, None)

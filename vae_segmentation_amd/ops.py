@@ -923,13 +923,22 @@ class ConvK3(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
         lazy = _take_lazy(gy)                   # gy is an un-applied gradient handed over by the consumer of this conv's output
-        if lazy is not None and not (ctx.needs_input_grad[0] and xs is not None and x.shape[-1] == 8 and gy.shape[-1] == 8):
-            gy, lazy = apply_lazy(gy, lazy), None     # this conv cannot fuse it (not the 8 -> 8 shape class / no lazy input): apply now
+        if lazy is not None and not (ctx.needs_input_grad[0] and x.shape[-1] == 8 and gy.shape[-1] == 8):
+            gy, lazy = apply_lazy(gy, lazy), None     # this conv cannot fuse it (not the 8 -> 8 shape class / no input gradient wanted): apply now
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, gy.shape[-1], gy.dtype)
-            if lazy is not None:
+            if lazy is not None and xs is not None:
                 gx, gy = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K3, real_channels=(cout, cin), defer=ctx.defer, lazy=lazy,
                                             want_dx=ctx.needs_input_grad[2])
+            elif lazy is not None:                # the conv's own input is a stored tensor (VAE.in_block on the prediction): no sums to fuse
+                ax, axs, asums = lazy
+                gx = torch.empty_like(x)
+                dx = torch.empty_like(gy) if ctx.needs_input_grad[2] else None
+                n_, d_, h_, w_, c_ = gy.shape
+                check(lib.vs_conv_k3_bwd_data_fused_apply(gy.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), gx.data_ptr(),
+                                                          None, None, None, _p(dx), n_, d_, h_, w_, c_, x.shape[-1], vs_dtype(x), EPS_IN, _stream()),
+                      "conv_k3_bwd_data_fused_apply")
+                gy = dx
             elif xs is not None:
                 gx = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K3, real_channels=(cout, cin), defer=ctx.defer)
             else:
@@ -1071,6 +1080,7 @@ class ConvK2S2(torch.autograd.Function):
         ctx.save_for_backward(x, xs, weight)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
+        ctx.defer = bool(getattr(x, "_vs_defer_apply", False)) and xs is not None     # see _LAZY_APPLY
         return y
 
     @staticmethod
@@ -1082,7 +1092,7 @@ class ConvK2S2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_SCATTER_D1, gy.shape[-1], gy.dtype)
             if xs is not None:
-                gx = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K2S2, scatter=True)
+                gx = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K2S2, scatter=True, defer=ctx.defer)
             else:
                 gx = conv_scatter(gy, None, wpb, None, x.shape[-1])
         if ctx.needs_input_grad[2]:
