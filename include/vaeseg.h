@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VS_VERSION 203
+#define VS_VERSION 204
 
 enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2 };   /* storage type of activations: fp32 (parity mode), bf16, IEEE fp16 (needs loss scaling, see vs_loss_scale_*) */
 #ifndef VS_STAT_SLOTS
@@ -109,7 +109,9 @@ int vs_conv_scatter_bwd_data(const void* x, const void* w_packed, void* y, const
  * between two backward-data launches of the 8-channel full-resolution layers (3 tensor passes at 96^3) disappears; dx_out (nullable)
  * receives the applied gradient (what the weight gradient of this layer reads).  mask_x / mask_stats / sums: all three as in
  * vs_conv_gather_bwd_data (the conv's own input is a lazy activation) or all NULL (it is a stored tensor: no sums to accumulate).
- * 16-bit storage, c_in = m_out = 8 only (VS_ESHAPE). */
+ * 16-bit storage; kernels exist for the single-chunk layers of the full- and half-resolution levels (c_in 8 or 16: igemm_k3t.h, igemm_k3b.h FA);
+ * any other shape returns VS_ESHAPE — ask vs_conv_k3_fused_apply_supported first (1 / 0; lazy_input: the conv's own input is a lazy activation). */
+int vs_conv_k3_fused_apply_supported(int n, int d, int h, int w, int c_in, int m_out, int lazy_input, int dtype);
 int vs_conv_k3_bwd_data_fused_apply(const void* g, const void* act_x, const double* act_stats, const double* act_sums,
                                     const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,
                                     void* dx_out, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);

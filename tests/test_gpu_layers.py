@@ -229,4 +229,55 @@ def test_k3_bwd_data_with_fused_apply(case, dtype, want_dx):
     assert relerr(y3.float().cpu(), y_ref2.float().cpu()) < 4 * ulp
     # shapes outside the 8 -> 8 class are refused, not mis-computed
     assert lib.vs_conv_k3_bwd_data_fused_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), y.data_ptr(),
-                                               mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(), None, n, d, h, w, 16, 8, dt, 1e-5, st) == -2
+                                               mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(), None, n, d, h, w, 32, 32, dt, 1e-5, st) == -2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(2, 48, 16, 16, True), (2, 48, 16, 8, False), (2, 48, 16, 32, False), (2, 96, 8, 16, False), (1, 64, 16, 16, True),
+                                  (2, 80, 16, 16, True), (1, 20, 16, 16, True), (3, 12, 8, 16, False), (2, 24, 16, 32, False)])
+def test_k3b_bwd_data_with_fused_apply(case, dtype):
+    """the same comparison for the k3b_kernel FA instantiations (igemm_k3b.h): the single-chunk backward-data launches of the 48^3 level
+    (16 -> 16 with a lazy conv input, 16 -> 8 / 16 -> 32 with a stored one), the 96^3 8 -> 16 one, and their 64^3 / 80^3 / ragged relatives;
+    (n, side, gradient channels, conv-input channels, conv input is lazy)"""
+    ops = _ops()
+    from vae_segmentation_amd._lib import check, lib
+    n, s_, c, m, lazy_in = case
+    d, h, w = s_, s_, s_ + (4 if s_ < 40 else 0)
+    dev = "cuda"
+    gen = torch.Generator().manual_seed(s_ + c)
+    ax = (torch.randn(n, d, h, w, c, generator=gen) * 1.3 + 0.2).to(dtype).to(dev)
+    g = torch.randn(n, d, h, w, c, generator=gen).to(dtype).to(dev)
+    mx = (torch.randn(n, d, h, w, m, generator=gen) * 0.8 - 0.1).to(dtype).to(dev)
+    wt = (torch.randn(c, m, 3, 3, 3, generator=gen) * 0.1).to(dev)                        # forward conv m -> c; backward-data c -> m
+    ops.stats_arena_begin(ax.device)
+    axs, mxs = ops.instnorm_stats(ax), ops.instnorm_stats(mx)
+    vox, dt, st = d * h * w, ops.vs_dtype(ax), ops._stream()
+    assert lib.vs_conv_k3_fused_apply_supported(n, d, h, w, c, m, int(lazy_in), dt) == 1
+    asums = ops._new_stats(n, c, ax.device)
+    check(lib.vs_instnorm_relu_bwd_reduce(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), n, vox, c, dt, 1e-5, st), "reduce")
+    wpb = ops.pack_weight(wt, ops.VS_PACK_ROWS_D1_FLIP, c, dtype)
+    dx_ref = torch.empty_like(g)
+    check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), dx_ref.data_ptr(), n, vox, c, dt, 1e-5, st), "apply")
+    y_ref, y = torch.empty_like(mx), torch.empty_like(mx)
+    s_ref, s2 = ops._new_stats(n, m, ax.device), ops._new_stats(n, m, ax.device)
+    dx = torch.full_like(g, 7.0)
+    if lazy_in:
+        check(lib.vs_conv_gather_bwd_data(dx_ref.data_ptr(), wpb.data_ptr(), y_ref.data_ptr(), mx.data_ptr(), mxs.data_ptr(), s_ref.data_ptr(),
+                                          n, d, h, w, c, m, ops.VS_CONV_K3, dt, 1e-5, st), "bwd_data")
+        check(lib.vs_conv_k3_bwd_data_fused_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), y.data_ptr(),
+                                                  mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(), dx.data_ptr(), n, d, h, w, c, m, dt, 1e-5, st), "fused")
+    else:
+        check(lib.vs_conv_gather_fwd(dx_ref.data_ptr(), None, wpb.data_ptr(), None, y_ref.data_ptr(), None, n, d, h, w, c, m, ops.VS_CONV_K3, dt, 1e-5, st), "plain")
+        check(lib.vs_conv_k3_bwd_data_fused_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), y.data_ptr(),
+                                                  None, None, None, dx.data_ptr(), n, d, h, w, c, m, dt, 1e-5, st), "fused")
+    torch.cuda.synchronize()
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    a, b = dx.float(), dx_ref.float()
+    assert float(((a - b).abs() / b.abs().clamp_min(1e-3)).max()) <= 2.1 * ulp
+    assert float((a != b).float().mean()) < 0.02
+    assert relerr(y.float().cpu(), y_ref.float().cpu()) < 4 * ulp
+    if lazy_in:
+        t2, tr = ops.stats_total(s2), ops.stats_total(s_ref)
+        assert float((t2 - tr).abs().max() / tr.abs().max()) < 4 * ulp
+    # a shape without a fused kernel says so and is refused
+    assert lib.vs_conv_k3_fused_apply_supported(n, 12, 12, 12, 32, 32, 1, dt) == 0

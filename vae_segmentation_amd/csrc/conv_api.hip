@@ -5,6 +5,7 @@
 int g1_dispatch_k3_f32(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_dispatch_k3_f16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
+int g1_k3_fa_supported(const G1Params& p, int ck, int mt);
 
 static int dispatch_k3(const G1Params& p, int dtype, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s) {
     if (dtype == VS_F32) return g1_dispatch_k3_f32(p, ck, mt, epi, tiles, row_tiles, s);
@@ -38,7 +39,7 @@ static int check_common(const void* x, const void* w, int n, int d, int h, int w
 static int gather_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                        void* y, double* y_stats, const void* mask_x, const double* mask_stats, double* sums,
                        int n, int d, int h, int w, int c_in, int m_out, int kind, int dtype, float eps, void* stream,
-                       const void* fa_x = nullptr, const double* fa_sums = nullptr, void* fa_dx = nullptr) {
+                       const void* fa_x = nullptr, const double* fa_sums = nullptr, void* fa_dx = nullptr, int* fa_query = nullptr) {
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
     if (!y || m_out <= 0 || m_out % 8 || ((uintptr_t)y & 15)) return VS_EINVAL;
@@ -77,6 +78,10 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     const int rows16 = p.rb_total * 16;
     const int mt = (kind != VS_CONV_K3 && p.tyn == 64) ? 16 : pick_mt(rows16, tiles);
     const int row_tiles = rows16 / mt;
+    if (fa_query != nullptr) {                             // planning only: would a fused-apply launch of this shape find a kernel?
+        *fa_query = (kind == VS_CONV_K3 && dtype != VS_F32) ? g1_k3_fa_supported(p, ck, mt) : 0;
+        return VS_OK;
+    }
     if (kind == VS_CONV_K3) {
         return dispatch_k3(p, dtype, ck, mt, EPI_RAW, (int)tiles, row_tiles, (hipStream_t)stream);
     }
@@ -103,10 +108,20 @@ extern "C" int vs_conv_k3_bwd_data_fused_apply(const void* g, const void* act_x,
     if (!g || !act_x || !act_stats || !act_sums) return VS_EINVAL;
     if ((mask_x == nullptr) != (sums == nullptr) || (mask_x == nullptr) != (mask_stats == nullptr)) return VS_EINVAL;    // all three (lazy conv input) or none
     if (dtype == VS_F32) return VS_EDTYPE;
-    if (c_in != 8 || m_out != 8) return VS_ESHAPE;       // the Toeplitz kernel's shape class (igemm_k3t.h): the 8-channel full-resolution layers
     if (((uintptr_t)act_x & 15) || (dx_out && ((uintptr_t)dx_out & 15))) return VS_EALIGN;
     return gather_impl(g, act_stats, w_packed, nullptr, y, nullptr, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, VS_CONV_K3, dtype, eps,
                        stream, act_x, act_sums, dx_out);
+}
+
+extern "C" int vs_conv_k3_fused_apply_supported(int n, int d, int h, int w, int c_in, int m_out, int lazy_input, int dtype) {
+    if (dtype == VS_F32 || !vs_dtype_ok(dtype)) return 0;
+    static const char dummy[16] __attribute__((aligned(16))) = {0};        // planning only: no pointer is dereferenced
+    static double dsink[2];
+    int ok = 0;
+    const int rc = gather_impl(dummy, (const double*)dummy, dummy, nullptr, (void*)dummy, nullptr, lazy_input ? dummy : nullptr,
+                               lazy_input ? (const double*)dummy : nullptr, lazy_input ? dsink : nullptr, n, d, h, w, c_in, m_out, VS_CONV_K3,
+                               dtype, 1e-5f, nullptr, dummy, (const double*)dummy, nullptr, &ok);
+    return rc == VS_OK ? ok : 0;
 }
 
 static int scatter_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias, void* y,

@@ -4,3 +4,6 @@
 int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s) {
     return dispatch_k3_h16<unsigned short>(p, ck, mt, epi, tiles, row_tiles, s);
 }
+
+// conv_api.hip: is there a fused-apply kernel for this (already planned) backward-data launch?  The same for both 16-bit storage types.
+int g1_k3_fa_supported(const G1Params& p, int ck, int mt) { return k3_h16_fa_supported(p, ck, mt) ? 1 : 0; }

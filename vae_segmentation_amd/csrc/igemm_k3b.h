@@ -64,11 +64,15 @@ struct K3BGeom {
 // use, or an exec-masked tail store, makes the compiler drain vmcnt(0): it then waits for the prefetched stage as well)
 // T: unsigned short (bf16 bits) or vs_half (fp16) — same fragment shapes, same MFMA rate; last template argument so that the profiler's
 // kernel names keep their prefix
-template <int CK, int MT, int EPI, bool SUMS, int YT = 4, bool HS = false, typename T = unsigned short>
+// FA (backward-data use, CK < 32): the input gradient arrives un-applied (p.x = g = dL/da of a = relu(norm(p.fa_x)), statistics p.x_stats,
+// IN-backward sums p.fa_sums) and the apply pass runs while the halo tile is staged; centre voxels also go to p.fa_dx when given (see
+// igemm_k3t.h, where the same is done for the 8 -> 8 layers)
+template <int CK, int MT, int EPI, bool SUMS, int YT = 4, bool HS = false, typename T = unsigned short, bool FA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
-    YT == 8 ? 2 : (CK == 32 ? (MT == 32 ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : (CK == 16 && SUMS ? 3 : 4))), 8))) void k3b_kernel(const G1Params p) {
+    YT == 8 ? 2 : (CK == 32 ? (MT == 32 ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : ((CK == 16 && SUMS) || FA ? 3 : 4))), 8))) void k3b_kernel(const G1Params p) {
     K3_TICK_INIT
     using GEO = K3BGeom<CK, MT, YT>;
+    static_assert(!FA || (CK < 32 && !HS && EPI == EPI_RAW), "fused apply: single-chunk backward-data kernels");
     static_assert(YT == 4 || (YT == 8 && CK < 32 && MT == 16), "tall tiles: single-chunk layers, 16 rows");
     constexpr int TV = GEO::TV, PLANE = (YT + 2) * 18;
     static_assert(CK == 8 || CK == 16 || CK == 32, "chunk width");
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     float* s_shift = s_scale + p.N * p.C;
     float* s_mkm = s_shift + p.N * p.C;                  // mean / rstd of the mask tensor's channels (fused IN-bwd sums)
     float* s_mkr = s_mkm + p.N * p.M;
+    float* s_fa = s_shift + p.N * p.C + (SUMS ? 2 * p.N * p.M : 0);   // FA: rstd, -mean*rstd, m1, m2 of the input gradient's activation, [N*C] each
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int rb0 = blockIdx.y * RB;
@@ -94,6 +99,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     constexpr bool has_sums = SUMS;
     const int total_tiles = p.tiles_per_sample * p.N;
     const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.C * 2));
+    const i32x4 frsrc = make_rsrc(FA ? p.fa_x : p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.C * 2));
+    const i32x4 dxrsrc = make_rsrc(FA && p.fa_dx != nullptr ? p.fa_dx : p.x, (FA && p.fa_dx != nullptr) ? (unsigned int)((long long)p.N * p.D * p.H * p.W * p.C * 2) : 0u);
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
 
     // the (sum, sumsq) pair this thread turns into a table entry is requested first of all: it is the oldest load in the
@@ -102,6 +109,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     const int st_n = SUMS ? p.N * p.M : (has_stats ? p.N * p.C : 0);
     double st_pre[2] = {0.0, 1.0};
     if (tid < st_n) stat_load(st_src, (size_t)tid, (size_t)st_n, st_pre);
+    double fa_pre[2][2] = {{0.0, 1.0}, {0.0, 0.0}};      // FA: waves 1.. request the activation's (sum, sumsq) and (sum g*mask, sum g*mask*xhat) pairs
+    if constexpr (FA) {
+        if (tid >= 64 && tid < 64 + p.N * p.C) {
+            stat_load(p.x_stats, (size_t)(tid - 64), (size_t)p.N * p.C, fa_pre[0]);
+            stat_load(p.fa_sums, (size_t)(tid - 64), (size_t)p.N * p.C, fa_pre[1]);
+        }
+    }
 
     // ---- per-thread stage geometry (tile independent) -----------------------------------------------------------------
     // fragment b of this thread is 16-byte part `part` (the same for every b: 256 % U == 0) of tile voxel tv_b
@@ -110,12 +124,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     // 32-channel tile's swizzle bit of fragment b kept in swzbits
     int rel_off[NIT], tzyx[NIT];
     const int lds_w0 = (tid / U) * CKB;
-    unsigned int swzbits = 0;
+    unsigned int swzbits = 0, cbits = 0;                  // cbits (FA): fragment b belongs to a centre (non-halo) voxel of the tile
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
         const int u = tid + b * 256;
         const int tv = u / U;
         const int tx_ = tv % 18, ty_ = (tv / 18) % (YT + 2), tz_ = tv / PLANE;
+        cbits |= (u < NU && tz_ >= 1 && tz_ <= 4 && ty_ >= 1 && ty_ <= YT && tx_ >= 1 && tx_ <= 16) ? (1u << b) : 0u;
         rel_off[b] = (((tz_ * p.H + ty_) * p.W + tx_) * p.C + part * 8) * 2;              // bytes from the tile's (0,0,0) halo voxel
         tzyx[b] = u < NU ? (tz_ | (ty_ << 8) | (tx_ << 16)) : 0x00ffffff;                 // out-of-list fragments fail every bounds test
         if (CK == 32) swzbits |= (unsigned int)((tx_ >> 2) & 1) << b;                     // see baddr[] below
@@ -129,7 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         w_off[i] = (rb0 + rb) * (p.nch * NKGC * 64) + r;                                   // + ch * NKGC * 64
     }
 
-    u32x4 xv[NIT], wv[NWI];
+    u32x4 xv[NIT], wv[NWI], fv[FA ? NIT : 1];
     unsigned int okbits = 0;
     struct Coord { int n, z0, y0, x0; };
     auto tile_coord = [&](int t) {                        // scalar: t is workgroup-uniform
@@ -156,6 +171,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
             const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             okbits |= ok ? (1u << b) : 0u;
             xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, ok ? base + rel_off[b] : -1, 0, 0));
+            if constexpr (FA) fv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(frsrc, ok ? base + rel_off[b] : -1, 0, 0));
+        }
+    };
+    auto write_x_fa = [&](const Coord& c) {             // FA: apply pass on the staged fragments [+ the applied gradient of the centre voxels to fa_dx]
+        f32x2 r2[4], s2[4], a2[4], b2[4];
+        const int c0 = c.n * p.C + part * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r2[i] = *(const f32x2*)(s_fa + 0 * p.N * p.C + c0 + 2 * i);
+            s2[i] = *(const f32x2*)(s_fa + 1 * p.N * p.C + c0 + 2 * i);
+            a2[i] = *(const f32x2*)(s_fa + 2 * p.N * p.C + c0 + 2 * i);
+            b2[i] = *(const f32x2*)(s_fa + 3 * p.N * p.C + c0 + 2 * i);
+        }
+        const int base = (((c.n * p.D + c.z0 - 1) * p.H + c.y0 - 1) * p.W + c.x0 - 1) * p.C * 2;
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) {
+            u32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x2 g2, x2;
+                g2[0] = H16<T>::lo(xv[b][i]); g2[1] = H16<T>::hi(xv[b][i]);
+                x2[0] = H16<T>::lo(fv[b][i]); x2[1] = H16<T>::hi(fv[b][i]);
+                const f32x2 xh = x2 * r2[i] + s2[i];
+                f32x2 gm;
+                gm[0] = xh[0] > 0.f ? g2[0] : 0.f;
+                gm[1] = xh[1] > 0.f ? g2[1] : 0.f;
+                const f32x2 d = r2[i] * (gm - a2[i] - xh * b2[i]);
+                v[i] = H16<T>::pack2(d);
+            }
+            const bool ok = (okbits >> b) & 1u;           // out-of-volume halo voxels: the gradient is zero-padded
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ok ? v[i] : 0u;
+            *(u32x4*)(s_tile + lds_w0 + b * 4096 + part * 16) = v;
+            if (p.fa_dx != nullptr)                        // workgroup-uniform
+                vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), dxrsrc, (ok && ((cbits >> b) & 1u)) ? base + rel_off[b] : -1, 0, 0);
         }
     };
     auto write_x = [&](int n, int ch) {
@@ -222,6 +272,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         if constexpr (SUMS) { s_mkm[i] = m; s_mkr[i] = r; }
         else { s_scale[i] = r; s_shift[i] = -m * r; }
     }
+    if constexpr (FA) {
+        if (tid >= 64 && tid < 64 + p.N * p.C) {
+            const int i = tid - 64;
+            float m, r;
+            stats_to_mean_rstd_fast(fa_pre[0], p.inv_count_in, p.eps, m, r);
+            s_fa[0 * p.N * p.C + i] = r;
+            s_fa[1 * p.N * p.C + i] = -m * r;
+            s_fa[2 * p.N * p.C + i] = (float)(fa_pre[1][0] * p.inv_count_in);
+            s_fa[3 * p.N * p.C + i] = (float)(fa_pre[1][1] * p.inv_count_in);
+        }
+    }
 
     // ---- LDS read addresses ---------------------------------------------------------------------------------------------
     // B fragment of (tap, column voxel (wave, cg, col)): tile voxel (wave + dz, cg + dy, col + dx).
@@ -278,7 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         for (int ch = 0; ch < p.nch; ++ch) {
             if (!first) __syncthreads();                 // every wave is done reading the previous stage
             K3_TICK(1);
-            write_x(n, ch);
+            if constexpr (FA) write_x_fa(cur); else write_x(n, ch);
             if constexpr (restage_w) write_w();
             first = false;
             K3_TICK(2);
@@ -447,10 +508,11 @@ static inline void k3b_fastdiv(int d, unsigned int& m, unsigned int& s) {
     m = (unsigned int)((((1ull << (32 + s)) + (unsigned long long)d - 1) / (unsigned long long)d) - (1ull << 32));
 }
 
-template <typename T, int CK, int MT, int EPI, bool SUMS, int YT, bool HS>
+template <typename T, int CK, int MT, int EPI, bool SUMS, int YT, bool HS, bool FA = false>
 static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
     using GEO = K3BGeom<CK, MT, YT>;
-    const size_t tables = (size_t)2 * p_in.N * p_in.C * sizeof(float) + (p_in.sums ? (size_t)2 * p_in.N * p_in.M * sizeof(float) : 0);
+    if (FA && (p_in.N * p_in.C > 192 || p_in.nch != 1 || !p_in.x_stats || !p_in.fa_sums)) return VS_ESHAPE;
+    const size_t tables = (size_t)(FA ? 6 : 2) * p_in.N * p_in.C * sizeof(float) + (p_in.sums ? (size_t)2 * p_in.N * p_in.M * sizeof(float) : 0);
     const size_t lds = K3B_LDS_TILE + (size_t)GEO::TILE_BYTES + GEO::W_BYTES + tables;
     if (lds > 160 * 1024) return VS_ESHAPE;
     G1Params p = p_in;
@@ -464,8 +526,8 @@ static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     k3b_fastdiv(p.tiles_per_sample, p.fd_m[0], p.fd_s[0]);
     k3b_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3b_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
-    if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr)) return VS_EINVAL;
-    auto kern = k3b_kernel<CK, MT, EPI, SUMS, YT, HS, T>;
+    if (SUMS != (p.sums != nullptr) || (SUMS && !FA && p.x_stats != nullptr)) return VS_EINVAL;
+    auto kern = k3b_kernel<CK, MT, EPI, SUMS, YT, HS, T, FA>;
     // idempotent one-time opt-in to the full 160 KiB of dynamic LDS (not a stream operation)
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -482,8 +544,18 @@ static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     return VS_OK;
 }
 
+// the fused-apply instantiations: the single-chunk backward-data layers of the 96^3 / 48^3 levels (and their 128^3 / 160^3 counterparts)
+template <int CK, int MT, int EPI, bool SUMS, int YT>
+constexpr bool k3b_has_fa() {
+    return EPI == EPI_RAW && ((CK == 16 && MT == 16) || (CK == 8 && MT == 16 && !SUMS && YT == 4) || (CK == 16 && MT == 32 && !SUMS && YT == 4));
+}
+
 template <typename T, int CK, int MT, int EPI, bool SUMS, int YT = 4>
 static int k3b_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
+    if (p.fa_x != nullptr) {
+        if constexpr (k3b_has_fa<CK, MT, EPI, SUMS, YT>()) return k3b_launch_t<T, CK, MT, EPI, SUMS, YT, false, true>(p, tiles_total, row_tiles, stream);
+        else return VS_ESHAPE;
+    }
     if (!SUMS && p.x_stats != nullptr) return k3b_launch_t<T, CK, MT, EPI, SUMS, YT, !SUMS>(p, tiles_total, row_tiles, stream);
     return k3b_launch_t<T, CK, MT, EPI, SUMS, YT, false>(p, tiles_total, row_tiles, stream);
 }

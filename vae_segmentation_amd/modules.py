@@ -226,6 +226,8 @@ class VAE(nn.Module):
                 ops.mark_defer_apply(a.raw, self.in_block.conv[0])              # in_block's output feeds down1's strided conv only
             for blk in (self.down1, self.down2, self.down3, self.down4, self.down5):
                 a = blk(a)
+                if blk is not self.down5 and a.stats is not None:
+                    ops.mark_defer_apply(a.raw, blk.conv[1].conv[6])            # a Down block's last conv feeds the next block's strided conv only (no skips in the VAE)
             feat = ops.Materialize.apply(a.raw, a.stats, None, None)
             x_mean, x_std = ops.LinearCLPair.apply(feat, self.fc_mean.weight, self.fc_mean.bias, False,
                                                    self.fc_std.weight, self.fc_std.bias, True)
@@ -242,8 +244,8 @@ class VAE(nn.Module):
         a = Act(h, None)
         for blk in (self.up1, self.up2, self.up3, self.up4, self.up5):
             a = _dropout(blk(a), dropout)
-        if a.stats is not None:
-            ops.mark_defer_apply(a.raw, self.up5.conv[1].conv[6])           # up5's last conv feeds out_block only
+            if a.stats is not None:
+                ops.mark_defer_apply(a.raw, blk.conv[1].conv[6])             # an Up block's last conv feeds the next block's transposed conv / out_block only
         recon = ops.ConvK3Softmax.apply(a.raw, a.stats, self.out_block.weight, self.out_block.bias)
         if not mid_input:
             return recon, x_mean, x_std

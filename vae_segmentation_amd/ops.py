@@ -534,11 +534,17 @@ _LAZY_APPLY = {"grads": {}, "callback": False}
 
 
 def mark_defer_apply(x, producer):
-    """x: the raw output of `producer` (an nn.Conv3d holder run by ConvK3) about to be consumed, once, by a 3x3x3 conv op"""
-    if (FUSE_APPLY and x.dtype != torch.float32 and x.shape[-1] == 8 and tuple(producer.weight.shape[2:]) == (3, 3, 3)
-            and cpad(producer.weight.shape[1]) == 8 and producer.weight.shape[0] == 8):
+    """x: the raw output of `producer` (an nn.Conv3d holder run by ConvK3, 3x3x3) about to be consumed, exactly once, by a conv op that honours
+    the mark (ConvK3, ConvK3Softmax[CL], ConvK2S2, ConvT2S2).  Marked when the producer's backward-data launch has a fused-apply kernel
+    (vs_conv_k3_fused_apply_supported: the single-chunk layers of the full- and half-resolution levels)."""
+    if FUSE_APPLY and x.dtype != torch.float32 and x.shape[-1] in (8, 16) and tuple(producer.weight.shape[2:]) == (3, 3, 3):
         x._vs_defer_apply = True
     return x
+
+
+def _fa_supported(gy, x, lazy_input):
+    n, d, h, w, c = gy.shape
+    return bool(lib.vs_conv_k3_fused_apply_supported(n, d, h, w, c, x.shape[-1], 1 if lazy_input else 0, vs_dtype(gy)))
 
 
 def _defer_register(g, x, xs, sums):
@@ -588,9 +594,10 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None, 
         dx = torch.empty_like(gy) if want_dx else None
         kid = nb = fl = None
         if PROFILE is not None:
-            kid = _k3_kid(_tname(x), 8, 16, sums=True, geom=(gn, gd, gh, gw), m=c) + "+apply"
-            nb = (3 * gy.numel() + 2 * g.numel() + (gy.numel() if want_dx else 0)) * _esize(x) // 1 + 8 * 8 * 27 * _esize(x)
-            fl = 2.0 * (g.numel() // c) * 27 * 8 * 8
+            tiles = gn * ((gd + 3) // 4) * ((gh + 3) // 4) * ((gw + 15) // 16)
+            kid = _k3_kid(_tname(x), min(gc, 32), _pick_mt((c + 15) // 16 * 16, tiles), sums=True, geom=(gn, gd, gh, gw), m=c) + "+apply"
+            nb = (2 * gy.numel() + 2 * g.numel() + (gy.numel() if want_dx else 0)) * _esize(x) + gc * c * 27 * _esize(x)
+            fl = 2.0 * (g.numel() // c) * 27 * gc * c
         with _timed(kid, nb, fl, "bwd+apply gy%s->m%d" % (tuple(gy.shape), c)):
             check(lib.vs_conv_k3_bwd_data_fused_apply(gy.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), g.data_ptr(),
                                                       x.data_ptr(), xs.data_ptr(), sums.data_ptr(), _p(dx), gn, gd, gh, gw, gc, c, dt, EPS_IN,
@@ -923,8 +930,8 @@ class ConvK3(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         gx = gw = gb = None
         lazy = _take_lazy(gy)                   # gy is an un-applied gradient handed over by the consumer of this conv's output
-        if lazy is not None and not (ctx.needs_input_grad[0] and x.shape[-1] == 8 and gy.shape[-1] == 8):
-            gy, lazy = apply_lazy(gy, lazy), None     # this conv cannot fuse it (not the 8 -> 8 shape class / no input gradient wanted): apply now
+        if lazy is not None and not (ctx.needs_input_grad[0] and _fa_supported(gy, x, xs is not None)):
+            gy, lazy = apply_lazy(gy, lazy), None     # no fused-apply kernel for this launch / no input gradient wanted: apply now
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, gy.shape[-1], gy.dtype)
             if lazy is not None and xs is not None:
@@ -1114,6 +1121,7 @@ class ConvT2S2(torch.autograd.Function):
         ctx.save_for_backward(x, xs, weight)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
+        ctx.defer = bool(getattr(x, "_vs_defer_apply", False)) and xs is not None     # see _LAZY_APPLY
         return y
 
     @staticmethod
@@ -1125,7 +1133,7 @@ class ConvT2S2(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D0, gy.shape[-1], gy.dtype)
             if xs is not None:
-                gx = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K2S2)
+                gx = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K2S2, defer=ctx.defer)
             else:
                 gx, _ = conv_gather(gy, None, wpb, None, x.shape[-1], VS_CONV_K2S2, False)
         if ctx.needs_input_grad[2]:
