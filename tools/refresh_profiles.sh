@@ -1,16 +1,29 @@
 #!/bin/bash
-# GPU box: regenerate what profiles/ holds for the current build -> gpurun_out/prof/ (copy the summaries into profiles/ afterwards).
-#   gpurun --timeout 900 -- 'bash tools/refresh_profiles.sh'
+# GPU box: regenerate everything profiles/ holds for the current build -> gpurun_out/prof/ (copy the summaries into profiles/ afterwards).
+#   gpurun --timeout 1100 -- 'bash tools/refresh_profiles.sh'
 set -e -o pipefail
 export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-python3 $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+Q="--no-cpu-baseline --no-fp32-mode --no-families"
+# 1. the bench line (+ the live-timed launches behind roofline.families)
+python3 $ROOT/bench.py --dump-launches $OUT/live_launches.json > $OUT/bench.json 2> $OUT/bench.err
+echo "bench done"
+# 2. per-kernel summary and the launches of one replayed step
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $ROOT/bench.py --steps 20 --warmup 3 $Q > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+python3 $ROOT/tools/step_trace.py $(find $OUT/stats -name "*kernel_trace.csv" | head -1) $OUT/step_kernels.json > $OUT/step_kernels.txt
+echo "stats done"
+# 3. HBM traffic (separate passes, MI355X_MICROARCH.md HBM section)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fp32-mode > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fp32-mode > /dev/null 2> $OUT/pmc_write.err
 python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write auto $OUT/hbm_traffic.json > $OUT/hbm_traffic.txt
-find $OUT -name "*kernel_stats.csv" -o -name "*domain_stats.csv" | head
-tail -c 400 $OUT/bench.json
+echo "traffic done"
+# 4. matrix-core counters
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o p -- python3 $ROOT/bench.py --steps 5 --warmup 1 $Q > /dev/null 2> $OUT/pmc_mfma.err
+python3 $ROOT/tools/pmc_mfma.py $OUT/pmc_mfma $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/mfma_util.json > $OUT/mfma_util.txt
+echo "mfma done"
+# 5. the other BASELINE configurations
+python3 $ROOT/tools/run_configs.py all $OUT/other_configs.jsonl > $OUT/other_configs.txt 2> $OUT/other_configs.err
+head -3 $OUT/step_kernels.txt; head -1 $OUT/hbm_traffic.txt; tail -c 300 $OUT/bench.json
