@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VS_VERSION 204
+#define VS_VERSION 205
 
 enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2 };   /* storage type of activations: fp32 (parity mode), bf16, IEEE fp16 (needs loss scaling, see vs_loss_scale_*) */
 #ifndef VS_STAT_SLOTS
@@ -247,6 +247,32 @@ int vs_dropout(const void* x, void* out, long long count, float p, unsigned long
  * mask[i] = 0 or 1/(1-p).  Element order: the tensor's own memory order — channels-last [N][V][C] for vs_dropout, planar [N][2][V]
  * for the logits.  Lets a checker feed the SAME mask to the reference arithmetic (F.dropout replaced by a multiply). */
 int vs_dropout_mask(float* mask, long long count, float p, unsigned long long seed, void* stream);
+
+/* ---- training data pipeline on the device ---------------------------------------------------------------------------
+ * Planar fp32 volumes [D][H][W].  What utils/utils.py's transform chain does per sample on CPU workers (main_source.py:191-211):
+ * NumpyLoader_Multi_merge relabelling (utils.py:253-262), CropResize (utils.py:326-383), MySpatialTransform = batchgenerators
+ * augment_spatial (utils.py:927-968; rotation, scale, random crop; cubic-spline image / nearest label), Clip + CenterIntensities
+ * (utils.py:508-533, 575-618).  The interpolation arithmetic is scipy.ndimage's, which skimage.transform.resize and augment_spatial call. */
+/* box6 = {min z, y, x, max z, y, x} of label > 0 (INT_MAX / -1 when there is none) */
+int vs_data_bbox(const float* label, int d, int h, int w, int* box6, void* stream);
+/* out = target of the last (source -> target) pair whose source equals the label, 0 otherwise; sources / targets: HOST arrays, n_pairs <= 16 */
+int vs_data_relabel(const float* in, float* out, long long total, const float* sources, const float* targets, int n_pairs, void* stream);
+/* dst[p] = src[p - off + lo] for p - off + lo inside [lo, hi) of the source, 0 elsewhere (crop + np.pad); lo3 / hi3 / off3: HOST arrays */
+int vs_data_crop_pad(const float* src, float* dst, int sd, int sh, int sw, int dd, int dh, int dw, const int* lo3, const int* hi3,
+                     const int* off3, void* stream);
+/* scipy.ndimage.gaussian_filter1d(mode='mirror', truncate=4.0) along one axis (src != dst) */
+int vs_data_gaussian_axis(const float* src, float* dst, int d, int h, int w, int axis, float sigma, void* stream);
+int vs_data_minmax(const float* x, long long total, float* minmax2, void* stream);
+/* scipy.ndimage.zoom(mode='mirror', grid_mode=True), order 0 or 1; order 1 results are clamped to [clip_lo, clip_hi] unless clip_lo > clip_hi */
+int vs_data_zoom(const float* src, float* dst, int sd, int sh, int sw, int dd, int dh, int dw, int order, float clip_lo, float clip_hi, void* stream);
+/* order-3 B-spline coefficients of x in fp64 (scipy.ndimage.spline_filter, mirror boundary) */
+int vs_data_spline3_prefilter(const float* x, double* coef, int d, int h, int w, void* stream);
+/* dst[o] = sample(src, A (o - (P-1)/2) + ctr), scipy map_coordinates(mode='constant', cval): order 3 (src = the fp64 coefficients) or 0 (src = fp32
+ * volume); a9 (row-major 3x3) / ctr3: HOST arrays */
+int vs_data_affine_sample(const void* src, float* dst, int sd, int sh, int sw, int pd, int ph, int pw, const double* a9, const double* ctr3, int order,
+                          float cval, void* stream);
+/* x = (clamp(x, lo, hi) - subtrahend) / divisor, in place */
+int vs_data_clip_center(float* x, long long total, float lo, float hi, float subtrahend, float divisor, void* stream);
 
 /* ---- layout glue at the NCDHW boundary ----------------------------------------------------------- */
 /* planar fp32 [N][c_src][V] -> channels-last [N][V][c_pad] (zero-filled channels >= c_src) */

@@ -1,0 +1,114 @@
+"""GPU: the device data pipeline (vae_segmentation_amd/data_gpu.py, vs_data_* kernels) against the numpy / scipy
+oracle (oracle/data_cpu.py) on the same inputs.  Exact for the integer / copy steps (bounding box, relabelling, crop + pad, nearest
+resampling away from ties), 1e-5 of the value range for the interpolating ones (the kernels keep scipy's fp64 arithmetic, results are fp32)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from oracle import data_cpu as O
+    from vae_segmentation_amd import data_gpu as D
+    return O, D
+
+
+def _volume(shape, seed, blob=((0.3, 0.7), (0.35, 0.8), (0.2, 0.6))):
+    rng = np.random.RandomState(seed)
+    merge = np.zeros(shape + (2,), np.float32)
+    merge[..., 0] = rng.randn(*shape) * 300 + 50
+    sl = tuple(slice(int(a * s), int(b * s)) for (a, b), s in zip(blob, shape))
+    merge[sl + (1,)] = rng.randint(1, 4, size=merge[sl + (1,)].shape)
+    return merge
+
+
+def _close(a, b, tol):
+    a, b = a.detach().cpu().double().numpy().reshape(b.shape), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+@pytest.mark.parametrize("shape,seed", [((60, 70, 50), 1), ((128, 96, 140), 2), ((33, 47, 29), 3)])
+def test_relabel_bbox_crop_pad(shape, seed):
+    O, D = _mods()
+    merge = _volume(shape, seed)
+    mask_index = [[[1, 3], 1], [2, 2]]
+    img, lab = O.load_merge(merge, mask_index)
+    lab_d = D.relabel(torch.from_numpy(merge[..., 1].copy()).cuda(), mask_index)
+    assert np.array_equal(lab_d.cpu().numpy(), lab)
+    box = D.bounding_box(lab_d)
+    idx = np.array(np.where(lab > 0)).T
+    assert np.array_equal(box[0], idx.min(0)) and np.array_equal(box[1], idx.max(0))
+    assert D.bounding_box(torch.zeros(8, 9, 10, device="cuda")) is None
+    centre, L, pad = O.crop_box(lab)
+    for shift in (0, 3):
+        ref = O.crop_pad_cube(img, centre, L, pad, shift)
+        got = D.crop_pad_cube(torch.from_numpy(img).cuda(), centre, L, pad, shift)
+        assert got.shape == ref.shape and np.array_equal(got.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("in_shape,out", [((37, 37, 37), 64), ((150, 150, 150), 64), ((64, 64, 64), 64), ((90, 90, 90), 128), ((52, 61, 70), 48)])
+def test_resize_vs_scipy_restated_skimage(in_shape, out):
+    O, D = _mods()
+    rng = np.random.RandomState(in_shape[0])
+    img = (rng.randn(*in_shape) * 300).astype(np.float32)
+    lab = ((rng.rand(*in_shape) > 0.6) * rng.randint(1, 3, size=in_shape)).astype(np.float32)
+    got_i = D.resize(torch.from_numpy(img).cuda(), (out,) * 3)
+    got_l = D.resize(torch.from_numpy(lab).cuda(), (out,) * 3, order=0, anti_aliasing=False)
+    assert _close(got_i, O.skimage_resize(img, (out,) * 3), 1e-5)
+    assert np.array_equal(got_l.cpu().numpy(), O.skimage_resize(lab, (out,) * 3, order=0, anti_aliasing=False))
+
+
+@pytest.mark.parametrize("side,patch,seed", [(64, 64, 0), (96, 96, 1), (128, 128, 2), (40, 32, 3)])
+def test_spatial_transform_vs_scipy(side, patch, seed):
+    """augment_spatial's rotation + scale + random crop: cubic-spline image (constant border -1024) and nearest label (border 0)"""
+    O, D = _mods()
+    rng = np.random.RandomState(seed)
+    img = (rng.randn(side, side, side) * 300).astype(np.float32)
+    lab = (rng.rand(side, side, side) > 0.5).astype(np.float32)
+    p = O.draw_spatial_params(np.random.RandomState(seed + 10), (side,) * 3, (patch,) * 3, [patch // 2 - 5] * 3)
+    ref_i, ref_l = O.spatial_transform(img, lab, (patch,) * 3, p["angles"], p["scale"], p["centre"])
+    t = D.MySpatialTransform((patch,) * 3, [patch // 2 - 5] * 3, random_crop=True, scale=(0.85, 1.15), do_elastic_deform=False, do_rotation=True,
+                             angle_x=(-0.2, 0.2), angle_y=(-0.2, 0.2), angle_z=(-0.2, 0.2), border_mode_data="constant", border_cval_data=-1024,
+                             data_key="venous", p_el_per_sample=0, label_key="venous_pancreas", p_scale_per_sample=1, p_rot_per_sample=1,
+                             rng=np.random.RandomState(seed + 10))
+    d = t({"venous": torch.from_numpy(img).cuda()[None, None], "venous_pancreas": torch.from_numpy(lab).cuda()[None, None]})
+    assert _close(d["venous"][0, 0], ref_i, 1e-5)                  # the transform's own draws == the oracle's (same RandomState seed, same order)
+    got_l = d["venous_pancreas"][0, 0].cpu().numpy()
+    assert (got_l != ref_l).mean() < 1e-5                          # nearest: identical away from exact .5 ties
+    assert float((d["venous"] == -1024).float().mean()) > 0 or p["scale"] < 1.0
+
+
+def test_train_sample_pipeline_vs_oracle():
+    """the whole per-sample chain of main_source.py:191-211 (relabel -> CropResize -> MySpatialTransform -> Clip -> CenterIntensities)"""
+    O, D = _mods()
+    merge = _volume((110, 120, 100), 7)
+    mask_index = [[[1, 2, 3], 1]]
+    patch = (64, 64, 64)
+    p = O.draw_spatial_params(np.random.RandomState(5), patch, patch, [27] * 3)
+    ref_i, ref_l = O.train_sample(merge, patch, p, mask_index)
+    t = D.MySpatialTransform(patch, [27] * 3, random_crop=True, scale=(0.85, 1.15), do_elastic_deform=False, angle_x=(-0.2, 0.2), angle_y=(-0.2, 0.2),
+                             angle_z=(-0.2, 0.2), border_mode_data="constant", border_cval_data=-1024, data_key="venous", label_key="venous_pancreas",
+                             p_el_per_sample=0)
+    img, lab = D.train_sample(torch.from_numpy(merge).cuda(), patch, mask_index, t, (p["angles"], p["scale"], p["centre"], True))
+    assert img.shape == (1, 1) + patch and lab.shape == (1, 1) + patch
+    assert _close(img[0, 0], ref_i, 2e-5)
+    assert (lab[0, 0].cpu().numpy() != ref_l).mean() < 1e-4
+    # no augmentation (--no_aug)
+    img2, lab2 = D.train_sample(torch.from_numpy(merge).cuda(), patch, mask_index)
+    ref_i2, ref_l2 = O.train_sample(merge, patch, None, mask_index)
+    assert _close(img2[0, 0], ref_i2, 2e-5) and np.array_equal(lab2[0, 0].cpu().numpy(), ref_l2)
+    # an empty label falls back to the reference's fixed box (utils/utils.py:355-358)
+    empty = merge.copy(); empty[..., 1] = 0
+    img3, _ = D.train_sample(torch.from_numpy(empty).cuda(), patch)
+    assert _close(img3[0, 0], O.train_sample(empty, patch, None)[0], 2e-5)
+
+
+def test_unsupported_settings_raise():
+    O, D = _mods()
+    with pytest.raises(NotImplementedError):
+        D.MySpatialTransform((32,) * 3, do_elastic_deform=True, border_mode_data="constant")
+    with pytest.raises(NotImplementedError):
+        D.MySpatialTransform((32,) * 3, do_elastic_deform=False)                       # default border_mode_data='nearest'
+    with pytest.raises(TypeError):
+        D.bounding_box(torch.zeros(4, 4, 4))

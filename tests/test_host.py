@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
                  "vs_conv_k3_softmax2_dropout_fwd", "vs_conv_wgrad_multi", "vs_conv_wgrad_multi_workspace_bytes",
                  "vs_dice_loss_multi_fwd", "vs_dice_loss_multi_bwd", "vs_dice_loss_multi_scratch_doubles"):
         assert must in protos, must
-    assert _lib.lib.vs_version() == 204
+    assert _lib.lib.vs_version() == 205
     assert b"dtype" in _lib.lib.vs_strerror(-3)
 
 
