@@ -736,6 +736,11 @@ def drop_stale_wgrads():
     if g["descs"] or g["callback"]:
         g["descs"], g["keep"], g["callback"], g["bytes"], g["flops"] = [], [], False, 0.0, 0.0
     g["slots"] = {}
+    # the same for gradients parked / handed over un-applied by a pass that died: their addresses may be recycled by now, and a later
+    # backward must never mistake a fresh tensor at such an address for one of them
+    for reg in (_PENDING, _LAZY_APPLY):
+        reg["grads"].clear()
+        reg["callback"] = False
 
 
 def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb):
