@@ -74,10 +74,15 @@ def skimage_resize(image, output_shape, order=1, anti_aliasing=None):
     return out.astype(image.dtype)
 
 
-def crop_resize(img, label, output_size, shift=0):
-    centre, L, pad = crop_box(label)
+def crop_resize(img, label, output_size, shift=0, pred=None):
+    """pred (a coarse prediction, utils/utils.py:345-358): when given, the box comes from pred > 0 instead of the label, pred itself is cropped
+    (without the shift), padded and resized with order 0, and a third array is returned"""
+    centre, L, pad = crop_box(label if pred is None else pred)
     img_c, lab_c = crop_pad_cube(img, centre, L, pad, shift), crop_pad_cube(label, centre, L, pad, shift)
-    return skimage_resize(img_c, output_size), skimage_resize(lab_c, output_size, order=0, anti_aliasing=False)
+    out = (skimage_resize(img_c, output_size), skimage_resize(lab_c, output_size, order=0, anti_aliasing=False))
+    if pred is not None:
+        out += (skimage_resize(crop_pad_cube(pred, centre, L, pad, 0), output_size, order=0, anti_aliasing=False),)
+    return out
 
 
 # ---- batchgenerators.augmentations.spatial_transformations.augment_spatial, as MySpatialTransform configures it -------------------------

@@ -112,3 +112,16 @@ def test_unsupported_settings_raise():
         D.MySpatialTransform((32,) * 3, do_elastic_deform=False)                       # default border_mode_data='nearest'
     with pytest.raises(TypeError):
         D.bounding_box(torch.zeros(4, 4, 4))
+
+
+def test_crop_resize_with_coarse_prediction():
+    """CropResize's `_pancreas_pred` branch (utils/utils.py:345-358, the validation pipelines with load_pred): the box comes from the prediction"""
+    O, D = _mods()
+    merge = _volume((70, 90, 80), 11)
+    img, lab = O.load_merge(merge, [[[1, 2, 3], 1]])
+    pred = np.zeros_like(lab); pred[20:48, 30:70, 25:60] = 1
+    ref = O.crop_resize(img, lab, (48, 48, 48), pred=pred)
+    d = D.CropResize(["venous"], (48, 48, 48))({"venous": torch.from_numpy(img).cuda(), "venous_pancreas": torch.from_numpy(lab).cuda(),
+                                                "venous_pancreas_pred": torch.from_numpy(pred).cuda()})
+    assert _close(d["venous"], ref[0], 1e-5)
+    assert np.array_equal(d["venous_pancreas"].cpu().numpy(), ref[1]) and np.array_equal(d["venous_pancreas_pred"].cpu().numpy(), ref[2])

@@ -2,7 +2,7 @@
 same names, constructor arguments and dict-in / dict-out protocol, operating on CUDA tensors through libvaeseg's vs_data_* kernels.
 
     NumpyLoader_Multi_merge   utils/utils.py:220-276   (the relabelling; file I/O stays with the caller: hand it the merge array)
-    CropResize                utils/utils.py:326-383   (training branch: bounding box of the label, cube crop + zero pad, resize)
+    CropResize                utils/utils.py:326-383   (bounding box of the label or of a coarse prediction, cube crop + zero pad, resize)
     MySpatialTransform        utils/utils.py:927-968   (batchgenerators augment_spatial: rotation, scale, random crop; elastic deformation,
                                                         which main_source.py:198 switches off, is not implemented)
     Clip, CenterIntensities   utils/utils.py:508-533, 575-618
@@ -98,7 +98,7 @@ class BaseTransform:
 
 
 class CropResize(BaseTransform):
-    """utils/utils.py:326-383, training branch (fields f and f + '_pancreas')"""
+    """utils/utils.py:326-383 (fields f, f + '_pancreas' and, when present, the coarse prediction f + '_pancreas_pred' that then defines the box)"""
 
     def __init__(self, fields, output_size, pad=32, shift=0):
         super().__init__(fields)
@@ -109,12 +109,20 @@ class CropResize(BaseTransform):
             if data_dict.get(f) is None:
                 continue
             img, label = data_dict[f], data_dict[f + "_pancreas"]
-            box = bounding_box(label)
+            pred = data_dict.get(f + "_pancreas_pred")
+            if isinstance(pred, torch.Tensor):               # utils/utils.py:345-358: the box of a coarse prediction (which the reference assumes non-empty)
+                box = bounding_box(pred)
+                if box is None:
+                    raise ValueError("CropResize: empty %s_pancreas_pred (the reference fails on np.max of an empty index array here)" % f)
+            else:
+                box = bounding_box(label)
             if box is not None:
                 centre, L = (box[1] + box[0]) // 2, int(np.max(box[1] - box[0]))
             else:
                 centre, L = np.array([64, 64, 64]), 32
             pad = int(L * 0.1)
+            if isinstance(pred, torch.Tensor):
+                data_dict[f + "_pancreas_pred"] = resize(crop_pad_cube(pred, centre, L, pad, 0), self.output_size, order=0, anti_aliasing=False)
             lab_c = crop_pad_cube(label, centre, L, pad, self.shift)
             data_dict["ori_shape"] = np.array(list(label.shape) + list(lab_c.shape))
             data_dict[f] = resize(crop_pad_cube(img, centre, L, pad, self.shift), self.output_size)
