@@ -4,7 +4,8 @@ The reference's scripts (main_source.py 853 lines, main_target.py 1063 lines) ar
 pipeline + the train / validate / checkpoint loop.  The data pipeline, TensorBoard writer and plotting are out of scope
  and their dependencies are absent, so the entry points here keep the reference's flag names and
 loop semantics (methods, loss bodies, frozen sub-nets, optimiser groups, epoch arithmetic, checkpoint dict layout, score
-JSON) and feed the step from a deterministic synthetic dataset (`--synthetic`, the only data source available).
+JSON) and feed the step from a deterministic synthetic dataset (`--synthetic`, the default) or, with `--real_data`, from merge.npy cases
+run through the device data pipeline (data_gpu.py).
 
 One process per GPU: under torchrun (WORLD_SIZE > 1) every rank builds the same replica, takes its own shard of the
 synthetic volumes and averages gradients with one RCCL all-reduce per step (vae_segmentation_amd.ddp) — the replacement
@@ -66,7 +67,69 @@ class SyntheticVolumes(torch.utils.data.Dataset):
         return {IMG_KEY: torch.from_numpy(img[None]), LABEL_KEY: torch.from_numpy(label[None])}
 
 
+# ----------------------------------------------------------------------------------------------------
+# real data: merge.npy cases from a json list, transformed on the device (main_source.py:125-131,186-243 with data_gpu.py's pipeline)
+# ----------------------------------------------------------------------------------------------------
+def filedict_from_json(json_path, key, epoch=1):
+    """main_source.py:123-131: the case names under `key`, repeated `epoch` times"""
+    import json
+    with open(json_path, "r") as f:
+        names = json.load(f).get(key, [])
+    return list(names) * epoch
+
+
+def mask_index_of(args):
+    """main_source.py:92-95"""
+    if str(args.pan_index) != "10":
+        return [[0, 0]] + [[int(f), i + 1] for i, f in enumerate(str(args.pan_index).split(","))]
+    return [[0, 0], [[1, 2], 1]]
+
+
+class DeviceCaseLoader:
+    """What BaseDataset + the transform stack + DataLoader deliver in the reference (main_source.py:186-243), with the transforms on the
+    device: np.load of each case's merge array is the only host work; relabel / CropResize / MySpatialTransform / Clip / CenterIntensities
+    run as vs_data_* kernels (data_gpu.py).  Yields {IMG_KEY, LABEL_KEY: (B, 1, S, S, S) CUDA tensors}."""
+
+    def __init__(self, names, root, args, batch_size, train, shuffle, rank=0, world=1, seed=0):
+        from . import data_gpu
+        self.names, self.root, self.bs, self.shuffle = list(names)[rank::world], root, batch_size, shuffle
+        self.patch, self.mask_index, self.epoch, self.seed = (args.size,) * 3, mask_index_of(args), 0, seed + rank
+        self.drop_last = train
+        self.transform = None
+        if train and not getattr(args, "no_aug", False):                       # main_source.py:195-205
+            self.transform = data_gpu.MySpatialTransform(
+                self.patch, [d // 2 - 5 for d in self.patch], random_crop=True, scale=(0.85, 1.15), do_elastic_deform=False, alpha=(0, 500),
+                do_rotation=True, sigma=(10, 30.), angle_x=(-0.2, 0.2), angle_y=(-0.2, 0.2), angle_z=(-0.2, 0.2), border_mode_data="constant",
+                border_cval_data=-1024, data_key=IMG_KEY, p_el_per_sample=0, label_key=LABEL_KEY, p_scale_per_sample=1, p_rot_per_sample=1,
+                rng=np.random.RandomState(seed + 1000 * rank))
+        self._dg = data_gpu
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return len(self.names) // self.bs if self.drop_last else (len(self.names) + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        order = np.arange(len(self.names))
+        if self.shuffle:
+            np.random.RandomState(self.seed + self.epoch).shuffle(order)
+        for b in range(len(self)):
+            imgs, labs = [], []
+            for i in order[b * self.bs:(b + 1) * self.bs]:
+                merge = torch.from_numpy(np.load(os.path.join(self.root, self.names[i])).astype(np.float32)).cuda(non_blocking=True)
+                img, lab = self._dg.train_sample(merge, self.patch, self.mask_index, self.transform, field=IMG_KEY)
+                imgs.append(img); labs.append(lab)
+            yield {IMG_KEY: torch.cat(imgs), LABEL_KEY: torch.cat(labs)}
+
+
 def make_loaders(args, rank, world):
+    if getattr(args, "real_data", False):
+        json_path = os.path.join("lists", args.data_path)
+        train = DeviceCaseLoader(filedict_from_json(json_path, args.train_list, args.eval_epoch), args.data_root, args, args.batch_size, True,
+                                 shuffle=args.method != "domain_adaptation", rank=rank, world=world)       # main_source.py:232-236
+        val = DeviceCaseLoader(filedict_from_json(json_path, args.val_list), args.val_data_root, args, 1, False, False)
+        return train, val, train                      # the loader doubles as the 'sampler': set_epoch reshuffles
     train = SyntheticVolumes(args.synthetic_train, args.size, seed=1)
     val = SyntheticVolumes(args.synthetic_val, args.size, seed=2)
     sampler = None
@@ -168,9 +231,6 @@ def run(args, side="source"):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not args.synthetic:
-        raise SystemExit("only --synthetic data is available in this build: the reference's NumPy/SimpleITK/batchgenerators "
-                         "pipeline (utils/utils.py) is out of scope and its dependencies are not installed")
     assert args.save_epoch % args.eval_epoch == 0
     nc = n_class_of(args)
     method = args.method
@@ -392,7 +452,9 @@ def run(args, side="source"):
 
 def add_native_flags(parser):
     g = parser.add_argument_group("native (MI355X) additions")
-    g.add_argument("--synthetic", action="store_true", default=True, help="synthetic volumes (the only data source in this build)")
+    g.add_argument("--synthetic", action="store_true", default=True, help="synthetic volumes (default: no dataset ships with this repository)")
+    g.add_argument("--real_data", action="store_true", help="train / validate on the merge.npy cases of lists/<data_path>[train_list | val_list] under "
+                   "data_root / val_data_root, transformed on the device (data_gpu.py) — the reference's loader stack (main_source.py:186-243)")
     g.add_argument("--size", type=int, default=128, help="cubic patch side (reference: patch_size 128, main_source.py:117)")
     g.add_argument("--dtype", default="fp32", choices=["fp32", "bf16", "fp16"], help="kernel storage dtype")
     g.add_argument("--synthetic_train", type=int, default=16)
