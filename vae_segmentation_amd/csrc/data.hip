@@ -30,12 +30,23 @@ __global__ __launch_bounds__(256) void dp_bbox_kernel(const float* __restrict__ 
             mx[0] = max(mx[0], z); mx[1] = max(mx[1], y); mx[2] = max(mx[2], x);
         }
     }
+    // one atomic per (workgroup, bound): same-address device atomics retire ~25 ns apart, and one per wave of a 20M-voxel case made this the
+    // longest kernel of the pipeline (1.33 ms of 2.66)
+    __shared__ int s_mn[4][3], s_mx[4][3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         int a = mn[k], b = mx[k];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { a = min(a, __shfl_xor(a, o, 64)); b = max(b, __shfl_xor(b, o, 64)); }
-        if ((threadIdx.x & 63) == 0) { if (a != INT_MAX) atomicMin(box + k, a); if (b >= 0) atomicMax(box + 3 + k, b); }
+        if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6][k] = a; s_mx[threadIdx.x >> 6][k] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        const int a = min(min(s_mn[0][k], s_mn[1][k]), min(s_mn[2][k], s_mn[3][k]));
+        const int b = max(max(s_mx[0][k], s_mx[1][k]), max(s_mx[2][k], s_mx[3][k]));
+        if (a != INT_MAX) atomicMin(box + k, a);
+        if (b >= 0) atomicMax(box + 3 + k, b);
     }
 }
 
@@ -124,7 +135,13 @@ __global__ __launch_bounds__(256) void dp_minmax_kernel(const float* __restrict_
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) { lo = fminf(lo, x[i]); hi = fmaxf(hi, x[i]); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o, 64)); hi = fmaxf(hi, __shfl_xor(hi, o, 64)); }
-    if ((threadIdx.x & 63) == 0) { dp_atomic_minf(mm, lo); dp_atomic_maxf(mm + 1, hi); }
+    __shared__ float s_lo[4], s_hi[4];
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {                              // one CAS loop per workgroup and bound
+        dp_atomic_minf(mm, fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3])));
+        dp_atomic_maxf(mm + 1, fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3])));
+    }
 }
 
 // ---- order-3 B-spline coefficients (scipy.ndimage.spline_filter1d, mode 'mirror' — what map_coordinates(mode='constant') prefilters with):
@@ -213,7 +230,8 @@ static inline bool dp_dims_ok(int d, int h, int w) { return d > 0 && h > 0 && w 
 extern "C" int vs_data_bbox(const float* label, int d, int h, int w, int* box6, void* stream) {
     if (!label || !box6 || !dp_dims_ok(d, h, w)) return VS_EINVAL;
     hipLaunchKernelGGL(dp_bbox_init_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, box6);
-    hipLaunchKernelGGL(dp_bbox_kernel, dim3(dp_blocks((long long)d * h * w / 4)), dim3(256), 0, (hipStream_t)stream, label, d, h, w, box6);
+    const int bb = dp_blocks((long long)d * h * w / 16);
+    hipLaunchKernelGGL(dp_bbox_kernel, dim3(bb < 2048 ? bb : 2048), dim3(256), 0, (hipStream_t)stream, label, d, h, w, box6);
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -254,7 +272,8 @@ extern "C" int vs_data_gaussian_axis(const float* src, float* dst, int d, int h,
 extern "C" int vs_data_minmax(const float* x, long long total, float* minmax2, void* stream) {
     if (!x || !minmax2 || total <= 0) return VS_EINVAL;
     hipLaunchKernelGGL(dp_minmax_init_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, minmax2);
-    hipLaunchKernelGGL(dp_minmax_kernel, dim3(dp_blocks(total / 4)), dim3(256), 0, (hipStream_t)stream, x, total, minmax2);
+    const int mb = dp_blocks(total / 16);
+    hipLaunchKernelGGL(dp_minmax_kernel, dim3(mb < 2048 ? mb : 2048), dim3(256), 0, (hipStream_t)stream, x, total, minmax2);
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
