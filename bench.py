@@ -175,8 +175,13 @@ def make_step(a, dtype, rank, use_dist):
         step = gs.step
 
     def closer():
+        """before the eager family-timing passes: gradients back to ordinary tensors, and the captured step's autograd graph and gradient
+        accumulators (created on its warm-up stream) released — eager passes on the default stream would otherwise reuse them and pay
+        autograd's cross-stream synchronisation on every parameter"""
         if sync is not None:
             sync.close()
+        if not a.no_graph:
+            gs.loss = gs.aux = gs._accumulators = None
     return step, loss_fn, seg_params, closer
 
 
@@ -255,6 +260,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    del loss                                    # the last reference to the captured step's autograd graph (see closer())
     ms_per_step = 1e3 * dt / a.steps
 
     families, fp32_mode, cpu = None, None, None
