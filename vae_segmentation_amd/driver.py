@@ -92,7 +92,10 @@ class DeviceCaseLoader:
 
     def __init__(self, names, root, args, batch_size, train, shuffle, rank=0, world=1, seed=0):
         from . import data_gpu
-        self.names, self.root, self.bs, self.shuffle = list(names)[rank::world], root, batch_size, shuffle
+        names = list(names)
+        if train and world > 1:
+            names = names[:len(names) // world * world]          # every rank the same number of steps (the all-reduce is collective)
+        self.names, self.root, self.bs, self.shuffle = names[rank::world], root, batch_size, shuffle
         self.patch, self.mask_index, self.epoch, self.seed = (args.size,) * 3, mask_index_of(args), 0, seed + rank
         self.drop_last = train
         self.transform = None
