@@ -166,7 +166,8 @@ def make_step(a, dtype, rank, use_dist):
             else:
                 loss.backward()
             if sync is not None:
-                opt.step_with(sync.params, sync(), **kw)
+                sync()
+                opt.step_with(*sync.live(), **kw)
             else:
                 opt.step(**kw)
             return loss

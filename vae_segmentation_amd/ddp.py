@@ -67,6 +67,7 @@ class FlatGradSync:
         self.buckets = [self.flat[:n0], self.flat[n0:]] if small else [self.flat]
         self.views = [slot[id(p)] for p in self.params]                 # aligned with self.params
         self._first_ids = {id(p) for p in big}
+        self._second_ids = {id(p) for p in small}
         self._tab, self._tab0 = _Tables(), _Tables()
         self._async = self.overlap
         self._works = []
@@ -93,21 +94,35 @@ class FlatGradSync:
                 dist.broadcast(p.data, src, group=self.group)
 
     # -- phases ---------------------------------------------------------------------------------------------------
-    def _stragglers(self, grads):
-        """Gradients that did not land in their slot (accumulation into an existing .grad, hooks, direct=False): gathered by
-        one multi-tensor copy.  In the steady state of the direct mode this list is empty and nothing is launched."""
+    def live(self):
+        """(params, views) of the parameters that take part in this step: requires_grad may be switched off for some of them after
+        construction (embed_train freezes its Encoder on even epochs, main_source.py:550-554) — their slots are still exchanged (zeros or
+        an old average, harmless) but must never reach the optimiser."""
+        keep = [i for i, p in enumerate(self.params) if p.requires_grad]
+        return [self.params[i] for i in keep], [self.views[i] for i in keep]
+
+    def _stragglers(self, grads, only=None):
+        """Gradients that did not land in their slot (accumulation into an existing .grad, hooks, direct=False, every non-conv parameter:
+        Linear weights, BatchNorm affine): gathered by one multi-tensor copy.  In the steady state of the direct mode with conv-only
+        networks this list is empty and nothing is launched.  A parameter that received NO gradient in this pass has its slot zeroed —
+        the slot still holds the previous step's average, which the optimiser would otherwise apply again.
+        only: a set of parameter ids restricting the pass to one bucket."""
         src, dst = [], []
-        for g, v in zip(grads, self.views):
+        for p, g, v in zip(self.params, grads, self.views):
+            if only is not None and id(p) not in only:
+                continue
             if g is None:
+                if p.requires_grad:
+                    v.zero_()
                 continue
             if g.data_ptr() != v.data_ptr():
                 src.append(g)
                 dst.append(v)
         return src, dst
 
-    def gather(self, grads=None, tab=None):
+    def gather(self, grads=None, tab=None, only=None):
         grads = [p.grad for p in self.params] if grads is None else grads
-        src, dst = self._stragglers(grads)
+        src, dst = self._stragglers(grads, only)
         if not src:
             return
         if self.flat.is_cuda:
@@ -160,10 +175,10 @@ class FlatGradSync:
             self.gather(grads)
             self.start(0)
         else:
-            self.gather([g if id(p) in self._first_ids else None for g, p in zip(grads, self.params)], self._tab0)
+            self.gather(grads, self._tab0, only=self._first_ids)    # bucket-0 stragglers (fc weights ...) BEFORE its all-reduce starts
             self.start(0)
             ops.flush_wgrads()                                       # bucket-1 weight gradients run under bucket 0's all-reduce
-            self.gather(grads)
+            self.gather(grads, only=self._second_ids)
             self.start(1)
         self.wait()
         return self.views

@@ -314,6 +314,9 @@ def run(args, side="source"):
     if sync is not None:
         sync.broadcast_parameters(0)
     ops.set_overlap(False)          # serial launch order: measured 1-2 % faster than the side-stream branch (train.GraphedStep)
+    # fp16 storage: Dice gradients are O(1e-6), below fp16's normal range — dynamic loss scaling on the device (optim.LossScaler)
+    scaler = optim.LossScaler() if dtype == torch.float16 else None
+    skw = {} if scaler is None else {"scaler": scaler}
 
     runner = None
     if method == "domain_adaptation" and getattr(args, "val_finetune", 0) and rank == 0:
@@ -365,6 +368,8 @@ def run(args, side="source"):
 
     def loss_key(epoch):
         """what of the loss expression depends on the epoch (main_target.py:583-592): a captured step is rebuilt when it changes"""
+        if method == "domain_adaptation_dis":                               # main_target.py:720-723: lambda ramps with the epoch during the warm-up
+            return min(epoch, warmup_epochs)
         if method != "domain_adaptation" or getattr(args, "domain_loss_type", 0) != 0 or getattr(args, "only_pseudo", False):
             return 0
         if turn_epoch != -1:
@@ -388,7 +393,7 @@ def run(args, side="source"):
                 model.Vae.eval()
             if use_graph and (stepper is None or stepper_key != loss_key(epoch)):
                 stepper = None                                        # release the old capture's memory pool first
-                stepper = T.GraphedStep(loss_fn, params, optimizer, grad_sync=sync, warmup=1)
+                stepper = T.GraphedStep(loss_fn, params, optimizer, grad_sync=sync, warmup=1, scaler=scaler)
                 stepper_key = loss_key(epoch)
                 if rank == 0:
                     print("train step captured as a HIP graph (%s)" % ("2 graphs + bucketed all-reduce" if stepper.graph2 is not None else "1 graph"))
@@ -405,18 +410,38 @@ def run(args, side="source"):
                     every = max(1, args.pseudo_save_epoch // args.eval_epoch)
                     if epoch != 0 and epoch % every == 0 and (getattr(args, "update_every_iteration", False) or idx % max(1, n_iter // args.eval_epoch) == 0):
                         optim.ema_update(teacher.Seg, model.Seg, args.alpha)
+                if method == "domain_adaptation_dis" and getattr(args, "pseudo_save_epoch", 0) and epoch % args.pseudo_save_epoch == 0:
+                    # main_target.py:710-712: the pseudo-label network is re-loaded from the student (in place: a captured graph replays it)
+                    with torch.no_grad():
+                        teacher.load_state_dict(model.Seg.state_dict())
+                    ops.clear_pack_cache()
+                    ops.refresh_frozen_packs(teacher)
+                    if getattr(args, "tag", False):
+                        lambda_vae /= 10
+                        stepper_key = None                                   # lambda is baked into the captured loss expression
+                if use_graph and stepper is not None and stepper_key is None:
+                    stepper = None
+                    stepper = T.GraphedStep(loss_fn, params, optimizer, grad_sync=sync, warmup=1, scaler=scaler)
+                    stepper_key = loss_key(epoch)
                 if stepper is not None:
                     stepper.step()
                     aux = stepper.aux
                 else:
-                    for p in params:
-                        p.grad = None
+                    # optimizer.zero_grad() over ALL parameters, as the reference does every iteration (main_source.py:660): a parameter that is
+                    # frozen for this epoch (embed_train's Encoder on even epochs) must not keep the gradient of its last trained step
+                    for grp in optimizer.param_groups:
+                        for p in grp["params"]:
+                            p.grad = None
                     loss, aux = loss_fn()
-                    loss.backward()
-                    if sync is not None:
-                        optimizer.step_with(sync.params, sync())
+                    if scaler is not None:
+                        loss.backward(gradient=scaler.seed)
                     else:
-                        optimizer.step()
+                        loss.backward()
+                    if sync is not None:
+                        sync()
+                        optimizer.step_with(*sync.live(), **skw)
+                    else:
+                        optimizer.step(**skw)
                 seen += bs
                 if rank == 0 and idx % args.display_freq == 0:              # logging syncs the host every display_freq steps only
                     parts = ", ".join("%s %.4f" % (k, v.item()) for k, v in aux.items() if k != "batch")

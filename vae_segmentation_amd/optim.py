@@ -122,7 +122,10 @@ class SGD(torch.optim.Optimizer):
 
 
 class Adam(torch.optim.Optimizer):
-    """torch.optim.Adam(lr, betas, eps, weight_decay) as one kernel per group."""
+    """torch.optim.Adam(lr, betas, eps, weight_decay) as one kernel per group.
+    Deviation under a LossScaler (fp16 only; the reference has no mixed precision): when the device-side overflow flag skips an update the
+    host-side ``state['step']`` has still advanced (reading the flag would sync), so after a skipped step the bias corrections run one step
+    ahead of torch.cuda.amp.GradScaler's."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))

@@ -97,9 +97,7 @@ def domain_adaptation_losses(student, teacher, img, label, lambda_vae=1.0, domai
         final = lambda_vae * recon_loss + fake_loss
     elif domain_loss_type == 10:
         raise NotImplementedError("domain_loss_type 10 reads `val_batch`, undefined in the reference's training loop (main_target.py:568)")
-    elif domain_loss_type != 0:
-        raise NotImplementedError("domain_loss_type %r" % (domain_loss_type,))
-    elif turn_epoch != -1:
+    elif turn_epoch != -1:              # every other domain_loss_type (1-7, ...) falls through to the default branches, as in the reference (:583-592)
         final = lambda_vae * recon_loss if (epoch // turn_epoch) % 2 == 0 else lambda_vae * recon_loss + fake_loss
     elif epoch >= lambda_vae_warmup:
         final = lambda_vae * recon_loss + fake_loss
@@ -283,15 +281,18 @@ class GraphedStep:
             self.optimizer.step(**kw)
             return self.loss
         if self.graph2 is not None:
+            # bucket-0 stragglers (gradients autograd did not write into their flat slot: Linear weights, BatchNorm affine, ...) must be in
+            # the bucket BEFORE its all-reduce starts; copying them afterwards would both miss the average and race with the collective
+            s.gather(self.grads, s._tab0, only=s._first_ids)
             s.start(0)
             self.graph2.replay()
-            s.gather(self.grads)
+            s.gather(self.grads, only=s._second_ids)
             s.start(1)
         else:
             s.gather(self.grads)
             s.start(0)
         s.wait()
-        self.optimizer.step_with(s.params, s.views, **kw)
+        self.optimizer.step_with(*s.live(), **kw)
         return self.loss
 
 
