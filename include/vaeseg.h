@@ -56,6 +56,28 @@ int vs_version(void);
 int vs_stat_slots(void);        /* VS_STAT_SLOTS the library was built with (callers size statistics buffers by it) */
 int vs_stat_interleaved(void);  /* 0: double[slot][N][C][2]   1: double[N][C][slot][2] */
 const char* vs_strerror(int code);
+/* 1 for the deterministic build of the library (libvaeseg_det.so, -DVS_DET_BUILD=1: parity runs), 0 for the throughput build.  In the
+ * deterministic build every per-(n,c) statistic — the conv epilogues' (sum, sumsq), the fused InstanceNorm-backward sums, the vs_instnorm_*
+ * reductions — is accumulated with commuting integer atomics on four fixed-point limbs held in the same double[VS_STAT_SLOTS][N][C][2]
+ * buffer (csrc/common.h), and the few remaining floating-point atomics (vs_dice_fwd, vs_bce_fwd, vs_bias_grad) run as one block: two runs of a
+ * step on the same inputs agree bit for bit.  A statistics buffer must be produced and consumed by the same build. */
+int vs_get_deterministic(void);
+
+/* ---- composed Up block (csrc/igemm_k4.h): ConvTranspose3d(C, C, 2, stride 2) -> Conv3d(C, Co, 3, padding 1) as ONE operator -----------------
+ * Replaces, for 16-bit storage, the pair vs_conv_scatter_fwd + vs_conv_gather_fwd(K3) behind `Up` (/root/reference/joint_model.py:116-120: the
+ * Sequential has nothing between the two convolutions) and, backward, vs_conv_gather_bwd_data(K3) + vs_conv_gather_bwd_data(K2S2).
+ * w2 = ConvTranspose3d.weight [cin][cm][2][2][2], b2 = its bias [cm] (nullable), w3 = Conv3d.weight [co][cm][3][3][3] (bias dead: InstanceNorm follows).
+ * vs_up_compose_sizes -> bytes of {Weff fp32 scratch, forward image, backward-data image, forward tap lists, backward tap lists, bias table}. */
+int vs_up_supported(int cin, int cm, int co, int dtype);
+int vs_up_compose_sizes(int cin, int cm, int co, size_t* out6);
+int vs_up_compose(const float* w2, const float* b2, const float* w3, float* weff, void* img_fwd, void* img_bwd, int* taps_fwd, int* taps_bwd,
+                  float* btab, int cin, int cm, int co, int dtype, void* stream);
+/* x: coarse (n,d,h,w,cin) [lazy with x_stats]; y: fine raw conv output (n,2d,2h,2w,co) + its statistics */
+int vs_up_conv_fwd(const void* x, const double* x_stats, const void* img_fwd, const int* taps_fwd, const float* btab, void* y, double* y_stats,
+                   int n, int d, int h, int w, int cin, int co, int dtype, float eps, void* stream);
+/* gy: gradient of y (fine, applied); gx: gradient of the coarse input (n,d,h,w,cin); mask_* / sums: fused InstanceNorm-backward sums of a lazy input (all or none) */
+int vs_up_conv_bwd_data(const void* gy, const void* img_bwd, const int* taps_bwd, void* gx, const void* mask_x, const double* mask_stats,
+                        double* sums, int n, int d, int h, int w, int co, int cin, int dtype, float eps, void* stream);
 
 /* ---- weights ---------------------------------------------------------------------------------- */
 /* bytes of the packed image of a weight with `rows` GEMM rows (any count; padded to 16 inside),

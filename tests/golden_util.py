@@ -123,8 +123,13 @@ def check_tensor_f64(gold, prefix, t, k=64, floor=1e-3, factor=3.0, what=""):
     return mine, theirs
 
 
-def check_grads_f64(gold, prefix, named_grads, k=16, floor=2e-3, factor=8.0, dead_atol=1e-5, what=""):
-    """Per-parameter gradient check against the fp64 yardstick; returns [(name, mine, reference-fp32, limit applied)]."""
+def check_grads_f64(gold, prefix, named_grads, k=16, floor=2e-3, factor=2.0, dead_atol=1e-5, what="", cap=None, hard_factor=8.0):
+    """Per-parameter gradient check against the fp64 yardstick; returns [(name, mine, reference-fp32, limit applied)].
+    limit = max(floor, factor x the reference-fp32 run's own distance to fp64) [capped at `cap`].  factor 2 (round 2 used 8).
+    hard_factor: for the sizes where the reference's own fp32 gradients sit 1e-2 .. 1e-1 from fp64 (ReLU masks flip under rounding, so
+    the two fp32 results are two draws of the same chaotic amplification and their RATIO is heavy-tailed): a tensor beyond `factor` is
+    recorded in OUTLIERS (printed by vacuity() and committed in profiles/r03_parity_report.txt) and only fails beyond hard_factor (round 2's
+    bound), also capped."""
     report = []
     for name, g in named_grads:
         key = "%s.grad.%s" % (prefix, name)
@@ -145,9 +150,20 @@ def check_grads_f64(gold, prefix, named_grads, k=16, floor=2e-3, factor=8.0, dea
         mine = max(_sample_err(a[sample_idx(a.size, k)], s64, rms), abs(my_l2 - l64) / l64)
         theirs = max(_sample_err(s32, s64, rms), abs(float(gold[key + ".l2"]) - l64) / l64)
         lim = max(floor, factor * theirs)
+        if cap is not None:
+            lim = min(lim, max(cap, floor))
         report.append((name, mine, theirs, lim))
+        hard = max(floor, (hard_factor or factor) * theirs)
+        if cap is not None:
+            hard = min(hard, max(cap, floor))
+        if lim < mine <= hard:
+            OUTLIERS.append((what or prefix, name, mine, theirs, lim))
+            continue
         assert mine <= lim, "%s: grad %s err vs fp64 %.3g > %.3g (reference fp32: %.3g)" % (what, name, mine, lim, theirs)
     return report
+
+
+OUTLIERS = []       # (what, tensor, HIP error vs fp64, reference-fp32 error vs fp64, limit): beyond factor x, within hard_factor x
 
 
 def vacuity(report, what=""):
@@ -155,6 +171,12 @@ def vacuity(report, what=""):
     far from fp64, the check says little) and the median limit, so a weak gate is visible in the test output."""
     lims = sorted(r[3] for r in report)
     loose = sum(1 for v in lims if v > 1e-2)
-    print("\n%s: %d gradient tensors checked, %d with a limit above 1e-2, median limit %.2e, worst own error %.2e"
-          % (what, len(lims), loose, lims[len(lims) // 2] if lims else 0.0, max((r[1] for r in report), default=0.0)))
+    ratios = sorted(r[1] / max(r[2], 1e-30) for r in report)
+    print("\n%s: %d gradient tensors checked, %d with a limit above 1e-2, median limit %.2e, worst own error %.2e; "
+          "HIP error / reference-fp32 error (both vs fp64): median %.2f, max %.2f"
+          % (what, len(lims), loose, lims[len(lims) // 2] if lims else 0.0, max((r[1] for r in report), default=0.0),
+             ratios[len(ratios) // 2] if ratios else 0.0, ratios[-1] if ratios else 0.0))
+    for w, name, mine, theirs, lim in OUTLIERS:
+        if w == what:
+            print("   outlier %-40s HIP %.3e  reference fp32 %.3e  (limit %.3e, ratio %.1f)" % (name, mine, theirs, lim, mine / max(theirs, 1e-30)))
     return loose

@@ -45,6 +45,37 @@ def _report(tag, errs, lims):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", K3_LAYERS)
 def test_k3_layer_shapes(case, dtype):
+    _k3_case(case, dtype)
+
+
+# BASELINE configs[4]: 160^3, batch 2 per GPU, fp16 storage (and the fp32 parity mode): the levels 160 / 80 / 40 / 20 / 10 / 5 — the odd side 5
+# and the largest tensors the 32-bit byte offsets of the 16-bit kernels must hold (2 x 160^3 x 16 channels x 2 B = 262 MB) included
+K3_LAYERS_160 = [(2, 1, 8, 160), (2, 8, 8, 160), (2, 16, 8, 160), (2, 8, 16, 80), (2, 16, 16, 80), (2, 32, 16, 80), (2, 16, 32, 40), (2, 32, 32, 40),
+                 (2, 64, 32, 40), (2, 64, 64, 20), (2, 128, 64, 20), (2, 128, 128, 10), (2, 256, 128, 10), (2, 128, 256, 5), (2, 256, 256, 5)]
+K2_LAYERS_160 = [(2, 8, 160), (2, 16, 80), (2, 32, 40), (2, 64, 20), (2, 128, 10)]
+T2_LAYERS_160 = [(2, 16, 80), (2, 32, 40), (2, 64, 20), (2, 128, 10), (2, 256, 5)]
+DT160 = [torch.float32, torch.float16]
+
+
+@pytest.mark.parametrize("dtype", DT160)
+@pytest.mark.parametrize("case", K3_LAYERS_160)
+def test_k3_layer_shapes_160(case, dtype):
+    _k3_case(case, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT160)
+@pytest.mark.parametrize("case", K2_LAYERS_160)
+def test_k2s2_layer_shapes_160(case, dtype):
+    test_k2s2_layer_shapes(case, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT160)
+@pytest.mark.parametrize("case", T2_LAYERS_160)
+def test_transposed_layer_shapes_160(case, dtype):
+    test_transposed_layer_shapes(case, dtype)
+
+
+def _k3_case(case, dtype):
     ops = _ops()
     n, cin, cout, s = case
     x = rnd(n, cin, s, s, s, seed=1)
@@ -69,7 +100,10 @@ def test_k3_layer_shapes(case, dtype):
             "stat_sum": float((st[..., 0] - ref_sum).abs().max() / ref_sq.sqrt().max()),
             "stat_sq": float((st[..., 1] - ref_sq).abs().max() / ref_sq.max()),
             "gx": relerr(from_cl(x_cl.grad, cin), xq.grad), "gw": relerr(w_gpu.grad.cpu(), wq.grad)}
-    lims = {"y": tol, "stat_sum": 4 * tol, "stat_sq": 4 * tol, "gx": 4 * tol, "gw": 4 * tol}
+    # the channel sum is a near-cancelling sum: its rounding noise grows like sqrt(voxels) against the sqrt(sum of squares) scale used above
+    # (tests/test_gpu_ops.py, CONV_CASES_LARGE) — the 160^3 cases get the corresponding factor over the 96^3 ones
+    grow = max(1.0, (s / 96.0) ** 1.5)
+    lims = {"y": tol, "stat_sum": 4 * tol * grow, "stat_sq": 4 * tol, "gx": 4 * tol, "gw": 4 * tol}
     _report("k3 %s %s" % (case, dtype), errs, lims)
 
 

@@ -16,8 +16,9 @@ pytestmark = pytest.mark.gpu
 RTOL_FP32 = 1e-3          # north_star tolerance (floor of every fp64-yardstick check below)
 RTOL_GRAD_FP32 = 2e-3     # floor for gradients; see tests/golden_util.py: limits are max(floor, k x the
                           # reference-fp32 run's own distance to the same code run in fp64), k = 3 for forward
-                          # tensors / losses and 8 for gradients (measured: 2-5x, run-to-run variable because
-                          # the fp64 atomics of the statistics arrive in a different order each run).  Through ~60 InstanceNorm/ReLU layers the
+                          # tensors / losses and 2 for gradients; a gradient tensor between 2x and 8x is listed by name as an outlier
+                          # (profiles/r03_parity_report.txt), beyond 8x it fails.  The runs are made in the library's deterministic mode
+                          # (tests/conftest.py), so every number here reproduces bit for bit.  Through ~60 InstanceNorm/ReLU layers the
                           # reference's eager fp32 gradients themselves sit 1e-2..1e-1 from the fp64 result at
                           # 64^3..128^3 (at this random init the net amplifies a 1e-7 rounding perturbation ~1e6x:
                           # ReLU masks flip), and that distance is itself a random draw per tensor.
@@ -105,7 +106,10 @@ def test_seg96_vs_reference_golden():
     loss.backward()
     G.scalar_close(g, "dice_loss", loss.item(), RTOL_FP32)
     G.check_tensor_f64(g, "pred", aux["batch"]["pred"], k=512, floor=RTOL_FP32)
-    rep = G.check_grads_f64(g, "seg", [(n, p.grad) for n, p in seg.named_parameters()], floor=RTOL_GRAD_FP32)
+    # at this size the reference's own fp32 gradients are 2e-3 .. 3e-3 from fp64 and HIP's 3e-4 .. 1.5e-2: the deepest tensors sit 4 - 6 x the
+    # reference's distance (listed as outliers; profiles/r03_parity_report.txt has the full-tensor table).  That is amplification of a different
+    # rounding draw, not kernel error: tests/test_gpu_backward_steps.py pins every single backward step of this very pass to < 5e-6.
+    rep = G.check_grads_f64(g, "seg", [(n, p.grad) for n, p in seg.named_parameters()], floor=RTOL_GRAD_FP32, what="seg96")
     G.vacuity(rep, "seg96")
 
 
@@ -153,7 +157,7 @@ def test_joint_train_step_vs_reference_golden(side, bs, name):
     G.check_tensor_f64(g, "recon", b["recon"], k=512, floor=RTOL_FP32)
     assert G.rel_l2(b["mean"].detach().cpu(), g["mean@f64"]) < max(RTOL_FP32, 3 * G.rel_l2(g["mean"], g["mean@f64"]))
     assert G.rel_l2(b["std"].detach().cpu(), g["std@f64"]) < max(RTOL_FP32, 3 * G.rel_l2(g["std"], g["std@f64"]))
-    rep = G.check_grads_f64(g, "seg", [(n, p.grad) for n, p in joint.Seg.named_parameters()], floor=RTOL_GRAD_FP32)
+    rep = G.check_grads_f64(g, "seg", [(n, p.grad) for n, p in joint.Seg.named_parameters()], floor=RTOL_GRAD_FP32, what=name)
     print("\n%s: worst grad error vs fp64: HIP %.3g, reference fp32 %.3g" % (name, max(r[1] for r in rep), max(r[2] for r in rep)))
     G.vacuity(rep, name)
     assert all(p.grad is None for p in joint.Vae.parameters())
@@ -175,7 +179,7 @@ def test_domain_adaptation128_vs_reference_golden():
     # pseudo-label voxels may flip only where the teacher's soft output is within rounding of 0.5
     fake_sum = aux["batch"]["fake"].double().sum().item()
     assert abs(fake_sum - float(g["fake.sum"])) <= 4
-    G.vacuity(G.check_grads_f64(g, "seg", [(n, p.grad) for n, p in student.Seg.named_parameters()], floor=RTOL_GRAD_FP32), "da128 type 0")
+    G.vacuity(G.check_grads_f64(g, "seg", [(n, p.grad) for n, p in student.Seg.named_parameters()], floor=RTOL_GRAD_FP32, what="da128 type 0"), "da128 type 0")
     # domain_loss_type 8 (main_target.py:550-560): loss and its own gradient set; evaluated on the host (as the reference) and on the device
     for host in (True, False):
         for p in student.Seg.parameters():
@@ -183,7 +187,7 @@ def test_domain_adaptation128_vs_reference_golden():
         f8, _ = T.domain_adaptation_losses(student, teacher, img, lab, lambda_vae=1.0, domain_loss_type=8, host_schedule=host)
         f8.backward()
         G.scalar_close(g, "final8", f8.item(), RTOL_FP32)
-        G.vacuity(G.check_grads_f64(g, "seg8", [(n, p.grad) for n, p in student.Seg.named_parameters()], floor=RTOL_GRAD_FP32), "da128 type 8")
+        G.vacuity(G.check_grads_f64(g, "seg8", [(n, p.grad) for n, p in student.Seg.named_parameters()], floor=RTOL_GRAD_FP32, what="da128 type 8"), "da128 type 8")
     # the other scalar combinations of main_target.py:571-592 against the same arithmetic on the golden's terms
     r, f = float(g["recon_loss@f64"]), float(g["fake_loss@f64"])
     for kw, want in ((dict(domain_loss_type=11), r + f + r * f), (dict(domain_loss_type=12), r + f - r * f),
@@ -465,12 +469,11 @@ def test_seg32_dropout_with_exported_masks_vs_oracle(monkeypatch):
         # the bias of a stride-2 / transposed conv in front of an InstanceNorm'd DoubleConv acts only through the zero padding of the
         # next 3x3x3 conv: its exact gradient is a near-cancelling sum over the voxels (|sum| ~ 1e-3 of sum |.|), so fp32 rounding of the
         # terms shows up amplified ~1e3 times in the relative error — floor 1e-2 for these 8 vectors
-        # weights: 2e-2.  Measured over 28 runs of this test: 21 within 2e-3, 6 between 2.5e-3 and 3.4e-3, one at 6.4e-3, always on the deepest
-        # tensors (in_block / up4.conv.0) — the fp64 statistics atomics arrive in a different order each run, and at 32^3 a single activation
-        # that sits at a ReLU edge and is kept (x 1.25) by the dropout mask moves those gradients by that much when it flips (the oracle's own
-        # fp32 run moves 1e-5 .. 6e-4 between runs).  What this test is for — the exported masks are the ones the kernels applied — fails at
-        # O(1): a wrong or shifted mask changes every gradient entirely.  The tight gradient gates are the mask-free ones (seg32, layers).
-        floor = 2e-2
+        # weights: the 2e-3 floor.  In the default (fp64-atomic) mode this gate was unreliable — over 28 runs 21 within 2e-3, 6 between 2.5e-3 and
+        # 3.4e-3, one at 6.4e-3: the statistics atomics arrive in a different order each run, and at 32^3 a single activation that sits at a
+        # ReLU edge and is kept (x 1.25) by the dropout mask moves the deepest gradients by that much when it flips.  The test suite runs in the
+        # library's deterministic mode (tests/conftest.py): one fixed summation, the same numbers every run.
+        floor = 2e-3
         lim = max(floor, 8 * theirs)
         over += lim > 1e-2
         assert mine <= lim, (n, mine, lim, theirs)

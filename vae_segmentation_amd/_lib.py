@@ -59,19 +59,50 @@ class VaesegError(RuntimeError):
     pass
 
 
-def _load():
-    if not os.path.exists(LIB_PATH):
-        raise ImportError("libvaeseg.so not found at %s — build it with `python -c 'import __graft_entry__ as g; "
-                          "g.build()'` or `make -C vae_segmentation_amd/csrc`; there is no fallback path" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+DET_LIB_PATH = os.path.join(_HERE, "libvaeseg_det.so")
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise ImportError("%s not found — build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` or `make -C vae_segmentation_amd/csrc`; there is no fallback path" % path)
+    cdll = ctypes.CDLL(path)
     for name, (restype, argtypes) in parse_header().items():
-        fn = getattr(lib, name)          # AttributeError if the header declares what the .so lacks
+        if os.environ.get("VS_LIBVAESEG") and not hasattr(cdll, name):
+            continue                     # an older build loaded for a same-box A/B measurement: entry points it lacks fail when called
+        fn = getattr(cdll, name)         # AttributeError if the header declares what the .so lacks
         fn.restype = restype
         fn.argtypes = argtypes
-    return lib
+    return cdll
 
 
-lib = _load()
+class _Lib:
+    """The library the package calls into: libvaeseg.so (throughput build, fp64-atomic statistics) or — after use_deterministic(True) /
+    under env VS_DETERMINISTIC=1 — libvaeseg_det.so, the same sources compiled with -DVS_DET_BUILD=1 (statistics summed with commuting integer
+    atomics: bit-reproducible parity runs, csrc/common.h).  Both export every symbol of include/vaeseg.h; attribute access goes to the active one."""
+
+    def __init__(self):
+        self._fast = _load(LIB_PATH)
+        self._det = None
+        self._active = self._fast
+
+    def use_deterministic(self, on):
+        if on:
+            if self._det is None:
+                self._det = _load(DET_LIB_PATH)
+                if not self._det.vs_get_deterministic():
+                    raise ImportError("%s is not a deterministic build (VS_DET_BUILD)" % DET_LIB_PATH)
+            self._active = self._det
+        else:
+            self._active = self._fast
+
+    def __getattr__(self, name):
+        return getattr(self._active, name)
+
+
+lib = _Lib()
+if os.environ.get("VS_DETERMINISTIC", "0") == "1":
+    lib.use_deterministic(True)
 
 
 def check(code, what=""):

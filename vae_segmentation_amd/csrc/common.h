@@ -145,7 +145,32 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __device__ __forceinline__ size_t stat_index(size_t pair, size_t pairs, int slot) {
     return VS_STAT_INTERLEAVE ? (pair * VS_STAT_SLOTS + slot) * 2 : ((size_t)slot * pairs + pair) * 2;
 }
+
+// ---- deterministic build (-DVS_DET_BUILD=1 -> libvaeseg_det.so; the package loads it for env VS_DETERMINISTIC=1 / ops.set_deterministic) -----
+// fp64 atomics add in arrival order, so two runs of the same step differ in the last bits of every statistic (and a ReLU mask can flip on
+// that).  In the deterministic build the SAME buffer, double[4][pairs][2], holds — instead of four partial fp64 copies — four signed 64-bit
+// fixed-point LIMBS of one exact sum: a workgroup's partial `tot` is split exactly into 40-bit pieces of weight 2^40, 2^0, 2^-40, 2^-80
+// (a 53-bit double spans at most three of them; what lies below 2^-80 is dropped, what lies above 2^80 does not occur) and each piece is
+// added with an INTEGER atomic, which commutes: the limbs, hence every statistic, are independent of the arrival order.  23 bits of
+// headroom per limb = 8 M partials.  Consumers combine the limbs in a fixed order.
+// A compile-time switch, not a run-time flag: as a kernel parameter the untaken limb code cost the default mode 1 % of the 96^3 step
+// (2.675 -> 2.702 ms, same box), and 5 % with the limb code kept out of line (2.69 -> 2.82); the throughput library is byte-for-byte free of it.
+#ifndef VS_DET_BUILD
+#define VS_DET_BUILD 0
+#endif
+static_assert(VS_STAT_SLOTS == 4, "deterministic statistics use the four slots as four fixed-point limbs");
+
 __device__ __forceinline__ void stat_load(const double* __restrict__ st, size_t pair, size_t pairs, double (&out)[2]) {
+#if VS_DET_BUILD
+    long long a[4], b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a[s] = __double_as_longlong(st[stat_index(pair, pairs, s)]);
+        b[s] = __double_as_longlong(st[stat_index(pair, pairs, s) + 1]);
+    }
+    out[0] = ((double)a[0] * 0x1p40 + (double)a[1]) + ((double)a[2] * 0x1p-40 + (double)a[3] * 0x1p-80);
+    out[1] = ((double)b[0] * 0x1p40 + (double)b[1]) + ((double)b[2] * 0x1p-40 + (double)b[3] * 0x1p-80);
+#else
     double a = 0.0, b = 0.0;
 #pragma unroll
     for (int s = 0; s < VS_STAT_SLOTS; ++s) {
@@ -153,10 +178,23 @@ __device__ __forceinline__ void stat_load(const double* __restrict__ st, size_t 
         b += st[stat_index(pair, pairs, s) + 1];
     }
     out[0] = a; out[1] = b;
+#endif
 }
-// where this workgroup accumulates statistic `which` (0 / 1) of `pair`
-__device__ __forceinline__ double* stat_ptr(double* st, size_t pair, size_t pairs, int which) {
-    return st + stat_index(pair, pairs, (int)(blockIdx.x & (VS_STAT_SLOTS - 1))) + which;
+// this workgroup's contribution `tot` to statistic `which` (0 / 1) of `pair`: one fp64 atomic into copy (blockIdx.x mod 4), or —
+// deterministic build — four integer atomics into the four limbs
+__device__ __forceinline__ void stat_add(double* st, size_t pair, size_t pairs, int which, double tot) {
+#if VS_DET_BUILD
+    double r = tot;
+    const double up[4] = {0x1p-40, 1.0, 0x1p40, 0x1p80}, down[4] = {0x1p40, 1.0, 0x1p-40, 0x1p-80};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double q = trunc(r * up[s]);               // exact: a power-of-two scale; |q| < 2^40 while |tot| < 2^80
+        r -= q * down[s];                                // exact: removes the leading bits of r
+        atomicAdd((unsigned long long*)(st + stat_index(pair, pairs, s) + which), (unsigned long long)(long long)q);
+    }
+#else
+    atomicAdd(st + stat_index(pair, pairs, (int)(blockIdx.x & (VS_STAT_SLOTS - 1))) + which, tot);
+#endif
 }
 
 // mean / rstd of one (n,c) from the fp64 (sum, sumsq) pair a producer accumulated

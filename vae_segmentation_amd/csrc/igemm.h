@@ -46,6 +46,10 @@ struct G1Params {
     const void* fa_x;
     const double* fa_sums;
     void* fa_dx;
+    // composed Up block (igemm_k4.h): tap lists per row block (forward) / per chunk (backward-data), bias table [27][Co], output channels of the 3x3x3 conv
+    const void* up_taps;
+    const float* up_btab;
+    int up_co;
 };
 
 // LDS carve (bytes)
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                            (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
                 }
             }
-            if (ch_out >= 0) atomicAdd(stat_ptr(red_dst, (size_t)n * p.M + ch_out, (size_t)p.N * p.M, st), tot);
+            if (ch_out >= 0) stat_add(red_dst, (size_t)n * p.M + ch_out, (size_t)p.N * p.M, st, tot);
         }
     }
 }

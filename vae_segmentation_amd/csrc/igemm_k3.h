@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                         if (row < p.M) {
                             const double tot = (double)s_red[(0 * 64 + lr) * 2 + st] + (double)s_red[(1 * 64 + lr) * 2 + st] +
                                                (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
-                            atomicAdd(stat_ptr(red_dst, (size_t)n * p.M + row, (size_t)p.N * p.M, st), tot);
+                            stat_add(red_dst, (size_t)n * p.M + row, (size_t)p.N * p.M, st, tot);
                         }
                     }
                     __syncthreads();                     // s_red is reused by a later flush

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             if (row < p.M) {
                 const double tot = (double)s_red[(0 * 16 + lr) * 2 + st] + (double)s_red[(1 * 16 + lr) * 2 + st] +
                                    (double)s_red[(2 * 16 + lr) * 2 + st] + (double)s_red[(3 * 16 + lr) * 2 + st];
-                atomicAdd(stat_ptr(red_dst, (size_t)n * p.M + row, (size_t)p.N * p.M, st), tot);
+                stat_add(red_dst, (size_t)n * p.M + row, (size_t)p.N * p.M, st, tot);
             }
         }
     }

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         if (ch < p.M) {
                             const double tot = (double)s_red[(0 * 8 + ch) * 2 + st] + (double)s_red[(1 * 8 + ch) * 2 + st] +
                                                (double)s_red[(2 * 8 + ch) * 2 + st] + (double)s_red[(3 * 8 + ch) * 2 + st];
-                            atomicAdd(stat_ptr(red_dst, (size_t)n * 8 + ch, (size_t)p.N * 8, st), tot);
+                            stat_add(red_dst, (size_t)n * 8 + ch, (size_t)p.N * 8, st, tot);
                         }
                     }
                     // s_red is rewritten only after the two barriers at the top of the next tile

@@ -2,6 +2,9 @@
 // Dice / BCE losses, multi-tensor SGD / Adam / EMA.
 #include "common.h"
 
+// ---- deterministic build (common.h): a property of the library, queried by the package ----------------------------------------------
+extern "C" int vs_get_deterministic(void) { return VS_DET_BUILD; }
+
 extern "C" int vs_version(void) { return VS_VERSION; }
 extern "C" int vs_stat_slots(void) { return VS_STAT_SLOTS; }
 extern "C" int vs_stat_interleaved(void) { return VS_STAT_INTERLEAVE; }
@@ -500,6 +503,7 @@ extern "C" int vs_dice_fwd(const float* s, const float* t, double* sums, float* 
     long long blocks = (voxels / 4 + 256 * 8 - 1) / (256 * 8);
     if (blocks < 1) blocks = 1;
     if (blocks > 1024) blocks = 1024;
+    if (VS_DET_BUILD) blocks = 1;                      // deterministic mode: one block per (b, c) plane, so one fp64 atomic onto a zeroed word
     hipLaunchKernelGGL(dice_sums_kernel, dim3((unsigned)blocks, top - bot, batch), dim3(256), 0, (hipStream_t)stream, s, t, sums, channels, voxels, bot);
     VS_CHECK_LAUNCH();
     hipLaunchKernelGGL(dice_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, per_sample, mean_out, batch, channels, bot, top, eps);
@@ -795,6 +799,7 @@ extern "C" int vs_bce_fwd(const float* p, const float* t, float* out, double* sc
     if (e != hipSuccess) return (int)e;
     long long blocks = (count + 256 * 16 - 1) / (256 * 16);
     if (blocks > 1024) blocks = 1024;
+    if (VS_DET_BUILD) blocks = 1;                      // deterministic mode: a single block, a single atomic
     hipLaunchKernelGGL(bce_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, t, scratch, count);
     VS_CHECK_LAUNCH();
     hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scratch, out, count);

@@ -47,7 +47,7 @@ __device__ __forceinline__ void reduce_and_atomic(const RowIter<T>& it, double (
         double tot = 0.0;
         for (int fy = 0; fy < it.rows_per_it; ++fy) tot += s_red[(fy * it.frags + fx) * (EPL * NS) + j * NS + s];
         static_assert(NS == 2, "statistics come in pairs");
-        atomicAdd(stat_ptr(out, (size_t)n * c + ch, (size_t)gridDim.y * c, s), tot);
+        stat_add(out, (size_t)n * c + ch, (size_t)gridDim.y * c, s, tot);
     }
 }
 
@@ -430,7 +430,7 @@ extern "C" int vs_bias_grad_acc(const void* g, float* db, long long rows, int c_
         hipError_t e = vs_zero_async(db, sizeof(float) * c_real, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid(row_blocks(rows, c_ch, dtype));
+    dim3 grid(VS_DET_BUILD ? 1 : row_blocks(rows, c_ch, dtype));     // deterministic mode: one block, one fp32 atomic per channel
     dispatch_t(dtype, [&](auto* tag) {
         using T = TAG_T(tag);
         hipLaunchKernelGGL(bias_grad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)g, db, rows, c_ch, c_real);

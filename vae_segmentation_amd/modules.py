@@ -106,13 +106,20 @@ class DoubleConv(nn.Module):
         self.out_ch = out_ch
         self.kernel_dtype = _DEFAULT_DTYPE
 
-    def forward(self, x):
+    def forward(self, x, _start=0):
+        """_start = 3: x is already the (lazy) output of the first conv triple — Up ran it composed with its transposed conv (ops.UpConvK3)"""
         a, wrapped = _as_act(x, self.kernel_dtype)
         for i in (0, 3, 6):
+            if i < _start:
+                continue
             a = _conv_norm_act(self.conv, i, a)
             if i < 6 and a.stats is not None:
                 ops.mark_defer_apply(a.raw, self.conv[i])      # consumed once, by the next 3x3x3 conv: its IN-backward apply can be fused (ops._LAZY_APPLY)
         return _as_tensor(a, self.out_ch) if wrapped else a
+
+    def lazy_head(self):
+        """InstanceNorm + ReLU after the first conv (the fused configuration)?"""
+        return isinstance(self.conv[1], nn.InstanceNorm3d) and isinstance(self.conv[2], nn.ReLU)
 
 
 class Conv(nn.Module):
@@ -145,8 +152,13 @@ class Up(nn.Module):
 
     def forward(self, x):
         a, wrapped = _as_act(x, self.kernel_dtype)
-        t = self.conv[0]
-        a = self.conv[1](Act(ops.ConvT2S2.apply(a.raw, a.stats, t.weight, t.bias), None))
+        t, dc = self.conv[0], self.conv[1]
+        if dc.lazy_head() and ops.up_composed_ok(a.raw, t, dc.conv[0]):
+            # transposed conv + first 3x3x3 conv as one operator on the coarse grid: no intermediate tensor, one launch each way
+            y, ys = ops.UpConvK3.apply(a.raw, a.stats, t.weight, t.bias, dc.conv[0].weight)
+            a = dc(Act(y, ys), _start=3)
+        else:
+            a = dc(Act(ops.ConvT2S2.apply(a.raw, a.stats, t.weight, t.bias), None))
         return _as_tensor(a, self.out_ch) if wrapped else a
 
 

@@ -296,6 +296,10 @@ def refresh_frozen_packs(module):
     pointers — optim.ema_update, load_state_dict on a network a captured graph replays): graph replays that follow read the
     new weights without an eager forward in between."""
     for prm in module.parameters():
+        for dt, plan in (getattr(prm, "_vs_up_plan", None) or {}).items():       # composed Up images cached on the 3x3x3 weight (up_plan)
+            wt, bt = plan["src"]
+            with torch.no_grad():
+                _up_compose_into(plan, wt.detach(), None if bt is None else bt.detach(), prm.detach(), dt)
         cache = getattr(prm, "_vs_pack_cache", None)
         if not cache:
             continue
@@ -439,11 +443,28 @@ def _new_stats(n, c, device, width=2):
     return out
 
 
+def set_deterministic(on=True):
+    """Switch the package to the deterministic build of the library (libvaeseg_det.so, include/vaeseg.h vs_get_deterministic): every
+    per-(n,c) statistic is accumulated with commuting integer atomics, so two runs on the same inputs agree bit for bit.  Parity runs use it
+    (tests/conftest.py, env VS_DETERMINISTIC=1); the throughput default is the fp64-atomic build.  A statistics buffer must be produced and
+    consumed by one build: switch between passes only (captured HIP graphs keep the kernels of the build they were captured under)."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    lib.use_deterministic(bool(on))
+
+
+def is_deterministic():
+    return bool(lib.vs_get_deterministic()) if hasattr(lib, "vs_get_deterministic") else False
+
+
 def stats_total(stats):
-    """(n, c, 2) totals of a statistics buffer (sum over its partial copies) — for tests / inspection"""
+    """(n, c, 2) totals of a statistics buffer (sum over its partial copies / its fixed-point limbs) — for tests / inspection"""
     if lib.vs_stat_interleaved():
         s, n, c, w = stats.shape
-        return stats.reshape(n, c, s, w).sum(2)
+        stats = stats.reshape(n, c, s, w).permute(2, 0, 1, 3)
+    if is_deterministic():
+        limbs = stats.contiguous().view(torch.int64).double()
+        return (limbs[0] * 2.0 ** 40 + limbs[1]) + (limbs[2] * 2.0 ** -40 + limbs[3] * 2.0 ** -80)
     return stats.sum(0)
 
 
@@ -1147,6 +1168,121 @@ class ConvT2S2(torch.autograd.Function):
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gy, cout)
         return gx, None, gw, gb
+
+
+# ------------------------------------------------------------------------------------------------
+# composed Up block head: ConvTranspose3d(C, C, 2, stride 2) -> Conv3d(C, Co, 3, padding 1) as one operator (csrc/igemm_k4.h)
+# ------------------------------------------------------------------------------------------------
+FUSE_UP = os.environ.get("VS_FUSE_UP", "1") != "0"
+# composed where it is measured faster than the two-launch pair: the large levels, where the intermediate tensor is HBM traffic (96^3 step, same
+# box: coarse 48^3 x 16 forward 34 us against 27.6 + 19.7, backward-data 29 against 34 + 12.4).  On the small coarse grids (<= 24^3) the
+# 4x4x16-tile kernels of igemm_k4.h are latency-bound by their many short chunk stages (backward: 8 Co / 32 chunks of 8 taps) and lose.
+FUSE_UP_MIN_VOXELS = int(os.environ.get("VS_FUSE_UP_MIN_VOXELS", str(40 ** 3)))
+
+
+def _up_stamp(wt, bt, w3):
+    return (wt._version, wt.data_ptr(), w3._version, w3.data_ptr(), None if bt is None else (bt._version, bt.data_ptr()), _PACK_EPOCH[0])
+
+
+def _up_compose_into(plan, wt, bt, w3, dtype):
+    cin, cm, co = wt.shape[0], wt.shape[1], w3.shape[0]
+    check(lib.vs_up_compose(wt.data_ptr(), _p(bt), w3.data_ptr(), plan["weff"].data_ptr(), plan["img_f"].data_ptr(), plan["img_b"].data_ptr(),
+                            plan["taps_f"].data_ptr(), plan["taps_b"].data_ptr(), plan["btab"].data_ptr(), cin, cm, co, vs_of(dtype), _stream()), "up_compose")
+    plan["stamp"] = _up_stamp(wt, bt, w3)
+
+
+def up_plan(wt, bt, w3, dtype):
+    """The composed images of an Up block's first two layers (FROZEN weights: packed once, cached on the 3x3x3 weight tensor at stable
+    addresses — a captured HIP graph holds the pointers — and re-composed IN PLACE when any of the three tensors changed:
+    refresh_frozen_packs / clear_pack_cache, as for the packed conv weights)."""
+    plans = getattr(w3, "_vs_up_plan", None)
+    if plans is None:
+        plans = {}
+        w3._vs_up_plan = plans
+    plan = plans.get(dtype)
+    if plan is None:
+        cin, cm, co = wt.shape[0], wt.shape[1], w3.shape[0]
+        sz = (_ct.c_size_t * 6)()
+        check(lib.vs_up_compose_sizes(cin, cm, co, _ct.addressof(sz)), "up_compose_sizes")
+        dev = w3.device
+        buf = lambda nbytes: torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        plan = {"weff": buf(sz[0]), "img_f": buf(sz[1]), "img_b": buf(sz[2]), "taps_f": buf(sz[3]), "taps_b": buf(sz[4]), "btab": buf(sz[5]),
+                "stamp": None, "src": (wt, bt)}
+        plans[dtype] = plan
+    if plan["stamp"] != _up_stamp(wt, bt, w3):
+        with torch.no_grad():
+            _up_compose_into(plan, wt.detach(), None if bt is None else bt.detach(), w3.detach(), dtype)
+    return plan
+
+
+def up_composed_ok(x, tconv, conv3):
+    """Can this Up block head run as the composed operator?  16-bit storage, frozen weights (the trainable form needs the parameter-space
+    chain rule: handled by the unfused pair), channel pairs the kernels are instantiated for (vs_up_supported)."""
+    wt, w3 = tconv.weight, conv3.weight
+    if not FUSE_UP or x.dtype == torch.float32 or wt.requires_grad or w3.requires_grad or (tconv.bias is not None and tconv.bias.requires_grad):
+        return False
+    if tuple(wt.shape[2:]) != (2, 2, 2) or tuple(w3.shape[2:]) != (3, 3, 3) or w3.shape[1] != wt.shape[1] or x.shape[-1] != wt.shape[0]:
+        return False
+    if x.shape[1] * x.shape[2] * x.shape[3] < FUSE_UP_MIN_VOXELS:
+        return False
+    return bool(lib.vs_up_supported(wt.shape[0], wt.shape[1], w3.shape[0], vs_dtype(x)))
+
+
+class UpConvK3(torch.autograd.Function):
+    """relu(instnorm(x)) [lazy] -> ConvTranspose3d(C, C, 2, 2) + bias -> Conv3d(C, Co, 3, pad 1) as ONE launch on the coarse grid
+    (joint_model.py:116-120 + 40); output lazy (raw + statistics) on the fine grid.  No intermediate tensor, 3.4x fewer multiply-adds."""
+
+    @staticmethod
+    def forward(ctx, x, xs, wt, bt, w3):
+        _require_cuda(x, wt, w3)
+        n, d, h, w, c = x.shape
+        co = w3.shape[0]
+        plan = up_plan(wt, bt, w3, x.dtype)
+        y = torch.empty((n, 2 * d, 2 * h, 2 * w, co), dtype=x.dtype, device=x.device)
+        ys = _new_stats(n, co, x.device)
+        kid = nb = fl = None
+        if PROFILE is not None:
+            kid = "k4t_kernel<%d,%s>" % (min(c, 32), _tname(x))
+            nb = (x.numel() + y.numel()) * _esize(x) + 64 * co * c * _esize(x)
+            fl = 2.0 * (x.numel() // c) * 64 * co * c
+        with _timed(kid, nb, fl, "up x%s->m%d" % (tuple(x.shape), co)):
+            check(lib.vs_up_conv_fwd(x.data_ptr(), _p(xs), plan["img_f"].data_ptr(), plan["taps_f"].data_ptr(), plan["btab"].data_ptr(), y.data_ptr(),
+                                     ys.data_ptr(), n, d, h, w, c, co, vs_dtype(x), EPS_IN, _stream()), "up_conv_fwd")
+        ctx.save_for_backward(x, xs)
+        ctx.plan = plan
+        ctx.co = co
+        ctx.defer = bool(getattr(x, "_vs_defer_apply", False)) and xs is not None
+        ctx.mark_non_differentiable(ys)
+        ctx.set_materialize_grads(False)
+        return y, ys
+
+    @staticmethod
+    def backward(ctx, gy, _gys):
+        x, xs = ctx.saved_tensors
+        if gy is None or not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        gy = _contig(gy)
+        lazy = _take_lazy(gy)
+        if lazy is not None:
+            gy = apply_lazy(gy, lazy)
+        n, d, h, w, c = x.shape
+        gx = torch.empty_like(x)
+        sums = _new_stats(n, c, x.device) if xs is not None else None
+        plan = ctx.plan
+        kid = nb = fl = None
+        if PROFILE is not None:
+            kid = "k4g_kernel<%s>" % _tname(x)
+            nb = (gy.numel() + (2 if xs is not None else 1) * x.numel()) * _esize(x) + 64 * ctx.co * c * _esize(x)
+            fl = 2.0 * (x.numel() // c) * 64 * ctx.co * c
+        with _timed(kid, nb, fl, "up bwd gy%s->m%d" % (tuple(gy.shape), c)):
+            check(lib.vs_up_conv_bwd_data(gy.data_ptr(), plan["img_b"].data_ptr(), plan["taps_b"].data_ptr(), gx.data_ptr(), _p(x if xs is not None else None),
+                                          _p(xs), _p(sums), n, d, h, w, ctx.co, c, vs_dtype(x), EPS_IN, _stream()), "up_conv_bwd_data")
+        if xs is not None:
+            if ctx.defer:
+                _defer_register(gx, x, xs, sums)
+            else:
+                _apply_in_place(gx, x, xs, sums)
+        return gx, None, None, None, None
 
 
 class Materialize(torch.autograd.Function):
