@@ -157,3 +157,38 @@ def test_joint160_fp16_train_steps_and_memory():
     assert all(torch.isfinite(p).all() for p in params)
     assert any(not torch.equal(p.detach().cpu(), q.detach()) for p, q in zip(params[:4], list(O.deterministic_fill_(M.Segmentation(1, 2, norm_type=1), seed=0).parameters())[:4]))
     assert peak < 40.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_activation_recomputation_gives_identical_gradients_and_saves_memory(dtype):
+    """BASELINE configs[4] names activation checkpointing: modules.set_recompute re-runs every Down / Up block in backward instead of keeping
+    its interior activations.  In the deterministic build (the test session's) the recomputed statistics are bit-identical to the first pass,
+    so the gradients must be too; the peak memory of the pass must drop."""
+    M, O, T, optim = _mods()
+    from vae_segmentation_amd import ops
+    assert ops.is_deterministic()
+    side = 64
+    img, lab = O.synthetic_image(2, side, 2).cuda(), O.synthetic_label(2, side, 3).cuda()
+    seed = torch.tensor(1024.0, device="cuda") if dtype == torch.float16 else None      # a fixed loss scale: fp16 Dice gradients are subnormal without one
+    res = {}
+    for rec in (False, True):
+        joint = _build_joint(M, O, side, dtype)
+        M.set_recompute(rec)
+        ops.set_wgrad_grouping(False)          # both arms launch the weight gradients per layer (recomputation does; the grouped launches split K differently)
+        try:
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            final, aux = T.joint_train_losses(joint, img, lab)
+            final.backward(gradient=seed)
+            torch.cuda.synchronize()
+            res[rec] = (final.detach().clone(), [p.grad.detach().clone() for p in joint.Seg.parameters()], torch.cuda.max_memory_allocated() - base)
+        finally:
+            M.set_recompute(False)
+            ops.set_wgrad_grouping(True)
+        del joint, final, aux
+    assert torch.equal(res[False][0], res[True][0])
+    for a, b in zip(res[False][1], res[True][1]):
+        assert torch.equal(a, b)
+    print("\npeak memory of one %s joint_train pass at %d^3, batch 2: %.0f MB kept, %.0f MB with recomputation" % (dtype, side, res[False][2] / 2 ** 20, res[True][2] / 2 ** 20))
+    assert res[True][2] < 0.8 * res[False][2]

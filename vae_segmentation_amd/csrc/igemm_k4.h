@@ -37,7 +37,8 @@ struct K4Geom {
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // CK: input-channel chunk (16: Cin = 16, Co = 8, 12 taps = 6 k-groups per row block; 32: 8 taps = 8 k-groups per row block and chunk)
 // RB: 16-row blocks per workgroup.  Row blocks are numbered (p, co / 16) [Co >= 16] or (pz, py) with rows (px, co) [Co = 8].
-template <int CK, int RB, bool HS, typename T>
+// W1: single input-channel chunk (Cin <= 32) — the weight block is staged once, not per tile
+template <int CK, int RB, bool HS, typename T, bool W1 = (CK == 16)>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 && RB == 4 ? 1 : 2, 2))) void k4t_kernel(const G1Params p) {
     constexpr int TV = K4Geom::TV, PLANE = K4Geom::PLANE;
     constexpr int NT = CK == 32 ? 8 : 6;                 // k-groups per (row block, chunk)
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ssum[rb][r] = 0.f; ssq[rb][r] = 0.f; }
     bool first = true;
+    if constexpr (W1) write_w();
     __syncthreads();
 
     const int F_D = 2 * p.D, F_H = 2 * p.H, F_W = 2 * p.W;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
         for (int ch = 0; ch < p.nch; ++ch) {
             if (!first) __syncthreads();
             write_x(n, ch);
-            write_w();
+            if constexpr (!W1) write_w();
             first = false;
             __syncthreads();
             {
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
                 const int tn = last_ch ? t + G : t;
                 if (last_ch) nxt = tile_coord(tn);
                 if (tn < t_end) {
-                    load_w(last_ch ? 0 : ch + 1);
+                    if constexpr (!W1) load_w(last_ch ? 0 : ch + 1);
                     load_x(last_ch ? nxt : cur, last_ch ? 0 : ch + 1);
                 }
             }
@@ -608,7 +610,7 @@ static inline int k4_grid_x(int tiles_total, int row_tiles) {
     return tiles_total < wg ? tiles_total : wg;
 }
 
-template <typename T, int CK, int RB, bool HS>
+template <typename T, int CK, int RB, bool HS, bool W1 = (CK == 16)>
 static int k4t_launch_t(G1Params p, hipStream_t stream) {
     constexpr int NT = CK == 32 ? 8 : 6, NU = 648 * (CK * 2 / 16), NWF = RB * NT * 64;
     const size_t lds = K4_LDS_TILE + (size_t)((NU + 255) / 256) * 4096 + (size_t)((NWF + 255) / 256) * 4096 + (size_t)2 * p.N * p.C * 4 + (size_t)27 * RB * 16 * 4;
@@ -617,7 +619,7 @@ static int k4t_launch_t(G1Params p, hipStream_t stream) {
     k4_fastdiv(p.tiles_per_sample, p.fd_m[0], p.fd_s[0]);
     k4_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k4_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
-    auto kern = k4t_kernel<CK, RB, HS, T>;
+    auto kern = k4t_kernel<CK, RB, HS, T, W1>;
     static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
     hipLaunchKernelGGL(kern, dim3(k4_grid_x(p.tiles_per_sample * p.N, row_tiles), row_tiles), dim3(256), lds, stream, p);
@@ -633,6 +635,10 @@ static int k4t_launch(const G1Params& p, int rb, hipStream_t s) {
         return hs ? k4t_launch_t<T, 16, 4, true>(p, s) : k4t_launch_t<T, 16, 4, false>(p, s);
     }
     if (p.C % 32 || p.up_co % 16) return VS_ESHAPE;
+    if (p.nch == 1) {
+        if (rb == 4) return hs ? k4t_launch_t<T, 32, 4, true, true>(p, s) : k4t_launch_t<T, 32, 4, false, true>(p, s);
+        return hs ? k4t_launch_t<T, 32, 2, true, true>(p, s) : k4t_launch_t<T, 32, 2, false, true>(p, s);
+    }
     if (rb == 4) return hs ? k4t_launch_t<T, 32, 4, true>(p, s) : k4t_launch_t<T, 32, 4, false>(p, s);
     return hs ? k4t_launch_t<T, 32, 2, true>(p, s) : k4t_launch_t<T, 32, 2, false>(p, s);
 }

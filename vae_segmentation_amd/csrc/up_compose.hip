@@ -235,8 +235,9 @@ extern "C" int vs_up_conv_fwd(const void* x, const double* x_stats, const void* 
     p.inv_count_in = 1.0 / ((double)d * h * w);
     p.inv_count_out = 1.0 / (8.0 * d * h * w);
     // 4 row blocks per workgroup (the staged tile is shared by them); 2 where that leaves too few workgroups
+    static const int rb_env = getenv("VS_UP_RB") ? atoi(getenv("VS_UP_RB")) : 0;      // tuning knob
     int rb = 4;
-    if (cin >= 32 && (long long)p.tiles_per_sample * n * (p.rb_total / 4) < 128) rb = 2;
+    if (cin >= 32) rb = rb_env ? rb_env : 2;
     if (dtype == VS_BF16) return k4t_launch<unsigned short>(p, rb, (hipStream_t)stream);
     return k4t_launch<vs_half>(p, rb, (hipStream_t)stream);
 }

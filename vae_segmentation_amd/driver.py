@@ -302,6 +302,8 @@ def run(args, side="source"):
         freeze(teacher)
         set_kernel_dtype(teacher, dtype)
     set_kernel_dtype(model, dtype)
+    from . import modules as _modules
+    _modules.set_recompute(bool(getattr(args, "recompute", False)))
 
     if hasattr(model, "Seg") and hasattr(model, "Vae"):
         groups = [{"params": list(model.Seg.parameters()), "lr": args.lr_seg, "model": "Seg"},
@@ -490,5 +492,7 @@ def add_native_flags(parser):
     g.add_argument("--max_iters", type=int, default=0, help="stop each epoch after this many steps (0 = whole loader)")
     g.add_argument("--display_freq", type=int, default=10)
     g.add_argument("--no_graph", action="store_true", help="eager launches instead of the HIP-graph replayed step")
+    g.add_argument("--recompute", action="store_true", help="activation recomputation (checkpointing) of the Down / Up blocks: interior activations are "
+                   "re-computed in backward instead of kept (BASELINE configs[4]); trades bandwidth for memory")
     g.add_argument("--train_first_epoch", action="store_true", help="domain_adaptation: also train in epoch 0 (the reference only "
                    "validates there, main_target.py:506)")

@@ -181,6 +181,43 @@ class Down(nn.Module):
         return _as_tensor(a, self.out_ch) if wrapped else a
 
 
+_RECOMPUTE = [False]
+
+
+def set_recompute(enabled=True):
+    """Activation recomputation ("checkpointing", BASELINE configs[4]) for the Down / Up blocks of Segmentation and VAE: a block keeps only
+    its input (raw tensor + statistics) through the forward pass and re-runs its kernels when backward reaches it.  Off by default — 160^3,
+    batch 2, fp16 peaks at 3.5 GB of the 288 GB, and the step is bound by the bandwidth recomputation spends — but the switch exists
+    (entry points: --recompute) for volumes that need the memory.  In the deterministic build the recomputed statistics are bit-identical
+    to the first pass, so are the gradients (tests/test_gpu_fp16.py).  Costs launches as well as bandwidth: the weight gradients leave the
+    grouped end-of-pass launches (they would pin every operand until the end)."""
+    _RECOMPUTE[0] = bool(enabled)
+    # the grouped weight gradients are deferred to the end of backward and keep every layer's operands alive until then — exactly the memory
+    # recomputation is meant to free: in this mode each layer's weight gradient is launched where its backward runs
+    ops.set_wgrad_grouping(not enabled)
+
+
+def _run_block(blk, a):
+    """blk(a) for a Down / Up block on a lazy activation; under set_recompute the block's interior activations are not kept."""
+    if not (_RECOMPUTE[0] and torch.is_grad_enabled() and a.raw.requires_grad):
+        return blk(a)
+    from torch.utils.checkpoint import checkpoint
+
+    def run(raw, stats):
+        out = blk(Act(raw, stats))
+        return out.raw, out.stats
+
+    marks = getattr(a.raw, "_vs_defer_apply", False)
+
+    def run_marked(raw, stats):
+        if marks:
+            raw._vs_defer_apply = True
+        return run(raw, stats)
+
+    raw, stats = checkpoint(run_marked, a.raw, a.stats, use_reentrant=False, preserve_rng_state=False)
+    return Act(raw, stats)
+
+
 def _dropout(a, p):
     """F.dropout(x, p, training=True) after an Up block (joint_model.py:256-264,379-385): the lazy activation is
     materialised, masked and scaled; p == 0 (the reference default, main_target.py:70-71) costs nothing."""
@@ -237,7 +274,7 @@ class VAE(nn.Module):
             if a.stats is not None:
                 ops.mark_defer_apply(a.raw, self.in_block.conv[0])              # in_block's output feeds down1's strided conv only
             for blk in (self.down1, self.down2, self.down3, self.down4, self.down5):
-                a = blk(a)
+                a = _run_block(blk, a)
                 if blk is not self.down5 and a.stats is not None:
                     ops.mark_defer_apply(a.raw, blk.conv[1].conv[6])            # a Down block's last conv feeds the next block's strided conv only (no skips in the VAE)
             feat = ops.Materialize.apply(a.raw, a.stats, None, None)
@@ -255,7 +292,7 @@ class VAE(nn.Module):
         h = ops.LinearToCL.apply(z, self.fc2.weight, self.fc2.bias, self.top_ch, self.side, self.kernel_dtype)
         a = Act(h, None)
         for blk in (self.up1, self.up2, self.up3, self.up4, self.up5):
-            a = _dropout(blk(a), dropout)
+            a = _dropout(_run_block(blk, a), dropout)
             if a.stats is not None:
                 ops.mark_defer_apply(a.raw, blk.conv[1].conv[6])             # an Up block's last conv feeds the next block's transposed conv / out_block only
         recon = ops.ConvK3Softmax.apply(a.raw, a.stats, self.out_block.weight, self.out_block.bias)
@@ -294,18 +331,18 @@ class Segmentation(nn.Module):
         ops.stats_arena_begin(x.device)
         a = Act(ops.PackPlanar.apply(x, self.kernel_dtype), None)
         x1 = self.in_block(a)
-        x2 = self.down1(x1)
-        x3 = self.down2(x2)
-        x4 = self.down3(x3)
-        x5 = self.down4(x4)
-        u = _dropout(self.up2(x5), dropout)
-        u = self.up3(u)
+        x2 = _run_block(self.down1, x1)
+        x3 = _run_block(self.down2, x2)
+        x4 = _run_block(self.down3, x3)
+        x5 = _run_block(self.down4, x4)
+        u = _dropout(_run_block(self.up2, x5), dropout)
+        u = _run_block(self.up3, u)
         # skips (joint_model.py:380,382).  x3 / x2 also feed down3 / down2's strided conv: their skip gradient is parked for that conv's
         # backward to sum in (ops._park_gradient) instead of an add launch of autograd's
         u = _dropout(Act(ops.Materialize.apply(u.raw, u.stats, x3.raw, x3.stats, True), None), dropout)
-        u = self.up4(u)
+        u = _run_block(self.up4, u)
         u = _dropout(Act(ops.Materialize.apply(u.raw, u.stats, x2.raw, x2.stats, True), None), dropout)
-        u = _dropout(self.up5(u), dropout)
+        u = _dropout(_run_block(self.up5, u), dropout)
         if u.stats is not None:
             ops.mark_defer_apply(u.raw, self.up5.conv[1].conv[6])           # up5's last conv feeds out_block only
         if dropout:     # the reference also drops the two logits before the softmax (joint_model.py:386-388): fused epilogue

@@ -1176,8 +1176,10 @@ class ConvT2S2(torch.autograd.Function):
 FUSE_UP = os.environ.get("VS_FUSE_UP", "1") != "0"
 # composed where it is measured faster than the two-launch pair: the large levels, where the intermediate tensor is HBM traffic (96^3 step, same
 # box: coarse 48^3 x 16 forward 34 us against 27.6 + 19.7, backward-data 29 against 34 + 12.4).  On the small coarse grids (<= 24^3) the
-# 4x4x16-tile kernels of igemm_k4.h are latency-bound by their many short chunk stages (backward: 8 Co / 32 chunks of 8 taps) and lose.
-FUSE_UP_MIN_VOXELS = int(os.environ.get("VS_FUSE_UP_MIN_VOXELS", str(40 ** 3)))
+# 4x4x16-tile kernels of igemm_k4.h are latency-bound by their many short chunk stages (backward: 8 Co / 32 chunks of 8 taps) and lose or tie
+# (isolated, forward / backward-data against the pair: 24^3 x 32: 26.8 / 17.8 us vs 32 / 19; 12^3 x 64: 16.5 / 19.1 vs 24 / 19; in the replayed
+# step the pair is faster than in isolation and the composed form measured +0.05 ms when enabled at every level).
+FUSE_UP_MIN_VOXELS = int(os.environ.get("VS_FUSE_UP_MIN_VOXELS", str(44 ** 3)))
 
 
 def _up_stamp(wt, bt, w3):
