@@ -41,7 +41,9 @@ enum { VS_OK = 0, VS_EINVAL = -1, VS_ESHAPE = -2, VS_EDTYPE = -3, VS_EWORKSPACE 
 enum {
     VS_CONV_K3 = 0,     /* 3x3x3, stride 1, pad 1          nn.Conv3d(...,3,padding=1)        joint_model.py:40,43,46,106,224,366 */
     VS_CONV_K2S2 = 1,   /* 2x2x2, stride 2, pad 0          nn.Conv3d(C,C,2,stride=2)         joint_model.py:130 */
-    VS_CONV_T2S2 = 2    /* 2x2x2 transposed, stride 2      nn.ConvTranspose3d(C,C,2,stride=2) joint_model.py:118 */
+    VS_CONV_T2S2 = 2,   /* 2x2x2 transposed, stride 2      nn.ConvTranspose3d(C,C,2,stride=2) joint_model.py:118 */
+    VS_CONV_UP = 3      /* vs_wgrad_desc only: the composed Up block (vs_up_*): p = the FINE output gradient (n,2dp,2hp,2wp,Co) read space-to-depth
+                           (m_ch = m_real = 8 Co view channels (parity, co); reserved_ = Co), q = the coarse input, dw = dWeff [8 Co][c_real][27] */
 };
 
 /* how a weight tensor src[d0][d1][ntaps] (fp32, the reference's parameter layout) is packed into MFMA
@@ -75,6 +77,15 @@ int vs_up_compose(const float* w2, const float* b2, const float* w3, float* weff
 /* x: coarse (n,d,h,w,cin) [lazy with x_stats]; y: fine raw conv output (n,2d,2h,2w,co) + its statistics */
 int vs_up_conv_fwd(const void* x, const double* x_stats, const void* img_fwd, const int* taps_fwd, const float* btab, void* y, double* y_stats,
                    int n, int d, int h, int w, int cin, int co, int dtype, float eps, void* stream);
+/* Weight gradients of the composed block: vs_conv_wgrad_multi with a VS_CONV_UP descriptor gives dWeff27[(parity, co)][ci][27 coarse offsets];
+ * vs_up_faces sums the output gradient over the 26 boundary classes of the fine volume (the transposed conv's bias acts only through the zero
+ * padding of the 3x3x3 conv: its gradient is a boundary quantity, and the sum over the whole volume of an InstanceNorm-backward output is 0)
+ * into G, a statistics-format buffer double[VS_STAT_SLOTS][27 co / 2][2] (ACCUMULATED: caller zeroes; entry cls * co + c = statistic (e & 1) of
+ * pair e >> 1; a second use of the weights in the same pass simply adds); vs_up_chain applies the parameter-space chain rule:
+ * dw3 [co][cm][27], dw2 [cin][cm][8], db2 [cm] (any of them nullable). */
+int vs_up_faces(const void* gy, double* G, int n, int fd, int fh, int fw, int co, int dtype, void* stream);
+int vs_up_chain(const float* dweff27, const double* G, const float* w2, const float* b2, const float* w3, float* dw2, float* db2, float* dw3,
+                int cin, int cm, int co, void* stream);
 /* gy: gradient of y (fine, applied); gx: gradient of the coarse input (n,d,h,w,cin); mask_* / sums: fused InstanceNorm-backward sums of a lazy input (all or none) */
 int vs_up_conv_bwd_data(const void* gy, const void* img_bwd, const int* taps_bwd, void* gx, const void* mask_x, const double* mask_stats,
                         double* sums, int n, int d, int h, int w, int co, int cin, int dtype, float eps, void* stream);
@@ -182,7 +193,7 @@ typedef struct vs_wgrad_desc {
     long long bias_rows;
     int bias_c_ch, bias_c_real;
     int n, dp, hp, wp, m_ch, c_ch, m_real, c_real, kind;
-    int reserved_;
+    int reserved_;      /* VS_CONV_UP: Co, the channels of the fine tensor p points to; 0 otherwise */
 } vs_wgrad_desc;
 size_t vs_conv_wgrad_multi_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype);
 int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,

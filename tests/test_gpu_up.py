@@ -70,6 +70,51 @@ def test_up_composed_vs_cpu_autograd(case, dtype, lazy):
     assert not bad, bad
 
 
+TRAIN_CASES = [(2, 16, 8, 48, 48, 48), (1, 16, 8, 5, 6, 19), (2, 32, 16, 12, 12, 12), (1, 64, 32, 4, 6, 5), (2, 16, 8, 1, 2, 1), (1, 128, 64, 3, 3, 3)]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", TRAIN_CASES)
+def test_up_composed_weight_gradients_vs_cpu_autograd(case, dtype):
+    """Trainable weights: dWeff from the VS_CONV_UP weight-gradient launch + the boundary sums (vs_up_faces) through the parameter-space chain
+    rule (vs_up_chain) against autograd's gradients of ConvTranspose3d.weight / .bias and Conv3d.weight."""
+    ops = _ops()
+    n, c, co, d, h, w = case
+    x = rnd(n, c, d, h, w, seed=41)
+    w2 = rnd(c, c, 2, 2, 2, seed=42, scale=(3.0 / c) ** 0.5)
+    b2 = rnd(c, seed=43, scale=0.3)
+    w3 = rnd(co, c, 3, 3, 3, seed=44, scale=(3.0 / (27 * c)) ** 0.5)
+    # an upstream gradient with zero mean per (n, channel), as the InstanceNorm backward that always follows produces (the bias gradient uses it)
+    gy = rnd(n, co, 2 * d, 2 * h, 2 * w, seed=45)
+    gy = q(gy, dtype)
+    gy = gy - gy.mean((2, 3, 4), keepdim=True)
+    xq = q(x, dtype).requires_grad_(True)
+    w2q, w3q, b2q = q(w2, dtype).requires_grad_(True), q(w3, dtype).requires_grad_(True), b2.clone().requires_grad_(True)
+    y_ref = F.conv3d(F.conv_transpose3d(in_relu(xq), w2q, b2q, stride=2), w3q, None, padding=1)
+    gq = q(gy, dtype)                     # what the kernel reads; its channel sums are zero only up to the rounding (the reference sees the same values)
+    (y_ref * gq).sum().backward()
+
+    x_cl = to_cl(x, c, dtype).requires_grad_(True)
+    xs = ops.instnorm_stats(x_cl.detach())
+    wt, bt, wc = w2q.detach().cuda().requires_grad_(True), b2.cuda().requires_grad_(True), w3q.detach().cuda().requires_grad_(True)
+    ops.stats_arena_begin(x_cl.device)
+    y, ys = ops.UpConvK3.apply(x_cl, xs, wt, bt, wc)
+    y.backward(to_cl(gy, co, dtype))
+    torch.cuda.synchronize()
+    tol = TOL[dtype]
+    # the kernel takes the volume sum of gy as exactly zero (what an InstanceNorm backward gives); the reference's db2 / dW3 carry the rounding
+    # residue of gq's channel sums times the weights: compare against the reference minus that residue
+    resid = gq.sum((0, 2, 3, 4))                                     # [co]
+    gb_ref = b2q.grad - (w3q.detach().sum((2, 3, 4)) * resid[:, None]).sum(0)
+    gw3_ref = w3q.grad - resid[:, None, None, None, None] * b2.view(1, -1, 1, 1, 1)
+    errs = {"gx": relerr(from_cl(x_cl.grad, c), xq.grad), "gw2": relerr(wt.grad.cpu(), w2q.grad), "gb2": relerr(bt.grad.cpu(), gb_ref),
+            "gw3": relerr(wc.grad.cpu(), gw3_ref)}
+    lims = {"gx": 4 * tol, "gw2": 4 * tol, "gb2": 4 * tol, "gw3": 4 * tol}
+    bad = {k: (errs[k], lims[k]) for k in errs if not errs[k] < lims[k]}
+    print("\nup train %s %s: %s" % (case, dtype, ", ".join("%s %.2e (<%.1e)" % (k, errs[k], lims[k]) for k in errs)))
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("dtype", DT)
 def test_up_block_module_uses_composed_path_when_frozen(dtype):
     """`Up` (joint_model.py:114-124) with frozen weights runs the composed operator and matches the two-launch form of the same module."""

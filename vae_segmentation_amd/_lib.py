@@ -18,7 +18,7 @@ HEADER = os.path.join(os.path.dirname(_HERE), "include", "vaeseg.h")
 LIB_PATH = os.environ.get("VS_LIBVAESEG") or os.path.join(_HERE, "libvaeseg.so")      # VS_LIBVAESEG: an alternative build (A/B measurements)
 
 VS_F32, VS_BF16, VS_F16 = 0, 1, 2
-VS_CONV_K3, VS_CONV_K2S2, VS_CONV_T2S2 = 0, 1, 2
+VS_CONV_K3, VS_CONV_K2S2, VS_CONV_T2S2, VS_CONV_UP = 0, 1, 2, 3
 VS_PACK_ROWS_D0, VS_PACK_ROWS_D1_FLIP, VS_PACK_SCATTER_D1 = 0, 1, 2
 
 _SCALARS = {"int": ctypes.c_int, "unsigned long long": ctypes.c_ulonglong, "long long": ctypes.c_longlong, "float": ctypes.c_float,

@@ -39,7 +39,7 @@ struct K4Geom {
 // RB: 16-row blocks per workgroup.  Row blocks are numbered (p, co / 16) [Co >= 16] or (pz, py) with rows (px, co) [Co = 8].
 // W1: single input-channel chunk (Cin <= 32) — the weight block is staged once, not per tile
 template <int CK, int RB, bool HS, typename T, bool W1 = (CK == 16)>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 && RB == 4 ? 1 : 2, 2))) void k4t_kernel(const G1Params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 && RB == 4 ? 1 : (CK == 16 && RB == 2 ? 3 : 2), CK == 16 && RB == 2 ? 4 : 2))) void k4t_kernel(const G1Params p) {
     constexpr int TV = K4Geom::TV, PLANE = K4Geom::PLANE;
     constexpr int NT = CK == 32 ? 8 : 6;                 // k-groups per (row block, chunk)
     constexpr int CKB = CK * 2, U = CKB / 16, NU = TV * U, NIT = (NU + 255) / 256;
@@ -200,6 +200,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
     bool first = true;
     if constexpr (W1) write_w();
     __syncthreads();
+    // the per-lane LDS offset of every (row block, k-group)'s tap: tile independent, so it is read ONCE into registers — read inside the MFMA
+    // loop, the table lookup put a second dependent LDS round trip in front of every k-group's B fragments
+    int toff[RB * NT];
+#pragma unroll
+    for (int i = 0; i < RB * NT; ++i) {
+        if constexpr (CK == 32) {
+            const int code = s_taps[i];
+            const int dx = code >> 28;
+            toff[i] = (dx == 0 ? baddr[0] : (dx == 1 ? baddr[1] : baddr[2])) + (code & 0x0fffffff);
+        } else {
+            toff[i] = baddr[0] + s_taps[i * 4 + g];
+        }
+    }
 
     const int F_D = 2 * p.D, F_H = 2 * p.H, F_W = 2 * p.W;
     for (; t < t_end; t += G) {
@@ -228,14 +241,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
             }
             auto read_kg = [&](int i, u32x4& a, u32x4 (&b)[4]) {     // i = rb * NT + kg
                 a = *(const u32x4*)(s_wl + i * 1024);
-                int o;
-                if constexpr (CK == 32) {
-                    const int code = s_taps[i];
-                    const int dx = code >> 28;
-                    o = (dx == 0 ? baddr[0] : (dx == 1 ? baddr[1] : baddr[2])) + (code & 0x0fffffff);
-                } else {
-                    o = baddr[0] + s_taps[i * 4 + g];
-                }
+                const int o = toff[i];
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + o + cg * 18 * CKB);
             };
@@ -477,6 +483,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         u32x2 mk[RB][4];
 
         for (int ch = 0; ch < p.nch; ++ch) {
+            // this chunk's tap offsets: requested before the stage is written, in registers by the time the MFMA loop starts
+            int toff[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int code = s_taps[ch * NT + j];
+                const int dx = code >> 28;
+                toff[j] = (dx == 0 ? baddr[0] : (dx == 1 ? baddr[1] : baddr[2])) + (code & 0x0fffffff);
+            }
             if (!first) __syncthreads();
             write_x();
             write_w();
@@ -500,13 +514,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     load_x(last_ch ? nxt : cur, last_ch ? 0 : ch + 1);
                 }
             }
-            const int* tp = s_taps + ch * NT;
             auto read_kg = [&](int j, u32x4 (&a)[RB], u32x4 (&b)[4]) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) a[rb] = *(const u32x4*)(s_wl + (rb * NT + j) * 1024);
-                const int code = tp[j];
-                const int dx = code >> 28;
-                const int o = (dx == 0 ? baddr[0] : (dx == 1 ? baddr[1] : baddr[2])) + (code & 0x0fffffff);
+                const int o = toff[j];
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + o + cg * 18 * CKB);
             };
@@ -604,7 +615,7 @@ static inline void k4_fastdiv(int d, unsigned int& m, unsigned int& s) {
 }
 
 static inline int k4_grid_x(int tiles_total, int row_tiles) {
-    const int per_cu = 2;
+    static const int per_cu = getenv("VS_UP_WGS_PER_CU") ? atoi(getenv("VS_UP_WGS_PER_CU")) : 2;      // tuning knob
     int wg = 256 * per_cu / (row_tiles < per_cu ? row_tiles : per_cu);
     if (wg < 256) wg = 256;
     return tiles_total < wg ? tiles_total : wg;
@@ -632,6 +643,7 @@ static int k4t_launch(const G1Params& p, int rb, hipStream_t s) {
     const bool hs = p.x_stats != nullptr;
     if (p.C == 16) {
         if (p.up_co != 8) return VS_ESHAPE;
+        if (rb == 2) return hs ? k4t_launch_t<T, 16, 2, true>(p, s) : k4t_launch_t<T, 16, 2, false>(p, s);
         return hs ? k4t_launch_t<T, 16, 4, true>(p, s) : k4t_launch_t<T, 16, 4, false>(p, s);
     }
     if (p.C % 32 || p.up_co % 16) return VS_ESHAPE;

@@ -10,7 +10,7 @@
 #include <stdlib.h>
 #include "common.h"
 
-enum { G3_K3 = 0, G3_K2S2 = 1 };
+enum { G3_K3 = 0, G3_K2S2 = 1, G3_UP = 2 };   // G3_UP: the composed Up block (igemm_k4.h): Q as K3 on the coarse grid, P = the FINE output gradient read space-to-depth
 #define G3_MAXN 16
 
 struct G3Params {
@@ -24,12 +24,13 @@ struct G3Params {
     int ksplit, total_tiles, tiles_per_sample, tyn, txn;
     float eps;
     double inv_cnt_p, inv_cnt_q;
+    int up_co;                // G3_UP: channels of the fine tensor P points to (Mch = 8 * up_co is its space-to-depth view)
 };
 
 template <int CB, int KIND> struct G3Geo {
-    static constexpr int NTAPS = KIND == G3_K3 ? 27 : 8;
+    static constexpr int NTAPS = KIND != G3_K2S2 ? 27 : 8;
     static constexpr int NCB = CB == 16 ? NTAPS : (NTAPS + 1) / 2;
-    static constexpr int QZ = KIND == G3_K3 ? 6 : 8, QY = KIND == G3_K3 ? 6 : 8, QX = KIND == G3_K3 ? 18 : 32;
+    static constexpr int QZ = KIND != G3_K2S2 ? 6 : 8, QY = KIND != G3_K2S2 ? 6 : 8, QX = KIND != G3_K2S2 ? 18 : 32;
     static constexpr int QV = QZ * QY * QX;
 };
 
@@ -244,11 +245,24 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
     const int ppart = tid & 1, qpart = tid % QU;
     const bool pch_ok = mb * 16 + ppart * 8 < p.Mch, qch_ok = cb * CB + qpart * 8 < p.Cch;
     int prel[2], pzyx[2];
+    // G3_UP: view channel block mb of coarse voxel v = 16 channels of the fine tensor [N][2Dp][2Hp][2Wp][Co] around voxel 2v:
+    // Co = 8: mb = (pz, py), the block's halves are the x parities; Co = 16: mb = parity; Co >= 32: mb = (parity, 16-channel block)
+    const int up_fh = 2 * p.Hp, up_fw = 2 * p.Wp;
+    int up_mb_off = 0;
+    if constexpr (KIND == G3_UP) {
+        const int co = p.up_co;
+        if (co == 8) up_mb_off = ((((mb >> 1) & 1) * up_fh + (mb & 1)) * up_fw) * co * 2;
+        else {
+            const int nb16 = co / 16, pp = mb / nb16, cb16 = mb - pp * nb16;
+            up_mb_off = ((((pp >> 2) & 1) * up_fh + ((pp >> 1) & 1)) * up_fw + (pp & 1)) * co * 2 + cb16 * 32;
+        }
+    }
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int v = (tid + b * 256) >> 1;
         const int lx = v & 15, ly = (v >> 4) & 3, lz = v >> 6;
-        prel[b] = (((lz * p.Hp + ly) * p.Wp + lx) * p.Mch + mb * 16 + ppart * 8) * 2;
+        if constexpr (KIND == G3_UP) prel[b] = (((2 * lz) * up_fh + 2 * ly) * up_fw + 2 * lx) * p.up_co * 2 + up_mb_off + ppart * 16;
+        else prel[b] = (((lz * p.Hp + ly) * p.Wp + lx) * p.Mch + mb * 16 + ppart * 8) * 2;
         pzyx[b] = pch_ok ? (lz | (ly << 8) | (lx << 16)) : 0x00ffffff;
     }
     int qrel[NITQ], qzyx[NITQ];
@@ -268,7 +282,8 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         const int tx = tl % p.txn, ty = (tl / p.txn) % p.tyn, tz = tl / (p.txn * p.tyn);
         const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
         okbits = 0;
-        const int pbase = (((n * p.Dp + z0) * p.Hp + y0) * p.Wp + x0) * p.Mch * 2;
+        const int pbase = KIND == G3_UP ? (((n * 2 * p.Dp + 2 * z0) * up_fh + 2 * y0) * up_fw + 2 * x0) * p.up_co * 2
+                                        : (((n * p.Dp + z0) * p.Hp + y0) * p.Wp + x0) * p.Mch * 2;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int gz = z0 + (pzyx[b] & 0xff), gy = y0 + ((pzyx[b] >> 8) & 0xff), gx = x0 + (pzyx[b] >> 16);
@@ -276,7 +291,7 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
             okbits |= ok ? (1u << b) : 0u;
             pv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(prsrc, ok ? pbase + prel[b] : -1, 0, 0));
         }
-        const int qz0 = KIND == G3_K3 ? z0 - 1 : 2 * z0, qy0 = KIND == G3_K3 ? y0 - 1 : 2 * y0, qx0 = KIND == G3_K3 ? x0 - 1 : 2 * x0;
+        const int qz0 = KIND != G3_K2S2 ? z0 - 1 : 2 * z0, qy0 = KIND != G3_K2S2 ? y0 - 1 : 2 * y0, qx0 = KIND != G3_K2S2 ? x0 - 1 : 2 * x0;
         const int qbase = (((n * p.Dq + qz0) * p.Hq + qy0) * p.Wq + qx0) * p.Cch * 2;
 #pragma unroll
         for (int b = 0; b < NITQ; ++b) {
@@ -346,9 +361,9 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
 #pragma unroll
     for (int k = 0; k < NCB; ++k) {
         int tap = CB == 16 ? k : 2 * k + (p4 >> 1);
-        if (tap >= NTAPS) tap = KIND == G3_K3 ? 13 : 0;
+        if (tap >= NTAPS) tap = KIND != G3_K2S2 ? 13 : 0;
         int dz, dy, dx;
-        if (KIND == G3_K3) { dz = tap / 9; dy = (tap / 3) % 3; dx = tap % 3; }
+        if (KIND != G3_K2S2) { dz = tap / 9; dy = (tap / 3) % 3; dx = tap % 3; }
         else { dz = (tap >> 2) & 1; dy = (tap >> 1) & 1; dx = tap & 1; }
         qoff[k] = ((dz * QY + dy) * QX + dx) * QROW + (CB == 16 ? p4 * 8 : (p4 & 1) * 8);
     }
@@ -369,7 +384,7 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
             const int pa0 = (((wave * 4 + 2 * s) * 16 + xr) * 32) + p4 * 8;
             const u32x4 a = tr_pair(s_p, pa0, pa0 + 16 * 32);
             int qb0, qb1;
-            if (KIND == G3_K3) {
+            if (KIND != G3_K2S2) {
                 qb0 = ((wave * QY + 2 * s) * QX + xr) * QROW;
                 qb1 = qb0 + QX * QROW;
             } else {
@@ -463,7 +478,7 @@ static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind,
     cbsz = c_ch >= 16 ? 16 : 8;
     mbn = (m_ch + 15) / 16;
     cbn = (c_ch + cbsz - 1) / cbsz;
-    const int ntaps = kind == VS_CONV_K3 ? 27 : 8;
+    const int ntaps = kind != VS_CONV_K2S2 ? 27 : 8;
     ncb = cbsz == 16 ? ntaps : (ntaps + 1) / 2;
     tyn = (hp + 3) / 4; txn = (wp + 15) / 16;
     tiles_per_sample = ((dp + 3) / 4) * tyn * txn;
@@ -760,7 +775,8 @@ static int multi_validate(const vs_wgrad_desc& d) {
     if (!d.p || !d.q || !d.dw) return VS_EINVAL;
     if (d.n <= 0 || d.n > G3_MAXN || d.dp <= 0 || d.hp <= 0 || d.wp <= 0) return VS_ESHAPE;
     if (d.m_ch % 8 || d.c_ch % 8 || d.m_real > d.m_ch || d.c_real > d.c_ch || d.m_real <= 0 || d.c_real <= 0) return VS_ESHAPE;
-    if (d.kind != VS_CONV_K3 && d.kind != VS_CONV_K2S2) return VS_EINVAL;
+    if (d.kind != VS_CONV_K3 && d.kind != VS_CONV_K2S2 && d.kind != VS_CONV_UP) return VS_EINVAL;
+    if (d.kind == VS_CONV_UP && (d.reserved_ <= 0 || d.m_ch != 8 * d.reserved_ || d.c_ch < 16 || d.p_stats)) return VS_ESHAPE;     // reserved_ = Co; 16-channel Q blocks only
     if (d.bias_g) {
         if (!d.db || d.bias_rows <= 0 || d.bias_c_real <= 0 || d.bias_c_real > d.bias_c_ch) return VS_EINVAL;
         if (d.bias_c_ch <= 0 || d.bias_c_ch % 8 || d.bias_c_ch > 2048 || 256 % (d.bias_c_ch / 8)) return VS_ESHAPE;
@@ -773,7 +789,7 @@ static int multi_validate(const vs_wgrad_desc& d) {
 static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPlan& plan) {
     static const long long target = getenv("VS_WGRAD_GROUP_WGS") ? atoll(getenv("VS_WGRAD_GROUP_WGS")) : 512;     // measured best of 384..2560 (two workgroups per CU are resident)
     plan.layers.resize(count);
-    long long bucket_work[4] = {0, 0, 0, 0};
+    long long bucket_work[6] = {0, 0, 0, 0, 0, 0};       // (cbsz 16 | 8) x (K3, K2S2, UP)
     for (int i = 0; i < count; ++i) {
         const vs_wgrad_desc& d = descs[i];
         int rc = multi_validate(d);
@@ -785,16 +801,17 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         g3_plan(d.n, d.dp, d.hp, d.wp, d.m_ch, d.c_ch, d.kind, L.cbsz, p.mbn, p.cbn, L.ncb, p.tiles_per_sample, p.tyn, p.txn, ks_unused, false);
         p.P = d.p; p.P_stats = d.p_stats; p.Q = d.q; p.Q_stats = d.q_stats;
         p.N = d.n; p.Dp = d.dp; p.Hp = d.hp; p.Wp = d.wp;
-        const int s = d.kind == VS_CONV_K3 ? 1 : 2;
+        const int s = d.kind != VS_CONV_K2S2 ? 1 : 2;
         p.Dq = d.dp * s; p.Hq = d.hp * s; p.Wq = d.wp * s;
         p.Mch = d.m_ch; p.Cch = d.c_ch;
+        p.up_co = d.kind == VS_CONV_UP ? d.reserved_ : 0;
         p.total_tiles = p.tiles_per_sample * d.n;
         p.eps = eps;
         p.inv_cnt_p = 1.0 / ((double)d.dp * d.hp * d.wp);
         p.inv_cnt_q = 1.0 / ((double)p.Dq * p.Hq * p.Wq);
         if ((long long)d.n * d.dp * d.hp * d.wp * d.m_ch * 2 >= 2147483648ll || (long long)d.n * p.Dq * p.Hq * p.Wq * d.c_ch * 2 >= 2147483648ll) return VS_ESHAPE;
         L.kind = d.kind; L.m_real = d.m_real; L.c_real = d.c_real; L.dw = d.dw;
-        bucket_work[(L.cbsz == 16 ? 0 : 1) + (d.kind == VS_CONV_K3 ? 0 : 2)] += (long long)p.mbn * p.cbn * p.total_tiles;
+        bucket_work[(L.cbsz == 16 ? 0 : 1) + 2 * (d.kind == VS_CONV_K3 ? 0 : (d.kind == VS_CONV_K2S2 ? 1 : 2))] += (long long)p.mbn * p.cbn * p.total_tiles;
     }
     // descriptors that share dw (db): parts of one gradient
     for (int i = 0; i < count; ++i) {
@@ -817,7 +834,7 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
     for (int i = 0; i < count; ++i) {                      // k-splits
         MultiLayer& L = plan.layers[i];
         G3Params& p = L.p;
-        const long long w = bucket_work[(L.cbsz == 16 ? 0 : 1) + (L.kind == VS_CONV_K3 ? 0 : 2)];
+        const long long w = bucket_work[(L.cbsz == 16 ? 0 : 1) + 2 * (L.kind == VS_CONV_K3 ? 0 : (L.kind == VS_CONV_K2S2 ? 1 : 2))];
         long long tpw = (w + target - 1) / target;            // tiles per workgroup
         if (tpw < 1) tpw = 1;
         long long ks = (p.total_tiles + tpw - 1) / tpw;
@@ -949,8 +966,8 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
     char* ws = (char*)workspace;
 
     // ---- the four (CB, KIND) buckets, heaviest workgroups first, G3_GROUP_MAX layers per grid ----
-    for (int bucket = 0; bucket < 4; ++bucket) {
-        const int cbsz = (bucket & 1) ? 8 : 16, kind = (bucket & 2) ? VS_CONV_K2S2 : VS_CONV_K3;
+    for (int bucket = 0; bucket < 6; ++bucket) {
+        const int cbsz = (bucket & 1) ? 8 : 16, kind = bucket < 2 ? VS_CONV_K3 : (bucket < 4 ? VS_CONV_K2S2 : VS_CONV_UP);
         std::vector<int> idx;
         for (int i = 0; i < count; ++i)
             if (plan.layers[i].cbsz == cbsz && plan.layers[i].kind == kind) idx.push_back(i);
@@ -968,7 +985,10 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
             }
             if (wg >= 2147483647ll) return VS_ESHAPE;
             for (int j = grp.n; j <= G3_GROUP_MAX; ++j) grp.wg_start[j] = (int)wg;
-            if (f16) {
+            if (kind == VS_CONV_UP) {
+                if (cbsz != 16) return VS_ESHAPE;
+                rc = f16 ? g3b_group_run<vs_half, 16, G3_UP>(grp, st) : g3b_group_run<unsigned short, 16, G3_UP>(grp, st);
+            } else if (f16) {
                 if (kind == VS_CONV_K3) rc = cbsz == 16 ? g3b_group_run<vs_half, 16, G3_K3>(grp, st) : g3b_group_run<vs_half, 8, G3_K3>(grp, st);
                 else rc = cbsz == 16 ? g3b_group_run<vs_half, 16, G3_K2S2>(grp, st) : g3b_group_run<vs_half, 8, G3_K2S2>(grp, st);
             } else {
@@ -1012,7 +1032,7 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
                 int parts = 1;
                 while (parts < G3_RED_ROWS && parts * 8 < L.total_slabs) parts *= 2;
                 red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.total_slabs, L.cbsz,
-                                        L.kind == VS_CONV_K3 ? 27 : 8, L.ncb, 0, parts});
+                                        L.kind != VS_CONV_K2S2 ? 27 : 8, L.ncb, 0, parts});
                 blocks.push_back(vs_ceil_div(slab_elems, 256 * (G3_RED_ROWS / parts)));
             }
             if (descs[i].bias_g && L.bias_primary == i) {

@@ -155,7 +155,7 @@ class Up(nn.Module):
         t, dc = self.conv[0], self.conv[1]
         if dc.lazy_head() and ops.up_composed_ok(a.raw, t, dc.conv[0]):
             # transposed conv + first 3x3x3 conv as one operator on the coarse grid: no intermediate tensor, one launch each way
-            y, ys = ops.UpConvK3.apply(a.raw, a.stats, t.weight, t.bias, dc.conv[0].weight)
+            y, ys = ops.UpConvK3.apply(a.raw, a.stats, t.weight, t.bias, dc.conv[0].weight, dc.conv[0].bias)
             a = dc(Act(y, ys), _start=3)
         else:
             a = dc(Act(ops.ConvT2S2.apply(a.raw, a.stats, t.weight, t.bias), None))

@@ -14,7 +14,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (VS_BF16, VS_CONV_K2S2, VS_CONV_K3, VS_F16, VS_F32, VS_PACK_ROWS_D0, VS_PACK_ROWS_D1_FLIP,
+from ._lib import (VS_BF16, VS_CONV_K2S2, VS_CONV_K3, VS_CONV_UP, VS_F16, VS_F32, VS_PACK_ROWS_D0, VS_PACK_ROWS_D1_FLIP,
                    VS_PACK_SCATTER_D1, check, lib)
 
 _DT_TORCH = {VS_F32: torch.float32, VS_BF16: torch.bfloat16, VS_F16: torch.float16}
@@ -300,6 +300,7 @@ def refresh_frozen_packs(module):
             wt, bt = plan["src"]
             with torch.no_grad():
                 _up_compose_into(plan, wt.detach(), None if bt is None else bt.detach(), prm.detach(), dt)
+                plan["stamp"] = _up_stamp(wt, bt, prm)
         cache = getattr(prm, "_vs_pack_cache", None)
         if not cache:
             continue
@@ -321,6 +322,7 @@ def repack_trainable():
     """Re-pack every registered trainable weight image with ONE launch (call after the weights changed in place)."""
     import struct
     r = _REPACK
+    _recompose_trainable_ups()
     live = [p for p in r["params"].values() if getattr(p, "_vs_pack_plan", None)]
     if not live:
         return
@@ -757,6 +759,7 @@ def drop_stale_wgrads():
     if g["descs"] or g["callback"]:
         g["descs"], g["keep"], g["callback"], g["bytes"], g["flops"] = [], [], False, 0.0, 0.0
     g["slots"] = {}
+    _UP_JOBS.clear()
     # the same for gradients parked / handed over un-applied by a pass that died: their addresses may be recycled by now, and a later
     # backward must never mistake a fresh tensor at such an address for one of them
     for reg in (_PENDING, _LAZY_APPLY):
@@ -764,7 +767,7 @@ def drop_stale_wgrads():
         reg["callback"] = False
 
 
-def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb):
+def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb, up_co=0):
     p, ps, q, qs, m_real, c_real, kind = wgrad_args
     g = _GROUP
     if g["descs"] and g["dtype"] != p.dtype:
@@ -772,16 +775,19 @@ def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb):
     g["dtype"] = p.dtype
     n, dp, hp, wp_, m_ch = p.shape
     gw_ptr = gw if isinstance(gw, int) else gw.data_ptr()
+    if kind == VS_CONV_UP:                   # p is the FINE gradient (n, 2dp, 2hp, 2wp, Co): the descriptor's grid is the coarse one, its rows the 8 Co view channels
+        dp, hp, wp_, m_ch = dp // 2, hp // 2, wp_ // 2, 8 * up_co
     d = WgradDesc(p.data_ptr(), _p(ps), q.data_ptr(), _p(qs), gw_ptr, None, None, 0, 0, 0,
-                  n, dp, hp, wp_, m_ch, q.shape[-1], m_real, c_real, kind, 0)
+                  n, dp, hp, wp_, m_ch, q.shape[-1], m_real, c_real, kind, up_co)
     if bias_args is not None:
         bg = bias_args[0]
         gb_ptr = gb if isinstance(gb, int) else gb.data_ptr()
         d.bias_g, d.db, d.bias_rows, d.bias_c_ch, d.bias_c_real = bg.data_ptr(), gb_ptr, bg.numel() // bg.shape[-1], bg.shape[-1], bias_args[1]
         g["keep"].append(bg)
-    taps = 27 if kind == VS_CONV_K3 else 8
-    nb = (p.numel() // m_ch * m_real + q.numel() // q.shape[-1] * c_real) * _esize(p) + m_real * c_real * taps * 4
-    fl = 2.0 * (p.numel() // m_ch) * taps * m_real * c_real
+    taps = 8 if kind == VS_CONV_K2S2 else 27
+    nb = (p.numel() + q.numel() // q.shape[-1] * c_real) * _esize(p) + m_real * c_real * taps * 4 if kind == VS_CONV_UP else \
+        (p.numel() // m_ch * m_real + q.numel() // q.shape[-1] * c_real) * _esize(p) + m_real * c_real * taps * 4
+    fl = 2.0 * (q.numel() // q.shape[-1]) * taps * m_real * c_real if kind == VS_CONV_UP else 2.0 * (p.numel() // m_ch) * taps * m_real * c_real
     first = g["split"] is None or bool(g["split"](weight))
     g["descs"].append((d, first, nb, fl))
     g["keep"].extend(t for t in keep if t is not None)
@@ -827,6 +833,7 @@ def flush_wgrads(first_only=False):
     with _timed("wgrad_multi(%d layers)" % len(descs), nb, fl):
         check(lib.vs_conv_wgrad_multi(_ct.addressof(arr), len(descs), ws.data_ptr(), nbytes, dt, EPS_IN, _stream()), "conv_wgrad_multi")
     if not later:
+        _run_up_jobs()                          # parameter-space chain rule of the composed Up heads: reads the dWeff the launch above reduced
         g["keep"] = []                          # launched on the current stream: the allocator may recycle the inputs now
 
 
@@ -1180,17 +1187,26 @@ FUSE_UP = os.environ.get("VS_FUSE_UP", "1") != "0"
 # (isolated, forward / backward-data against the pair: 24^3 x 32: 26.8 / 17.8 us vs 32 / 19; 12^3 x 64: 16.5 / 19.1 vs 24 / 19; in the replayed
 # step the pair is faster than in isolation and the composed form measured +0.05 ms when enabled at every level).
 FUSE_UP_MIN_VOXELS = int(os.environ.get("VS_FUSE_UP_MIN_VOXELS", str(44 ** 3)))
+# Trainable weights through the composed head: built and parity-green (tests/test_gpu_up.py: dW3, dW2, db2 against autograd), but not yet a
+# win in the replayed 96^3 step — the weight-gradient side gains 40 us (the largest layer of the 16-channel bucket leaves it, the transposed
+# conv's weight gradient and its 113 MB operand disappear) and the per-step helpers give 80 back (re-composition 32 us, boundary sums 21,
+# chain rule 28: single-digit-microsecond work in launches bound by their dependent round trips): 2.69 vs 2.66 ms, same box.  Off by default.
+FUSE_UP_TRAINABLE = os.environ.get("VS_FUSE_UP_TRAINABLE", "0") == "1"
 
 
 def _up_stamp(wt, bt, w3):
-    return (wt._version, wt.data_ptr(), w3._version, w3.data_ptr(), None if bt is None else (bt._version, bt.data_ptr()), _PACK_EPOCH[0])
+    return (wt._version, wt.data_ptr(), w3._version, w3.data_ptr(), None if bt is None else (bt._version, bt.data_ptr()),
+            _TRAIN_EPOCH[0] if (w3.requires_grad or wt.requires_grad) else _PACK_EPOCH[0])
+
+
+_UP_TRAINABLE = {}      # id(w3) -> (plan, wt, bt, w3, dtype): composed images of trainable Up heads, re-composed by repack_trainable() after every optimiser step
 
 
 def _up_compose_into(plan, wt, bt, w3, dtype):
+    """(re)compose in place; the caller sets plan["stamp"] from the PARAMETERS (detached aliases carry their own version counters)"""
     cin, cm, co = wt.shape[0], wt.shape[1], w3.shape[0]
     check(lib.vs_up_compose(wt.data_ptr(), _p(bt), w3.data_ptr(), plan["weff"].data_ptr(), plan["img_f"].data_ptr(), plan["img_b"].data_ptr(),
                             plan["taps_f"].data_ptr(), plan["taps_b"].data_ptr(), plan["btab"].data_ptr(), cin, cm, co, vs_of(dtype), _stream()), "up_compose")
-    plan["stamp"] = _up_stamp(wt, bt, w3)
 
 
 def up_plan(wt, bt, w3, dtype):
@@ -1211,17 +1227,33 @@ def up_plan(wt, bt, w3, dtype):
         plan = {"weff": buf(sz[0]), "img_f": buf(sz[1]), "img_b": buf(sz[2]), "taps_f": buf(sz[3]), "taps_b": buf(sz[4]), "btab": buf(sz[5]),
                 "stamp": None, "src": (wt, bt)}
         plans[dtype] = plan
+    if w3.requires_grad or wt.requires_grad:
+        _UP_TRAINABLE[(id(w3), dtype)] = (plan, wt, bt, w3, dtype)
     if plan["stamp"] != _up_stamp(wt, bt, w3):
         with torch.no_grad():
             _up_compose_into(plan, wt.detach(), None if bt is None else bt.detach(), w3.detach(), dtype)
+            plan["stamp"] = _up_stamp(wt, bt, w3)
     return plan
 
 
+def _recompose_trainable_ups():
+    for plan, wt, bt, w3, dtype in _UP_TRAINABLE.values():
+        with torch.no_grad():
+            _up_compose_into(plan, wt.detach(), None if bt is None else bt.detach(), w3.detach(), dtype)
+            plan["stamp"] = _up_stamp(wt, bt, w3)
+
+
 def up_composed_ok(x, tconv, conv3):
-    """Can this Up block head run as the composed operator?  16-bit storage, frozen weights (the trainable form needs the parameter-space
-    chain rule: handled by the unfused pair), channel pairs the kernels are instantiated for (vs_up_supported)."""
+    """Can this Up block head run as the composed operator?  16-bit storage, channel pairs the kernels are instantiated for
+    (vs_up_supported), large enough a grid to win (FUSE_UP_MIN_VOXELS).  Trainable weights: their gradients come from the composed
+    weight-gradient (VS_CONV_UP descriptor in the grouped end-of-pass launches) through the parameter-space chain rule (vs_up_chain) — needs
+    the grouped, single-phase weight-gradient mode (the default)."""
     wt, w3 = tconv.weight, conv3.weight
-    if not FUSE_UP or x.dtype == torch.float32 or wt.requires_grad or w3.requires_grad or (tconv.bias is not None and tconv.bias.requires_grad):
+    if not FUSE_UP or x.dtype == torch.float32:
+        return False
+    trainable = wt.requires_grad or w3.requires_grad or (tconv.bias is not None and tconv.bias.requires_grad)
+    if trainable and (not FUSE_UP_TRAINABLE or not _GROUP["enabled"] or _SIDE["enabled"] or _GROUP["split"] is not None
+                      or not (wt.is_leaf and w3.is_leaf)):
         return False
     if tuple(wt.shape[2:]) != (2, 2, 2) or tuple(w3.shape[2:]) != (3, 3, 3) or w3.shape[1] != wt.shape[1] or x.shape[-1] != wt.shape[0]:
         return False
@@ -1235,11 +1267,12 @@ class UpConvK3(torch.autograd.Function):
     (joint_model.py:116-120 + 40); output lazy (raw + statistics) on the fine grid.  No intermediate tensor, 3.4x fewer multiply-adds."""
 
     @staticmethod
-    def forward(ctx, x, xs, wt, bt, w3):
+    def forward(ctx, x, xs, wt, bt, w3, b3=None):
         _require_cuda(x, wt, w3)
         n, d, h, w, c = x.shape
         co = w3.shape[0]
         plan = up_plan(wt, bt, w3, x.dtype)
+        ctx.b3 = b3                                # the 3x3x3 conv's bias: dead (InstanceNorm follows, SURVEY F10) — its gradient is returned as zeros
         y = torch.empty((n, 2 * d, 2 * h, 2 * w, co), dtype=x.dtype, device=x.device)
         ys = _new_stats(n, co, x.device)
         kid = nb = fl = None
@@ -1253,6 +1286,7 @@ class UpConvK3(torch.autograd.Function):
         ctx.save_for_backward(x, xs)
         ctx.plan = plan
         ctx.co = co
+        ctx.params = (wt, bt, w3)               # Parameters (long-lived leaves): read by the chain rule, their gradient slots looked up in backward
         ctx.defer = bool(getattr(x, "_vs_defer_apply", False)) and xs is not None
         ctx.mark_non_differentiable(ys)
         ctx.set_materialize_grads(False)
@@ -1261,12 +1295,19 @@ class UpConvK3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gys):
         x, xs = ctx.saved_tensors
-        if gy is None or not ctx.needs_input_grad[0]:
-            return None, None, None, None, None
+        if gy is None:
+            return None, None, None, None, None, None
         gy = _contig(gy)
         lazy = _take_lazy(gy)
         if lazy is not None:
             gy = apply_lazy(gy, lazy)
+        gwt = gbt = gw3 = gb3 = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            gwt, gbt, gw3 = _up_weight_grads(gy, x, xs, ctx.params, ctx.co, ctx.needs_input_grad)
+        if ctx.b3 is not None and ctx.needs_input_grad[5]:
+            gb3 = _dead_bias_grad(ctx.b3, ctx.b3.shape[0], x.device)
+        if not ctx.needs_input_grad[0]:
+            return None, None, gwt, gbt, gw3, gb3
         n, d, h, w, c = x.shape
         gx = torch.empty_like(x)
         sums = _new_stats(n, c, x.device) if xs is not None else None
@@ -1284,7 +1325,45 @@ class UpConvK3(torch.autograd.Function):
                 _defer_register(gx, x, xs, sums)
             else:
                 _apply_in_place(gx, x, xs, sums)
-        return gx, None, None, None, None
+        return gx, None, gwt, gbt, gw3, gb3
+
+
+_UP_JOBS = {}       # id(w3) -> the pending chain-rule job of a trainable composed Up head in the current backward pass
+
+
+def _up_weight_grads(gy, x, xs, params, co, needs):
+    """Weight gradients of the composed head: dWeff27 from a VS_CONV_UP descriptor in the grouped end-of-pass launch, the boundary sums of gy
+    now (vs_up_faces), and a chain-rule job that flush_wgrads() runs right after the grouped launch.  -> (g wt, g bt, g w3) for autograd
+    (unwritten until then, like every deferred weight gradient); later uses of the same weights in one pass add to the first use's job."""
+    wt, bt, w3 = params
+    n, d, h, w, c = x.shape
+    job = _UP_JOBS.get(id(w3))
+    first = job is None
+    if first:
+        dev = x.device
+        gwt = _grad_slot(wt, wt.shape) if needs[2] else None
+        gbt = _grad_slot(bt, bt.shape) if (bt is not None and needs[3]) else None
+        gw3 = _grad_slot(w3, w3.shape) if needs[4] else None
+        # the job holds raw ADDRESSES of the gradients, not the tensors: AccumulateGrad adopts a gradient as .grad (no copy of the still
+        # unwritten buffer) only if nobody else holds the tensor object; .grad keeps the storage alive until the chain rule has written it
+        job = {"dweff": torch.empty(8 * co * c * 27, dtype=torch.float32, device=dev),
+               "faces": _new_stats(1, 27 * co // 2, dev),          # zeroed, statistics format: vs_up_faces accumulates (every use of the weights)
+               "gwt": _p(gwt), "gbt": _p(gbt), "gw3": _p(gw3), "params": params, "co": co}
+        _UP_JOBS[id(w3)] = job
+    check(lib.vs_up_faces(gy.data_ptr(), job["faces"].data_ptr(), n, 2 * d, 2 * h, 2 * w, co, vs_dtype(gy), _stream()), "up_faces")
+    _group_submit(w3, (gy, x, xs), (gy, None, x, xs, 8 * co, c, VS_CONV_UP), None, job["dweff"], None, up_co=co)
+    deferrable = all(p is None or (p.is_leaf and p.grad is None and not _has_hooks(p)) for p in (wt, bt, w3)) and not torch.is_grad_enabled()
+    if not deferrable:
+        flush_wgrads()                          # runs the chain rule too
+    return (gwt, gbt, gw3) if first else (None, None, None)
+
+
+def _run_up_jobs():
+    for job in _UP_JOBS.values():
+        wt, bt, w3 = job["params"]
+        check(lib.vs_up_chain(job["dweff"].data_ptr(), job["faces"].data_ptr(), wt.data_ptr(), _p(bt), w3.data_ptr(), job["gwt"], job["gbt"],
+                              job["gw3"], wt.shape[0], wt.shape[1], job["co"], _stream()), "up_chain")
+    _UP_JOBS.clear()
 
 
 class Materialize(torch.autograd.Function):
