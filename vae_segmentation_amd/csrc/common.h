@@ -120,6 +120,16 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, f32x4 c,
 }
 
 // ---- wave reductions ---------------------------------------------------------------------------
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane of the row: four DPP moves (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror) instead of four ds_bpermute round trips per __shfl_xor chain
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -472,8 +472,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float s = ssum[rb][r], q = ssq[rb][r];
-#pragma unroll
-                            for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                            { s = row16_sum(s); q = row16_sum(q); }      // DPP: the four-step __shfl_xor butterfly was four ds_bpermute round trips per statistic
                             if (col == 0) {
                                 const int lr = rb * 16 + 4 * g + r;
                                 s_red[(wave * 64 + lr) * 2 + 0] = s;

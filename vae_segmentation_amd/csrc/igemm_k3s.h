@@ -258,8 +258,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float s = ssum[r], q = ssq[r];
-#pragma unroll
-            for (int o2 = 1; o2 < 16; o2 <<= 1) { s += __shfl_xor(s, o2, 64); q += __shfl_xor(q, o2, 64); }
+            { s = row16_sum(s); q = row16_sum(q); }
             if (col == 0) {
                 s_red[(wave * 16 + 4 * g + r) * 2 + 0] = s;
                 s_red[(wave * 16 + 4 * g + r) * 2 + 1] = q;

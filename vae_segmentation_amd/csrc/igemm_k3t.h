@@ -335,8 +335,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float s = ssum[r], q = ssq[r];
-#pragma unroll
-                        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                        { s = row16_sum(s); q = row16_sum(q); }      // DPP: the four-step __shfl_xor butterfly was four ds_bpermute round trips per statistic
                         s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
                         if (col == 0 && dx2 == 0) {
                             s_red[(wave * 8 + c4 + r) * 2 + 0] = s;

@@ -23,9 +23,23 @@
 #include <stdlib.h>
 #include "igemm.h"
 
-#define K4_LDS_RED 0           // float[4][64][2]
-#define K4_LDS_TAPS 2048       // int[<= 512]: tap codes / per-lane-group tap offsets
-#define K4_LDS_TILE 4096       // halo tile, weight block, tables
+#ifdef VS_STAMPS   // diagnostic build only (tools/build_stamps.sh, tools/stamps_k4.py): per-phase cycle sums of wave 0
+__device__ unsigned long long g_k4_stamps[2048 * 8];
+extern "C" int vs_debug_read_k4_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k4_stamps), sizeof(unsigned long long) * n);
+}
+#define K4_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk_acc[i] += now_ - tk_last; tk_last = now_; } while (0)
+#define K4_TICK_INIT unsigned long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk_last = __builtin_amdgcn_s_memtime(); tk_acc[7] = __builtin_amdgcn_s_memrealtime();
+#define K4_TICK_FLUSH do { if (threadIdx.x == 0) { tk_acc[7] = (tk_acc[7] << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull); for (int i_ = 0; i_ < 8; ++i_) g_k4_stamps[((blockIdx.y * gridDim.x + blockIdx.x) & 2047) * 8 + i_] = tk_acc[i_]; } } while (0)
+#else
+#define K4_TICK(i)
+#define K4_TICK_INIT
+#define K4_TICK_FLUSH
+#endif
+
+#define K4_LDS_RED 0           // float[4][64][2] + float[64][2]
+#define K4_LDS_TAPS 2560       // int[<= 512]: tap codes / per-lane-group tap offsets
+#define K4_LDS_TILE 4608       // halo tile, weight block, tables
 
 // tap code of a coarse neighbour (dz, dy, dx in 0..2, i.e. offset - 1 .. +1) = dz * 9 + dy * 3 + dx; 27 = none (zero weights, reads the centre)
 struct K4Geom {
@@ -40,6 +54,7 @@ struct K4Geom {
 // W1: single input-channel chunk (Cin <= 32) — the weight block is staged once, not per tile
 template <int CK, int RB, bool HS, typename T, bool W1 = (CK == 16)>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 && RB == 4 ? 1 : (CK == 16 && RB == 2 ? 3 : 2), CK == 16 && RB == 2 ? 4 : 2))) void k4t_kernel(const G1Params p) {
+    K4_TICK_INIT
     constexpr int TV = K4Geom::TV, PLANE = K4Geom::PLANE;
     constexpr int NT = CK == 32 ? 8 : 6;                 // k-groups per (row block, chunk)
     constexpr int CKB = CK * 2, U = CKB / 16, NU = TV * U, NIT = (NU + 255) / 256;
@@ -171,11 +186,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
             s_taps[tid] = (dz * PLANE + dy * 18 + dx) * CKB + (gg & 1) * 16;
         }
     }
-    for (int i = tid; i < 27 * RB * 16; i += 256) {
-        const int cls = i / (RB * 16), lr = i - cls * (RB * 16);
-        const int rbg = rb0 + lr / 16, r16 = lr & 15;
-        const int co = Co >= 16 ? (rbg % nb) * 16 + r16 : (r16 & 7);
-        s_bt[i] = (p.up_btab != nullptr && rbg < p.rb_total) ? p.up_btab[cls * Co + co] : 0.f;
+    {   // the bias table of this workgroup's rows: every thread's loads requested before the first is stored (a load -> LDS store loop waits
+        // for each in turn: seven L2 round trips in the prologue)
+        constexpr int NBT = (27 * RB * 16 + 255) / 256;
+        float bq[NBT];
+#pragma unroll
+        for (int u = 0; u < NBT; ++u) {
+            const int i = tid + u * 256;
+            const int cls = i / (RB * 16), lr = i - cls * (RB * 16);
+            const int rbg = rb0 + lr / 16, r16 = lr & 15;
+            const int co = Co >= 16 ? (rbg % nb) * 16 + r16 : (r16 & 7);
+            bq[u] = (i < 27 * RB * 16 && p.up_btab != nullptr && rbg < p.rb_total) ? p.up_btab[cls * Co + co] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < NBT; ++u)
+            if (tid + u * 256 < 27 * RB * 16) s_bt[tid + u * 256] = bq[u];
     }
     for (int i = tid; i < st_n; i += 256) {
         double st[2] = {st_pre[0], st_pre[1]};
@@ -215,6 +240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
     }
 
     const int F_D = 2 * p.D, F_H = 2 * p.H, F_W = 2 * p.W;
+    K4_TICK(0);
     for (; t < t_end; t += G) {
         const int n = cur.n, z0 = cur.z0, y0 = cur.y0, x0 = cur.x0;
         const int oz = z0 + wave;
@@ -226,10 +252,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
 
         for (int ch = 0; ch < p.nch; ++ch) {
             if (!first) __syncthreads();
+            K4_TICK(1);
             write_x(n, ch);
             if constexpr (!W1) write_w();
             first = false;
+            K4_TICK(2);
             __syncthreads();
+            K4_TICK(3);
             {
                 const bool last_ch = ch + 1 == p.nch;
                 const int tn = last_ch ? t + G : t;
@@ -246,6 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
                 for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + o + cg * 18 * CKB);
             };
             u32x4 fa[2], fb[2][4];
+            K4_TICK(4);
             read_kg(0, fa[0], fb[0]);
 #pragma unroll
             for (int i = 0; i < RB * NT; ++i) {
@@ -254,34 +284,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
                 for (int cg = 0; cg < 4; ++cg) acc[i / NT][cg] = mfma16(fa[i & 1], fb[i & 1][cg], acc[i / NT][cg], (T*)nullptr);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            K4_TICK(5);
         }
 
         // ---- epilogue: row (p, co) of coarse column v -> fine voxel 2 v + p ----
+        // (address, boundary class and validity are built from per-tile / per-row-block / per-row pieces: the epilogue is VALU-bound,
+        // ~45 instructions per stored fragment before the hoisting)
         const int ox = x0 + col;
+        const bool zx_ok = oz < p.D && ox < p.W;
+        const int e_tile = (((n * F_D + 2 * oz) * F_H + 2 * y0) * F_W + 2 * ox) * Co * 2;      // fine voxel (2 oz, 2 y0, 2 ox), channel 0
+        const int e_row = 2 * F_W * Co * 2;                                                     // one coarse row = two fine rows
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int rbg = rb0 + rb;
             int pz, py, px, co0;
             if (Co >= 16) { const int pp = rbg / nb; pz = (pp >> 2) & 1; py = (pp >> 1) & 1; px = pp & 1; co0 = (rbg % nb) * 16 + 4 * g; }
             else { pz = (rbg >> 1) & 1; py = rbg & 1; px = g >> 1; co0 = (g & 1) * 4; }
-            const bool rvalid = rbg < p.rb_total;
+            const bool rvalid = rbg < p.rb_total && zx_ok;
             const int fz = 2 * oz + pz, fx = 2 * ox + px;
             const int cz = fz == 0 ? 0 : (fz == F_D - 1 ? 2 : 1), cx = fx == 0 ? 0 : (fx == F_W - 1 ? 2 : 1);
+            const float* bt0 = s_bt + (cz * 9 + cx) * (RB * 16) + rb * 16 + 4 * g;                  // + cy * 3 * RB * 16
+            const int e_rb = e_tile + ((pz * F_H + py) * F_W + px) * Co * 2 + co0 * 2;
 #pragma unroll
             for (int cg = 0; cg < 4; ++cg) {
-                const int oy = y0 + cg;
-                const bool valid = rvalid && oz < p.D && oy < p.H && ox < p.W;
-                const int fy = 2 * oy + py;
+                const int fy = 2 * (y0 + cg) + py;
                 const int cy = fy == 0 ? 0 : (fy == F_H - 1 ? 2 : 1);
-                const float* bt = s_bt + ((cz * 3 + cy) * 3 + cx) * (RB * 16) + rb * 16 + 4 * g;
+                const f32x4 bb = *(const f32x4*)(bt0 + cy * (3 * RB * 16));
+                const bool valid = rvalid && y0 + cg < p.H;
                 f32x2 lo, hi;
-                lo[0] = acc[rb][cg][0] + bt[0]; lo[1] = acc[rb][cg][1] + bt[1];
-                hi[0] = acc[rb][cg][2] + bt[2]; hi[1] = acc[rb][cg][3] + bt[3];
+                lo[0] = acc[rb][cg][0] + bb[0]; lo[1] = acc[rb][cg][1] + bb[1];
+                hi[0] = acc[rb][cg][2] + bb[2]; hi[1] = acc[rb][cg][3] + bb[3];
                 i32x2 pk;
                 pk[0] = (int)H16<T>::pack2(lo);
                 pk[1] = (int)H16<T>::pack2(hi);
-                const int e = ((((n * F_D + fz) * F_H + fy) * F_W + fx) * Co + co0) * 2;
-                vs_raw_buffer_store_b64(pk, yrsrc, valid ? e : -1, 0, 0);
+                vs_raw_buffer_store_b64(pk, yrsrc, valid ? e_rb + cg * e_row : -1, 0, 0);
                 float v[4];
                 v[0] = H16<T>::lo((unsigned int)pk[0]); v[1] = H16<T>::hi((unsigned int)pk[0]);
                 v[2] = H16<T>::lo((unsigned int)pk[1]); v[3] = H16<T>::hi((unsigned int)pk[1]);
@@ -290,6 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
                 for (int r = 0; r < 4; ++r) { ssum[rb][r] += v[r]; ssq[rb][r] += v[r] * v[r]; }
             }
         }
+        K4_TICK(6);
         if (p.y_stats != nullptr) {
             const bool flush = t + G >= t_end || nxt.n != n;
             if (flush) {
@@ -297,9 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float s = ssum[rb][r], q = ssq[rb][r];
-#pragma unroll
-                        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                        const float s = row16_sum(ssum[rb][r]), q = row16_sum(ssq[rb][r]);
                         if (col == 0) {
                             const int lr = rb * 16 + 4 * g + r;
                             s_red[(wave * 64 + lr) * 2 + 0] = s;
@@ -308,19 +343,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
                         ssum[rb][r] = 0.f; ssq[rb][r] = 0.f;
                     }
                 __syncthreads();
-                // rows of equal output channel (the parities) are folded first: one contribution per (workgroup, channel, statistic)
+                // rows of equal output channel (the parities) are folded first: one contribution per (workgroup, channel, statistic).
+                // Two short passes (a single pass — 16 threads walking all 64 rows with the channel test — was 7 us per flush, two thirds of the
+                // kernel): every (row, statistic) sums its four waves, then every (channel, statistic) its rows, which lie `ndist` apart.
                 const int ndist = Co >= 16 ? (RB < nb ? RB : nb) * 16 : 8;
+                float* s_row = s_red + 4 * 64 * 2;           // [RB * 16][2] (behind the per-wave partials)
+                if (tid < RB * 16 * 2) {
+                    const int lr = tid >> 1, st = tid & 1;
+                    s_row[tid] = ((rb0 + lr / 16) < p.rb_total)
+                                     ? (s_red[(0 * 64 + lr) * 2 + st] + s_red[(1 * 64 + lr) * 2 + st]) + (s_red[(2 * 64 + lr) * 2 + st] + s_red[(3 * 64 + lr) * 2 + st])
+                                     : 0.f;
+                }
+                __syncthreads();
                 if (tid < ndist * 2) {
                     const int ci = tid >> 1, st = tid & 1;
-                    const int cb = Co >= 16 ? ((rb0 % nb) + ci / 16) % nb : 0;
-                    const int co = Co >= 16 ? cb * 16 + (ci & 15) : ci;
+                    // local rows of this channel: Co = 8: ci, ci + 8, ...; Co >= 16: row (ci & 15) of the row blocks whose co-block is ci / 16 (every nb-th, or one)
                     double tot = 0.0;
-                    for (int lr = 0; lr < RB * 16; ++lr) {
-                        const int rbg = rb0 + lr / 16;
-                        const int co_r = Co >= 16 ? (rbg % nb) * 16 + (lr & 15) : (lr & 7);
-                        if (co_r == co && rbg < p.rb_total)
-                            tot += (double)s_red[(0 * 64 + lr) * 2 + st] + (double)s_red[(1 * 64 + lr) * 2 + st] +
-                                   (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
+                    int co;
+                    if (Co >= 16) {
+                        const int cbl = ci >> 4;                                          // index among this workgroup's distinct co-blocks
+                        co = (((rb0 % nb) + cbl) % nb) * 16 + (ci & 15);
+                        for (int rb = cbl; rb < RB; rb += (RB < nb ? RB : nb)) tot += (double)s_row[(rb * 16 + (ci & 15)) * 2 + st];
+                    } else {
+                        co = ci;
+                        for (int lr = ci; lr < RB * 16; lr += 8) tot += (double)s_row[lr * 2 + st];
                     }
                     stat_add(p.y_stats, (size_t)n * Co + co, (size_t)p.N * Co, st, tot);
                 }
@@ -328,7 +374,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CK == 32 &&
             }
         }
         cur = nxt;
+        K4_TICK(1);            // (diagnostic build: the statistics flush is booked under slot 1)
     }
+    K4_TICK_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -579,8 +627,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float s = ssum[rb][r], q = ssq[rb][r];
-#pragma unroll
-                        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                        { s = row16_sum(s); q = row16_sum(q); }      // DPP: the four-step __shfl_xor butterfly was four ds_bpermute round trips per statistic
                         if (col == 0) {
                             const int lr = rb * 16 + 4 * g + r;
                             s_red[(wave * 64 + lr) * 2 + 0] = s;

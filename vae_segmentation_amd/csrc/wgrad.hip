@@ -378,6 +378,38 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         __syncthreads();
         if (t + p.ksplit < p.total_tiles) request(t + p.ksplit);
         // ---- two K-steps of 32 voxels: y rows (2s, 2s+1) of this wave's z-slice ----
+        if constexpr (CB == 16 && KIND != G3_K2S2) {
+            // 16-channel 3x3x3 blocks: tap (dz, dy, dx) of K-step s needs the Q rows (2s + dy, 2s + dy + 1) of plane wave + dz at x shift dx —
+            // the six rows of a plane serve all (s, dy): each row fragment is read ONCE per (dz, dx) (18 transposing reads per plane) and the
+            // B operands are register pairs of them, instead of 2 reads per MFMA (the kernel is bound by these reads: 112 -> 58 per tile and wave)
+            const int xr = 4 * g + q4;
+            u32x4 a2[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int pa0 = (((wave * 4 + 2 * s) * 16 + xr) * 32) + p4 * 8;
+                a2[s] = tr_pair(s_p, pa0, pa0 + 16 * 32);
+            }
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                s16x4 rr[6][3];
+#pragma unroll
+                for (int yr = 0; yr < 6; ++yr)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        rr[yr][dx] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s_q + (((wave + dz) * QY + yr) * QX + xr + dx) * QROW + p4 * 8));
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            typedef __attribute__((ext_vector_type(8))) short s16x8;
+                            const s16x8 v = __builtin_shufflevector(rr[2 * s + dy][dx], rr[2 * s + dy + 1][dx], 0, 1, 2, 3, 4, 5, 6, 7);
+                            const int k = dz * 9 + dy * 3 + dx;
+                            acc[k] = mfma16(a2[s], __builtin_bit_cast(u32x4, v), acc[k], (T*)nullptr);
+                        }
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int xr = 4 * g + q4;                                   // this lane's tr-read row: voxel x
