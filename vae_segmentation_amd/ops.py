@@ -1187,11 +1187,15 @@ FUSE_UP = os.environ.get("VS_FUSE_UP", "1") != "0"
 # (isolated, forward / backward-data against the pair: 24^3 x 32: 26.8 / 17.8 us vs 32 / 19; 12^3 x 64: 16.5 / 19.1 vs 24 / 19; in the replayed
 # step the pair is faster than in isolation and the composed form measured +0.05 ms when enabled at every level).
 FUSE_UP_MIN_VOXELS = int(os.environ.get("VS_FUSE_UP_MIN_VOXELS", str(44 ** 3)))
-# Trainable weights through the composed head: built and parity-green (tests/test_gpu_up.py: dW3, dW2, db2 against autograd), but not yet a
-# win in the replayed 96^3 step — the weight-gradient side gains 40 us (the largest layer of the 16-channel bucket leaves it, the transposed
-# conv's weight gradient and its 113 MB operand disappear) and the per-step helpers give 80 back (re-composition 32 us, boundary sums 21,
-# chain rule 28: single-digit-microsecond work in launches bound by their dependent round trips): 2.69 vs 2.66 ms, same box.  Off by default.
-FUSE_UP_TRAINABLE = os.environ.get("VS_FUSE_UP_TRAINABLE", "0") == "1"
+# Trainable weights through the composed head (tests/test_gpu_up.py: dW3, dW2, db2 against autograd): the weight-gradient side gains (the largest
+# layer of the 16-channel bucket leaves it, the transposed conv's weight gradient and its full-resolution operand disappear) and the per-step
+# helpers cost ~80 us whatever the volume (re-composition 32, boundary sums 21, chain rule 28: microseconds of work in launches bound by
+# their dependent round trips).  Measured, same box: 96^3 B=2 (2 x 48^3 coarse voxels) 2.69 vs 2.66 ms and 128^3 B=1 (64^3) 3.87 vs 3.84 — a loss;
+# 160^3 B=2 (2 x 80^3) 6.84 vs 7.19 ms — a 5 % gain.  Enabled from FUSE_UP_TRAINABLE_MIN_VOXELS coarse voxels (batch included) up;
+# VS_FUSE_UP_TRAINABLE=0 / 1 forces it off / on.
+_FUT = os.environ.get("VS_FUSE_UP_TRAINABLE", "")
+FUSE_UP_TRAINABLE = _FUT != "0"
+FUSE_UP_TRAINABLE_MIN_VOXELS = 0 if _FUT == "1" else int(os.environ.get("VS_FUSE_UP_TRAINABLE_MIN_VOXELS", "500000"))     # coarse voxels of the whole batch
 
 
 def _up_stamp(wt, bt, w3):
@@ -1258,6 +1262,8 @@ def up_composed_ok(x, tconv, conv3):
     if tuple(wt.shape[2:]) != (2, 2, 2) or tuple(w3.shape[2:]) != (3, 3, 3) or w3.shape[1] != wt.shape[1] or x.shape[-1] != wt.shape[0]:
         return False
     if x.shape[1] * x.shape[2] * x.shape[3] < FUSE_UP_MIN_VOXELS:
+        return False
+    if trainable and x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] < FUSE_UP_TRAINABLE_MIN_VOXELS:
         return False
     return bool(lib.vs_up_supported(wt.shape[0], wt.shape[1], w3.shape[0], vs_dtype(x)))
 
