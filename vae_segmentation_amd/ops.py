@@ -1181,12 +1181,11 @@ class ConvT2S2(torch.autograd.Function):
 # composed Up block head: ConvTranspose3d(C, C, 2, stride 2) -> Conv3d(C, Co, 3, padding 1) as one operator (csrc/igemm_k4.h)
 # ------------------------------------------------------------------------------------------------
 FUSE_UP = os.environ.get("VS_FUSE_UP", "1") != "0"
-# composed where it is measured faster than the two-launch pair: the large levels, where the intermediate tensor is HBM traffic (96^3 step, same
-# box: coarse 48^3 x 16 forward 34 us against 27.6 + 19.7, backward-data 29 against 34 + 12.4).  On the small coarse grids (<= 24^3) the
-# 4x4x16-tile kernels of igemm_k4.h are latency-bound by their many short chunk stages (backward: 8 Co / 32 chunks of 8 taps) and lose or tie
-# (isolated, forward / backward-data against the pair: 24^3 x 32: 26.8 / 17.8 us vs 32 / 19; 12^3 x 64: 16.5 / 19.1 vs 24 / 19; in the replayed
-# step the pair is faster than in isolation and the composed form measured +0.05 ms when enabled at every level).
-FUSE_UP_MIN_VOXELS = int(os.environ.get("VS_FUSE_UP_MIN_VOXELS", str(44 ** 3)))
+# composed where it is measured faster than the two-launch pair.  Same-box sweep of this threshold on the 96^3 step (frozen VAE heads only),
+# coarse voxels per sample: 48^3 only 2.551 ms; + 24^3 2.531; + 12^3 2.517; + 6^3 2.523; + 3^3 2.550 — on the 6^3 / 3^3 grids the 4x4x16-tile
+# kernels of igemm_k4.h are mostly padding and their backward walks 8 Co / 32 short chunk stages.  At 160^3 (coarse 80^3 / 40^3 / 20^3 ...):
+# 6.99 -> 6.88 ms once the 40^3 level is in.  Isolated kernels, forward / backward-data: 48^3 x 16: 19.8 / 20.0 us (pair: 27.6 + 19.7 / 34 + 12.4).
+FUSE_UP_MIN_VOXELS = int(os.environ.get("VS_FUSE_UP_MIN_VOXELS", "1000"))
 # Trainable weights through the composed head (tests/test_gpu_up.py: dW3, dW2, db2 against autograd): the weight-gradient side gains (the largest
 # layer of the 16-channel bucket leaves it, the transposed conv's weight gradient and its full-resolution operand disappear) and the per-step
 # helpers cost ~80 us whatever the volume (re-composition 32, boundary sums 21, chain rule 28: microseconds of work in launches bound by
