@@ -211,7 +211,10 @@ def step_roofline(dtype, ms_per_step, families):
            "hbm": {"achieved": nbytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS}}
     lead = "hbm" if t_hbm >= t_mfma else "mfma"
     out.update({"bound": lead, "achieved": out[lead]["achieved"], "peak": out[lead]["peak"], "unit": out[lead]["unit"], "frac": out[lead]["frac"],
-                "traffic": profiling.measured_step_traffic()})
+                "traffic": profiling.measured_step_traffic(),
+                # `traffic` comes from the newest committed PMC summary (profiles/rNN_hbm_traffic.json), not from this run: true here means that
+                # summary was taken on other kernel sources than the ones that just ran
+                "traffic_stale": profiling.traffic_is_stale()})
     if families is not None:
         out["families"] = families
     return out

@@ -3,7 +3,8 @@ prescribes: counters are in KiB; on gfx950 FETCH_SIZE reports half of a wide coa
 usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <step_equivalents_in_the_run | auto> [out.json]
 (step equivalents: every forward+backward pass of the bf16 step in the run — bench.py's eager warm-up and family-timing passes, --warmup,
 --steps; launches per step = sampled launches / that.  auto: the launches of the once-per-pass grouped weight-gradient kernel)"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(d, counter):
@@ -29,6 +30,11 @@ for k in fetch:
     if "spin_kernel" not in k:
         total += b * n / steps
 out["_step_total_bytes"] = total
+try:                                   # which kernel sources this was measured on (bench.py flags `traffic_stale` when they differ from the tree's)
+    from vae_segmentation_amd import profiling
+    out["_sources_sha16"] = profiling.sources_sha()
+except Exception as exc:               # the summary is still worth having
+    print("no source hash:", exc)
 print("HBM traffic per step (FETCH_SIZE x2 + WRITE_SIZE over all kernels): %.3f GB" % (total / 1e9))
 for k, v in sorted(((k, v) for k, v in out.items() if isinstance(v, dict)), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_sampled"])[:14]:
     print("%-72s %6.1f/step %9.2f MB/launch (fetch x2 %.2f MB, write %.2f MB)" % (k[:72], v["launches_per_step"], v["hbm_bytes_per_launch"] / 1e6,

@@ -47,13 +47,15 @@ if which in ("all", "da128"):
                lambda: T.domain_adaptation_losses(s, t, img, lab, lambda_vae=1.0, domain_loss_type=lt, host_schedule=False), params, opt, 1)
         del s, t; torch.cuda.empty_cache()
 if which in ("all", "joint160"):
-    for dtype in ("fp16", "bf16"):
+    for dtype, recompute in (("fp16", False), ("bf16", False), ("bf16", True)):
+        M.set_recompute(recompute)                       # activations of the Down / Up blocks rebuilt in backward
         j = joint(160, dtype)
         img, lab = O.synthetic_image(2, 160, 2).cuda(), O.synthetic_label(2, 160, 3).cuda()
         params = list(j.Seg.parameters()); opt = optim.SGD(params, lr=1e-2, momentum=0.9)
-        timeit("configs[4] (one GPU's share): 160^3 joint_train B=2 %s%s" % (dtype, " + dynamic loss scale" if dtype == "fp16" else ""),
+        timeit("configs[4] (one GPU's share): 160^3 joint_train B=2 %s%s%s" % (dtype, " + dynamic loss scale" if dtype == "fp16" else "", " + activation recomputation" if recompute else ""),
                lambda: T.joint_train_losses(j, img, lab), params, opt, 2, scaler=optim.LossScaler() if dtype == "fp16" else None)
         del j; torch.cuda.empty_cache()
+    M.set_recompute(False)
 if which in ("all", "fp32"):
     j = joint(96, "fp32")
     img, lab = O.synthetic_image(2, 96, 2).cuda(), O.synthetic_label(2, 96, 3).cuda()

@@ -65,6 +65,32 @@ def collect(fwd_bwd, params, steps=2):
     return agg
 
 
+def sources_sha():
+    """sha256 (first 16 hex digits) over the kernel sources (csrc/*.hip, *.h, *.inc and include/vaeseg.h): stored with a PMC traffic summary
+    (tools/pmc_traffic.py) so that a bench line can tell whether its `traffic` figure was measured on the kernels it ran."""
+    import glob
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "vae_segmentation_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "vae_segmentation_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(root, "vae_segmentation_amd", "csrc", "*.inc")) + [os.path.join(root, "include", "vaeseg.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_is_stale(path=None):
+    """True when the newest committed PMC summary was taken on different kernel sources than the ones in the tree (or carries no hash)."""
+    import json
+    try:
+        table = json.load(open(path or _traffic_path()))
+    except Exception:
+        return None
+    return table.get("_sources_sha16") != sources_sha()
+
+
 def _traffic_path():
     import glob
     import os
@@ -94,6 +120,7 @@ FAMILIES = (
     ("conv3x3x3, 16-channel layers (k3b<16|8,..>)", lambda k: k.startswith("k3b_kernel<16") or k.startswith("k3b_kernel<8")),
     ("conv3x3x3, 8-channel full-resolution layers (k3t)", lambda k: k.startswith("k3t_kernel")),
     ("conv3x3x3, fp32 kernels (k3_kernel<float>)", lambda k: k.startswith("k3_kernel")),
+    ("composed Up heads: transposed conv + 3x3x3 as one operator (k4t, k4g)", lambda k: k.startswith("k4t_kernel") or k.startswith("k4g_kernel")),
     ("stride-2 / transposed convs (g1)", lambda k: k.startswith("g1_kernel")),
     ("weight gradients (grouped)", lambda k: k.startswith("wgrad_multi") or k.startswith("g3")),
     ("InstanceNorm+ReLU backward apply", lambda k: k.startswith("in_relu_bwd")),
