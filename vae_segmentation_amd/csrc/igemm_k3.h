@@ -16,7 +16,10 @@
 #define K3_LDS_TAPS 2048      // int[64]
 #define K3_LDS_TILE 2304      // halo tile, then mean/rstd tables float[2][N*C]
 
-template <typename T, int CK, int MT, int EPI>
+// YT: rows of 16 voxels per wave (tile 4 x YT x 16).  The exact-f32 MFMA runs at 1/16 of the 16-bit rate, so the fp32 layers are bound by MFMA cycles
+// per wave; at the 12^3 / 24^3 levels a 4x4x16 tiling yields 72-288 workgroups for 1024 SIMDs and one wave carries 4 column groups x all of K:
+// shorter tiles (more halo, which is L2-resident there) spread the same MFMAs over 4x the waves.
+template <typename T, int CK, int MT, int EPI, int YT = 4>
 __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     using E = ET<T>;
     constexpr int EPL = E::EPL, KG = E::KG;
@@ -27,15 +30,16 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     constexpr int TPK = KG > CK ? KG / CK : 1;
     constexpr int KPT = KG > CK ? 1 : CK / KG;
     constexpr int U = CKB / 16;
-    constexpr int NU = G1_TILE_VOX * U;
+    constexpr int PLANE = (YT + 2) * 18, TVOX = 6 * PLANE;     // staged halo voxels
+    constexpr int NU = TVOX * U;
     constexpr int NIT = (NU + 255) / 256;
-    constexpr bool PF = NIT <= 12;                       // prefetch the next stage into registers while computing
+    constexpr bool PF = NIT <= 14;                       // prefetch the next stage into registers while computing
     constexpr int SB = PF ? NIT : (NIT + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_red = (float*)(smem + K3_LDS_RED);
     int* s_taps = (int*)(smem + K3_LDS_TAPS);
     char* s_tile = smem + K3_LDS_TILE;
-    float* s_mean = (float*)(s_tile + G1_TILE_VOX * CKB);
+    float* s_mean = (float*)(s_tile + TVOX * CKB);
     float* s_rstd = s_mean + p.N * p.C;
     float* s_mkm = s_rstd + p.N * p.C;                   // mean / rstd of the mask tensor's channels (fused IN-bwd sums)
     float* s_mkr = s_mkm + p.N * p.M;
@@ -65,11 +69,11 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     if (tid < 32) {
         const int t = tid < 27 ? tid : 13;
         const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-        s_taps[tid] = ((dz * 6 + dy) * 18 + dx) * CKB;
+        s_taps[tid] = (dz * PLANE + dy * 18 + dx) * CKB;
     }
-    int lds_base[4];
+    int lds_base[YT];
 #pragma unroll
-    for (int cg = 0; cg < 4; ++cg) lds_base[cg] = ((wave * 6 + cg) * 18 + col) * CKB + ((g * EPL) % CK) * (int)sizeof(T);
+    for (int cg = 0; cg < YT; ++cg) lds_base[cg] = (wave * PLANE + cg * 18 + col) * CKB + ((g * EPL) % CK) * (int)sizeof(T);
 
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
     const size_t rb_stride = (size_t)p.nch * NKG * 64;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
         for (int b = 0; b < SB; ++b) {
             const int u = tid + b * 256;
             const int tv = u / U, part = u - tv * U;
-            const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / 108;
+            const int tx_ = tv % 18, ty_ = (tv / 18) % (YT + 2), tz_ = tv / PLANE;
             rel_off[b] = ((tz_ * p.H + ty_) * p.W + tx_) * p.C + part * EPL;
             tzyx[b] = u < NU ? (tz_ | (ty_ << 8) | (tx_ << 16)) : 0x00ffffff;      // out-of-list fragments fail every bounds test
             lds_w[b] = tv * CKB + part * 16;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
         n = t / p.tiles_per_sample;
         const int tl = t - n * p.tiles_per_sample;
         x0 = (tl % p.txn) * 16;
-        y0 = ((tl / p.txn) % p.tyn) * 4;
+        y0 = ((tl / p.txn) % p.tyn) * YT;
         z0 = (tl / (p.txn * p.tyn)) * 4;
     };
     auto stage_load = [&](int t, int ch, int it0) {
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
             for (int b = 0; b < SB; ++b) {
                 const int u = tid + (it0 + b) * 256;
                 const int tv = u / U, part = u - tv * U;
-                const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / 108;
+                const int tx_ = tv % 18, ty_ = (tv / 18) % (YT + 2), tz_ = tv / PLANE;
                 const int gz = z0 + tz_ - 1, gy = y0 + ty_ - 1, gx = x0 + tx_ - 1;
                 ok[b] = (it0 + b < NIT) && u < NU && gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
                 const size_t e = ok[b] ? ((((size_t)n * p.D + gz) * p.H + gy) * p.W + gx) * p.C + ch * CK + part * EPL : 0;
@@ -158,11 +162,11 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     for (; t < total_tiles; t += gridDim.x) {
         int n, z0, y0, x0;
         tile_origin(t, n, z0, y0, x0);
-        f32x4 acc[RB][4];
+        f32x4 acc[RB][YT];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cg = 0; cg < YT; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int ch = 0; ch < p.nch; ++ch) {
             if constexpr (PF) {
@@ -193,13 +197,13 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
                     const int toff = s_taps[kg * TPK + sub];
-                    u32x4 b[4];
+                    u32x4 b[YT];
 #pragma unroll
-                    for (int cg = 0; cg < 4; ++cg) b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff);
+                    for (int cg = 0; cg < YT; ++cg) b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff);
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                        for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
+                        for (int cg = 0; cg < YT; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
                 }
             } else {
                 constexpr int NK = NTAPS * KPT;
@@ -215,26 +219,26 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                 auto lds_off = [&](int kg) {
                     const int tap = kg / KPT, kk = kg - tap * KPT;
                     const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
-                    return ((dz * 6 + dy) * 18 + dx) * CKB + kk * KG * (int)sizeof(T);
+                    return (dz * PLANE + dy * 18 + dx) * CKB + kk * KG * (int)sizeof(T);
                 };
-                u32x4 bnext[4];
+                u32x4 bnext[YT];
 #pragma unroll
-                for (int cg = 0; cg < 4; ++cg) bnext[cg] = *(const u32x4*)(s_tile + lds_base[cg] + lds_off(0));
+                for (int cg = 0; cg < YT; ++cg) bnext[cg] = *(const u32x4*)(s_tile + lds_base[cg] + lds_off(0));
 #pragma unroll 1
                 for (int kgb = 0; kgb < NK; kgb += PD) {
 #pragma unroll
                     for (int j = 0; j < PD; ++j) {
                         const int kg = kgb + j;
                         if (kg < NK) {
-                            u32x4 a[RB], b[4];
+                            u32x4 a[RB], b[YT];
 #pragma unroll
                             for (int rb = 0; rb < RB; ++rb) a[rb] = abuf[j][rb];
 #pragma unroll
-                            for (int cg = 0; cg < 4; ++cg) b[cg] = bnext[cg];
+                            for (int cg = 0; cg < YT; ++cg) b[cg] = bnext[cg];
                             if (kg + 1 < NK) {
                                 const int o = lds_off(kg + 1);
 #pragma unroll
-                                for (int cg = 0; cg < 4; ++cg) bnext[cg] = *(const u32x4*)(s_tile + lds_base[cg] + o);
+                                for (int cg = 0; cg < YT; ++cg) bnext[cg] = *(const u32x4*)(s_tile + lds_base[cg] + o);
                             }
                             if (kg + PD < NK) {
 #pragma unroll
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
 #pragma unroll
                             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                                for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
+                                for (int cg = 0; cg < YT; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
                         }
                     }
                 }
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                 const float b0 = p.bias ? p.bias[0] : 0.f, b1 = p.bias ? p.bias[1] : 0.f;
                 const size_t V = (size_t)p.D * p.H * p.W;
 #pragma unroll
-                for (int cg = 0; cg < 4; ++cg) {
+                for (int cg = 0; cg < YT; ++cg) {
                     const int oy = y0 + cg, ox = x0 + col;
                     if (!(oz < p.D && oy < p.H && ox < p.W)) continue;
                     float l0 = acc[0][cg][0] + b0, l1 = acc[0][cg][1] + b1;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                     for (int r = 0; r < 4; ++r) bv[r] = p.bias[row + r];
                 }
 #pragma unroll
-                for (int cg = 0; cg < 4; ++cg) {
+                for (int cg = 0; cg < YT; ++cg) {
                     const int oy = y0 + cg, ox = x0 + col;
                     if (!(rvalid && oz < p.D && oy < p.H && ox < p.W)) continue;
                     float v[4];
@@ -360,12 +364,18 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     }
 }
 
-template <typename T, int CK, int MT, int EPI>
-static int k3_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
+template <typename T, int CK, int MT, int EPI, int YT = 4>
+static int k3_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
+    G1Params p = p_in;
+    if (YT != 4) {                                       // re-tile the volume in 4 x YT x 16 tiles
+        p.tyn = (p.H + YT - 1) / YT;
+        p.tiles_per_sample = ((p.D + 3) / 4) * p.tyn * p.txn;
+        tiles_total = p.tiles_per_sample * p.N;
+    }
     const size_t tables = (size_t)2 * p.N * p.C * sizeof(float) + (p.sums ? (size_t)2 * p.N * p.M * sizeof(float) : 0);
-    const size_t lds = K3_LDS_TILE + (size_t)G1_TILE_VOX * CK * sizeof(T) + tables;
+    const size_t lds = K3_LDS_TILE + (size_t)6 * (YT + 2) * 18 * CK * sizeof(T) + tables;
     if (lds > 160 * 1024) return VS_ESHAPE;
-    auto kern = k3_kernel<T, CK, MT, EPI>;
+    auto kern = k3_kernel<T, CK, MT, EPI, YT>;
     // idempotent one-time opt-in to the full 160 KiB of dynamic LDS (not a stream operation)
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

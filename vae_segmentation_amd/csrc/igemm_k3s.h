@@ -13,6 +13,12 @@
 #include <stdlib.h>
 #include "igemm.h"
 
+#ifndef K3_TICK                // phase stamps exist in the 16-bit translation units only (igemm_k3b.h)
+#define K3_TICK(i)
+#define K3_TICK_INIT
+#define K3_TICK_FLUSH
+#endif
+
 #define K3S_LDS_RED 0          // float[4][16][2]
 #define K3S_LDS_TILE 512
 // then: padded sample chunk [TV][64 B] (at least 16 KB: the cross-wave partials alias it), scale / shift tables [C] each
@@ -20,13 +26,18 @@
 // TVC: compile-time bound of the padded voxel count (128: up to 3x3x3, 512: up to 6x6x6) -> staging fragments per thread
 // HS: the input is a lazy activation (normalise + ReLU while staging) — compile-time, like every other condition on the staging path: a
 // run-time test between a load and its use makes the compiler drain vmcnt(0), i.e. wait for the prefetched stages as well
-// T: unsigned short (bf16 bits) or vs_half (fp16); last template argument (kernel-name prefix unchanged)
+// T: unsigned short (bf16 bits), vs_half (fp16) or float; last template argument (kernel-name prefix unchanged).  A STAGE is 64 bytes per voxel
+// in every type: a 32-channel chunk of the 16-bit types, HALF a chunk (16 channels, one of the two k-groups the packed image holds per tap) of
+// fp32 — the exact-f32 MFMA runs at 1/16 of the 16-bit rate, so for fp32 the tap split over the waves and the unpadded columns matter even more
+// (k3_kernel at 6^3 x 128: 81 us, at 3^3 x 256: 142 us).
 template <bool SUMS, int TVC, bool HS, typename T = unsigned short>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k3s_kernel(const G1Params p) {
     K3_TICK_INIT
     constexpr int NIT = TVC * 4 / 256;                   // 16-byte fragments per thread per stage
     constexpr int NWI = 7;                               // weight fragments per thread per stage (27 * 64 / 256)
     constexpr int NKW = 7;                               // taps per wave per chunk (wave w: w, w + 4, ...)
+    constexpr int ES = (int)sizeof(T), EPL = 16 / ES, CHS = 64 / ES;     // element size, elements per fragment, channels per stage
+    constexpr int SPC = 32 / CHS;                        // stages per 32-channel chunk of the packed weight image (1, or 2 for fp32)
     constexpr int NCG = TVC == 128 ? 2 : 4;              // 16-column groups that can hold voxels: up to 3x3x3 = 27 voxels fill two (the other two were 4.5 of 13 us of MFMA phase on padding)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_red = (float*)(smem + K3S_LDS_RED);
@@ -40,7 +51,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int n = blockIdx.x / p.tiles_per_sample, ct = blockIdx.x - n * p.tiles_per_sample;
     const int rb0 = blockIdx.y;                          // 16-row block
     constexpr bool has_stats = HS;
-    const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * V * p.C * 2));
+    const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * V * p.C * ES));
+    const int nst = p.nch * SPC;                         // stages
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
 
     // a / d for 0 <= a < 2048, 1 <= d <= 10 (everything here is that small): one multiply instead of a ~45-instruction integer
@@ -56,7 +68,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const int pv = (tid >> 2) + 64 * b;
         const int t2 = sdiv(pv, inv_px), px = pv - t2 * PX, pz = sdiv(t2, inv_py), py = t2 - pz * PY;
         const bool ok = pv < TV && px >= 1 && px <= p.W && py >= 1 && py <= p.H && pz >= 1 && pz <= p.D;
-        goff[b] = ok ? ((((n * p.D + pz - 1) * p.H + py - 1) * p.W + px - 1) * p.C + part * 8) * 2 : -1;
+        goff[b] = ok ? ((((n * p.D + pz - 1) * p.H + py - 1) * p.W + px - 1) * p.C + part * EPL) * ES : -1;
         swzbits |= (unsigned int)((px >> 2) & 1) << b;
     }
     // weights: with the taps split over the waves, tap (wave + 4 i)'s A fragment is used by this wave only — it goes from global
@@ -65,31 +77,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
         const int kg = (tid >> 6) + 4 * i < 27 ? (tid >> 6) + 4 * i : 26;
-        w_off[i] = rb0 * (p.nch * 27 * 64) + kg * 64 + (tid & 63);          // + ch * 27 * 64
+        w_off[i] = rb0 * (p.nch * 27 * 64 * SPC) + kg * (64 * SPC) + (tid & 63);          // + (st / SPC) * 27 * 64 * SPC + (st % SPC) * 64
     }
     // two stages in flight (registers): with the MFMA phase this short, a stage requested only one stage ahead arrived late every time
     u32x4 xv0[NIT], wv0[NWI], xv1[NIT], wv1[NWI];
     auto load_stage = [&](int ch, u32x4 (&xv)[NIT], u32x4 (&wv)[NWI]) {
 #pragma unroll
-        for (int i = 0; i < NWI; ++i) wv[i] = wp[w_off[i] + ch * (27 * 64)];
+        for (int i = 0; i < NWI; ++i) wv[i] = wp[w_off[i] + (ch / SPC) * (27 * 64 * SPC) + (ch % SPC) * 64];
 #pragma unroll
         for (int b = 0; b < NIT; ++b)
             xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, goff[b] >= 0 ? goff[b] + ch * 64 : -1, 0, 0));
     };
     auto write_stage = [&](int ch, const u32x4 (&xv)[NIT], const u32x4 (&wv)[NWI]) {
-        f32x2 sc[4], sh[4];
+        f32x2 sc[4], sh[4];                              // 16-bit: 8 channels; fp32: 4 (sc[0..1], sh[0..1])
         if (has_stats) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sc[i] = *(const f32x2*)(s_scale + ch * 32 + part * 8 + 2 * i);
-                sh[i] = *(const f32x2*)(s_shift + ch * 32 + part * 8 + 2 * i);
+            for (int i = 0; i < EPL / 2; ++i) {
+                sc[i] = *(const f32x2*)(s_scale + ch * CHS + part * EPL + 2 * i);
+                sh[i] = *(const f32x2*)(s_shift + ch * CHS + part * EPL + 2 * i);
             }
         }
 #pragma unroll
         for (int b = 0; b < NIT; ++b) {
             u32x4 v = xv[b];
             if (has_stats) {
-                const u32x4 a = act8<T>(v, sc, sh);
+                u32x4 a;
+                if constexpr (ES == 2) a = act8<T>(v, sc, sh);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned int w = v[i];      // (a bit_cast applied to the vector element itself is mis-compiled: common.h, fp16 unpack)
+                        const float scale = i & 1 ? sc[i >> 1][1] : sc[i >> 1][0], shift = i & 1 ? sh[i >> 1][1] : sh[i >> 1][0];
+                        a[i] = __float_as_uint(fmaxf(__uint_as_float(w) * scale + shift, 0.f));
+                    }
+                }
                 const bool ok = goff[b] >= 0;             // zero padding applies to the normalised activation
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
@@ -102,7 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 
     // ---- first stage in flight; tables; per-lane read offsets ----------------------------------------------------------------
     load_stage(0, xv0, wv0);
-    if (p.nch > 1) load_stage(1, xv1, wv1);
+    if (nst > 1) load_stage(1, xv1, wv1);
     if (has_stats) {
         for (int c = tid; c < p.C; c += 256) {
             float m, r;
@@ -173,7 +194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma16(a, b[cg], acc[cg], (T*)nullptr);
         }
     };
-    for (int ch = 0; ch < p.nch; ch += 2) {
+    for (int ch = 0; ch < nst; ch += 2) {
         if (ch > 0) __syncthreads();                     // every wave is done reading the previous stage
         K3_TICK(1);
         write_stage(ch, xv0, wv0);
@@ -182,11 +203,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         K3_TICK(3);
 #pragma unroll
         for (int i = 0; i < NKW; ++i) wa[i] = wv0[i];
-        if (ch + 2 < p.nch) load_stage(ch + 2, xv0, wv0);
+        if (ch + 2 < nst) load_stage(ch + 2, xv0, wv0);
         K3_TICK(4);
         multiply();
         K3_TICK(5);
-        if (ch + 1 < p.nch) {
+        if (ch + 1 < nst) {
             __syncthreads();
             K3_TICK(1);
             write_stage(ch + 1, xv1, wv1);
@@ -195,7 +216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             K3_TICK(3);
 #pragma unroll
             for (int i = 0; i < NKW; ++i) wa[i] = wv1[i];
-            if (ch + 3 < p.nch) load_stage(ch + 3, xv1, wv1);
+            if (ch + 3 < nst) load_stage(ch + 3, xv1, wv1);
             K3_TICK(4);
             multiply();
             K3_TICK(5);
@@ -219,29 +240,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     // ---- epilogue: column voxel v of sample n, rows row0 .. row0 + 3 ---------------------------------------------------------------------
     const int v = ct * 64 + wave * 16 + col;
     const bool valid = v < V && row0 < p.M && wave < NCG;
-    const int e = ((n * V + v) * p.M + row0) * 2;        // byte offset in y (and in the mask tensor)
-    const i32x4 yrsrc = make_rsrc(p.y, (unsigned int)((long long)p.N * V * p.M * 2));
-    u32x2 mk = u32x2{0u, 0u};
+    const int e = ((n * V + v) * p.M + row0) * ES;       // byte offset in y (and in the mask tensor)
+    const i32x4 yrsrc = make_rsrc(p.y, (unsigned int)((long long)p.N * V * p.M * ES));
+    float xv4[4] = {0.f, 0.f, 0.f, 0.f};                 // SUMS: the mask tensor's values under this lane's outputs
     if constexpr (SUMS) {
-        const i32x4 mrsrc = make_rsrc(p.mask_x, (unsigned int)((long long)p.N * V * p.M * 2));
-        mk = __builtin_bit_cast(u32x2, vs_raw_buffer_load_b64(mrsrc, valid ? e : -1, 0, 0));
+        const i32x4 mrsrc = make_rsrc(p.mask_x, (unsigned int)((long long)p.N * V * p.M * ES));
+        if constexpr (ES == 2) {
+            const u32x2 mk = __builtin_bit_cast(u32x2, vs_raw_buffer_load_b64(mrsrc, valid ? e : -1, 0, 0));
+            xv4[0] = H16<T>::lo(mk[0]); xv4[1] = H16<T>::hi(mk[0]);
+            xv4[2] = H16<T>::lo(mk[1]); xv4[3] = H16<T>::hi(mk[1]);
+        } else {
+            const f32x4 mk = __builtin_bit_cast(f32x4, vs_raw_buffer_load_b128(mrsrc, valid ? e : -1, 0, 0));
+            xv4[0] = mk[0]; xv4[1] = mk[1]; xv4[2] = mk[2]; xv4[3] = mk[3];
+        }
     }
-    f32x2 lo, hi;
-    lo[0] = o[0] + bv[0]; lo[1] = o[1] + bv[1];
-    hi[0] = o[2] + bv[2]; hi[1] = o[3] + bv[3];
-    i32x2 pk;
-    pk[0] = (int)H16<T>::pack2(lo);
-    pk[1] = (int)H16<T>::pack2(hi);
-    vs_raw_buffer_store_b64(pk, yrsrc, valid ? e : -1, 0, 0);
-    float sv[4];                                         // round once to T; the statistics are those of the stored values
-    sv[0] = H16<T>::lo((unsigned int)pk[0]); sv[1] = H16<T>::hi((unsigned int)pk[0]);
-    sv[2] = H16<T>::lo((unsigned int)pk[1]); sv[3] = H16<T>::hi((unsigned int)pk[1]);
+    float sv[4];                                         // 16-bit: round once to T; the statistics are those of the stored values
+    if constexpr (ES == 2) {
+        f32x2 lo, hi;
+        lo[0] = o[0] + bv[0]; lo[1] = o[1] + bv[1];
+        hi[0] = o[2] + bv[2]; hi[1] = o[3] + bv[3];
+        i32x2 pk;
+        pk[0] = (int)H16<T>::pack2(lo);
+        pk[1] = (int)H16<T>::pack2(hi);
+        vs_raw_buffer_store_b64(pk, yrsrc, valid ? e : -1, 0, 0);
+        sv[0] = H16<T>::lo((unsigned int)pk[0]); sv[1] = H16<T>::hi((unsigned int)pk[0]);
+        sv[2] = H16<T>::lo((unsigned int)pk[1]); sv[3] = H16<T>::hi((unsigned int)pk[1]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = o[r] + bv[r];
+        vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{sv[0], sv[1], sv[2], sv[3]}), yrsrc, valid ? e : -1, 0, 0);
+    }
     if (!valid) { sv[0] = 0.f; sv[1] = 0.f; sv[2] = 0.f; sv[3] = 0.f; }
     float ssum[4], ssq[4];
     if constexpr (SUMS) {
-        float xv4[4];
-        xv4[0] = H16<T>::lo(mk[0]); xv4[1] = H16<T>::hi(mk[0]);
-        xv4[2] = H16<T>::lo(mk[1]); xv4[3] = H16<T>::hi(mk[1]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float xh = (xv4[r] - mm[r]) * mr[r];
