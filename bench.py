@@ -186,6 +186,9 @@ def make_step(a, dtype, rank, use_dist):
     return step, loss_fn, seg_params, closer
 
 
+HOST_ISSUE = {"s": 0.0}
+
+
 def timed_steps(step, steps, warmup, fence):
     for _ in range(warmup):
         step()
@@ -193,6 +196,7 @@ def timed_steps(step, steps, warmup, fence):
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
+    HOST_ISSUE["s"] = time.perf_counter() - t0      # host time to ISSUE the steps (graph launch + the eager exchange / optimiser launches), before the fence
     fence()
     return time.perf_counter() - t0, loss
 
@@ -264,6 +268,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    host_issue_ms = 1e3 * HOST_ISSUE["s"] / a.steps
     del loss                                    # the last reference to the captured step's autograd graph (see closer())
     ms_per_step = 1e3 * dt / a.steps
 
@@ -305,6 +310,9 @@ def main():
             "config": {"workload": "configs[1]: %d^3 joint VAE+seg training step (joint_train), batch=%d/GPU, %s activations + fp32 accumulate, "
                                    "SGD momentum 0.9, VAE frozen, HIP-graph replay" % (a.side, BATCH, a.dtype),
                        "global_batch": world * BATCH, "parallelism": "dp%d" % world, "final_loss": final_loss,
+                       # host time per step to issue the work (one graph launch, then the exchange and the optimiser eagerly); far below ms_per_step = the
+                       # step is GPU-bound and capturing those tail launches into the graph as well would not shorten it
+                       "host_issue_ms_per_step": round(host_issue_ms, 4),
                        "grad_exchange": (("2-bucket RCCL all-reduce, bucket 0 under the full-resolution weight-gradient kernels"
                                           if os.environ.get("VS_DDP_OVERLAP", "0") == "1" else
                                           "one RCCL all-reduce of the flat gradient buffer (written in place by the weight-gradient kernels) after the pass")

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import torch
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -180,3 +181,25 @@ def vacuity(report, what=""):
         if w == what:
             print("   outlier %-40s HIP %.3e  reference fp32 %.3e  (limit %.3e, ratio %.1f)" % (name, mine, theirs, lim, mine / max(theirs, 1e-30)))
     return loose
+
+
+class _RoundStorage(torch.autograd.Function):
+    """y -> y rounded to a 16-bit type and back (and the same for the gradient flowing back): what storing an activation in that type does."""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.to(dt).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).to(g.dtype), None
+
+
+def emulate_storage_rounding(model, dtype):
+    """Forward hooks on every Conv3d / ConvTranspose3d of a CPU (oracle) model that round its output, and the gradient w.r.t. it, to `dtype`:
+    the reference's own arithmetic with 16-bit STORAGE of the conv outputs — what the bf16 / fp16 throughput modes add to the fp32 path,
+    nothing else.  Returns the hook handles."""
+    import torch.nn as nn
+    return [m.register_forward_hook(lambda mod, inp, out: _RoundStorage.apply(out, dtype))
+            for m in model.modules() if isinstance(m, (nn.Conv3d, nn.ConvTranspose3d))]

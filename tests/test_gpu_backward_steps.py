@@ -9,7 +9,8 @@ gradient w.r.t. one activation from the gradient w.r.t. the next one:
     g(y_a)  =  d/dy_a [ conv_b( relu(instnorm(y_a)) ) ] ^T  g(y_b)                      inside a DoubleConv (joint_model.py:35-52)
     g(y_a)  =  d/dy_a [ conv_0( down / transposed conv( relu(instnorm(y_a)) [+ skip] ) ) ]^T g(y_0)     across a Down / Up boundary (:114-136, :380-382)
 
-with HIP's own inputs on the right-hand side.  If every step agrees to fp32 rounding (measured 3e-7 .. 1e-6 relative L2; asserted < 5e-6), the
+with HIP's own inputs on the right-hand side (elements inside the ReLU's rounding band |x_hat| < 1e-5 — a handful per tensor — excluded: _rl).
+If every step agrees to fp32 rounding (measured 3e-7 .. 1e-6 relative L2; asserted < 5e-6), the
 backward kernels — bwd-data with the fused InstanceNorm-backward sums, the apply pass, the stride-2 / transposed gathers and scatters, the skip
 merges and their parked gradients — compute the reference's arithmetic at the real shapes, and whatever end-to-end distance remains is the
 network's sensitivity, not the kernels'."""
@@ -24,8 +25,14 @@ def _planar(t, c):
     return t.double().cpu()[..., :c].permute(0, 4, 1, 2, 3).contiguous()
 
 
-def _rl(a, b):
-    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+def _rl(a, b, y):
+    """relative L2 distance of two gradients w.r.t. the raw activation y, outside the ReLU's rounding band: an element whose normalised value
+    |x_hat| is below 1e-5 can fall on either side of the ReLU under fp32 rounding (HIP evaluates x_hat in fp32, the recomputation in fp64), and ONE
+    such element among the 14 M of a 96^3 x 8 tensor is a relative L2 difference of ~1e-4 (a typical element is 1/sqrt(14 M) = 2.7e-4 of the norm) —
+    seen once the upstream fp32 kernels changed their rounding.  Those elements (a handful per tensor; counted and printed) are left out of the norm."""
+    band = F.instance_norm(y.detach(), eps=1e-5).abs() < 1e-5
+    d = (a - b).masked_fill(band, 0.0)
+    return float(d.norm() / b.norm().clamp_min(1e-300)), int(band.sum())
 
 
 def _act(y):
@@ -61,10 +68,10 @@ def test_seg96_every_backward_step_matches_fp64_recomputation(monkeypatch):
     Gr = lambda name: _planar(rec[name]["g"], mods[name].weight.shape[0])
     results = []
 
-    def check(tag, got, want):
-        e = _rl(got, want)
+    def check(tag, got, want, y):
+        e, nband = _rl(got, want, y)
         results.append((tag, e))
-        print("%-58s %.3e" % (tag, e))
+        print("%-58s %.3e   (%d of %d elements inside the ReLU rounding band, excluded)" % (tag, e, nband, y.numel()))
 
     print("\nsingle backward steps, HIP fp32 vs fp64 recomputation from HIP's own inputs (relative L2)")
     # ---- inside every DoubleConv: conv.6 -> conv.3 -> conv.0 ----
@@ -73,19 +80,19 @@ def test_seg96_every_backward_step_matches_fp64_recomputation(monkeypatch):
             ka, kb = "%s.conv.1.conv.%d" % (blk, a_i), "%s.conv.1.conv.%d" % (blk, b_i)
             y = Y(ka).requires_grad_(True)
             F.conv3d(_act(y), W(kb), padding=1).backward(Gr(kb))
-            check("%s -> %s" % (kb, ka), Gr(ka), y.grad)
+            check("%s -> %s" % (kb, ka), Gr(ka), y.grad, y)
     # ---- Down boundaries without a skip consumer: in_block -> down1, down3 -> down4 ----
     for src, blk in (("in_block.conv.0", "down1"), ("down3.conv.1.conv.6", "down4")):
         y = Y(src).requires_grad_(True)
         u = F.conv3d(_act(y), W(blk + ".conv.0"), Bv(blk + ".conv.0"), stride=2)
         F.conv3d(u, W(blk + ".conv.1.conv.0"), padding=1).backward(Gr(blk + ".conv.1.conv.0"))
-        check("%s.conv.1.conv.0 -> [k2s2] -> %s" % (blk, src), Gr(src), y.grad)
+        check("%s.conv.1.conv.0 -> [k2s2] -> %s" % (blk, src), Gr(src), y.grad, y)
     # ---- Up boundaries without a skip: down4 -> up2, up2 -> up3 ----
     for src, blk in (("down4.conv.1.conv.6", "up2"), ("up2.conv.1.conv.6", "up3")):
         y = Y(src).requires_grad_(True)
         u = F.conv_transpose3d(_act(y), W(blk + ".conv.0"), Bv(blk + ".conv.0"), stride=2)
         F.conv3d(u, W(blk + ".conv.1.conv.0"), padding=1).backward(Gr(blk + ".conv.1.conv.0"))
-        check("%s.conv.1.conv.0 -> [convT] -> %s" % (blk, src), Gr(src), y.grad)
+        check("%s.conv.1.conv.0 -> [convT] -> %s" % (blk, src), Gr(src), y.grad, y)
     # ---- the additive skips (joint_model.py:380,382): u = act(up_k.conv.6) + act(x_skip) feeds up_{k+1}; x_skip also feeds the next Down ----
     for up_src, skip_src, up_blk, down_blk in (("up3.conv.1.conv.6", "down2.conv.1.conv.6", "up4", "down3"),
                                                 ("up4.conv.1.conv.6", "down1.conv.1.conv.6", "up5", "down2")):
@@ -95,8 +102,8 @@ def test_seg96_every_backward_step_matches_fp64_recomputation(monkeypatch):
         d = F.conv3d(_act(ys), W(down_blk + ".conv.0"), Bv(down_blk + ".conv.0"), stride=2)
         o2 = F.conv3d(d, W(down_blk + ".conv.1.conv.0"), padding=1)
         torch.autograd.backward([o1, o2], [Gr(up_blk + ".conv.1.conv.0"), Gr(down_blk + ".conv.1.conv.0")])
-        check("%s.conv.1.conv.0 -> [convT, skip add] -> %s" % (up_blk, up_src), Gr(up_src), yu.grad)
-        check("%s + %s -> [skip + k2s2] -> %s" % (up_blk, down_blk, skip_src), Gr(skip_src), ys.grad)
+        check("%s.conv.1.conv.0 -> [convT, skip add] -> %s" % (up_blk, up_src), Gr(up_src), yu.grad, yu)
+        check("%s + %s -> [skip + k2s2] -> %s" % (up_blk, down_blk, skip_src), Gr(skip_src), ys.grad, ys)
     worst = max(results, key=lambda r: r[1])
     print("worst step: %s %.3e" % worst)
     assert worst[1] < 5e-6, worst

@@ -96,6 +96,40 @@ def test_joint96_full_tensor_gradients_vs_cpu_oracle():
     assert abs(final.item() - l64) <= max(1e-3 * abs(l64), 3 * abs(l32 - l64))
     med, outliers = _table("joint96 (configs[1])", hip, g32, g64)
     assert med <= 2.0, med
+    # The benchmarked THROUGHPUT modes on the same inputs and weights (16-bit storage of activations and packed weights, fp32 accumulation) —
+    # reported, not gated (north_star's 1e-3 is an fp32 statement).  At these synthetic, randomly initialised weights the network
+    # amplifies a rounding perturbation ~1e6 x (the reference's own fp32 run is 5-7 % from fp64), so ANY 16-bit storage of the conv outputs
+    # decorrelates the gradient: the last table is the CPU oracle itself with its conv outputs (and their gradients) rounded to bf16 and nothing
+    # else changed (golden_util.emulate_storage_rounding) — the HIP bf16 mode sits where that emulation sits.  What is asserted: the loss.
+    def cosines(g):
+        c = sorted(float((g[n] * g64[n]).sum() / (g[n].norm() * g64[n].norm()).clamp_min(1e-300)) for n in g64
+                   if not G.is_dead_bias(n) and float(g64[n].norm()) > 0)
+        return c[0], c[len(c) // 2]
+    for dt, name in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+        M.set_kernel_dtype(joint, dt)
+        for p in joint.Seg.parameters():
+            p.grad = None
+        seed = torch.tensor(1024.0, device="cuda") if dt == torch.float16 else None      # fp16: Dice gradients are subnormal without a loss scale
+        f16, _ = T.joint_train_losses(joint, img.cuda(), lab.cuda())
+        f16.backward(gradient=seed)
+        scale = 1024.0 if dt == torch.float16 else 1.0
+        h16 = {n: p.grad.detach().double().cpu() / scale for n, p in joint.Seg.named_parameters()}
+        print("\njoint96 loss in the %s throughput mode: HIP %.6f (fp64 %.6f, relative difference %.2e)" % (name, f16.item(), l64, abs(f16.item() - l64) / abs(l64)))
+        _table("joint96, HIP %s storage mode" % name, h16, g32, g64, floor=2e-3, factor=2.0, hard=1e9)
+        print("%s mode: cosine between HIP and fp64 gradient tensors: min %.3f, median %.3f" % ((name,) + cosines(h16)))
+        assert abs(f16.item() - l64) <= 2e-2 * abs(l64)
+    oj = _oracle_joint(O, 96, torch.float32)
+    hooks = G.emulate_storage_rounding(oj, torch.bfloat16)
+    ol, _ = O.joint_train_losses(oj, img, lab)
+    ol.backward()
+    ge = {n: p.grad.detach().double() for n, p in oj.Seg.named_parameters()}
+    for h in hooks:
+        h.remove()
+    print("\njoint96 loss of the CPU oracle with bf16 storage of its conv outputs: %.6f" % float(ol))
+    _table("joint96, CPU oracle fp32 with conv outputs rounded to bf16 (emulated storage)", ge, g32, g64, floor=2e-3, factor=2.0, hard=1e9)
+    print("emulated bf16 storage: cosine between its and the fp64 gradient tensors: min %.3f, median %.3f" % cosines(ge))
+    print("oracle fp32: cosine between its and the fp64 gradient tensors: min %.3f, median %.3f" % cosines(g32))
+    M.set_kernel_dtype(joint, torch.float32)
 
 
 def test_seg96_full_tensor_gradients_vs_cpu_oracle():

@@ -42,7 +42,8 @@ def test_argument_validation_without_gpu():
     assert lib.vs_packed_weight_bytes(16, 8, 27, 1) == 1 * 1 * 7 * 64 * 8 * 2
     # ... except the 8-channel 3x3x3 layers (<= 8 rows, bf16), packed as 9 Toeplitz k-groups (tz, ty) for k3t_kernel
     assert lib.vs_packed_weight_bytes(8, 8, 27, 1) == 9 * 64 * 8 * 2
-    assert lib.vs_packed_weight_bytes(8, 8, 27, 0) == 1 * 1 * 14 * 64 * 4 * 4        # fp32 keeps the standard order
+    assert lib.vs_packed_weight_bytes(8, 8, 27, 0) == 18 * 64 * 4 * 4                # fp32: 18 y-Toeplitz k-groups (36 window taps (dz, wy, dx), two per k-group) for k3_kernel<.., TY>
+    assert lib.vs_packed_weight_bytes(16, 8, 27, 0) == 1 * 1 * 14 * 64 * 4 * 4       # more than 8 rows: the standard order
     assert lib.vs_packed_weight_bytes(64, 64, 27, 0) == 4 * 2 * 54 * 64 * 4 * 4
     assert lib.vs_conv_wgrad_workspace_bytes(2, 96, 96, 96, 8, 8, 0) > 0
     # maximum sizes: shapes the 32-bit offsets of the kernels cannot address are refused (VS_ESHAPE = -2), never mis-computed.

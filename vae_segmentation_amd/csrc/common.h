@@ -337,6 +337,12 @@ __device__ __forceinline__ u32x4 act8(const u32x4 raw, const f32x2 (&sc)[4], con
 static __host__ __device__ inline bool vs_k3_toeplitz(int rows, int c_pad, int ntaps, int dtype) {
     return (dtype == VS_BF16 || dtype == VS_F16) && ntaps == 27 && c_pad == 8 && rows <= 8;
 }
+// The same layers in fp32 (k3_kernel<float, 8, 16, EPI, 4, true>, igemm_k3.h) use a Toeplitz layout along y: [k-group][lane][4],
+// row (lane & 15) = (dy2, co), 36 window taps t = (dz, wy, dx) with wy = 0..3, k-group kg holds taps 2 kg and 2 kg + 1,
+// k = ((lane >> 5) = which of the two, ci = 4 * ((lane >> 4) & 1) + j), value W[co][ci][dz][wy - dy2][dx] or 0: 18 k-groups.
+static __host__ __device__ inline bool vs_k3_toeplitz_f32(int rows, int c_pad, int ntaps, int dtype) {
+    return dtype == VS_F32 && ntaps == 27 && c_pad == 8 && rows <= 8;
+}
 
 // Zeroing as a kernel, never hipMemsetAsync: inside a replayed HIP graph a memset node was observed to run out of order with the
 // kernel nodes around it after a host-side D2H copy (second test-time-training case, nondeterministic bias gradients); kernel nodes

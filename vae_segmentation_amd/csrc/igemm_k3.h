@@ -19,11 +19,18 @@
 // YT: rows of 16 voxels per wave (tile 4 x YT x 16).  The exact-f32 MFMA runs at 1/16 of the 16-bit rate, so the fp32 layers are bound by MFMA cycles
 // per wave; at the 12^3 / 24^3 levels a 4x4x16 tiling yields 72-288 workgroups for 1024 SIMDs and one wave carries 4 column groups x all of K:
 // shorter tiles (more halo, which is L2-resident there) spread the same MFMAs over 4x the waves.
-template <typename T, int CK, int MT, int EPI, int YT = 4>
+// TY (fp32, 8 stored input and <= 8 output channels: the full-resolution layers): Toeplitz rows along y.  With 8 real rows half of every exact-f32
+// MFMA multiplies padding, and these launches are MFMA-bound (96^3: 135 us against 80 us of MFMA cycles).  Rows become (dy2, co) — two output
+// voxels adjacent in y times 8 channels — over a 4-tall window: 36 window taps (dz, wy, dx) instead of 27, weights W[co][ci][dz][wy - dy2][dx]
+// or zero (pack.hip, vs_k3_toeplitz_f32), a wave's four rows of 16 voxels become two row PAIRS: 18 k-groups x 2 column groups x 4 MFMAs per tile
+// and wave instead of 14 x 4 x 4 (1.56x fewer).
+template <typename T, int CK, int MT, int EPI, int YT = 4, bool TY = false>
 __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     using E = ET<T>;
     constexpr int EPL = E::EPL, KG = E::KG;
-    constexpr int NTAPS = 27;
+    static_assert(!TY || (sizeof(T) == 4 && CK == 8 && MT == 16 && YT == 4), "y-Toeplitz: the fp32 8-channel layers");
+    constexpr int NTAPS = TY ? 36 : 27;
+    constexpr int NCGW = TY ? 2 : YT;                    // column groups per wave (TY: row pairs)
     constexpr int NKG = (NTAPS * CK + KG - 1) / KG;
     constexpr int RB = MT / 16;
     constexpr int CKB = CK * (int)sizeof(T);
@@ -66,14 +73,20 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
             s_mkr[i] = r;
         }
     }
-    if (tid < 32) {
-        const int t = tid < 27 ? tid : 13;
-        const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-        s_taps[tid] = (dz * PLANE + dy * 18 + dx) * CKB;
+    if (tid < 64) {
+        if constexpr (TY) {
+            const int t = tid < 36 ? tid : 16;            // (dz, wy, dx); padded entries read the centre voxel (their weights are zero)
+            const int dz = t / 12, wy = (t / 3) % 4, dx = t % 3;
+            s_taps[tid] = (dz * PLANE + wy * 18 + dx) * CKB;
+        } else {
+            const int t = tid < 27 ? tid : 13;
+            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+            s_taps[tid] = (dz * PLANE + dy * 18 + dx) * CKB;
+        }
     }
-    int lds_base[YT];
+    int lds_base[NCGW];
 #pragma unroll
-    for (int cg = 0; cg < YT; ++cg) lds_base[cg] = (wave * PLANE + cg * 18 + col) * CKB + ((g * EPL) % CK) * (int)sizeof(T);
+    for (int cg = 0; cg < NCGW; ++cg) lds_base[cg] = (wave * PLANE + (TY ? 2 * cg : cg) * 18 + col) * CKB + ((g * EPL) % CK) * (int)sizeof(T);
 
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
     const size_t rb_stride = (size_t)p.nch * NKG * 64;
@@ -162,11 +175,11 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     for (; t < total_tiles; t += gridDim.x) {
         int n, z0, y0, x0;
         tile_origin(t, n, z0, y0, x0);
-        f32x4 acc[RB][YT];
+        f32x4 acc[RB][NCGW];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int cg = 0; cg < YT; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cg = 0; cg < NCGW; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int ch = 0; ch < p.nch; ++ch) {
             if constexpr (PF) {
@@ -197,13 +210,13 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb) a[rb] = wch[(size_t)(rb0 + rb) * rb_stride + kg * 64];
                     const int toff = s_taps[kg * TPK + sub];
-                    u32x4 b[YT];
+                    u32x4 b[NCGW];
 #pragma unroll
-                    for (int cg = 0; cg < YT; ++cg) b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff);
+                    for (int cg = 0; cg < NCGW; ++cg) b[cg] = *(const u32x4*)(s_tile + lds_base[cg] + toff);
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                        for (int cg = 0; cg < YT; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
+                        for (int cg = 0; cg < NCGW; ++cg) acc[rb][cg] = mfma16(a[rb], b[cg], acc[rb][cg], (T*)nullptr);
                 }
             } else {
                 constexpr int NK = NTAPS * KPT;
@@ -266,12 +279,12 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
         // ---- epilogue of this tile ----
         const int oz = z0 + wave;
         if constexpr (EPI == EPI_SOFTMAX2) {
-            if (g == 0) {
+            if (TY ? (g & 1) == 0 : g == 0) {                 // the lanes holding rows (dy2,) 0 .. 3: the two logits are rows 0 and 1
                 const float b0 = p.bias ? p.bias[0] : 0.f, b1 = p.bias ? p.bias[1] : 0.f;
                 const size_t V = (size_t)p.D * p.H * p.W;
 #pragma unroll
-                for (int cg = 0; cg < YT; ++cg) {
-                    const int oy = y0 + cg, ox = x0 + col;
+                for (int cg = 0; cg < NCGW; ++cg) {
+                    const int oy = TY ? y0 + 2 * cg + (g >> 1) : y0 + cg, ox = x0 + col;
                     if (!(oz < p.D && oy < p.H && ox < p.W)) continue;
                     float l0 = acc[0][cg][0] + b0, l1 = acc[0][cg][1] + b1;
                     const size_t v = ((size_t)oz * p.H + oy) * p.W + ox;
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
             T* __restrict__ yout = (T*)p.y;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
-                const int row = (rb0 + rb) * 16 + 4 * g;
+                const int row = TY ? 4 * (g & 1) : (rb0 + rb) * 16 + 4 * g;      // TY: lane group g holds (dy2 = g >> 1, channels 4 (g & 1) ..)
                 const bool rvalid = row < p.M;
                 float bv[4] = {0.f, 0.f, 0.f, 0.f};
                 if (p.bias && rvalid) {
@@ -298,8 +311,8 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                     for (int r = 0; r < 4; ++r) bv[r] = p.bias[row + r];
                 }
 #pragma unroll
-                for (int cg = 0; cg < YT; ++cg) {
-                    const int oy = y0 + cg, ox = x0 + col;
+                for (int cg = 0; cg < NCGW; ++cg) {
+                    const int oy = TY ? y0 + 2 * cg + (g >> 1) : y0 + cg, ox = x0 + col;
                     if (!(rvalid && oz < p.D && oy < p.H && ox < p.W)) continue;
                     float v[4];
 #pragma unroll
@@ -351,9 +364,13 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
                     if (tid < MT * 2) {
                         const int lr = tid >> 1, st = tid & 1;
                         const int row = rb0 * 16 + lr;
-                        if (row < p.M) {
-                            const double tot = (double)s_red[(0 * 64 + lr) * 2 + st] + (double)s_red[(1 * 64 + lr) * 2 + st] +
-                                               (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
+                        if (TY ? lr < 8 && lr < p.M : row < p.M) {
+                            double tot = (double)s_red[(0 * 64 + lr) * 2 + st] + (double)s_red[(1 * 64 + lr) * 2 + st] +
+                                         (double)s_red[(2 * 64 + lr) * 2 + st] + (double)s_red[(3 * 64 + lr) * 2 + st];
+                            if constexpr (TY) {             // channel lr: rows lr (dy2 = 0) and lr + 8 (dy2 = 1); lane row 4 g + r = 8 dy2 + channel
+                                tot += (double)s_red[(0 * 64 + lr + 8) * 2 + st] + (double)s_red[(1 * 64 + lr + 8) * 2 + st] +
+                                       (double)s_red[(2 * 64 + lr + 8) * 2 + st] + (double)s_red[(3 * 64 + lr + 8) * 2 + st];
+                            }
                             stat_add(red_dst, (size_t)n * p.M + row, (size_t)p.N * p.M, st, tot);
                         }
                     }
@@ -364,7 +381,7 @@ __global__ __launch_bounds__(256) void k3_kernel(const G1Params p) {
     }
 }
 
-template <typename T, int CK, int MT, int EPI, int YT = 4>
+template <typename T, int CK, int MT, int EPI, int YT = 4, bool TY = false>
 static int k3_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
     G1Params p = p_in;
     if (YT != 4) {                                       // re-tile the volume in 4 x YT x 16 tiles
@@ -375,7 +392,7 @@ static int k3_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipSt
     const size_t tables = (size_t)2 * p.N * p.C * sizeof(float) + (p.sums ? (size_t)2 * p.N * p.M * sizeof(float) : 0);
     const size_t lds = K3_LDS_TILE + (size_t)6 * (YT + 2) * 18 * CK * sizeof(T) + tables;
     if (lds > 160 * 1024) return VS_ESHAPE;
-    auto kern = k3_kernel<T, CK, MT, EPI, YT>;
+    auto kern = k3_kernel<T, CK, MT, EPI, YT, TY>;
     // idempotent one-time opt-in to the full 160 KiB of dynamic LDS (not a stream operation)
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

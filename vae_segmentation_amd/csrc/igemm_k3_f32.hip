@@ -7,10 +7,11 @@
 #define K3_ALL_MT(CKV) K3_CASE(CKV, 16) K3_CASE(CKV, 32) K3_CASE(CKV, 64)
 
 int g1_dispatch_k3_f32(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s) {
-    if (epi == EPI_SOFTMAX2) {
-        if (ck == 8 && mt == 16) return k3_launch<float, 8, 16, EPI_SOFTMAX2>(p, tiles, row_tiles, s);
-        return VS_ESHAPE;
+    if (ck == 8 && p.C == 8 && p.M == 8 && mt == 16) {     // the 8-channel full-resolution layers: y-Toeplitz rows (weights packed to match: vs_k3_toeplitz_f32)
+        if (epi == EPI_SOFTMAX2) return k3_launch<float, 8, 16, EPI_SOFTMAX2, 4, true>(p, tiles, row_tiles, s);
+        return k3_launch<float, 8, 16, EPI_RAW, 4, true>(p, tiles, row_tiles, s);
     }
+    if (epi == EPI_SOFTMAX2) return VS_ESHAPE;             // out_block is an 8-channel layer (above)
     if (k3s_takes(p, ck))                                 // volumes up to 6^3: flattened columns, the waves split the taps (igemm_k3s.h)
         return p.sums ? k3s_launch<float, true>(p, s) : k3s_launch<float, false>(p, s);
     // C >= 32 (the 24^3 level and below): the exact-f32 MFMA makes these layers MFMA-cycle bound per wave, and 4x4x16 tiles of 16-32 rows leave

@@ -26,6 +26,21 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ src, T* __res
                 else { if (co < d1 && ci < d0) v[ci] = src[((size_t)ci * d1 + co) * 27 + (26 - tap)]; }
             }
         }
+    } else if (sizeof(T) == 4 && form != VS_PACK_SCATTER_D1 && vs_k3_toeplitz_f32(form == VS_PACK_ROWS_D0 ? d0 : d1, c_pad, ntaps, VS_F32)) {
+        // y-Toeplitz image of the same layers in fp32 (common.h vs_k3_toeplitz_f32, igemm_k3.h TY): [kg][lane][4]
+        const int lane = (int)(frag & 63), kg = (int)(frag >> 6);
+        const int row = lane & 15, dy2 = row >> 3, co = row & 7, g = lane >> 4;
+        const int t = kg * 2 + (g >> 1), ci0 = (g & 1) * 4;
+        const int dz = t / 12, wy = (t / 3) % 4, dx = t % 3, dy = wy - dy2;
+        if (dy >= 0 && dy <= 2) {
+            const int tap = dz * 9 + dy * 3 + dx;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int ci = ci0 + j;
+                if (form == VS_PACK_ROWS_D0) { if (co < d0 && ci < d1) v[j] = src[((size_t)co * d1 + ci) * 27 + tap]; }
+                else { if (co < d1 && ci < d0) v[j] = src[((size_t)ci * d1 + co) * 27 + (26 - tap)]; }
+            }
+        }
     } else {
         const int CK = c_pad < 32 ? c_pad : 32;
         const int nch = c_pad / CK;
@@ -93,6 +108,7 @@ extern "C" int vs_pack_weight_multi(const vs_pack_desc* descs, int n_desc, int t
 
 static long long packed_elems(int rows, int c_pad, int gemm_taps, int dtype) {
     if (vs_k3_toeplitz(rows, c_pad, gemm_taps, dtype)) return 9 * 64 * 8;
+    if (vs_k3_toeplitz_f32(rows, c_pad, gemm_taps, dtype)) return 18 * 64 * 4;
     const int EPL = dtype == VS_F32 ? 4 : 8, KG = 4 * EPL;
     const int CK = c_pad < 32 ? c_pad : 32;
     const int nch = c_pad / CK;
