@@ -447,6 +447,8 @@ struct G3Group {
     G3Params p[G3_GROUP_MAX];
     int wg_start[G3_GROUP_MAX + 1];
     int n;
+    int xcd;          // the k-splits of a single-block-pair layer are dealt so that the workgroups of one XCD walk neighbouring tiles (their Q halos then meet in that
+                      // XCD's L2: 8-channel bucket 572 -> 343 MB per launch, step time unchanged); VS_WGRAD_XCD=0 restores the plain order
 };
 
 template <int CB, int KIND, typename T = unsigned short>
@@ -459,8 +461,19 @@ __global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
     const G3Params p = grp.p[l];
     const int local = b - grp.wg_start[l];
     const int pairs = p.mbn * p.cbn;
-    const int ks = local / pairs;
-    g3b_body<T, CB, KIND>(p, local - ks * pairs, ks);
+    int ks = local / pairs;
+    if (grp.xcd && pairs == 1 && p.ksplit >= 16) {          // hardware deals consecutive workgroup ids to the 8 XCDs in turn: XCD x gets one contiguous run of k-splits
+        const int b0 = grp.wg_start[l], x = b & 7;
+        int start = 0;
+#pragma unroll
+        for (int xx = 0; xx < 8; ++xx) {
+            const int first = (xx - b0) & 7;                                        // smallest local index on XCD xx
+            const int cnt = first < p.ksplit ? (p.ksplit - first + 7) >> 3 : 0;
+            start += xx < x ? cnt : 0;
+        }
+        ks = start + ((local - ((x - b0) & 7)) >> 3);
+    }
+    g3b_body<T, CB, KIND>(p, local - (local / pairs) * pairs, ks);
 }
 
 // Sum the partial slabs (fixed order, fp64) into the reference's [m][c][tap] layout.  A block = 64 consecutive slab
@@ -1006,6 +1019,8 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return plan.layers[a].work > plan.layers[b].work; });
         for (size_t at = 0; at < idx.size(); at += G3_GROUP_MAX) {
             G3Group grp{};
+            static const int xcd_walk = getenv("VS_WGRAD_XCD") ? atoi(getenv("VS_WGRAD_XCD")) : 1;
+            grp.xcd = xcd_walk;
             grp.n = (int)std::min<size_t>(G3_GROUP_MAX, idx.size() - at);
             long long wg = 0;
             for (int j = 0; j < grp.n; ++j) {
