@@ -76,10 +76,104 @@ __device__ __forceinline__ void g3_body(const G3Params& p, const int bx, const i
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int mb = bx / p.cbn, cb = bx - mb * p.cbn;
-    const T* __restrict__ Pp = (const T*)p.P;
-    const T* __restrict__ Qp = (const T*)p.Q;
     const bool p_stats = p.P_stats != nullptr, q_stats = p.Q_stats != nullptr;
+    const i32x4 prsrc = make_rsrc(p.P, (unsigned int)((long long)p.N * p.Dp * p.Hp * p.Wp * p.Mch * (int)sizeof(T)));
+    const i32x4 qrsrc = make_rsrc(p.Q, (unsigned int)((long long)p.N * p.Dq * p.Hq * p.Wq * p.Cch * (int)sizeof(T)));
 
+    // ---- tile-independent fragment geometry (as g3b_body): the next tile's P and Q fragments are requested — bounds-checked buffer loads, no
+    // branches — right after the current tile went to LDS, so their latency is covered by the MFMA phase (the round-1 form loaded, staged and
+    // multiplied each tile in turn, with ~80 integer operations of address arithmetic per fragment: 180 us per 96^3 layer for 80 us of MFMA cycles)
+    constexpr int PU = 16 / EPL, QU = CB / EPL;           // 16-byte fragments per P / Q voxel
+    constexpr int NP = PU;                                // P fragments per thread (256 voxels x PU / 256 threads)
+    constexpr int NQ = QV * QU, NITQ = (NQ + 255) / 256;
+    const int ppart = tid % PU, qpart = tid % QU;         // constant per thread (256 % PU == 256 % QU == 0)
+    const bool pch_ok = mb * 16 + ppart * EPL < p.Mch, qch_ok = cb * CB + qpart * EPL < p.Cch;
+    int prel[NP], pzyx[NP];
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+        const int v = (tid + b * 256) / PU;
+        const int lx = v & 15, ly = (v >> 4) & 3, lz = v >> 6;
+        prel[b] = (((lz * p.Hp + ly) * p.Wp + lx) * p.Mch + mb * 16 + ppart * EPL) * (int)sizeof(T);
+        pzyx[b] = pch_ok ? (lz | (ly << 8) | (lx << 16)) : 0x00ffffff;
+    }
+    int qrel[NITQ], qzyx[NITQ];
+#pragma unroll
+    for (int b = 0; b < NITQ; ++b) {
+        const int u = tid + b * 256;
+        const int v = u / QU;
+        const int lx = v % QX, ly = (v / QX) % QY, lz = v / (QX * QY);
+        qrel[b] = (((lz * p.Hq + ly) * p.Wq + lx) * p.Cch + cb * CB + qpart * EPL) * (int)sizeof(T);
+        qzyx[b] = (u < NQ && qch_ok) ? (lz | (ly << 8) | (lx << 16)) : 0x00ffffff;
+    }
+    u32x4 pv[NP], qv[NITQ];
+    unsigned long long okbits = 0;                        // bit b: P fragment b inside the volume; bit NP + b: Q fragment b (up to 4 + 32 of them)
+    auto request = [&](int t) {
+        const int n = t / p.tiles_per_sample;
+        const int tl = t - n * p.tiles_per_sample;
+        const int tx = tl % p.txn, ty = (tl / p.txn) % p.tyn, tz = tl / (p.txn * p.tyn);
+        const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+        okbits = 0;
+        const int pbase = (((n * p.Dp + z0) * p.Hp + y0) * p.Wp + x0) * p.Mch * (int)sizeof(T);
+#pragma unroll
+        for (int b = 0; b < NP; ++b) {
+            const int gz = z0 + (pzyx[b] & 0xff), gy = y0 + ((pzyx[b] >> 8) & 0xff), gx = x0 + (pzyx[b] >> 16);
+            const bool ok = gz < p.Dp && gy < p.Hp && gx < p.Wp;
+            okbits |= ok ? (1ull << b) : 0ull;
+            pv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(prsrc, ok ? pbase + prel[b] : -1, 0, 0));
+        }
+        const int qz0 = KIND == G3_K3 ? z0 - 1 : 2 * z0, qy0 = KIND == G3_K3 ? y0 - 1 : 2 * y0, qx0 = KIND == G3_K3 ? x0 - 1 : 2 * x0;
+        const int qbase = (((n * p.Dq + qz0) * p.Hq + qy0) * p.Wq + qx0) * p.Cch * (int)sizeof(T);
+#pragma unroll
+        for (int b = 0; b < NITQ; ++b) {
+            const int gz = qz0 + (qzyx[b] & 0xff), gy = qy0 + ((qzyx[b] >> 8) & 0xff), gx = qx0 + (qzyx[b] >> 16);
+            const bool ok = (unsigned)gz < (unsigned)p.Dq && (unsigned)gy < (unsigned)p.Hq && (unsigned)gx < (unsigned)p.Wq;
+            okbits |= ok ? (1ull << (NP + b)) : 0ull;
+            qv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(qrsrc, ok ? qbase + qrel[b] : -1, 0, 0));
+        }
+    };
+    auto commit = [&](int n) {                            // registers -> (normalised) fp32 LDS tiles; out-of-volume fragments are zeros
+#pragma unroll
+        for (int b = 0; b < NP; ++b) {
+            float f[EPL];
+            frag_unpack(pv[b], f, (T*)nullptr);
+            const bool ok = (okbits >> b) & 1ull;
+#pragma unroll
+            for (int jj = 0; jj < EPL; ++jj) {
+                if (p_stats) {
+                    const float tt = (f[jj] - s_pm[n * 16 + ppart * EPL + jj]) * s_pr[n * 16 + ppart * EPL + jj];
+                    f[jj] = tt > 0.f ? tt : 0.f;
+                }
+                f[jj] = ok ? f[jj] : 0.f;
+            }
+            const int v = (tid + b * 256) / PU;
+#pragma unroll
+            for (int jj = 0; jj < EPL; jj += 4)
+                *(f32x4*)(s_p + v * 16 + ppart * EPL + jj) = f32x4{f[jj], f[jj + 1], f[jj + 2], f[jj + 3]};
+        }
+#pragma unroll
+        for (int b = 0; b < NITQ; ++b) {
+            float f[EPL];
+            frag_unpack(qv[b], f, (T*)nullptr);
+            const bool ok = (okbits >> (NP + b)) & 1ull;
+#pragma unroll
+            for (int jj = 0; jj < EPL; ++jj) {
+                if (q_stats) {
+                    const float tt = (f[jj] - s_qm[n * 16 + qpart * EPL + jj]) * s_qr[n * 16 + qpart * EPL + jj];
+                    f[jj] = tt > 0.f ? tt : 0.f;
+                }
+                f[jj] = ok ? f[jj] : 0.f;
+            }
+            const int u = tid + b * 256;
+            if (b < NITQ - 1 || u < NQ) {
+#pragma unroll
+                for (int jj = 0; jj < EPL; jj += 4)
+                    *(f32x4*)(s_q + (u / QU) * CB + qpart * EPL + jj) = f32x4{f[jj], f[jj + 1], f[jj + 2], f[jj + 3]};
+            }
+        }
+    };
+
+    int t = ks;                                           // ksplit never exceeds the tile count
+    request(t);
     // mean / rstd tables for this WG's channel blocks, all samples
     for (int i = tid; i < p.N * 16; i += 256) {
         const int n = i >> 4, c = i & 15;
@@ -110,63 +204,11 @@ __device__ __forceinline__ void g3_body(const G3Params& p, const int bx, const i
 #pragma unroll
     for (int k = 0; k < NCB; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int t = ks; t < p.total_tiles; t += p.ksplit) {
-        const int n = t / p.tiles_per_sample;
-        const int tl = t - n * p.tiles_per_sample;
-        const int tx = tl % p.txn, ty = (tl / p.txn) % p.tyn, tz = tl / (p.txn * p.tyn);
-        const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+    for (; t < p.total_tiles; t += p.ksplit) {
         __syncthreads();      // previous tile fully consumed (also orders the stats tables on the first pass)
-        // ---- stage P: 256 voxels x 16 channels of the m-block, fp32 in LDS ----
-        for (int u = tid; u < 256 * (16 / EPL); u += 256) {
-            const int v = u / (16 / EPL), part = u - v * (16 / EPL);
-            const int lx = v & 15, ly = (v >> 4) & 3, lz = v >> 6;
-            const int gz = z0 + lz, gy = y0 + ly, gx = x0 + lx;
-            const int c0 = mb * 16 + part * EPL;
-            float f[EPL];
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) f[j] = 0.f;
-            if (gz < p.Dp && gy < p.Hp && gx < p.Wp && c0 < p.Mch) {
-                const size_t e = ((((size_t)n * p.Dp + gz) * p.Hp + gy) * p.Wp + gx) * p.Mch + c0;
-                frag_unpack(*(const u32x4*)(Pp + e), f, (T*)nullptr);
-                if (p_stats) {
-#pragma unroll
-                    for (int j = 0; j < EPL; ++j) {
-                        const float tt = (f[j] - s_pm[n * 16 + part * EPL + j]) * s_pr[n * 16 + part * EPL + j];
-                        f[j] = tt > 0.f ? tt : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < EPL; j += 4)
-                *(f32x4*)(s_p + v * 16 + part * EPL + j) = f32x4{f[j], f[j + 1], f[j + 2], f[j + 3]};
-        }
-        // ---- stage Q: halo (K3) or 2x-upsampled (K2S2) region x CB channels ----
-        for (int u = tid; u < QV * (CB / EPL); u += 256) {
-            const int v = u / (CB / EPL), part = u - v * (CB / EPL);
-            const int lx = v % QX, ly = (v / QX) % QY, lz = v / (QX * QY);
-            int gz, gy, gx;
-            if (KIND == G3_K3) { gz = z0 + lz - 1; gy = y0 + ly - 1; gx = x0 + lx - 1; }
-            else { gz = 2 * z0 + lz; gy = 2 * y0 + ly; gx = 2 * x0 + lx; }
-            const int c0 = cb * CB + part * EPL;
-            float f[EPL];
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) f[j] = 0.f;
-            if (gz >= 0 && gz < p.Dq && gy >= 0 && gy < p.Hq && gx >= 0 && gx < p.Wq && c0 < p.Cch) {
-                const size_t e = ((((size_t)n * p.Dq + gz) * p.Hq + gy) * p.Wq + gx) * p.Cch + c0;
-                frag_unpack(*(const u32x4*)(Qp + e), f, (T*)nullptr);
-                if (q_stats) {
-#pragma unroll
-                    for (int j = 0; j < EPL; ++j) {
-                        const float tt = (f[j] - s_qm[n * 16 + part * EPL + j]) * s_qr[n * 16 + part * EPL + j];
-                        f[j] = tt > 0.f ? tt : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < EPL; j += 4)
-                *(f32x4*)(s_q + v * CB + part * EPL + j) = f32x4{f[j], f[j + 1], f[j + 2], f[j + 3]};
-        }
+        commit(t / p.tiles_per_sample);
         __syncthreads();
+        if (t + p.ksplit < p.total_tiles) request(t + p.ksplit);
         // ---- 64 voxels of this wave's z-slice, 4 per MFMA step ----
 #pragma unroll 2
         for (int step = 0; step < 16; ++step) {
@@ -530,9 +572,10 @@ static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind,
     const long long total = (long long)tiles_per_sample * n;
     static const long long wg_target = getenv("VS_WGRAD_WGS") ? atoll(getenv("VS_WGRAD_WGS")) : 512;   // tuning knob: ~2 workgroups per CU overall
     long long want = (wg_target + (long long)mbn * cbn - 1) / ((long long)mbn * cbn);
-    // fp32 (parity) mode: at most two tiles per workgroup, so an fp32 MFMA accumulator never chains more than 128
-    // products before the fp64 slab reduction
-    if (short_chains && (total + 1) / 2 > want) want = (total + 1) / 2;
+    // fp32 (parity) mode: a bounded number of tiles per workgroup, so that an fp32 MFMA accumulator chains a bounded number of products (64 per
+    // tile and wave) before the fp64 slab reduction: VS_WGRAD_F32_TILES tiles (see the default's comment)
+    static const long long f32_tiles = getenv("VS_WGRAD_F32_TILES") ? atoll(getenv("VS_WGRAD_F32_TILES")) : 2;
+    if (short_chains && (total + f32_tiles - 1) / f32_tiles > want) want = (total + f32_tiles - 1) / f32_tiles;
     if (want < 1) want = 1;
     if (want > total) want = total;
     // keep the slab workspace <= 64 MiB
@@ -631,6 +674,8 @@ static int wgrad_single(const void* P, const double* p_stats, const void* Q, con
 #define G3_GO(T) \
     if (kind == VS_CONV_K3) return cbsz == 16 ? g3_run<T, 16, G3_K3>(p, dw, m_real, c_real, st, rws, rsl) : g3_run<T, 8, G3_K3>(p, dw, m_real, c_real, st, rws, rsl); \
     return cbsz == 16 ? g3_run<T, 16, G3_K2S2>(p, dw, m_real, c_real, st, rws, rsl) : g3_run<T, 8, G3_K2S2>(p, dw, m_real, c_real, st, rws, rsl);
+    // both kernels address P and Q with signed 32-bit byte offsets (bounds-checked buffer loads)
+    if (dtype == VS_F32 && ((long long)n * dp * hp * wp * m_ch * 4 >= 2147483648ll || (long long)n * p.Dq * p.Hq * p.Wq * c_ch * 4 >= 2147483648ll)) return VS_ESHAPE;
     if (dtype == VS_F32) { G3_GO(float) }
 #undef G3_GO
     // g3b_kernel addresses P and Q with signed 32-bit byte offsets
