@@ -1066,6 +1066,34 @@ __global__ __launch_bounds__(256) void grid_barrier_probe_kernel(unsigned int* f
     __shared__ int s_fail;
     if (threadIdx.x == 0) s_fail = 0;
     __syncthreads();
+    if ((mode & 0xff) == 2 || (mode & 0xff) == 3) {
+        // Group protocol of an in-epilogue InstanceNorm-backward apply: groups of gsz = mode >> 8 workgroups; per iteration
+        // every workgroup adds 32 fp64 partial sums (what the backward-data kernels do today), then — mode 2 only — signals its group's counter
+        // (release), polls it, and reads the 32 totals back with device-scope atomic loads.  mode 3 = the atomics alone: the difference is the price.
+        // ticks[n_wg ..] holds the sums: [group][parity][32] doubles (zeroed by the caller).
+        const int gsz = mode >> 8, grp = blockIdx.x / gsz;
+        double* sums = (double*)(ticks + n_wg) + (size_t)grp * 64;
+        double sink = 0.0;
+        for (int it = 1; it <= iters; ++it) {
+            double* cur = sums + (it & 1) * 32;
+            if (threadIdx.x < 32) atomicAdd(cur + threadIdx.x, 1.0);
+            if ((mode & 0xff) == 2) {
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    __hip_atomic_fetch_add(flags + grp, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    int spins = 0;
+                    while (__hip_atomic_load(flags + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)it * (unsigned int)gsz && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+                    if (spins >= (1 << 20)) s_fail = 1;
+                }
+                __syncthreads();
+                if (s_fail) break;
+                if (threadIdx.x < 32) sink += __hip_atomic_load(cur + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (threadIdx.x < 32 && sink == -1.0) flags[n_wg] = 1u;            // keep the loads alive
+        if (threadIdx.x == 0) ticks[blockIdx.x] = s_fail ? ~0ull : __builtin_amdgcn_s_memrealtime() - t0;
+        return;
+    }
     if (mode == 1) {
         // one counter: every workgroup adds 1 and its thread 0 polls the counter (n serialized atomics + n pollers of one word)
         for (int it = 1; it <= iters; ++it) {
