@@ -571,7 +571,9 @@ def _fa_supported(gy, x, lazy_input):
 
 
 def _defer_register(g, x, xs, sums):
-    _LAZY_APPLY["grads"][(g.data_ptr(), tuple(g.shape))] = (x, xs, sums)
+    # g itself is kept in the entry: the key is its address, and a live reference is what guarantees that address cannot be recycled for another
+    # gradient of the same shape before the producing conv's backward takes the entry
+    _LAZY_APPLY["grads"][(g.data_ptr(), tuple(g.shape))] = (x, xs, sums, g)
     if not _LAZY_APPLY["callback"]:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_lazy_apply_done)
@@ -581,7 +583,8 @@ def _defer_register(g, x, xs, sums):
 
 
 def _take_lazy(g):
-    return _LAZY_APPLY["grads"].pop((g.data_ptr(), tuple(g.shape)), None) if _LAZY_APPLY["grads"] else None
+    ent = _LAZY_APPLY["grads"].pop((g.data_ptr(), tuple(g.shape)), None) if _LAZY_APPLY["grads"] else None
+    return None if ent is None else ent[:3]
 
 
 def _lazy_apply_done():
