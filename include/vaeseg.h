@@ -379,6 +379,15 @@ int vs_dice_loss_multi_fwd(const float* s, const float* const* t, const float* w
 int vs_dice_loss_multi_bwd(const float* s, const float* const* t, const float* w, int k, const double* scratch,
                            const float* gout, float* gs, float* const* gt, int batch, int channels, long long voxels,
                            int bot, int top, float eps, void* stream);
+/* The same with LABEL targets: labels[j] non-NULL (labels itself may be NULL) makes target j the one-hot of that label volume
+ * ([batch][voxels] floats, truncated to int as vs_onehot does: main_source.py:449-451) evaluated on the fly — t[j] is then ignored,
+ * gt[j] must be NULL, and the one-hot tensor (2 x the prediction's size, written once and read twice per step) never exists. */
+int vs_dice_loss_multi_labels_fwd(const float* s, const float* const* t, const float* const* labels, const float* w, int k, double* scratch,
+                                  float* terms, float* final_out, int batch, int channels, long long voxels, int bot, int top, float eps,
+                                  void* stream);
+int vs_dice_loss_multi_labels_bwd(const float* s, const float* const* t, const float* const* labels, const float* w, int k,
+                                  const double* scratch, const float* gout, float* gs, float* const* gt, int batch, int channels,
+                                  long long voxels, int bot, int top, float eps, void* stream);
 /* nn.BCELoss() mean reduction (utils/evaluation.py:29-39), log clamped at -100 like torch */
 int vs_bce_fwd(const float* p, const float* t, float* out, double* scratch, long long count, void* stream);
 int vs_bce_bwd(const float* p, const float* t, const float* gout, float* gp, long long count, void* stream);

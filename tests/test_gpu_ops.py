@@ -466,6 +466,34 @@ def test_grouped_weight_gradients_many_layers(dtype):
             assert relerr(gb, sb) < 1e-5, case
 
 
+def test_dice_loss_sum_label_target_equals_materialised_one_hot():
+    """ops.LabelTarget (the one-hot of main_source.py:449-451 evaluated inside the loss kernels) against the same loss on the materialised
+    one-hot: loss, terms and the gradients of the source and of the other target, bit for bit; also through the unfused spelling."""
+    ops = _ops()
+    b, c, side = 2, 2, 16
+    g = torch.Generator().manual_seed(11)
+    src = torch.softmax(torch.randn(b, c, side, side, side, generator=g), 1)
+    other = torch.softmax(torch.randn(b, c, side, side, side, generator=g), 1)
+    label = (torch.rand(b, 1, side, side, side, generator=g) > 0.6).float()
+    res = {}
+    for mode in ("label", "onehot", "label_unfused"):
+        ops.FUSED_LOSS[0] = mode != "label_unfused"
+        try:
+            s_g, o_g = src.cuda().requires_grad_(True), other.cuda().requires_grad_(True)
+            gt = ops.onehot(label.cuda(), c) if mode == "onehot" else ops.LabelTarget(label.cuda())
+            final, terms = ops.dice_loss_sum(s_g, [(o_g, 0.1), (gt, 1.0)], botindex=1, topindex=2, eps=1e-4)
+            final.backward()
+            res[mode] = (final.detach().cpu(), torch.stack([t.detach().cpu() for t in terms]), s_g.grad.cpu(), o_g.grad.cpu())
+        finally:
+            ops.FUSED_LOSS[0] = True
+    for a, b_ in zip(res["label"], res["onehot"]):
+        assert torch.equal(a, b_)
+    for a, b_ in zip(res["label_unfused"], res["onehot"]):
+        assert relerr(a, b_) < 1e-5
+    with pytest.raises(ValueError):                          # a label volume of the wrong size is refused, not mis-indexed
+        ops.dice_loss_sum(src.cuda(), [(ops.LabelTarget(label[:, :, :8].cuda()), 1.0)], botindex=1, topindex=2, eps=1e-4)
+
+
 @pytest.mark.parametrize("k", [1, 2, 3])
 def test_dice_loss_sum_matches_reference_spelling(k):
     """ops.dice_loss_sum (one launch each way) against the reference's spelling — 1 - avg_dsc per term, torch scalar arithmetic

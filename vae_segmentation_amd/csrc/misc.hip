@@ -551,6 +551,7 @@ extern "C" int vs_dice_bwd(const float* s, const float* t, const double* sums, c
 struct DiceMulti {
     const float* s;
     const float* t[DICE_MULTI_MAX];
+    const float* lab[DICE_MULTI_MAX];      // non-null: target j is the one-hot of these labels ([B][voxels] floats, truncated as vs_onehot does) — never materialised
     float* gt[DICE_MULTI_MAX];
     float w[DICE_MULTI_MAX];
     int k;
@@ -560,6 +561,14 @@ struct DiceMulti {
 // same-line fp64 atomic made a 432-block single-launch version (atomics + last-block ticket) cost 58 us; two small launches
 // cost 12, and the fixed summation order makes the loss bitwise reproducible.
 #define DICE_MULTI_BLOCKS 256
+// four consecutive values of target j in channel c of sample b
+__device__ __forceinline__ f32x4 dice_target4(const DiceMulti& a, int j, size_t plane, int b, int c, long long voxels, long long i) {
+    if (a.lab[j] != nullptr) {
+        const f32x4 l = *(const f32x4*)(a.lab[j] + (size_t)b * voxels + i * 4);
+        return f32x4{(int)l[0] == c ? 1.f : 0.f, (int)l[1] == c ? 1.f : 0.f, (int)l[2] == c ? 1.f : 0.f, (int)l[3] == c ? 1.f : 0.f};
+    }
+    return *(const f32x4*)(a.t[j] + plane + i * 4);
+}
 __global__ __launch_bounds__(256) void dice_multi_partial_kernel(const DiceMulti a, double* __restrict__ part, int channels, long long voxels, int bot) {
     const int c = bot + blockIdx.y, b = blockIdx.z, K = a.k;
     const size_t plane = ((size_t)b * channels + c) * voxels;
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(256) void dice_multi_partial_kernel(const DiceMulti
 #pragma unroll
         for (int j = 0; j < DICE_MULTI_MAX; ++j) {
             if (j < K) {
-                const f32x4 y = *(const f32x4*)(a.t[j] + plane + i * 4);
+                const f32x4 y = dice_target4(a, j, plane, b, c, voxels, i);
                 aI[j] += (double)(x[0] * y[0] + x[1] * y[1]) + (double)(x[2] * y[2] + x[3] * y[3]);
                 aT[j] += (double)(y[0] + y[1]) + (double)(y[2] + y[3]);
             }
@@ -669,15 +678,17 @@ __global__ __launch_bounds__(256) void dice_multi_finish_kernel(const DiceMulti 
     }
 }
 
-static int dice_multi_args(DiceMulti& a, const float* s, const float* const* t, const float* w, float* const* gt, int k) {
+static int dice_multi_args(DiceMulti& a, const float* s, const float* const* t, const float* w, float* const* gt, int k, const float* const* lab = nullptr) {
     if (!s || !t || !w || k <= 0 || k > DICE_MULTI_MAX) return VS_EINVAL;
     a = DiceMulti{};
     a.s = s; a.k = k;
     if ((uintptr_t)s & 15) return VS_EALIGN;
     for (int j = 0; j < k; ++j) {
-        if (!t[j]) return VS_EINVAL;
-        if (((uintptr_t)t[j] & 15) || (gt && gt[j] && ((uintptr_t)gt[j] & 15))) return VS_EALIGN;
-        a.t[j] = t[j]; a.w[j] = w[j]; a.gt[j] = gt ? gt[j] : nullptr;
+        const float* lj = lab ? lab[j] : nullptr;
+        if (!t[j] && !lj) return VS_EINVAL;
+        if (lj && gt && gt[j]) return VS_EINVAL;                 // a label target has no gradient
+        if (((uintptr_t)t[j] & 15) || ((uintptr_t)lj & 15) || (gt && gt[j] && ((uintptr_t)gt[j] & 15))) return VS_EALIGN;
+        a.t[j] = lj ? nullptr : t[j]; a.lab[j] = lj; a.w[j] = w[j]; a.gt[j] = gt ? gt[j] : nullptr;
     }
     return VS_OK;
 }
@@ -689,8 +700,14 @@ extern "C" size_t vs_dice_loss_multi_scratch_doubles(int k, int batch, int chann
 
 extern "C" int vs_dice_loss_multi_fwd(const float* s, const float* const* t, const float* w, int k, double* scratch, float* terms,
                                       float* final_out, int batch, int channels, long long voxels, int bot, int top, float eps, void* stream) {
+    return vs_dice_loss_multi_labels_fwd(s, t, nullptr, w, k, scratch, terms, final_out, batch, channels, voxels, bot, top, eps, stream);
+}
+
+extern "C" int vs_dice_loss_multi_labels_fwd(const float* s, const float* const* t, const float* const* labels, const float* w, int k, double* scratch,
+                                             float* terms, float* final_out, int batch, int channels, long long voxels, int bot, int top, float eps,
+                                             void* stream) {
     DiceMulti a;
-    int rc = dice_multi_args(a, s, t, w, nullptr, k);
+    int rc = dice_multi_args(a, s, t, w, nullptr, k, labels);
     if (rc) return rc;
     if (!scratch || !terms || !final_out || batch <= 0 || batch > 64 || channels <= 0 || voxels <= 0 || bot < 0 || top > channels || bot >= top) return VS_EINVAL;
     if (voxels & 3) return VS_EALIGN;
@@ -746,7 +763,7 @@ __global__ __launch_bounds__(256) void dice_multi_bwd_kernel(const DiceMulti a, 
         for (int j = 0; j < DICE_MULTI_MAX; ++j) {
             if (j < K) {
                 if (gs) {
-                    const f32x4 y = *(const f32x4*)(a.t[j] + plane + i * 4);
+                    const f32x4 y = dice_target4(a, j, plane, b, c, voxels, i);
                     acc[0] += k1[j] * y[0]; acc[1] += k1[j] * y[1]; acc[2] += k1[j] * y[2]; acc[3] += k1[j] * y[3];
                 }
                 if (a.gt[j]) *(f32x4*)(a.gt[j] + plane + i * 4) = f32x4{k1[j] * x[0] - k2[j], k1[j] * x[1] - k2[j], k1[j] * x[2] - k2[j], k1[j] * x[3] - k2[j]};
@@ -759,8 +776,14 @@ __global__ __launch_bounds__(256) void dice_multi_bwd_kernel(const DiceMulti a, 
 extern "C" int vs_dice_loss_multi_bwd(const float* s, const float* const* t, const float* w, int k, const double* scratch, const float* gout,
                                       float* gs, float* const* gt, int batch, int channels, long long voxels, int bot, int top, float eps,
                                       void* stream) {
+    return vs_dice_loss_multi_labels_bwd(s, t, nullptr, w, k, scratch, gout, gs, gt, batch, channels, voxels, bot, top, eps, stream);
+}
+
+extern "C" int vs_dice_loss_multi_labels_bwd(const float* s, const float* const* t, const float* const* labels, const float* w, int k,
+                                             const double* scratch, const float* gout, float* gs, float* const* gt, int batch, int channels,
+                                             long long voxels, int bot, int top, float eps, void* stream) {
     DiceMulti a;
-    int rc = dice_multi_args(a, s, t, w, gt, k);
+    int rc = dice_multi_args(a, s, t, w, gt, k, labels);
     if (rc) return rc;
     if (!scratch || !gout || batch <= 0 || channels <= 0 || voxels <= 0 || (voxels & 3) || bot < 0 || top > channels || bot >= top) return VS_EINVAL;
     if (gs && ((uintptr_t)gs & 15)) return VS_EALIGN;

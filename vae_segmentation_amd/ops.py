@@ -1838,6 +1838,15 @@ class Dice(torch.autograd.Function):
         return gs, gt, None, None, None, None
 
 
+class LabelTarget:
+    """A Dice target given as its LABEL volume (B,1,D,H,W; values 0..n_class-1): dice_loss_sum evaluates the one-hot (main_source.py:449-451) on
+    the fly inside the loss kernels, so the one-hot tensor is neither written nor read (vs_dice_loss_multi_labels_*)."""
+
+    def __init__(self, label):
+        _require_cuda(label)
+        self.label = _contig(label.float())
+
+
 class DiceLossSum(torch.autograd.Function):
     """final = sum_j w[j] * (1 - avg_dsc(s, t_j))  — the loss line of every train method (main_source.py:469-471,
     main_target.py:588-592) — in TWO forward launches (per-block partials, finish) and ONE backward launch: the source is read once
@@ -1845,21 +1854,28 @@ class DiceLossSum(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, s, bot, top, eps, weights, *targets):
+        # weights: one number per target, or (number, True) for a target that is a LABEL volume (LabelTarget: one-hot on the fly)
+        is_lab = [isinstance(w, tuple) and bool(w[1]) for w in weights]
+        weights = [w[0] if isinstance(w, tuple) else w for w in weights]
         _require_cuda(s, *targets)
         k = len(targets)
         s = _contig(s.float())
         ts = [_contig(t.float()) for t in targets]
         b, c = s.shape[0], s.shape[1]
         voxels = s.numel() // (b * c)
+        for t, lab in zip(ts, is_lab):
+            if lab and t.numel() != b * voxels:
+                raise ValueError("label target: expected %d x %d labels, got %s" % (b, voxels, tuple(t.shape)))
         scratch = torch.empty(lib.vs_dice_loss_multi_scratch_doubles(k, b, c), dtype=torch.float64, device=s.device)
         terms = torch.empty(k, dtype=torch.float32, device=s.device)
         final = torch.empty((), dtype=torch.float32, device=s.device)
-        tp = (_ct.c_void_p * k)(*[t.data_ptr() for t in ts])
+        tp = (_ct.c_void_p * k)(*[None if lab else t.data_ptr() for t, lab in zip(ts, is_lab)])
+        lp = (_ct.c_void_p * k)(*[t.data_ptr() if lab else None for t, lab in zip(ts, is_lab)])
         wp = (_ct.c_float * k)(*[float(w) for w in weights])
-        check(lib.vs_dice_loss_multi_fwd(s.data_ptr(), _ct.addressof(tp), _ct.addressof(wp), k, scratch.data_ptr(), terms.data_ptr(),
-                                         final.data_ptr(), b, c, voxels, bot, top, float(eps), _stream()), "dice_loss_multi_fwd")
+        check(lib.vs_dice_loss_multi_labels_fwd(s.data_ptr(), _ct.addressof(tp), _ct.addressof(lp), _ct.addressof(wp), k, scratch.data_ptr(),
+                                                terms.data_ptr(), final.data_ptr(), b, c, voxels, bot, top, float(eps), _stream()), "dice_loss_multi_fwd")
         ctx.save_for_backward(s, scratch, *ts)
-        ctx.cfg = (bot, top, float(eps), [float(w) for w in weights])
+        ctx.cfg = (bot, top, float(eps), [float(w) for w in weights], is_lab)
         ctx.mark_non_differentiable(terms)
         ctx.set_materialize_grads(False)      # no zero-fill launch for the terms' gradient
         return final, terms
@@ -1868,7 +1884,7 @@ class DiceLossSum(torch.autograd.Function):
     def backward(ctx, g, _gterms):
         s, scratch = ctx.saved_tensors[:2]
         ts = ctx.saved_tensors[2:]
-        bot, top, eps, weights = ctx.cfg
+        bot, top, eps, weights, is_lab = ctx.cfg
         if g is None:
             return (None,) * (5 + len(ts))
         k = len(ts)
@@ -1876,13 +1892,14 @@ class DiceLossSum(torch.autograd.Function):
         voxels = s.numel() // (b * c)
         g = _contig(g.float())
         gs = torch.empty_like(s) if ctx.needs_input_grad[0] else None
-        gts = [torch.empty_like(t) if ctx.needs_input_grad[5 + j] else None for j, t in enumerate(ts)]
+        gts = [torch.empty_like(t) if ctx.needs_input_grad[5 + j] and not is_lab[j] else None for j, t in enumerate(ts)]
         if gs is not None or any(x is not None for x in gts):
-            tp = (_ct.c_void_p * k)(*[t.data_ptr() for t in ts])
+            tp = (_ct.c_void_p * k)(*[None if lab else t.data_ptr() for t, lab in zip(ts, is_lab)])
+            lp = (_ct.c_void_p * k)(*[t.data_ptr() if lab else None for t, lab in zip(ts, is_lab)])
             gp = (_ct.c_void_p * k)(*[_p(x) for x in gts])
             wp = (_ct.c_float * k)(*weights)
-            check(lib.vs_dice_loss_multi_bwd(s.data_ptr(), _ct.addressof(tp), _ct.addressof(wp), k, scratch.data_ptr(), g.data_ptr(), _p(gs),
-                                             _ct.addressof(gp), b, c, voxels, bot, top, eps, _stream()), "dice_loss_multi_bwd")
+            check(lib.vs_dice_loss_multi_labels_bwd(s.data_ptr(), _ct.addressof(tp), _ct.addressof(lp), _ct.addressof(wp), k, scratch.data_ptr(),
+                                                    g.data_ptr(), _p(gs), _ct.addressof(gp), b, c, voxels, bot, top, eps, _stream()), "dice_loss_multi_bwd")
         return (gs, None, None, None, None) + tuple(gts)
 
 
@@ -1895,13 +1912,15 @@ def dice_loss_sum(source, targets_and_weights, botindex=0, topindex=2, eps=1e-6)
     channels = source.shape[1]
     bot, top = (botindex, min(topindex, channels)) if channels > 1 else (0, 1)
     if not FUSED_LOSS[0] or len(targets_and_weights) > 4:
+        targets_and_weights = [(onehot(t.label, channels) if isinstance(t, LabelTarget) else t, w) for t, w in targets_and_weights]
         terms = [1 - Dice.apply(source, t, bot, top, eps, True) for t, _ in targets_and_weights]
         final = None
         for term, (_, w) in zip(terms, targets_and_weights):
             part = term if w == 1 else w * term
             final = part if final is None else final + part
         return final, terms
-    final, terms = DiceLossSum.apply(source, bot, top, eps, [w for _, w in targets_and_weights], *[t for t, _ in targets_and_weights])
+    final, terms = DiceLossSum.apply(source, bot, top, eps, [(w, isinstance(t, LabelTarget)) for t, w in targets_and_weights],
+                                     *[t.label if isinstance(t, LabelTarget) else t for t, _ in targets_and_weights])
     return final, list(terms.unbind(0))
 
 

@@ -17,19 +17,35 @@ from . import ops
 from .evaluation import EPS_EVALUATION, EPS_MAIN_SOURCE, KLloss, avg_dsc, binarize, confident_binarize
 
 
+# The ground truth of these two methods feeds the loss only: its one-hot (main_source.py:449-451) is evaluated inside the loss kernels from the
+# label volume (ops.LabelTarget) instead of being written as a tensor first — one launch and 21 MB per step at 96^3.  VS_LAZY_ONEHOT=0 materialises
+# batch["gt"] as the reference does (the other methods, whose networks or losses read batch["gt"], always do).
+LAZY_ONEHOT = os.environ.get("VS_LAZY_ONEHOT", "1") != "0"
+
+
+def _gt(batch, label, n_class):
+    if LAZY_ONEHOT and label.is_cuda:
+        batch["label"] = label
+        return ops.LabelTarget(label)
+    batch["gt"] = ops.onehot(label, n_class)
+    return batch["gt"]
+
+
 def joint_train_losses(joint, img, label, lambda_vae=0.1, eps=EPS_MAIN_SOURCE, n_class=2):
-    batch = {"img": img, "gt": ops.onehot(label, n_class)}
+    batch = {"img": img}
+    gt = _gt(batch, label, n_class)
     batch = joint(batch, "img", "pred", "recon")
     # final = lambda_vae * (1 - avg_dsc(pred, recon)) + (1 - avg_dsc(pred, gt))        (main_source.py:469-471), one launch each way
-    final, (recon_loss, dsc_loss) = ops.dice_loss_sum(batch["pred"], [(batch["recon"], lambda_vae), (batch["gt"], 1.0)],
+    final, (recon_loss, dsc_loss) = ops.dice_loss_sum(batch["pred"], [(batch["recon"], lambda_vae), (gt, 1.0)],
                                                       botindex=1, topindex=n_class, eps=eps)
     return final, {"recon_loss": recon_loss, "dice_loss": dsc_loss, "batch": batch}
 
 
 def seg_train_losses(seg, img, label, eps=EPS_MAIN_SOURCE, n_class=2):
-    batch = {"img": img, "gt": ops.onehot(label, n_class)}
+    batch = {"img": img}
+    gt = _gt(batch, label, n_class)
     batch = seg(batch, "img", "pred")
-    final, (dsc_loss,) = ops.dice_loss_sum(batch["pred"], [(batch["gt"], 1.0)], botindex=1, topindex=n_class, eps=eps)
+    final, (dsc_loss,) = ops.dice_loss_sum(batch["pred"], [(gt, 1.0)], botindex=1, topindex=n_class, eps=eps)
     return final, {"dice_loss": dsc_loss, "batch": batch}
 
 
