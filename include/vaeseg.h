@@ -432,19 +432,6 @@ int vs_copy_scale_multi(const float* const* srcs, float* const* dsts, const long
 /* flat helper: dst[i] = src[i]*scale (dst may equal src: the 1/world scale after a sum all-reduce when the collective has no average) */
 int vs_scale_copy(const float* src, float* dst, long long count, float scale, void* stream);
 
-/* Measurement aid (no reference counterpart): one wave idles on the stream for `microseconds` (<= 1000).  bench.py's live
- * per-kernel timing enqueues it in front of each HIP-event bracket so that the event, kernel and event packets are already
- * queued when it retires; without it every packet of an eager step meets an idle queue and the bracket measures the
- * command processor's wake-up latency (2-7 us) on top of the kernel. */
-int vs_spin(int microseconds, void* stream);
-/* Measurement aid: `n_wg` (<= 1024, all resident) workgroups pass `iters` device-wide barriers (one release store per workgroup into
- * flags[n_wg], every workgroup polls all flags); ticks[n_wg] receives each workgroup's 100 MHz-clock ticks for the whole loop.
- * mode 1: one shared counter (fetch-add + poll) instead.  flags must be zero on entry.  Answers "what would fusing two dependent launches into one cost?" (profiles/README.md). */
-/* Measurement aid: n_wg workgroups of 256 threads each store (mode 0 plain, 1 non-temporal, 2 / 3 relaxed atomic store at agent / system
- * scope) or only load (mode 4) one float of p[n_wg * 256 + 1] (tools/launch_floor.py). */
-int vs_debug_store_probe(float* p, int n_wg, int mode, void* stream);
-int vs_debug_grid_barrier_probe(unsigned int* flags, unsigned long long* ticks, int n_wg, int iters, int mode, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,227 @@
+"""Does the benchmarked 16-bit step TRAIN like the fp32 step?  (VERDICT r03 "Next round" 1b / 1c.)
+
+At the benchmark's state — random weights, an image that carries no information about the label — the parameter gradients of the bf16 / fp16
+storage modes are nearly uncorrelated with the fp64 gradient (profiles/r03_parity_report.txt: median cosine 0.18), because the untrained
+network amplifies any rounding perturbation ~1e6 x.  That says nothing about whether a 16-bit step trains.  Here a LEARNABLE synthetic task
+(tests/learnable_task.py: the image carries the label, 8 training volumes cycled as 4 batches of 2, one held-out batch) is trained with
+exactly the loop of the reference (/root/reference/main_source.py:421-441 seg_train, :449-471 joint_train, :660-661 SGD step; momentum 0.9,
+lr 1e-2) through train.GraphedStep ON THE BENCHMARKED LIBRARY (libvaeseg.so, `atomic_mode`), 300 steps each in fp32 / bf16 / fp16 from the
+same weights, and
+
+  * the Dice loss of the 16-bit runs must stay within 0.05 of the fp32 run's at every 50-step checkpoint and within 0.02 at the end
+    (10-step window means);
+  * the held-out hard Dice is reported;
+  * at the TRAINED state (the fp32 run's step-300 weights at 96^3) the parameter gradients of the three modes are compared with the CPU
+    oracle's fp64 gradient: cosine and relative L2 per tensor — the number that decides whether bf16 may stay the headline mode.
+
+joint_train uses a VAE pre-trained for 150 fp32 steps on the task's label volumes (the reference loads one: --load_prefix_vae), frozen.
+The curves go to gpurun_out/r04_convergence.json (committed as profiles/r04_convergence.json); `pytest -s` prints the tables."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as G
+from tests import learnable_task
+
+pytestmark = pytest.mark.gpu
+
+STEPS, LR, MOM = 300, 1e-2, 0.9
+MODES = [("fp32", torch.float32), ("bf16", torch.bfloat16), ("fp16", torch.float16)]
+RESULTS = {}
+_STATE = {}
+
+
+def _mods():
+    import joint_model
+    from oracle import ref_cpu as O
+    from vae_segmentation_amd import evaluation, ops, optim
+    from vae_segmentation_amd import train as T
+    return joint_model, O, T, ops, optim, evaluation
+
+
+def _data(side):
+    if ("data", side) not in _STATE:
+        img, lab = learnable_task.volumes(10, side, seed=side)
+        _STATE[("data", side)] = (img.cuda(), lab.cuda())
+    return _STATE[("data", side)]
+
+
+def _pretrained_vae_state(side):
+    """150 eager fp32 vae_train steps (main_source.py:389-413) on the label volumes; the same frozen VAE goes into every joint run"""
+    key = ("vae", side)
+    if key not in _STATE:
+        M, O, T, ops, optim, _ = _mods()
+        vae = O.deterministic_fill_(M.VAE(2, 2, norm_type=1, dim=128, spatial=side), seed=0).cuda()
+        opt = optim.SGD(vae.parameters(), lr=LR, momentum=MOM)
+        _, lab = _data(side)
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        first = last = None
+        for i in range(150):
+            b = (i % 4) * 2
+            opt.zero_grad()
+            noise = torch.randn(2, 128, device="cuda", generator=gen)
+            loss, aux = T.vae_train_losses(vae, lab[b:b + 2], scale=0.35, noise=noise)
+            loss.backward()
+            opt.step()
+            if i == 0:
+                first = float(aux["dice_loss"])
+            last = float(aux["dice_loss"])
+        print("\nVAE pre-training at %d^3: reconstruction Dice loss %.3f -> %.3f in 150 steps" % (side, first, last))
+        _STATE[key] = {k: v.detach().clone() for k, v in vae.state_dict().items()}
+        del vae, opt
+        ops.clear_pack_cache()
+    return _STATE[key]
+
+
+def _build(method, side, dtype):
+    M, O, T, ops, optim, _ = _mods()
+    seg = M.Segmentation(n_channels=1, n_class=2, norm_type=1)
+    if method == "seg_train":
+        net = O.deterministic_fill_(seg, seed=0).cuda()
+        M.set_kernel_dtype(net, dtype)
+        return net, net
+    vae = M.VAE(n_channels=2, n_class=2, norm_type=1, dim=128, spatial=side)
+    joint = M.Joint(models=[seg, vae])
+    O.deterministic_fill_(joint, seed=0)
+    joint = joint.cuda()
+    joint.Vae.load_state_dict(_pretrained_vae_state(side))
+    for p in joint.Vae.parameters():
+        p.requires_grad = False
+    joint.Vae.eval()
+    ops.clear_pack_cache()
+    M.set_kernel_dtype(joint, dtype)
+    return joint, joint.Seg
+
+
+def _train(method, side, name, dtype):
+    """-> (per-step Dice loss [STEPS], held-out hard Dice, the trained Segmentation)"""
+    M, O, T, ops, optim, E = _mods()
+    img, lab = _data(side)
+    net, seg = _build(method, side, dtype)
+    params = [p for p in seg.parameters()]
+    opt = optim.SGD(params, lr=LR, momentum=MOM)
+    scaler = optim.LossScaler() if dtype == torch.float16 else None
+    ib, lb = img[0:2].clone(), lab[0:2].clone()
+    if method == "seg_train":
+        loss_fn = lambda: T.seg_train_losses(net, ib, lb)
+    else:
+        loss_fn = lambda: T.joint_train_losses(net, ib, lb, lambda_vae=0.1)
+    gs = T.GraphedStep(loss_fn, params, opt, warmup=1, scaler=scaler)
+    curve = torch.zeros(STEPS, device="cuda")
+    for i in range(STEPS):
+        b = (i % 4) * 2
+        ib.copy_(img[b:b + 2])
+        lb.copy_(lab[b:b + 2])
+        gs.step()
+        curve[i] = gs.aux["dice_loss"].detach()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        batch = {"img": img[8:10], "gt": ops.onehot(lab[8:10], 2)}
+        batch = seg(batch, "img", "pred")
+        held = float(E.avg_dsc(batch, "pred", "gt", binary=True, botindex=1, topindex=2))
+    gs.loss = gs.aux = None
+    return curve.cpu().numpy().astype(np.float64), held, seg
+
+
+def _window(curve, end, width=10):
+    return float(curve[max(0, end - width):end].mean())
+
+
+def _dump():
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "r04_convergence.json"), "w") as f:
+            json.dump(RESULTS, f, indent=1)
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("method,side", [("seg_train", 64), ("joint_train", 64), ("joint_train", 96)])
+def test_16bit_modes_train_like_fp32(method, side, atomic_mode):
+    from vae_segmentation_amd import ops
+    assert not ops.is_deterministic()                          # libvaeseg.so: the benchmarked library
+    curves, held = {}, {}
+    for name, dtype in MODES:
+        curves[name], held[name], seg = _train(method, side, name, dtype)
+        if name == "fp32" and method == "joint_train" and side == 96:
+            _STATE["trained_seg96"] = {k: v.detach().clone() for k, v in seg.state_dict().items()}
+        del seg
+    marks = list(range(50, STEPS + 1, 50))
+    print("\n==== %s at %d^3, batch 2, SGD(lr %g, momentum %g), %d steps: Dice loss (10-step window means) ====" % (method, side, LR, MOM, STEPS))
+    print("%-6s %8s " % ("mode", "step 1") + " ".join("%8d" % m for m in marks) + "   held-out hard Dice")
+    for name, _ in MODES:
+        print("%-6s %8.4f " % (name, curves[name][0]) + " ".join("%8.4f" % _window(curves[name], m) for m in marks) + "   %.4f" % held[name])
+    RESULTS["%s_%d" % (method, side)] = {
+        "method": method, "side": side, "batch": 2, "steps": STEPS, "lr": LR, "momentum": MOM, "library": "libvaeseg.so (fp64-atomic statistics)",
+        "checkpoints": marks, "window": 10,
+        "dice_loss_at_checkpoints": {n: [_window(curves[n], m) for m in marks] for n, _ in MODES},
+        "held_out_hard_dice": held, "dice_loss_curve": {n: [round(float(v), 5) for v in curves[n]] for n, _ in MODES}}
+    _dump()
+    assert curves["fp32"][0] > 0.5 and _window(curves["fp32"], STEPS) < 0.5 * curves["fp32"][0], "the fp32 run itself must learn the task"
+    for name in ("bf16", "fp16"):
+        for m in marks:
+            d = abs(_window(curves[name], m) - _window(curves["fp32"], m))
+            assert d < (0.02 if m == STEPS else 0.05), "%s vs fp32 at step %d: %.4f vs %.4f" % (
+                name, m, _window(curves[name], m), _window(curves["fp32"], m))
+        assert abs(held[name] - held["fp32"]) < 0.05, (name, held)
+
+
+def test_gradient_fidelity_at_a_trained_state(atomic_mode):
+    """the fp32 run's step-300 weights at 96^3 (joint_train): CPU oracle fp64 gradient on a training batch vs the HIP gradients of the three modes"""
+    M, O, T, ops, optim, _ = _mods()
+    side = 96
+    if "trained_seg96" not in _STATE:
+        _, _, seg = _train("joint_train", side, "fp32", torch.float32)
+        _STATE["trained_seg96"] = {k: v.detach().clone() for k, v in seg.state_dict().items()}
+        del seg
+    img, lab = _data(side)
+    ib, lb = img[0:2], lab[0:2]
+    oj = O.build_joint(side).double()
+    oj.Seg.load_state_dict({k: v.double().cpu() for k, v in _STATE["trained_seg96"].items()})
+    oj.Vae.load_state_dict({k: v.double().cpu() for k, v in _pretrained_vae_state(side).items()})
+    ol, _ = O.joint_train_losses(oj, ib.double().cpu(), lb.cpu())
+    ol.backward()
+    g64 = {n: p.grad.detach().clone() for n, p in oj.Seg.named_parameters()}
+    o32 = O.build_joint(side)
+    o32.Seg.load_state_dict({k: v.cpu() for k, v in _STATE["trained_seg96"].items()})
+    o32.Vae.load_state_dict({k: v.cpu() for k, v in _pretrained_vae_state(side).items()})
+    l32, _ = O.joint_train_losses(o32, ib.cpu(), lb.cpu())
+    l32.backward()
+    rows = {"oracle fp32": (float(l32), {n: p.grad.detach().double() for n, p in o32.Seg.named_parameters()})}
+    for name, dtype in MODES:
+        joint, seg = _build("joint_train", side, dtype)
+        seg.load_state_dict(_STATE["trained_seg96"])
+        ops.weights_changed()
+        seed = torch.tensor(1024.0, device="cuda") if dtype == torch.float16 else None
+        final, _ = T.joint_train_losses(joint, ib, lb, lambda_vae=0.1)
+        final.backward(gradient=seed)
+        sc = 1024.0 if dtype == torch.float16 else 1.0
+        rows["HIP " + name] = (float(final), {n: p.grad.detach().double().cpu() / sc for n, p in seg.named_parameters()})
+        del joint, seg
+    print("\n==== gradient fidelity at a TRAINED state (joint_train 96^3 B=2, fp32 run's step-%d weights), against the CPU oracle in fp64 ====" % STEPS)
+    print("loss: oracle fp64 %.6f" % float(ol))
+    summary = {}
+    for tag, (loss, g) in rows.items():
+        cos, rl2 = [], []
+        for n, ref in g64.items():
+            if G.is_dead_bias(n) or float(ref.norm()) == 0:
+                continue
+            cos.append(float((g[n] * ref).sum() / (g[n].norm() * ref.norm()).clamp_min(1e-300)))
+            rl2.append(float((g[n] - ref).norm() / ref.norm()))
+        flat = torch.cat([g[n].flatten() for n in g64 if not G.is_dead_bias(n)])
+        flat64 = torch.cat([g64[n].flatten() for n in g64 if not G.is_dead_bias(n)])
+        whole = float((flat * flat64).sum() / (flat.norm() * flat64.norm()))
+        cs, rs = sorted(cos), sorted(rl2)
+        summary[tag] = {"loss": loss, "cosine_min": cs[0], "cosine_median": cs[len(cs) // 2], "cosine_whole_gradient": whole,
+                        "rel_l2_median": rs[len(rs) // 2], "rel_l2_max": rs[-1]}
+        print("%-12s loss %.6f | per-tensor cosine to fp64: min %.3f median %.3f | whole-gradient cosine %.3f | relative L2: median %.3e max %.3e"
+              % (tag, loss, cs[0], cs[len(cs) // 2], whole, rs[len(rs) // 2], rs[-1]))
+    RESULTS["trained_state_gradient_fidelity_joint_train_96"] = summary
+    _dump()
+    assert abs(rows["HIP fp32"][0] - float(ol)) < 1e-3 * abs(float(ol)) + 1e-5
+    for name in ("bf16", "fp16"):
+        assert abs(rows["HIP " + name][0] - float(ol)) < 2e-2 * abs(float(ol)) + 1e-3

@@ -36,6 +36,20 @@ def _ops():
     return ops
 
 
+def _last_call(fn):
+    """One-slot memo for the CPU references: the two `lib_mode` runs of a case (tests/conftest.py; innermost parameter, so they are
+    neighbours) share one F.conv3d autograd pass instead of paying for it twice.  One slot: a 96^3 reference is hundreds of MB."""
+    slot = {}
+
+    def wrapped(*key):
+        if slot.get("key") != key:
+            slot.clear()
+            slot["val"] = fn(*key)
+            slot["key"] = key
+        return slot["val"]
+    return wrapped
+
+
 def _report(tag, errs, lims):
     bad = {k: (errs[k], lims[k]) for k in errs if not errs[k] < lims[k]}
     print("\n%s: %s" % (tag, ", ".join("%s %.2e (<%.1e)" % (k, errs[k], lims[k]) for k in errs)))
@@ -75,8 +89,8 @@ def test_transposed_layer_shapes_160(case, dtype):
     test_transposed_layer_shapes(case, dtype)
 
 
-def _k3_case(case, dtype):
-    ops = _ops()
+@_last_call
+def _k3_ref(case, dtype):
     n, cin, cout, s = case
     x = rnd(n, cin, s, s, s, seed=1)
     wt = rnd(cout, cin, 3, 3, 3, seed=2, scale=(3.0 / (27 * cin)) ** 0.5)
@@ -84,6 +98,13 @@ def _k3_case(case, dtype):
     xq, wq, gq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), q(gy, dtype)
     y_ref = F.conv3d(in_relu(xq), wq, None, padding=1)
     (y_ref * gq).sum().backward()
+    return x, wt, gy, xq, wq, y_ref.detach()
+
+
+def _k3_case(case, dtype):
+    ops = _ops()
+    n, cin, cout, s = case
+    x, wt, gy, xq, wq, y_ref = _k3_ref(case, dtype)
 
     x_cl = to_cl(x, ops.cpad(cin), dtype).requires_grad_(True)
     xs = ops.instnorm_stats(x_cl.detach())
@@ -107,10 +128,8 @@ def _k3_case(case, dtype):
     _report("k3 %s %s" % (case, dtype), errs, lims)
 
 
-@pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("case", K2_LAYERS)
-def test_k2s2_layer_shapes(case, dtype):
-    ops = _ops()
+@_last_call
+def _k2s2_ref(case, dtype):
     n, c, s = case
     x = rnd(n, c, s, s, s, seed=4)
     wt = rnd(c, c, 2, 2, 2, seed=5, scale=(3.0 / (8 * c)) ** 0.5)
@@ -119,6 +138,15 @@ def test_k2s2_layer_shapes(case, dtype):
     xq, wq, bq, gq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), b.clone().requires_grad_(True), q(gy, dtype)
     y_ref = F.conv3d(in_relu(xq), wq, bq, stride=2)
     (y_ref * gq).sum().backward()
+    return x, wt, b, gy, xq, wq, bq, y_ref.detach()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", K2_LAYERS)
+def test_k2s2_layer_shapes(case, dtype):
+    ops = _ops()
+    n, c, s = case
+    x, wt, b, gy, xq, wq, bq, y_ref = _k2s2_ref(case, dtype)
     x_cl = to_cl(x, c, dtype).requires_grad_(True)
     xs = ops.instnorm_stats(x_cl.detach())
     w_gpu, b_gpu = q(wt, dtype).cuda().requires_grad_(True), b.cuda().requires_grad_(True)
@@ -132,10 +160,8 @@ def test_k2s2_layer_shapes(case, dtype):
     _report("k2s2 %s %s" % (case, dtype), errs, {"y": tol, "gx": 4 * tol, "gw": 4 * tol, "gb": 4 * tol})
 
 
-@pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("case", T2_LAYERS)
-def test_transposed_layer_shapes(case, dtype):
-    ops = _ops()
+@_last_call
+def _t2_ref(case, dtype):
     n, c, s = case
     x = rnd(n, c, s, s, s, seed=8)
     wt = rnd(c, c, 2, 2, 2, seed=9, scale=(3.0 / c) ** 0.5)
@@ -144,6 +170,15 @@ def test_transposed_layer_shapes(case, dtype):
     xq, wq, bq, gq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), b.clone().requires_grad_(True), q(gy, dtype)
     y_ref = F.conv_transpose3d(in_relu(xq), wq, bq, stride=2)
     (y_ref * gq).sum().backward()
+    return x, wt, b, gy, xq, wq, bq, y_ref.detach()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", T2_LAYERS)
+def test_transposed_layer_shapes(case, dtype):
+    ops = _ops()
+    n, c, s = case
+    x, wt, b, gy, xq, wq, bq, y_ref = _t2_ref(case, dtype)
     x_cl = to_cl(x, c, dtype).requires_grad_(True)
     xs = ops.instnorm_stats(x_cl.detach())
     w_gpu, b_gpu = q(wt, dtype).cuda().requires_grad_(True), b.cuda().requires_grad_(True)
@@ -157,12 +192,8 @@ def test_transposed_layer_shapes(case, dtype):
     _report("convT %s %s" % (case, dtype), errs, {"y": tol, "gx": 4 * tol, "gw": 4 * tol, "gb": 4 * tol})
 
 
-@pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("case", [(2, 96), (1, 128)])
-def test_out_block_softmax_layer_shapes(case, dtype):
-    """out_block (8 -> 2, live bias) + Softmax at full resolution, with the backward through the softmax, the fused IN-backward sums and
-    the weight / bias gradients (joint_model.py:366-367,386-388)."""
-    ops = _ops()
+@_last_call
+def _out_block_ref(case, dtype):
     n, s = case
     x = rnd(n, 8, s, s, s, seed=12)
     wt = rnd(2, 8, 3, 3, 3, seed=13, scale=0.3)
@@ -171,6 +202,17 @@ def test_out_block_softmax_layer_shapes(case, dtype):
     xq, wq, bq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), b.clone().requires_grad_(True)
     p_ref = torch.softmax(F.conv3d(in_relu(xq), wq, bq, padding=1), dim=1)
     (p_ref * gp).sum().backward()
+    return x, wt, b, gp, xq, wq, bq, p_ref.detach()
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [(2, 96), (1, 128)])
+def test_out_block_softmax_layer_shapes(case, dtype):
+    """out_block (8 -> 2, live bias) + Softmax at full resolution, with the backward through the softmax, the fused IN-backward sums and
+    the weight / bias gradients (joint_model.py:366-367,386-388)."""
+    ops = _ops()
+    n, s = case
+    x, wt, b, gp, xq, wq, bq, p_ref = _out_block_ref(case, dtype)
     x_cl = to_cl(x, 8, dtype).requires_grad_(True)
     xs = ops.instnorm_stats(x_cl.detach())
     w_gpu, b_gpu = q(wt, dtype).cuda().requires_grad_(True), b.cuda().requires_grad_(True)

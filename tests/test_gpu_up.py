@@ -25,6 +25,25 @@ def _ops():
     return ops
 
 
+from tests.test_gpu_layers import _last_call          # noqa: E402  (one-slot memo of the CPU reference, shared by the two lib_mode runs of a case)
+
+
+@_last_call
+def _up_ref(case, dtype, lazy):
+    n, c, co, d, h, w = case
+    x = rnd(n, c, d, h, w, seed=21)
+    w2 = rnd(c, c, 2, 2, 2, seed=22, scale=(3.0 / c) ** 0.5)
+    b2 = rnd(c, seed=23, scale=0.3)
+    w3 = rnd(co, c, 3, 3, 3, seed=24, scale=(3.0 / (27 * c)) ** 0.5)
+    gy = rnd(n, co, 2 * d, 2 * h, 2 * w, seed=25)
+    xq, gq = q(x, dtype).requires_grad_(True), q(gy, dtype)
+    w2q, w3q = q(w2, dtype), q(w3, dtype)
+    a = in_relu(xq) if lazy else xq
+    y_ref = F.conv3d(F.conv_transpose3d(a, w2q, b2, stride=2), w3q, None, padding=1)
+    (y_ref * gq).sum().backward()
+    return x, b2, gy, xq, w2q, w3q, y_ref.detach()
+
+
 @pytest.mark.parametrize("lazy", [True, False])
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", UP_CASES)
@@ -36,16 +55,7 @@ def test_up_composed_vs_cpu_autograd(case, dtype, lazy):
     big = n * d * h * w * c > 3_000_000
     if big and not lazy:
         pytest.skip("the large shapes run once, with the lazy input the networks use")
-    x = rnd(n, c, d, h, w, seed=21)
-    w2 = rnd(c, c, 2, 2, 2, seed=22, scale=(3.0 / c) ** 0.5)
-    b2 = rnd(c, seed=23, scale=0.3)
-    w3 = rnd(co, c, 3, 3, 3, seed=24, scale=(3.0 / (27 * c)) ** 0.5)
-    gy = rnd(n, co, 2 * d, 2 * h, 2 * w, seed=25)
-    xq, gq = q(x, dtype).requires_grad_(True), q(gy, dtype)
-    w2q, w3q = q(w2, dtype), q(w3, dtype)
-    a = in_relu(xq) if lazy else xq
-    y_ref = F.conv3d(F.conv_transpose3d(a, w2q, b2, stride=2), w3q, None, padding=1)
-    (y_ref * gq).sum().backward()
+    x, b2, gy, xq, w2q, w3q, y_ref = _up_ref(case, dtype, lazy)
 
     x_cl = to_cl(x, c, dtype).requires_grad_(True)
     xs = ops.instnorm_stats(x_cl.detach()) if lazy else None
@@ -143,3 +153,71 @@ def test_up_block_module_uses_composed_path_when_frozen(dtype):
     print("\nUp module composed vs two-launch (%s): y %.2e, grad %.2e (relative L2)" % (dtype, ey, eg))
     # two 16-bit evaluations of the same block: each rounds differently, and three InstanceNorm/ReLU layers follow (a flipped ReLU edge moves single gradient elements by O(0.1))
     assert ey < 4 * TOL[dtype] and eg < {torch.bfloat16: 0.15, torch.float16: 0.05}[dtype]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_trainable_composed_up_multi_step_matches_two_launch_form(dtype, monkeypatch):
+    """The trainable composed head across optimiser steps: `Up` (joint_model.py:114-124) trained for 4 SGD(momentum) steps with the
+    composed operator forced on at a small size — eagerly and through a captured train.GraphedStep (raw-address chain-rule job, re-composition
+    of the images after every step by ops.weights_changed) — against the two-launch form of the same module.  Graph and eager run the same
+    kernels on the same data (tight bound); composed vs two-launch are two 16-bit evaluations of the block (the bound of the frozen test above)."""
+    import joint_model as M
+    from oracle import ref_cpu as O
+    from vae_segmentation_amd import optim
+    from vae_segmentation_amd import train as T
+    ops = _ops()
+    monkeypatch.setattr(ops, "FUSE_UP_TRAINABLE", True)
+    monkeypatch.setattr(ops, "FUSE_UP_TRAINABLE_MIN_VOXELS", 0)
+    monkeypatch.setattr(ops, "FUSE_UP_MIN_VOXELS", 0)
+    x = rnd(2, 32, 12, 12, 12, seed=61).cuda()
+    steps = 4
+
+    def run(fuse, graph):
+        monkeypatch.setattr(ops, "FUSE_UP", fuse)
+        up = O.deterministic_fill_(M.Up(32, 16, norm_type=1), seed=5).cuda()
+        M.set_kernel_dtype(up, dtype)
+        params = [p for p in up.parameters()]
+        opt = optim.SGD(params, lr=0.05, momentum=0.9)
+        n_reg = len(ops._UP_TRAINABLE)
+
+        def loss_fn():
+            ops.stats_arena_begin(x.device)
+            y = up(x)
+            return (y.float() ** 2).mean(), {}
+
+        losses = []
+        if graph:
+            gs = T.GraphedStep(loss_fn, params, opt, warmup=1)
+            for _ in range(steps):
+                losses.append(gs.step().detach().clone())
+            gs.loss = gs.aux = None
+        else:
+            for _ in range(steps):
+                for p_ in params:
+                    p_.grad = None
+                loss, _ = loss_fn()
+                loss.backward()
+                opt.step()
+                losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        assert (len(ops._UP_TRAINABLE) > n_reg) == fuse, "composed trainable path %s" % ("was not taken" if fuse else "was taken")
+        return [float(v) for v in losses], {n: p.detach().float().cpu().clone() for n, p in up.named_parameters()}
+
+    init = {n: p.detach().float().clone() for n, p in O.deterministic_fill_(M.Up(32, 16, norm_type=1), seed=5).named_parameters()}
+    l_e, w_e = run(True, False)
+    l_g, w_g = run(True, True)
+    l_t, w_t = run(False, False)
+    rl2 = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-20))
+    print("\ntrainable composed Up, %s: losses eager %s | graph %s | two-launch %s" % (dtype, ["%.5f" % v for v in l_e], ["%.5f" % v for v in l_g], ["%.5f" % v for v in l_t]))
+    live = [n for n in w_e if float((w_t[n] - init[n]).norm()) > 1e-6 * float(init[n].norm()) + 1e-9]          # parameters that moved (dead biases do not)
+    assert len(live) >= 4, live
+    for n in live:
+        # the same kernels, replayed: weights after 4 steps agree to rounding of the fp64-atomic statistics (bit-identical on the deterministic build)
+        assert rl2(w_g[n], w_e[n]) < (1e-6 if ops.is_deterministic() else 1e-3), n
+        # composed vs two-launch: compare the UPDATE the 4 steps made
+        du_c, du_t = w_e[n] - init[n], w_t[n] - init[n]
+        assert rl2(du_c, du_t) < {torch.bfloat16: 0.25, torch.float16: 0.08}[dtype], (n, rl2(du_c, du_t))
+    for a, b in zip(l_e, l_t):
+        assert abs(a - b) < 4 * TOL[dtype] * abs(b) + 1e-6
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) < 1e-4 * abs(b) + 1e-7

@@ -3,7 +3,8 @@ dependent launches into one.  usage: python tools/barrier_probe.py [iters]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vae_segmentation_amd._lib import lib, check
+from vae_segmentation_amd import _lib  # noqa: F401  (loads torch's HIP runtime first)
+from tools.probe import lib, check
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 for mode, n in [(m, n) for m in (0, 1) for n in (8, 32, 72, 144, 256, 288, 432, 512)]:
     flags = torch.zeros(n, dtype=torch.int32, device="cuda")

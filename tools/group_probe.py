@@ -3,7 +3,8 @@ partial sums by fp64 atomics (done today), then group counter + poll + atomic lo
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vae_segmentation_amd._lib import lib, check
+from vae_segmentation_amd import _lib  # noqa: F401  (loads torch's HIP runtime first)
+from tools.probe import lib, check
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 for n, gsz in [(32, 1), (64, 4), (72, 9), (144, 9), (288, 72), (288, 144), (256, 256)]:
     res = {}

@@ -3,7 +3,8 @@ eager stream launches.  usage: python tools/launch_floor.py [N]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vae_segmentation_amd._lib import lib, check
+from vae_segmentation_amd import _lib  # noqa: F401  (loads torch's HIP runtime first)
+from tools.probe import lib, check
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):

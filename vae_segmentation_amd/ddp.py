@@ -71,6 +71,7 @@ class FlatGradSync:
         self._tab, self._tab0 = _Tables(), _Tables()
         self._async = self.overlap
         self._works = []
+        self._no_grad = set()           # ids of parameters whose .grad was None in the last pass (see _stragglers / live)
         self._avg = True
         if self.direct:
             from . import ops
@@ -97,24 +98,26 @@ class FlatGradSync:
     def live(self):
         """(params, views) of the parameters that take part in this step: requires_grad may be switched off for some of them after
         construction (embed_train freezes its Encoder on even epochs, main_source.py:550-554) — their slots are still exchanged (zeros or
-        an old average, harmless) but must never reach the optimiser."""
-        keep = [i for i, p in enumerate(self.params) if p.requires_grad]
+        an old average, harmless) but must never reach the optimiser.  The same holds for a parameter that received NO gradient in this pass
+        (`.grad is None`): the single-GPU path and the reference's optimisers skip it, so it is skipped here too — no momentum drift or
+        weight decay on a gradient that does not exist, and the same result at every world size."""
+        keep = [i for i, p in enumerate(self.params) if p.requires_grad and id(p) not in self._no_grad]
         return [self.params[i] for i in keep], [self.views[i] for i in keep]
 
     def _stragglers(self, grads, only=None):
         """Gradients that did not land in their slot (accumulation into an existing .grad, hooks, direct=False, every non-conv parameter:
         Linear weights, BatchNorm affine): gathered by one multi-tensor copy.  In the steady state of the direct mode with conv-only
-        networks this list is empty and nothing is launched.  A parameter that received NO gradient in this pass has its slot zeroed —
-        the slot still holds the previous step's average, which the optimiser would otherwise apply again.
+        networks this list is empty and nothing is launched.  A parameter that received NO gradient in this pass is remembered in
+        self._no_grad: its slot (the previous step's average, or zeros) is exchanged like the rest but live() keeps it from the optimiser.
         only: a set of parameter ids restricting the pass to one bucket."""
         src, dst = [], []
         for p, g, v in zip(self.params, grads, self.views):
             if only is not None and id(p) not in only:
                 continue
             if g is None:
-                if p.requires_grad:
-                    v.zero_()
+                self._no_grad.add(id(p))
                 continue
+            self._no_grad.discard(id(p))
             if g.data_ptr() != v.data_ptr():
                 src.append(g)
                 dst.append(v)

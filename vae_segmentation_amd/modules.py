@@ -182,6 +182,7 @@ class Down(nn.Module):
 
 
 _RECOMPUTE = [False]
+_RECOMPUTE_SAVED_GROUPING = [True]
 
 
 def set_recompute(enabled=True):
@@ -191,15 +192,32 @@ def set_recompute(enabled=True):
     (entry points: --recompute) for volumes that need the memory.  In the deterministic build the recomputed statistics are bit-identical
     to the first pass, so are the gradients (tests/test_gpu_fp16.py).  Costs launches as well as bandwidth: the weight gradients leave the
     grouped end-of-pass launches (they would pin every operand until the end)."""
-    _RECOMPUTE[0] = bool(enabled)
+    enabled = bool(enabled)
+    if enabled == _RECOMPUTE[0]:
+        return                          # nothing to switch: in particular set_recompute(False) on a fresh process leaves VS_WGRAD_GROUP / set_wgrad_grouping alone
+    _RECOMPUTE[0] = enabled
     # the grouped weight gradients are deferred to the end of backward and keep every layer's operands alive until then — exactly the memory
-    # recomputation is meant to free: in this mode each layer's weight gradient is launched where its backward runs
-    ops.set_wgrad_grouping(not enabled)
+    # recomputation is meant to free: in this mode each layer's weight gradient is launched where its backward runs; switching recomputation off
+    # restores whatever grouping was in force before it was switched on
+    if enabled:
+        _RECOMPUTE_SAVED_GROUPING[0] = bool(ops._GROUP["enabled"])
+        ops.set_wgrad_grouping(False)
+    else:
+        ops.set_wgrad_grouping(_RECOMPUTE_SAVED_GROUPING[0])
+
+
+def _has_training_batchnorm(blk):
+    return any(isinstance(m, nn.BatchNorm3d) and m.training for m in blk.modules())
 
 
 def _run_block(blk, a):
     """blk(a) for a Down / Up block on a lazy activation; under set_recompute the block's interior activations are not kept."""
     if not (_RECOMPUTE[0] and torch.is_grad_enabled() and a.raw.requires_grad):
+        return blk(a)
+    if _has_training_batchnorm(blk):
+        # BatchNorm3d in training mode updates running_mean / running_var / num_batches_tracked in its forward (ops.NormAct): the recomputation
+        # pass would apply the momentum update a second time per step.  Such blocks keep their activations (no reference entry point builds them:
+        # every script passes norm_type=1).
         return blk(a)
     from torch.utils.checkpoint import checkpoint
 

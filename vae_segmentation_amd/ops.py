@@ -10,6 +10,7 @@ For autograd, ``stats`` is a non-differentiable side output and the gradient att
 total derivative (the InstanceNorm+ReLU backward is applied by the consumer's backward).
 """
 import os
+import weakref as _weakref
 
 import torch
 
@@ -79,6 +80,7 @@ def _k3_kid(tname, ck, mt, sums=False, geom=None, m=None, lazy=False):
 
 
 PROFILE_PRIME_US = 80
+PROFILE_SPIN = [None]          # set by profiling.py (the measurement aid lives in tools/probe/libvsprobe.so, not in the product library)
 
 
 class _timed:
@@ -88,9 +90,9 @@ class _timed:
     def __enter__(self):
         if self.rec is not None:
             if PROFILE_PRIME_US:
-                # keep the queue busy while the bracket is enqueued (include/vaeseg.h, vs_spin): the two event packets and
+                # keep the queue busy while the bracket is enqueued (tools/probe: vs_spin): the two event packets and
                 # the kernel then run back to back, as the kernel does inside the replayed graph
-                check(lib.vs_spin(PROFILE_PRIME_US, _stream()), "spin")
+                PROFILE_SPIN[0](PROFILE_PRIME_US, _stream())
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             self.rec.append(e)
@@ -1205,7 +1207,10 @@ def _up_stamp(wt, bt, w3):
             _TRAIN_EPOCH[0] if (w3.requires_grad or wt.requires_grad) else _PACK_EPOCH[0])
 
 
-_UP_TRAINABLE = {}      # id(w3) -> (plan, wt, bt, w3, dtype): composed images of trainable Up heads, re-composed by repack_trainable() after every optimiser step
+# (id(w3), dtype) -> weak references to (wt, bt, w3): the trainable Up heads whose composed images repack_trainable() re-composes after every
+# optimiser step.  Weak: a model that has been dropped (TestTimeFinetune copies, test fixtures) leaves the registry with its parameters, the
+# plan itself lives on w3 (`_vs_up_plan`).  Entries are NOT pruned by use: a captured graph replays the composed kernels without running up_plan.
+_UP_TRAINABLE = {}
 
 
 def _up_compose_into(plan, wt, bt, w3, dtype):
@@ -1233,8 +1238,8 @@ def up_plan(wt, bt, w3, dtype):
         plan = {"weff": buf(sz[0]), "img_f": buf(sz[1]), "img_b": buf(sz[2]), "taps_f": buf(sz[3]), "taps_b": buf(sz[4]), "btab": buf(sz[5]),
                 "stamp": None, "src": (wt, bt)}
         plans[dtype] = plan
-    if w3.requires_grad or wt.requires_grad:
-        _UP_TRAINABLE[(id(w3), dtype)] = (plan, wt, bt, w3, dtype)
+    if (w3.requires_grad or wt.requires_grad) and (id(w3), dtype) not in _UP_TRAINABLE:
+        _UP_TRAINABLE[(id(w3), dtype)] = (_weakref.ref(wt), None if bt is None else _weakref.ref(bt), _weakref.ref(w3))
     if plan["stamp"] != _up_stamp(wt, bt, w3):
         with torch.no_grad():
             _up_compose_into(plan, wt.detach(), None if bt is None else bt.detach(), w3.detach(), dtype)
@@ -1243,7 +1248,12 @@ def up_plan(wt, bt, w3, dtype):
 
 
 def _recompose_trainable_ups():
-    for plan, wt, bt, w3, dtype in _UP_TRAINABLE.values():
+    for key, (rwt, rbt, rw3) in list(_UP_TRAINABLE.items()):
+        wt, bt, w3, dtype = rwt(), None if rbt is None else rbt(), rw3(), key[1]
+        plan = None if w3 is None else (getattr(w3, "_vs_up_plan", None) or {}).get(dtype)
+        if wt is None or plan is None or (rbt is not None and bt is None) or id(w3) != key[0]:
+            del _UP_TRAINABLE[key]          # the model is gone
+            continue
         with torch.no_grad():
             _up_compose_into(plan, wt.detach(), None if bt is None else bt.detach(), w3.detach(), dtype)
             plan["stamp"] = _up_stamp(wt, bt, w3)

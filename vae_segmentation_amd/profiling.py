@@ -12,17 +12,25 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3}
 LAST_EVENT_OVERHEAD_US = 0.0
 
 
+def _spin(us, stream):
+    """tools/probe/libvsprobe.so: vs_spin — a measurement aid, deliberately not an entry point of libvaeseg.so"""
+    from tools import probe
+    probe.check(probe.lib.vs_spin(int(us), stream), "spin")
+
+
+ops.PROFILE_SPIN[0] = _spin
+
+
 def event_bracket_overhead_us(trials=24, spin_us=20):
     """What a HIP-event bracket adds to the kernel inside it (launch + the second event's marker packet): brackets of a
     kernel of KNOWN duration — vs_spin idles for exactly spin_us on the 100 MHz device clock — primed like the real ones."""
-    from ._lib import lib, check
     stream = torch.cuda.current_stream().cuda_stream
     over = []
     for _ in range(trials):
-        check(lib.vs_spin(ops.PROFILE_PRIME_US, stream), "spin")
+        _spin(ops.PROFILE_PRIME_US, stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(lib.vs_spin(spin_us, stream), "spin")
+        _spin(spin_us, stream)
         e1.record()
         torch.cuda.synchronize()
         over.append(e0.elapsed_time(e1) * 1e3 - spin_us)
