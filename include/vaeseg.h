@@ -198,6 +198,14 @@ typedef struct vs_wgrad_desc {
 size_t vs_conv_wgrad_multi_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype);
 int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
                         float eps, void* stream);
+/* The same with the width of the grids chosen by the caller: each (channel block, kind) bucket is ONE persistent grid of about
+ * `target_workgroups` workgroups, every workgroup walking its share of the tiles (0 = the default, 512: two per CU).  A small target
+ * (32 .. 128) makes a launch that occupies a fraction of the chip for proportionally longer — the form that can run on a second stream
+ * UNDER the latency-bound low-resolution half of backward (ops.py: early weight-gradient flush) without taking the critical path's CUs.
+ * The workspace size depends on the target (fewer k-splits, fewer slabs): query it with the same value. */
+size_t vs_conv_wgrad_multi_throttled_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype, int target_workgroups);
+int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
+                                  float eps, int target_workgroups, void* stream);
 /* db[c] = sum over rows of g[rows][c_ch], c < c_real (bias gradient of a conv whose bias is live). */
 int vs_bias_grad(const void* g, float* db, long long rows, int c_ch, int c_real, int dtype, void* stream);
 /* same; accumulate != 0 adds to db instead of overwriting it (a bias used several times in one backward pass) */

@@ -320,14 +320,19 @@ def test_k3_bwd_data_with_fused_apply(case, dtype, want_dx):
                                               None, None, None, None, n, d, h, w, 8, 8, dt, 1e-5, st), "fused, no sums")
     torch.cuda.synchronize()
     assert _rel_l2(y3, y_ref2) < 4 * ulp
-    # shapes outside the 8 -> 8 class are refused, not mis-computed
+    # shapes without a fused-apply kernel are refused (VS_ESHAPE) before anything is launched, not mis-computed: 256 channels (the per-(n,c) tables of the
+    # fused kernels hold at most 192 pairs) — the planning query says the same
+    assert lib.vs_conv_k3_fused_apply_supported(n, d, h, w, 256, 256, 1, dt) == 0
     assert lib.vs_conv_k3_bwd_data_fused_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), y.data_ptr(),
-                                               mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(), None, n, d, h, w, 32, 32, dt, 1e-5, st) == -2
+                                               mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(), None, n, d, h, w, 256, 256, dt, 1e-5, st) == -2
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", [(2, 48, 16, 16, True), (2, 48, 16, 8, False), (2, 48, 16, 32, False), (2, 96, 8, 16, False), (1, 64, 16, 16, True),
-                                  (2, 80, 16, 16, True), (1, 20, 16, 16, True), (3, 12, 8, 16, False), (2, 24, 16, 32, False)])
+                                  (2, 80, 16, 16, True), (1, 20, 16, 16, True), (3, 12, 8, 16, False), (2, 24, 16, 32, False),
+                                  # 32-channel chunks (k3b<32,16|32,...,FA>, one or two chunks): the 24^3 / 12^3 levels of configs[1], 32^3 / 16^3 of configs[3], ragged
+                                  (2, 24, 32, 32, True), (2, 24, 32, 16, False), (2, 24, 32, 64, True), (2, 12, 64, 64, True), (2, 12, 64, 32, False),
+                                  (1, 32, 32, 32, True), (1, 16, 64, 64, True), (3, 10, 32, 32, True), (1, 8, 64, 128, True)])
 def test_k3b_bwd_data_with_fused_apply(case, dtype):
     """the same comparison for the k3b_kernel FA instantiations (igemm_k3b.h): the single-chunk backward-data launches of the 48^3 level
     (16 -> 16 with a lazy conv input, 16 -> 8 / 16 -> 32 with a stored one), the 96^3 8 -> 16 one, and their 64^3 / 80^3 / ragged relatives;
@@ -370,5 +375,5 @@ def test_k3b_bwd_data_with_fused_apply(case, dtype):
     if lazy_in:
         t2, tr = ops.stats_total(s2), ops.stats_total(s_ref)
         assert float((t2 - tr).abs().max() / tr.abs().max()) < (4 * ulp if not edge else 0.05)
-    # a shape without a fused kernel says so and is refused
-    assert lib.vs_conv_k3_fused_apply_supported(n, 12, 12, 12, 32, 32, 1, dt) == 0
+    # a shape without a fused kernel says so: the 6^3 volumes of the deep levels run k3s_kernel, which has no fused-apply form
+    assert lib.vs_conv_k3_fused_apply_supported(n, 6, 6, 6, 128, 128, 1, dt) == 0

@@ -178,7 +178,6 @@ def test_trainable_composed_up_multi_step_matches_two_launch_form(dtype, monkeyp
         M.set_kernel_dtype(up, dtype)
         params = [p for p in up.parameters()]
         opt = optim.SGD(params, lr=0.05, momentum=0.9)
-        n_reg = len(ops._UP_TRAINABLE)
 
         def loss_fn():
             ops.stats_arena_begin(x.device)
@@ -200,7 +199,8 @@ def test_trainable_composed_up_multi_step_matches_two_launch_form(dtype, monkeyp
                 opt.step()
                 losses.append(loss.detach().clone())
         torch.cuda.synchronize()
-        assert (len(ops._UP_TRAINABLE) > n_reg) == fuse, "composed trainable path %s" % ("was not taken" if fuse else "was taken")
+        mine = {id(p_) for p_ in params}
+        assert any(k[0] in mine for k in ops._UP_TRAINABLE) == fuse, "composed trainable path %s" % ("was not taken" if fuse else "was taken")
         return [float(v) for v in losses], {n: p.detach().float().cpu().clone() for n, p in up.named_parameters()}
 
     init = {n: p.detach().float().clone() for n, p in O.deterministic_fill_(M.Up(32, 16, norm_type=1), seed=5).named_parameters()}

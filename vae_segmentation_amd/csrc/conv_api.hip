@@ -76,7 +76,10 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     tiles = (long long)p.tiles_per_sample * n;
     p.inv_count_out = 1.0 / ((double)p.Do * p.Ho * p.Wo);
     const int rows16 = p.rb_total * 16;
-    const int mt = (kind != VS_CONV_K3 && p.tyn == 64) ? 16 : pick_mt(rows16, tiles);
+    int mt = (kind != VS_CONV_K3 && p.tyn == 64) ? 16 : pick_mt(rows16, tiles);
+    // fused apply on 32-channel chunks: every row-block workgroup of a tile repeats the apply pass over the tile's halo, and the kernel runs one
+    // workgroup per CU (512 VGPRs) — 32-row tiles halve both the repeats and the workgroup count (24^3 x 32: 144 workgroups, one round)
+    if (kind == VS_CONV_K3 && fa_x != nullptr && ck == 32 && mt == 16 && rows16 % 32 == 0) mt = 32;
     const int row_tiles = rows16 / mt;
     if (fa_query != nullptr) {                             // planning only: would a fused-apply launch of this shape find a kernel?
         *fa_query = (kind == VS_CONV_K3 && dtype != VS_F32) ? g1_k3_fa_supported(p, ck, mt) : 0;

@@ -64,15 +64,16 @@ struct K3BGeom {
 // use, or an exec-masked tail store, makes the compiler drain vmcnt(0): it then waits for the prefetched stage as well)
 // T: unsigned short (bf16 bits) or vs_half (fp16) — same fragment shapes, same MFMA rate; last template argument so that the profiler's
 // kernel names keep their prefix
-// FA (backward-data use, CK < 32): the input gradient arrives un-applied (p.x = g = dL/da of a = relu(norm(p.fa_x)), statistics p.x_stats,
+// FA (backward-data use; CK == 32: any chunk count, one wave per SIMD — the second staged operand does not fit 256 VGPRs — the 24^3 / 12^3 levels):
+// the input gradient arrives un-applied (p.x = g = dL/da of a = relu(norm(p.fa_x)), statistics p.x_stats,
 // IN-backward sums p.fa_sums) and the apply pass runs while the halo tile is staged; centre voxels also go to p.fa_dx when given (see
 // igemm_k3t.h, where the same is done for the 8 -> 8 layers)
 template <int CK, int MT, int EPI, bool SUMS, int YT = 4, bool HS = false, typename T = unsigned short, bool FA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
-    YT == 8 ? 2 : (CK == 32 ? (MT == 32 ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : ((CK == 16 && SUMS) || FA ? 3 : 4))), 8))) void k3b_kernel(const G1Params p) {
+    YT == 8 ? 2 : (CK == 32 ? ((MT == 32 || FA) ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : ((CK == 16 && SUMS) || FA ? 3 : 4))), 8))) void k3b_kernel(const G1Params p) {
     K3_TICK_INIT
     using GEO = K3BGeom<CK, MT, YT>;
-    static_assert(!FA || (CK < 32 && !HS && EPI == EPI_RAW), "fused apply: single-chunk backward-data kernels");
+    static_assert(!FA || (!HS && EPI == EPI_RAW), "fused apply: backward-data kernels");
     static_assert(YT == 4 || (YT == 8 && CK < 32 && MT == 16), "tall tiles: single-chunk layers, 16 rows");
     constexpr int TV = GEO::TV, PLANE = (YT + 2) * 18;
     static_assert(CK == 8 || CK == 16 || CK == 32, "chunk width");
@@ -174,9 +175,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
             if constexpr (FA) fv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(frsrc, ok ? base + rel_off[b] : -1, 0, 0));
         }
     };
-    auto write_x_fa = [&](const Coord& c) {             // FA: apply pass on the staged fragments [+ the applied gradient of the centre voxels to fa_dx]
+    auto write_x_fa = [&](const Coord& c, int ch) {     // FA: apply pass on the staged fragments [+ the applied gradient of the centre voxels to fa_dx]
         f32x2 r2[4], s2[4], a2[4], b2[4];
-        const int c0 = c.n * p.C + part * 8;
+        const int c0 = c.n * p.C + ch * CK + part * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             r2[i] = *(const f32x2*)(s_fa + 0 * p.N * p.C + c0 + 2 * i);
@@ -184,7 +185,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
             a2[i] = *(const f32x2*)(s_fa + 2 * p.N * p.C + c0 + 2 * i);
             b2[i] = *(const f32x2*)(s_fa + 3 * p.N * p.C + c0 + 2 * i);
         }
-        const int base = (((c.n * p.D + c.z0 - 1) * p.H + c.y0 - 1) * p.W + c.x0 - 1) * p.C * 2;
+        const int base = ((((c.n * p.D + c.z0 - 1) * p.H + c.y0 - 1) * p.W + c.x0 - 1) * p.C + ch * CK) * 2;
+        // the applied gradient goes out once per tile: with several row-block workgroups per tile (gridDim.y > 1) only the first one stores it
+        const bool store_dx = p.fa_dx != nullptr && blockIdx.y == 0;          // workgroup-uniform
 #pragma unroll
         for (int b = 0; b < NIT; ++b) {
             u32x4 v;
@@ -203,8 +206,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
             const bool ok = (okbits >> b) & 1u;           // out-of-volume halo voxels: the gradient is zero-padded
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = ok ? v[i] : 0u;
-            *(u32x4*)(s_tile + lds_w0 + b * 4096 + part * 16) = v;
-            if (p.fa_dx != nullptr)                        // workgroup-uniform
+            const int pw = CK == 32 ? (part ^ (int)(((swzbits >> b) & 1u) << 1)) : part;
+            *(u32x4*)(s_tile + lds_w0 + b * 4096 + pw * 16) = v;
+            if (store_dx)
                 vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), dxrsrc, (ok && ((cbits >> b) & 1u)) ? base + rel_off[b] : -1, 0, 0);
         }
     };
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
         for (int ch = 0; ch < p.nch; ++ch) {
             if (!first) __syncthreads();                 // every wave is done reading the previous stage
             K3_TICK(1);
-            if constexpr (FA) write_x_fa(cur); else write_x(n, ch);
+            if constexpr (FA) write_x_fa(cur, ch); else write_x(n, ch);
             if constexpr (restage_w) write_w();
             first = false;
             K3_TICK(2);
@@ -510,7 +514,7 @@ static inline void k3b_fastdiv(int d, unsigned int& m, unsigned int& s) {
 template <typename T, int CK, int MT, int EPI, bool SUMS, int YT, bool HS, bool FA = false>
 static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
     using GEO = K3BGeom<CK, MT, YT>;
-    if (FA && (p_in.N * p_in.C > 192 || p_in.nch != 1 || !p_in.x_stats || !p_in.fa_sums)) return VS_ESHAPE;
+    if (FA && (p_in.N * p_in.C > 192 || (CK < 32 && p_in.nch != 1) || !p_in.x_stats || !p_in.fa_sums)) return VS_ESHAPE;
     const size_t tables = (size_t)(FA ? 6 : 2) * p_in.N * p_in.C * sizeof(float) + (p_in.sums ? (size_t)2 * p_in.N * p_in.M * sizeof(float) : 0);
     const size_t lds = K3B_LDS_TILE + (size_t)GEO::TILE_BYTES + GEO::W_BYTES + tables;
     if (lds > 160 * 1024) return VS_ESHAPE;
@@ -546,7 +550,8 @@ static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
 // the fused-apply instantiations: the single-chunk backward-data layers of the 96^3 / 48^3 levels (and their 128^3 / 160^3 counterparts)
 template <int CK, int MT, int EPI, bool SUMS, int YT>
 constexpr bool k3b_has_fa() {
-    return EPI == EPI_RAW && ((CK == 16 && MT == 16) || (CK == 8 && MT == 16 && !SUMS && YT == 4) || (CK == 16 && MT == 32 && !SUMS && YT == 4));
+    return EPI == EPI_RAW && ((CK == 16 && MT == 16) || (CK == 8 && MT == 16 && !SUMS && YT == 4) || (CK == 16 && MT == 32 && !SUMS && YT == 4) ||
+                              (CK == 32 && YT == 4));
 }
 
 template <typename T, int CK, int MT, int EPI, bool SUMS, int YT = 4>

@@ -876,8 +876,9 @@ static int multi_validate(const vs_wgrad_desc& d) {
 
 // bf16 plan: every layer gets its own slab region; k-splits are chosen per (CB, KIND) bucket so that the bucket's ONE grid has
 // about `target` workgroups of about equal tile counts.
-static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPlan& plan) {
-    static const long long target = getenv("VS_WGRAD_GROUP_WGS") ? atoll(getenv("VS_WGRAD_GROUP_WGS")) : 512;     // measured best of 384..2560 (two workgroups per CU are resident)
+static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPlan& plan, int target_wgs = 0) {
+    static const long long target_default = getenv("VS_WGRAD_GROUP_WGS") ? atoll(getenv("VS_WGRAD_GROUP_WGS")) : 512;     // measured best of 384..2560 (two workgroups per CU are resident)
+    const long long target = target_wgs > 0 ? target_wgs : target_default;
     plan.layers.resize(count);
     long long bucket_work[6] = {0, 0, 0, 0, 0, 0};       // (cbsz 16 | 8) x (K3, K2S2, UP)
     for (int i = 0; i < count; ++i) {
@@ -938,7 +939,7 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         if (d.bias_g) {
             const int rpi = 256 / (d.bias_c_ch / 8);
             long long nb = (d.bias_rows + (long long)rpi * 32 - 1) / ((long long)rpi * 32);
-            L.bias_nblk = (int)std::min<long long>(std::max<long long>(nb, 1), 256);     // <= 2 rounds of the reduce's 16 x 8 loads
+            L.bias_nblk = (int)std::min<long long>(std::max<long long>(nb, 1), target_wgs > 0 ? std::max(8, target_wgs / 2) : 256);     // <= 2 rounds of the reduce's 16 x 8 loads
         }
     }
     for (int i = 0; i < count; ++i) {                      // slab regions: the parts of one gradient lie back to back
@@ -983,7 +984,15 @@ static int g3b_group_run(const G3Group& grp, hipStream_t s) {
 }  // namespace
 
 extern "C" size_t vs_conv_wgrad_multi_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype) {
-    if (!descs || count <= 0) return 0;
+    return vs_conv_wgrad_multi_throttled_workspace_bytes(descs, count, dtype, 0);
+}
+extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
+                                   float eps, void* stream) {
+    return vs_conv_wgrad_multi_throttled(descs, count, workspace, workspace_bytes, dtype, eps, 0, stream);
+}
+
+extern "C" size_t vs_conv_wgrad_multi_throttled_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype, int target_workgroups) {
+    if (!descs || count <= 0 || target_workgroups < 0) return 0;
     if (dtype == VS_F32) {                        // serial per-layer launches share one region; the uses of one weight need theirs side by side
         size_t mx = 0;
         for (int i = 0; i < count; ++i) {
@@ -999,13 +1008,13 @@ extern "C" size_t vs_conv_wgrad_multi_workspace_bytes(const vs_wgrad_desc* descs
         return mx;
     }
     MultiPlan plan;
-    if (multi_plan(descs, count, 0.f, plan)) return 0;
+    if (multi_plan(descs, count, 0.f, plan, target_workgroups)) return 0;
     return plan.bytes;
 }
 
-extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
-                                   float eps, void* stream) {
-    if (!descs || count <= 0 || !workspace) return VS_EINVAL;
+extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
+                                             float eps, int target_workgroups, void* stream) {
+    if (!descs || count <= 0 || !workspace || target_workgroups < 0) return VS_EINVAL;
     if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
     const bool f16 = dtype == VS_F16;
     hipStream_t st = (hipStream_t)stream;
@@ -1049,7 +1058,7 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
         return VS_OK;
     }
     MultiPlan plan;
-    int rc = multi_plan(descs, count, eps, plan);
+    int rc = multi_plan(descs, count, eps, plan, target_workgroups);
     if (rc) return rc;
     if (workspace_bytes < plan.bytes) return VS_EWORKSPACE;
     if ((uintptr_t)workspace % 16) return VS_EINVAL;

@@ -555,6 +555,12 @@ def _pending_done():
 # rstd * (g*mask - m1 - xhat*m2) while it stages its input — the standalone apply launch (3 tensor passes at 96^3) disappears.
 # An entry nobody took by the end of the pass means a consumer treated an un-applied gradient as applied: that is an error, not a fallback.
 FUSE_APPLY = os.environ.get("VS_FUSE_APPLY", "1") != "0"
+# channels of the activations whose producer may have a fused-apply kernel: 8 / 16 (k3t, single-chunk k3b: the 96^3 / 48^3 levels) and, opt-in
+# (VS_FUSE_APPLY_32=1), 32 / 64 (k3b<32,16|32,...,FA>: the 24^3 / 12^3 levels).  The 32-channel form exists, is tested (tests/test_gpu_layers.py)
+# and is OFF by default: measured on the 96^3 step (profiles/README.md, round 4) the fused launch costs 14.0 us at 24^3 x 32 against 8.7 + 4.3 for
+# the pair it replaces and 18.4 against 8.7 + 3.9 at 12^3 x 64 (two chunks) — 2.566 vs 2.519 ms per step.  The library has the last word
+# (vs_conv_k3_fused_apply_supported): a marked tensor whose producer has no such kernel gets the standalone apply in the producer's backward.
+_FA_CHANNELS = (8, 16, 32, 64) if os.environ.get("VS_FUSE_APPLY_32", "0") != "0" else (8, 16)
 _LAZY_APPLY = {"grads": {}, "callback": False}
 
 
@@ -562,7 +568,7 @@ def mark_defer_apply(x, producer):
     """x: the raw output of `producer` (an nn.Conv3d holder run by ConvK3, 3x3x3) about to be consumed, exactly once, by a conv op that honours
     the mark (ConvK3, ConvK3Softmax[CL], ConvK2S2, ConvT2S2).  Marked when the producer's backward-data launch has a fused-apply kernel
     (vs_conv_k3_fused_apply_supported: the single-chunk layers of the full- and half-resolution levels)."""
-    if FUSE_APPLY and x.dtype != torch.float32 and x.shape[-1] in (8, 16) and tuple(producer.weight.shape[2:]) == (3, 3, 3):
+    if FUSE_APPLY and x.dtype != torch.float32 and x.shape[-1] in _FA_CHANNELS and tuple(producer.weight.shape[2:]) == (3, 3, 3):
         x._vs_defer_apply = True
     return x
 
@@ -741,6 +747,71 @@ _GROUP = {"enabled": os.environ.get("VS_WGRAD_GROUP", "1") != "0", "descs": [], 
 # destination: vs_conv_wgrad_multi sums the uses, and the later uses return None to autograd (nothing left to accumulate).
 
 
+# Early, throttled flush.  The grouped launches above wait for the end of backward, where ~0.33 ms of weight-gradient
+# kernels run alone — while the low-resolution half of the pass (24^3 and below: ~130 launches that occupy a few dozen CUs each for ~8 us)
+# leaves most of the chip idle.  When the first small layer of a pass submits its descriptor and the queue already holds the big decoder-side
+# layers (out_block, up5, up4: their operands are final by then), those are issued AT ONCE on a second stream as persistent grids of
+# EARLY["wgs"] workgroups (vs_conv_wgrad_multi_throttled): a fraction of the chip for proportionally longer, under the latency-bound window.
+# One fork, one join (at the end-of-pass flush); inside a HIP-graph capture the second stream is a parallel branch.  Round 2's attempt used
+# full-width grids on the branch and lost 0.13 ms: the branch took the critical path's CUs and bandwidth.
+EARLY = {"enabled": os.environ.get("VS_WGRAD_EARLY", "0") != "0", "wgs": int(os.environ.get("VS_WGRAD_EARLY_WGS", "64")),
+         "small_voxels": int(os.environ.get("VS_WGRAD_EARLY_SMALL", str(2 * 24 ** 3))),      # a layer at or below this many voxels (batch included) opens the window
+         "min_bytes": float(os.environ.get("VS_WGRAD_EARLY_MIN_MB", "40")) * 1e6,            # worth a fork only if the queued big layers move at least this much
+         "done": False, "stream": None, "forked": False, "keep": [], "flushed": set()}
+
+
+def set_wgrad_early(enabled=True, wgs=None):
+    flush_wgrads()
+    EARLY["enabled"] = bool(enabled)
+    if wgs is not None:
+        EARLY["wgs"] = int(wgs)
+
+
+def _early_join():
+    if EARLY["forked"]:
+        torch.cuda.current_stream().wait_stream(EARLY["stream"])
+        EARLY["forked"] = False
+    EARLY["keep"] = []
+
+
+def _maybe_flush_early(voxels):
+    g, e = _GROUP, EARLY
+    if (not e["enabled"] or e["done"] or g["split"] is not None or PROFILE is not None or voxels > e["small_voxels"] or not g["callback"]
+            or g["dtype"] == torch.float32):
+        return
+    big = [x for x in g["descs"] if x[4] > e["small_voxels"]]
+    if sum(x[2] for x in big) < e["min_bytes"]:
+        return
+    e["done"] = True                              # one fork per pass
+    rest = [x for x in g["descs"] if x[4] <= e["small_voxels"]]
+    if e["stream"] is None:
+        e["stream"] = torch.cuda.Stream()
+    e["stream"].wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(e["stream"]):
+        ws = _issue_wgrads(big, e["wgs"])
+    e["forked"] = True
+    # operands, workspace: referenced until the join (the allocator must not hand their memory to the main stream's next tensors)
+    e["keep"] = g["keep"] + [ws]
+    e["flushed"].update(int(x[0].dw) for x in big)
+    g["descs"], g["keep"] = rest, []
+
+
+def _issue_wgrads(entries, target_wgs=0):
+    descs = [x[0] for x in entries]
+    arr = (WgradDesc * len(descs))(*descs)
+    dt = vs_of(_GROUP["dtype"])
+    dev = torch.device("cuda", torch.cuda.current_device())
+    nbytes = lib.vs_conv_wgrad_multi_throttled_workspace_bytes(_ct.addressof(arr), len(descs), dt, target_wgs)
+    if nbytes == 0:
+        _GROUP["descs"], _GROUP["keep"] = [], []
+        raise _lib.VaesegError("vs_conv_wgrad_multi: unsupported layer in the deferred weight-gradient list")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    nb, fl = sum(x[2] for x in entries), sum(x[3] for x in entries)
+    with _timed("wgrad_multi(%d layers)" % len(descs), nb, fl):
+        check(lib.vs_conv_wgrad_multi_throttled(_ct.addressof(arr), len(descs), ws.data_ptr(), nbytes, dt, EPS_IN, target_wgs, _stream()), "conv_wgrad_multi")
+    return ws
+
+
 def set_wgrad_grouping(enabled=True):
     """Defer weight/bias gradients to the end of backward and issue them as grouped launches (default on)."""
     flush_wgrads()
@@ -764,6 +835,10 @@ def drop_stale_wgrads():
     if g["descs"] or g["callback"]:
         g["descs"], g["keep"], g["callback"], g["bytes"], g["flops"] = [], [], False, 0.0, 0.0
     g["slots"] = {}
+    if EARLY["forked"] or EARLY["done"]:        # a pass that died after its early fork: join the branch, forget its bookkeeping
+        _early_join()
+        EARLY["done"] = False
+        EARLY["flushed"].clear()
     _UP_JOBS.clear()
     # the same for gradients parked / handed over un-applied by a pass that died: their addresses may be recycled by now, and a later
     # backward must never mistake a fresh tensor at such an address for one of them
@@ -794,7 +869,8 @@ def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb, up_co=0):
         (p.numel() // m_ch * m_real + q.numel() // q.shape[-1] * c_real) * _esize(p) + m_real * c_real * taps * 4
     fl = 2.0 * (q.numel() // q.shape[-1]) * taps * m_real * c_real if kind == VS_CONV_UP else 2.0 * (p.numel() // m_ch) * taps * m_real * c_real
     first = g["split"] is None or bool(g["split"](weight))
-    g["descs"].append((d, first, nb, fl))
+    voxels = n * dp * hp * wp_
+    g["descs"].append((d, first, nb, fl, voxels))
     g["keep"].extend(t for t in keep if t is not None)
     if not g["callback"]:
         try:
@@ -802,12 +878,16 @@ def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb, up_co=0):
             g["callback"] = True
         except RuntimeError:
             flush_wgrads()                      # not inside a backward pass: nothing will call back
+            return
+    _maybe_flush_early(voxels)
 
 
 def _group_backward_done():
     _GROUP["callback"] = False
     flush_wgrads(first_only=_GROUP["split"] is not None)
     _GROUP["slots"] = {}
+    EARLY["done"] = False
+    EARLY["flushed"].clear()
 
 
 def pending_wgrads():
@@ -819,24 +899,15 @@ def flush_wgrads(first_only=False):
     set_wgrad_split — only the first phase."""
     g = _GROUP
     if not g["descs"]:
+        _early_join()
         return
     now = [e for e in g["descs"] if e[1]] if first_only else g["descs"]
     later = [e for e in g["descs"] if not e[1]] if first_only else []
     g["descs"] = later
     if not now:
         return
-    descs = [e[0] for e in now]
-    arr = (WgradDesc * len(descs))(*descs)
-    dt = vs_of(g["dtype"])
-    dev = g["keep"][0].device
-    nbytes = lib.vs_conv_wgrad_multi_workspace_bytes(_ct.addressof(arr), len(descs), dt)
-    if nbytes == 0:
-        g["descs"], g["keep"] = [], []
-        raise _lib.VaesegError("vs_conv_wgrad_multi: unsupported layer in the deferred weight-gradient list")
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    nb, fl = sum(e[2] for e in now), sum(e[3] for e in now)
-    with _timed("wgrad_multi(%d layers)" % len(descs), nb, fl):
-        check(lib.vs_conv_wgrad_multi(_ct.addressof(arr), len(descs), ws.data_ptr(), nbytes, dt, EPS_IN, _stream()), "conv_wgrad_multi")
+    _issue_wgrads(now)
+    _early_join()                               # the early branch (if one was forked in this pass) meets the main stream behind the remaining layers' launches
     if not later:
         _run_up_jobs()                          # parameter-space chain rule of the composed Up heads: reads the dWeff the launch above reduced
         g["keep"] = []                          # launched on the current stream: the allocator may recycle the inputs now
@@ -861,14 +932,21 @@ def _side_grads(weight, keep, wgrad_args, bias_args, bias=None):
     grad mode is on (autograd would then clone the still-unwritten tensor); -> (gw, gb)."""
     grouping = _GROUP["enabled"] and not _SIDE["enabled"]
     slot = _GROUP["slots"].get(id(weight)) if grouping and weight.is_leaf else None
+    if slot is not None and slot[0] in EARLY["flushed"]:
+        # the first use of this weight was reduced by the early branch already: this use gets a destination of its own and autograd adds the two
+        slot = None
+        early_reuse = True
+    else:
+        early_reuse = False
     if slot is not None:
         # a later use of the same weight in this pass: one more descriptor with the first use's destination, nothing returned to autograd
         _group_submit(weight, keep, wgrad_args, bias_args if slot[1] is not None else None, slot[0], slot[1])
         return None, None
-    gw = _grad_slot(weight, weight.shape)
+    gw = _grad_slot(weight, weight.shape) if not early_reuse else torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
     gb = None
     if bias_args is not None:
-        gb = _grad_slot(bias, (bias_args[1],)) if bias is not None else torch.empty(bias_args[1], dtype=torch.float32, device=keep[0].device)
+        gb = (_grad_slot(bias, (bias_args[1],)) if bias is not None and not early_reuse else
+              torch.empty(bias_args[1], dtype=torch.float32, device=keep[0].device))
     # deferring hands autograd a still-unwritten tensor: only sound when its consumer is the parameter's AccumulateGrad (a leaf), which keeps it
     # untouched until the pass ends; a non-leaf weight's gradient is read by the next backward node at once
     deferrable = (weight.is_leaf and weight.grad is None and not _has_hooks(weight) and not torch.is_grad_enabled()
