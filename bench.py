@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="testing aid: initialise the process group and run the gradient "
                     "all-reduce path even with one rank (exercises RCCL on a 1-GPU box)")
     ap.add_argument("--master-port", type=int, default=29533)
+    ap.add_argument("--no-exchange-forms", action="store_true", help="N > 1: skip the no-exchange / other-exchange-form timing legs")
     return ap.parse_args()
 
 
@@ -136,8 +137,10 @@ def cpu_baseline(side, steps, budget_s=40.0):
                       "median, %d threads" % (len(timed), side, BATCH, cores)}
 
 
-def make_step(a, dtype, rank, use_dist):
-    """-> (step(), loss_fn, seg_params, closer): one train step of configs[1] in the given kernel dtype."""
+def make_step(a, dtype, rank, use_dist, overlap=None, info=None):
+    """-> (step(), loss_fn, seg_params, closer): one train step of configs[1] in the given kernel dtype.
+    overlap: None = the default exchange form (ddp.FlatGradSync: one bucket unless VS_DDP_OVERLAP=1), True / False forces the form.
+    info (dict, optional): receives what was built ("tail_in_graph", "buckets")."""
     from vae_segmentation_amd import ddp, optim
     from vae_segmentation_amd import train as T
     joint, img, lab = build(a.side, dtype, rank)
@@ -146,9 +149,12 @@ def make_step(a, dtype, rank, use_dist):
     seg_params = [p for p in joint.Seg.parameters()]
     scaler = optim.LossScaler() if dtype == "fp16" else None          # fp16 storage: dynamic loss scale, on the device
     kw = {} if scaler is None else {"scaler": scaler}
-    sync = ddp.FlatGradSync(seg_params) if use_dist else None
+    sync = ddp.FlatGradSync(seg_params, overlap=overlap) if use_dist else None
     if sync is not None:
         sync.broadcast_parameters(0)
+    if info is not None:
+        info["buckets"] = len(sync.buckets) if sync is not None else 0
+        info["tail_in_graph"] = False
 
     def loss_fn():
         return T.joint_train_losses(joint, img, lab, lambda_vae=0.1)
@@ -174,6 +180,8 @@ def make_step(a, dtype, rank, use_dist):
     else:
         gs = T.GraphedStep(loss_fn, seg_params, opt, grad_sync=sync, warmup=2, scaler=scaler)
         step = gs.step
+        if info is not None:
+            info["tail_in_graph"] = bool(gs.tail)
 
     def closer():
         """before the eager family-timing passes: gradients back to ordinary tensors, and the captured step's autograd graph and gradient
@@ -182,6 +190,8 @@ def make_step(a, dtype, rank, use_dist):
         if sync is not None:
             sync.close()
         if not a.no_graph:
+            if gs.grad_sync is not None:
+                gs.grad_sync.close()              # the flat buffer GraphedStep made for its captured optimiser launch
             gs.loss = gs.aux = gs._accumulators = None
     return step, loss_fn, seg_params, closer
 
@@ -261,16 +271,58 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, use_dist)
-    dt, loss = timed_steps(step, a.steps, a.warmup, fence)
+    # N > 1 self-check: the ranks the launcher promised are the ranks the collective library really connected (sum of ones over the job)
+    nranks_seen = 1
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        one = torch.ones(1, device="cuda" if a.backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        nranks_seen = int(round(float(one.item())))
+        if nranks_seen != dist.get_world_size() or dist.get_world_size() != world:
+            raise SystemExit("process group has %d ranks, the collective summed %d, WORLD_SIZE=%d" % (dist.get_world_size(), nranks_seen, world))
+
+    def max_over_ranks(sec):
+        if not use_dist:
+            return sec
+        t = torch.tensor([sec], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    info = {}
+    step, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, use_dist, info=info)
+    dt, loss = timed_steps(step, a.steps, a.warmup, fence)
+    dt = max_over_ranks(dt)
     final_loss = float(loss.item())
     host_issue_ms = 1e3 * HOST_ISSUE["s"] / a.steps
     del loss                                    # the last reference to the captured step's autograd graph (see closer())
     ms_per_step = 1e3 * dt / a.steps
+
+    # ---- the exchange, measured in the same run (every rank takes part: these are collective) ----------------------------------------
+    # exposed cost of the gradient exchange = this job's step minus the same step without the exchange (replicas drift apart in that leg: it is
+    # timed, not trained); and the other exchange form (two buckets, bucket 0 all-reduced under the remaining weight-gradient kernels), so
+    # that ONE run decides which form should be the default at this world size.
+    exchange = None
+    if use_dist and not a.no_graph and not a.no_exchange_forms:
+        n_x = max(10, min(a.steps, 50))
+        closer()
+        del step, loss_fn, seg_params
+        torch.cuda.empty_cache()
+        info0, info1 = {}, {}
+        step_n, _, _, closer_n = make_step(a, a.dtype, rank, False, info=info0)
+        dt_n, _ = timed_steps(step_n, n_x, 3, fence)
+        dt_n = max_over_ranks(dt_n)
+        closer_n()
+        del step_n
+        torch.cuda.empty_cache()
+        other = not (os.environ.get("VS_DDP_OVERLAP", "0") == "1")
+        step_o, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, True, overlap=other, info=info1)
+        dt_o, _ = timed_steps(step_o, n_x, 3, fence)
+        dt_o = max_over_ranks(dt_o)
+        exchange = {"steps": n_x, "no_exchange_ms_per_step": round(1e3 * dt_n / n_x, 4),
+                    "exposed_exchange_ms_per_step": round(ms_per_step - 1e3 * dt_n / n_x, 4),
+                    "default_form": {"buckets": info.get("buckets"), "tail_in_graph": info.get("tail_in_graph"), "ms_per_step": round(ms_per_step, 4)},
+                    "other_form": {"buckets": info1.get("buckets"), "overlap": other, "tail_in_graph": info1.get("tail_in_graph"),
+                                   "ms_per_step": round(1e3 * dt_o / n_x, 4)}}
+        step = step_o
 
     families, fp32_mode, cpu = None, None, None
     if rank == 0 and not a.no_families:
@@ -313,6 +365,9 @@ def main():
                        # host time per step to issue the work (one graph launch, then the exchange and the optimiser eagerly); far below ms_per_step = the
                        # step is GPU-bound and capturing those tail launches into the graph as well would not shorten it
                        "host_issue_ms_per_step": round(host_issue_ms, 4),
+                       # the whole step — pass, exchange, optimiser, weight re-pack — is ONE replayed HIP graph when true (train.GraphedStep, captured tail)
+                       "tail_in_graph": info.get("tail_in_graph", False),
+                       "nranks": nranks_seen, "exchange": exchange,
                        "grad_exchange": (("2-bucket RCCL all-reduce, bucket 0 under the full-resolution weight-gradient kernels"
                                           if os.environ.get("VS_DDP_OVERLAP", "0") == "1" else
                                           "one RCCL all-reduce of the flat gradient buffer (written in place by the weight-gradient kernels) after the pass")

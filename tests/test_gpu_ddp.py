@@ -187,3 +187,23 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["config"]["global_batch"] == 4 and rec["cpu_baseline"] is None
+    # the N > 1 line checks itself: ranks really connected, the exposed exchange measured in the same run, both exchange forms timed
+    cfg = rec["config"]
+    assert cfg["nranks"] == 2
+    ex = cfg["exchange"]
+    assert ex["no_exchange_ms_per_step"] > 0 and ex["default_form"]["buckets"] == 1 and ex["other_form"]["buckets"] == 2
+    assert ex["other_form"]["ms_per_step"] > 0 and abs(ex["exposed_exchange_ms_per_step"] - (rec["ms_per_step"] - ex["no_exchange_ms_per_step"])) < 1e-3
+    assert cfg["tail_in_graph"] is False                       # gloo collectives are not capturable: the tail stays eager (RCCL: test below)
+
+
+def test_bench_one_rank_rccl_whole_step_is_one_graph():
+    """bench.py --force-dist on one rank through RCCL: the all-reduce, the SGD launch and the weight re-pack are captured into the step's graph
+    (config.tail_in_graph) and the line carries the exchange legs."""
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "5", "--warmup", "2", "--side", "64",
+                          "--no-families", "--no-cpu-baseline", "--no-fp32-mode", "--master-port", "29557"],
+                         env=dict(os.environ, PYTHONPATH=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    cfg = rec["config"]
+    assert cfg["tail_in_graph"] is True and cfg["nranks"] == 1
+    assert cfg["exchange"]["default_form"]["tail_in_graph"] is True and cfg["exchange"]["other_form"]["buckets"] == 2

@@ -39,9 +39,12 @@ class FlatGradSync:
     train.GraphedStep drives the same phases around two captured graphs.  ``direct=False`` keeps the classic form: gradients
     wherever autograd put them, one gather launch (vs_copy_scale_multi), one all-reduce."""
 
-    def __init__(self, params, process_group=None, direct=True, split_numel=8192, overlap=None):
+    def __init__(self, params, process_group=None, direct=True, split_numel=8192, overlap=None, exchange=True):
+        """exchange=False: no collective at all — the flat buffer only pins every gradient to a fixed address (train.GraphedStep's captured
+        optimiser launch on one rank)."""
         self.params = [p for p in params if p.requires_grad]
         self.group = process_group
+        self.exchange = bool(exchange)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         dev = self.params[0].device
         self.direct = bool(direct) and dev.type == "cuda"
@@ -141,7 +144,7 @@ class FlatGradSync:
         torch's RCCL process group runs collectives on its own stream (async_op=True), so kernels launched next — the bucket-1
         weight gradients — run underneath it.  (A communication stream of our own was measured and dropped: its extra cross-stream
         edges cost 0.14 ms per step on top of the collective's.)"""
-        if self.world == 1 and not dist.is_initialized():
+        if not self.exchange or (self.world == 1 and not dist.is_initialized()):
             return
         b = self.buckets[i]
         if not b.is_cuda:                                            # CPU tensors (gloo tests)

@@ -81,7 +81,14 @@ class SGD(torch.optim.Optimizer):
         return self.step(_override={id(p): g for p, g in zip(params, grads)}, scaler=scaler)
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, _override=None, scaler=None):
+    def prepare(self, params, grads):
+        """Build the device-side pointer tables and the momentum buffers for step_with(params, grads) WITHOUT updating anything: a stream
+        capture that includes the optimiser (train.GraphedStep, captured tail) must find them ready — building them copies host tables
+        to the device, which a capture cannot contain."""
+        return self.step(_override={id(p): g for p, g in zip(params, grads)}, _dry=True)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0, _override=None, scaler=None, _dry=False):
         ops.join_side()
         todo = []
         for gi, group in enumerate(self.param_groups):
@@ -107,6 +114,8 @@ class SGD(torch.optim.Optimizer):
             tab = self._tables.setdefault(gi, _Tables())
             (pp, gp, bp, sizes, bm), nb = tab.get([ps, grads, bufs], ps[0].device)
             todo.append((group, grads, pp, gp, bp, sizes, bm, nb))
+        if _dry:
+            return None
         if scaler is not None:
             for t in todo:                                   # every group is checked before any group is updated
                 scaler.check(t[1])

@@ -241,9 +241,18 @@ class GraphedStep:
     current kernels the serial graph is 1-2 % faster (3.87 vs 3.94 ms) — the branch's forks/joins and the contention for CUs cost
     more than the concurrency returns.
     ``scaler``: an optim.LossScaler (fp16 storage) — backward is seeded with its device-resident scale, the optimiser unscales / skips.
+    ``capture_tail`` (default: on, VS_GRAPH_TAIL=0 switches it off): the TAIL of the step — the gradient all-reduce (RCCL collectives capture into
+    a HIP graph on this stack: tools/rccl_capture_probe.py), the SGD launch and the re-pack of the trainable weight images — is part of the
+    same graph, so a step is ONE graph launch and nothing else.  Conditions (otherwise the tail stays eager, `self.tail` says which):
+    one bucket (not the two-phase overlapped form), no LossScaler, optim.SGD (Adam's bias corrections are host-side per-step state), every
+    gradient written straight into its flat slot (no stragglers to gather), the process group is RCCL or absent.  The learning rate,
+    momentum and weight decay are kernel ARGUMENTS baked into the captured launch: step() compares the optimiser's current values with the
+    captured ones and re-captures when a scheduler changed them (once per epoch in the reference's schedules, main_source.py:674-677).
     Models with dropout > 0 cannot be captured (ops.next_dropout_seed raises during capture): run them eagerly."""
 
-    def __init__(self, loss_fn, params, optimizer, grad_sync=None, warmup=2, overlap=False, scaler=None):
+    def __init__(self, loss_fn, params, optimizer, grad_sync=None, warmup=2, overlap=False, scaler=None, capture_tail=None):
+        from . import ddp as _ddp
+        from . import optim as _optim
         ops.set_overlap(overlap and os.environ.get("VS_OVERLAP", "1") != "0")       # VS_OVERLAP=0: measurement aid
         self.loss_fn, self.params, self.optimizer, self.grad_sync = loss_fn, list(params), optimizer, grad_sync
         self._one = None
@@ -251,15 +260,51 @@ class GraphedStep:
         self.graph = self.graph2 = None
         self.loss = None
         self.aux = None
-        two_phase = grad_sync is not None and len(grad_sync.buckets) > 1
+        self.recaptures = 0
+        two_phase = self._two_phase = grad_sync is not None and len(grad_sync.buckets) > 1
+        if capture_tail is None:
+            capture_tail = os.environ.get("VS_GRAPH_TAIL", "1") != "0"
+        import torch.distributed as dist
+        # grad_sync None = the caller wants no exchange (one rank, or a timing leg): nothing collective is captured then
+        rccl_or_none = grad_sync is None or (not dist.is_initialized()) or dist.get_backend(grad_sync.group) == "nccl"
+        self.tail = (bool(capture_tail) and warmup >= 1 and not two_phase and scaler is None and isinstance(optimizer, _optim.SGD)
+                     and rccl_or_none and all(p.is_cuda for p in self.params))
+        self._own_sync = False
+        if self.tail and grad_sync is None:
+            # one rank, no exchange: the flat buffer still serves — it gives every gradient a FIXED address, which the captured optimiser launch needs
+            self.grad_sync = grad_sync = _ddp.FlatGradSync(self.params, overlap=False, exchange=False)
+            self._own_sync = True
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self._accumulators = capture_safe_accumulators(self.params)      # kept: the capture must find these, not default-stream ones
             for _ in range(warmup):
                 self._eager_fwd_bwd()
+            if self.tail:
+                self._prepare_tail()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        self._capture()
+
+    def _hyper(self):
+        return [(float(g["lr"]), float(g["momentum"]), float(g["weight_decay"])) for g in self.optimizer.param_groups]
+
+    def _prepare_tail(self):
+        """after a warm-up pass: can the tail be captured (every live gradient sits in its flat slot), and are the tables it needs built?"""
+        s = self.grad_sync
+        src, _ = s._stragglers([p.grad for p in self.params])
+        if src or not s.direct:
+            self.tail = False                    # a gather launch with tables built at capture time would be needed: the tail stays eager
+            if self._own_sync:
+                s.close()
+                self.grad_sync, self._own_sync = None, False
+            return
+        self.optimizer.prepare(*s.live())
+        ops.repack_trainable()                   # builds the descriptor table of the multi-tensor re-pack (same images, same weights: idempotent)
+
+    def _capture(self):
+        two_phase = self._two_phase
+        self.graph = self.graph2 = None
         self.graph = torch.cuda.CUDAGraph()
         for p in self.params:
             p.grad = None
@@ -270,6 +315,13 @@ class GraphedStep:
         with torch.cuda.graph(self.graph):
             self._accumulators = capture_safe_accumulators(self.params)
             self._eager_fwd_bwd(rest=not two_phase)
+            if self.tail:
+                s = self.grad_sync
+                s._stragglers([p.grad for p in self.params])      # bookkeeping only (which parameters got no gradient): _prepare_tail saw no stragglers
+                s.start(0)
+                s.wait()
+                self.optimizer.step_with(*s.live())
+        self._tail_hyper = self._hyper()
         if two_phase:
             self.graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
@@ -290,6 +342,12 @@ class GraphedStep:
             ops.join_side()      # side-stream weight gradients (a parallel branch of the captured graph) / the second weight-gradient phase
 
     def step(self):
+        if self.tail:
+            if self._hyper() != self._tail_hyper:            # a scheduler moved lr / momentum / weight decay: they are baked into the captured launch
+                self.recaptures += 1
+                self._capture()
+            self.graph.replay()
+            return self.loss
         self.graph.replay()
         s = self.grad_sync
         kw = {} if self.scaler is None else {"scaler": self.scaler}
