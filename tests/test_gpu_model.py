@@ -428,6 +428,10 @@ def test_seg32_dropout_with_exported_masks_vs_oracle(monkeypatch):
         seeds.append(s)
         return s
     monkeypatch.setattr(ops, "next_dropout_seed", recording_seed)
+    # the masks are a pure function of (torch's seed, the process-wide dropout call counter): pin both, or the draw — and with it which activations
+    # sit on a ReLU edge under a kept mask element — depends on how many dropout sites earlier tests of the process happened to run
+    torch.manual_seed(1234)
+    monkeypatch.setattr(ops, "_DROPOUT_CALLS", [1000])
     p, side, bs = 0.2, 32, 2
     seg = _fill(M.Segmentation(1, 2, norm_type=1), 0, O)
     img, lab = O.synthetic_image(bs, side, 2), O.synthetic_label(bs, side, 3)
