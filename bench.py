@@ -31,6 +31,18 @@ SIDE, BATCH, DIM = 96, 2, 128
 # algorithmic work per volume per joint_train step at 96^3: 3 Seg passes + 2 VAE passes
 FLOPS_PER_VOLUME = 164.0e9
 BYTES_PER_VOLUME = {"bf16": 1.28e9, "fp16": 1.28e9, "fp32": 2.56e9}
+# --config: the workload.  joint96 = BASELINE configs[1], the configuration the metric is quoted on and the DEFAULT (what the driver times);
+# da128 = configs[3] (128^3 teacher-student domain_adaptation step, batch 1), joint160 = one GPU's share of configs[4] (160^3 joint_train, batch 2,
+# fp16 storage + dynamic loss scaling).  Algorithmic FLOPs / fused-minimum bytes per volume per step: BASELINE.md section 3.
+CONFIGS = {
+    "joint96": {"side": 96, "batch": 2, "method": "joint_train", "dtype": "bf16", "flops": 164.0e9, "bytes16": 1.28e9,
+                "name": "configs[1]: %d^3 joint VAE+seg training step (joint_train), batch=%d/GPU"},
+    "da128": {"side": 128, "batch": 1, "method": "domain_adaptation", "dtype": "bf16", "flops": 545.3e9, "bytes16": 4.2e9,
+              "name": "configs[3]: %d^3 teacher-student domain-adaptation step (domain_adaptation, loss type 0: student Seg+VAE forward/backward, teacher "
+                      "Seg+VAE forward, pseudo-label, three Dice terms), batch=%d/GPU"},
+    "joint160": {"side": 160, "batch": 2, "method": "joint_train", "dtype": "fp16", "flops": 759.3e9, "bytes16": 5.9e9,
+                 "name": "configs[4], one GPU's share: %d^3 joint VAE+seg training step (joint_train), batch=%d/GPU"},
+}
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}
 
@@ -40,8 +52,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
-    ap.add_argument("--side", type=int, default=SIDE)
+    ap.add_argument("--config", default="joint96", choices=sorted(CONFIGS), help="workload: joint96 = BASELINE configs[1] (default, the metric's "
+                    "configuration), da128 = configs[3], joint160 = one GPU's share of configs[4]")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16", "fp32"], help="storage type of activations / packed weights (default: the config's)")
+    ap.add_argument("--side", type=int, default=None, help="volume side (default: the config's; another value is a plumbing run without a roofline)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the fp32 (parity-mode) timing entry")
@@ -54,8 +68,14 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="testing aid: initialise the process group and run the gradient "
                     "all-reduce path even with one rank (exercises RCCL on a 1-GPU box)")
     ap.add_argument("--master-port", type=int, default=29533)
+    ap.add_argument("--recompute", action="store_true", help="activation recomputation in the Down / Up blocks (joint_model.set_recompute, DESIGN 4.4)")
     ap.add_argument("--no-exchange-forms", action="store_true", help="N > 1: skip the no-exchange / other-exchange-form timing legs")
-    return ap.parse_args()
+    a = ap.parse_args()
+    cfg = CONFIGS[a.config]
+    a.dtype = a.dtype or cfg["dtype"]
+    a.side = a.side or cfg["side"]
+    a.batch = cfg["batch"]
+    return a
 
 
 def spawn_ranks(a):
@@ -69,21 +89,32 @@ def spawn_ranks(a):
     return subprocess.call(cmd, env=env)
 
 
-def build(side, dtype, rank):
+def build(side, dtype, rank, batch=BATCH, teacher=False):
+    """-> (joint, img, label[, teacher]): Joint(Segmentation, frozen VAE(spatial=side)) with the RNG-free weight fill, synthetic inputs resident in HBM;
+    teacher: a second, fully frozen Joint whose Seg has another fill (main_target.py:397-406: the teacher starts as a copy and drifts by EMA)."""
     import torch
     import joint_model as M
     from oracle import ref_cpu as O      # only for the RNG-free weight fill / synthetic inputs shared with the tests
-    seg = M.Segmentation(n_channels=1, n_class=2, norm_type=1)
-    vae = M.VAE(n_channels=2, n_class=2, norm_type=1, dim=DIM, spatial=side)
-    joint = M.Joint(models=[seg, vae])
-    O.deterministic_fill_(joint, seed=0)
-    joint = joint.cuda()
-    for p in joint.Vae.parameters():
-        p.requires_grad = False
-    joint.Vae.eval()
-    M.set_kernel_dtype(joint, {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype])
-    img = O.synthetic_image(BATCH, side, seed=2 + 10 * rank).cuda()
-    lab = O.synthetic_label(BATCH, side, seed=3 + 10 * rank).cuda()
+    kd = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype]
+
+    def make(seg_seed=None, frozen=False):
+        seg = M.Segmentation(n_channels=1, n_class=2, norm_type=1)
+        vae = M.VAE(n_channels=2, n_class=2, norm_type=1, dim=DIM, spatial=side)
+        joint = M.Joint(models=[seg, vae])
+        O.deterministic_fill_(joint, seed=0)
+        if seg_seed is not None:
+            O.deterministic_fill_(joint.Seg, seed=seg_seed)
+        joint = joint.cuda()
+        for p in (joint.parameters() if frozen else joint.Vae.parameters()):
+            p.requires_grad = False
+        joint.Vae.eval()
+        return M.set_kernel_dtype(joint, kd)
+
+    joint = make()
+    img = O.synthetic_image(batch, side, seed=2 + 10 * rank).cuda()
+    lab = O.synthetic_label(batch, side, seed=3 + 10 * rank).cuda()
+    if teacher:
+        return joint, img, lab, make(seg_seed=1, frozen=True)
     return joint, img, lab
 
 
@@ -111,20 +142,29 @@ def usable_cores():
     return max(1, min(n, 64))        # eager conv3d on CPU stops scaling well before 64 threads
 
 
-def cpu_baseline(side, steps, budget_s=40.0):
-    """The oracle's joint_train step (stock eager PyTorch fp32) on the host cores; 1 warm-up + `steps` timed."""
+def cpu_baseline(side, steps, budget_s=40.0, batch=BATCH, method="joint_train"):
+    """The oracle's step of the same workload (stock eager PyTorch fp32) on the host cores; 1 warm-up + `steps` timed."""
     import torch
     from oracle import ref_cpu as O
     cores = usable_cores()
     torch.set_num_threads(cores)
     joint = O.build_joint(side)
-    img, lab = O.synthetic_image(BATCH, side, 2), O.synthetic_label(BATCH, side, 3)
+    teacher = None
+    if method == "domain_adaptation":
+        teacher = O.build_joint(side)
+        O.deterministic_fill_(teacher.Seg, seed=1)
+        for p in teacher.parameters():
+            p.requires_grad = False
+    img, lab = O.synthetic_image(batch, side, 2), O.synthetic_label(batch, side, 3)
     opt = torch.optim.SGD(joint.Seg.parameters(), lr=1e-2, momentum=0.9)
     times, t_start = [], time.perf_counter()
     for i in range(steps + 1):
         t0 = time.perf_counter()
         opt.zero_grad()
-        loss, _ = O.joint_train_losses(joint, img, lab)
+        if teacher is not None:
+            loss, _ = O.domain_adaptation_losses(joint, teacher, img, lab, lambda_vae=1.0, domain_loss_type=0)
+        else:
+            loss, _ = O.joint_train_losses(joint, img, lab)
         loss.backward()
         opt.step()
         times.append(time.perf_counter() - t0)
@@ -132,9 +172,9 @@ def cpu_baseline(side, steps, budget_s=40.0):
             break
     timed = sorted(times[1:]) if len(times) > 1 else times
     med = timed[len(timed) // 2]
-    return {"value": BATCH / med, "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": "1 warm-up + %d timed joint_train steps at %d^3 B=%d, eager PyTorch fp32 (oracle/ref_cpu.py), "
-                      "median, %d threads" % (len(timed), side, BATCH, cores)}
+    return {"value": batch / med, "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": "1 warm-up + %d timed %s steps at %d^3 B=%d, eager PyTorch fp32 (oracle/ref_cpu.py), "
+                      "median, %d threads" % (len(timed), method, side, batch, cores)}
 
 
 def make_step(a, dtype, rank, use_dist, overlap=None, info=None):
@@ -143,7 +183,12 @@ def make_step(a, dtype, rank, use_dist, overlap=None, info=None):
     info (dict, optional): receives what was built ("tail_in_graph", "buckets")."""
     from vae_segmentation_amd import ddp, optim
     from vae_segmentation_amd import train as T
-    joint, img, lab = build(a.side, dtype, rank)
+    method = CONFIGS[a.config]["method"]
+    teacher = None
+    if method == "domain_adaptation":
+        joint, img, lab, teacher = build(a.side, dtype, rank, a.batch, teacher=True)
+    else:
+        joint, img, lab = build(a.side, dtype, rank, a.batch)
     opt = optim.SGD([{"params": joint.Seg.parameters(), "lr": 1e-2}, {"params": joint.Vae.parameters(), "lr": 0.0}],
                     lr=1e-2, momentum=0.9, weight_decay=0.0)
     seg_params = [p for p in joint.Seg.parameters()]
@@ -157,6 +202,8 @@ def make_step(a, dtype, rank, use_dist, overlap=None, info=None):
         info["tail_in_graph"] = False
 
     def loss_fn():
+        if teacher is not None:          # main_target.py:520-596, loss type 0, lambda_vae 1.0 (scripts/target/domain_msd_dh.bash:12-13); the schedule stays on the device
+            return T.domain_adaptation_losses(joint, teacher, img, lab, lambda_vae=1.0, domain_loss_type=0, host_schedule=False)
         return T.joint_train_losses(joint, img, lab, lambda_vae=0.1)
 
     if a.no_graph:
@@ -211,12 +258,13 @@ def timed_steps(step, steps, warmup, fence):
     return time.perf_counter() - t0, loss
 
 
-def step_roofline(dtype, ms_per_step, families):
+def step_roofline(dtype, ms_per_step, families, config="joint96"):
     """Whole-step roofline: the step is HBM-bound by the algorithm (2.56 GB -> 0.32 ms at 8 TB/s against
     328 GF -> 0.13 ms at the bf16 MFMA peak), so `achieved` = algorithmic bytes per step / measured step time."""
     from vae_segmentation_amd import profiling
-    nbytes = BYTES_PER_VOLUME[dtype] * BATCH
-    flops = FLOPS_PER_VOLUME * BATCH
+    cfg = CONFIGS[config]
+    nbytes = cfg["bytes16"] * (2.0 if dtype == "fp32" else 1.0) * cfg["batch"]
+    flops = cfg["flops"] * cfg["batch"]
     sec = ms_per_step * 1e-3
     t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_PEAK_TFLOPS[dtype] * 1e12)
     out = {"scope": "whole step (one HIP-graph replay + optimiser launches)",
@@ -225,10 +273,10 @@ def step_roofline(dtype, ms_per_step, families):
            "hbm": {"achieved": nbytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS}}
     lead = "hbm" if t_hbm >= t_mfma else "mfma"
     out.update({"bound": lead, "achieved": out[lead]["achieved"], "peak": out[lead]["peak"], "unit": out[lead]["unit"], "frac": out[lead]["frac"],
-                "traffic": profiling.measured_step_traffic(),
-                # `traffic` comes from the newest committed PMC summary (profiles/rNN_hbm_traffic.json), not from this run: true here means that
-                # summary was taken on other kernel sources than the ones that just ran
-                "traffic_stale": profiling.traffic_is_stale()})
+                # `traffic` comes from the newest committed PMC summary (profiles/rNN_hbm_traffic.json: the joint96 bf16 step), not from this run:
+                # traffic_stale true means that summary was taken on other kernel sources than the ones that just ran
+                "traffic": profiling.measured_step_traffic() if (config == "joint96" and dtype == "bf16") else None,
+                "traffic_stale": profiling.traffic_is_stale() if (config == "joint96" and dtype == "bf16") else None})
     if families is not None:
         out["families"] = families
     return out
@@ -287,6 +335,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    if a.recompute:
+        import joint_model
+        joint_model.set_recompute(True)
     info = {}
     step, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, use_dist, info=info)
     dt, loss = timed_steps(step, a.steps, a.warmup, fence)
@@ -346,22 +397,26 @@ def main():
         step32, _, _, closer32 = make_step(a, "fp32", rank, False)
         n32 = max(5, min(a.steps, 10))
         dt32, _ = timed_steps(step32, n32, 2, lambda: torch.cuda.synchronize())
-        fp32_mode = {"ms_per_step": 1e3 * dt32 / n32, "value": BATCH * n32 / dt32, "unit": "volumes/s", "steps": n32,
+        fp32_mode = {"ms_per_step": 1e3 * dt32 / n32, "value": a.batch * n32 / dt32, "unit": "volumes/s", "steps": n32,
                      "note": "fp32 storage + exact-f32 MFMA: the mode that meets the 1e-3 parity gate (tests/test_gpu_model.py)"}
         del step32
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.side, a.cpu_steps)
+        cpu = cpu_baseline(a.side, a.cpu_steps, batch=a.batch, method=CONFIGS[a.config]["method"])
 
     if rank == 0:
-        vols = world * BATCH * a.steps / dt
+        vols = world * a.batch * a.steps / dt
+        cfg = CONFIGS[a.config]
         out = {
-            "metric": "3D train-step volumes/sec at 96^3 batch=2 (joint VAE+seg)", "value": vols, "unit": "volumes/s",
+            "metric": ("3D train-step volumes/sec at 96^3 batch=2 (joint VAE+seg)" if a.config == "joint96" else
+                       "3D train-step volumes/sec at %d^3 batch=%d (%s)" % (a.side, a.batch, cfg["method"])), "value": vols, "unit": "volumes/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[a.dtype], "data": "synthetic",
-            "config": {"workload": "configs[1]: %d^3 joint VAE+seg training step (joint_train), batch=%d/GPU, %s activations + fp32 accumulate, "
-                                   "SGD momentum 0.9, VAE frozen, HIP-graph replay" % (a.side, BATCH, a.dtype),
-                       "global_batch": world * BATCH, "parallelism": "dp%d" % world, "final_loss": final_loss,
+            "config": {"workload": (cfg["name"] % (a.side, a.batch)) + ", %s activations + fp32 accumulate%s, SGD momentum 0.9, VAE frozen, HIP-graph replay"
+                                   % (a.dtype, " + dynamic loss scaling" if a.dtype == "fp16" else ""),
+                       "global_batch": world * a.batch, "parallelism": "dp%d" % world, "final_loss": final_loss,
+                       "activation_recomputation": bool(a.recompute),
+                       "peak_device_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
                        # host time per step to issue the work (one graph launch, then the exchange and the optimiser eagerly); far below ms_per_step = the
                        # step is GPU-bound and capturing those tail launches into the graph as well would not shorten it
                        "host_issue_ms_per_step": round(host_issue_ms, 4),
@@ -372,7 +427,7 @@ def main():
                                           if os.environ.get("VS_DDP_OVERLAP", "0") == "1" else
                                           "one RCCL all-reduce of the flat gradient buffer (written in place by the weight-gradient kernels) after the pass")
                                          if use_dist else "none (1 rank)")},
-            "roofline": step_roofline(a.dtype, ms_per_step / 1.0, families) if a.side == SIDE else None,
+            "roofline": step_roofline(a.dtype, ms_per_step / 1.0, families, a.config) if a.side == cfg["side"] else None,
             "fp32_parity_mode": fp32_mode, "cpu_baseline": cpu,
         }
         sys.stdout.flush()

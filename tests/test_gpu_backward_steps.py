@@ -107,3 +107,63 @@ def test_seg96_every_backward_step_matches_fp64_recomputation(monkeypatch):
     worst = max(results, key=lambda r: r[1])
     print("worst step: %s %.3e" % worst)
     assert worst[1] < 5e-6, worst
+
+
+def test_seg96_every_forward_step_matches_fp64_recomputation(monkeypatch):
+    """The forward analogue: every conv output of Segmentation at 96^3, B = 2, recomputed in fp64 on the CPU from the raw tensor the
+    HIP pass itself produced one step earlier — inside every DoubleConv, across every Down / Up boundary (stride-2 and transposed convs with their live
+    biases), through both additive skips, from the image into in_block and from up5 through out_block + softmax to the prediction.  The forward is
+    continuous in its inputs (no rounding band to exclude); every step must agree to fp32 rounding, so whatever distance the end-to-end seg96 comparison
+    shows (tests/test_gpu_parity_report.py: a 4-6x draw against one oracle-fp32 run) is accumulated network sensitivity, not a kernel's arithmetic."""
+    import joint_model as M
+    from oracle import ref_cpu as O
+    from vae_segmentation_amd import modules
+
+    seg = O.deterministic_fill_(M.Segmentation(1, 2, norm_type=1), seed=0).cuda()        # fp32 kernels: the parity mode
+    names = {id(m): n for n, m in seg.named_modules()}
+    rec = {}
+    orig = modules._conv3
+
+    def conv3(conv, a):
+        out = orig(conv, a)
+        rec[names[id(conv)]] = out.raw.detach()
+        return out
+
+    monkeypatch.setattr(modules, "_conv3", conv3)
+    img = O.synthetic_image(2, 96, 2)
+    with torch.no_grad():
+        batch = seg({"img": img.cuda()}, "img", "pred")
+    torch.cuda.synchronize()
+    mods = dict(seg.named_modules())
+    W = lambda name: mods[name].weight.detach().double().cpu()
+    Bv = lambda name: mods[name].bias.detach().double().cpu()
+    Y = lambda name: _planar(rec[name], mods[name].weight.shape[0])
+    results = []
+
+    def check(tag, got, want):
+        e = float((got - want).norm() / want.norm().clamp_min(1e-300))
+        results.append((tag, e))
+        print("%-64s %.3e" % (tag, e))
+
+    print("\nsingle forward steps, HIP fp32 vs fp64 recomputation from HIP's own inputs (relative L2)")
+    with torch.no_grad():
+        check("img -> in_block.conv.0", Y("in_block.conv.0"), F.conv3d(img.double(), W("in_block.conv.0"), padding=1))
+        for blk in ("down1", "down2", "down3", "down4", "up2", "up3", "up4", "up5"):
+            for a_i, b_i in ((0, 3), (3, 6)):
+                ka, kb = "%s.conv.1.conv.%d" % (blk, a_i), "%s.conv.1.conv.%d" % (blk, b_i)
+                check("%s -> %s" % (ka, kb), Y(kb), F.conv3d(_act(Y(ka)), W(kb), padding=1))
+        for src, blk in (("in_block.conv.0", "down1"), ("down1.conv.1.conv.6", "down2"), ("down2.conv.1.conv.6", "down3"), ("down3.conv.1.conv.6", "down4")):
+            u = F.conv3d(_act(Y(src)), W(blk + ".conv.0"), Bv(blk + ".conv.0"), stride=2)
+            check("%s -> [k2s2] -> %s.conv.1.conv.0" % (src, blk), Y(blk + ".conv.1.conv.0"), F.conv3d(u, W(blk + ".conv.1.conv.0"), padding=1))
+        for src, blk in (("down4.conv.1.conv.6", "up2"), ("up2.conv.1.conv.6", "up3")):
+            u = F.conv_transpose3d(_act(Y(src)), W(blk + ".conv.0"), Bv(blk + ".conv.0"), stride=2)
+            check("%s -> [convT] -> %s.conv.1.conv.0" % (src, blk), Y(blk + ".conv.1.conv.0"), F.conv3d(u, W(blk + ".conv.1.conv.0"), padding=1))
+        for up_src, skip_src, blk in (("up3.conv.1.conv.6", "down2.conv.1.conv.6", "up4"), ("up4.conv.1.conv.6", "down1.conv.1.conv.6", "up5")):
+            u = F.conv_transpose3d(_act(Y(up_src)) + _act(Y(skip_src)), W(blk + ".conv.0"), Bv(blk + ".conv.0"), stride=2)
+            check("%s + %s -> [skip add, convT] -> %s.conv.1.conv.0" % (up_src, skip_src, blk), Y(blk + ".conv.1.conv.0"),
+                  F.conv3d(u, W(blk + ".conv.1.conv.0"), padding=1))
+        logits = F.conv3d(_act(Y("up5.conv.1.conv.6")), W("out_block"), Bv("out_block"), padding=1)
+        check("up5.conv.1.conv.6 -> out_block -> softmax (pred)", batch["pred"].double().cpu(), torch.softmax(logits, 1))
+    worst = max(results, key=lambda r: r[1])
+    print("worst step: %s %.3e" % worst)
+    assert len(results) == 26 and worst[1] < 5e-6, worst

@@ -1,66 +1,36 @@
-"""GPU-box aid: time the other BASELINE configs, HIP-graph replayed — configs[3] 128^3 domain_adaptation (types 0 and 8), configs[4]
-160^3 joint_train in fp16 with dynamic loss scaling (and in bf16), and the fp32 parity mode of configs[1].  Writes one JSON line per
-configuration.   usage: python tools/run_configs.py [all|da128|joint160|fp32] [out.jsonl]"""
-import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-import joint_model as M
-from oracle import ref_cpu as O
-from vae_segmentation_amd import ops, optim, train as T
+"""GPU-box aid: the other BASELINE configs through bench.py (same timing protocol, same JSON line with the `roofline` object computed from
+BASELINE.md section 3's algorithmic figures) — configs[3] 128^3 domain_adaptation, configs[4] 160^3 joint_train in fp16 with dynamic loss scaling
+(and in bf16, and with activation recomputation), and configs[1] in the fp32 parity mode.  One child process per configuration (this parent never
+touches the GPU); writes one JSON line per configuration.   usage: python tools/run_configs.py [all|da128|joint160|fp32] [out.jsonl] [steps]"""
+import json
+import os
+import subprocess
+import sys
 
-DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
-out_path = sys.argv[2] if len(sys.argv) > 2 else None
-records = []
-
-
-def joint(side, dtype):
-    j = M.Joint([M.Segmentation(1, 2, norm_type=1), M.VAE(2, 2, norm_type=1, dim=128, spatial=side)])
-    O.deterministic_fill_(j, 0); j = j.cuda()
-    for p in j.Vae.parameters(): p.requires_grad = False
-    M.set_kernel_dtype(j, DT[dtype])
-    return j
-
-
-def timeit(name, loss_fn, params, opt, vols, steps=20, scaler=None):
-    torch.cuda.reset_peak_memory_stats()
-    gs = T.GraphedStep(loss_fn, params, opt, warmup=2, scaler=scaler)
-    for _ in range(3): gs.step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(steps): gs.step()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    rec = {"config": name, "ms_per_step": round(dt * 1e3, 3), "volumes_per_s": round(vols / dt, 1),
-           "peak_device_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "loss": round(float(gs.loss.item()), 5),
-           "loss_scale": None if scaler is None else float(scaler.scale.item())}
-    records.append(rec)
-    print(json.dumps(rec), flush=True)
-
-
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
-if which in ("all", "da128"):
-    for lt in (0, 8):
-        s, t = joint(128, "bf16"), joint(128, "bf16")
-        O.deterministic_fill_(t.Seg, 1); t = t.cuda()
-        for p in t.parameters(): p.requires_grad = False
-        img, lab = O.synthetic_image(1, 128, 2).cuda(), O.synthetic_label(1, 128, 3).cuda()
-        params = list(s.Seg.parameters()); opt = optim.SGD(params, lr=1e-2, momentum=0.9)
-        timeit("configs[3]: 128^3 domain_adaptation B=1 bf16, domain_loss_type %d" % lt,
-               lambda: T.domain_adaptation_losses(s, t, img, lab, lambda_vae=1.0, domain_loss_type=lt, host_schedule=False), params, opt, 1)
-        del s, t; torch.cuda.empty_cache()
-if which in ("all", "joint160"):
-    for dtype, recompute in (("fp16", False), ("bf16", False), ("bf16", True)):
-        M.set_recompute(recompute)                       # activations of the Down / Up blocks rebuilt in backward
-        j = joint(160, dtype)
-        img, lab = O.synthetic_image(2, 160, 2).cuda(), O.synthetic_label(2, 160, 3).cuda()
-        params = list(j.Seg.parameters()); opt = optim.SGD(params, lr=1e-2, momentum=0.9)
-        timeit("configs[4] (one GPU's share): 160^3 joint_train B=2 %s%s%s" % (dtype, " + dynamic loss scale" if dtype == "fp16" else "", " + activation recomputation" if recompute else ""),
-               lambda: T.joint_train_losses(j, img, lab), params, opt, 2, scaler=optim.LossScaler() if dtype == "fp16" else None)
-        del j; torch.cuda.empty_cache()
-    M.set_recompute(False)
-if which in ("all", "fp32"):
-    j = joint(96, "fp32")
-    img, lab = O.synthetic_image(2, 96, 2).cuda(), O.synthetic_label(2, 96, 3).cuda()
-    params = list(j.Seg.parameters()); opt = optim.SGD(params, lr=1e-2, momentum=0.9)
-    timeit("configs[1] in the fp32 parity mode: 96^3 joint_train B=2", lambda: T.joint_train_losses(j, img, lab), params, opt, 2)
+out_path = sys.argv[2] if len(sys.argv) > 2 else None
+steps = sys.argv[3] if len(sys.argv) > 3 else "30"
+RUNS = [("da128", ["--config", "da128"]),
+        ("joint160", ["--config", "joint160"]),
+        ("joint160", ["--config", "joint160", "--dtype", "bf16"]),
+        ("joint160", ["--config", "joint160", "--dtype", "bf16", "--recompute"]),
+        ("fp32", ["--config", "joint96", "--dtype", "fp32"])]
+records = []
+for tag, extra in RUNS:
+    if which not in ("all", tag):
+        continue
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "5", "--no-fp32-mode", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if not line:
+        print("FAILED: %s\n%s" % (" ".join(extra), r.stderr[-1500:]), flush=True)
+        continue
+    rec = json.loads(line[-1])
+    records.append(rec)
+    rf = rec.get("roofline") or {}
+    print("%-55s %8.3f ms/step %8.1f volumes/s  %s roofline %.1f %%  peak %.2f GB" % (" ".join(extra), rec["ms_per_step"], rec["value"], rf.get("bound"),
+                                                                                   100 * rf.get("frac", 0.0), rec["config"].get("peak_device_memory_GB", 0)), flush=True)
 if out_path:
     with open(out_path, "w") as f:
         for r in records:
