@@ -31,7 +31,7 @@ extern "C" {
 
 #define VS_VERSION 205
 
-enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2 };   /* storage type of activations: fp32 (parity mode), bf16, IEEE fp16 (needs loss scaling, see vs_loss_scale_*) */
+enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2, VS_F32X3 = 3 /* PACK-ONLY: three-bf16-limb image of an fp32 3x3x3 weight, see vs_conv_k3_f32_limbs */ };   /* storage type of activations: fp32 (parity mode), bf16, IEEE fp16 (needs loss scaling, see vs_loss_scale_*) */
 #ifndef VS_STAT_SLOTS
 #define VS_STAT_SLOTS 4        /* measured on one MI355X, 96^3 step: 1 copy 2.908 ms, 2: 2.820, 4: 2.797, 8: 3.021 (consumers read every copy) */
 #endif
@@ -145,6 +145,13 @@ int vs_conv_scatter_bwd_data(const void* x, const void* w_packed, void* y, const
  * 16-bit storage; kernels exist for the single-chunk layers of the full- and half-resolution levels (c_in 8 or 16: igemm_k3t.h, igemm_k3b.h FA);
  * any other shape returns VS_ESHAPE — ask vs_conv_k3_fused_apply_supported first (1 / 0; lazy_input: the conv's own input is a lazy activation). */
 int vs_conv_k3_fused_apply_supported(int n, int d, int h, int w, int c_in, int m_out, int lazy_input, int dtype);
+/* fp32 parity mode: 1 when the 3x3x3 convolutions of dtype VS_F32 run on the bf16 matrix cores through exact three-limb operand splitting
+ * (csrc/igemm_k3x.h: every fp32 operand = three bf16 limbs, six exact limb products per product, fp32 accumulation — 2.7x fewer matrix cycles
+ * than the exact-f32 MFMA at the accuracy of one fp32 rounding).  Their packed weights must then be VS_F32X3 images: vs_pack_weight /
+ * vs_packed_weight_bytes / vs_pack_weight_multi with dtype VS_F32X3 (a PACK-ONLY dtype: tensors stay VS_F32).  Env VS_F32_LIMBS=0 -> 0: the
+ * exact-f32 MFMA kernels with plain VS_F32 images. */
+int vs_conv_k3_f32_limbs(void);
+
 int vs_conv_k3_bwd_data_fused_apply(const void* g, const void* act_x, const double* act_stats, const double* act_sums,
                                     const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,
                                     void* dx_out, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);

@@ -6,8 +6,27 @@ int g1_dispatch_k3_f32(const G1Params& p, int ck, int mt, int epi, int tiles, in
 int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_dispatch_k3_f16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_k3_fa_supported(const G1Params& p, int ck, int mt);
+int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
+
+// fp32 parity mode: the 3x3x3 convolutions run on the bf16 matrix cores through exact three-limb operand splitting (igemm_k3x.h); their packed
+// weights are VS_F32X3 images (pack.hip).  VS_F32_LIMBS=0 keeps the exact-f32 MFMA kernels (igemm_k3.h) and the plain fp32 images.
+extern "C" int vs_conv_k3_f32_limbs(void) {
+    static const int on = getenv("VS_F32_LIMBS") ? atoi(getenv("VS_F32_LIMBS")) : 1;
+    return on ? 1 : 0;
+}
 
 static int dispatch_k3(const G1Params& p, int dtype, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s) {
+    if (dtype == VS_F32 && vs_conv_k3_f32_limbs()) {
+        G1Params q = p;
+        const int ckx = p.C < 16 ? p.C : 16;
+        q.nch = p.C / ckx;
+        const int rows16 = epi == EPI_SOFTMAX2 ? 16 : p.rb_total * 16;
+        // 32-row workgroups (B fragments shared by two row blocks) when that still fills the chip; chunks of 16 channels with a 32-row weight block
+        // fill the 160 KB of LDS exactly, so the per-(n,c) tables must be small
+        int mtx = 16;
+        if (rows16 % 32 == 0 && (long long)tiles * (rows16 / 32) >= 256 && (ckx == 8 || (size_t)2 * p.N * (p.C + p.M) * sizeof(float) <= 3000)) mtx = 32;
+        return g1_dispatch_k3_x3(q, ckx, mtx, epi, tiles, rows16 / mtx, s);
+    }
     if (dtype == VS_F32) return g1_dispatch_k3_f32(p, ck, mt, epi, tiles, row_tiles, s);
     if (dtype == VS_BF16) return g1_dispatch_k3_bf16(p, ck, mt, epi, tiles, row_tiles, s);
     return g1_dispatch_k3_f16(p, ck, mt, epi, tiles, row_tiles, s);

@@ -1,0 +1,28 @@
+// fp32 parity mode, 3x3x3 convolutions on the bf16 matrix cores through exact three-limb operand splitting (igemm_k3x.h)
+#include <stdlib.h>
+#include "igemm_dispatch.h"
+#include "igemm_k3x.h"
+
+// ck = min(C, 16); mt = 16 or 32 rows per workgroup
+int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s) {
+    if (epi == EPI_SOFTMAX2) {
+        if (ck != 8 || mt != 16 || p.nch != 1) return VS_ESHAPE;      // out_block: 8 stored channels -> 2 logits
+        return k3x_launch<8, 16, EPI_SOFTMAX2, false>(p, tiles, row_tiles, s);
+    }
+    if (ck == 8) {
+        if (p.nch != 1) return VS_ESHAPE;
+        if (mt == 16) return k3x_launch<8, 16, EPI_RAW, false>(p, tiles, row_tiles, s);
+        if (mt == 32) return k3x_launch<8, 32, EPI_RAW, false>(p, tiles, row_tiles, s);
+        return VS_ESHAPE;
+    }
+    if (ck == 16) {
+        if (p.nch == 1) {
+            if (mt == 16) return k3x_launch<16, 16, EPI_RAW, false>(p, tiles, row_tiles, s);
+            if (mt == 32) return k3x_launch<16, 32, EPI_RAW, false>(p, tiles, row_tiles, s);
+        } else {
+            if (mt == 16) return k3x_launch<16, 16, EPI_RAW, true>(p, tiles, row_tiles, s);
+            if (mt == 32) return k3x_launch<16, 32, EPI_RAW, true>(p, tiles, row_tiles, s);
+        }
+    }
+    return VS_ESHAPE;
+}

@@ -71,6 +71,49 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ src, T* __res
     *(u32x4*)(dst + i) = frag_pack(v, (T*)nullptr);
 }
 
+// VS_F32X3 image of a 3x3x3 weight for k3x_kernel (igemm_k3x.h): [row block][chunk of CK = min(c_pad, 16) channels][k-group of 32][limb 0..2][lane][8 bf16]
+//   row = rb*16 + (lane & 15);  k within the chunk = kg*32 + (lane >> 4)*8 + j;  tap = k / CK, c = ch*CK + k % CK
+// limb 0 = w rounded to bf16, limb 1 = w - limb0 rounded to bf16, limb 2 = the rest (8 + 8 + 8 significant bits).  One thread per 16-byte fragment.
+__device__ __forceinline__ void pack_one_limbs(const float* __restrict__ src, unsigned short* __restrict__ dst, int d0, int d1, int ntaps,
+                                               int c_pad, int form, long long total, long long frag) {
+    const long long i = frag * 8;
+    if (i >= total) return;
+    const int CK = c_pad < 16 ? c_pad : 16;
+    const int nch = c_pad / CK;
+    const int nkg = (ntaps * CK + 31) / 32;
+    long long r = frag;
+    const int lane = (int)(r % 64); r /= 64;
+    const int limb = (int)(r % 3); r /= 3;
+    const int kg = (int)(r % nkg); r /= nkg;
+    const int ch = (int)(r % nch);
+    const int rb = (int)(r / nch);
+    const int row = rb * 16 + (lane & 15);
+    const int kk0 = kg * 32 + (lane >> 4) * 8;           // 8 divides CK: the fragment stays inside one tap
+    const int tap = kk0 / CK;
+    const int c0 = ch * CK + kk0 % CK;
+    unsigned short o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j;
+        float v = 0.f;
+        if (form == VS_PACK_ROWS_D0) { if (row < d0 && tap < ntaps && c < d1) v = src[((size_t)row * d1 + c) * ntaps + tap]; }
+        else { if (row < d1 && tap < ntaps && c < d0) v = src[((size_t)c * d1 + row) * ntaps + (ntaps - 1 - tap)]; }
+        const unsigned short b0 = f2bf(v);                // round-to-nearest limbs, as k3x_split4 (igemm_k3x.h) forms them for the activations
+        const float r1 = v - bf2f(b0);
+        const unsigned short b1 = f2bf(r1);
+        const float r2 = r1 - bf2f(b1);
+        o[j] = limb == 0 ? b0 : (limb == 1 ? b1 : f2bf(r2));
+    }
+    u32x4 pk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pk[q] = (unsigned int)o[2 * q] | ((unsigned int)o[2 * q + 1] << 16);
+    *(u32x4*)(dst + i) = pk;
+}
+__global__ void pack_weight_limbs_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int d0, int d1, int ntaps, int c_pad, int form,
+                                         long long total) {
+    pack_one_limbs(src, dst, d0, d1, ntaps, c_pad, form, total, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int d0, int d1, int ntaps,
                                    int c_pad, int form, long long total) {
@@ -94,7 +137,8 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const vs_pack_de
     }
     const vs_pack_desc d = descs[lo];
     const long long i = (long long)(lb - d.first_block) * 256 + threadIdx.x;
-    if (d.dtype == VS_F32) pack_one<float>(d.src, (float*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
+    if (d.dtype == VS_F32X3) pack_one_limbs(d.src, (unsigned short*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
+    else if (d.dtype == VS_F32) pack_one<float>(d.src, (float*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
     else if (d.dtype == VS_BF16) pack_one<unsigned short>(d.src, (unsigned short*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
     else pack_one<vs_half>(d.src, (vs_half*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
 }
@@ -107,6 +151,10 @@ extern "C" int vs_pack_weight_multi(const vs_pack_desc* descs, int n_desc, int t
 }
 
 static long long packed_elems(int rows, int c_pad, int gemm_taps, int dtype) {
+    if (dtype == VS_F32X3) {                             // bf16 elements of the three-limb image (3x3x3 weights only)
+        const int CK = c_pad < 16 ? c_pad : 16;
+        return (long long)((rows + 15) / 16) * (c_pad / CK) * ((gemm_taps * CK + 31) / 32) * 3 * 64 * 8;
+    }
     if (vs_k3_toeplitz(rows, c_pad, gemm_taps, dtype)) return 9 * 64 * 8;
     if (vs_k3_toeplitz_f32(rows, c_pad, gemm_taps, dtype)) return 18 * 64 * 4;
     const int EPL = dtype == VS_F32 ? 4 : 8, KG = 4 * EPL;
@@ -125,7 +173,8 @@ extern "C" int vs_pack_weight(const float* src, void* dst, int d0, int d1, int n
                               void* stream) {
     if (!src || !dst || d0 <= 0 || d1 <= 0) return VS_EINVAL;
     if (!(c_pad == 8 || c_pad == 16 || (c_pad % 32 == 0 && c_pad > 0))) return VS_ESHAPE;
-    if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
+    if (!vs_dtype_ok(dtype) && dtype != VS_F32X3) return VS_EDTYPE;
+    if (dtype == VS_F32X3 && (form == VS_PACK_SCATTER_D1 || ntaps != 27)) return VS_ESHAPE;      // three-limb images exist for the 3x3x3 kernels only
     int rows, kc, gemm_taps;
     if (form == VS_PACK_ROWS_D0) { rows = d0; kc = d1; gemm_taps = ntaps; }
     else if (form == VS_PACK_ROWS_D1_FLIP) { rows = d1; kc = d0; gemm_taps = ntaps; }
@@ -135,6 +184,11 @@ extern "C" int vs_pack_weight(const float* src, void* dst, int d0, int d1, int n
     if (!(ntaps == 27 || ntaps == 8)) return VS_ESHAPE;
     const long long total = packed_elems(rows, c_pad, gemm_taps, dtype);
     const int blocks = vs_ceil_div(total / (dtype == VS_F32 ? 4 : 8), 256);      // one thread per 16-byte fragment
+    if (dtype == VS_F32X3) {
+        hipLaunchKernelGGL(pack_weight_limbs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, d0, d1, ntaps, c_pad, form, total);
+        VS_CHECK_LAUNCH();
+        return VS_OK;
+    }
     dispatch_t(dtype, [&](auto* tag) {
         using T = TAG_T(tag);
         hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, d0, d1, ntaps, c_pad, form, total);
