@@ -145,12 +145,12 @@ int vs_conv_scatter_bwd_data(const void* x, const void* w_packed, void* y, const
  * 16-bit storage; kernels exist for the single-chunk layers of the full- and half-resolution levels (c_in 8 or 16: igemm_k3t.h, igemm_k3b.h FA);
  * any other shape returns VS_ESHAPE — ask vs_conv_k3_fused_apply_supported first (1 / 0; lazy_input: the conv's own input is a lazy activation). */
 int vs_conv_k3_fused_apply_supported(int n, int d, int h, int w, int c_in, int m_out, int lazy_input, int dtype);
-/* fp32 parity mode: 1 when the 3x3x3 convolutions of dtype VS_F32 run on the bf16 matrix cores through exact three-limb operand splitting
+/* fp32 parity mode: 1 when a 3x3x3 convolution of dtype VS_F32 on a (d, h, w) volume with c_in stored input channels runs on the bf16 matrix cores through exact three-limb operand splitting
  * (csrc/igemm_k3x.h: every fp32 operand = three bf16 limbs, six exact limb products per product, fp32 accumulation — 2.7x fewer matrix cycles
  * than the exact-f32 MFMA at the accuracy of one fp32 rounding).  Their packed weights must then be VS_F32X3 images: vs_pack_weight /
  * vs_packed_weight_bytes / vs_pack_weight_multi with dtype VS_F32X3 (a PACK-ONLY dtype: tensors stay VS_F32).  Env VS_F32_LIMBS=0 -> 0: the
- * exact-f32 MFMA kernels with plain VS_F32 images. */
-int vs_conv_k3_f32_limbs(void);
+ * exact-f32 MFMA kernels with plain VS_F32 images; so do the volumes up to 6^3 with c_in a multiple of 32 (k3s_kernel<float>). */
+int vs_conv_k3_f32_limbs(int d, int h, int w, int c_in);
 
 int vs_conv_k3_bwd_data_fused_apply(const void* g, const void* act_x, const double* act_stats, const double* act_sums,
                                     const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,

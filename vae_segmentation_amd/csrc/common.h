@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "../../include/vaeseg.h"
 
@@ -331,6 +332,24 @@ __device__ __forceinline__ u32x4 act8(const u32x4 raw, const f32x2 (&sc)[4], con
     return r;
 }
 
+// ---- fp32 parity mode on the bf16 matrix cores (igemm_k3x.h, wgrad.hip g3x_kernel) ----
+// three-way split of four fp32 values into bf16 limbs, packed two per dword: out[l][0] = (v0, v1), out[l][1] = (v2, v3) of limb l.
+// Round-to-nearest limbs (v_cvt_pk_bf16_f32), not truncation: x0 = rne(x), x1 = rne(x - x0), x2 = rne(x - x0 - x1); the subtractions are exact and
+// x0 + x1 + x2 = x up to 2^-25 |x|.  With truncated limbs every limb has the sign of x, so the dropped products x1*w2 + x2*w1 + x2*w2 all have the
+// sign of x*w: a 3e-8 relative BIAS that adds up coherently in the per-channel sums of a whole volume (seen: 8.6e-5 on the 96^3 statistics check);
+// rounded limbs make the dropped terms zero-mean.
+__device__ __forceinline__ void vs_limb_split4(const float (&v)[4], unsigned int (&out)[3][2]) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const f32x2 x = f32x2{v[2 * q], v[2 * q + 1]};
+        const unsigned int p0 = H16<unsigned short>::pack2(x);
+        const f32x2 r1 = x - f32x2{H16<unsigned short>::lo(p0), H16<unsigned short>::hi(p0)};
+        const unsigned int p1 = H16<unsigned short>::pack2(r1);
+        const f32x2 r2 = r1 - f32x2{H16<unsigned short>::lo(p1), H16<unsigned short>::hi(p1)};
+        out[0][q] = p0; out[1][q] = p1; out[2][q] = H16<unsigned short>::pack2(r2);
+    }
+}
+
 // (bf16, 3x3x3, 8 stored k-side channels, <= 8 rows) weights — the 8-channel full-resolution layers — are packed in the Toeplitz
 // fragment order of k3t_kernel (igemm_k3t.h): [k-group (tz,ty)][lane][8], row (lane & 15) = (dx2, co), k = (xpos = lane >> 4, ci),
 // value W[co][ci][tz][ty][xpos - dx2] or 0.  pack.hip (image) and igemm_k3_bf16.hip (dispatch) both key on this predicate.
@@ -342,6 +361,15 @@ static __host__ __device__ inline bool vs_k3_toeplitz(int rows, int c_pad, int n
 // k = ((lane >> 5) = which of the two, ci = 4 * ((lane >> 4) & 1) + j), value W[co][ci][dz][wy - dy2][dx] or 0: 18 k-groups.
 static __host__ __device__ inline bool vs_k3_toeplitz_f32(int rows, int c_pad, int ntaps, int dtype) {
     return dtype == VS_F32 && ntaps == 27 && c_pad == 8 && rows <= 8;
+}
+
+// Channel-chunk width of the fp32 limb kernels (igemm_k3x.h) and of their VS_F32X3 weight images (pack.hip): min(c_pad, VS_K3X_CK), VS_K3X_CK = 8 or 16
+// (env, read once; default below).  8: a stage's three limb planes + weight block take 64 KB of LDS — two workgroups per CU, whose staging and MFMA
+// phases overlap; 16: half as many stages per tile, 115 KB — one workgroup per CU.
+static inline int vs_k3x_ck(int c_pad) {
+    static const int ck = getenv("VS_K3X_CK") ? atoi(getenv("VS_K3X_CK")) : 8;      // measured on the fp32 96^3 step: 7.34 ms (8) vs 7.55 ms (16)
+    const int w = ck == 8 ? 8 : 16;
+    return c_pad < w ? c_pad : w;
 }
 
 // Zeroing as a kernel, never hipMemsetAsync: inside a replayed HIP graph a memset node was observed to run out of order with the

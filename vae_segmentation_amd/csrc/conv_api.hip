@@ -10,15 +10,20 @@ int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int
 
 // fp32 parity mode: the 3x3x3 convolutions run on the bf16 matrix cores through exact three-limb operand splitting (igemm_k3x.h); their packed
 // weights are VS_F32X3 images (pack.hip).  VS_F32_LIMBS=0 keeps the exact-f32 MFMA kernels (igemm_k3.h) and the plain fp32 images.
-extern "C" int vs_conv_k3_f32_limbs(void) {
+extern "C" int vs_conv_k3_f32_limbs(int d, int h, int w, int c_in) {
     static const int on = getenv("VS_F32_LIMBS") ? atoi(getenv("VS_F32_LIMBS")) : 1;
-    return on ? 1 : 0;
+    if (!on) return 0;
+    // volumes up to 6^3 with C a multiple of 32 stay on k3s_kernel<float> (igemm_k3s.h: the whole padded sample in LDS, the waves split the taps): a
+    // 4x4x16 tile is mostly padding there and the limb kernel would walk C / 16 chunk stages per workgroup (3^3 x 256: 92 us against 26)
+    static const int small = getenv("VS_K3_SMALL") ? atoi(getenv("VS_K3_SMALL")) : 1;
+    if (small && c_in % 32 == 0 && c_in <= 1024 && (long long)(d + 2) * (h + 2) * (w + 2) <= 512) return 0;
+    return 1;
 }
 
 static int dispatch_k3(const G1Params& p, int dtype, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s) {
-    if (dtype == VS_F32 && vs_conv_k3_f32_limbs()) {
+    if (dtype == VS_F32 && vs_conv_k3_f32_limbs(p.D, p.H, p.W, p.C)) {
         G1Params q = p;
-        const int ckx = p.C < 16 ? p.C : 16;
+        const int ckx = vs_k3x_ck(p.C);
         q.nch = p.C / ckx;
         const int rows16 = epi == EPI_SOFTMAX2 ? 16 : p.rb_total * 16;
         // 32-row workgroups (B fragments shared by two row blocks) when that still fills the chip; chunks of 16 channels with a 32-row weight block

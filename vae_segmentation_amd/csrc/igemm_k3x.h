@@ -35,30 +35,12 @@ struct K3XGeom {
     static constexpr int W_BYTES = NWI * 256 * 16;
 };
 
-// three-way split of four fp32 values into bf16 limbs, packed two per dword: out[l][0] = (v0, v1), out[l][1] = (v2, v3) of limb l.
-// Round-to-nearest limbs (v_cvt_pk_bf16_f32), not truncation: x0 = rne(x), x1 = rne(x - x0), x2 = rne(x - x0 - x1); the subtractions are exact and
-// x0 + x1 + x2 = x up to 2^-25 |x|.  With truncated limbs every limb has the sign of x, so the dropped products x1*w2 + x2*w1 + x2*w2 all have the
-// sign of x*w: a 3e-8 relative BIAS that adds up coherently in the per-channel sums of a whole volume (seen: 8.6e-5 on the 96^3 statistics check);
-// rounded limbs make the dropped terms zero-mean.
-__device__ __forceinline__ void k3x_split4(const float (&v)[4], unsigned int (&out)[3][2]) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const f32x2 x = f32x2{v[2 * q], v[2 * q + 1]};
-        const unsigned int p0 = H16<unsigned short>::pack2(x);
-        const f32x2 r1 = x - f32x2{H16<unsigned short>::lo(p0), H16<unsigned short>::hi(p0)};
-        const unsigned int p1 = H16<unsigned short>::pack2(r1);
-        const f32x2 r2 = r1 - f32x2{H16<unsigned short>::lo(p1), H16<unsigned short>::hi(p1)};
-        out[0][q] = p0; out[1][q] = p1; out[2][q] = H16<unsigned short>::pack2(r2);
-    }
-}
-
 // SUMS: backward-data use (fused IN-backward sums of the output against the mask tensor); HS: the input is a lazy activation; MULTI: more than one
 // channel chunk (the weight block is re-staged per chunk) — all compile-time, like every condition on the staging path (igemm_k3b.h)
 template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 ? 2 : 1))) void k3x_kernel(const G1Params p) {
     using GEO = K3XGeom<CK, MT>;
     static_assert(CK == 8 || CK == 16, "chunk width");
-    static_assert(!(CK == 8 && MULTI), "8-channel layers are a single chunk");
     constexpr int TV = GEO::TV, PLANE = 6 * 18, U = GEO::U, NIT = GEO::NIT, CKB2 = GEO::CKB2, RB = GEO::RB, NKGC = GEO::NKGC;
     constexpr int NU = TV * U, NWF = GEO::NWF, NWI = GEO::NWI, PB = GEO::PLANE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -153,7 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
                 }
             }
             unsigned int lm[3][2];
-            k3x_split4(v, lm);
+            vs_limb_split4(v, lm);
 #pragma unroll
             for (int l = 0; l < 3; ++l) *(u32x2*)(s_tile + l * PB + lds_w0 + b * 2048) = u32x2{lm[l][0], lm[l][1]};
         }

@@ -10,9 +10,13 @@ int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int
         return k3x_launch<8, 16, EPI_SOFTMAX2, false>(p, tiles, row_tiles, s);
     }
     if (ck == 8) {
-        if (p.nch != 1) return VS_ESHAPE;
-        if (mt == 16) return k3x_launch<8, 16, EPI_RAW, false>(p, tiles, row_tiles, s);
-        if (mt == 32) return k3x_launch<8, 32, EPI_RAW, false>(p, tiles, row_tiles, s);
+        if (p.nch == 1) {
+            if (mt == 16) return k3x_launch<8, 16, EPI_RAW, false>(p, tiles, row_tiles, s);
+            if (mt == 32) return k3x_launch<8, 32, EPI_RAW, false>(p, tiles, row_tiles, s);
+        } else {                                          // VS_K3X_CK=8: 8-channel chunks for every layer (two workgroups per CU)
+            if (mt == 16) return k3x_launch<8, 16, EPI_RAW, true>(p, tiles, row_tiles, s);
+            if (mt == 32) return k3x_launch<8, 32, EPI_RAW, true>(p, tiles, row_tiles, s);
+        }
         return VS_ESHAPE;
     }
     if (ck == 16) {

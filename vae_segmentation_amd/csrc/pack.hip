@@ -75,10 +75,9 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ src, T* __res
 //   row = rb*16 + (lane & 15);  k within the chunk = kg*32 + (lane >> 4)*8 + j;  tap = k / CK, c = ch*CK + k % CK
 // limb 0 = w rounded to bf16, limb 1 = w - limb0 rounded to bf16, limb 2 = the rest (8 + 8 + 8 significant bits).  One thread per 16-byte fragment.
 __device__ __forceinline__ void pack_one_limbs(const float* __restrict__ src, unsigned short* __restrict__ dst, int d0, int d1, int ntaps,
-                                               int c_pad, int form, long long total, long long frag) {
+                                               int c_pad, int form, long long total, long long frag, int CK) {
     const long long i = frag * 8;
     if (i >= total) return;
-    const int CK = c_pad < 16 ? c_pad : 16;
     const int nch = c_pad / CK;
     const int nkg = (ntaps * CK + 31) / 32;
     long long r = frag;
@@ -110,8 +109,8 @@ __device__ __forceinline__ void pack_one_limbs(const float* __restrict__ src, un
     *(u32x4*)(dst + i) = pk;
 }
 __global__ void pack_weight_limbs_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int d0, int d1, int ntaps, int c_pad, int form,
-                                         long long total) {
-    pack_one_limbs(src, dst, d0, d1, ntaps, c_pad, form, total, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+                                         long long total, int ck) {
+    pack_one_limbs(src, dst, d0, d1, ntaps, c_pad, form, total, (long long)blockIdx.x * blockDim.x + threadIdx.x, ck);
 }
 
 template <typename T>
@@ -121,7 +120,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict_
 }
 
 // descs[].first_block counts 256-thread blocks of FRAGMENTS (vs_pack_desc::total / EPL of them per image)
-__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const vs_pack_desc* __restrict__ descs, int n_desc, int total_blocks) {
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const vs_pack_desc* __restrict__ descs, int n_desc, int total_blocks, int k3x_ck) {
     // XCD-aware block order: a fragment gathers 8 floats that lie 27 taps (108 bytes) apart, so the 27 k-groups of one (row block,
     // channel chunk) — seven consecutive blocks — read the same cache lines.  Consecutive hardware block ids go to different XCDs
     // (8, each with its own L2), which made every XCD fetch those lines for itself: 103 MB of HBM traffic for 9 MB of weights.
@@ -137,7 +136,7 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const vs_pack_de
     }
     const vs_pack_desc d = descs[lo];
     const long long i = (long long)(lb - d.first_block) * 256 + threadIdx.x;
-    if (d.dtype == VS_F32X3) pack_one_limbs(d.src, (unsigned short*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
+    if (d.dtype == VS_F32X3) pack_one_limbs(d.src, (unsigned short*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i, d.c_pad < k3x_ck ? d.c_pad : k3x_ck);
     else if (d.dtype == VS_F32) pack_one<float>(d.src, (float*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
     else if (d.dtype == VS_BF16) pack_one<unsigned short>(d.src, (unsigned short*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
     else pack_one<vs_half>(d.src, (vs_half*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
@@ -145,14 +144,14 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const vs_pack_de
 
 extern "C" int vs_pack_weight_multi(const vs_pack_desc* descs, int n_desc, int total_blocks, void* stream) {
     if (!descs || n_desc <= 0 || total_blocks <= 0) return VS_EINVAL;
-    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(8 * ((total_blocks + 7) / 8)), dim3(256), 0, (hipStream_t)stream, descs, n_desc, total_blocks);
+    hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(8 * ((total_blocks + 7) / 8)), dim3(256), 0, (hipStream_t)stream, descs, n_desc, total_blocks, vs_k3x_ck(16));
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
 
 static long long packed_elems(int rows, int c_pad, int gemm_taps, int dtype) {
     if (dtype == VS_F32X3) {                             // bf16 elements of the three-limb image (3x3x3 weights only)
-        const int CK = c_pad < 16 ? c_pad : 16;
+        const int CK = vs_k3x_ck(c_pad);
         return (long long)((rows + 15) / 16) * (c_pad / CK) * ((gemm_taps * CK + 31) / 32) * 3 * 64 * 8;
     }
     if (vs_k3_toeplitz(rows, c_pad, gemm_taps, dtype)) return 9 * 64 * 8;
@@ -185,7 +184,8 @@ extern "C" int vs_pack_weight(const float* src, void* dst, int d0, int d1, int n
     const long long total = packed_elems(rows, c_pad, gemm_taps, dtype);
     const int blocks = vs_ceil_div(total / (dtype == VS_F32 ? 4 : 8), 256);      // one thread per 16-byte fragment
     if (dtype == VS_F32X3) {
-        hipLaunchKernelGGL(pack_weight_limbs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, d0, d1, ntaps, c_pad, form, total);
+        hipLaunchKernelGGL(pack_weight_limbs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, d0, d1, ntaps, c_pad, form, total,
+                           vs_k3x_ck(c_pad));
         VS_CHECK_LAUNCH();
         return VS_OK;
     }

@@ -480,6 +480,176 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
 template <int CB, int KIND, typename T = unsigned short>
 __global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) { g3b_body<T, CB, KIND>(p, blockIdx.x, blockIdx.y); }
 
+// ---------------------------------------------------------------------------------------------------
+// fp32 parity mode, 3x3x3 layers: the same GEMM on the bf16 matrix cores through three-limb operand splitting (igemm_k3x.h explains the
+// arithmetic: x = x0 + x1 + x2 in bf16 limbs, six exact limb products per product, fp32 accumulation — 2.7x fewer matrix cycles than
+// g3_kernel's exact-f32 MFMAs).  Structure of g3b_body: P and Q tiles are fetched one tile ahead (bounds-checked buffer loads of fp32
+// fragments, 4 channels each), normalised in fp32, split, and written to LDS as three limb PLANES of the bf16 tile layout; the operands are
+// read with ds_read_b64_tr_b16 per plane.  Slab layout and reduction are g3b_kernel's.  (Stride-2 kinds keep g3_kernel: their three Q limb
+// planes of 8x8x32 voxels would not fit the LDS.)
+// ---------------------------------------------------------------------------------------------------
+#define G3X_LDS_P (4 * G3_MAXN * 16 * 4)
+#define G3X_LDS_Q (G3X_LDS_P + 3 * 256 * 16 * 2)
+
+template <int CB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 ? 2 : 1))) void g3x_kernel(const G3Params p) {
+    using GEO = G3Geo<CB, G3_K3>;
+    constexpr int NCB = GEO::NCB, QY = GEO::QY, QX = GEO::QX, QV = GEO::QV;
+    constexpr int QROW = CB * 2;                 // bytes per Q-tile voxel in one limb plane
+    constexpr int QU = CB / 4;                   // fp32 fragments (4 channels) per Q-tile voxel
+    constexpr int NQ = QV * QU;
+    constexpr int NITQ = (NQ + 255) / 256;
+    constexpr int PPB = 256 * 32, QPB = QV * QROW;      // bytes of one P / Q limb plane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_pm = (float*)(smem + G3_LDS_STATS);        // mean / rstd of P's and Q's 16 channels, per sample (the fp32 mode's (x - mean) * rstd)
+    float* s_pr = s_pm + G3_MAXN * 16;
+    float* s_qm = s_pr + G3_MAXN * 16;
+    float* s_qr = s_qm + G3_MAXN * 16;
+    char* s_p = smem + G3X_LDS_P;                // [3 limbs][256 voxels][16 ch] bf16
+    char* s_q = smem + G3X_LDS_Q;                // [3 limbs][QV voxels][CB ch] bf16
+
+    const int bx = blockIdx.x, ks = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
+    const int q4 = col >> 2, p4 = col & 3;
+    const int mb = bx / p.cbn, cb = bx - mb * p.cbn;
+    const bool p_stats = p.P_stats != nullptr, q_stats = p.Q_stats != nullptr;
+    const i32x4 prsrc = make_rsrc(p.P, (unsigned int)((long long)p.N * p.Dp * p.Hp * p.Wp * p.Mch * 4));
+    const i32x4 qrsrc = make_rsrc(p.Q, (unsigned int)((long long)p.N * p.Dq * p.Hq * p.Wq * p.Cch * 4));
+
+    // P fragment b: voxel (tid + 256 b) >> 2 of the 4x4x16 tile, channels 4 * ppart ..; Q fragment b: voxel u / QU of the halo region, channels 4 * qpart ..
+    const int ppart = tid & 3, qpart = tid % QU;
+    const bool pch_ok = mb * 16 + ppart * 4 < p.Mch, qch_ok = cb * CB + qpart * 4 < p.Cch;
+    int prel[4], pzyx[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int v = (tid + b * 256) >> 2;
+        const int lx = v & 15, ly = (v >> 4) & 3, lz = v >> 6;
+        prel[b] = (((lz * p.Hp + ly) * p.Wp + lx) * p.Mch + mb * 16 + ppart * 4) * 4;
+        pzyx[b] = pch_ok ? (lz | (ly << 8) | (lx << 16)) : 0x00ffffff;
+    }
+    int qrel[NITQ], qzyx[NITQ];
+#pragma unroll
+    for (int b = 0; b < NITQ; ++b) {
+        const int u = tid + b * 256;
+        const int v = u / QU;
+        const int lx = v % QX, ly = (v / QX) % QY, lz = v / (QX * QY);
+        qrel[b] = (((lz * p.Hq + ly) * p.Wq + lx) * p.Cch + cb * CB + qpart * 4) * 4;
+        qzyx[b] = (u < NQ && qch_ok) ? (lz | (ly << 8) | (lx << 16)) : 0x00ffffff;
+    }
+    u32x4 pv[4], qv[NITQ];
+    unsigned int okbits = 0;                     // bit b: P fragment b inside the volume; bit 4 + b: Q fragment b
+    auto request = [&](int t) {
+        const int n = t / p.tiles_per_sample;
+        const int tl = t - n * p.tiles_per_sample;
+        const int tx = tl % p.txn, ty = (tl / p.txn) % p.tyn, tz = tl / (p.txn * p.tyn);
+        const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+        okbits = 0;
+        const int pbase = (((n * p.Dp + z0) * p.Hp + y0) * p.Wp + x0) * p.Mch * 4;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gz = z0 + (pzyx[b] & 0xff), gy = y0 + ((pzyx[b] >> 8) & 0xff), gx = x0 + (pzyx[b] >> 16);
+            const bool ok = gz < p.Dp && gy < p.Hp && gx < p.Wp;
+            okbits |= ok ? (1u << b) : 0u;
+            pv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(prsrc, ok ? pbase + prel[b] : -1, 0, 0));
+        }
+        const int qz0 = z0 - 1, qy0 = y0 - 1, qx0 = x0 - 1;
+        const int qbase = (((n * p.Dq + qz0) * p.Hq + qy0) * p.Wq + qx0) * p.Cch * 4;
+#pragma unroll
+        for (int b = 0; b < NITQ; ++b) {
+            const int gz = qz0 + (qzyx[b] & 0xff), gy = qy0 + ((qzyx[b] >> 8) & 0xff), gx = qx0 + (qzyx[b] >> 16);
+            const bool ok = (unsigned)gz < (unsigned)p.Dq && (unsigned)gy < (unsigned)p.Hq && (unsigned)gx < (unsigned)p.Wq;
+            okbits |= ok ? (16u << b) : 0u;
+            qv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(qrsrc, ok ? qbase + qrel[b] : -1, 0, 0));
+        }
+    };
+    auto put = [&](const u32x4 raw, bool lazy, bool ok, const float* s_m, const float* s_r, char* plane0, int plane_bytes) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(raw[j]);
+        if (lazy) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = (v[j] - s_m[j]) * s_r[j];
+                v[j] = ok ? fmaxf(t, 0.f) : 0.f;          // zero padding applies to the normalised activation
+            }
+        }
+        unsigned int lm[3][2];
+        vs_limb_split4(v, lm);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) *(u32x2*)(plane0 + l * plane_bytes) = u32x2{lm[l][0], lm[l][1]};
+    };
+    auto commit = [&](int n) {                   // registers -> normalised limb planes
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            put(pv[b], p_stats, (okbits >> b) & 1u, s_pm + n * 16 + ppart * 4, s_pr + n * 16 + ppart * 4, s_p + ((tid + b * 256) >> 2) * 32 + ppart * 8, PPB);
+#pragma unroll
+        for (int b = 0; b < NITQ; ++b) {
+            const int u = tid + b * 256;
+            if (b < NITQ - 1 || u < NQ)
+                put(qv[b], q_stats, (okbits >> (4 + b)) & 1u, s_qm + n * 16 + qpart * 4, s_qr + n * 16 + qpart * 4, s_q + (u / QU) * QROW + qpart * 8, QPB);
+        }
+    };
+
+    int t = ks;                                  // ksplit never exceeds the tile count
+    request(t);
+    for (int i = tid; i < p.N * 16; i += 256) {
+        const int n = i >> 4, c = i & 15;
+        float m = 0.f, r = 1.f;
+        const int pc = mb * 16 + c;
+        if (p_stats && pc < p.Mch) stats_to_mean_rstd(p.P_stats, (size_t)n * p.Mch + pc, (size_t)p.N * p.Mch, p.inv_cnt_p, p.eps, m, r);
+        s_pm[i] = m; s_pr[i] = r;
+        m = 0.f; r = 1.f;
+        const int qc = cb * CB + c;
+        if (q_stats && c < CB && qc < p.Cch) stats_to_mean_rstd(p.Q_stats, (size_t)n * p.Cch + qc, (size_t)p.N * p.Cch, p.inv_cnt_q, p.eps, m, r);
+        s_qm[i] = m; s_qr[i] = r;
+    }
+    // per-lane byte offsets into a Q limb plane of this lane's tr-read row for each column block (tap part only)
+    int qoff[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) {
+        int tap = CB == 16 ? k : 2 * k + (p4 >> 1);
+        if (tap >= 27) tap = 13;
+        const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
+        qoff[k] = ((dz * QY + dy) * QX + dx) * QROW + (CB == 16 ? p4 * 8 : (p4 & 1) * 8);
+    }
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (; t < p.total_tiles; t += p.ksplit) {
+        __syncthreads();                         // tables visible / every wave is done reading the previous tile
+        commit(t / p.tiles_per_sample);
+        __syncthreads();
+        if (t + p.ksplit < p.total_tiles) request(t + p.ksplit);
+        // two K-steps of 32 voxels: y rows (2s, 2s+1) of this wave's z-slice; per column block three B limbs against three A limbs, six MFMAs
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int xr = 4 * g + q4;                                   // this lane's tr-read row: voxel x
+            const int pa0 = (((wave * 4 + 2 * s) * 16 + xr) * 32) + p4 * 8;
+            u32x4 a[3];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) a[l] = tr_pair(s_p + l * PPB, pa0, pa0 + 16 * 32);
+            const int qb0 = ((wave * QY + 2 * s) * QX + xr) * QROW;
+            const int qb1 = qb0 + QX * QROW;
+#pragma unroll
+            for (int k = 0; k < NCB; ++k) {
+                u32x4 b[3];
+#pragma unroll
+                for (int l = 0; l < 3; ++l) b[l] = tr_pair(s_q + l * QPB, qb0 + qoff[k], qb1 + qoff[k]);
+                // limb pairs (P limb i, Q limb j), smallest products first
+                acc[k] = mfma16(a[2], b[0], acc[k], (unsigned short*)nullptr);
+                acc[k] = mfma16(a[1], b[1], acc[k], (unsigned short*)nullptr);
+                acc[k] = mfma16(a[0], b[2], acc[k], (unsigned short*)nullptr);
+                acc[k] = mfma16(a[1], b[0], acc[k], (unsigned short*)nullptr);
+                acc[k] = mfma16(a[0], b[1], acc[k], (unsigned short*)nullptr);
+                acc[k] = mfma16(a[0], b[0], acc[k], (unsigned short*)nullptr);
+            }
+        }
+    }
+    const size_t slab_elems = (size_t)p.mbn * p.cbn * NCB * 256;
+    g3_finish<NCB>(acc, (float*)s_p, p.ws + (size_t)ks * slab_elems + ((size_t)bx * NCB) * 256, wave, col, g);
+}
+
 // Grouped launch: the weight gradients of up to G3_GROUP_MAX layers of one (CB, KIND) instantiation in ONE grid.  Weight
 // gradients are leaves of backward, so the host defers them to the end of the pass and issues them together: the small
 // layers (tens of workgroups each, start-up bound) then share the chip instead of queueing behind one another.
@@ -574,7 +744,7 @@ static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind,
     long long want = (wg_target + (long long)mbn * cbn - 1) / ((long long)mbn * cbn);
     // fp32 (parity) mode: a bounded number of tiles per workgroup, so that an fp32 MFMA accumulator chains a bounded number of products (64 per
     // tile and wave) before the fp64 slab reduction: VS_WGRAD_F32_TILES tiles (see the default's comment)
-    static const long long f32_tiles = getenv("VS_WGRAD_F32_TILES") ? atoll(getenv("VS_WGRAD_F32_TILES")) : 2;
+    static const long long f32_tiles = getenv("VS_WGRAD_F32_TILES") ? atoll(getenv("VS_WGRAD_F32_TILES")) : 8;      // 8 x 64 voxels x 32-wide MFMAs: 512-product chains per accumulator and limb pair
     if (short_chains && (total + f32_tiles - 1) / f32_tiles > want) want = (total + f32_tiles - 1) / f32_tiles;
     if (want < 1) want = 1;
     if (want > total) want = total;
@@ -632,6 +802,18 @@ static int g3_run(const G3Params& p, float* dw, int m_real, int c_real, hipStrea
     return reduce_slabs > 0 ? g3_reduce_launch<CB, KIND>(reduce_ws, dw, m_real, c_real, p.mbn, p.cbn, reduce_slabs, s) : VS_OK;
 }
 
+template <int CB>
+static int g3x_run(const G3Params& p, float* dw, int m_real, int c_real, hipStream_t s, const float* reduce_ws, int reduce_slabs) {
+    using GEO = G3Geo<CB, G3_K3>;
+    constexpr size_t lds = G3X_LDS_Q + (size_t)3 * GEO::QV * CB * 2;
+    auto kern = g3x_kernel<CB>;
+    static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr_err != hipSuccess) return (int)attr_err;
+    hipLaunchKernelGGL(kern, dim3(p.mbn * p.cbn, p.ksplit), dim3(256), lds, s, p);
+    VS_CHECK_LAUNCH();
+    return reduce_slabs > 0 ? g3_reduce_launch<CB, G3_K3>(reduce_ws, dw, m_real, c_real, p.mbn, p.cbn, reduce_slabs, s) : VS_OK;
+}
+
 // One layer's kernel into `workspace`.  prior_slabs >= 0: reduce (prior_slabs + this layer's) slabs starting prior_slabs slabs BEFORE
 // `workspace` into dw; prior_slabs < 0: no reduction (an earlier part of a multi-use weight).  *slabs_out = this layer's slab count.
 static int wgrad_single(const void* P, const double* p_stats, const void* Q, const double* q_stats, float* dw,
@@ -676,7 +858,12 @@ static int wgrad_single(const void* P, const double* p_stats, const void* Q, con
     return cbsz == 16 ? g3_run<T, 16, G3_K2S2>(p, dw, m_real, c_real, st, rws, rsl) : g3_run<T, 8, G3_K2S2>(p, dw, m_real, c_real, st, rws, rsl);
     // both kernels address P and Q with signed 32-bit byte offsets (bounds-checked buffer loads)
     if (dtype == VS_F32 && ((long long)n * dp * hp * wp * m_ch * 4 >= 2147483648ll || (long long)n * p.Dq * p.Hq * p.Wq * c_ch * 4 >= 2147483648ll)) return VS_ESHAPE;
-    if (dtype == VS_F32) { G3_GO(float) }
+    if (dtype == VS_F32) {
+        // 3x3x3 layers: limb arithmetic on the bf16 matrix cores (g3x_kernel); VS_F32_LIMBS=0 and the stride-2 kinds: exact-f32 MFMA (g3_kernel)
+        static const int limbs = getenv("VS_F32_LIMBS") ? atoi(getenv("VS_F32_LIMBS")) : 1;
+        if (limbs && kind == VS_CONV_K3) return cbsz == 16 ? g3x_run<16>(p, dw, m_real, c_real, st, rws, rsl) : g3x_run<8>(p, dw, m_real, c_real, st, rws, rsl);
+        G3_GO(float)
+    }
 #undef G3_GO
     // g3b_kernel addresses P and Q with signed 32-bit byte offsets
     if ((long long)n * dp * hp * wp * m_ch * 2 >= 2147483648ll || (long long)n * p.Dq * p.Hq * p.Wq * c_ch * 2 >= 2147483648ll) return VS_ESHAPE;

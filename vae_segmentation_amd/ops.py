@@ -27,13 +27,15 @@ VS_F32X3 = 3
 F32X3 = "f32x3"
 _DT_TORCH[VS_F32X3] = F32X3
 _DT_VS[F32X3] = VS_F32X3
-_F32_LIMBS = bool(lib.vs_conv_k3_f32_limbs())
+_F32_LIMBS = bool(lib.vs_conv_k3_f32_limbs(96, 96, 96, 8))
 
 
-def k3_pack_dtype(dtype):
-    """the image format of a 3x3x3 weight for activations of `dtype`: the limb image in the fp32 parity mode (when the library runs it on the
-    bf16 matrix cores), the storage type itself otherwise"""
-    return F32X3 if (dtype == torch.float32 and _F32_LIMBS) else dtype
+def k3_pack_dtype(x):
+    """the image format of a 3x3x3 weight applied to the channels-last tensor x: the limb image in the fp32 parity mode where the library runs
+    that launch on the bf16 matrix cores (vs_conv_k3_f32_limbs: not the volumes up to 6^3 of the deep levels), the storage type itself otherwise"""
+    if x.dtype == torch.float32 and lib.vs_conv_k3_f32_limbs(x.shape[1], x.shape[2], x.shape[3], x.shape[4]):
+        return F32X3
+    return x.dtype
 
 
 def vs_of(dtype):
@@ -1038,7 +1040,7 @@ class ConvK3(torch.autograd.Function):
     def forward(ctx, x, xs, weight, bias, live_bias=False):
         _require_cuda(x, weight)
         cout, cin = weight.shape[0], weight.shape[1]
-        wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, x.shape[-1], k3_pack_dtype(x.dtype))
+        wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, x.shape[-1], k3_pack_dtype(x))
         # live_bias: the general norm path (NormAct) — under BatchNorm in eval mode the bias is not cancelled by the normalisation
         ctx.live_bias = bool(live_bias) and bias is not None
         y, ys = conv_gather(x, xs, wp, bias if ctx.live_bias else None, cpad(cout), VS_CONV_K3, True, real_channels=(cin, cout))
@@ -1062,7 +1064,7 @@ class ConvK3(torch.autograd.Function):
         if lazy is not None and not (ctx.needs_input_grad[0] and _fa_supported(gy, x, xs is not None)):
             gy, lazy = apply_lazy(gy, lazy), None     # no fused-apply kernel for this launch / no input gradient wanted: apply now
         if ctx.needs_input_grad[0]:
-            wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, gy.shape[-1], k3_pack_dtype(gy.dtype))
+            wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, gy.shape[-1], k3_pack_dtype(gy))
             if lazy is not None and xs is not None:
                 gx, gy = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K3, real_channels=(cout, cin), defer=ctx.defer, lazy=lazy,
                                             want_dx=ctx.needs_input_grad[2])
@@ -1100,7 +1102,7 @@ class ConvK3Softmax(torch.autograd.Function):
         if weight.shape[0] != 2:
             raise NotImplementedError("fused out_block+softmax kernel is written for n_class == 2")
         n, d, h, w, c = x.shape
-        wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, c, k3_pack_dtype(x.dtype))
+        wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, c, k3_pack_dtype(x))
         prob = torch.empty((n, 2, d, h, w), dtype=torch.float32, device=x.device)
         check(lib.vs_conv_k3_softmax2_dropout_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), prob.data_ptr(), n, d, h, w, c,
                                                   vs_dtype(x), EPS_IN, float(drop_p), drop_seed, _stream()), "conv_k3_softmax2_fwd")
@@ -1121,7 +1123,7 @@ class ConvK3Softmax(torch.autograd.Function):
                                           ctx.drop[0], ctx.drop[1], _stream()), "softmax2_bwd")
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, k3_pack_dtype(x.dtype))
+            wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, k3_pack_dtype(x))
             if xs is not None:
                 gx = conv_bwd_data_lazy(gl, wpb, x, xs, VS_CONV_K3, real_channels=(2, weight.shape[1]), defer=ctx.defer)
             else:
@@ -1146,7 +1148,7 @@ class ConvK3SoftmaxCL(torch.autograd.Function):
         if weight.shape[0] != 2 or x.dtype == torch.float32:
             raise NotImplementedError("fused out_block+softmax with a channels-last copy: n_class == 2, 16-bit storage")
         n, d, h, w, c = x.shape
-        wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, c, k3_pack_dtype(x.dtype))
+        wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, c, k3_pack_dtype(x))
         prob = torch.empty((n, 2, d, h, w), dtype=torch.float32, device=x.device)
         prob_cl = torch.empty((n, d, h, w, 8), dtype=x.dtype, device=x.device)
         check(lib.vs_conv_k3_softmax2_cl_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), prob.data_ptr(), prob_cl.data_ptr(), n, d, h, w, c,
@@ -1172,7 +1174,7 @@ class ConvK3SoftmaxCL(torch.autograd.Function):
                                      _stream()), "softmax2_cl_bwd")
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, k3_pack_dtype(x.dtype))
+            wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, k3_pack_dtype(x))
             if xs is not None:
                 gx = conv_bwd_data_lazy(gl, wpb, x, xs, VS_CONV_K3, real_channels=(2, weight.shape[1]), defer=ctx.defer)
             else:
