@@ -107,16 +107,13 @@ def scalar_close(gold, key, val, floor=1e-3, factor=3.0):
     return mine / max(abs(f64), 1e-30)
 
 
-# Floors of the END-TO-END comparisons against the fp64 yardstick at small sizes (32^3 .. 128^3 through 30-60 InstanceNorm/ReLU layers).  What those
-# comparisons measure is one draw of the network's rounding amplification (ReLU masks flip under a 1e-7 perturbation), not a kernel error:
+# Floor for END-TO-END gradient comparisons against the fp64 yardstick where three networks are chained (Embed at 128^3: ~90 InstanceNorm/ReLU layers).
+# What such a comparison measures is one draw of the network's rounding amplification (ReLU masks flip under a 1e-7 perturbation), not a kernel error:
 # tools/limb_accuracy.py (profiles/r04_fp32_limb_accuracy.txt) perturbs the weights of Segmentation at 32^3 by +-1 fp32 ulp and re-runs the SAME
-# kernels — the worst gradient tensor lands anywhere between 2e-4 and 5.1e-3 from the fp64 result, the median between 8e-5 and 2e-3, for the exact-f32
-# MFMA kernels and for the limb kernels (csrc/igemm_k3x.h) alike.  Round 3's floor (2e-3) sat inside that spread and held only for the particular draw
-# of the kernels it was calibrated on.  The kernels themselves are pinned where the comparison is exact: per op (tests/test_gpu_ops.py,
-# tests/test_gpu_layers.py: 2e-5 against CPU autograd, measured 3e-7) and per single forward / backward step recomputed in fp64 from the kernels' own
-# inputs (tests/test_gpu_backward_steps.py: asserted 5e-6, measured 9e-7).
+# kernels — the worst gradient tensor lands anywhere between 2e-4 and 5e-3 from the fp64 result.  The kernels themselves are pinned where the
+# comparison is exact: per op (tests/test_gpu_ops.py, tests/test_gpu_layers.py: 2e-5 against CPU autograd, measured 1e-7 .. 7e-7) and per single
+# forward / backward step recomputed in fp64 from the kernels' own inputs (tests/test_gpu_backward_steps.py: asserted 5e-6, measured 9e-7).
 DRAW_FLOOR_GRAD = 8e-3
-DRAW_FLOOR_FWD = 4e-3
 
 
 def check_tensor_f64(gold, prefix, t, k=64, floor=1e-3, factor=3.0, what=""):

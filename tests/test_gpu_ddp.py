@@ -5,7 +5,7 @@
     kernels) — must reproduce the plain single-process step;
   * two ranks (gloo, sharing the one GPU of the box): the average of the per-rank micro-batch gradients must equal the gradient of
     the GLOBAL batch — checked against the same network on the global batch in one process, and against the CPU oracle run in fp64
-    on the global batch (the fp64 yardstick of tests/golden_util.py, floor 8e-3: DRAW_FLOOR_GRAD) — and replicas must stay bit-identical over steps;
+    on the global batch (the fp64 yardstick of tests/golden_util.py, floor 2e-3) — and replicas must stay bit-identical over steps;
   * `python bench.py --gpus 2` launched WITHOUT torchrun spawns its own ranks and prints one JSON line.
 """
 import json
@@ -89,7 +89,7 @@ if rank == 0:
             worst = max(worst, float((a - g).norm() / g.norm()))
     print("rank 0: averaged micro-batch gradients vs single-process global batch: worst rel l2 %%.2e" %% worst)
     assert worst < (1e-4 if world > 1 else 1e-5), worst
-    # (b) the CPU oracle on the global batch, in fp64 and in fp32: the HIP average must be as close to fp64 as fp32 eager is (x8), floor 8e-3
+    # (b) the CPU oracle on the global batch, in fp64 and in fp32: the HIP average must be as close to fp64 as fp32 eager is (x8), floor 2e-3
     res = {}
     for dt in (torch.float64, torch.float32):
         o = O.deterministic_fill_(O.Segmentation(1, 2, norm_type=1), seed=0).to(dt)
@@ -103,7 +103,7 @@ if rank == 0:
             continue
         mine = float((a.double() - g64).norm() / g64.norm())
         theirs = float((g32 - g64).norm() / g64.norm())
-        lim = max(8e-3, 8 * theirs)          # tests/golden_util.py DRAW_FLOOR_GRAD: at 32^3 the distance to fp64 is a draw of the rounding amplification (2e-4 .. 5e-3)
+        lim = max(2e-3, 8 * theirs)
         n_checked += 1
         if lim > 1e-2: over.append(name)
         assert mine <= lim, (name, mine, lim, theirs)

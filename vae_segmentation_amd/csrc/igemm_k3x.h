@@ -203,11 +203,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
         // byte offset of output voxel (n, oz, y0 + cg, x0 + col), row 4g of row block rb: ebase + cg * W*M*4 + rb * 64; -1 = dropped
         const int ebase = ((((n * p.D + oz) * p.H + y0) * p.W + x0 + col) * p.M + rb0 * 16 + 4 * g) * 4;
         const bool zx_ok = oz < p.D && x0 + col < p.W;
-        f32x4 acc[RB][4];
+        // two accumulators per output tile: the leading products x0*w0 in `acc`, the five products of weight <= 2^-8 in `acl`, added once in the
+        // epilogue.  In one accumulator the big running sum was rounded by all six MFMAs of every k-group; measured on the layer tests (max error of y
+        // against CPU fp32 autograd): 1.2e-6 with one accumulator, the exact-f32 kernels' 4e-7 with two
+        f32x4 acc[RB][4], acl[RB][4];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int cg = 0; cg < 4; ++cg) { acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         u32x4 mk[RB][4];                                 // mask tensor values under this tile's outputs (fused IN-bwd sums)
 
         for (int ch = 0; ch < p.nch; ++ch) {
@@ -256,17 +259,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
                 // limb pairs (activation limb i, weight limb j), smallest products first; four independent accumulators between dependent MFMAs
                 constexpr int PI[6] = {2, 1, 0, 1, 0, 0}, PJ[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                for (int q = 0; q < 5; ++q)
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                         for (int cg = 0; cg < 4; ++cg)
-                            acc[rb][cg] = mfma16(fa[kg & 1][rb][PJ[q]], fb[kg & 1][cg][PI[q]], acc[rb][cg], (unsigned short*)nullptr);
+                            acl[rb][cg] = mfma16(fa[kg & 1][rb][PJ[q]], fb[kg & 1][cg][PI[q]], acl[rb][cg], (unsigned short*)nullptr);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg)
+                        acc[rb][cg] = mfma16(fa[kg & 1][rb][0], fb[kg & 1][cg][0], acc[rb][cg], (unsigned short*)nullptr);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 
         // ---- epilogue of this tile ----
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] += acl[rb][cg];
         if constexpr (EPI == EPI_SOFTMAX2) {
             if (g == 0) {
                 const float b0 = bv[0][0], b1 = bv[0][1];

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void g3b_kernel(const G3Params p) { g3b_body<T
 #define G3X_LDS_Q (G3X_LDS_P + 3 * 256 * 16 * 2)
 
 template <int CB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 ? 2 : 1))) void g3x_kernel(const G3Params p) {
+__device__ __forceinline__ void g3x_body(const G3Params& p, const int bx, const int ks) {
     using GEO = G3Geo<CB, G3_K3>;
     constexpr int NCB = GEO::NCB, QY = GEO::QY, QX = GEO::QX, QV = GEO::QV;
     constexpr int QROW = CB * 2;                 // bytes per Q-tile voxel in one limb plane
@@ -508,7 +508,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 
     char* s_p = smem + G3X_LDS_P;                // [3 limbs][256 voxels][16 ch] bf16
     char* s_q = smem + G3X_LDS_Q;                // [3 limbs][QV voxels][CB ch] bf16
 
-    const int bx = blockIdx.x, ks = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int q4 = col >> 2, p4 = col & 3;
     const int mb = bx / p.cbn, cb = bx - mb * p.cbn;
@@ -612,9 +611,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 
         const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3;
         qoff[k] = ((dz * QY + dy) * QX + dx) * QROW + (CB == 16 ? p4 * 8 : (p4 & 1) * 8);
     }
-    f32x4 acc[NCB];
+    f32x4 acc[NCB], acl[NCB];                    // leading products / the five small limb products (igemm_k3x.h: two accumulators)
 #pragma unroll
-    for (int k = 0; k < NCB; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < NCB; ++k) { acc[k] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     for (; t < p.total_tiles; t += p.ksplit) {
         __syncthreads();                         // tables visible / every wave is done reading the previous tile
@@ -637,18 +636,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 
 #pragma unroll
                 for (int l = 0; l < 3; ++l) b[l] = tr_pair(s_q + l * QPB, qb0 + qoff[k], qb1 + qoff[k]);
                 // limb pairs (P limb i, Q limb j), smallest products first
-                acc[k] = mfma16(a[2], b[0], acc[k], (unsigned short*)nullptr);
-                acc[k] = mfma16(a[1], b[1], acc[k], (unsigned short*)nullptr);
-                acc[k] = mfma16(a[0], b[2], acc[k], (unsigned short*)nullptr);
-                acc[k] = mfma16(a[1], b[0], acc[k], (unsigned short*)nullptr);
-                acc[k] = mfma16(a[0], b[1], acc[k], (unsigned short*)nullptr);
+                acl[k] = mfma16(a[2], b[0], acl[k], (unsigned short*)nullptr);
+                acl[k] = mfma16(a[1], b[1], acl[k], (unsigned short*)nullptr);
+                acl[k] = mfma16(a[0], b[2], acl[k], (unsigned short*)nullptr);
+                acl[k] = mfma16(a[1], b[0], acl[k], (unsigned short*)nullptr);
+                acl[k] = mfma16(a[0], b[1], acl[k], (unsigned short*)nullptr);
                 acc[k] = mfma16(a[0], b[0], acc[k], (unsigned short*)nullptr);
             }
         }
     }
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) acc[k] += acl[k];
     const size_t slab_elems = (size_t)p.mbn * p.cbn * NCB * 256;
     g3_finish<NCB>(acc, (float*)s_p, p.ws + (size_t)ks * slab_elems + ((size_t)bx * NCB) * 256, wave, col, g);
 }
+
+template <int CB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 ? 2 : 1))) void g3x_kernel(const G3Params p) { g3x_body<CB>(p, blockIdx.x, blockIdx.y); }
 
 // Grouped launch: the weight gradients of up to G3_GROUP_MAX layers of one (CB, KIND) instantiation in ONE grid.  Weight
 // gradients are leaves of backward, so the host defers them to the end of the pass and issues them together: the small
@@ -686,6 +690,19 @@ __global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
         ks = start + ((local - ((x - b0) & 7)) >> 3);
     }
     g3b_body<T, CB, KIND>(p, local - (local / pairs) * pairs, ks);
+}
+
+// the same grouping for the limb kernel of the fp32 parity mode (3x3x3 layers): one grid per channel-block width
+template <int CB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 ? 2 : 1))) void g3x_group_kernel(const G3Group grp) {
+    const int b = blockIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < G3_GROUP_MAX; ++i) l += (i < grp.n && b >= grp.wg_start[i]) ? 1 : 0;
+    const G3Params p = grp.p[l];
+    const int local = b - grp.wg_start[l];
+    const int pairs = p.mbn * p.cbn;
+    g3x_body<CB>(p, local - (local / pairs) * pairs, local / pairs);
 }
 
 // Sum the partial slabs (fixed order, fp64) into the reference's [m][c][tap] layout.  A block = 64 consecutive slab
@@ -1168,6 +1185,99 @@ static int g3b_group_run(const G3Group& grp, hipStream_t s) {
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
+
+
+// ---- fp32 parity mode: the 3x3x3 layers of a pass as grouped limb launches (g3x_group_kernel), one grid per channel-block width ----------
+static bool f32_limbs_on() {
+    static const int on = getenv("VS_F32_LIMBS") ? atoi(getenv("VS_F32_LIMBS")) : 1;
+    return on != 0;
+}
+// descriptors of the pass that take the limb path, bias requests stripped (the fp32 branch sums biases with vs_bias_grad_acc); cb: 16 / 8
+static std::vector<vs_wgrad_desc> f32_limb_subset(const vs_wgrad_desc* descs, int count, int cb) {
+    std::vector<vs_wgrad_desc> out;
+    if (!f32_limbs_on()) return out;
+    for (int i = 0; i < count; ++i) {
+        if (descs[i].kind != VS_CONV_K3 || (descs[i].c_ch >= 16 ? 16 : 8) != cb) continue;
+        vs_wgrad_desc d = descs[i];
+        d.bias_g = nullptr; d.db = nullptr; d.bias_rows = 0; d.bias_c_ch = 0; d.bias_c_real = 0;
+        out.push_back(d);
+    }
+    return out;
+}
+static inline int f32_limb_target(int cb) { return cb == 16 ? 256 : 512; }       // resident workgroups: one per CU (16-channel blocks: 90 KB of LDS), two (8)
+
+template <int CB>
+static int g3x_group_run(const G3Group& grp, hipStream_t s) {
+    using GEO = G3Geo<CB, G3_K3>;
+    constexpr size_t lds = G3X_LDS_Q + (size_t)3 * GEO::QV * CB * 2;
+    auto kern = g3x_group_kernel<CB>;
+    static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr_err != hipSuccess) return (int)attr_err;
+    hipLaunchKernelGGL(kern, dim3(grp.wg_start[grp.n]), dim3(256), lds, s, grp);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+static int f32_limb_group_launch(const std::vector<vs_wgrad_desc>& sub, int cb, float eps, char* ws, size_t ws_bytes, hipStream_t st) {
+    if (sub.empty()) return VS_OK;
+    MultiPlan plan;
+    int rc = multi_plan(sub.data(), (int)sub.size(), eps, plan, f32_limb_target(cb));
+    if (rc) return rc;
+    if (ws_bytes < plan.bytes) return VS_EWORKSPACE;
+    const int count = (int)sub.size();
+    for (int i = 0; i < count; ++i) {                    // fp32 operands: 4-byte elements under the 32-bit buffer offsets
+        const vs_wgrad_desc& d = sub[i];
+        if ((long long)d.n * d.dp * d.hp * d.wp * d.m_ch * 4 >= 2147483648ll || (long long)d.n * d.dp * d.hp * d.wp * d.c_ch * 4 >= 2147483648ll) return VS_ESHAPE;
+    }
+    std::vector<int> idx(count);
+    for (int i = 0; i < count; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return plan.layers[a].work > plan.layers[b].work; });
+    for (size_t at = 0; at < idx.size(); at += G3_GROUP_MAX) {
+        G3Group grp{};
+        grp.xcd = 0;
+        grp.n = (int)std::min<size_t>(G3_GROUP_MAX, idx.size() - at);
+        long long wg = 0;
+        for (int j = 0; j < grp.n; ++j) {
+            MultiLayer& L = plan.layers[idx[at + j]];
+            grp.p[j] = L.p;
+            grp.p[j].ws = (float*)(ws + L.ws_off);
+            grp.wg_start[j] = (int)wg;
+            wg += (long long)L.p.mbn * L.p.cbn * L.p.ksplit;
+        }
+        if (wg >= 2147483647ll) return VS_ESHAPE;
+        for (int j = grp.n; j <= G3_GROUP_MAX; ++j) grp.wg_start[j] = (int)wg;
+        rc = cb == 16 ? g3x_group_run<16>(grp, st) : g3x_group_run<8>(grp, st);
+        if (rc) return rc;
+    }
+    std::vector<G3RedDesc> red;
+    std::vector<int> blocks;
+    for (int i = 0; i < count; ++i) {
+        const MultiLayer& L = plan.layers[i];
+        if (L.primary != i) continue;
+        const long long slab_elems = (long long)L.p.mbn * L.p.cbn * L.ncb * 256;
+        int parts = 1;
+        while (parts < G3_RED_ROWS && parts * 8 < L.total_slabs) parts *= 2;
+        red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.total_slabs, L.cbsz, 27, L.ncb, 0, parts});
+        blocks.push_back(vs_ceil_div(slab_elems, 256 * (G3_RED_ROWS / parts)));
+    }
+    for (size_t at = 0; at < red.size(); at += G3_RED_MAX) {
+        G3RedGroup grp{};
+        grp.n = (int)std::min<size_t>(G3_RED_MAX, red.size() - at);
+        long long blk = 0;
+        for (int j = 0; j < grp.n; ++j) { grp.d[j] = red[at + j]; grp.blk_start[j] = (int)blk; blk += blocks[at + j]; }
+        if (blk >= 2147483647ll) return VS_ESHAPE;
+        for (int j = grp.n; j <= G3_RED_MAX; ++j) grp.blk_start[j] = (int)blk;
+        hipLaunchKernelGGL(g3_reduce_group_kernel, dim3((unsigned)blk), dim3(64 * G3_RED_ROWS), 0, st, grp);
+        VS_CHECK_LAUNCH();
+    }
+    return VS_OK;
+}
+static size_t f32_limb_group_bytes(const std::vector<vs_wgrad_desc>& sub, int cb) {
+    if (sub.empty()) return 0;
+    MultiPlan plan;
+    if (multi_plan(sub.data(), (int)sub.size(), 0.f, plan, f32_limb_target(cb))) return 0;
+    return (plan.bytes + 255) / 256 * 256;
+}
 }  // namespace
 
 extern "C" size_t vs_conv_wgrad_multi_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype) {
@@ -1181,8 +1291,11 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
 extern "C" size_t vs_conv_wgrad_multi_throttled_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype, int target_workgroups) {
     if (!descs || count <= 0 || target_workgroups < 0) return 0;
     if (dtype == VS_F32) {                        // serial per-layer launches share one region; the uses of one weight need theirs side by side
+        // the 3x3x3 layers of the limb path come first: two grouped regions (16- / 8-channel blocks); the serial region of the other layers follows
+        const size_t limb_bytes = f32_limb_group_bytes(f32_limb_subset(descs, count, 16), 16) + f32_limb_group_bytes(f32_limb_subset(descs, count, 8), 8);
         size_t mx = 0;
         for (int i = 0; i < count; ++i) {
+            if (f32_limbs_on() && descs[i].kind == VS_CONV_K3) continue;
             bool first = true;
             for (int j = 0; j < i; ++j) first = first && descs[j].dw != descs[i].dw;
             if (!first) continue;
@@ -1192,7 +1305,7 @@ extern "C" size_t vs_conv_wgrad_multi_throttled_workspace_bytes(const vs_wgrad_d
                     sum += vs_conv_wgrad_workspace_bytes(descs[j].n, descs[j].dp, descs[j].hp, descs[j].wp, descs[j].m_ch, descs[j].c_ch, descs[j].kind);
             mx = std::max(mx, sum);
         }
-        return mx;
+        return limb_bytes + mx;
     }
     MultiPlan plan;
     if (multi_plan(descs, count, 0.f, plan, target_workgroups)) return 0;
@@ -1206,12 +1319,27 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
     const bool f16 = dtype == VS_F16;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VS_F32) {
-        // parity mode is not launch-bound: the per-layer kernels, one after the other on the same stream
         for (int i = 0; i < count; ++i) {
             int rc = multi_validate(descs[i]);
             if (rc) return rc;
         }
+        // the 3x3x3 layers: grouped limb launches on the bf16 matrix cores (g3x_group_kernel) — with per-layer launches the 16 small layers of a
+        // step cost 30-47 us each (one tile per workgroup under fixed prologue / slab costs); the stride-2 kinds: per-layer exact-f32 kernels
+        {
+            char* wsp = (char*)workspace;
+            size_t left = workspace_bytes;
+            for (int cb = 16; cb >= 8; cb -= 8) {
+                const std::vector<vs_wgrad_desc> sub = f32_limb_subset(descs, count, cb);
+                const size_t need = f32_limb_group_bytes(sub, cb);
+                if (need > left) return VS_EWORKSPACE;
+                int rc = f32_limb_group_launch(sub, cb, eps, wsp, left, st);
+                if (rc) return rc;
+                wsp += need; left -= need;
+            }
+            workspace = wsp; workspace_bytes = left;
+        }
         for (int i = 0; i < count; ++i) {
+            if (f32_limbs_on() && descs[i].kind == VS_CONV_K3) continue;
             bool first = true;
             for (int j = 0; j < i; ++j) first = first && descs[j].dw != descs[i].dw;
             if (!first) continue;
