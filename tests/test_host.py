@@ -80,10 +80,14 @@ def test_grouped_weight_gradient_planning_without_gpu():
     arr = (ops.WgradDesc * len(layers))(*layers)
     grouped = lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(arr), len(layers), VS_BF16)
     single = [lib.vs_conv_wgrad_workspace_bytes(x.n, x.dp, x.hp, x.wp, x.m_ch, x.c_ch, x.kind) for x in layers]
-    # grouped: every layer owns a slab region (they run in one grid); fp32 mode: serial per-layer launches share the largest one
+    # grouped: every layer owns a slab region (they run in one grid); fp32 mode: the 3x3x3 layers likewise (grouped limb launches, csrc/wgrad.hip
+    # g3x_group_kernel), the stride-2 layers' serial per-layer launches share the largest of THEIR regions behind them
     assert grouped > 0 and grouped % 16 == 0
     assert grouped >= 128 * 128 * 27 * 4                       # at least one slab of the 128x128 layer
-    assert lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(arr), len(layers), VS_F32) == max(single)
+    f32 = lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(arr), len(layers), VS_F32)
+    k2 = (ops.WgradDesc * 2)(*layers[3:])
+    assert lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(k2), 2, VS_F32) == max(single[3:])           # stride-2 layers only: the serial rule
+    assert f32 >= max(single[3:]) + 128 * 128 * 27 * 4 and f32 % 16 == 0
     assert lib.vs_conv_wgrad_multi(ctypes.addressof(arr), len(layers), None, 0, VS_BF16, 1e-5, None) == -1      # no workspace
     assert lib.vs_conv_wgrad_multi(ctypes.addressof(arr), len(layers), fake, 16, VS_BF16, 1e-5, None) == -4      # VS_EWORKSPACE
     # a weight used several times in one pass: descriptors with the same destination are summed — their slabs lie side by side
