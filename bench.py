@@ -44,7 +44,10 @@ CONFIGS = {
                  "name": "configs[4], one GPU's share: %d^3 joint VAE+seg training step (joint_train), batch=%d/GPU"},
 }
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}
+# fp32: the parity mode runs its 3x3x3 convolutions and their weight gradients (96.7 % of the FLOPs) on the bf16 matrix cores, six exact limb
+# products per fp32 product (csrc/igemm_k3x.h): its matrix peak is the bf16 dense peak / 6 = 416.7 TFLOP/s of fp32-equivalent work
+# (the exact-f32 MFMA it replaces peaks at 157.3)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 2500.0 / 6.0}
 
 
 def parse():
@@ -398,7 +401,9 @@ def main():
         n32 = max(5, min(a.steps, 10))
         dt32, _ = timed_steps(step32, n32, 2, lambda: torch.cuda.synchronize())
         fp32_mode = {"ms_per_step": 1e3 * dt32 / n32, "value": a.batch * n32 / dt32, "unit": "volumes/s", "steps": n32,
-                     "note": "fp32 storage + exact-f32 MFMA: the mode that meets the 1e-3 parity gate (tests/test_gpu_model.py)"}
+                     "note": "fp32 storage; 3x3x3 convolutions and their weight gradients on the bf16 matrix cores through three-limb operand splitting (six exact "
+                             "limb products per product, fp32 accumulation: csrc/igemm_k3x.h) - the mode that meets the 1e-3 parity gate (tests/test_gpu_model.py); "
+                             "round 3 ran it on the exact-f32 MFMA at 9.83 ms"}
         del step32
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.side, a.cpu_steps, batch=a.batch, method=CONFIGS[a.config]["method"])

@@ -6,7 +6,7 @@ from . import ops
 
 LAST_LAUNCHES = []
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s achievable
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 157.3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "f32": 2500.0 / 6.0}      # f32: six bf16 limb products per fp32 product (csrc/igemm_k3x.h)
 
 
 LAST_EVENT_OVERHEAD_US = 0.0
