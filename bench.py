@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--master-port", type=int, default=29533)
     ap.add_argument("--recompute", action="store_true", help="activation recomputation in the Down / Up blocks (joint_model.set_recompute, DESIGN 4.4)")
     ap.add_argument("--no-exchange-forms", action="store_true", help="N > 1: skip the no-exchange / other-exchange-form timing legs")
+    ap.add_argument("--no-other-form", action="store_true", help="N > 1: time the no-exchange leg but not the other exchange form")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     a.dtype = a.dtype or cfg["dtype"]
@@ -367,16 +368,22 @@ def main():
         closer_n()
         del step_n
         torch.cuda.empty_cache()
-        other = not (os.environ.get("VS_DDP_OVERLAP", "0") == "1")
-        step_o, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, True, overlap=other, info=info1)
-        dt_o, _ = timed_steps(step_o, n_x, 3, fence)
-        dt_o = max_over_ranks(dt_o)
         exchange = {"steps": n_x, "no_exchange_ms_per_step": round(1e3 * dt_n / n_x, 4),
                     "exposed_exchange_ms_per_step": round(ms_per_step - 1e3 * dt_n / n_x, 4),
                     "default_form": {"buckets": info.get("buckets"), "tail_in_graph": info.get("tail_in_graph"), "ms_per_step": round(ms_per_step, 4)},
-                    "other_form": {"buckets": info1.get("buckets"), "overlap": other, "tail_in_graph": info1.get("tail_in_graph"),
-                                   "ms_per_step": round(1e3 * dt_o / n_x, 4)}}
-        step = step_o
+                    "other_form": None}
+        if rank == 0:       # the measured line so far, for the record, should the last leg never return (nothing parses stderr)
+            print("bench.py: default exchange form %.4f ms per step, without exchange %.4f; timing the other form now"
+                  % (ms_per_step, 1e3 * dt_n / n_x), file=sys.stderr, flush=True)
+        other = not (os.environ.get("VS_DDP_OVERLAP", "0") == "1")
+        if a.no_other_form:
+            step, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, True, info=info1)
+        else:
+            step, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, True, overlap=other, info=info1)
+            dt_o, _ = timed_steps(step, n_x, 3, fence)
+            dt_o = max_over_ranks(dt_o)
+            exchange["other_form"] = {"buckets": info1.get("buckets"), "overlap": other, "tail_in_graph": info1.get("tail_in_graph"),
+                                      "ms_per_step": round(1e3 * dt_o / n_x, 4)}
 
     families, fp32_mode, cpu = None, None, None
     if rank == 0 and not a.no_families:

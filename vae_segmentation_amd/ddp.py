@@ -28,6 +28,45 @@ from ._lib import check, lib
 from .optim import _Tables
 
 
+_CAPTURABLE = {}
+
+
+def collective_capturable(group=None):
+    """Can an all-reduce of this process group be captured into a HIP graph?  Answered once per group by capturing and replaying a tiny one
+    (every rank runs the same probe, so the ranks agree); train.GraphedStep keeps the tail of the step eager when the answer is no."""
+    if not dist.is_initialized():
+        return True
+    key = id(group)
+    if key in _CAPTURABLE:
+        return _CAPTURABLE[key]
+    ok = False
+    if dist.get_backend(group) == "nccl" and torch.cuda.is_available():
+        try:
+            x = torch.ones(256, device="cuda")
+            dist.all_reduce(x, group=group)                  # communicator set-up happens eagerly, outside the capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    dist.all_reduce(x, group=group)
+            torch.cuda.current_stream().wait_stream(side)
+            g.replay()
+            torch.cuda.synchronize()
+            ok = bool(torch.isfinite(x).all())
+        except Exception as e:                               # noqa: BLE001 — whatever the stack refuses, the eager tail works
+            import sys
+            print("vae_segmentation_amd.ddp: all-reduce is not capturable on this stack (%s: %s); the exchange stays outside the step's graph"
+                  % (type(e).__name__, e), file=sys.stderr)
+            try:
+                torch.cuda.synchronize()
+            except Exception:                                # noqa: BLE001
+                pass
+    _CAPTURABLE[key] = ok
+    return ok
+
+
 class FlatGradSync:
     """Flat gradient buffer + bucketed all-reduce.  Use:
 

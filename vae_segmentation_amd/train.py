@@ -266,7 +266,8 @@ class GraphedStep:
             capture_tail = os.environ.get("VS_GRAPH_TAIL", "1") != "0"
         import torch.distributed as dist
         # grad_sync None = the caller wants no exchange (one rank, or a timing leg): nothing collective is captured then
-        rccl_or_none = grad_sync is None or (not dist.is_initialized()) or dist.get_backend(grad_sync.group) == "nccl"
+        rccl_or_none = (grad_sync is None or (not dist.is_initialized()) or not getattr(grad_sync, "exchange", True)
+                        or (dist.get_backend(grad_sync.group) == "nccl" and _ddp.collective_capturable(grad_sync.group)))
         self.tail = (bool(capture_tail) and warmup >= 1 and not two_phase and scaler is None and isinstance(optimizer, _optim.SGD)
                      and rccl_or_none and all(p.is_cuda for p in self.params))
         self._own_sync = False
