@@ -178,9 +178,12 @@ def _blocks_norm(dt):
 
     def case(tag, mod, shape, seed, eval_after_train=False):
         O.bn_fill_(O.deterministic_fill_(mod, seed=seed))
+        if "_gs_" in tag:                     # GSNorm3d blocks: positive weights on positive inputs (oracle.ref_cpu.positive_fill_)
+            O.positive_fill_(mod)
         mod = mod.to(dt)
         n = int(np.prod(shape))
-        x = torch.from_numpy(2 * O.hashed_uniform(n, 7001, seed) - 1).to(dt).view(shape).requires_grad_(True)
+        u = O.hashed_uniform(n, 7001, seed)
+        x = torch.from_numpy(u if "_gs_" in tag else 2 * u - 1).to(dt).view(shape).requires_grad_(True)
         if eval_after_train:                  # one training pass moves the running statistics, then the block is used in eval mode
             mod.train()
             with torch.no_grad():
@@ -205,6 +208,10 @@ def _blocks_norm(dt):
     case("dconv_soft_8_16", RM.DoubleConv(8, 16, norm_type=1, soft=True), (2, 8, 16, 16, 16), 27)
     case("conv_soft_2_8", RM.Conv(2, 8, norm_type=1, soft=True), (2, 2, 16, 16, 16), 28)
     case("dconv_bn_soft_8_16", RM.DoubleConv(8, 16, norm_type=2, soft=True), (2, 8, 16, 16, 16), 29)
+    # norm_type=3: GSNorm3d(out_ch, num_group=1) inside Conv / DoubleConv / Down (joint_model.py:14-15,17-33; instantiated nowhere in the reference)
+    case("conv_gs_2_8", RM.Conv(2, 8, norm_type=3), (2, 2, 16, 16, 16), 41)
+    case("dconv_gs_8_16", RM.DoubleConv(8, 16, norm_type=3), (2, 8, 16, 16, 16), 42)
+    case("down_gs_8_16", RM.Down(8, 16, norm_type=3), (2, 8, 16, 16, 16), 43)
     return d
 
 

@@ -44,11 +44,15 @@ FMAPS = (8, 16, 32, 64, 128, 256)
 # building blocks
 # --------------------------------------------------------------------------------------
 def norm_layer(norm_type, channels):
+    """/root/reference/joint_model.py:9-15.  norm_type 3 = GSNorm3d with num_group 1: the reference's Conv / DoubleConv never forward their
+    num_group argument (joint_model.py:41,44,47,107)."""
     if norm_type == 1:
         return nn.InstanceNorm3d(channels)
     if norm_type == 2:
         return nn.BatchNorm3d(channels, momentum=0.1)
-    raise ValueError("oracle covers norm_type 1 (InstanceNorm3d) and 2 (BatchNorm3d) only")
+    if norm_type == 3:
+        return GSNorm3d(channels, num_group=1)
+    raise ValueError("norm_type must be 1 (InstanceNorm3d), 2 (BatchNorm3d) or 3 (GSNorm3d)")
 
 
 def _act(soft, inplace):
@@ -723,6 +727,16 @@ def deterministic_fill_(module, seed=0, gain=1.0):
             bound = 0.1 if p.dim() == 1 else gain * math.sqrt(3.0 / _fan_in(name, p))
             vals = (2.0 * u - 1.0) * np.float32(bound)
             p.copy_(torch.from_numpy(vals).view_as(p))
+    return module
+
+
+def positive_fill_(module):
+    """After deterministic_fill_: every parameter replaced by its absolute value.  For the GSNorm3d blocks (norm_type 3): the layer divides by the
+    per-voxel channel SUM + 1e-4, which is ill-conditioned wherever mixed-sign channels cancel; positive weights on positive inputs keep the
+    sums away from zero so that a fixture pins arithmetic, not the position of near-singular voxels.  Same call on the reference modules and the native ones."""
+    with torch.no_grad():
+        for p in module.parameters():
+            p.abs_()
     return module
 
 

@@ -93,8 +93,11 @@ def test_blocks_norm_vs_reference_golden(tag):
     g = G.load("blocks_norm")
     native = {"conv": M.Conv, "dconv": M.DoubleConv, "down": M.Down, "up": M.Up}[tag.split("_")[0]]
     a, b = [int(v) for v in tag.split("_")[-2:]]
-    mod = native(a, b, norm_type=2 if "_bn" in tag else 1, soft="_soft" in tag)
-    mod = O.bn_fill_(O.deterministic_fill_(mod, seed=int(g[tag + ".seed"]))).cuda()
+    mod = native(a, b, norm_type=2 if "_bn" in tag else (3 if "_gs_" in tag else 1), soft="_soft" in tag)
+    mod = O.bn_fill_(O.deterministic_fill_(mod, seed=int(g[tag + ".seed"])))
+    if "_gs_" in tag:                      # GSNorm3d blocks (norm_type=3): positive weights on positive inputs, as the fixture was made
+        O.positive_fill_(mod)
+    mod = mod.cuda()
     y, gin = run_block_norm(mod, g, tag, device="cuda")
     G.check_tensor(g, tag + ".out", y, rtol=1e-3, what=tag)
     G.check_tensor(g, tag + ".gin", gin, rtol=1e-3, what=tag)

@@ -131,8 +131,10 @@ def test_module_surface_on_cpu_is_constructible_but_not_runnable():
         joint({"x": torch.zeros(1, 1, 96, 96, 96)}, "x", "p", "r")
     bn = M.Segmentation(1, 2)                                # the constructors' default norm_type=2: BatchNorm3d holders, reference state_dict keys
     assert "in_block.conv.1.running_var" in bn.state_dict() and isinstance(M.DoubleConv(8, 8, norm_type=1, soft=True).conv[2], torch.nn.Softplus)
-    with pytest.raises(NotImplementedError):
-        M.Segmentation(1, 2, norm_type=3)                    # GSNorm3d: nothing in the reference instantiates it
+    gs = M.Segmentation(1, 2, norm_type=3)                   # GSNorm3d holders (joint_model.py:14-15): parameter-less, same state_dict keys as norm_type=1
+    assert list(gs.state_dict().keys()) == list(M.Segmentation(1, 2, norm_type=1).state_dict().keys())
+    with pytest.raises(ValueError):
+        M.Segmentation(1, 2, norm_type=4)
     with pytest.raises(NotImplementedError):
         M.Segmentation(1, 3, norm_type=1)
 

@@ -72,6 +72,10 @@ BLOCKS_NORM = {
     "dconv_soft_8_16": lambda: O.DoubleConv(8, 16, norm_type=1, soft=True),
     "conv_soft_2_8": lambda: O.Conv(2, 8, norm_type=1, soft=True),
     "dconv_bn_soft_8_16": lambda: O.DoubleConv(8, 16, norm_type=2, soft=True),
+    # norm_type=3: GSNorm3d (one group) inside the blocks — positive weights on positive inputs (oracle.ref_cpu.positive_fill_)
+    "conv_gs_2_8": lambda: O.Conv(2, 8, norm_type=3),
+    "dconv_gs_8_16": lambda: O.DoubleConv(8, 16, norm_type=3),
+    "down_gs_8_16": lambda: O.Down(8, 16, norm_type=3),
 }
 
 
@@ -79,7 +83,8 @@ def run_block_norm(mod, g, tag, device="cpu"):
     """the case of oracle/make_golden.py:_blocks_norm on `mod` -> (out, input gradient)"""
     seed = int(g[tag + ".seed"])
     shape = tuple(int(v) for v in g[tag + ".shape"])
-    x = torch.from_numpy(2 * O.hashed_uniform(int(np.prod(shape)), 7001, seed) - 1).view(shape).to(device).requires_grad_(True)
+    u = O.hashed_uniform(int(np.prod(shape)), 7001, seed)
+    x = torch.from_numpy(u if "_gs_" in tag else 2 * u - 1).view(shape).to(device).requires_grad_(True)
     if "_eval_" in tag:
         mod.train()
         with torch.no_grad():
@@ -106,6 +111,8 @@ def test_blocks_norm(tag):
     """BatchNorm3d (training / eval) and Softplus blocks: the oracle against the reference's own blocks"""
     g = G.load("blocks_norm")
     mod = O.bn_fill_(O.deterministic_fill_(BLOCKS_NORM[tag](), seed=int(g[tag + ".seed"])))
+    if "_gs_" in tag:
+        O.positive_fill_(mod)
     y, gin = run_block_norm(mod, g, tag)
     G.check_tensor(g, tag + ".out", y, rtol=1e-5, what=tag)
     G.check_tensor(g, tag + ".gin", gin, rtol=1e-5, what=tag)

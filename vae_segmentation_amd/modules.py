@@ -12,7 +12,7 @@ The configuration every entry point of the reference uses — ``norm_type=1`` (I
 settings, ``norm_type=2`` (BatchNorm3d, the class default, with affine parameters and running statistics) and ``soft=True``
 (Softplus), run through ``ops.NormAct``: native too, but as separate streaming passes after each conv (nothing in the reference
 reaches them: main_source.py:250-272, main_target.py:317-342 pass norm_type=1, and every block receives soft=False).
-The ``*_GS`` classes, which no reference code instantiates, live in ``modules_gs.py``; ``norm_type=3`` inside these blocks raises.
+The ``*_GS`` classes, which no reference code instantiates, live in ``modules_gs.py``; ``norm_type=3`` (GSNorm3d with one group) inside these blocks runs as three native passes.
 """
 import torch
 import torch.nn as nn
@@ -55,7 +55,19 @@ def Normalization(norm_type, out_channels, num_group=1):
         return nn.InstanceNorm3d(out_channels)
     if norm_type == 2:
         return nn.BatchNorm3d(out_channels, momentum=0.1)
-    raise NotImplementedError("norm_type=3 (GSNorm3d, joint_model.py:17-33) has no native kernel; nothing in the reference instantiates it")
+    if norm_type == 3:
+        return GSNormHolder(out_channels, num_group)
+    raise ValueError("norm_type must be 1 (InstanceNorm3d), 2 (BatchNorm3d) or 3 (GSNorm3d)")
+
+
+class GSNormHolder(nn.Module):
+    """joint_model.py:17-33 at a block's Sequential index (norm_type=3): parameter-less; x[:, group] / (sum over the group's channels + 1e-4).
+    The reference's Conv / DoubleConv never forward num_group (joint_model.py:41,44,47,107), so inside these blocks it is always one group.
+    Native through vs_gsnorm_* (ops.GSNorm), as the `*_GS` family's own GSNorm3d (modules_gs.py)."""
+
+    def __init__(self, out_ch, num_group=1):
+        super().__init__()
+        self.out_ch, self.num_group = out_ch, num_group
 
 
 def _activation(soft, inplace):
@@ -87,6 +99,13 @@ def _conv_norm_act(seq, i, a):
     if isinstance(norm, nn.InstanceNorm3d) and isinstance(actm, nn.ReLU):
         return _conv3(conv, a)
     y, ys = ops.ConvK3.apply(a.raw, a.stats, conv.weight, conv.bias, True)
+    if isinstance(norm, GSNormHolder):
+        # conv (live bias: nothing cancels it) -> group-sum normalisation -> activation, three native passes
+        if y.shape[-1] != norm.out_ch:
+            raise ValueError("GSNorm3d(%d) got %d stored channels" % (norm.out_ch, y.shape[-1]))
+        z = ops.GSNorm.apply(y, norm.num_group)
+        act = ops.VS_ACT_SOFTPLUS if isinstance(actm, nn.Softplus) else ops.VS_ACT_RELU
+        return Act(ops.NormAct.apply(z, ys, None, None, "none", act, conv.weight.shape[0]), None)
     bn = norm if isinstance(norm, nn.BatchNorm3d) else None
     act = ops.VS_ACT_SOFTPLUS if isinstance(actm, nn.Softplus) else ops.VS_ACT_RELU
     out = ops.NormAct.apply(y, ys, bn.weight if bn is not None else None, bn.bias if bn is not None else None, bn, act, conv.weight.shape[0])
