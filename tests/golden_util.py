@@ -107,13 +107,15 @@ def scalar_close(gold, key, val, floor=1e-3, factor=3.0):
     return mine / max(abs(f64), 1e-30)
 
 
-# Floor for END-TO-END gradient comparisons against the fp64 yardstick where three networks are chained (Embed at 128^3: ~90 InstanceNorm/ReLU layers).
-# What such a comparison measures is one draw of the network's rounding amplification (ReLU masks flip under a 1e-7 perturbation), not a kernel error:
-# tools/limb_accuracy.py (profiles/r04_fp32_limb_accuracy.txt) perturbs the weights of Segmentation at 32^3 by +-1 fp32 ulp and re-runs the SAME
-# kernels — the worst gradient tensor lands anywhere between 2e-4 and 5e-3 from the fp64 result.  The kernels themselves are pinned where the
-# comparison is exact: per op (tests/test_gpu_ops.py, tests/test_gpu_layers.py: 2e-5 against CPU autograd, measured 1e-7 .. 7e-7) and per single
-# forward / backward step recomputed in fp64 from the kernels' own inputs (tests/test_gpu_backward_steps.py: asserted 5e-6, measured 9e-7).
-DRAW_FLOOR_GRAD = 8e-3
+# Floor for the END-TO-END gradient comparison of Embed at 128^3 (three chained networks, ~90 InstanceNorm/ReLU layers) against the fp64 yardstick.
+# The reference's own eager fp32 run sits 3.4e-2 (median over its 138 tensors) from its fp64 run there, and a handful of encoder tensors are on a
+# knife edge: tools/limb_accuracy_embed.py (profiles/r04_fp32_limb_accuracy.txt) — enc.down3 / down4 gradients are 4e-6 from fp64 in the reference's
+# fp32 run and in the exact-f32 MFMA kernels' unperturbed run, and 1.0e-2 .. 1.5e-2 as soon as the weights move by +-1 fp32 ulp (exact-f32 kernels) or
+# the kernels round differently (limb kernels, perturbed or not): one activation on a ReLU edge decides.  A ratio to the reference's own error cannot
+# gate such tensors; the floor holds the draw.  The kernels are pinned where the comparison is exact: per op (tests/test_gpu_ops.py,
+# tests/test_gpu_layers.py: 2e-5 against CPU autograd, measured 1e-7 .. 7e-7) and per single forward / backward step recomputed in fp64 from the
+# kernels' own inputs (tests/test_gpu_backward_steps.py: asserted 5e-6, measured 9e-7).
+DRAW_FLOOR_GRAD = 2.5e-2
 
 
 def check_tensor_f64(gold, prefix, t, k=64, floor=1e-3, factor=3.0, what=""):
