@@ -372,6 +372,14 @@ static inline int vs_k3x_ck(int c_pad) {
     return c_pad < w ? c_pad : w;
 }
 
+// (VS_F32X3, 3x3x3, 8 stored k-side channels, <= 8 rows) — the 8-channel full-resolution layers of the fp32 parity mode — are packed in the Toeplitz limb
+// order of k3xt_kernel (igemm_k3x.h): [k-group (tz,ty)][limb][lane][8], row (lane & 15) = (dx2, co), k = (xpos = lane >> 4, ci), value
+// W[co][ci][tz][ty][xpos - dx2] or 0.  pack.hip (image) and igemm_k3x.hip (dispatch) both key on this predicate (VS_K3X_TOEPLITZ=0: off).
+static inline bool vs_k3x_toeplitz(int rows, int c_pad, int ntaps) {
+    static const int on = getenv("VS_K3X_TOEPLITZ") ? atoi(getenv("VS_K3X_TOEPLITZ")) : 1;
+    return on && ntaps == 27 && c_pad == 8 && rows <= 8;
+}
+
 // Zeroing as a kernel, never hipMemsetAsync: inside a replayed HIP graph a memset node was observed to run out of order with the
 // kernel nodes around it after a host-side D2H copy (second test-time-training case, nondeterministic bias gradients); kernel nodes
 // are ordered.  One workgroup is enough for the few hundred bytes zeroed here.

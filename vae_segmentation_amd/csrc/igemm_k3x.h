@@ -410,3 +410,301 @@ static int k3x_launch(const G1Params& p, int tiles_total, int row_tiles, hipStre
     if (p.x_stats != nullptr) return k3x_launch_t<CK, MT, EPI, false, true, MULTI>(p, tiles_total, row_tiles, stream);
     return k3x_launch_t<CK, MT, EPI, false, false, MULTI>(p, tiles_total, row_tiles, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// k3xt_kernel: the limb kernel for 8 stored input AND output channels (in_block, up5's second and third conv, out_block and their backward-data:
+// the full-resolution layers, a third of the fp32 step).  With 8 real rows half of every MFMA of k3x_kernel multiplies padding, and those launches
+// are bound by MFMA and LDS-read cycles (50-70 us at 96^3 against 25 us of HBM time).  As in k3t_kernel (igemm_k3t.h) the 16 MFMA rows become
+// TOEPLITZ rows (dx2, co) — two x-adjacent output voxels times 8 channels — and a k-group is one (tz, ty) pair with k = (window position 0..3, ci):
+// an MFMA column set covers 32 voxels of a row, 9 k-groups x 6 limb products per 32 voxels instead of 14 x 6, and every accumulator lane is a real
+// output.  Tile 4 x 2 x 32 (halo 6 x 4 x 34: three limb planes 43 KB + weight block 27 KB -> two workgroups per CU); a wave owns one z-plane:
+// two rows of 32 voxels.  Weights: the Toeplitz VS_F32X3 image (pack.hip), value W[co][ci][tz][ty][xpos - dx2] or 0.
+#define K3XT_HX 34
+#define K3XT_HY 4
+#define K3XT_TV (6 * K3XT_HY * K3XT_HX)
+#define K3XT_NIT ((K3XT_TV * 2 + 255) / 256)
+#define K3XT_PB (K3XT_NIT * 256 * 8)
+#define K3XT_NWF (9 * 3 * 64)
+#define K3XT_NWI ((K3XT_NWF + 255) / 256)
+#define K3XT_WB (K3XT_NWI * 256 * 16)
+
+template <int EPI, bool SUMS, bool HS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k3xt_kernel(const G1Params p) {
+    constexpr int TV = K3XT_TV, PLANE = K3XT_HY * K3XT_HX, NIT = K3XT_NIT, PB = K3XT_PB, NWI = K3XT_NWI, NWF = K3XT_NWF, NU = TV * 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_red = (float*)(smem + K3X_LDS_RED);
+    char* s_tile = smem + K3X_LDS_TILE;
+    char* s_w = s_tile + 3 * PB;
+    float* s_mean = (float*)(s_w + K3XT_WB);
+    float* s_rstd = s_mean + p.N * 8;
+    float* s_mkm = s_rstd + p.N * 8;
+    float* s_mkr = s_mkm + p.N * 8;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
+    const int total_tiles = p.tiles_per_sample * p.N;
+    const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * 8 * 4));
+    const u32x4* __restrict__ wp = (const u32x4*)p.wp;
+
+    const double* st_src = SUMS ? p.mask_stats : p.x_stats;
+    const int st_n = (SUMS || HS) ? p.N * 8 : 0;
+    double st_pre[2] = {0.0, 1.0};
+    if (tid < st_n) stat_load(st_src, (size_t)tid, (size_t)st_n, st_pre);
+
+    // fragment b = channels 4*part .. of halo voxel tv_b = (tid + 256 b) >> 1
+    const int part = tid & 1;
+    int rel_off[NIT], tzyx[NIT];
+    const int lds_w0 = (tid >> 1) * 16 + part * 8;        // + b * 2048, + limb * PB
+#pragma unroll
+    for (int b = 0; b < NIT; ++b) {
+        const int u = tid + b * 256;
+        const int tv = u >> 1;
+        const int tx_ = tv % K3XT_HX, ty_ = (tv / K3XT_HX) % K3XT_HY, tz_ = tv / PLANE;
+        rel_off[b] = (((tz_ * p.H + ty_) * p.W + tx_) * 8 + part * 4) * 4;
+        tzyx[b] = u < NU ? (tz_ | (ty_ << 8) | (tx_ << 16)) : 0x00ffffff;
+    }
+    int w_off[NWI];
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+        const int f = tid + i * 256;
+        w_off[i] = f > NWF - 1 ? NWF - 1 : f;
+    }
+    u32x4 xv[NIT], wv[NWI];
+    unsigned int okbits = 0;
+    struct Coord { int n, z0, y0, x0; };
+    auto tile_coord = [&](int t) {
+        Coord c;
+        c.n = fdiv(t, p.fd_m[0], p.fd_s[0]);
+        const int tl = t - c.n * p.tiles_per_sample;
+        const int tz = fdiv(tl, p.fd_m[1], p.fd_s[1]);
+        const int r = tl - tz * (p.txn * p.tyn);
+        const int ty = fdiv(r, p.fd_m[2], p.fd_s[2]);
+        c.z0 = tz * 4; c.y0 = ty * 2; c.x0 = (r - ty * p.txn) * 32;
+        return c;
+    };
+    auto load_x = [&](const Coord& c) {
+        const int base = (((c.n * p.D + c.z0 - 1) * p.H + c.y0 - 1) * p.W + c.x0 - 1) * 8 * 4;
+        okbits = 0;
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) {
+            const int gz = c.z0 - 1 + (tzyx[b] & 0xff), gy = c.y0 - 1 + ((tzyx[b] >> 8) & 0xff), gx = c.x0 - 1 + (tzyx[b] >> 16);
+            const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            okbits |= ok ? (1u << b) : 0u;
+            xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, ok ? base + rel_off[b] : -1, 0, 0));
+        }
+    };
+    auto write_x = [&](int n) {
+        float mn[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (HS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mn[j] = s_mean[n * 8 + part * 4 + j]; rs[j] = s_rstd[n * 8 + part * 4 + j]; }
+        }
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(xv[b][j]);
+            if constexpr (HS) {
+                const bool ok = (okbits >> b) & 1u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = (v[j] - mn[j]) * rs[j];
+                    v[j] = ok ? fmaxf(t, 0.f) : 0.f;
+                }
+            }
+            unsigned int lm[3][2];
+            vs_limb_split4(v, lm);
+#pragma unroll
+            for (int l = 0; l < 3; ++l) *(u32x2*)(s_tile + l * PB + lds_w0 + b * 2048) = u32x2{lm[l][0], lm[l][1]};
+        }
+    };
+
+    int t, t_end, G;
+    if (((int)gridDim.x & 7) == 0) {
+        const int xcd = (int)blockIdx.x & 7;
+        G = (int)gridDim.x >> 3;
+        t = (int)(((long long)total_tiles * xcd) >> 3) + ((int)blockIdx.x >> 3);
+        t_end = (int)(((long long)total_tiles * (xcd + 1)) >> 3);
+    } else { G = (int)gridDim.x; t = (int)blockIdx.x; t_end = total_tiles; }
+    Coord cur = tile_coord(t), nxt = cur;
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) wv[i] = wp[w_off[i]];
+    load_x(cur);
+    // this lane's accumulator rows 4g .. 4g+3 = (dx2 = g >> 1, channels 4 (g & 1) ..)
+    const int dx2 = g >> 1, ch0 = 4 * (g & 1);
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (p.bias != nullptr && ch0 + r < (EPI == EPI_SOFTMAX2 ? 2 : p.M)) ? p.bias[ch0 + r] : 0.f;
+    const i32x4 yrsrc = make_rsrc(p.y, (unsigned int)((long long)p.N * p.D * p.H * p.W * 8 * 4));
+    const i32x4 mrsrc = make_rsrc(p.mask_x, (unsigned int)((long long)p.N * p.D * p.H * p.W * 8 * 4));
+    if (tid < st_n) {
+        float m, r;
+        pair_to_mean_rstd(st_pre, SUMS ? p.inv_count_out : p.inv_count_in, p.eps, m, r);
+        if constexpr (SUMS) { s_mkm[tid] = m; s_mkr[tid] = r; }
+        else { s_mean[tid] = m; s_rstd[tid] = r; }
+    }
+    // B fragment of (k-group (tz, ty), row cg, lane (col, g)): limb plane + ((wave + tz) * PLANE + (cg + ty) * HX + 2 col + g) * 16
+    const int baddr = (wave * PLANE + 2 * col + g) * 16;
+    const char* s_wl = s_w + lane * 16;
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bv[r]));
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) *(u32x4*)(s_w + (tid + i * 256) * 16) = wv[i];
+    bool first = true;
+    __syncthreads();
+
+    for (; t < t_end; t += G) {
+        const int n = cur.n, z0 = cur.z0, y0 = cur.y0, x0 = cur.x0;
+        const int oz = z0 + wave, ox = x0 + 2 * col + dx2;
+        const int ebase = ((((n * p.D + oz) * p.H + y0) * p.W + ox) * 8 + ch0) * 4;          // + cg * W * 8 * 4
+        const bool zx_ok = oz < p.D && ox < p.W;
+        f32x4 acc[2], acl[2];
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) { acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[cg] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        u32x4 mk[2];
+        if (!first) __syncthreads();
+        write_x(n);
+        first = false;
+        __syncthreads();
+        if constexpr (EPI == EPI_RAW && SUMS) {
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                const bool valid = zx_ok && y0 + cg < p.H && ch0 < p.M;
+                mk[cg] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(mrsrc, valid ? ebase + cg * p.W * 32 : -1, 0, 0));
+            }
+        }
+        nxt = tile_coord(t + G);
+        if (t + G < t_end) load_x(nxt);
+#pragma unroll
+        for (int kg = 0; kg < 9; ++kg) {
+            const int tz = kg / 3, ty = kg % 3;
+            u32x4 a[3], b[2][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a[j] = *(const u32x4*)(s_wl + (kg * 3 + j) * 1024);
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) b[cg][i] = *(const u32x4*)(s_tile + i * PB + baddr + (tz * PLANE + (cg + ty) * K3XT_HX) * 16);
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                acl[cg] = mfma16(a[0], b[cg][2], acl[cg], (unsigned short*)nullptr);
+                acl[cg] = mfma16(a[1], b[cg][1], acl[cg], (unsigned short*)nullptr);
+                acl[cg] = mfma16(a[2], b[cg][0], acl[cg], (unsigned short*)nullptr);
+                acl[cg] = mfma16(a[0], b[cg][1], acl[cg], (unsigned short*)nullptr);
+                acl[cg] = mfma16(a[1], b[cg][0], acl[cg], (unsigned short*)nullptr);
+                acc[cg] = mfma16(a[0], b[cg][0], acc[cg], (unsigned short*)nullptr);
+            }
+        }
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) acc[cg] += acl[cg];
+
+        if constexpr (EPI == EPI_SOFTMAX2) {
+            if ((g & 1) == 0) {                              // the lanes holding channels 0 .. 3 of voxel ox: the two logits are channels 0 and 1
+                const size_t V = (size_t)p.D * p.H * p.W;
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    const int oy = y0 + cg;
+                    if (!(oz < p.D && oy < p.H && ox < p.W)) continue;
+                    float l0 = acc[cg][0] + bv[0], l1 = acc[cg][1] + bv[1];
+                    const size_t v = ((size_t)oz * p.H + oy) * p.W + ox;
+                    if (p.drop_p > 0.f) {
+                        l0 *= dropout_scale(p.drop_seed, ((unsigned long long)n * 2 + 0) * V + v, p.drop_p);
+                        l1 *= dropout_scale(p.drop_seed, ((unsigned long long)n * 2 + 1) * V + v, p.drop_p);
+                    }
+                    const float mx = fmaxf(l0, l1);
+                    const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx);
+                    const float inv = 1.f / (e0 + e1);
+                    p.prob[((size_t)n * 2 + 0) * V + v] = e0 * inv;
+                    p.prob[((size_t)n * 2 + 1) * V + v] = e1 * inv;
+                }
+            }
+        } else {
+            const bool rvalid = ch0 < p.M;
+            float mm[4] = {0.f, 0.f, 0.f, 0.f}, mr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (SUMS && rvalid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { mm[r] = s_mkm[n * 8 + ch0 + r]; mr[r] = s_mkr[n * 8 + ch0 + r]; }
+            }
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                const bool valid = rvalid && zx_ok && y0 + cg < p.H;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[cg][r] + bv[r];
+                vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{v[0], v[1], v[2], v[3]}), yrsrc, valid ? ebase + cg * p.W * 32 : -1, 0, 0);
+                if (!valid) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+                if constexpr (SUMS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xh = (__uint_as_float(mk[cg][r]) - mm[r]) * mr[r];
+                        const float gm = xh > 0.f ? v[r] : 0.f;
+                        ssum[r] += gm; ssq[r] += gm * xh;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ssum[r] += v[r]; ssq[r] += v[r] * v[r]; }
+                }
+            }
+            double* const red_dst = SUMS ? p.sums : p.y_stats;
+            if (red_dst != nullptr) {
+                const bool flush = t + G >= t_end || nxt.n != n;       // workgroup-uniform
+                if (flush) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float s = row16_sum(ssum[r]), q = row16_sum(ssq[r]);
+                        if (col == 0) {
+                            s_red[(wave * 16 + 4 * g + r) * 2 + 0] = s;
+                            s_red[(wave * 16 + 4 * g + r) * 2 + 1] = q;
+                        }
+                        ssum[r] = 0.f; ssq[r] = 0.f;
+                    }
+                    __syncthreads();
+                    if (tid < 16) {                              // channel tid >> 1: rows (dx2 = 0, ch) and (dx2 = 1, ch) = accumulator rows ch and ch + 8, of the four waves
+                        const int chn = tid >> 1, st = tid & 1;
+                        if (chn < p.M) {
+                            double tot = 0.0;
+#pragma unroll
+                            for (int w = 0; w < 4; ++w) tot += (double)s_red[(w * 16 + chn) * 2 + st] + (double)s_red[(w * 16 + chn + 8) * 2 + st];
+                            stat_add(red_dst, (size_t)n * p.M + chn, (size_t)p.N * p.M, st, tot);
+                        }
+                    }
+                    if (t + G < t_end) __syncthreads();
+                }
+            }
+        }
+        cur = nxt;
+    }
+}
+
+template <int EPI, bool SUMS, bool HS>
+static int k3xt_launch_t(const G1Params& p_in, hipStream_t stream) {
+    G1Params p = p_in;
+    p.tyn = (p.H + 1) / 2; p.txn = (p.W + 31) / 32;
+    p.tiles_per_sample = ((p.D + 3) / 4) * p.tyn * p.txn;
+    const int tiles_total = p.tiles_per_sample * p.N;
+    const size_t lds = K3X_LDS_TILE + (size_t)3 * K3XT_PB + K3XT_WB + (size_t)4 * p.N * 8 * sizeof(float);
+    if (lds > 160 * 1024 || p.N * 8 > 256) return VS_ESHAPE;
+    if ((long long)p.N * p.D * p.H * p.W * 8 * 4 >= 2147483648ll) return VS_ESHAPE;
+    k3x_fastdiv(p.tiles_per_sample, p.fd_m[0], p.fd_s[0]);
+    k3x_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
+    k3x_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
+    if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr) || p.C != 8 || p.M != 8) return VS_EINVAL;
+    auto kern = k3xt_kernel<EPI, SUMS, HS>;
+    static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_err != hipSuccess) return (int)attr_err;
+    const int wg = 512;                                  // two workgroups per CU (73 KB of LDS each)
+    const int gx = tiles_total < wg ? tiles_total : wg;
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, stream, p);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+template <int EPI>
+static int k3xt_launch(const G1Params& p, hipStream_t stream) {
+    if (p.sums != nullptr) {
+        if constexpr (EPI == EPI_RAW) return k3xt_launch_t<EPI, true, false>(p, stream);
+        else return VS_EINVAL;
+    }
+    if (p.x_stats != nullptr) return k3xt_launch_t<EPI, false, true>(p, stream);
+    return k3xt_launch_t<EPI, false, false>(p, stream);
+}

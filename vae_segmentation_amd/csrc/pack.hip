@@ -74,10 +74,38 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ src, T* __res
 // VS_F32X3 image of a 3x3x3 weight for k3x_kernel (igemm_k3x.h): [row block][chunk of CK = min(c_pad, 16) channels][k-group of 32][limb 0..2][lane][8 bf16]
 //   row = rb*16 + (lane & 15);  k within the chunk = kg*32 + (lane >> 4)*8 + j;  tap = k / CK, c = ch*CK + k % CK
 // limb 0 = w rounded to bf16, limb 1 = w - limb0 rounded to bf16, limb 2 = the rest (8 + 8 + 8 significant bits).  One thread per 16-byte fragment.
+__device__ __forceinline__ unsigned short limb_of(float v, int limb) {       // round-to-nearest limbs, as vs_limb_split4 (common.h) forms them for the activations
+    const unsigned short b0 = f2bf(v);
+    const float r1 = v - bf2f(b0);
+    const unsigned short b1 = f2bf(r1);
+    return limb == 0 ? b0 : (limb == 1 ? b1 : f2bf(r1 - bf2f(b1)));
+}
+
+// CK < 0: the Toeplitz limb image of the 8-channel layers (common.h vs_k3x_toeplitz, igemm_k3x.h k3xt_kernel): [kg = tz*3+ty][limb][lane][ci]
 __device__ __forceinline__ void pack_one_limbs(const float* __restrict__ src, unsigned short* __restrict__ dst, int d0, int d1, int ntaps,
                                                int c_pad, int form, long long total, long long frag, int CK) {
     const long long i = frag * 8;
     if (i >= total) return;
+    if (CK < 0) {
+        const int lane = (int)(frag & 63), limb = (int)((frag >> 6) % 3), kg = (int)(frag / 192);
+        const int row = lane & 15, dx2 = row >> 3, co = row & 7, tx = (lane >> 4) - dx2;
+        unsigned short o[8];
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            float v = 0.f;
+            if (tx >= 0 && tx <= 2) {
+                const int tap = kg * 3 + tx;
+                if (form == VS_PACK_ROWS_D0) { if (co < d0 && ci < d1) v = src[((size_t)co * d1 + ci) * 27 + tap]; }
+                else { if (co < d1 && ci < d0) v = src[((size_t)ci * d1 + co) * 27 + (26 - tap)]; }
+            }
+            o[ci] = limb_of(v, limb);
+        }
+        u32x4 pk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = (unsigned int)o[2 * q] | ((unsigned int)o[2 * q + 1] << 16);
+        *(u32x4*)(dst + i) = pk;
+        return;
+    }
     const int nch = c_pad / CK;
     const int nkg = (ntaps * CK + 31) / 32;
     long long r = frag;
@@ -97,11 +125,7 @@ __device__ __forceinline__ void pack_one_limbs(const float* __restrict__ src, un
         float v = 0.f;
         if (form == VS_PACK_ROWS_D0) { if (row < d0 && tap < ntaps && c < d1) v = src[((size_t)row * d1 + c) * ntaps + tap]; }
         else { if (row < d1 && tap < ntaps && c < d0) v = src[((size_t)c * d1 + row) * ntaps + (ntaps - 1 - tap)]; }
-        const unsigned short b0 = f2bf(v);                // round-to-nearest limbs, as k3x_split4 (igemm_k3x.h) forms them for the activations
-        const float r1 = v - bf2f(b0);
-        const unsigned short b1 = f2bf(r1);
-        const float r2 = r1 - bf2f(b1);
-        o[j] = limb == 0 ? b0 : (limb == 1 ? b1 : f2bf(r2));
+        o[j] = limb_of(v, limb);
     }
     u32x4 pk;
 #pragma unroll
@@ -136,7 +160,11 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const vs_pack_de
     }
     const vs_pack_desc d = descs[lo];
     const long long i = (long long)(lb - d.first_block) * 256 + threadIdx.x;
-    if (d.dtype == VS_F32X3) pack_one_limbs(d.src, (unsigned short*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i, d.c_pad < k3x_ck ? d.c_pad : k3x_ck);
+    if (d.dtype == VS_F32X3) {
+        const int rows = d.form == VS_PACK_ROWS_D0 ? d.d0 : d.d1;
+        const bool toep = k3x_ck < 0 ? false : (d.total == 9ll * 3 * 64 * 8 && d.c_pad == 8 && rows <= 8);      // the Toeplitz image has its own size: 13,824 elements
+        pack_one_limbs(d.src, (unsigned short*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i, toep ? -1 : (d.c_pad < k3x_ck ? d.c_pad : k3x_ck));
+    }
     else if (d.dtype == VS_F32) pack_one<float>(d.src, (float*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
     else if (d.dtype == VS_BF16) pack_one<unsigned short>(d.src, (unsigned short*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
     else pack_one<vs_half>(d.src, (vs_half*)d.dst, d.d0, d.d1, d.ntaps, d.c_pad, d.form, d.total, i);
@@ -151,6 +179,7 @@ extern "C" int vs_pack_weight_multi(const vs_pack_desc* descs, int n_desc, int t
 
 static long long packed_elems(int rows, int c_pad, int gemm_taps, int dtype) {
     if (dtype == VS_F32X3) {                             // bf16 elements of the three-limb image (3x3x3 weights only)
+        if (vs_k3x_toeplitz(rows, c_pad, gemm_taps)) return 9ll * 3 * 64 * 8;
         const int CK = vs_k3x_ck(c_pad);
         return (long long)((rows + 15) / 16) * (c_pad / CK) * ((gemm_taps * CK + 31) / 32) * 3 * 64 * 8;
     }
@@ -185,7 +214,7 @@ extern "C" int vs_pack_weight(const float* src, void* dst, int d0, int d1, int n
     const int blocks = vs_ceil_div(total / (dtype == VS_F32 ? 4 : 8), 256);      // one thread per 16-byte fragment
     if (dtype == VS_F32X3) {
         hipLaunchKernelGGL(pack_weight_limbs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst, d0, d1, ntaps, c_pad, form, total,
-                           vs_k3x_ck(c_pad));
+                           vs_k3x_toeplitz(rows, c_pad, gemm_taps) ? -1 : vs_k3x_ck(c_pad));
         VS_CHECK_LAUNCH();
         return VS_OK;
     }
