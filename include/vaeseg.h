@@ -337,6 +337,15 @@ int vs_softmax2_dropout_bwd(const float* prob, const float* gprob, void* glogit,
  * `dtype`, channels 0..1 used, may be NULL) — the gradients of prob and of its channels-last copy (vs_conv_k3_softmax2_cl_fwd). */
 int vs_softmax2_cl_bwd(const float* prob, const float* gprob, const void* gprob_cl, void* glogit, int n, long long voxels,
                        int c_pad, int dtype, float drop_p, unsigned long long drop_seed, void* stream);
+/* nn.Softmax(dim=1) over n_class = 1..8 classes as its own pass (joint_model.py:225,266 / 367,388 with a label set of more than one structure:
+ * main_source.py:92-93 makes n_class = 1 + the number of --pan_index entries; the two-class case has the fused kernels above).
+ * fwd: channels 0..n_class-1 of channels-last logits [n][v][c_pad] -> planar fp32 prob [n][n_class][v]; drop_p > 0 first applies
+ * F.dropout to the logits (joint_model.py:386-387; element index = planar index into [n][n_class][v]).
+ * bwd: glogit[n,v,k] = p_k (g_k - sum_j p_j g_j) (then the dropout's backward), written channels-last with c_pad channels, k >= n_class zero. */
+int vs_softmax_cl_fwd(const void* logits, float* prob, int n, long long voxels, int c_pad, int n_class, int dtype, float drop_p,
+                      unsigned long long drop_seed, void* stream);
+int vs_softmax_cl_bwd(const float* prob, const float* gprob, void* glogit, int n, long long voxels, int c_pad, int n_class, int dtype,
+                      float drop_p, unsigned long long drop_seed, void* stream);
 /* label (float, values 0..n_class-1) [N][1][V] -> one-hot planar fp32 [N][n_class][V]   (main_source.py:449-451) */
 int vs_onehot(const float* label, float* out, int n, long long voxels, int n_class, void* stream);
 /* mode 0: (a >= 0.5) ; mode 1: a>hi -> 1, a<lo -> 0, else a        (utils/evaluation.py:9-18) */

@@ -404,10 +404,10 @@ def _vae64(dt):
     return d
 
 
-def joint_case(side, native, dt=torch.float32):
+def joint_case(side, native, dt=torch.float32, n_class=2):
     """joint_train step (main_source.py:449-471,660) on the reference Joint."""
-    seg = RM.Segmentation(n_channels=1, n_class=2, norm_type=1)
-    vae = RM.VAE(n_channels=2, n_class=2, norm_type=1, dim=128)
+    seg = RM.Segmentation(n_channels=1, n_class=n_class, norm_type=1)
+    vae = RM.VAE(n_channels=n_class, n_class=n_class, norm_type=1, dim=128)
     joint = RM.Joint(models=[seg, vae])
     if not native:
         fwd = composed_vae(vae, side // 32)
@@ -423,32 +423,60 @@ def gold_joint(side, batch_size, name):
     save(name, both_precisions(lambda dt: _joint(side, batch_size, name, dt)))
 
 
-def _joint(side, batch_size, name, dt):
+def _joint(side, batch_size, name, dt, n_class=2):
     d = {}
     native = side == 128
-    joint, fwd = joint_case(side, native, dt)
-    img, lab = O.synthetic_image(batch_size, side, seed=2).to(dt), O.synthetic_label(batch_size, side, seed=3)
-    batch = {"img": img, "gt": O.one_hot(lab).to(dt)}
+    joint, fwd = joint_case(side, native, dt, n_class)
+    img, lab = O.synthetic_image(batch_size, side, seed=2).to(dt), O.synthetic_label(batch_size, side, seed=3, n_class=n_class)
+    batch = {"img": img, "gt": O.one_hot(lab, n_class).to(dt)}
     t0 = time.time()
     if native:
         batch = joint(batch, "img", "pred", "recon")
     else:
         batch = joint.Seg(batch, "img", "pred")
         batch["recon"], batch["mean"], batch["std"] = fwd(batch["pred"])
-    recon_loss = 1 - main_source_avg_dsc(batch["pred"], batch["recon"], 1, 2)
-    dsc_loss = 1 - main_source_avg_dsc(batch["pred"], batch["gt"], 1, 2)
+    recon_loss = 1 - main_source_avg_dsc(batch["pred"], batch["recon"], 1, n_class)
+    dsc_loss = 1 - main_source_avg_dsc(batch["pred"], batch["gt"], 1, n_class)
     final = 0.1 * recon_loss + dsc_loss
     final.backward()
     print("  %s fwd+bwd %.1fs" % (name, time.time() - t0))
     d["recon_loss"], d["dice_loss"], d["final"] = (recon_loss.detach().numpy(), dsc_loss.detach().numpy(),
                                                    final.detach().numpy())
-    d["recon_loss_eps1e6"] = (1 - REV.avg_dsc(batch, "pred", "recon", botindex=1, topindex=2)).detach().numpy()
+    d["recon_loss_eps1e6"] = (1 - REV.avg_dsc(batch, "pred", "recon", botindex=1, topindex=n_class)).detach().numpy()
     d["kl"] = REV.KLloss(batch).detach().numpy()
     d["mean"], d["std"] = batch["mean"].detach().numpy(), batch["std"].detach().numpy()
     put(d, "pred", batch["pred"], 512)
     put(d, "recon", batch["recon"], 512)
     put_grads(d, "seg", joint.Seg)
     d["vae_grads_none"] = np.asarray(all(p.grad is None for p in joint.Vae.parameters()))
+    return d
+
+
+def gold_multiclass():
+    """More than one labelled structure (main_source.py:92-93: n_class = 1 + the number of --pan_index entries): a seg_train step with four
+    classes at 32^3 and a joint_train step with three classes at 64^3, both on the unmodified reference modules."""
+    d = {}
+    for k, v in both_precisions(_seg32_c4).items():
+        d["seg32_c4/" + k] = v
+    for k, v in both_precisions(lambda dt: _joint(64, 2, "joint64_c3", dt, n_class=3)).items():
+        d["joint64_c3/" + k] = v
+    save("multiclass", d)
+
+
+def _seg32_c4(dt):
+    d = {}
+    seg = RM.Segmentation(n_channels=1, n_class=4, norm_type=1)
+    O.deterministic_fill_(seg, seed=0)
+    seg = seg.to(dt)
+    img, lab = O.synthetic_image(2, 32, seed=2).to(dt), O.synthetic_label(2, 32, seed=3, n_class=4)
+    batch = {"img": img, "gt": O.one_hot(lab, 4).to(dt)}
+    batch = seg(batch, "img", "pred")
+    dsc = 1 - main_source_avg_dsc(batch["pred"], batch["gt"], 1, 4)
+    dsc.backward()
+    d["dice_loss"] = dsc.detach().numpy()
+    d["dice_loss_eps1e6"] = (1 - REV.avg_dsc(batch, "pred", "gt", botindex=1, topindex=4)).detach().numpy()
+    put(d, "pred", batch["pred"], 256)
+    put_grads(d, "seg", seg)
     return d
 
 
@@ -807,6 +835,7 @@ CASES = {
     "blocks_norm": gold_blocks_norm,
     "seg32_bn": gold_seg32_bn,
     "gs": gold_gs,
+    "multiclass": gold_multiclass,
 }
 
 if __name__ == "__main__":

@@ -759,23 +759,27 @@ def synthetic_image(batch, side, seed=2):
     return torch.from_numpy(np.clip(g, -1, 1).astype(np.float32)).view(batch, 1, side, side, side)
 
 
-def synthetic_label(batch, side, seed=3, kind="ellipsoid"):
-    """(B,1,S,S,S) float labels in {0,1}: a centred ellipsoid with a hashed ragged rim, or Bernoulli(0.1)."""
+def synthetic_label(batch, side, seed=3, kind="ellipsoid", n_class=2):
+    """(B,1,S,S,S) float labels in {0..n_class-1}: a centred ellipsoid with a hashed ragged rim (n_class > 2: nested ellipsoidal shells,
+    label k inside the k-th), or Bernoulli(0.1)."""
     n = batch * side ** 3
     u = hashed_uniform(n, 2001, seed).reshape(batch, side, side, side)
     if kind == "bernoulli":
-        lab = (u < 0.1)
+        lab = (u < 0.1).astype(np.float32)
     else:
         ax = (np.arange(side, dtype=np.float32) + 0.5) / side - 0.5
         z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
         r = (z / 0.30) ** 2 + (y / 0.22) ** 2 + (x / 0.36) ** 2
-        lab = (r[None] + 0.35 * (u - 0.5)) < 1.0
+        rr = r[None] + 0.35 * (u - 0.5)
+        lab = np.zeros(rr.shape, dtype=np.float32)
+        for k in range(1, n_class):
+            lab += rr < ((n_class - k) / (n_class - 1.0)) ** 2          # k = 1: the threshold 1.0 of the two-class volume
     return torch.from_numpy(lab.astype(np.float32)).view(batch, 1, side, side, side)
 
 
-def build_joint(spatial, dim=128, seed=0):
-    seg = Segmentation(n_channels=1, n_class=2, norm_type=1)
-    vae = VAE(n_channels=2, n_class=2, norm_type=1, dim=dim, spatial=spatial)
+def build_joint(spatial, dim=128, seed=0, n_class=2):
+    seg = Segmentation(n_channels=1, n_class=n_class, norm_type=1)
+    vae = VAE(n_channels=n_class, n_class=n_class, norm_type=1, dim=dim, spatial=spatial)
     joint = Joint([seg, vae])
     deterministic_fill_(joint, seed=seed)
     for p in joint.Vae.parameters():

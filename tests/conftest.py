@@ -22,7 +22,7 @@ BOTH_LIBS = {
     "test_gpu_up": {"test_up_composed_vs_cpu_autograd", "test_up_composed_weight_gradients_vs_cpu_autograd",
                     "test_up_block_module_uses_composed_path_when_frozen", "test_trainable_composed_up_multi_step_matches_two_launch_form"},
     "test_gpu_ops": {"test_conv_k3_fwd_bwd_large", "test_conv_k3_fwd_bwd", "test_conv_k3_small_volume_odd_chunk_counts", "test_conv_k2s2_fwd_bwd",
-                     "test_conv_transpose_fwd_bwd", "test_out_block_softmax", "test_materialize_skip_add", "test_linear_layers",
+                     "test_conv_transpose_fwd_bwd", "test_out_block_softmax", "test_softmax_pass_with_logit_dropout", "test_materialize_skip_add", "test_linear_layers",
                      "test_reparam_kl_dice_bce_label_ops", "test_dice_loss_sum_matches_reference_spelling", "test_weight_used_several_times_in_one_backward"},
     "test_gpu_model": {"test_bf16_mode_joint96_close_to_fp32_reference", "test_bf16_joint_step_same_with_and_without_the_channels_last_prediction",
                        "test_sgd_step_and_graph_replay_match_eager"},

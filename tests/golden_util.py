@@ -11,6 +11,11 @@ def load(name):
     return dict(np.load(os.path.join(GOLD, name + ".npz")))
 
 
+def sub(gold, prefix):
+    """The keys of one case of a multi-case fixture ('seg32_c4/...'), prefix stripped."""
+    return {k[len(prefix):]: v for k, v in gold.items() if k.startswith(prefix)}
+
+
 def sample_idx(n, k=64):
     if n <= k:
         return np.arange(n)

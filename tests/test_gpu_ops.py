@@ -183,13 +183,15 @@ def test_conv_transpose_fwd_bwd(case, lazy, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_out_block_softmax(dtype):
+@pytest.mark.parametrize("nc", [2, 1, 3, 4, 8])
+def test_out_block_softmax(dtype, nc):
+    """nc = 2: the fused epilogue; other class counts (main_source.py:92-93): the plain conv + vs_softmax_cl_fwd / _bwd."""
     ops = _ops()
     n, d, h, w = 2, 6, 8, 20
     x = rnd(n, 8, d, h, w, seed=12)
-    wt = rnd(2, 8, 3, 3, 3, seed=13, scale=0.3)
-    b = rnd(2, seed=14, scale=0.2)
-    gp = rnd(n, 2, d, h, w, seed=15)
+    wt = rnd(nc, 8, 3, 3, 3, seed=13, scale=0.3)
+    b = rnd(nc, seed=14, scale=0.2)
+    gp = rnd(n, nc, d, h, w, seed=15)
     xq, wq, bq = q(x, dtype).requires_grad_(True), q(wt, dtype).requires_grad_(True), b.clone().requires_grad_(True)
     p_ref = torch.softmax(F.conv3d(in_relu(xq), wq, bq, padding=1), dim=1)
     (p_ref * gp).sum().backward()
@@ -204,6 +206,47 @@ def test_out_block_softmax(dtype):
     assert relerr(from_cl(x_cl.grad, 8), xq.grad) < tol * 4
     assert relerr(w_gpu.grad.cpu(), wq.grad) < tol * 4
     assert relerr(b_gpu.grad.cpu(), bq.grad) < tol * 4
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("nc,cp", [(3, 8), (5, 8), (8, 8), (3, 16)])
+def test_softmax_pass_with_logit_dropout(dtype, nc, cp):
+    """vs_softmax_cl_fwd / _bwd with the logit dropout of joint_model.py:386-387: against torch on the same logits times the mask the library
+    exports for the same seed (vs_dropout_mask, element index = planar index)."""
+    ops = _ops()
+    from vae_segmentation_amd._lib import check, lib
+    n, d, h, w = 2, 5, 6, 7
+    vox = d * h * w
+    logits = rnd(n, nc, d, h, w, seed=70, scale=3.0)
+    gp = rnd(n, nc, d, h, w, seed=71)
+    lq = q(logits, dtype)
+    l_cl = to_cl(logits, cp, dtype)
+    if cp > nc:
+        l_cl[..., nc:] = 7.0                      # whatever sits in the padded channels must not reach the probabilities
+    seed, pdrop = 4242, 0.3
+    mask = torch.empty(n * nc * vox, dtype=torch.float32, device="cuda")
+    check(lib.vs_dropout_mask(mask.data_ptr(), mask.numel(), pdrop, seed, None), "dropout_mask")
+    mask = mask.view(n, nc, d, h, w).cpu()
+    assert 0.5 < (mask > 0).float().mean() < 0.9
+    for p_use, m in ((0.0, torch.ones_like(mask)), (pdrop, mask)):
+        lr = lq.clone().requires_grad_(True)
+        p_ref = torch.softmax(lr * m, dim=1)
+        (p_ref * gp).sum().backward()
+        prob = torch.empty((n, nc, d, h, w), dtype=torch.float32, device="cuda")
+        check(lib.vs_softmax_cl_fwd(l_cl.data_ptr(), prob.data_ptr(), n, vox, cp, nc, ops.vs_dtype(l_cl), p_use, seed, None), "softmax_cl_fwd")
+        gl = torch.full((n, d, h, w, cp), 9.0, dtype=dtype, device="cuda")
+        check(lib.vs_softmax_cl_bwd(prob.data_ptr(), gp.cuda().contiguous().data_ptr(), gl.data_ptr(), n, vox, cp, nc, ops.vs_dtype(l_cl), p_use, seed, None),
+              "softmax_cl_bwd")
+        torch.cuda.synchronize()
+        assert relerr(prob.cpu(), p_ref.detach()) < 1e-5
+        assert float((prob.sum(1) - 1).abs().max()) < 1e-5
+        assert relerr(from_cl(gl, nc), lr.grad) < TOL[dtype]
+        if cp > nc:
+            assert float(gl[..., nc:].float().abs().max()) == 0.0
+    # refused arguments
+    assert lib.vs_softmax_cl_fwd(l_cl.data_ptr(), prob.data_ptr(), n, vox, cp, 9, ops.vs_dtype(l_cl), 0.0, 0, None) != 0
+    assert lib.vs_softmax_cl_fwd(l_cl.data_ptr(), prob.data_ptr(), n, vox, 12, nc, ops.vs_dtype(l_cl), 0.0, 0, None) != 0
+    assert lib.vs_softmax_cl_bwd(prob.data_ptr(), None, gl.data_ptr(), n, vox, cp, nc, ops.vs_dtype(l_cl), 0.0, 0, None) != 0
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
                  "vs_binarize", "vs_bce_fwd", "vs_sgd_momentum_multi", "vs_adam_multi", "vs_ema_multi", "vs_strerror",
                  "vs_version", "vs_conv_wgrad_workspace_bytes", "vs_copy_scale_multi", "vs_conv_gather_bwd_data",
                  "vs_conv_scatter_bwd_data", "vs_pack_weight_multi", "vs_dropout", "vs_softmax2_dropout_bwd",
-                 "vs_conv_k3_softmax2_dropout_fwd", "vs_conv_wgrad_multi", "vs_conv_wgrad_multi_workspace_bytes",
+                 "vs_conv_k3_softmax2_dropout_fwd", "vs_softmax_cl_fwd", "vs_softmax_cl_bwd", "vs_conv_wgrad_multi", "vs_conv_wgrad_multi_workspace_bytes",
                  "vs_dice_loss_multi_fwd", "vs_dice_loss_multi_bwd", "vs_dice_loss_multi_scratch_doubles"):
         assert must in protos, must
     assert _lib.lib.vs_version() == 205
@@ -135,8 +135,9 @@ def test_module_surface_on_cpu_is_constructible_but_not_runnable():
     assert list(gs.state_dict().keys()) == list(M.Segmentation(1, 2, norm_type=1).state_dict().keys())
     with pytest.raises(ValueError):
         M.Segmentation(1, 2, norm_type=4)
-    with pytest.raises(NotImplementedError):
-        M.Segmentation(1, 3, norm_type=1)
+    assert M.Segmentation(1, 3, norm_type=1).out_block.weight.shape[0] == 3 and M.VAE(5, 5, norm_type=1, dim=128).in_block.conv[0].weight.shape[1] == 5
+    with pytest.raises(NotImplementedError):                 # the probabilities travel in one 8-channel fragment
+        M.Segmentation(1, 9, norm_type=1)
 
 
 WORKER = r"""

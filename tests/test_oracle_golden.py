@@ -194,6 +194,26 @@ def test_seg32():
     assert l4.item() == pytest.approx(float(g["dice_loss_eps1e4"]), rel=1e-6)
 
 
+def test_multiclass_seg32_four_classes_and_joint64_three_classes():
+    """n_class = 1 + the number of labelled structures (main_source.py:92-93): the oracle against the reference's modules for 4 and 3 classes."""
+    g = G.sub(G.load("multiclass"), "seg32_c4/")
+    seg = O.deterministic_fill_(O.Segmentation(1, 4, norm_type=1), seed=0)
+    loss, aux = O.seg_train_losses(seg, O.synthetic_image(2, 32, 2), O.synthetic_label(2, 32, 3, n_class=4), n_class=4)
+    loss.backward()
+    assert loss.item() == pytest.approx(float(g["dice_loss"]), rel=1e-6)
+    G.check_tensor(g, "pred", aux["batch"]["pred"], k=256, rtol=1e-5)
+    G.check_grads(g, "seg", [(n, p.grad) for n, p in seg.named_parameters()], rtol=1e-5)
+    g = G.sub(G.load("multiclass"), "joint64_c3/")
+    joint = O.build_joint(64, n_class=3)
+    final, aux = O.joint_train_losses(joint, O.synthetic_image(2, 64, 2), O.synthetic_label(2, 64, 3, n_class=3), n_class=3)
+    final.backward()
+    assert final.item() == pytest.approx(float(g["final"]), rel=1e-6)
+    assert aux["recon_loss"].item() == pytest.approx(float(g["recon_loss"]), rel=1e-5)
+    G.check_tensor(g, "pred", aux["batch"]["pred"], k=512, rtol=1e-5)
+    G.check_tensor(g, "recon", aux["batch"]["recon"], k=512, rtol=1e-5)
+    G.check_grads(g, "seg", [(n, p.grad) for n, p in joint.Seg.named_parameters()], rtol=1e-4)
+
+
 def test_seg96():
     g = G.load("seg96")
     seg = O.deterministic_fill_(O.Segmentation(1, 2, norm_type=1), seed=0)

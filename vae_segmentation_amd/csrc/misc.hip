@@ -113,6 +113,119 @@ extern "C" int vs_softmax2_cl_bwd(const float* prob, const float* gprob, const v
     return VS_OK;
 }
 
+// ---- softmax over n_class = 1..8 classes as its own pass ------------------------------------------
+// The two-class case (every configuration BASELINE names) has the fused out_block epilogue; a label set with more structures
+// (main_source.py:92-93: n_class = 1 + number of --pan_index entries) takes the plain 3x3x3 conv and these two kernels.
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&f)[8]) {
+    constexpr int EPL = ET<T>::EPL;
+#pragma unroll
+    for (int k = 0; k < 8 / EPL; ++k) {
+        float part[EPL];
+        frag_unpack(*(const u32x4*)(p + k * EPL), part, (T*)nullptr);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) f[k * EPL + j] = part[j];
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&f)[8]) {
+    constexpr int EPL = ET<T>::EPL;
+#pragma unroll
+    for (int k = 0; k < 8 / EPL; ++k) {
+        float part[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) part[j] = f[k * EPL + j];
+        *(u32x4*)(p + k * EPL) = frag_pack(part, (T*)nullptr);
+    }
+}
+
+template <typename T>
+__global__ void softmaxn_fwd_kernel(const T* __restrict__ logits, float* __restrict__ prob, long long voxels, int c_pad, int nc, long long total,
+                                    float drop_p, unsigned long long drop_seed) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / voxels, v = i - n * voxels;
+        float l[8];
+        load8(logits + i * c_pad, l);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c < nc) {
+                if (drop_p > 0.f) l[c] *= dropout_scale(drop_seed, ((unsigned long long)n * nc + c) * voxels + v, drop_p);
+                mx = fmaxf(mx, l[c]);
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            l[c] = c < nc ? expf(l[c] - mx) : 0.f;
+            sum += l[c];
+        }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < nc) prob[(n * nc + c) * voxels + v] = l[c] * inv;
+    }
+}
+
+template <typename T>
+__global__ void softmaxn_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ gprob, T* __restrict__ gl, long long voxels, int c_pad, int nc,
+                                    long long total, float drop_p, unsigned long long drop_seed) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / voxels, v = i - n * voxels;
+        float p[8], g[8], dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            p[c] = c < nc ? prob[(n * nc + c) * voxels + v] : 0.f;
+            g[c] = c < nc ? gprob[(n * nc + c) * voxels + v] : 0.f;
+            dot += p[c] * g[c];
+        }
+        float f[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            f[c] = p[c] * (g[c] - dot);
+            if (drop_p > 0.f && c < nc) f[c] *= dropout_scale(drop_seed, ((unsigned long long)n * nc + c) * voxels + v, drop_p);
+        }
+        T* o = gl + i * c_pad;
+        store8(o, f);
+        const u32x4 z = u32x4{0u, 0u, 0u, 0u};
+        for (int c0 = 8; c0 < c_pad; c0 += ET<T>::EPL) *(u32x4*)(o + c0) = z;
+    }
+}
+
+static int softmaxn_check(const void* a, const void* b, int n, long long voxels, int c_pad, int n_class, int dtype, float drop_p) {
+    if (!a || !b || n <= 0 || voxels <= 0 || drop_p < 0.f || drop_p >= 1.f) return VS_EINVAL;
+    if (c_pad <= 0 || c_pad % 8 || n_class < 1 || n_class > 8) return VS_ESHAPE;
+    if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
+    return VS_OK;
+}
+
+extern "C" int vs_softmax_cl_fwd(const void* logits, float* prob, int n, long long voxels, int c_pad, int n_class, int dtype, float drop_p,
+                                 unsigned long long drop_seed, void* stream) {
+    const int rc = softmaxn_check(logits, prob, n, voxels, c_pad, n_class, dtype, drop_p);
+    if (rc) return rc;
+    const long long total = (long long)n * voxels;
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(softmaxn_fwd_kernel<T>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, (const T*)logits, prob, voxels, c_pad, n_class, total, drop_p, drop_seed);
+    });
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+extern "C" int vs_softmax_cl_bwd(const float* prob, const float* gprob, void* glogit, int n, long long voxels, int c_pad, int n_class, int dtype,
+                                 float drop_p, unsigned long long drop_seed, void* stream) {
+    const int rc = softmaxn_check(prob, glogit, n, voxels, c_pad, n_class, dtype, drop_p);
+    if (rc) return rc;
+    if (!gprob) return VS_EINVAL;
+    const long long total = (long long)n * voxels;
+    dispatch_t(dtype, [&](auto* tag) {
+        using T = TAG_T(tag);
+        hipLaunchKernelGGL(softmaxn_bwd_kernel<T>, GRID1D(total), dim3(256), 0, (hipStream_t)stream, prob, gprob, (T*)glogit, voxels, c_pad, n_class, total, drop_p, drop_seed);
+    });
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
 // ---- one-hot / binarize ---------------------------------------------------------------------------
 __global__ void onehot_kernel(const float* __restrict__ label, float* __restrict__ out, long long voxels, int n_class, long long total) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {

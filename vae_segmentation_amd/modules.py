@@ -255,6 +255,13 @@ def _run_block(blk, a):
     return Act(raw, stats)
 
 
+def _check_n_class(n_class):
+    """n_class = 1 + the number of labelled structures (main_source.py:92-93).  The probabilities, their gradient and the VAE's input travel in one
+    8-channel fragment, so up to 8 classes are native (two classes — every BASELINE configuration — through the fused out_block epilogue)."""
+    if not 1 <= int(n_class) <= 8:
+        raise NotImplementedError("native softmax / label kernels hold n_class in one 8-channel fragment: 1..8, got %r" % (n_class,))
+
+
 def _dropout(a, p):
     """F.dropout(x, p, training=True) after an Up block (joint_model.py:256-264,379-385): the lazy activation is
     materialised, masked and scaled; p == 0 (the reference default, main_target.py:70-71) costs nothing."""
@@ -272,8 +279,7 @@ class VAE(nn.Module):
     def __init__(self, n_channels, n_class, norm_type=2, n_fmaps=[8, 16, 32, 64, 128, 256], dim=1024, soft=False,
                  spatial=128):
         super().__init__()
-        if n_class != 2:
-            raise NotImplementedError("native softmax / label kernels are written for n_class == 2")
+        _check_n_class(n_class)
         if spatial % 32 or spatial < 64:
             raise ValueError("spatial must be a multiple of 32 and >= 64 (InstanceNorm needs > 1 voxel at down5)")
         f = list(n_fmaps)
@@ -343,8 +349,7 @@ class Segmentation(nn.Module):
 
     def __init__(self, n_channels, n_class, norm_type=2, n_fmaps=[8, 16, 32, 64, 128, 256]):
         super().__init__()
-        if n_class != 2:
-            raise NotImplementedError("native softmax / label kernels are written for n_class == 2")
+        _check_n_class(n_class)
         f = list(n_fmaps)
         self.in_block = Conv(n_channels, f[0], norm_type=norm_type, soft=False)
         self.down1 = Down(f[0], f[1], norm_type=norm_type, soft=False)
@@ -460,8 +465,7 @@ class Fusion(nn.Module):
 
     def __init__(self, n_channels_img, n_channels_mask, n_class, norm_type=2, n_fmaps=[8, 16, 32, 64, 128, 256]):
         super().__init__()
-        if n_class != 2:
-            raise NotImplementedError("native softmax / label kernels are written for n_class == 2")
+        _check_n_class(n_class)
         f = list(n_fmaps)
         self.in_block = Conv(n_channels_img, f[0], norm_type=norm_type, soft=False)
         self.down1 = Down(f[0], f[1], norm_type=norm_type, soft=False)

@@ -10,7 +10,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .modules import Act, _DEFAULT_DTYPE, _activation, _as_act, _as_tensor
+from .modules import Act, _DEFAULT_DTYPE, _activation, _as_act, _as_tensor, _check_n_class
 
 
 def _conv_act(conv, actm, a):
@@ -185,8 +185,7 @@ class Segmentation_GS(nn.Module):
 
     def __init__(self, n_channels, n_class, norm_type=2, n_fmaps=[8, 16, 32, 64, 128, 256]):
         super().__init__()
-        if n_class != 2:
-            raise NotImplementedError("native softmax / label kernels are written for n_class == 2")
+        _check_n_class(n_class)
         f = list(n_fmaps)
         self.in_block = Conv_GS(n_channels, f[0], num_group=2, soft=False)
         self.down1 = Down_GS(f[0], f[1], num_group=2, soft=False)
@@ -227,5 +226,5 @@ class Segmentation_GS(nn.Module):
         # the 1x1x1 out_block2 as the centre tap of a 3x3x3 kernel whose other 26 taps are zero: the same sums, on the existing conv
         w3 = F.pad(self.out_block2.weight, (1, 1, 1, 1, 1, 1))
         logits, _ = ops.ConvK3.apply(h.raw, None, w3, self.out_block2.bias, True)
-        data_dict[out_key] = ops.Softmax2.apply(logits)
+        data_dict[out_key] = ops.Softmax2.apply(logits, self.out_block2.weight.shape[0])
         return data_dict

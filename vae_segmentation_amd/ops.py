@@ -1043,7 +1043,10 @@ class ConvK3(torch.autograd.Function):
         wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, x.shape[-1], k3_pack_dtype(x))
         # live_bias: the general norm path (NormAct) — under BatchNorm in eval mode the bias is not cancelled by the normalisation
         ctx.live_bias = bool(live_bias) and bias is not None
-        y, ys = conv_gather(x, xs, wp, bias if ctx.live_bias else None, cpad(cout), VS_CONV_K3, True, real_channels=(cin, cout))
+        b_use = bias if ctx.live_bias else None
+        if b_use is not None and cout < cpad(cout):
+            b_use = torch.nn.functional.pad(b_use.detach().float(), (0, cpad(cout) - cout))      # the kernels read one bias per padded output row
+        y, ys = conv_gather(x, xs, wp, b_use, cpad(cout), VS_CONV_K3, True, real_channels=(cin, cout))
         ctx.save_for_backward(x, xs, weight)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias                   # a Parameter (long-lived leaf): only its gradient slot is looked up in backward
@@ -1093,19 +1096,26 @@ class ConvK3(torch.autograd.Function):
 
 
 class ConvK3Softmax(torch.autograd.Function):
-    """out_block (3x3x3 conv, live bias) + Softmax(dim=1) over 2 classes -> planar fp32 probabilities
-    (joint_model.py:224-225,265-266 / 366-367,386-388)."""
+    """out_block (3x3x3 conv, live bias) + Softmax(dim=1) -> planar fp32 probabilities (joint_model.py:224-225,265-266 / 366-367,386-388):
+    ONE fused launch for two classes (every BASELINE configuration), conv + softmax pass for 1 or 3..8 classes."""
 
     @staticmethod
     def forward(ctx, x, xs, weight, bias, drop_p=0.0, drop_seed=0):
         _require_cuda(x, weight)
-        if weight.shape[0] != 2:
-            raise NotImplementedError("fused out_block+softmax kernel is written for n_class == 2")
+        nc = weight.shape[0]
+        if not 1 <= nc <= 8:
+            raise NotImplementedError("out_block + softmax: n_class must be 1..8, got %d" % nc)
         n, d, h, w, c = x.shape
         wp = pack_weight_cached(weight, VS_PACK_ROWS_D0, c, k3_pack_dtype(x))
-        prob = torch.empty((n, 2, d, h, w), dtype=torch.float32, device=x.device)
-        check(lib.vs_conv_k3_softmax2_dropout_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), prob.data_ptr(), n, d, h, w, c,
-                                                  vs_dtype(x), EPS_IN, float(drop_p), drop_seed, _stream()), "conv_k3_softmax2_fwd")
+        prob = torch.empty((n, nc, d, h, w), dtype=torch.float32, device=x.device)
+        if nc == 2:
+            check(lib.vs_conv_k3_softmax2_dropout_fwd(x.data_ptr(), _p(xs), wp.data_ptr(), _p(bias), prob.data_ptr(), n, d, h, w, c,
+                                                      vs_dtype(x), EPS_IN, float(drop_p), drop_seed, _stream()), "conv_k3_softmax2_fwd")
+        else:       # more structures than one (main_source.py:92-93): the plain conv, then the softmax as its own pass
+            bias8 = None if bias is None else torch.nn.functional.pad(bias.detach().float(), (0, 8 - nc))      # the conv kernels read one bias per padded row
+            logits, _ = conv_gather(x, xs, wp, bias8, 8, VS_CONV_K3, False, real_channels=(weight.shape[1], nc))
+            check(lib.vs_softmax_cl_fwd(logits.data_ptr(), prob.data_ptr(), n, d * h * w, 8, nc, vs_dtype(x), float(drop_p), drop_seed, _stream()),
+                  "softmax_cl_fwd")
         ctx.save_for_backward(x, xs, weight, prob)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
@@ -1118,21 +1128,26 @@ class ConvK3Softmax(torch.autograd.Function):
         x, xs, weight, prob = ctx.saved_tensors
         n, d, h, w, c = x.shape
         gprob = _contig(gprob.float())
+        nc = weight.shape[0]
         gl = torch.empty((n, d, h, w, 8), dtype=x.dtype, device=x.device)
-        check(lib.vs_softmax2_dropout_bwd(prob.data_ptr(), gprob.data_ptr(), gl.data_ptr(), n, d * h * w, 8, vs_dtype(x),
-                                          ctx.drop[0], ctx.drop[1], _stream()), "softmax2_bwd")
+        if nc == 2:
+            check(lib.vs_softmax2_dropout_bwd(prob.data_ptr(), gprob.data_ptr(), gl.data_ptr(), n, d * h * w, 8, vs_dtype(x),
+                                              ctx.drop[0], ctx.drop[1], _stream()), "softmax2_bwd")
+        else:
+            check(lib.vs_softmax_cl_bwd(prob.data_ptr(), gprob.data_ptr(), gl.data_ptr(), n, d * h * w, 8, nc, vs_dtype(x),
+                                        ctx.drop[0], ctx.drop[1], _stream()), "softmax_cl_bwd")
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, k3_pack_dtype(x))
             if xs is not None:
-                gx = conv_bwd_data_lazy(gl, wpb, x, xs, VS_CONV_K3, real_channels=(2, weight.shape[1]), defer=ctx.defer)
+                gx = conv_bwd_data_lazy(gl, wpb, x, xs, VS_CONV_K3, real_channels=(nc, weight.shape[1]), defer=ctx.defer)
             else:
                 gx, _ = conv_gather(gl, None, wpb, None, c, VS_CONV_K3, False)
         if ctx.needs_input_grad[2]:
-            gw, gb = _side_grads(weight, (gl, x, xs), (gl, None, x, xs, 2, weight.shape[1], VS_CONV_K3),
-                                 (gl, 2) if ctx.has_bias and ctx.needs_input_grad[3] else None, ctx.bias_ref)
+            gw, gb = _side_grads(weight, (gl, x, xs), (gl, None, x, xs, nc, weight.shape[1], VS_CONV_K3),
+                                 (gl, nc) if ctx.has_bias and ctx.needs_input_grad[3] else None, ctx.bias_ref)
         elif ctx.has_bias and ctx.needs_input_grad[3]:
-            gb = bias_grad(gl, 2)
+            gb = bias_grad(gl, nc)
         return gx, None, gw, gb, None, None
 
 
@@ -1626,14 +1641,17 @@ class UpsampleTrilinear(torch.autograd.Function):
 
 
 class Softmax2(torch.autograd.Function):
-    """nn.Softmax(dim=1) over two classes as its own pass: channels-last logits (channels 0, 1) -> planar fp32 (N, 2, D, H, W)"""
+    """nn.Softmax(dim=1) as its own pass: channels-last logits (channels 0..n_class-1) -> planar fp32 (N, n_class, D, H, W); n_class 1..8"""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, n_class=2):
         _require_cuda(x)
         n, d, h, w, c = x.shape
-        prob = torch.empty((n, 2, d, h, w), dtype=torch.float32, device=x.device)
-        check(lib.vs_softmax2_fwd(x.data_ptr(), prob.data_ptr(), n, d * h * w, c, vs_dtype(x), _stream()), "softmax2_fwd")
+        prob = torch.empty((n, n_class, d, h, w), dtype=torch.float32, device=x.device)
+        if n_class == 2:
+            check(lib.vs_softmax2_fwd(x.data_ptr(), prob.data_ptr(), n, d * h * w, c, vs_dtype(x), _stream()), "softmax2_fwd")
+        else:
+            check(lib.vs_softmax_cl_fwd(x.data_ptr(), prob.data_ptr(), n, d * h * w, c, n_class, vs_dtype(x), 0.0, 0, _stream()), "softmax_cl_fwd")
         ctx.save_for_backward(prob)
         ctx.c, ctx.dtype = c, x.dtype
         return prob
@@ -1642,10 +1660,14 @@ class Softmax2(torch.autograd.Function):
     def backward(ctx, gprob):
         (prob,) = ctx.saved_tensors
         gprob = _contig(gprob.float())
-        n, _, d, h, w = prob.shape
+        n, nc, d, h, w = prob.shape
         g = torch.empty((n, d, h, w, ctx.c), dtype=ctx.dtype, device=prob.device)
-        check(lib.vs_softmax2_bwd(prob.data_ptr(), gprob.data_ptr(), g.data_ptr(), n, d * h * w, ctx.c, vs_of(ctx.dtype), _stream()), "softmax2_bwd")
-        return g
+        if nc == 2:
+            check(lib.vs_softmax2_bwd(prob.data_ptr(), gprob.data_ptr(), g.data_ptr(), n, d * h * w, ctx.c, vs_of(ctx.dtype), _stream()), "softmax2_bwd")
+        else:
+            check(lib.vs_softmax_cl_bwd(prob.data_ptr(), gprob.data_ptr(), g.data_ptr(), n, d * h * w, ctx.c, nc, vs_of(ctx.dtype), 0.0, 0, _stream()),
+                  "softmax_cl_bwd")
+        return g, None
 
 
 _DROPOUT_CALLS = [0]
