@@ -348,6 +348,34 @@ def test_bf16_mode_joint96_close_to_fp32_reference():
     assert all(np.isfinite(G.flat64(p.grad)).all() for p in joint.Seg.parameters())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_16bit_joint128_weight_gradients_same_with_and_without_m_packing(dtype, monkeypatch):
+    """The 128^3 joint step (2.1 M voxels per layer: the size from which the weight gradients of the layers with 8 stored output channels take the M-packed
+    form by default, csrc/wgrad.hip g3b_body): every gradient of the default plan equals the unpacked plan's up to the order of the fp32 sums, and the
+    forced-on plan is the default plan bit for bit."""
+    M, O, T = _mods()
+    img, lab = O.synthetic_image(1, 128, 2).cuda(), O.synthetic_label(1, 128, 3).cuda()
+    grads = {}
+    for mode in ("default", "1", "0"):
+        if mode == "default":
+            monkeypatch.delenv("VS_WGRAD_MPACK", raising=False)
+        else:
+            monkeypatch.setenv("VS_WGRAD_MPACK", mode)
+        joint = _build_joint(M, O, 128)
+        M.set_kernel_dtype(joint, dtype)
+        final, _ = T.joint_train_losses(joint, img, lab)
+        final.backward()
+        torch.cuda.synchronize()
+        grads[mode] = {n: p.grad.detach().float().cpu() for n, p in joint.Seg.named_parameters()}
+    for n, g1 in grads["1"].items():
+        assert torch.equal(grads["default"][n], g1), n
+        g0 = grads["0"][n]
+        if float(g0.norm()) > 0:
+            assert G.rel_l2(g1, g0) < 2e-5, (n, G.rel_l2(g1, g0))
+    packed = [n for n in grads["1"] if not torch.equal(grads["1"][n], grads["0"][n])]
+    assert any(n.startswith("in_block") for n in packed) and any(n.startswith("out_block") for n in packed), packed   # the packed layers do differ in the last bits
+
+
 def test_bf16_joint_step_same_with_and_without_the_channels_last_prediction(monkeypatch):
     """Joint.forward (joint_model.py:447-450) feeds Segmentation's prediction to the VAE.  In bf16 mode out_block writes the channels-last copy
     the VAE reads and the softmax backward takes the two gradient parts itself; VS_SOFTMAX_CL=0 spells it with vs_pack_planar,

@@ -435,6 +435,7 @@ GROUP_LAYERS = [  # (kind, N, Cin, Cout, D, H, W) — one backward pass over all
     ("k3", 2, 16, 16, 4, 4, 4), ("k3", 2, 16, 16, 5, 5, 5), ("k3", 2, 16, 16, 6, 6, 6), ("k3", 2, 32, 32, 4, 4, 4),
     ("k3", 2, 32, 32, 5, 5, 5), ("k3", 2, 64, 64, 3, 3, 3), ("k3", 2, 64, 64, 5, 5, 5), ("k3", 2, 128, 64, 3, 3, 3),
     ("k3", 2, 256, 256, 2, 2, 2), ("k3", 2, 16, 16, 20, 24, 40),
+    ("k3", 2, 8, 8, 7, 9, 21), ("k3", 2, 8, 2, 6, 5, 17), ("k3", 1, 3, 8, 5, 6, 33), ("k3", 2, 32, 8, 5, 7, 19),      # 8-channel layers at ragged sizes: the M-packed form's shifted rows at every border
     ("k2", 2, 8, 8, 8, 8, 16), ("k2", 2, 16, 16, 4, 6, 10), ("k2", 2, 64, 64, 2, 2, 6), ("k2", 2, 32, 32, 6, 6, 6),
     ("t2", 2, 16, 16, 4, 4, 8), ("t2", 2, 32, 32, 3, 5, 7), ("t2", 2, 128, 128, 3, 3, 3), ("t2", 2, 8, 8, 4, 4, 4),
 ]
@@ -481,10 +482,13 @@ def _group_layers_backward(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_grouped_weight_gradients_many_layers(dtype):
-    """vs_conv_wgrad_multi (main_source.py:660: the gradients the optimiser step reads): 30 layers of all conv kinds deferred to the end of ONE
+@pytest.mark.parametrize("mpack", ["1", "0"])
+def test_grouped_weight_gradients_many_layers(dtype, mpack, monkeypatch):
+    """vs_conv_wgrad_multi (main_source.py:660: the gradients the optimiser step reads): 34 layers of all conv kinds deferred to the end of ONE
     backward pass and issued as grouped launches — each against F.conv3d / F.conv_transpose3d autograd on the CPU, against the
-    per-layer launches (vs_conv_wgrad), and bitwise reproducible."""
+    per-layer launches (vs_conv_wgrad), and bitwise reproducible.  mpack: the M-packed form of the layers with 8 stored output channels
+    (csrc/wgrad.hip g3b_body; by default only from 2 M voxels on) forced on / off."""
+    monkeypatch.setenv("VS_WGRAD_MPACK", mpack)
     ops = _ops()
     assert ops._GROUP["enabled"]
     got, refs = _group_layers_backward(ops, dtype)

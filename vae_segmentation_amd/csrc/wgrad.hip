@@ -25,7 +25,33 @@ struct G3Params {
     float eps;
     double inv_cnt_p, inv_cnt_q;
     int up_co;                // G3_UP: channels of the fine tensor P points to (Mch = 8 * up_co is its space-to-depth view)
+    unsigned int fd_m[3];     // multiply-shift division (common.h fdiv) by tiles_per_sample, txn * tyn, txn: the tile coordinates of every loop
+    unsigned int fd_s;        //   round cost ~12 scalar instructions instead of ~100 (five 32-bit divisions); shifts packed 8 bits each
+    int mp;                   // 8-channel 3x3x3 layers with 8 stored P channels, 16-bit grouped path: MFMA rows 8..15 carry P shifted by one voxel in x
+                              //   (see g3b_body) — 9 column blocks (dz, dy) x {dx = 0, +1} instead of 14 blocks of two taps
 };
+
+// (m, s) with n / d == (mulhi(n, m) + n) >> s for every 0 <= n < 2^31 (as igemm_k3b.h k3b_fastdiv)
+static inline void g3_fastdiv(G3Params& p) {
+    const int d[3] = {p.tiles_per_sample, p.txn * p.tyn, p.txn};
+    p.fd_s = 0;
+    for (int i = 0; i < 3; ++i) {
+        unsigned int sh = 0;
+        while ((1ll << sh) < d[i]) ++sh;
+        p.fd_m[i] = (unsigned int)((((1ull << (32 + sh)) + (unsigned long long)d[i] - 1) / (unsigned long long)d[i]) - (1ull << 32));
+        p.fd_s |= sh << (8 * i);
+    }
+}
+// tile t -> sample n, tile origin (z0, y0, x0)
+__device__ __forceinline__ void g3_tile_coords(const G3Params& p, int t, int& n, int& z0, int& y0, int& x0) {
+    n = fdiv(t, p.fd_m[0], p.fd_s & 0xff);
+    const int tl = t - n * p.tiles_per_sample;
+    const int tz = fdiv(tl, p.fd_m[1], (p.fd_s >> 8) & 0xff);
+    const int r = tl - tz * p.txn * p.tyn;
+    const int ty = fdiv(r, p.fd_m[2], (p.fd_s >> 16) & 0xff);
+    const int tx = r - ty * p.txn;
+    z0 = tz * 4; y0 = ty * 4; x0 = tx * 16;
+}
 
 template <int CB, int KIND> struct G3Geo {
     static constexpr int NTAPS = KIND != G3_K2S2 ? 27 : 8;
@@ -42,20 +68,22 @@ template <int CB, int KIND> struct G3Geo {
 // Sum the four waves' accumulators in a fixed order (w0+w1+w2+w3: bitwise reproducible) through LDS and write ONE
 // partial slab per workgroup: ws[ks][mb*cbn+cb][k][col][row].  `s_buf` needs NCB*256 floats.
 template <int NCB>
-__device__ __forceinline__ void g3_finish(f32x4 (&acc)[NCB], float* s_buf, float* ws_tile, int wave, int col, int g) {
+__device__ __forceinline__ void g3_finish(f32x4 (&acc)[NCB], float* s_buf, float* ws_tile, int wave, int col, int g, int nk = NCB) {
     float* mine = s_buf + col * 16 + 4 * g;
     for (int w = 0; w < 4; ++w) {
         __syncthreads();
         if (wave == w) {
 #pragma unroll
             for (int k = 0; k < NCB; ++k) {
-                f32x4 v = acc[k];
-                if (w > 0) {
-                    const f32x4 o = *(const f32x4*)(mine + k * 256);
-                    v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                if (k < nk) {                             // uniform: the M-packed form of g3b_body uses the first 9 blocks
+                    f32x4 v = acc[k];
+                    if (w > 0) {
+                        const f32x4 o = *(const f32x4*)(mine + k * 256);
+                        v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                    }
+                    if (w < 3) *(f32x4*)(mine + k * 256) = v;
+                    else *(f32x4*)(ws_tile + (size_t)k * 256 + col * 16 + 4 * g) = v;
                 }
-                if (w < 3) *(f32x4*)(mine + k * 256) = v;
-                else *(f32x4*)(ws_tile + (size_t)k * 256 + col * 16 + 4 * g) = v;
             }
         }
     }
@@ -108,10 +136,8 @@ __device__ __forceinline__ void g3_body(const G3Params& p, const int bx, const i
     u32x4 pv[NP], qv[NITQ];
     unsigned long long okbits = 0;                        // bit b: P fragment b inside the volume; bit NP + b: Q fragment b (up to 4 + 32 of them)
     auto request = [&](int t) {
-        const int n = t / p.tiles_per_sample;
-        const int tl = t - n * p.tiles_per_sample;
-        const int tx = tl % p.txn, ty = (tl / p.txn) % p.tyn, tz = tl / (p.txn * p.tyn);
-        const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+        int n, z0, y0, x0;
+        g3_tile_coords(p, t, n, z0, y0, x0);
         okbits = 0;
         const int pbase = (((n * p.Dp + z0) * p.Hp + y0) * p.Wp + x0) * p.Mch * (int)sizeof(T);
 #pragma unroll
@@ -206,7 +232,7 @@ __device__ __forceinline__ void g3_body(const G3Params& p, const int bx, const i
 
     for (; t < p.total_tiles; t += p.ksplit) {
         __syncthreads();      // previous tile fully consumed (also orders the stats tables on the first pass)
-        commit(t / p.tiles_per_sample);
+        commit(fdiv(t, p.fd_m[0], p.fd_s & 0xff));
         __syncthreads();
         if (t + p.ksplit < p.total_tiles) request(t + p.ksplit);
         // ---- 64 voxels of this wave's z-slice, 4 per MFMA step ----
@@ -258,7 +284,7 @@ __device__ __forceinline__ u32x4 tr_pair(const char* s_base, int off0, int off1)
 // no branches) right after tile t went to LDS, so their latency is covered by tile t's MFMA phase; the lazy operands'
 // normalise+ReLU runs as packed fma / packed max (common.h act8).
 // T: unsigned short (bf16 bits) or vs_half (fp16) — the transposing LDS read moves 16-bit words, whatever they encode
-template <typename T, int CB, int KIND>
+template <typename T, int CB, int KIND, bool MP = false>
 __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const int ks) {
     using GEO = G3Geo<CB, KIND>;
     constexpr int NTAPS = GEO::NTAPS, NCB = GEO::NCB, QY = GEO::QY, QX = GEO::QX, QV = GEO::QV;
@@ -285,8 +311,19 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
     // P fragment b: voxel v = (tid + 256 b) >> 1 of the 4x4x16 tile, channel half `ppart`; Q fragment b: voxel qv of the halo /
     // strided region, 16-byte part `qpart` (constant per thread: 256 % QU == 0)
     const int ppart = tid & 1, qpart = tid % QU;
-    const bool pch_ok = mb * 16 + ppart * 8 < p.Mch, qch_ok = cb * CB + qpart * 8 < p.Cch;
-    int prel[2], pzyx[2];
+    // M-packed form (p.mp: 8 stored P channels, 8-channel Q, 3x3x3): the upper half of the 16 MFMA rows — padding otherwise — carries the SAME 8 channels
+    // one voxel further in x, rows (s, co): sum_v P(v + s) Q(v + t) = dW[t - s].  With column taps dx in {0, +1} the rows s = 0 give dx = 0, +1 and the rows
+    // s = 1 give dx = -1 (and dx = 0 again, dropped by the reduction): 9 column blocks (dz, dy) x {dx = 0 | +1} x 8 channels instead of 14 blocks of two
+    // taps — 18 instead of 28 MFMAs and 36 instead of 56 transposing LDS reads per tile and wave (the kernel is bound by LDS bandwidth and instruction issue).
+    // The shifted fragment is loaded straight from global memory into the slot of channels 8..15, so the P tile needs no halo.
+    // 16-channel Q blocks (a 16 -> 8 layer): the same rows against the taps dx in {0, +1} of all 16 channels — 18 blocks (dz, dy, dx select) instead of 27.
+    // (a kernel instantiation of its own, MP: with both forms behind a run-time branch the 16-channel kernel needed 408 registers instead of 236)
+    constexpr bool mp = MP && KIND == G3_K3;
+    const int pshift = mp ? ppart : 0, pchan = mp ? 0 : ppart * 8;
+    const bool pch_ok = mp || mb * 16 + ppart * 8 < p.Mch, qch_ok = cb * CB + qpart * 8 < p.Cch;
+    // bounds tests in limit form: fragment b lies inside the volume iff z0 < plz[b] && y0 < ply[b] && x0 < plx[b] (tile origin scalar, limits per lane:
+    // three compares per fragment instead of unpacking packed local coordinates every tile — the kernel is bound by instruction issue)
+    int prel[2], plz[2], ply[2], plx[2];
     // G3_UP: view channel block mb of coarse voxel v = 16 channels of the fine tensor [N][2Dp][2Hp][2Wp][Co] around voxel 2v:
     // Co = 8: mb = (pz, py), the block's halves are the x parities; Co = 16: mb = parity; Co >= 32: mb = (parity, 16-channel block)
     const int up_fh = 2 * p.Hp, up_fw = 2 * p.Wp;
@@ -304,32 +341,29 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         const int v = (tid + b * 256) >> 1;
         const int lx = v & 15, ly = (v >> 4) & 3, lz = v >> 6;
         if constexpr (KIND == G3_UP) prel[b] = (((2 * lz) * up_fh + 2 * ly) * up_fw + 2 * lx) * p.up_co * 2 + up_mb_off + ppart * 16;
-        else prel[b] = (((lz * p.Hp + ly) * p.Wp + lx) * p.Mch + mb * 16 + ppart * 8) * 2;
-        pzyx[b] = pch_ok ? (lz | (ly << 8) | (lx << 16)) : 0x00ffffff;
+        else prel[b] = (((lz * p.Hp + ly) * p.Wp + lx + pshift) * p.Mch + mb * 16 + pchan) * 2;
+        plz[b] = pch_ok ? p.Dp - lz : 0; ply[b] = p.Hp - ly; plx[b] = p.Wp - lx - pshift;
     }
-    int qrel[NITQ], qzyx[NITQ];
+    int qrel[NITQ], qlz[NITQ], qly[NITQ], qlx[NITQ];      // Q fragment b inside iff (unsigned)(qz0 + qlz[b]) < Dq && ... (qz0 >= -1)
 #pragma unroll
     for (int b = 0; b < NITQ; ++b) {
         const int u = tid + b * 256;
         const int v = u / QU;
         const int lx = v % QX, ly = (v / QX) % QY, lz = v / (QX * QY);
         qrel[b] = (((lz * p.Hq + ly) * p.Wq + lx) * p.Cch + cb * CB + qpart * 8) * 2;
-        qzyx[b] = (u < NQ && qch_ok) ? (lz | (ly << 8) | (lx << 16)) : 0x00ffffff;
+        qlz[b] = (u < NQ && qch_ok) ? lz : 0x40000000; qly[b] = ly; qlx[b] = lx;
     }
     u32x4 pv[2], qv[NITQ];
     unsigned int okbits = 0;                     // bit b: P fragment b inside the volume; bit 2 + b: Q fragment b
     auto request = [&](int t) {
-        const int n = t / p.tiles_per_sample;
-        const int tl = t - n * p.tiles_per_sample;
-        const int tx = tl % p.txn, ty = (tl / p.txn) % p.tyn, tz = tl / (p.txn * p.tyn);
-        const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+        int n, z0, y0, x0;
+        g3_tile_coords(p, t, n, z0, y0, x0);
         okbits = 0;
         const int pbase = KIND == G3_UP ? (((n * 2 * p.Dp + 2 * z0) * up_fh + 2 * y0) * up_fw + 2 * x0) * p.up_co * 2
                                         : (((n * p.Dp + z0) * p.Hp + y0) * p.Wp + x0) * p.Mch * 2;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const int gz = z0 + (pzyx[b] & 0xff), gy = y0 + ((pzyx[b] >> 8) & 0xff), gx = x0 + (pzyx[b] >> 16);
-            const bool ok = gz < p.Dp && gy < p.Hp && gx < p.Wp;
+            const bool ok = z0 < plz[b] && y0 < ply[b] && x0 < plx[b];
             okbits |= ok ? (1u << b) : 0u;
             pv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(prsrc, ok ? pbase + prel[b] : -1, 0, 0));
         }
@@ -337,8 +371,7 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         const int qbase = (((n * p.Dq + qz0) * p.Hq + qy0) * p.Wq + qx0) * p.Cch * 2;
 #pragma unroll
         for (int b = 0; b < NITQ; ++b) {
-            const int gz = qz0 + (qzyx[b] & 0xff), gy = qy0 + ((qzyx[b] >> 8) & 0xff), gx = qx0 + (qzyx[b] >> 16);
-            const bool ok = (unsigned)gz < (unsigned)p.Dq && (unsigned)gy < (unsigned)p.Hq && (unsigned)gx < (unsigned)p.Wq;
+            const bool ok = (unsigned)(qz0 + qlz[b]) < (unsigned)p.Dq && (unsigned)(qy0 + qly[b]) < (unsigned)p.Hq && (unsigned)(qx0 + qlx[b]) < (unsigned)p.Wq;
             okbits |= ok ? (4u << b) : 0u;
             qv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(qrsrc, ok ? qbase + qrel[b] : -1, 0, 0));
         }
@@ -348,8 +381,8 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         if (p_stats) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                sc[i] = *(const f32x2*)(s_psc + n * 16 + ppart * 8 + 2 * i);
-                sh[i] = *(const f32x2*)(s_psh + n * 16 + ppart * 8 + 2 * i);
+                sc[i] = *(const f32x2*)(s_psc + n * 16 + pchan + 2 * i);
+                sh[i] = *(const f32x2*)(s_psh + n * 16 + pchan + 2 * i);
             }
         }
 #pragma unroll
@@ -407,8 +440,10 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         int dz, dy, dx;
         if (KIND != G3_K2S2) { dz = tap / 9; dy = (tap / 3) % 3; dx = tap % 3; }
         else { dz = (tap >> 2) & 1; dy = (tap >> 1) & 1; dx = tap & 1; }
+        if (mp) { dz = k / 3; dy = k % 3; dx = 1 + (p4 >> 1); }          // block k = (dz, dy): columns 0..7 the centre tap in x, 8..15 the tap one voxel on
         qoff[k] = ((dz * QY + dy) * QX + dx) * QROW + (CB == 16 ? p4 * 8 : (p4 & 1) * 8);
     }
+    const int nk = mp ? (CB == 16 ? 18 : 9) : NCB;
 
     f32x4 acc[NCB];
 #pragma unroll
@@ -416,7 +451,7 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
 
     for (; t < p.total_tiles; t += p.ksplit) {
         __syncthreads();                         // tables visible / every wave is done reading the previous tile
-        commit(t / p.tiles_per_sample);
+        commit(fdiv(t, p.fd_m[0], p.fd_s & 0xff));
         __syncthreads();
         if (t + p.ksplit < p.total_tiles) request(t + p.ksplit);
         // ---- two K-steps of 32 voxels: y rows (2s, 2s+1) of this wave's z-slice ----
@@ -431,6 +466,28 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
                 const int pa0 = (((wave * 4 + 2 * s) * 16 + xr) * 32) + p4 * 8;
                 a2[s] = tr_pair(s_p, pa0, pa0 + 16 * 32);
             }
+            if (mp) {                            // M-packed rows: the taps dx = 0, +1 (halo columns 1, 2) only, block (dz, dy, dx select)
+#pragma unroll
+                for (int dz = 0; dz < 3; ++dz) {
+                    s16x4 rr[6][2];
+#pragma unroll
+                    for (int yr = 0; yr < 6; ++yr)
+#pragma unroll
+                        for (int dxs = 0; dxs < 2; ++dxs)
+                            rr[yr][dxs] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(s_q + (((wave + dz) * QY + yr) * QX + xr + 1 + dxs) * QROW + p4 * 8));
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int dxs = 0; dxs < 2; ++dxs) {
+                                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                                const s16x8 v = __builtin_shufflevector(rr[2 * s + dy][dxs], rr[2 * s + dy + 1][dxs], 0, 1, 2, 3, 4, 5, 6, 7);
+                                const int k = (dz * 3 + dy) * 2 + dxs;
+                                acc[k] = mfma16(a2[s], __builtin_bit_cast(u32x4, v), acc[k], (T*)nullptr);
+                            }
+                }
+            } else
 #pragma unroll
             for (int dz = 0; dz < 3; ++dz) {
                 s16x4 rr[6][3];
@@ -465,16 +522,24 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
                 qb0 = ((2 * wave * QY + 2 * (2 * s)) * QX + 2 * xr) * QROW;
                 qb1 = qb0 + 2 * QX * QROW;
             }
+            constexpr int NK0 = (CB == 8 && KIND == G3_K3) ? 9 : NCB;      // the M-packed form stops after 9 blocks
 #pragma unroll
-            for (int k = 0; k < NCB; ++k) {
+            for (int k = 0; k < NK0; ++k) {
                 const u32x4 b = tr_pair(s_q, qb0 + qoff[k], qb1 + qoff[k]);
                 acc[k] = mfma16(a, b, acc[k], (T*)nullptr);
+            }
+            if (!mp) {
+#pragma unroll
+                for (int k = NK0; k < NCB; ++k) {
+                    const u32x4 b = tr_pair(s_q, qb0 + qoff[k], qb1 + qoff[k]);
+                    acc[k] = mfma16(a, b, acc[k], (T*)nullptr);
+                }
             }
         }
     }
 
-    const size_t slab_elems = (size_t)p.mbn * p.cbn * NCB * 256;
-    g3_finish<NCB>(acc, (float*)s_p, p.ws + (size_t)ks * slab_elems + ((size_t)bx * NCB) * 256, wave, col, g);
+    const size_t slab_elems = (size_t)p.mbn * p.cbn * nk * 256;
+    g3_finish<NCB>(acc, (float*)s_p, p.ws + (size_t)ks * slab_elems + ((size_t)bx * nk) * 256, wave, col, g, nk);
 }
 
 template <int CB, int KIND, typename T = unsigned short>
@@ -538,10 +603,8 @@ __device__ __forceinline__ void g3x_body(const G3Params& p, const int bx, const 
     u32x4 pv[4], qv[NITQ];
     unsigned int okbits = 0;                     // bit b: P fragment b inside the volume; bit 4 + b: Q fragment b
     auto request = [&](int t) {
-        const int n = t / p.tiles_per_sample;
-        const int tl = t - n * p.tiles_per_sample;
-        const int tx = tl % p.txn, ty = (tl / p.txn) % p.tyn, tz = tl / (p.txn * p.tyn);
-        const int z0 = tz * 4, y0 = ty * 4, x0 = tx * 16;
+        int n, z0, y0, x0;
+        g3_tile_coords(p, t, n, z0, y0, x0);
         okbits = 0;
         const int pbase = (((n * p.Dp + z0) * p.Hp + y0) * p.Wp + x0) * p.Mch * 4;
 #pragma unroll
@@ -617,7 +680,7 @@ __device__ __forceinline__ void g3x_body(const G3Params& p, const int bx, const 
 
     for (; t < p.total_tiles; t += p.ksplit) {
         __syncthreads();                         // tables visible / every wave is done reading the previous tile
-        commit(t / p.tiles_per_sample);
+        commit(fdiv(t, p.fd_m[0], p.fd_s & 0xff));
         __syncthreads();
         if (t + p.ksplit < p.total_tiles) request(t + p.ksplit);
         // two K-steps of 32 voxels: y rows (2s, 2s+1) of this wave's z-slice; per column block three B limbs against three A limbs, six MFMAs
@@ -667,7 +730,9 @@ struct G3Group {
                       // XCD's L2: 8-channel bucket 572 -> 343 MB per launch, step time unchanged); VS_WGRAD_XCD=0 restores the plain order
 };
 
-template <int CB, int KIND, typename T = unsigned short>
+static_assert(sizeof(G3Group) <= 4096, "G3Group travels as the kernel argument");
+
+template <int CB, int KIND, typename T = unsigned short, bool MP = false>
 // (3 waves per SIMD for the 8-channel bucket — the compiler gets there without AGPRs — changed nothing: 2.814 vs 2.810 ms per step)
 __global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
     const int b = blockIdx.x;
@@ -689,7 +754,7 @@ __global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
         }
         ks = start + ((local - ((x - b0) & 7)) >> 3);
     }
-    g3b_body<T, CB, KIND>(p, local - (local / pairs) * pairs, ks);
+    g3b_body<T, CB, KIND, MP>(p, local - (local / pairs) * pairs, ks);
 }
 
 // the same grouping for the limb kernel of the fp32 parity mode (3x3x3 layers): one grid per channel-block width
@@ -862,6 +927,7 @@ static int wgrad_single(const void* P, const double* p_stats, const void* Q, con
     p.Dq = dp * s; p.Hq = hp * s; p.Wq = wp * s;
     p.Mch = m_ch; p.Cch = c_ch;
     p.total_tiles = p.tiles_per_sample * n;
+    g3_fastdiv(p);
     p.eps = eps;
     p.inv_cnt_p = 1.0 / ((double)dp * hp * wp);
     p.inv_cnt_q = 1.0 / ((double)p.Dq * p.Hq * p.Wq);
@@ -985,9 +1051,17 @@ __global__ __launch_bounds__(64 * G3_RED_ROWS) void g3_reduce_group_kernel(const
             const int k = (int)((ee >> 8) % d.ncb);
             const int pair = (int)(ee / ((size_t)d.ncb * 256));
             const int mb = pair / d.cbn, cb = pair - mb * d.cbn;
-            const int m = mb * 16 + row;
+            int m = mb * 16 + row;
             int c, tap;
             if (d.cb == 16) { c = cb * 16 + col; tap = k; }
+            else if (d.cb & 0x100) {                       // M-packed forms (g3b_body): rows (s, co); 8-channel blocks: columns (dx select, ci), block k = (dz, dy);
+                const int sx = row >> 3;                  //                                         16-channel blocks: columns ci, block k = (dz, dy, dx select)
+                int dzdy, dxs;
+                m = row & 7;
+                if ((d.cb & 0xff) == 16) { c = cb * 16 + col; dzdy = k >> 1; dxs = k & 1; }
+                else { c = col & 7; dzdy = k; dxs = col >> 3; }
+                tap = (sx & dxs) ? d.ntaps : 3 * dzdy + 1 + dxs - sx;    // (s = 1, dx = +1) repeats the centre tap: dropped
+            }
             else { c = cb * 8 + (col & 7); tap = 2 * k + (col >> 3); }
             if (m < d.m_real && c < d.c_real && tap < d.ntaps) d.dw[((size_t)m * d.c_real + c) * d.ntaps + tap] = (float)tot;
         }
@@ -1080,11 +1154,12 @@ static int multi_validate(const vs_wgrad_desc& d) {
 
 // bf16 plan: every layer gets its own slab region; k-splits are chosen per (CB, KIND) bucket so that the bucket's ONE grid has
 // about `target` workgroups of about equal tile counts.
-static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPlan& plan, int target_wgs = 0) {
+static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPlan& plan, int target_wgs = 0, bool pack_m = false) {
     static const long long target_default = getenv("VS_WGRAD_GROUP_WGS") ? atoll(getenv("VS_WGRAD_GROUP_WGS")) : 512;     // measured best of 384..2560 (two workgroups per CU are resident)
     const long long target = target_wgs > 0 ? target_wgs : target_default;
     plan.layers.resize(count);
-    long long bucket_work[6] = {0, 0, 0, 0, 0, 0};       // (cbsz 16 | 8) x (K3, K2S2, UP)
+    long long bucket_work[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // (cbsz 16 | 8) x (K3, K2S2, UP, K3 M-packed): one grouped launch each
+    auto bucket_of = [](const MultiLayer& L) { return (L.cbsz == 16 ? 0 : 1) + 2 * (L.p.mp ? 3 : (L.kind == VS_CONV_K3 ? 0 : (L.kind == VS_CONV_K2S2 ? 1 : 2))); };
     for (int i = 0; i < count; ++i) {
         const vs_wgrad_desc& d = descs[i];
         int rc = multi_validate(d);
@@ -1101,12 +1176,20 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         p.Mch = d.m_ch; p.Cch = d.c_ch;
         p.up_co = d.kind == VS_CONV_UP ? d.reserved_ : 0;
         p.total_tiles = p.tiles_per_sample * d.n;
+        g3_fastdiv(p);
+        // g3b_body's M-packed forms.  Same-box A/B (profiles/r04_ab_wgrad_mpack.json): 160^3 B=2 6.74 -> 6.50 ms, 128^3 B=1 3.80 -> 3.75, 96^3 B=2 2.515 -> 2.526 (the
+        // per-tile time there does not follow the MFMA / LDS-read counts, and the packed layers cost two more launches) — so by default only
+        // from 2 M voxels per layer on; VS_WGRAD_MPACK=1 / 0 forces it on / off.
+        const char* mp_str = getenv("VS_WGRAD_MPACK");          // read per plan (not cached): the tests switch it between calls
+        const int mp_env = mp_str ? atoi(mp_str) : -1;
+        const bool mp_on = mp_env >= 0 ? mp_env != 0 : (long long)d.n * d.dp * d.hp * d.wp >= 2000000ll;
+        if (pack_m && mp_on && d.kind == VS_CONV_K3 && d.m_ch == 8 && (L.cbsz == 16 || d.c_ch == 8)) { p.mp = 1; L.ncb = L.cbsz == 16 ? 18 : 9; }
         p.eps = eps;
         p.inv_cnt_p = 1.0 / ((double)d.dp * d.hp * d.wp);
         p.inv_cnt_q = 1.0 / ((double)p.Dq * p.Hq * p.Wq);
         if ((long long)d.n * d.dp * d.hp * d.wp * d.m_ch * 2 >= 2147483648ll || (long long)d.n * p.Dq * p.Hq * p.Wq * d.c_ch * 2 >= 2147483648ll) return VS_ESHAPE;
         L.kind = d.kind; L.m_real = d.m_real; L.c_real = d.c_real; L.dw = d.dw;
-        bucket_work[(L.cbsz == 16 ? 0 : 1) + 2 * (d.kind == VS_CONV_K3 ? 0 : (d.kind == VS_CONV_K2S2 ? 1 : 2))] += (long long)p.mbn * p.cbn * p.total_tiles;
+        bucket_work[bucket_of(L)] += (long long)p.mbn * p.cbn * p.total_tiles;
     }
     // descriptors that share dw (db): parts of one gradient
     for (int i = 0; i < count; ++i) {
@@ -1115,7 +1198,7 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         for (int j = 0; j < i; ++j) {
             if (descs[j].dw == descs[i].dw && L.primary == i) {
                 const MultiLayer& F = plan.layers[j];
-                if (F.cbsz != L.cbsz || F.kind != L.kind || F.p.mbn != L.p.mbn || F.p.cbn != L.p.cbn || F.m_real != L.m_real || F.c_real != L.c_real)
+                if (F.cbsz != L.cbsz || F.kind != L.kind || F.p.mbn != L.p.mbn || F.p.cbn != L.p.cbn || F.m_real != L.m_real || F.c_real != L.c_real || F.p.mp != L.p.mp)
                     return VS_EINVAL;                     // same destination, different layer geometry
                 L.primary = F.primary;
             }
@@ -1129,7 +1212,7 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
     for (int i = 0; i < count; ++i) {                      // k-splits
         MultiLayer& L = plan.layers[i];
         G3Params& p = L.p;
-        const long long w = bucket_work[(L.cbsz == 16 ? 0 : 1) + 2 * (L.kind == VS_CONV_K3 ? 0 : (L.kind == VS_CONV_K2S2 ? 1 : 2))];
+        const long long w = bucket_work[bucket_of(L)];
         long long tpw = (w + target - 1) / target;            // tiles per workgroup
         if (tpw < 1) tpw = 1;
         long long ks = (p.total_tiles + tpw - 1) / tpw;
@@ -1171,11 +1254,11 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
     return VS_OK;
 }
 
-template <typename T, int CB, int KIND>
+template <typename T, int CB, int KIND, bool MP = false>
 static int g3b_group_run(const G3Group& grp, hipStream_t s) {
     using GEO = G3Geo<CB, KIND>;
     constexpr size_t lds = G3B_LDS_Q + (size_t)GEO::QV * CB * 2;
-    auto kern = g3b_group_kernel<CB, KIND, T>;
+    auto kern = g3b_group_kernel<CB, KIND, T, MP>;
     if (lds > 64 * 1024) {
         static const hipError_t attr_err =
             hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1308,7 +1391,7 @@ extern "C" size_t vs_conv_wgrad_multi_throttled_workspace_bytes(const vs_wgrad_d
         return limb_bytes + mx;
     }
     MultiPlan plan;
-    if (multi_plan(descs, count, 0.f, plan, target_workgroups)) return 0;
+    if (multi_plan(descs, count, 0.f, plan, target_workgroups, true)) return 0;
     return plan.bytes;
 }
 
@@ -1373,18 +1456,19 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
         return VS_OK;
     }
     MultiPlan plan;
-    int rc = multi_plan(descs, count, eps, plan, target_workgroups);
+    int rc = multi_plan(descs, count, eps, plan, target_workgroups, true);
     if (rc) return rc;
     if (workspace_bytes < plan.bytes) return VS_EWORKSPACE;
     if ((uintptr_t)workspace % 16) return VS_EINVAL;
     char* ws = (char*)workspace;
 
     // ---- the four (CB, KIND) buckets, heaviest workgroups first, G3_GROUP_MAX layers per grid ----
-    for (int bucket = 0; bucket < 6; ++bucket) {
-        const int cbsz = (bucket & 1) ? 8 : 16, kind = bucket < 2 ? VS_CONV_K3 : (bucket < 4 ? VS_CONV_K2S2 : VS_CONV_UP);
+    for (int bucket = 0; bucket < 8; ++bucket) {
+        const int cbsz = (bucket & 1) ? 8 : 16, kind = bucket < 2 || bucket >= 6 ? VS_CONV_K3 : (bucket < 4 ? VS_CONV_K2S2 : VS_CONV_UP);
+        const bool mpb = bucket >= 6;                    // the M-packed 3x3x3 layers (8 stored P channels): kernel instantiations of their own
         std::vector<int> idx;
         for (int i = 0; i < count; ++i)
-            if (plan.layers[i].cbsz == cbsz && plan.layers[i].kind == kind) idx.push_back(i);
+            if (plan.layers[i].cbsz == cbsz && plan.layers[i].kind == kind && (plan.layers[i].p.mp != 0) == mpb) idx.push_back(i);
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return plan.layers[a].work > plan.layers[b].work; });
         for (size_t at = 0; at < idx.size(); at += G3_GROUP_MAX) {
             G3Group grp{};
@@ -1404,6 +1488,9 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
             if (kind == VS_CONV_UP) {
                 if (cbsz != 16) return VS_ESHAPE;
                 rc = f16 ? g3b_group_run<vs_half, 16, G3_UP>(grp, st) : g3b_group_run<unsigned short, 16, G3_UP>(grp, st);
+            } else if (mpb) {
+                if (f16) rc = cbsz == 16 ? g3b_group_run<vs_half, 16, G3_K3, true>(grp, st) : g3b_group_run<vs_half, 8, G3_K3, true>(grp, st);
+                else rc = cbsz == 16 ? g3b_group_run<unsigned short, 16, G3_K3, true>(grp, st) : g3b_group_run<unsigned short, 8, G3_K3, true>(grp, st);
             } else if (f16) {
                 if (kind == VS_CONV_K3) rc = cbsz == 16 ? g3b_group_run<vs_half, 16, G3_K3>(grp, st) : g3b_group_run<vs_half, 8, G3_K3>(grp, st);
                 else rc = cbsz == 16 ? g3b_group_run<vs_half, 16, G3_K2S2>(grp, st) : g3b_group_run<vs_half, 8, G3_K2S2>(grp, st);
@@ -1447,7 +1534,7 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
                 // a partition sums up to 8 slabs in one round of independent loads: no more partitions (= threads, waves) than that needs
                 int parts = 1;
                 while (parts < G3_RED_ROWS && parts * 8 < L.total_slabs) parts *= 2;
-                red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.total_slabs, L.cbsz,
+                red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.total_slabs, L.cbsz | (L.p.mp ? 0x100 : 0),
                                         L.kind != VS_CONV_K2S2 ? 27 : 8, L.ncb, 0, parts});
                 blocks.push_back(vs_ceil_div(slab_elems, 256 * (G3_RED_ROWS / parts)));
             }
