@@ -303,7 +303,12 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int q4 = col >> 2, p4 = col & 3;       // tr-read addressing: this lane supplies row q4, columns 4*p4..4*p4+3
     const int mb = bx / p.cbn, cb = bx - mb * p.cbn;
-    const bool p_stats = p.P_stats != nullptr, q_stats = p.Q_stats != nullptr;
+    const bool p_stats_in = p.P_stats != nullptr, q_stats_in = p.Q_stats != nullptr;
+#ifdef VS_G3B_ABLATE                                 // diagnostic build (tools/build_stamps.sh): parts of the tile loop switched off to see what the loop time is made of
+    const int ablate = KIND == G3_K3 ? p.up_co : 0;      // 1: no MFMA phase, 4: no normalise, 8: no loads after the first tile, 16: no LDS writes, 32: no barriers
+#else
+    constexpr int ablate = 0;
+#endif
     const i32x4 prsrc = make_rsrc(p.P, (unsigned int)((long long)p.N * p.Dp * p.Hp * p.Wp * p.Mch * 2));
     const i32x4 qrsrc = make_rsrc(p.Q, (unsigned int)((long long)p.N * p.Dq * p.Hq * p.Wq * p.Cch * 2));
 
@@ -378,6 +383,7 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
     };
     auto commit = [&](int n) {                   // registers -> (normalised) LDS tiles
         f32x2 sc[4], sh[4];
+        const bool p_stats = p_stats_in && !(ablate & 4), q_stats = q_stats_in && !(ablate & 4);
         if (p_stats) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -423,11 +429,11 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
         const int n = i >> 4, c = i & 15;
         float m = 0.f, r = 1.f;
         const int pc = mb * 16 + c;
-        if (p_stats && pc < p.Mch) stats_to_mean_rstd_fast(p.P_stats, (size_t)n * p.Mch + pc, (size_t)p.N * p.Mch, p.inv_cnt_p, p.eps, m, r);
+        if (p_stats_in && pc < p.Mch) stats_to_mean_rstd_fast(p.P_stats, (size_t)n * p.Mch + pc, (size_t)p.N * p.Mch, p.inv_cnt_p, p.eps, m, r);
         s_psc[i] = r; s_psh[i] = -m * r;
         m = 0.f; r = 1.f;
         const int qc = cb * CB + c;
-        if (q_stats && c < CB && qc < p.Cch) stats_to_mean_rstd_fast(p.Q_stats, (size_t)n * p.Cch + qc, (size_t)p.N * p.Cch, p.inv_cnt_q, p.eps, m, r);
+        if (q_stats_in && c < CB && qc < p.Cch) stats_to_mean_rstd_fast(p.Q_stats, (size_t)n * p.Cch + qc, (size_t)p.N * p.Cch, p.inv_cnt_q, p.eps, m, r);
         s_qsc[i] = r; s_qsh[i] = -m * r;
     }
 
@@ -450,10 +456,11 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
     for (int k = 0; k < NCB; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (; t < p.total_tiles; t += p.ksplit) {
-        __syncthreads();                         // tables visible / every wave is done reading the previous tile
-        commit(fdiv(t, p.fd_m[0], p.fd_s & 0xff));
-        __syncthreads();
-        if (t + p.ksplit < p.total_tiles) request(t + p.ksplit);
+        if (!(ablate & 32) || t == ks) __syncthreads();      // tables visible / every wave is done reading the previous tile
+        if (!(ablate & 16)) commit(fdiv(t, p.fd_m[0], p.fd_s & 0xff));
+        if (!(ablate & 32)) __syncthreads();
+        if (t + p.ksplit < p.total_tiles && !(ablate & 8)) request(t + p.ksplit);
+        if (ablate & 1) continue;
         // ---- two K-steps of 32 voxels: y rows (2s, 2s+1) of this wave's z-slice ----
         if constexpr (CB == 16 && KIND != G3_K2S2) {
             // 16-channel 3x3x3 blocks: tap (dz, dy, dx) of K-step s needs the Q rows (2s + dy, 2s + dy + 1) of plane wave + dz at x shift dx —
@@ -1175,6 +1182,9 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         p.Dq = d.dp * s; p.Hq = d.hp * s; p.Wq = d.wp * s;
         p.Mch = d.m_ch; p.Cch = d.c_ch;
         p.up_co = d.kind == VS_CONV_UP ? d.reserved_ : 0;
+#ifdef VS_G3B_ABLATE
+        if (d.kind == VS_CONV_K3 && getenv("VS_G3B_ABLATE")) p.up_co = atoi(getenv("VS_G3B_ABLATE"));
+#endif
         p.total_tiles = p.tiles_per_sample * d.n;
         g3_fastdiv(p);
         // g3b_body's M-packed forms.  Same-box A/B (profiles/r04_ab_wgrad_mpack.json): 160^3 B=2 6.74 -> 6.50 ms, 128^3 B=1 3.80 -> 3.75, 96^3 B=2 2.515 -> 2.526 (the
