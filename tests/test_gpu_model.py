@@ -350,9 +350,9 @@ def test_bf16_mode_joint96_close_to_fp32_reference():
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_16bit_joint128_weight_gradients_same_with_and_without_m_packing(dtype, monkeypatch):
-    """The 128^3 joint step (2.1 M voxels per layer: the size from which the weight gradients of the layers with 8 stored output channels take the M-packed
-    form by default, csrc/wgrad.hip g3b_body): every gradient of the default plan equals the unpacked plan's up to the order of the fp32 sums, and the
-    forced-on plan is the default plan bit for bit."""
+    """The 128^3 joint step: the weight gradients of the layers with 8 stored output channels take the M-packed form by default (csrc/wgrad.hip g3b_body);
+    every gradient of the default plan equals the unpacked plan's (VS_WGRAD_MPACK=0) up to the order of the fp32 sums, and the forced-on plan is the
+    default plan bit for bit."""
     M, O, T = _mods()
     img, lab = O.synthetic_image(1, 128, 2).cuda(), O.synthetic_label(1, 128, 3).cuda()
     grads = {}

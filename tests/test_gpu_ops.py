@@ -487,7 +487,7 @@ def test_grouped_weight_gradients_many_layers(dtype, mpack, monkeypatch):
     """vs_conv_wgrad_multi (main_source.py:660: the gradients the optimiser step reads): 34 layers of all conv kinds deferred to the end of ONE
     backward pass and issued as grouped launches — each against F.conv3d / F.conv_transpose3d autograd on the CPU, against the
     per-layer launches (vs_conv_wgrad), and bitwise reproducible.  mpack: the M-packed form of the layers with 8 stored output channels
-    (csrc/wgrad.hip g3b_body; by default only from 2 M voxels on) forced on / off."""
+    (csrc/wgrad.hip g3b_body) on / off."""
     monkeypatch.setenv("VS_WGRAD_MPACK", mpack)
     ops = _ops()
     assert ops._GROUP["enabled"]

@@ -27,6 +27,7 @@ struct G3Params {
     int up_co;                // G3_UP: channels of the fine tensor P points to (Mch = 8 * up_co is its space-to-depth view)
     unsigned int fd_m[3];     // multiply-shift division (common.h fdiv) by tiles_per_sample, txn * tyn, txn: the tile coordinates of every loop
     unsigned int fd_s;        //   round cost ~12 scalar instructions instead of ~100 (five 32-bit divisions); shifts packed 8 bits each
+    int variant;              // which instantiation of g3b_body a workgroup of the all-buckets launch runs (g3b_uber_kernel): G3V_*
     int mp;                   // 8-channel 3x3x3 layers with 8 stored P channels, 16-bit grouped path: MFMA rows 8..15 carry P shifted by one voxel in x
                               //   (see g3b_body) — 9 column blocks (dz, dy) x {dx = 0, +1} instead of 14 blocks of two taps
 };
@@ -764,6 +765,44 @@ __global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
     g3b_body<T, CB, KIND, MP>(p, local - (local / pairs) * pairs, ks);
 }
 
+// Every bucket of a pass in ONE grid: a workgroup looks up its layer, then runs that layer's instantiation of g3b_body.  Per-bucket launches each pay
+// their own ramp and drain — every workgroup's prologue (statistics tables, first loads) and epilogue (slab reduction through LDS, slab store), about
+// 20 us of a 93 us launch (profiles/r04_wgrad_ablation.txt), run at the same moment on every CU; in one grid of several workgroups per slot they overlap
+// other workgroups' tile loops.  Registers and LDS are those of the largest instantiation (all of the big ones sit at two workgroups per CU anyway).
+enum { G3V_K3_16 = 0, G3V_K3_8, G3V_K2S2_16, G3V_K2S2_8, G3V_UP_16, G3V_K3_16_MP, G3V_K3_8_MP, G3V_COUNT };
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void g3b_uber_kernel(const G3Group grp) {      // (left alone the union of the variants' registers is 284)
+    const int b = blockIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < G3_GROUP_MAX; ++i) l += (i < grp.n && b >= grp.wg_start[i]) ? 1 : 0;
+    const G3Params p = grp.p[l];
+    const int local = b - grp.wg_start[l];
+    const int pairs = p.mbn * p.cbn;
+    int ks = local / pairs;
+    if (grp.xcd && pairs == 1 && p.ksplit >= 16) {          // as g3b_group_kernel: XCD x walks one contiguous run of k-splits
+        const int b0 = grp.wg_start[l], x = b & 7;
+        int start = 0;
+#pragma unroll
+        for (int xx = 0; xx < 8; ++xx) {
+            const int first = (xx - b0) & 7;
+            const int cnt = first < p.ksplit ? (p.ksplit - first + 7) >> 3 : 0;
+            start += xx < x ? cnt : 0;
+        }
+        ks = start + ((local - ((x - b0) & 7)) >> 3);
+    }
+    const int bx = local - (local / pairs) * pairs;
+    switch (p.variant) {                                   // uniform per workgroup
+        case G3V_K3_16:    g3b_body<T, 16, G3_K3, false>(p, bx, ks); break;
+        case G3V_K3_8:     g3b_body<T, 8, G3_K3, false>(p, bx, ks); break;
+        case G3V_K2S2_16:  g3b_body<T, 16, G3_K2S2, false>(p, bx, ks); break;
+        case G3V_K2S2_8:   g3b_body<T, 8, G3_K2S2, false>(p, bx, ks); break;
+        case G3V_UP_16:    g3b_body<T, 16, G3_UP, false>(p, bx, ks); break;
+        case G3V_K3_16_MP: g3b_body<T, 16, G3_K3, true>(p, bx, ks); break;
+        default:           g3b_body<T, 8, G3_K3, true>(p, bx, ks); break;
+    }
+}
+
 // the same grouping for the limb kernel of the fp32 parity mode (3x3x3 layers): one grid per channel-block width
 template <int CB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 ? 2 : 1))) void g3x_group_kernel(const G3Group grp) {
@@ -1187,12 +1226,11 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
 #endif
         p.total_tiles = p.tiles_per_sample * d.n;
         g3_fastdiv(p);
-        // g3b_body's M-packed forms.  Same-box A/B (profiles/r04_ab_wgrad_mpack.json): 160^3 B=2 6.74 -> 6.50 ms, 128^3 B=1 3.80 -> 3.75, 96^3 B=2 2.515 -> 2.526 (the
-        // per-tile time there does not follow the MFMA / LDS-read counts, and the packed layers cost two more launches) — so by default only
-        // from 2 M voxels per layer on; VS_WGRAD_MPACK=1 / 0 forces it on / off.
+        // g3b_body's M-packed forms.  Same-box A/B (profiles/r04_ab_wgrad_mpack.json): with one grid per bucket 160^3 B=2 6.74 -> 6.50 ms, 128^3 B=1 3.80 -> 3.75, but
+        // 96^3 B=2 2.515 -> 2.526 (the packed layers were two more launches); inside the all-buckets grid (g3b_uber_kernel) 96^3 gains too: 2.531 -> 2.513.
+        // VS_WGRAD_MPACK=0 switches it off.
         const char* mp_str = getenv("VS_WGRAD_MPACK");          // read per plan (not cached): the tests switch it between calls
-        const int mp_env = mp_str ? atoi(mp_str) : -1;
-        const bool mp_on = mp_env >= 0 ? mp_env != 0 : (long long)d.n * d.dp * d.hp * d.wp >= 2000000ll;
+        const bool mp_on = mp_str ? atoi(mp_str) != 0 : true;
         if (pack_m && mp_on && d.kind == VS_CONV_K3 && d.m_ch == 8 && (L.cbsz == 16 || d.c_ch == 8)) { p.mp = 1; L.ncb = L.cbsz == 16 ? 18 : 9; }
         p.eps = eps;
         p.inv_cnt_p = 1.0 / ((double)d.dp * d.hp * d.wp);
@@ -1279,6 +1317,39 @@ static int g3b_group_run(const G3Group& grp, hipStream_t s) {
     return VS_OK;
 }
 
+
+static int g3v_of(int cbsz, int kind, bool mp) {
+    if (kind == VS_CONV_UP) return G3V_UP_16;
+    if (kind == VS_CONV_K2S2) return cbsz == 16 ? G3V_K2S2_16 : G3V_K2S2_8;
+    if (mp) return cbsz == 16 ? G3V_K3_16_MP : G3V_K3_8_MP;
+    return cbsz == 16 ? G3V_K3_16 : G3V_K3_8;
+}
+static size_t g3v_lds(int variant) {
+    switch (variant) {
+        case G3V_K3_16: case G3V_K3_16_MP: return G3B_LDS_Q + (size_t)G3Geo<16, G3_K3>::QV * 16 * 2;
+        case G3V_K3_8: case G3V_K3_8_MP:   return G3B_LDS_Q + (size_t)G3Geo<8, G3_K3>::QV * 8 * 2;
+        case G3V_K2S2_16:                  return G3B_LDS_Q + (size_t)G3Geo<16, G3_K2S2>::QV * 16 * 2;
+        case G3V_K2S2_8:                   return G3B_LDS_Q + (size_t)G3Geo<8, G3_K2S2>::QV * 8 * 2;
+        default:                           return G3B_LDS_Q + (size_t)G3Geo<16, G3_UP>::QV * 16 * 2;
+    }
+}
+// relative duration of one tile of a variant's loop (sort key of the all-buckets launch: longest workgroups first)
+static double g3v_tile_cost(int variant) {
+    switch (variant) {
+        case G3V_K3_16: return 2.0; case G3V_K3_16_MP: return 1.5; case G3V_K3_8: return 1.0; case G3V_K3_8_MP: return 0.9;
+        case G3V_K2S2_16: return 1.6; case G3V_K2S2_8: return 0.8; default: return 2.0;
+    }
+}
+template <typename T>
+static int g3b_uber_run(const G3Group& grp, size_t lds, hipStream_t s) {
+    auto kern = g3b_uber_kernel<T>;
+    static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (attr_err != hipSuccess) return (int)attr_err;
+    if (lds > 96 * 1024) return VS_ESHAPE;
+    hipLaunchKernelGGL(kern, dim3(grp.wg_start[grp.n]), dim3(256), lds, s, grp);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
 
 // ---- fp32 parity mode: the 3x3x3 layers of a pass as grouped limb launches (g3x_group_kernel), one grid per channel-block width ----------
 static bool f32_limbs_on() {
@@ -1472,7 +1543,36 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
     if ((uintptr_t)workspace % 16) return VS_EINVAL;
     char* ws = (char*)workspace;
 
-    // ---- the four (CB, KIND) buckets, heaviest workgroups first, G3_GROUP_MAX layers per grid ----
+    // ---- every bucket in one grid (G3_GROUP_MAX layers per grid, longest workgroups first); VS_WGRAD_UBER=0: one grid per bucket ----
+    static const int uber = getenv("VS_WGRAD_UBER") ? atoi(getenv("VS_WGRAD_UBER")) : 1;
+    if (uber) {
+        std::vector<int> idx(count);
+        for (int i = 0; i < count; ++i) idx[i] = i;
+        auto key = [&](int a) { const MultiLayer& L = plan.layers[a]; return (double)L.work * g3v_tile_cost(g3v_of(L.cbsz, L.kind, L.p.mp != 0)); };
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key(a) > key(b); });
+        for (size_t at = 0; at < idx.size(); at += G3_GROUP_MAX) {
+            G3Group grp{};
+            static const int xcd_walk = getenv("VS_WGRAD_XCD") ? atoi(getenv("VS_WGRAD_XCD")) : 1;
+            grp.xcd = xcd_walk;
+            grp.n = (int)std::min<size_t>(G3_GROUP_MAX, idx.size() - at);
+            long long wg = 0;
+            size_t lds = 0;
+            for (int j = 0; j < grp.n; ++j) {
+                MultiLayer& L = plan.layers[idx[at + j]];
+                if (L.kind == VS_CONV_UP && L.cbsz != 16) return VS_ESHAPE;
+                grp.p[j] = L.p;
+                grp.p[j].ws = (float*)(ws + L.ws_off);
+                grp.p[j].variant = g3v_of(L.cbsz, L.kind, L.p.mp != 0);
+                lds = std::max(lds, g3v_lds(grp.p[j].variant));
+                grp.wg_start[j] = (int)wg;
+                wg += (long long)L.p.mbn * L.p.cbn * L.p.ksplit;
+            }
+            if (wg >= 2147483647ll) return VS_ESHAPE;
+            for (int j = grp.n; j <= G3_GROUP_MAX; ++j) grp.wg_start[j] = (int)wg;
+            rc = f16 ? g3b_uber_run<vs_half>(grp, lds, st) : g3b_uber_run<unsigned short>(grp, lds, st);
+            if (rc) return rc;
+        }
+    } else
     for (int bucket = 0; bucket < 8; ++bucket) {
         const int cbsz = (bucket & 1) ? 8 : 16, kind = bucket < 2 || bucket >= 6 ? VS_CONV_K3 : (bucket < 4 ? VS_CONV_K2S2 : VS_CONV_UP);
         const bool mpb = bucket >= 6;                    // the M-packed 3x3x3 layers (8 stored P channels): kernel instantiations of their own
