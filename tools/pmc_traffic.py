@@ -2,7 +2,7 @@
 prescribes: counters are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream, so it is doubled.
 usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <step_equivalents_in_the_run | auto> [out.json]
 (step equivalents: every forward+backward pass of the bf16 step in the run — bench.py's eager warm-up and family-timing passes, --warmup,
---steps; launches per step = sampled launches / that.  auto: the launches of the once-per-pass grouped weight-gradient kernel)"""
+--steps; launches per step = sampled launches / that.  auto: the launches of the once-per-pass slab reduction of the grouped weight gradients)"""
 import collections, csv, glob, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
@@ -18,7 +18,7 @@ def per_kernel(d, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 if sys.argv[3] == "auto":
-    steps = float(max(n for k, (f, n) in fetch.items() if k.startswith("void g3b_group_kernel<16, 0, unsigned short")))
+    steps = float(max(n for k, (f, n) in fetch.items() if k.startswith("g3_reduce_group_kernel")))          # one launch per pass
 else:
     steps = float(sys.argv[3])
 out, total = {}, 0.0

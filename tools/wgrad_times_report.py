@@ -10,7 +10,7 @@ for cfg in ("joint96", "joint160"):
     print(cfg, "%.3f ms per step under rocprofv3" % json.load(open(os.path.join(root, cfg + ".json")))["ms_per_step"])
     tot = 0.0
     for r in rows:
-        if any(k in r["Name"] for k in ("g3b_group", "g3_reduce_group", "bias_partial")):
+        if any(k in r["Name"] for k in ("g3b_group", "g3b_uber", "g3_reduce_group", "bias_partial")):
             print("  %-66s %3s calls  avg %7.1f us" % (r["Name"][:66], r["Calls"], float(r["AverageNs"]) / 1e3))
             tot += float(r["AverageNs"]) / 1e3
     print("  weight-gradient launches, total %.1f us per step" % tot)
