@@ -86,7 +86,10 @@ def test_grouped_weight_gradient_planning_without_gpu():
     assert grouped >= 128 * 128 * 27 * 4                       # at least one slab of the 128x128 layer
     f32 = lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(arr), len(layers), VS_F32)
     k2 = (ops.WgradDesc * 2)(*layers[3:])
-    assert lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(k2), 2, VS_F32) == max(single[3:])           # stride-2 layers only: the serial rule
+    k2_f32 = lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(k2), 2, VS_F32)
+    assert max(single[3:]) < k2_f32 <= max(single[3:]) + 2 * 256 * 32 * 8 + 512         # stride-2 layers only: the serial rule + their two bias layers' partial sums
+    nobias = (ops.WgradDesc * 2)(desc(2, 24, 24, 24, 32, 32, VS_CONV_K2S2), desc(2, 48, 48, 48, 8, 8, VS_CONV_K2S2))
+    assert lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(nobias), 2, VS_F32) == max(single[3:])
     assert f32 >= max(single[3:]) + 128 * 128 * 27 * 4 and f32 % 16 == 0
     assert lib.vs_conv_wgrad_multi(ctypes.addressof(arr), len(layers), None, 0, VS_BF16, 1e-5, None) == -1      # no workspace
     assert lib.vs_conv_wgrad_multi(ctypes.addressof(arr), len(layers), fake, 16, VS_BF16, 1e-5, None) == -4      # VS_EWORKSPACE

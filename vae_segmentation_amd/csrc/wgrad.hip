@@ -1133,10 +1133,11 @@ __global__ __launch_bounds__(256) void bias_partial_group_kernel(const G3BiasGro
     for (int i = 1; i < G3_BIAS_MAX; ++i) l += (i < grp.n && b >= grp.blk_start[i]) ? 1 : 0;
     const G3BiasDesc d = grp.d[l];
     const int lb = b - grp.blk_start[l];
-    const int frags = d.c_ch >> 3, fx = tid % frags, fy = tid / frags, rpi = 256 / frags;
-    float part[8];
+    constexpr int EPL = ET<T>::EPL;               // channels per 16-byte fragment: 8 (16-bit storage) or 4 (fp32)
+    const int frags = d.c_ch / EPL, fx = tid % frags, fy = tid / frags, rpi = 256 / frags;
+    float part[EPL];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) part[j] = 0.f;
+    for (int j = 0; j < EPL; ++j) part[j] = 0.f;
     // 8 rows in flight per thread (one load per iteration made the ~32 rounds of a 96^3 layer a dependent chain: 26 us for 100 MB)
     const long long vstep = (long long)d.nblk * rpi;
     for (long long v = (long long)lb * rpi + fy; v < d.rows; v += 8 * vstep) {
@@ -1144,21 +1145,21 @@ __global__ __launch_bounds__(256) void bias_partial_group_kernel(const G3BiasGro
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const long long vv = v + u * vstep;
-            q[u] = vv < d.rows ? *(const u32x4*)((const T*)d.g + vv * d.c_ch + fx * 8) : u32x4{0u, 0u, 0u, 0u};
+            q[u] = vv < d.rows ? *(const u32x4*)((const T*)d.g + vv * d.c_ch + fx * EPL) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            float f[8];
+            float f[EPL];
             frag_unpack(q[u], f, (T*)nullptr);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) part[j] += f[j];
+            for (int j = 0; j < EPL; ++j) part[j] += f[j];
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = part[j];
+    for (int j = 0; j < EPL; ++j) s_red[tid * 8 + j] = part[j];
     __syncthreads();
     for (int ch = tid; ch < d.c_real; ch += 256) {
-        const int cx = ch >> 3, j = ch & 7;
+        const int cx = ch / EPL, j = ch % EPL;
         double tot = 0.0;
         for (int y = 0; y < rpi; ++y) tot += (double)s_red[(y * frags + cx) * 8 + j];
         d.part[(size_t)lb * d.c_real + ch] = tot;
@@ -1452,6 +1453,22 @@ extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* 
     return vs_conv_wgrad_multi_throttled(descs, count, workspace, workspace_bytes, dtype, eps, 0, stream);
 }
 
+// fp32 mode: the bias gradients of a pass as the 16-bit path computes them (grouped partial sums, one fixed-order reduction) instead of a zero fill and a float-atomic
+// launch per layer.  The plan is multi_plan's; its bias regions follow its slab regions, so they are rebased to the start of the first one.
+static size_t f32_bias_base(const vs_wgrad_desc* descs, int count, const MultiPlan& plan) {
+    size_t base = (size_t)-1;
+    for (int i = 0; i < count; ++i) if (descs[i].bias_g) base = std::min(base, plan.layers[i].bias_off);
+    return base;
+}
+static size_t f32_bias_bytes(const vs_wgrad_desc* descs, int count, int target_workgroups) {
+    bool any = false;
+    for (int i = 0; i < count; ++i) any = any || descs[i].bias_g != nullptr;
+    if (!any) return 0;
+    MultiPlan plan;
+    if (multi_plan(descs, count, 0.f, plan, target_workgroups)) return 0;
+    return plan.bytes - f32_bias_base(descs, count, plan);
+}
+
 extern "C" size_t vs_conv_wgrad_multi_throttled_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype, int target_workgroups) {
     if (!descs || count <= 0 || target_workgroups < 0) return 0;
     if (dtype == VS_F32) {                        // serial per-layer launches share one region; the uses of one weight need theirs side by side
@@ -1469,7 +1486,7 @@ extern "C" size_t vs_conv_wgrad_multi_throttled_workspace_bytes(const vs_wgrad_d
                     sum += vs_conv_wgrad_workspace_bytes(descs[j].n, descs[j].dp, descs[j].hp, descs[j].wp, descs[j].m_ch, descs[j].c_ch, descs[j].kind);
             mx = std::max(mx, sum);
         }
-        return limb_bytes + mx;
+        return limb_bytes + (mx + 255) / 256 * 256 + f32_bias_bytes(descs, count, target_workgroups);
     }
     MultiPlan plan;
     if (multi_plan(descs, count, 0.f, plan, target_workgroups, true)) return 0;
@@ -1526,13 +1543,59 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
                 prior += slabs;
             }
         }
-        for (int i = 0; i < count; ++i) {
-            const vs_wgrad_desc& d = descs[i];
-            if (!d.bias_g) continue;
-            bool first = true;
-            for (int j = 0; j < i; ++j) first = first && !(descs[j].bias_g && descs[j].db == d.db);
-            int rc = vs_bias_grad_acc(d.bias_g, d.db, d.bias_rows, d.bias_c_ch, d.bias_c_real, dtype, first ? 0 : 1, stream);
+        bool any_bias = false;
+        for (int i = 0; i < count; ++i) any_bias = any_bias || descs[i].bias_g != nullptr;
+        if (any_bias) {
+            size_t mx = 0;                               // the serial region's size, as the workspace query counts it
+            for (int i = 0; i < count; ++i) {
+                if (f32_limbs_on() && descs[i].kind == VS_CONV_K3) continue;
+                bool first = true;
+                for (int j = 0; j < i; ++j) first = first && descs[j].dw != descs[i].dw;
+                if (!first) continue;
+                size_t sum = 0;
+                for (int j = i; j < count; ++j)
+                    if (descs[j].dw == descs[i].dw)
+                        sum += vs_conv_wgrad_workspace_bytes(descs[j].n, descs[j].dp, descs[j].hp, descs[j].wp, descs[j].m_ch, descs[j].c_ch, descs[j].kind);
+                mx = std::max(mx, sum);
+            }
+            mx = (mx + 255) / 256 * 256;
+            MultiPlan plan;
+            int rc = multi_plan(descs, count, eps, plan, target_workgroups);
             if (rc) return rc;
+            const size_t base = f32_bias_base(descs, count, plan);
+            if (workspace_bytes < mx + (plan.bytes - base)) return VS_EWORKSPACE;
+            char* bws = (char*)workspace + mx;
+            std::vector<int> idx;
+            for (int i = 0; i < count; ++i) if (descs[i].bias_g) idx.push_back(i);
+            for (size_t at = 0; at < idx.size(); at += G3_BIAS_MAX) {
+                G3BiasGroup grp{};
+                grp.n = (int)std::min<size_t>(G3_BIAS_MAX, idx.size() - at);
+                int blk = 0;
+                for (int j = 0; j < grp.n; ++j) {
+                    const int i = idx[at + j];
+                    const vs_wgrad_desc& d = descs[i];
+                    if (d.bias_c_ch % 4 || 256 % (d.bias_c_ch / 4)) return VS_ESHAPE;
+                    grp.d[j] = G3BiasDesc{d.bias_g, (double*)(bws + (plan.layers[i].bias_off - base)), d.bias_rows, d.bias_c_ch, d.bias_c_real, plan.layers[i].bias_nblk, 0};
+                    grp.blk_start[j] = blk;
+                    blk += plan.layers[i].bias_nblk;
+                }
+                for (int j = grp.n; j <= G3_BIAS_MAX; ++j) grp.blk_start[j] = blk;
+                hipLaunchKernelGGL(bias_partial_group_kernel<float>, dim3(blk), dim3(256), 0, st, grp);
+                VS_CHECK_LAUNCH();
+            }
+            std::vector<G3RedDesc> red;
+            for (int i = 0; i < count; ++i)
+                if (descs[i].bias_g && plan.layers[i].bias_primary == i)
+                    red.push_back(G3RedDesc{(const float*)(bws + (plan.layers[i].bias_off - base)), descs[i].db, 0, descs[i].bias_c_real, 0, 0, plan.layers[i].bias_total_blk, 0, 0, 0, 1, G3_RED_ROWS});
+            for (size_t at = 0; at < red.size(); at += G3_RED_MAX) {
+                G3RedGroup grp{};
+                grp.n = (int)std::min<size_t>(G3_RED_MAX, red.size() - at);
+                long long blk = 0;
+                for (int j = 0; j < grp.n; ++j) { grp.d[j] = red[at + j]; grp.blk_start[j] = (int)blk; blk += vs_ceil_div(red[at + j].c_real, 64); }
+                for (int j = grp.n; j <= G3_RED_MAX; ++j) grp.blk_start[j] = (int)blk;
+                hipLaunchKernelGGL(g3_reduce_group_kernel, dim3((unsigned)blk), dim3(64 * G3_RED_ROWS), 0, st, grp);
+                VS_CHECK_LAUNCH();
+            }
         }
         return VS_OK;
     }
