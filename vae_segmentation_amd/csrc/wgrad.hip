@@ -818,6 +818,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 
 
 // Sum the partial slabs (fixed order, fp64) into the reference's [m][c][tap] layout.  A block = 64 consecutive slab
 // elements (coalesced reads) x 16 slab partitions; each thread keeps 8 loads in flight, LDS combines the partitions.
+// fp32 mode, stride-2 kinds: the layers of a pass in one grid on the exact-f32 MFMA body (their Q limb planes would not fit the LDS)
+template <int CB, int KIND>
+__global__ __launch_bounds__(256) void g3_group_kernel(const G3Group grp) {
+    const int b = blockIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < G3_GROUP_MAX; ++i) l += (i < grp.n && b >= grp.wg_start[i]) ? 1 : 0;
+    const G3Params p = grp.p[l];
+    const int local = b - grp.wg_start[l];
+    const int pairs = p.mbn * p.cbn;
+    const int ks = local / pairs;
+    g3_body<float, CB, KIND>(p, local - ks * pairs, ks);
+}
+
 template <int CB, int KIND>
 __global__ __launch_bounds__(1024) void g3_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int m_real, int c_real, int mbn,
                                                          int cbn, int nslabs) {
@@ -1358,11 +1372,15 @@ static bool f32_limbs_on() {
     return on != 0;
 }
 // descriptors of the pass that take the limb path, bias requests stripped (the fp32 branch sums biases with vs_bias_grad_acc); cb: 16 / 8
-static std::vector<vs_wgrad_desc> f32_limb_subset(const vs_wgrad_desc* descs, int count, int cb) {
+// the fp32 mode's grouped launches: 3x3x3 layers on the limb kernels, stride-2 layers on the exact-f32 MFMA body; 16- and 8-channel blocks each
+struct F32Grp { int kind, cb; };
+static const F32Grp F32_GROUPS[4] = {{VS_CONV_K3, 16}, {VS_CONV_K3, 8}, {VS_CONV_K2S2, 16}, {VS_CONV_K2S2, 8}};
+static bool f32_grouped_kind(int kind) { return kind == VS_CONV_K2S2 || (kind == VS_CONV_K3 && f32_limbs_on()); }
+static std::vector<vs_wgrad_desc> f32_limb_subset(const vs_wgrad_desc* descs, int count, int cb, int kind = VS_CONV_K3) {
     std::vector<vs_wgrad_desc> out;
-    if (!f32_limbs_on()) return out;
+    if (!f32_grouped_kind(kind)) return out;
     for (int i = 0; i < count; ++i) {
-        if (descs[i].kind != VS_CONV_K3 || (descs[i].c_ch >= 16 ? 16 : 8) != cb) continue;
+        if (descs[i].kind != kind || (descs[i].c_ch >= 16 ? 16 : 8) != cb) continue;
         vs_wgrad_desc d = descs[i];
         d.bias_g = nullptr; d.db = nullptr; d.bias_rows = 0; d.bias_c_ch = 0; d.bias_c_real = 0;
         out.push_back(d);
@@ -1370,6 +1388,29 @@ static std::vector<vs_wgrad_desc> f32_limb_subset(const vs_wgrad_desc* descs, in
     return out;
 }
 static inline int f32_limb_target(int cb) { return cb == 16 ? 256 : 512; }       // resident workgroups: one per CU (16-channel blocks: 90 KB of LDS), two (8)
+// stride-2 layers (exact-f32 MFMA, fp32 accumulators): as many workgroups as keep a workgroup at <= 8 tiles — the bound on an accumulator's chain the
+// per-layer plan keeps (g3_plan: VS_WGRAD_F32_TILES)
+static int f32_group_target(const std::vector<vs_wgrad_desc>& sub, int cb, int kind) {
+    if (kind == VS_CONV_K3) return f32_limb_target(cb);
+    long long work = 0;
+    for (const vs_wgrad_desc& d : sub) {
+        int cbsz, mbn, cbn, ncb, tps, tyn, txn, ks;
+        g3_plan(d.n, d.dp, d.hp, d.wp, d.m_ch, d.c_ch, d.kind, cbsz, mbn, cbn, ncb, tps, tyn, txn, ks, false);
+        work += (long long)mbn * cbn * tps * d.n;
+    }
+    return (int)std::min<long long>(std::max<long long>(256, (work + 7) / 8), 1 << 20);
+}
+template <int CB, int KIND>
+static int g3_group_run(const G3Group& grp, hipStream_t s) {
+    using GEO = G3Geo<CB, KIND>;
+    constexpr size_t lds = G3_LDS_Q + (size_t)GEO::QV * CB * 4;
+    auto kern = g3_group_kernel<CB, KIND>;
+    static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr_err != hipSuccess) return (int)attr_err;
+    hipLaunchKernelGGL(kern, dim3(grp.wg_start[grp.n]), dim3(256), lds, s, grp);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
 
 template <int CB>
 static int g3x_group_run(const G3Group& grp, hipStream_t s) {
@@ -1383,16 +1424,17 @@ static int g3x_group_run(const G3Group& grp, hipStream_t s) {
     return VS_OK;
 }
 
-static int f32_limb_group_launch(const std::vector<vs_wgrad_desc>& sub, int cb, float eps, char* ws, size_t ws_bytes, hipStream_t st) {
+static int f32_limb_group_launch(const std::vector<vs_wgrad_desc>& sub, int cb, float eps, char* ws, size_t ws_bytes, hipStream_t st, int kind = VS_CONV_K3) {
     if (sub.empty()) return VS_OK;
     MultiPlan plan;
-    int rc = multi_plan(sub.data(), (int)sub.size(), eps, plan, f32_limb_target(cb));
+    int rc = multi_plan(sub.data(), (int)sub.size(), eps, plan, f32_group_target(sub, cb, kind));
     if (rc) return rc;
     if (ws_bytes < plan.bytes) return VS_EWORKSPACE;
     const int count = (int)sub.size();
     for (int i = 0; i < count; ++i) {                    // fp32 operands: 4-byte elements under the 32-bit buffer offsets
         const vs_wgrad_desc& d = sub[i];
-        if ((long long)d.n * d.dp * d.hp * d.wp * d.m_ch * 4 >= 2147483648ll || (long long)d.n * d.dp * d.hp * d.wp * d.c_ch * 4 >= 2147483648ll) return VS_ESHAPE;
+        const long long qv = kind == VS_CONV_K2S2 ? 8 : 1;          // Q grid: the fine one for the stride-2 kinds
+        if ((long long)d.n * d.dp * d.hp * d.wp * d.m_ch * 4 >= 2147483648ll || (long long)d.n * d.dp * d.hp * d.wp * qv * d.c_ch * 4 >= 2147483648ll) return VS_ESHAPE;
     }
     std::vector<int> idx(count);
     for (int i = 0; i < count; ++i) idx[i] = i;
@@ -1411,7 +1453,8 @@ static int f32_limb_group_launch(const std::vector<vs_wgrad_desc>& sub, int cb, 
         }
         if (wg >= 2147483647ll) return VS_ESHAPE;
         for (int j = grp.n; j <= G3_GROUP_MAX; ++j) grp.wg_start[j] = (int)wg;
-        rc = cb == 16 ? g3x_group_run<16>(grp, st) : g3x_group_run<8>(grp, st);
+        if (kind == VS_CONV_K2S2) rc = cb == 16 ? g3_group_run<16, G3_K2S2>(grp, st) : g3_group_run<8, G3_K2S2>(grp, st);
+        else rc = cb == 16 ? g3x_group_run<16>(grp, st) : g3x_group_run<8>(grp, st);
         if (rc) return rc;
     }
     std::vector<G3RedDesc> red;
@@ -1422,7 +1465,7 @@ static int f32_limb_group_launch(const std::vector<vs_wgrad_desc>& sub, int cb, 
         const long long slab_elems = (long long)L.p.mbn * L.p.cbn * L.ncb * 256;
         int parts = 1;
         while (parts < G3_RED_ROWS && parts * 8 < L.total_slabs) parts *= 2;
-        red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.total_slabs, L.cbsz, 27, L.ncb, 0, parts});
+        red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.total_slabs, L.cbsz, kind == VS_CONV_K2S2 ? 8 : 27, L.ncb, 0, parts});
         blocks.push_back(vs_ceil_div(slab_elems, 256 * (G3_RED_ROWS / parts)));
     }
     for (size_t at = 0; at < red.size(); at += G3_RED_MAX) {
@@ -1437,10 +1480,10 @@ static int f32_limb_group_launch(const std::vector<vs_wgrad_desc>& sub, int cb, 
     }
     return VS_OK;
 }
-static size_t f32_limb_group_bytes(const std::vector<vs_wgrad_desc>& sub, int cb) {
+static size_t f32_limb_group_bytes(const std::vector<vs_wgrad_desc>& sub, int cb, int kind = VS_CONV_K3) {
     if (sub.empty()) return 0;
     MultiPlan plan;
-    if (multi_plan(sub.data(), (int)sub.size(), 0.f, plan, f32_limb_target(cb))) return 0;
+    if (multi_plan(sub.data(), (int)sub.size(), 0.f, plan, f32_group_target(sub, cb, kind))) return 0;
     return (plan.bytes + 255) / 256 * 256;
 }
 }  // namespace
@@ -1473,10 +1516,11 @@ extern "C" size_t vs_conv_wgrad_multi_throttled_workspace_bytes(const vs_wgrad_d
     if (!descs || count <= 0 || target_workgroups < 0) return 0;
     if (dtype == VS_F32) {                        // serial per-layer launches share one region; the uses of one weight need theirs side by side
         // the 3x3x3 layers of the limb path come first: two grouped regions (16- / 8-channel blocks); the serial region of the other layers follows
-        const size_t limb_bytes = f32_limb_group_bytes(f32_limb_subset(descs, count, 16), 16) + f32_limb_group_bytes(f32_limb_subset(descs, count, 8), 8);
+        size_t limb_bytes = 0;
+        for (const F32Grp& gk : F32_GROUPS) limb_bytes += f32_limb_group_bytes(f32_limb_subset(descs, count, gk.cb, gk.kind), gk.cb, gk.kind);
         size_t mx = 0;
         for (int i = 0; i < count; ++i) {
-            if (f32_limbs_on() && descs[i].kind == VS_CONV_K3) continue;
+            if (f32_grouped_kind(descs[i].kind)) continue;
             bool first = true;
             for (int j = 0; j < i; ++j) first = first && descs[j].dw != descs[i].dw;
             if (!first) continue;
@@ -1509,18 +1553,18 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
         {
             char* wsp = (char*)workspace;
             size_t left = workspace_bytes;
-            for (int cb = 16; cb >= 8; cb -= 8) {
-                const std::vector<vs_wgrad_desc> sub = f32_limb_subset(descs, count, cb);
-                const size_t need = f32_limb_group_bytes(sub, cb);
+            for (const F32Grp& gk : F32_GROUPS) {
+                const std::vector<vs_wgrad_desc> sub = f32_limb_subset(descs, count, gk.cb, gk.kind);
+                const size_t need = f32_limb_group_bytes(sub, gk.cb, gk.kind);
                 if (need > left) return VS_EWORKSPACE;
-                int rc = f32_limb_group_launch(sub, cb, eps, wsp, left, st);
+                int rc = f32_limb_group_launch(sub, gk.cb, eps, wsp, left, st, gk.kind);
                 if (rc) return rc;
                 wsp += need; left -= need;
             }
             workspace = wsp; workspace_bytes = left;
         }
         for (int i = 0; i < count; ++i) {
-            if (f32_limbs_on() && descs[i].kind == VS_CONV_K3) continue;
+            if (f32_grouped_kind(descs[i].kind)) continue;
             bool first = true;
             for (int j = 0; j < i; ++j) first = first && descs[j].dw != descs[i].dw;
             if (!first) continue;
@@ -1548,7 +1592,7 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
         if (any_bias) {
             size_t mx = 0;                               // the serial region's size, as the workspace query counts it
             for (int i = 0; i < count; ++i) {
-                if (f32_limbs_on() && descs[i].kind == VS_CONV_K3) continue;
+                if (f32_grouped_kind(descs[i].kind)) continue;
                 bool first = true;
                 for (int j = 0; j < i; ++j) first = first && descs[j].dw != descs[i].dw;
                 if (!first) continue;
