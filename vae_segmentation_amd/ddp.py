@@ -63,6 +63,14 @@ def collective_capturable(group=None):
                 torch.cuda.synchronize()
             except Exception:                                # noqa: BLE001
                 pass
+    if dist.get_world_size(group) > 1 and dist.get_backend(group) == "nccl" and torch.cuda.is_available():
+        # every rank must take the same form of the tail (captured / eager): one that could not capture decides for all
+        try:
+            flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            ok = bool(flag.item() > 0.5)
+        except Exception:                                    # noqa: BLE001
+            ok = False
     _CAPTURABLE[key] = ok
     return ok
 
