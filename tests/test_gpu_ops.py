@@ -482,13 +482,14 @@ def _group_layers_backward(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("mpack", ["1", "0"])
-def test_grouped_weight_gradients_many_layers(dtype, mpack, monkeypatch):
+@pytest.mark.parametrize("mpack,uber", [("1", "1"), ("0", "1"), ("1", "0")])
+def test_grouped_weight_gradients_many_layers(dtype, mpack, uber, monkeypatch):
     """vs_conv_wgrad_multi (main_source.py:660: the gradients the optimiser step reads): 34 layers of all conv kinds deferred to the end of ONE
     backward pass and issued as grouped launches — each against F.conv3d / F.conv_transpose3d autograd on the CPU, against the
     per-layer launches (vs_conv_wgrad), and bitwise reproducible.  mpack: the M-packed form of the layers with 8 stored output channels
-    (csrc/wgrad.hip g3b_body) on / off."""
+    (csrc/wgrad.hip g3b_body) on / off; uber: all buckets in one grid / one grid per bucket."""
     monkeypatch.setenv("VS_WGRAD_MPACK", mpack)
+    monkeypatch.setenv("VS_WGRAD_UBER", uber)              # 1: every bucket in one grid (g3b_uber_kernel, the default); 0: one grid per bucket
     ops = _ops()
     assert ops._GROUP["enabled"]
     got, refs = _group_layers_backward(ops, dtype)

@@ -1651,7 +1651,8 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
     char* ws = (char*)workspace;
 
     // ---- every bucket in one grid (G3_GROUP_MAX layers per grid, longest workgroups first); VS_WGRAD_UBER=0: one grid per bucket ----
-    static const int uber = getenv("VS_WGRAD_UBER") ? atoi(getenv("VS_WGRAD_UBER")) : 1;
+    const char* uber_str = getenv("VS_WGRAD_UBER");       // read per call (the tests run both forms)
+    const int uber = uber_str ? atoi(uber_str) : 1;
     if (uber) {
         std::vector<int> idx(count);
         for (int i = 0; i < count; ++i) idx[i] = i;
