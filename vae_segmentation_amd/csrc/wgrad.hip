@@ -765,44 +765,6 @@ __global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
     g3b_body<T, CB, KIND, MP>(p, local - (local / pairs) * pairs, ks);
 }
 
-// Every bucket of a pass in ONE grid: a workgroup looks up its layer, then runs that layer's instantiation of g3b_body.  Per-bucket launches each pay
-// their own ramp and drain — every workgroup's prologue (statistics tables, first loads) and epilogue (slab reduction through LDS, slab store), about
-// 20 us of a 93 us launch (profiles/r04_wgrad_ablation.txt), run at the same moment on every CU; in one grid of several workgroups per slot they overlap
-// other workgroups' tile loops.  Registers and LDS are those of the largest instantiation (all of the big ones sit at two workgroups per CU anyway).
-enum { G3V_K3_16 = 0, G3V_K3_8, G3V_K2S2_16, G3V_K2S2_8, G3V_UP_16, G3V_K3_16_MP, G3V_K3_8_MP, G3V_COUNT };
-template <typename T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void g3b_uber_kernel(const G3Group grp) {      // (left alone the union of the variants' registers is 284)
-    const int b = blockIdx.x;
-    int l = 0;
-#pragma unroll
-    for (int i = 1; i < G3_GROUP_MAX; ++i) l += (i < grp.n && b >= grp.wg_start[i]) ? 1 : 0;
-    const G3Params p = grp.p[l];
-    const int local = b - grp.wg_start[l];
-    const int pairs = p.mbn * p.cbn;
-    int ks = local / pairs;
-    if (grp.xcd && pairs == 1 && p.ksplit >= 16) {          // as g3b_group_kernel: XCD x walks one contiguous run of k-splits
-        const int b0 = grp.wg_start[l], x = b & 7;
-        int start = 0;
-#pragma unroll
-        for (int xx = 0; xx < 8; ++xx) {
-            const int first = (xx - b0) & 7;
-            const int cnt = first < p.ksplit ? (p.ksplit - first + 7) >> 3 : 0;
-            start += xx < x ? cnt : 0;
-        }
-        ks = start + ((local - ((x - b0) & 7)) >> 3);
-    }
-    const int bx = local - (local / pairs) * pairs;
-    switch (p.variant) {                                   // uniform per workgroup
-        case G3V_K3_16:    g3b_body<T, 16, G3_K3, false>(p, bx, ks); break;
-        case G3V_K3_8:     g3b_body<T, 8, G3_K3, false>(p, bx, ks); break;
-        case G3V_K2S2_16:  g3b_body<T, 16, G3_K2S2, false>(p, bx, ks); break;
-        case G3V_K2S2_8:   g3b_body<T, 8, G3_K2S2, false>(p, bx, ks); break;
-        case G3V_UP_16:    g3b_body<T, 16, G3_UP, false>(p, bx, ks); break;
-        case G3V_K3_16_MP: g3b_body<T, 16, G3_K3, true>(p, bx, ks); break;
-        default:           g3b_body<T, 8, G3_K3, true>(p, bx, ks); break;
-    }
-}
-
 // the same grouping for the limb kernel of the fp32 parity mode (3x3x3 layers): one grid per channel-block width
 template <int CB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 ? 2 : 1))) void g3x_group_kernel(const G3Group grp) {
@@ -1139,14 +1101,8 @@ struct G3BiasGroup {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void bias_partial_group_kernel(const G3BiasGroup grp) {
-    __shared__ float s_red[256 * 8];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    int l = 0;
-#pragma unroll
-    for (int i = 1; i < G3_BIAS_MAX; ++i) l += (i < grp.n && b >= grp.blk_start[i]) ? 1 : 0;
-    const G3BiasDesc d = grp.d[l];
-    const int lb = b - grp.blk_start[l];
+__device__ __forceinline__ void bias_partial_body(const G3BiasDesc& d, const int lb, float* s_red) {
+    const int tid = threadIdx.x;
     constexpr int EPL = ET<T>::EPL;               // channels per 16-byte fragment: 8 (16-bit storage) or 4 (fp32)
     const int frags = d.c_ch / EPL, fx = tid % frags, fy = tid / frags, rpi = 256 / frags;
     float part[EPL];
@@ -1179,6 +1135,62 @@ __global__ __launch_bounds__(256) void bias_partial_group_kernel(const G3BiasGro
         d.part[(size_t)lb * d.c_real + ch] = tot;
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void bias_partial_group_kernel(const G3BiasGroup grp) {
+    __shared__ float s_red[256 * 8];
+    const int b = blockIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < G3_BIAS_MAX; ++i) l += (i < grp.n && b >= grp.blk_start[i]) ? 1 : 0;
+    bias_partial_body<T>(grp.d[l], b - grp.blk_start[l], s_red);
+}
+
+// Every bucket of a pass in ONE grid: a workgroup looks up its layer, then runs that layer's instantiation of g3b_body.  Per-bucket launches each pay
+// their own ramp and drain — every workgroup's prologue (statistics tables, first loads) and epilogue (slab reduction through LDS, slab store), about
+// 20 us of a 93 us launch (profiles/r04_wgrad_ablation.txt), run at the same moment on every CU; in one grid of several workgroups per slot they overlap
+// other workgroups' tile loops.  Registers and LDS are those of the largest instantiation (all of the big ones sit at two workgroups per CU anyway).
+// The bias gradients' partial sums ride in the same grid as one more variant: their entries re-use G3Params (P = the gradient rows, ws = the partial sums,
+// total_tiles = rows, Mch / Cch = stored / real channels, ksplit = blocks), so the separate 22 us launch disappears into the grid's tail.
+enum { G3V_K3_16 = 0, G3V_K3_8, G3V_K2S2_16, G3V_K2S2_8, G3V_UP_16, G3V_K3_16_MP, G3V_K3_8_MP, G3V_BIAS, G3V_COUNT };
+template <typename T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void g3b_uber_kernel(const G3Group grp) {      // (left alone the union of the variants' registers is 284)
+    const int b = blockIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < G3_GROUP_MAX; ++i) l += (i < grp.n && b >= grp.wg_start[i]) ? 1 : 0;
+    const G3Params p = grp.p[l];
+    const int local = b - grp.wg_start[l];
+    const int pairs = p.mbn * p.cbn;
+    int ks = local / pairs;
+    if (grp.xcd && pairs == 1 && p.ksplit >= 16) {          // as g3b_group_kernel: XCD x walks one contiguous run of k-splits
+        const int b0 = grp.wg_start[l], x = b & 7;
+        int start = 0;
+#pragma unroll
+        for (int xx = 0; xx < 8; ++xx) {
+            const int first = (xx - b0) & 7;
+            const int cnt = first < p.ksplit ? (p.ksplit - first + 7) >> 3 : 0;
+            start += xx < x ? cnt : 0;
+        }
+        ks = start + ((local - ((x - b0) & 7)) >> 3);
+    }
+    const int bx = local - (local / pairs) * pairs;
+    if (p.variant == G3V_BIAS) {
+        extern __shared__ __attribute__((aligned(16))) char smem_b[];
+        const G3BiasDesc d{p.P, (double*)p.ws, (long long)p.total_tiles, p.Mch, p.Cch, p.ksplit, 0};
+        bias_partial_body<T>(d, local, (float*)smem_b);
+        return;
+    }
+    switch (p.variant) {                                   // uniform per workgroup
+        case G3V_K3_16:    g3b_body<T, 16, G3_K3, false>(p, bx, ks); break;
+        case G3V_K3_8:     g3b_body<T, 8, G3_K3, false>(p, bx, ks); break;
+        case G3V_K2S2_16:  g3b_body<T, 16, G3_K2S2, false>(p, bx, ks); break;
+        case G3V_K2S2_8:   g3b_body<T, 8, G3_K2S2, false>(p, bx, ks); break;
+        case G3V_UP_16:    g3b_body<T, 16, G3_UP, false>(p, bx, ks); break;
+        case G3V_K3_16_MP: g3b_body<T, 16, G3_K3, true>(p, bx, ks); break;
+        default:           g3b_body<T, 8, G3_K3, true>(p, bx, ks); break;
+    }
+}
+
 
 namespace {
 struct MultiLayer {
@@ -1658,6 +1670,8 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
         for (int i = 0; i < count; ++i) idx[i] = i;
         auto key = [&](int a) { const MultiLayer& L = plan.layers[a]; return (double)L.work * g3v_tile_cost(g3v_of(L.cbsz, L.kind, L.p.mp != 0)); };
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key(a) > key(b); });
+        for (int i = 0; i < count; ++i)                      // the bias gradients' partial sums: entries -(i + 1), behind the weight layers (short workgroups)
+            if (descs[i].bias_g && descs[i].bias_rows < 2147483647ll) idx.push_back(-(i + 1));
         for (size_t at = 0; at < idx.size(); at += G3_GROUP_MAX) {
             G3Group grp{};
             static const int xcd_walk = getenv("VS_WGRAD_XCD") ? atoi(getenv("VS_WGRAD_XCD")) : 1;
@@ -1666,6 +1680,19 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
             long long wg = 0;
             size_t lds = 0;
             for (int j = 0; j < grp.n; ++j) {
+                if (idx[at + j] < 0) {
+                    const int i = -idx[at + j] - 1;
+                    const vs_wgrad_desc& d = descs[i];
+                    G3Params q{};
+                    q.P = d.bias_g; q.ws = (float*)(ws + plan.layers[i].bias_off);
+                    q.total_tiles = (int)d.bias_rows; q.Mch = d.bias_c_ch; q.Cch = d.bias_c_real; q.ksplit = plan.layers[i].bias_nblk;
+                    q.mbn = 1; q.cbn = 1; q.variant = G3V_BIAS;
+                    grp.p[j] = q;
+                    lds = std::max(lds, (size_t)256 * 8 * sizeof(float));
+                    grp.wg_start[j] = (int)wg;
+                    wg += q.ksplit;
+                    continue;
+                }
                 MultiLayer& L = plan.layers[idx[at + j]];
                 if (L.kind == VS_CONV_UP && L.cbsz != 16) return VS_ESHAPE;
                 grp.p[j] = L.p;
@@ -1719,10 +1746,10 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
             if (rc) return rc;
         }
     }
-    // ---- bias partials ----
+    // ---- bias partials (in the all-buckets grid above when it is on) ----
     {
         std::vector<int> idx;
-        for (int i = 0; i < count; ++i) if (descs[i].bias_g) idx.push_back(i);
+        for (int i = 0; i < count; ++i) if (descs[i].bias_g && (!uber || descs[i].bias_rows >= 2147483647ll)) idx.push_back(i);
         for (size_t at = 0; at < idx.size(); at += G3_BIAS_MAX) {
             G3BiasGroup grp{};
             grp.n = (int)std::min<size_t>(G3_BIAS_MAX, idx.size() - at);
