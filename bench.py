@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--recompute", action="store_true", help="activation recomputation in the Down / Up blocks (joint_model.set_recompute, DESIGN 4.4)")
     ap.add_argument("--no-exchange-forms", action="store_true", help="N > 1: skip the no-exchange / other-exchange-form timing legs")
     ap.add_argument("--no-other-form", action="store_true", help="N > 1: time the no-exchange leg but not the other exchange form")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1, default workload: skip the configs[3] / configs[4] entries (`other_configs`)")
+    ap.add_argument("--legs-budget-s", type=float, default=60.0, help="N > 1: the other exchange form is timed only if everything before it "
+                    "(set-up, main timing, the no-exchange leg) took less than this on every rank: rank 0's line must not wait for it")
     a = ap.parse_args()
     cfg = CONFIGS[a.config]
     a.dtype = a.dtype or cfg["dtype"]
@@ -211,9 +214,6 @@ def make_step(a, dtype, rank, use_dist, overlap=None, info=None):
         return T.joint_train_losses(joint, img, lab, lambda_vae=0.1)
 
     if a.no_graph:
-        from vae_segmentation_amd import ops as _ops
-        _ops.set_overlap(False)
-
         def step():
             for p in seg_params:
                 p.grad = None
@@ -286,7 +286,38 @@ def step_roofline(dtype, ms_per_step, families, config="joint96"):
     return out
 
 
+def other_configs(a, rank, torch):
+    """configs[3] (da128) and one GPU's share of configs[4] (joint160, fp16 storage + dynamic loss scaling) timed in the SAME run as the
+    headline workload, with the same protocol (HIP-graph replay, inputs resident, synchronise on both sides) on a short leg — 3 warm-up +
+    10 timed steps each — and the same whole-step roofline object, so that the driver's record carries a number for every single-GPU
+    configuration of BASELINE.json."""
+    import copy
+    out = []
+    for name in ("da128", "joint160"):
+        b = copy.copy(a)
+        cfg = CONFIGS[name]
+        b.config, b.side, b.batch, b.dtype = name, cfg["side"], cfg["batch"], cfg["dtype"]
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        info = {}
+        step, _, _, closer = make_step(b, b.dtype, rank, False, info=info)
+        n, w = 10, 3
+        dt, loss = timed_steps(step, n, w, lambda: torch.cuda.synchronize())
+        ms = 1e3 * dt / n
+        out.append({"config": name, "workload": (cfg["name"] % (b.side, b.batch)) + ", %s activations + fp32 accumulate%s, SGD momentum 0.9, VAE frozen, "
+                    "HIP-graph replay" % (b.dtype, " + dynamic loss scaling" if b.dtype == "fp16" else ""),
+                    "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[b.dtype], "value": b.batch * n / dt, "unit": "volumes/s",
+                    "ms_per_step": ms, "steps": n, "warmup": w, "final_loss": float(loss.item()), "tail_in_graph": info.get("tail_in_graph", False),
+                    "peak_device_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+                    "roofline": step_roofline(b.dtype, ms, None, name)})
+        closer()
+        del step, loss
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
+    t_process = time.perf_counter()
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
@@ -376,7 +407,12 @@ def main():
             print("bench.py: default exchange form %.4f ms per step, without exchange %.4f; timing the other form now"
                   % (ms_per_step, 1e3 * dt_n / n_x), file=sys.stderr, flush=True)
         other = not (os.environ.get("VS_DDP_OVERLAP", "0") == "1")
-        if a.no_other_form:
+        # every rank takes the same branch (the legs are collective): the slowest rank's clock decides
+        spent = max_over_ranks(time.perf_counter() - t_process)
+        exchange["seconds_before_other_form"] = round(spent, 1)
+        if a.no_other_form or spent > a.legs_budget_s:
+            if not a.no_other_form:
+                exchange["other_form_skipped"] = "%.0f s spent before it (budget %.0f s): the line is printed instead" % (spent, a.legs_budget_s)
             step, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, True, info=info1)
         else:
             step, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, True, overlap=other, info=info1)
@@ -385,7 +421,7 @@ def main():
             exchange["other_form"] = {"buckets": info1.get("buckets"), "overlap": other, "tail_in_graph": info1.get("tail_in_graph"),
                                       "ms_per_step": round(1e3 * dt_o / n_x, 4)}
 
-    families, fp32_mode, cpu = None, None, None
+    families, fp32_mode, cpu, others = None, None, None, None
     if rank == 0 and not a.no_families:
         # per-kernel-family timing: HIP events around every launch inside real (eager) forward+backward passes
         closer()                                 # gradients back to ordinary tensors for the eager profiling pass
@@ -411,7 +447,12 @@ def main():
                      "note": "fp32 storage; 3x3x3 convolutions and their weight gradients on the bf16 matrix cores through three-limb operand splitting (six exact "
                              "limb products per product, fp32 accumulation: csrc/igemm_k3x.h) - the mode that meets the 1e-3 parity gate (tests/test_gpu_model.py); "
                              "round 3 ran it on the exact-f32 MFMA at 9.83 ms"}
+        closer32()
         del step32
+    if rank == 0 and world == 1 and not use_dist and a.config == "joint96" and a.side == CONFIGS["joint96"]["side"] and not a.no_other_configs \
+            and not a.no_graph and not a.recompute:
+        peak_main = round(torch.cuda.max_memory_allocated() / 1e9, 2)
+        others = other_configs(a, rank, torch)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.side, a.cpu_steps, batch=a.batch, method=CONFIGS[a.config]["method"])
 
@@ -428,7 +469,7 @@ def main():
                                    % (a.dtype, " + dynamic loss scaling" if a.dtype == "fp16" else ""),
                        "global_batch": world * a.batch, "parallelism": "dp%d" % world, "final_loss": final_loss,
                        "activation_recomputation": bool(a.recompute),
-                       "peak_device_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+                       "peak_device_memory_GB": peak_main if others is not None else round(torch.cuda.max_memory_allocated() / 1e9, 2),
                        # host time per step to issue the work (one graph launch, then the exchange and the optimiser eagerly); far below ms_per_step = the
                        # step is GPU-bound and capturing those tail launches into the graph as well would not shorten it
                        "host_issue_ms_per_step": round(host_issue_ms, 4),
@@ -441,6 +482,8 @@ def main():
                                          if use_dist else "none (1 rank)")},
             "roofline": step_roofline(a.dtype, ms_per_step / 1.0, families, a.config) if a.side == cfg["side"] else None,
             "fp32_parity_mode": fp32_mode, "cpu_baseline": cpu,
+            # the other single-GPU configurations of BASELINE.json, timed in this run on short legs (3 warm-up + 10 steps): configs[3], configs[4]'s share
+            "other_configs": others,
         }
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())

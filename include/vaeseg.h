@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VS_VERSION 205
+#define VS_VERSION 500
 
 enum { VS_F32 = 0, VS_BF16 = 1, VS_F16 = 2, VS_F32X3 = 3 /* PACK-ONLY: three-bf16-limb image of an fp32 3x3x3 weight, see vs_conv_k3_f32_limbs */ };   /* storage type of activations: fp32 (parity mode), bf16, IEEE fp16 (needs loss scaling, see vs_loss_scale_*) */
 #ifndef VS_STAT_SLOTS
@@ -205,14 +205,6 @@ typedef struct vs_wgrad_desc {
 size_t vs_conv_wgrad_multi_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype);
 int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
                         float eps, void* stream);
-/* The same with the width of the grids chosen by the caller: each (channel block, kind) bucket is ONE persistent grid of about
- * `target_workgroups` workgroups, every workgroup walking its share of the tiles (0 = the default, 512: two per CU).  A small target
- * (32 .. 128) makes a launch that occupies a fraction of the chip for proportionally longer — the form that can run on a second stream
- * UNDER the latency-bound low-resolution half of backward (ops.py: early weight-gradient flush) without taking the critical path's CUs.
- * The workspace size depends on the target (fewer k-splits, fewer slabs): query it with the same value. */
-size_t vs_conv_wgrad_multi_throttled_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype, int target_workgroups);
-int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
-                                  float eps, int target_workgroups, void* stream);
 /* db[c] = sum over rows of g[rows][c_ch], c < c_real (bias gradient of a conv whose bias is live). */
 int vs_bias_grad(const void* g, float* db, long long rows, int c_ch, int c_real, int dtype, void* stream);
 /* same; accumulate != 0 adds to db instead of overwriting it (a bias used several times in one backward pass) */
@@ -348,6 +340,9 @@ int vs_softmax_cl_bwd(const float* prob, const float* gprob, void* glogit, int n
                       float drop_p, unsigned long long drop_seed, void* stream);
 /* label (float, values 0..n_class-1) [N][1][V] -> one-hot planar fp32 [N][n_class][V]   (main_source.py:449-451) */
 int vs_onehot(const float* label, float* out, int n, long long voxels, int n_class, void* stream);
+/* hard masks of the validation Dice (utils/evaluation.py:58-64: torch.argmax over channels -> scatter_ into zeros): x, out planar
+ * (n, n_class, voxels) fp32; out[b][k][v] = (k == argmax_k' x[b][k'][v]), ties to the first maximal channel as torch.argmax; any n_class >= 1 */
+int vs_hard_onehot(const float* x, float* out, int n, int n_class, long long voxels, void* stream);
 /* mode 0: (a >= 0.5) ; mode 1: a>hi -> 1, a<lo -> 0, else a        (utils/evaluation.py:9-18) */
 int vs_binarize(const float* a, float* out, long long count, int mode, float lo, float hi, void* stream);
 
@@ -438,6 +433,12 @@ int vs_adam_multi(float* const* params, const float* const* grads, float* const*
 int vs_sgd_momentum_scaled_multi(float* const* params, const float* const* grads, float* const* bufs, const long long* sizes,
                                  const int* block_map, int n_blocks, float lr, float momentum, float weight_decay,
                                  int first_step, const float* loss_scale, const float* found_inf, void* stream);
+/* the same update with the hyperparameters read from DEVICE memory, hyper[3] = {lr, momentum, weight_decay}: a launch captured into a HIP
+ * graph (train.GraphedStep's captured tail) follows a learning-rate schedule without being re-captured — the host rewrites the three floats.
+ * Momentum buffers must exist and hold zeros before the first step (buf = mom*0 + g = torch's clone(g)); loss_scale / found_inf may be NULL. */
+int vs_sgd_momentum_dev_multi(float* const* params, const float* const* grads, float* const* bufs, const long long* sizes,
+                              const int* block_map, int n_blocks, const float* hyper, const float* loss_scale,
+                              const float* found_inf, void* stream);
 int vs_adam_scaled_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                          const long long* sizes, const int* block_map, int n_blocks, float lr, double beta1, double beta2,
                          float eps, float weight_decay, int step, const float* loss_scale, const float* found_inf, void* stream);

@@ -707,6 +707,17 @@ def hashed_uniform(n, stream, seed=0):
     return ((h >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
 
 
+def kat_scores(seed, n_class=4, shape=(2, 3, 4, 5)):
+    """(B, n_class, D, H, W) hashed scores for the multi-class hard-Dice known-answer test (tests/golden/kats.npz: dice4_*), with two planted
+    ties — every channel equal at one voxel (argmax -> channel 0) and channels 1 and 2 sharing the maximum at another (-> channel 1)."""
+    b = shape[0]
+    x = torch.from_numpy(hashed_uniform(b * n_class * int(np.prod(shape[1:])), 8101, seed)).view(b, n_class, *shape[1:]).clone()
+    x[0, :, 0, 0, 0] = 0.25
+    x[b - 1, :, 1, 1, 1] = 0.1
+    x[b - 1, 1:3, 1, 1, 1] = 0.9
+    return x
+
+
 def _name_stream(name):
     return zlib.crc32(name.encode("utf-8")) & 0x7FFFFFFF
 

@@ -112,15 +112,99 @@ def scalar_close(gold, key, val, floor=1e-3, factor=3.0):
     return mine / max(abs(f64), 1e-30)
 
 
-# Floor for the END-TO-END gradient comparison of Embed at 128^3 (three chained networks, ~90 InstanceNorm/ReLU layers) against the fp64 yardstick.
-# The reference's own eager fp32 run sits 3.4e-2 (median over its 138 tensors) from its fp64 run there, and a handful of encoder tensors are on a
-# knife edge: tools/limb_accuracy_embed.py (profiles/r04_fp32_limb_accuracy.txt) — enc.down3 / down4 gradients are 4e-6 from fp64 in the reference's
-# fp32 run and in the exact-f32 MFMA kernels' unperturbed run, and 1.0e-2 .. 1.5e-2 as soon as the weights move by +-1 fp32 ulp (exact-f32 kernels) or
-# the kernels round differently (limb kernels, perturbed or not): one activation on a ReLU edge decides.  A ratio to the reference's own error cannot
-# gate such tensors; the floor holds the draw.  The kernels are pinned where the comparison is exact: per op (tests/test_gpu_ops.py,
-# tests/test_gpu_layers.py: 2e-5 against CPU autograd, measured 1e-7 .. 7e-7) and per single forward / backward step recomputed in fp64 from the
-# kernels' own inputs (tests/test_gpu_backward_steps.py: asserted 5e-6, measured 9e-7).
-DRAW_FLOOR_GRAD = 2.5e-2
+# ---------------------------------------------------------------------------------------------------
+# Measured-envelope checks for the end-to-end cases where the network amplifies rounding 1e4 - 1e6 x (seg96, joint96, embed128).
+# tests/golden/envelopes.npz (oracle/make_golden.py: gold_envelopes) holds, per tensor, the LARGEST distance to the reference's fp64 run over
+# the reference's own eager fp32 run and K = 11 more fp32 runs of it with every weight moved by +-1 ulp: what the reference's fp32 arithmetic
+# itself does to the quantity when its rounding falls differently.  HIP's fp32 mode must stay within `factor` (1.5) x that envelope, floors
+# 1e-3 (outputs) / 2e-3 (gradients) as everywhere.  No hand-set floor, no second (hard) bound, no outlier list: beyond the limit fails.
+# seg96 / joint96: one run of the candidate, every tensor.  embed128 (145 tensors, three chained networks): the candidate's median over three runs
+# (its own +-1-ulp draws) — see check_grads_env.
+# ---------------------------------------------------------------------------------------------------
+_ENV = {}
+
+
+def envelopes():
+    if not _ENV:
+        _ENV.update(load("envelopes"))
+    return _ENV
+
+
+def _dist_f64(a, gold, key, k):
+    l64 = float(gold[key + ".l2@f64"])
+    rms = l64 / np.sqrt(a.size)
+    s64 = gold[key + ".samples@f64"].astype(np.float64)
+    return max(_sample_err(a[sample_idx(a.size, k)], s64, rms), abs(float(np.sqrt((a * a).sum())) - l64) / max(l64, 1e-30))
+
+
+def check_tensor_env(gold, tag, prefix, t, k=64, floor=1e-3, factor=1.5, what=""):
+    """t against the fp64 run, limit = max(floor, factor x the reference-fp32 envelope of this tensor); -> (mine, envelope)"""
+    env = float(envelopes()["%s/%s.envelope" % (tag, prefix)])
+    mine = _dist_f64(flat64(t), gold, prefix, k)
+    lim = max(floor, factor * env)
+    assert mine <= lim, "%s %s: error vs fp64 %.3g > %.3g (= max(%.0e, %.1f x the reference's fp32 envelope %.3g))" % (what or tag, prefix, mine, lim, floor, factor, env)
+    return mine, env
+
+
+def perturb_ulp_(module, seed):
+    """oracle/make_golden.py's perturbation, on any device: every fp32 parameter moved by exactly one ulp, up or down by a hashed coin (seed 0: nothing)"""
+    from oracle import ref_cpu as O
+    if not seed:
+        return module
+    with torch.no_grad():
+        for i, prm in enumerate(module.parameters()):
+            if prm.dtype != torch.float32:
+                continue
+            up = torch.from_numpy(O.hashed_uniform(prm.numel(), 9100 + i, seed) < 0.5).view(prm.shape).to(prm.device)
+            inf = torch.full_like(prm, float("inf"))
+            prm.copy_(torch.where(up, torch.nextafter(prm, inf), torch.nextafter(prm, -inf)))
+    return module
+
+
+def grads_dist(gold, prefix, named_grads, k=16, dead_atol=1e-5, what=""):
+    """{parameter name: distance of its gradient to the fp64 run} for the live parameters (dead biases are checked against zero here)"""
+    out = {}
+    for name, g in named_grads:
+        key = "%s.grad.%s" % (prefix, name)
+        if key + ".none" in gold:
+            assert g is None, "%s: expected no grad for %s" % (what, name)
+            continue
+        assert g is not None, "%s: missing grad for %s" % (what, name)
+        a = flat64(g)
+        l64 = float(gold[key + ".l2@f64"])
+        if is_dead_bias(name) or l64 < dead_atol * np.sqrt(a.size) * 10:        # dead parameter (conv bias feeding InstanceNorm): exact value is 0
+            l32 = float(gold[key + ".l2"])
+            assert float(np.sqrt((a * a).sum())) <= max(10 * l32, dead_atol * np.sqrt(a.size) * 10), "%s: dead grad %s" % (what, name)
+            continue
+        out[name] = _dist_f64(a, gold, key, k)
+    return out
+
+
+def check_grads_env(gold, tag, prefix, named_grads, k=16, floor=2e-3, factor=1.5, dead_atol=1e-5, what="", draws=None):
+    """Per-parameter gradients against the fp64 run, each held to max(floor, factor x its reference-fp32 envelope).
+    draws: instead of named_grads, a list of grads_dist() results of several runs of the candidate (its own weights moved by +-1 ulp, as the
+    envelope's runs were): the MEDIAN over the runs is gated.  The envelope is a maximum over 12 runs of the reference; a 13th run of the very
+    same arithmetic exceeds it with probability 1/13 PER TENSOR, so with 145 tensors (embed128) a single candidate run cannot be held to the
+    envelope tensor by tensor — its median over three runs can, and a kernel that is systematically less accurate still fails.
+    -> [(name, mine, envelope, limit)]"""
+    if draws is None:
+        draws = [grads_dist(gold, prefix, named_grads, k, dead_atol, what)]
+    report, bad = [], []
+    for name in draws[0]:
+        env = float(envelopes()["%s/%s.grad.%s.envelope" % (tag, prefix, name)])
+        mine = float(np.median([d[name] for d in draws]))
+        lim = max(floor, factor * env)
+        report.append((name, mine, env, lim))
+        if mine > lim:
+            bad.append("%s: %.3g > %.3g (envelope %.3g; runs %s)" % (name, mine, lim, env, " ".join("%.3g" % d[name] for d in draws)))
+    assert not bad, "%s: %d gradient tensor(s) outside %.1f x the reference's fp32 envelope: %s" % (what or tag, len(bad), factor, "; ".join(bad))
+    return report
+
+
+def envelope_summary(report, what=""):
+    r = sorted(x[1] / max(x[2], 1e-30) for x in report)
+    print("\n%s: %d gradient tensors inside the envelope gate; HIP error / reference-fp32 envelope: median %.2f, max %.2f; worst HIP error %.2e, "
+          "median limit %.2e" % (what, len(r), r[len(r) // 2], r[-1], max(x[1] for x in report), sorted(x[3] for x in report)[len(r) // 2]))
 
 
 def check_tensor_f64(gold, prefix, t, k=64, floor=1e-3, factor=3.0, what=""):

@@ -152,9 +152,83 @@ print("rank %%d ok" %% rank)
 """
 
 
-def _launch(tmp_path, world, backend, port, overlap=False):
+# Two ranks (gloo, one GPU): what must hold at world size > 1 without a multi-GPU box.
+WORKER2 = r"""
+import os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, %(repo)r)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+import joint_model as M
+from oracle import ref_cpu as O
+from vae_segmentation_amd import ddp, optim, ops
+from vae_segmentation_amd import train as T
+
+# ---- (1) collective_capturable: one rank cannot capture -> NO rank replays, every rank answers False ------------------------
+replayed = []
+def fake_probe(group):
+    def replay():
+        replayed.append(1)
+        return True
+    return (rank == 0), (replay if rank == 0 else None)           # rank 0 "captured", rank 1 "could not"
+ddp._probe_capture = fake_probe
+ddp._CAPTURABLE.clear()
+assert ddp.collective_capturable(None) is False
+assert not replayed, "a rank replayed its probe although another rank had nothing to replay: the collectives would be unpaired"
+ddp._CAPTURABLE.clear()
+ddp._probe_capture = lambda group: (True, lambda: rank == 0)      # everybody captured; the replay's result is bad on rank 1 only
+assert ddp.collective_capturable(None) is False
+ddp._CAPTURABLE.clear()
+ddp._probe_capture = lambda group: (True, lambda: True)
+assert ddp.collective_capturable(None) is True
+ddp._CAPTURABLE.clear()
+assert ddp.average_supported(None) is False                       # gloo: sum, then scale — asked eagerly, remembered
+dist.barrier()
+
+# ---- (2) fp16 + dynamic loss scaling under data parallelism: an overflow on ONE rank skips the step on BOTH --------------
+SIDE = 32
+seg = M.set_kernel_dtype(O.deterministic_fill_(M.Segmentation(1, 2, norm_type=1), seed=0).cuda(), torch.float16)
+params = list(seg.parameters())
+img, lab = O.synthetic_image(1, SIDE, 2 + 10 * rank).cuda(), O.synthetic_label(1, SIDE, 3 + 10 * rank).cuda()
+opt = optim.SGD(params, lr=1e-2, momentum=0.9)
+sync = ddp.FlatGradSync(params)
+sync.broadcast_parameters(0)
+scaler = optim.LossScaler(init_scale=2.0 ** 10, growth_interval=1000)
+gs = T.GraphedStep(lambda: T.seg_train_losses(seg, img, lab), params, opt, grad_sync=sync, warmup=1, scaler=scaler)
+assert gs.tail is False                                           # gloo collectives do not capture: eager tail, same protocol
+start = [p.detach().clone() for p in params]
+gs.step()
+torch.cuda.synchronize()
+assert scaler.scale.item() == 2.0 ** 10 and any(not torch.equal(p.detach(), s) for p, s in zip(params, start)), "a clean step must go through"
+after1 = [p.detach().clone() for p in params]
+if rank == 1:
+    scaler.scale.fill_(2.0 ** 60)                                 # this rank's backward overflows fp16; rank 0's is clean
+gs.step()
+torch.cuda.synchronize()
+# the averaged gradient carries rank 1's inf / nan to rank 0: both flag it, both skip, both back off
+assert all(torch.equal(p.detach(), s) for p, s in zip(params, after1)), "rank %%d applied a step that overflowed on rank 1" %% rank
+assert scaler.scale.item() == (2.0 ** 59 if rank == 1 else 2.0 ** 9), scaler.scale.item()
+assert scaler.found_inf.item() == 0.0 and int(scaler.tracker.item()) == 0
+if rank == 1:
+    scaler.scale.fill_(2.0 ** 9)
+gs.step()
+torch.cuda.synchronize()
+assert any(not torch.equal(p.detach(), s) for p, s in zip(params, after1))
+flat = torch.cat([p.detach().reshape(-1) for p in params])
+both = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(both, flat)
+assert torch.equal(both[0], both[1]), "replicas diverged"
+assert all(torch.isfinite(p).all() for p in params)
+dist.barrier()
+dist.destroy_process_group()
+print("rank %%d ok" %% rank)
+"""
+
+
+def _launch(tmp_path, world, backend, port, overlap=False, worker=None):
     script = tmp_path / "ddp_worker.py"
-    script.write_text(WORKER % {"repo": REPO})
+    script.write_text((worker or WORKER) % {"repo": REPO})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), VS_TEST_BACKEND=backend,
                HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", VS_TEST_OVERLAP="1" if overlap else "0")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -174,6 +248,12 @@ def test_one_rank_rccl_graphed_step_with_flat_grad_sync(tmp_path, overlap):
 @pytest.mark.parametrize("overlap", [False, True])
 def test_two_rank_average_equals_global_batch_gradient(tmp_path, overlap):
     _launch(tmp_path, 2, "gloo", 29552 + 10 * overlap, overlap)
+
+
+def test_two_rank_capturable_agreement_and_loss_scaler_overflow_on_one_rank(tmp_path):
+    """(1) ddp.collective_capturable: a rank that cannot capture decides for all and nobody replays unpaired (ADVICE r04);
+    (2) fp16 + LossScaler under data parallelism: an overflow on one rank skips the step on both."""
+    _launch(tmp_path, 2, "gloo", 29571, worker=WORKER2)
 
 
 def test_bench_spawns_its_own_ranks(tmp_path):

@@ -88,6 +88,7 @@ def test_loss_scaler_protocol_overflow_skip_backoff_growth():
     opt = optim.SGD(params, lr=1e-2, momentum=0.9)
     scaler = optim.LossScaler(init_scale=2.0 ** 40, growth_factor=2.0, backoff_factor=0.5, growth_interval=3)
     gs = T.GraphedStep(lambda: T.joint_train_losses(joint, img, lab), params, opt, warmup=1, scaler=scaler)
+    assert gs.tail, "the scaled step's tail (finite check, scaled SGD, scale update, re-pack) must be inside the graph (VERDICT r04 item 3)"
     start = [p.detach().clone() for p in params]
     scales, moved = [], []
     for _ in range(40):

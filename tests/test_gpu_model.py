@@ -181,12 +181,11 @@ def test_seg96_vs_reference_golden():
     loss, aux = T.seg_train_losses(seg, O.synthetic_image(2, 96, 2).cuda(), O.synthetic_label(2, 96, 3).cuda())
     loss.backward()
     G.scalar_close(g, "dice_loss", loss.item(), RTOL_FP32)
-    G.check_tensor_f64(g, "pred", aux["batch"]["pred"], k=512, floor=RTOL_FP32)
-    # at this size the reference's own fp32 gradients are 2e-3 .. 3e-3 from fp64 and HIP's 3e-4 .. 1.5e-2: the deepest tensors sit 4 - 6 x the
-    # reference's distance (listed as outliers; profiles/r03_parity_report.txt has the full-tensor table).  That is amplification of a different
-    # rounding draw, not kernel error: tests/test_gpu_backward_steps.py pins every single backward step of this very pass to < 5e-6.
-    rep = G.check_grads_f64(g, "seg", [(n, p.grad) for n, p in seg.named_parameters()], floor=RTOL_GRAD_FP32, what="seg96")
-    G.vacuity(rep, "seg96")
+    G.check_tensor_env(g, "seg96", "pred", aux["batch"]["pred"], k=512, floor=RTOL_FP32)
+    # every gradient tensor within 1.5 x the MEASURED envelope of the reference's own fp32 arithmetic (tests/golden/envelopes.npz: the reference's
+    # fp32 step with its weights moved by +-1 ulp lands 2.5e-3 .. 1.8e-2 from its fp64 run at this size); no hand-set floor, no outlier list
+    rep = G.check_grads_env(g, "seg96", "seg", [(n, p.grad) for n, p in seg.named_parameters()], floor=RTOL_GRAD_FP32, what="seg96")
+    G.envelope_summary(rep, "seg96")
 
 
 def test_vae64_train_vs_golden():
@@ -229,13 +228,19 @@ def test_joint_train_step_vs_reference_golden(side, bs, name):
     for key, val in (("final", final), ("recon_loss", aux["recon_loss"]), ("dice_loss", aux["dice_loss"])):
         G.scalar_close(g, key, val.item(), RTOL_FP32)
     b = aux["batch"]
-    G.check_tensor_f64(g, "pred", b["pred"], k=512, floor=RTOL_FP32)
-    G.check_tensor_f64(g, "recon", b["recon"], k=512, floor=RTOL_FP32)
     assert G.rel_l2(b["mean"].detach().cpu(), g["mean@f64"]) < max(RTOL_FP32, 3 * G.rel_l2(g["mean"], g["mean@f64"]))
     assert G.rel_l2(b["std"].detach().cpu(), g["std@f64"]) < max(RTOL_FP32, 3 * G.rel_l2(g["std"], g["std@f64"]))
-    rep = G.check_grads_f64(g, "seg", [(n, p.grad) for n, p in joint.Seg.named_parameters()], floor=RTOL_GRAD_FP32, what=name)
-    print("\n%s: worst grad error vs fp64: HIP %.3g, reference fp32 %.3g" % (name, max(r[1] for r in rep), max(r[2] for r in rep)))
-    G.vacuity(rep, name)
+    if name == "joint96":       # BASELINE configs[1]: held to the measured envelope of the reference's own fp32 arithmetic (tests/golden/envelopes.npz)
+        G.check_tensor_env(g, name, "pred", b["pred"], k=512, floor=RTOL_FP32)
+        G.check_tensor_env(g, name, "recon", b["recon"], k=512, floor=RTOL_FP32)
+        rep = G.check_grads_env(g, name, "seg", [(n, p.grad) for n, p in joint.Seg.named_parameters()], floor=RTOL_GRAD_FP32, what=name)
+        G.envelope_summary(rep, name)
+    else:
+        G.check_tensor_f64(g, "pred", b["pred"], k=512, floor=RTOL_FP32)
+        G.check_tensor_f64(g, "recon", b["recon"], k=512, floor=RTOL_FP32)
+        rep = G.check_grads_f64(g, "seg", [(n, p.grad) for n, p in joint.Seg.named_parameters()], floor=RTOL_GRAD_FP32, what=name)
+        print("\n%s: worst grad error vs fp64: HIP %.3g, reference fp32 %.3g" % (name, max(r[1] for r in rep), max(r[2] for r in rep)))
+        G.vacuity(rep, name)
     assert all(p.grad is None for p in joint.Vae.parameters())
 
 
@@ -300,8 +305,6 @@ def test_test_time_finetune128_vs_reference_golden(graph):
         assert abs(score_noft.item() - float(g["score_noft@f64"])) < 2e-3
         assert abs(score.item() - float(g["score@f64"])) < 2e-3
         G.check_tensor_f64(g, "pred", pred, k=512, floor=RTOL_FP32)
-    from vae_segmentation_amd import ops
-    ops.set_overlap(False)
 
 
 def test_vae128_native_shapes_vs_reference_golden():
@@ -401,11 +404,10 @@ def test_bf16_joint_step_same_with_and_without_the_channels_last_prediction(monk
         assert float((a - b).norm() / b.norm().clamp_min(1e-20)) < 2e-2, n
 
 
-@pytest.mark.parametrize("overlap", [False, True])
-def test_sgd_step_and_graph_replay_match_eager(overlap):
+@pytest.mark.parametrize("tail", [True, False])
+def test_sgd_step_and_graph_replay_match_eager(tail):
     """Three SGD(momentum) steps: native multi-tensor kernel vs torch.optim.SGD on the oracle (CPU), then a
-    HIP-graph replayed step against the eager step (bitwise on the loss) — serial graph and with the weight-gradient
-    kernels on the side-stream branch."""
+    HIP-graph replayed step against the eager step — with the tail of the step (SGD launch, weight re-pack) inside the graph and outside it."""
     M, O, T = _mods()
     from vae_segmentation_amd import optim
     side, bs = 32, 2
@@ -429,7 +431,8 @@ def test_sgd_step_and_graph_replay_match_eager(overlap):
     ig, lg = img.cuda(), lab.cuda()
     opt_a = optim.SGD(seg_a.parameters(), lr=1e-2, momentum=0.9)
     opt_b = optim.SGD(seg_b.parameters(), lr=1e-2, momentum=0.9)
-    gs = T.GraphedStep(lambda: T.seg_train_losses(seg_b, ig, lg), seg_b.parameters(), opt_b, warmup=1, overlap=overlap)
+    gs = T.GraphedStep(lambda: T.seg_train_losses(seg_b, ig, lg), seg_b.parameters(), opt_b, warmup=1, capture_tail=tail)
+    assert gs.tail is tail
     for _ in range(2):
         opt_a.zero_grad()
         la, _ = T.seg_train_losses(seg_a, ig, lg)
@@ -439,8 +442,6 @@ def test_sgd_step_and_graph_replay_match_eager(overlap):
         assert abs(la.item() - lb.item()) < 1e-5
     for (n1, p1), (_, p2) in zip(seg_a.named_parameters(), seg_b.named_parameters()):
         assert G.rel_l2(p1.detach().cpu(), p2.detach().cpu()) < 1e-4, n1
-    from vae_segmentation_amd import ops
-    ops.set_overlap(False)
 
 
 # ---- Encoder / Fusion / Joint2 / Embed on the native kernels (goldens: oracle/make_golden.py gold_rank4) ----
@@ -501,24 +502,34 @@ def test_joint2_is_segmentation_then_discriminator():
 
 def test_embed128_vs_reference_golden():
     M, O, T = _mods()
+    from vae_segmentation_amd import ops
     from vae_segmentation_amd.evaluation import avg_dsc
     g = G.load("embed128")
-    emb = M.Embed(models=[M.Encoder(1, 128, norm_type=1), M.VAE(2, 2, norm_type=1, dim=128), M.Fusion(1, 2, 2, norm_type=1)])
-    O.deterministic_fill_(emb, seed=8)
-    emb = emb.cuda()
     img, gt = O.synthetic_image(1, 128, seed=2).cuda(), O.one_hot(O.synthetic_label(1, 128, seed=3)).cuda()
-    batch = emb({"img": img, "venous_pancreas_only": gt, "gt": gt}, "img", "pred", noise=torch.from_numpy(g["z"]).cuda())
-    dsc = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=2, eps=1e-4)
-    lat = torch.mean((batch["latent_code"] - batch["latent_code_gt"].detach()) ** 2)
-    (dsc + lat).backward()
-    G.scalar_close(g, "dice_loss", dsc.item(), RTOL_FP32)
-    G.scalar_close(g, "latent_loss", lat.item(), RTOL_FP32)
-    for k in ("pred", "gt_recon", "init_seg", "seg_recon"):        # factor 4 (not 3): `pred` sits behind all three networks; measured 2.7e-3 = 3.6 x the reference-fp32 run's own 7.4e-4
-        G.check_tensor_f64(g, k, batch[k], k=512, floor=RTOL_FP32, factor=4.0)
-    # three networks deep (Encoder -> VAE -> Fusion, ~90 InstanceNorm/ReLU layers at 128^3): the gradients' distance to fp64 is a draw of the rounding
-    # amplification, with a knife edge in the encoder (golden_util.DRAW_FLOOR_GRAD and the experiment behind it)
-    for pre, mod in (("enc", emb.Encoder), ("vae", emb.Vae), ("fus", emb.Fusion)):
-        G.check_grads_f64(g, pre, [(n, p.grad) for n, p in mod.named_parameters()], floor=G.DRAW_FLOOR_GRAD)
+    draws = {"enc": [], "vae": [], "fus": []}
+    for seed in (0, 1, 2):          # the candidate's own draws: its weights moved by +-1 ulp exactly as oracle/make_golden.py moves the reference's (seed 0: unmoved)
+        emb = M.Embed(models=[M.Encoder(1, 128, norm_type=1), M.VAE(2, 2, norm_type=1, dim=128), M.Fusion(1, 2, 2, norm_type=1)])
+        O.deterministic_fill_(emb, seed=8)
+        G.perturb_ulp_(emb, seed)
+        emb = emb.cuda()
+        batch = emb({"img": img, "venous_pancreas_only": gt, "gt": gt}, "img", "pred", noise=torch.from_numpy(g["z"]).cuda())
+        dsc = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=2, eps=1e-4)
+        lat = torch.mean((batch["latent_code"] - batch["latent_code_gt"].detach()) ** 2)
+        (dsc + lat).backward()
+        if seed == 0:
+            G.scalar_close(g, "dice_loss", dsc.item(), RTOL_FP32)
+            G.scalar_close(g, "latent_loss", lat.item(), RTOL_FP32)
+        # three networks deep (Encoder -> VAE -> Fusion, ~90 InstanceNorm/ReLU layers at 128^3).  Outputs: EVERY run within 1.5 x the measured envelope of the
+        # reference's own fp32 arithmetic (tests/golden/envelopes.npz); no hand-set floor (round 4 used 2.5e-2 on the gradients and a factor 4 on `pred`)
+        for k in ("pred", "gt_recon", "init_seg", "seg_recon"):
+            G.check_tensor_env(g, "embed128", k, batch[k], k=512, floor=RTOL_FP32)
+        for pre, mod in (("enc", emb.Encoder), ("vae", emb.Vae), ("fus", emb.Fusion)):
+            draws[pre].append(G.grads_dist(g, pre, [(n, p.grad) for n, p in mod.named_parameters()], what="embed128 " + pre))
+        del emb, batch, dsc, lat
+        ops.drop_stale_wgrads()
+    # gradients (145 live tensors): the median of the three runs, tensor by tensor, within 1.5 x the envelope (golden_util.check_grads_env says why not one run)
+    for pre in ("enc", "vae", "fus"):
+        G.envelope_summary(G.check_grads_env(g, "embed128", pre, None, floor=RTOL_GRAD_FP32, what="embed128 " + pre, draws=draws[pre]), "embed128 " + pre)
 
 
 def test_seg32_dropout_with_exported_masks_vs_oracle(monkeypatch):

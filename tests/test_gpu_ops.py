@@ -363,6 +363,16 @@ def test_reparam_kl_dice_bce_label_ops():
     assert abs(E.avg_dsc(bb, "s", "t", botindex=1, topindex=2, binary=True).item() - float(g["dice2_binary"])) < 1e-6
     assert abs(E.avg_dsc(bb, "s", "t", botindex=1, topindex=2, eps=1e-4).item() - float(g["dice3_eps1e4"])) < 1e-6
     assert abs(E.dice(bb["s"], bb["t"]).item() - float(g["dice_fn"])) < 1e-6
+    # hard Dice with FOUR classes (it used to raise for n_class != 2): the reference's values, ties included
+    s4, t4 = O.kat_scores(1), O.kat_scores(2)
+    hard = ops.hard_onehot(s4.cuda()).cpu()
+    assert torch.equal(hard.argmax(1).to(torch.int8), torch.from_numpy(g["dice4_argmax_s"])) and bool((hard.sum(1) == 1).all())
+    b4 = {"s": s4.cuda(), "t": t4.cuda()}
+    assert abs(E.avg_dsc(b4, "s", "t", binary=True, botindex=1, topindex=4).item() - float(g["dice4_binary"])) < 1e-6
+    assert abs(E.avg_dsc(b4, "s", "t", binary=True, botindex=0, topindex=4).item() - float(g["dice4_binary_all"])) < 1e-6
+    assert np.allclose(E.avg_dsc(b4, "s", "t", binary=True, botindex=1, topindex=4, return_mean=False).cpu().numpy(), g["dice4_binary_nomean"], atol=1e-6)
+    one = torch.rand(2, 1, 3, 4, 5)
+    assert bool((ops.hard_onehot(one.cuda()) == 1).all())                       # a single channel: argmax is 0 everywhere
     assert np.array_equal(E.binarize(torch.tensor([.49, .5, .81]).cuda()).cpu().numpy(), g["bin"])
     assert np.array_equal(E.confident_binarize(torch.tensor([.1, .2, .5, .8, .81]).cuda()).cpu().numpy(), g["cbin"])
     # BCE

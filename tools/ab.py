@@ -25,7 +25,7 @@ for r in range(a.rounds):
                 k, val = kv.split("=", 1)
                 env[k] = val
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "10", "--no-cpu-baseline", "--no-fp32-mode",
-               "--no-families"] + a.args.split()
+               "--no-families", "--no-other-configs"] + a.args.split()
         out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_wgrad
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-Q="--steps 3 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-families"
+Q="--steps 3 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-families --no-other-configs"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_INSTS_LDS --output-format csv -d $OUT/a -o p -- python3 $ROOT/bench.py $Q > /dev/null 2> $OUT/a.err
 echo "pass a done"
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/b -o p -- python3 $ROOT/bench.py $Q > /dev/null 2> $OUT/b.err

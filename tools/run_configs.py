@@ -20,7 +20,7 @@ records = []
 for tag, extra in RUNS:
     if which not in ("all", tag):
         continue
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "5", "--no-fp32-mode", "--no-cpu-baseline"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "5", "--no-fp32-mode", "--no-cpu-baseline", "--no-other-configs"] + extra
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if not line:

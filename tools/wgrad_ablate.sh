@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/wgrad_ablate
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 export VS_LIBVAESEG=$ROOT/tools/_stamps/libvaeseg_ablate.so
-Q="--no-cpu-baseline --no-fp32-mode --no-families --no-exchange-forms"
+Q="--no-cpu-baseline --no-fp32-mode --no-families --no-exchange-forms --no-other-configs"
 for flag in ${FLAGS:-0 1 4 8 16 32 5 9 13 29 61}; do
   export VS_G3B_ABLATE=$flag
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/f$flag -o b -- python3 $ROOT/bench.py --steps 10 --warmup 2 $Q > $OUT/f$flag.json 2> $OUT/f$flag.err

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/wgrad_times
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-Q="--no-cpu-baseline --no-fp32-mode --no-families --no-exchange-forms"
+Q="--no-cpu-baseline --no-fp32-mode --no-families --no-exchange-forms --no-other-configs"
 for cfg in joint96 joint160; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$cfg -o b -- python3 $ROOT/bench.py --config $cfg --steps 20 --warmup 3 $Q > $OUT/$cfg.json 2> $OUT/$cfg.err
   f=$(find $OUT/$cfg -name "*kernel_stats.csv" | head -1)

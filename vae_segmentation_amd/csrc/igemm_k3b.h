@@ -550,8 +550,9 @@ static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
 // the fused-apply instantiations: the single-chunk backward-data layers of the 96^3 / 48^3 levels (and their 128^3 / 160^3 counterparts)
 template <int CK, int MT, int EPI, bool SUMS, int YT>
 constexpr bool k3b_has_fa() {
-    return EPI == EPI_RAW && ((CK == 16 && MT == 16) || (CK == 8 && MT == 16 && !SUMS && YT == 4) || (CK == 16 && MT == 32 && !SUMS && YT == 4) ||
-                              (CK == 32 && YT == 4));
+    // (round 4 also instantiated CK == 32 — the 24^3 / 12^3 levels at one wave per SIMD — which measured slower twice and left the library:
+    //  profiles/r04_ab_fused_apply_32ch.json)
+    return EPI == EPI_RAW && ((CK == 16 && MT == 16) || (CK == 8 && MT == 16 && !SUMS && YT == 4) || (CK == 16 && MT == 32 && !SUMS && YT == 4));
 }
 
 template <typename T, int CK, int MT, int EPI, bool SUMS, int YT = 4>

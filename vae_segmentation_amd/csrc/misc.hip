@@ -242,6 +242,30 @@ extern "C" int vs_onehot(const float* label, float* out, int n, long long voxels
     return VS_OK;
 }
 
+// argmax over the channel axis of a planar (n, c, voxels) tensor -> its one-hot, the hard masks of the validation Dice (utils/evaluation.py:58-64:
+// torch.argmax -> scatter_).  Ties go to the FIRST maximal channel, as torch.argmax resolves them; a NaN channel wins (as torch's max does).
+__global__ void hard_onehot_kernel(const float* __restrict__ x, float* __restrict__ out, long long voxels, int c, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / voxels, v = i - b * voxels;
+        const float* xp = x + (size_t)b * c * voxels + v;
+        float best = xp[0];
+        int arg = 0;
+        for (int k = 1; k < c; ++k) {
+            const float val = xp[(size_t)k * voxels];
+            if (val > best || (val != val && best == best)) { best = val; arg = k; }
+        }
+        float* op = out + (size_t)b * c * voxels + v;
+        for (int k = 0; k < c; ++k) op[(size_t)k * voxels] = k == arg ? 1.f : 0.f;
+    }
+}
+extern "C" int vs_hard_onehot(const float* x, float* out, int n, int n_class, long long voxels, void* stream) {
+    if (!x || !out || n <= 0 || voxels <= 0 || n_class <= 0) return VS_EINVAL;
+    const long long total = (long long)n * voxels;
+    hipLaunchKernelGGL(hard_onehot_kernel, GRID1D(total), dim3(256), 0, (hipStream_t)stream, x, out, voxels, n_class, total);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
 __global__ void binarize_kernel(const float* __restrict__ a, float* __restrict__ out, long long count, int mode, float lo, float hi) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
         const float v = a[i];
@@ -954,8 +978,9 @@ extern "C" int vs_bce_bwd(const float* p, const float* t, const float* gout, flo
 __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* params, const float* const* grads, float* const* bufs,
                                                         const long long* sizes, const int* block_map, float lr, float momentum,
                                                         float wd, int first, const float* __restrict__ loss_scale,
-                                                        const float* __restrict__ found_inf) {
+                                                        const float* __restrict__ found_inf, const float* __restrict__ hyper) {
     if (found_inf != nullptr && found_inf[0] != 0.f) return;          // a non-finite gradient somewhere: the whole step is skipped
+    if (hyper != nullptr) { lr = hyper[0]; momentum = hyper[1]; wd = hyper[2]; }      // device-resident hyperparameters: a captured launch follows the schedule
     const float inv_scale = loss_scale != nullptr ? 1.f / loss_scale[0] : 1.f;
     const int ti = block_map[2 * blockIdx.x], start = block_map[2 * blockIdx.x + 1];
     float* p = params[ti];
@@ -994,7 +1019,16 @@ extern "C" int vs_sgd_momentum_scaled_multi(float* const* params, const float* c
                                             int first_step, const float* loss_scale, const float* found_inf, void* stream) {
     if (!params || !grads || !bufs || !sizes || !block_map || n_blocks <= 0) return VS_EINVAL;
     hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, params, grads, bufs, sizes, block_map, lr, momentum,
-                       weight_decay, first_step, loss_scale, found_inf);
+                       weight_decay, first_step, loss_scale, found_inf, (const float*)nullptr);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+extern "C" int vs_sgd_momentum_dev_multi(float* const* params, const float* const* grads, float* const* bufs, const long long* sizes,
+                                         const int* block_map, int n_blocks, const float* hyper, const float* loss_scale,
+                                         const float* found_inf, void* stream) {
+    if (!params || !grads || !bufs || !sizes || !block_map || n_blocks <= 0 || !hyper) return VS_EINVAL;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, params, grads, bufs, sizes, block_map, 0.f, 0.f,
+                       0.f, 0, loss_scale, found_inf, hyper);
     VS_CHECK_LAUNCH();
     return VS_OK;
 }

@@ -992,6 +992,7 @@ struct G3RedDesc {
     const float* ws; float* dw;
     int m_real, c_real, mbn, cbn, nslabs, cb, ntaps, ncb;
     int kind, parts;         // parts: slab partitions summed in parallel (power of two <= G3_RED_ROWS); a block covers 256 * G3_RED_ROWS / parts elements
+    int swap;                // the launch computed the TRANSPOSED gradient (operands exchanged, multi_plan): slab (m', c', tap') is dw[c'][m'][ntaps - 1 - tap']
 };
 #define G3_RED_MAX 56
 struct G3RedGroup {
@@ -1085,7 +1086,11 @@ __global__ __launch_bounds__(64 * G3_RED_ROWS) void g3_reduce_group_kernel(const
                 tap = (sx & dxs) ? d.ntaps : 3 * dzdy + 1 + dxs - sx;    // (s = 1, dx = +1) repeats the centre tap: dropped
             }
             else { c = cb * 8 + (col & 7); tap = 2 * k + (col >> 3); }
-            if (m < d.m_real && c < d.c_real && tap < d.ntaps) d.dw[((size_t)m * d.c_real + c) * d.ntaps + tap] = (float)tot;
+            if (m < d.m_real && c < d.c_real && tap < d.ntaps) {
+                // swap: rows are the conv's INPUT channels and the tap is mirrored (sum_v Q(v) P(v + o) = dW[-o]); m_real / c_real are the launch's
+                if (d.swap) d.dw[((size_t)c * d.m_real + m) * d.ntaps + (d.ntaps - 1 - tap)] = (float)tot;
+                else d.dw[((size_t)m * d.c_real + c) * d.ntaps + tap] = (float)tot;
+            }
         }
     }
 }
@@ -1196,6 +1201,7 @@ namespace {
 struct MultiLayer {
     G3Params p;
     int cbsz, ncb, kind, m_real, c_real;
+    int swap;                // operands exchanged (see multi_plan): the slabs hold dW transposed and tap-mirrored, the reduction writes it back
     int primary;             // index of the first descriptor with the same dw (a weight used several times in one backward pass:
                              // all uses write slabs into one contiguous region and ONE reduction sums them); == own index otherwise
     int total_slabs;         // primary only: slabs of all its parts
@@ -1233,11 +1239,25 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
     plan.layers.resize(count);
     long long bucket_work[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // (cbsz 16 | 8) x (K3, K2S2, UP, K3 M-packed): one grouped launch each
     auto bucket_of = [](const MultiLayer& L) { return (L.cbsz == 16 ? 0 : 1) + 2 * (L.p.mp ? 3 : (L.kind == VS_CONV_K3 ? 0 : (L.kind == VS_CONV_K2S2 ? 1 : 2))); };
+    // Operand exchange (round 5).  A 3x3x3 layer's gradient dW[m][c][o] = sum_v P(v)[m] Q(v + o)[c] stages Q with a halo (2.5 x the tile) and P without;
+    // when Q is a LAZY activation (statistics given) every halo fragment is normalised + ReLU'd + masked on its way to LDS — 24-28 vector instructions per
+    // 16-byte fragment in a kernel that is bound by instruction issue (profiles/r04_wgrad_counters_raw.txt).  The same sums with the roles exchanged,
+    // dW'[c][m][o'] = sum_v Q(v)[c] P(v + o')[m] = dW[m][c][-o'], put the halo on P — a stored gradient, staged as it is, out-of-volume fragments already
+    // zero from the bounds-checked load — and normalise Q once per voxel.  The reduction writes the transposed, tap-mirrored slabs back (G3RedDesc.swap).
+    // Taken when it does not widen the halo operand (m_ch <= c_ch); VS_WGRAD_SWAP=0 switches it off.
+    const char* swap_str = getenv("VS_WGRAD_SWAP");               // read per plan: the tests and the A/B runs switch it between calls
+    const bool swap_on = pack_m && (swap_str ? atoi(swap_str) != 0 : true);
+    std::vector<vs_wgrad_desc> eff(descs, descs + count);
     for (int i = 0; i < count; ++i) {
-        const vs_wgrad_desc& d = descs[i];
-        int rc = multi_validate(d);
+        int rc = multi_validate(descs[i]);
         if (rc) return rc;
+        vs_wgrad_desc& d = eff[i];
         MultiLayer& L = plan.layers[i];
+        L.swap = 0;
+        if (swap_on && d.kind == VS_CONV_K3 && d.q_stats != nullptr && d.p_stats == nullptr && d.m_ch <= d.c_ch) {
+            std::swap(d.p, d.q); std::swap(d.p_stats, d.q_stats); std::swap(d.m_ch, d.c_ch); std::swap(d.m_real, d.c_real);
+            L.swap = 1;
+        }
         G3Params& p = L.p;
         p = G3Params{};
         int ks_unused;
@@ -1273,7 +1293,7 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         for (int j = 0; j < i; ++j) {
             if (descs[j].dw == descs[i].dw && L.primary == i) {
                 const MultiLayer& F = plan.layers[j];
-                if (F.cbsz != L.cbsz || F.kind != L.kind || F.p.mbn != L.p.mbn || F.p.cbn != L.p.cbn || F.m_real != L.m_real || F.c_real != L.c_real || F.p.mp != L.p.mp)
+                if (F.cbsz != L.cbsz || F.kind != L.kind || F.p.mbn != L.p.mbn || F.p.cbn != L.p.cbn || F.m_real != L.m_real || F.c_real != L.c_real || F.p.mp != L.p.mp || F.swap != L.swap)
                     return VS_EINVAL;                     // same destination, different layer geometry
                 L.primary = F.primary;
             }
@@ -1500,12 +1520,17 @@ static size_t f32_limb_group_bytes(const std::vector<vs_wgrad_desc>& sub, int cb
 }
 }  // namespace
 
+// the grouped launches with a caller-chosen grid width (target_workgroups; 0 = the default, 512: two per CU).  Internal since round 5: the
+// early, throttled branch it was exported for (round 4) measured slower at every width (profiles/r04_ab_wgrad_early.json).
+static size_t wgrad_multi_workspace_bytes_impl(const vs_wgrad_desc* descs, int count, int dtype, int target_workgroups);
+static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
+                            float eps, int target_workgroups, void* stream);
 extern "C" size_t vs_conv_wgrad_multi_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype) {
-    return vs_conv_wgrad_multi_throttled_workspace_bytes(descs, count, dtype, 0);
+    return wgrad_multi_workspace_bytes_impl(descs, count, dtype, 0);
 }
 extern "C" int vs_conv_wgrad_multi(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
                                    float eps, void* stream) {
-    return vs_conv_wgrad_multi_throttled(descs, count, workspace, workspace_bytes, dtype, eps, 0, stream);
+    return wgrad_multi_impl(descs, count, workspace, workspace_bytes, dtype, eps, 0, stream);
 }
 
 // fp32 mode: the bias gradients of a pass as the 16-bit path computes them (grouped partial sums, one fixed-order reduction) instead of a zero fill and a float-atomic
@@ -1524,7 +1549,7 @@ static size_t f32_bias_bytes(const vs_wgrad_desc* descs, int count, int target_w
     return plan.bytes - f32_bias_base(descs, count, plan);
 }
 
-extern "C" size_t vs_conv_wgrad_multi_throttled_workspace_bytes(const vs_wgrad_desc* descs, int count, int dtype, int target_workgroups) {
+static size_t wgrad_multi_workspace_bytes_impl(const vs_wgrad_desc* descs, int count, int dtype, int target_workgroups) {
     if (!descs || count <= 0 || target_workgroups < 0) return 0;
     if (dtype == VS_F32) {                        // serial per-layer launches share one region; the uses of one weight need theirs side by side
         // the 3x3x3 layers of the limb path come first: two grouped regions (16- / 8-channel blocks); the serial region of the other layers follows
@@ -1549,8 +1574,8 @@ extern "C" size_t vs_conv_wgrad_multi_throttled_workspace_bytes(const vs_wgrad_d
     return plan.bytes;
 }
 
-extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
-                                             float eps, int target_workgroups, void* stream) {
+static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspace, size_t workspace_bytes, int dtype,
+                            float eps, int target_workgroups, void* stream) {
     if (!descs || count <= 0 || !workspace || target_workgroups < 0) return VS_EINVAL;
     if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
     const bool f16 = dtype == VS_F16;
@@ -1780,7 +1805,7 @@ extern "C" int vs_conv_wgrad_multi_throttled(const vs_wgrad_desc* descs, int cou
                 int parts = 1;
                 while (parts < G3_RED_ROWS && parts * 8 < L.total_slabs) parts *= 2;
                 red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.total_slabs, L.cbsz | (L.p.mp ? 0x100 : 0),
-                                        L.kind != VS_CONV_K2S2 ? 27 : 8, L.ncb, 0, parts});
+                                        L.kind != VS_CONV_K2S2 ? 27 : 8, L.ncb, 0, parts, L.swap});
                 blocks.push_back(vs_ceil_div(slab_elems, 256 * (G3_RED_ROWS / parts)));
             }
             if (descs[i].bias_g && L.bias_primary == i) {

@@ -256,7 +256,7 @@ class CenterIntensities(BaseTransform):
         return data_dict
 
 
-def train_sample(merge, patch_size, mask_index=None, transform=None, params=None, field="venous"):
+def train_sample(merge, patch_size, mask_index=None, transform=None, params=None, field="venous", shift=0):
     """One training sample through main_source.py:191-211 on the device: merge (D, H, W, >= 2) CUDA float32 tensor (what
     NumpyLoader_Multi_merge loads) -> (image (1, 1, P, P, P), label (1, 1, P, P, P)).  `transform`: a MySpatialTransform (None: no
     augmentation, --no_aug); `params`: its per-sample (angles, scale, centre, modified) instead of random draws."""
@@ -265,7 +265,7 @@ def train_sample(merge, patch_size, mask_index=None, transform=None, params=None
     if mask_index is not None:
         lab = relabel(lab, mask_index)
     d = {field: img, field + "_pancreas": lab}
-    d = CropResize([field], patch_size)(d)
+    d = CropResize([field], patch_size, shift=shift)(d)                 # --shift: main_target.py:81,204 (training crops only)
     d[field], d[field + "_pancreas"] = d[field][None, None], d[field + "_pancreas"][None, None]
     if transform is not None:
         d = transform(d, params=None if params is None else [params])

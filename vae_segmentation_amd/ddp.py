@@ -29,50 +29,92 @@ from .optim import _Tables
 
 
 _CAPTURABLE = {}
+_AVG_OK = {}
+
+
+def _probe_capture(group):
+    """This rank's own attempt: capture (NOT replay) a tiny all-reduce of `group` into a HIP graph.  -> (captured?, replay callable).
+    The communicator is set up by an eager collective first; nothing collective is replayed here, so a rank whose capture failed has issued
+    exactly the same collectives as one whose capture succeeded (the agreement below must pair like with like)."""
+    if dist.get_backend(group) != "nccl" or not torch.cuda.is_available():
+        return False, None
+    try:
+        x = torch.ones(256, device="cuda")
+        dist.all_reduce(x, group=group)                  # communicator set-up happens eagerly, outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                dist.all_reduce(x, group=group)
+        torch.cuda.current_stream().wait_stream(side)
+
+        def replay():
+            g.replay()
+            torch.cuda.synchronize()
+            return bool(torch.isfinite(x).all())
+        return True, replay
+    except Exception as e:                               # noqa: BLE001 — whatever the stack refuses, the eager tail works
+        import sys
+        print("vae_segmentation_amd.ddp: all-reduce is not capturable on this stack (%s: %s); the exchange stays outside the step's graph"
+              % (type(e).__name__, e), file=sys.stderr)
+        try:
+            torch.cuda.synchronize()
+        except Exception:                                # noqa: BLE001
+            pass
+        return False, None
+
+
+def _agree(ok, group):
+    """MIN over the ranks of a yes/no answer (an eager collective every rank issues, whatever its own answer): one 'no' decides for all."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(ok)
+    dev = "cuda" if (dist.get_backend(group) == "nccl" and torch.cuda.is_available()) else "cpu"
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item() > 0.5)
 
 
 def collective_capturable(group=None):
-    """Can an all-reduce of this process group be captured into a HIP graph?  Answered once per group by capturing and replaying a tiny one
-    (every rank runs the same probe, so the ranks agree); train.GraphedStep keeps the tail of the step eager when the answer is no."""
+    """Can an all-reduce of this process group be captured into a HIP graph?  Answered once per group: every rank tries to CAPTURE a tiny one,
+    the ranks agree on the outcome (MIN), and only if every rank captured do they all REPLAY it — a collective again, so the same number of
+    collectives is issued on every rank on every path — and agree once more on the result.  train.GraphedStep keeps the tail of the step
+    eager when the answer is no."""
     if not dist.is_initialized():
         return True
     key = id(group)
     if key in _CAPTURABLE:
         return _CAPTURABLE[key]
-    ok = False
-    if dist.get_backend(group) == "nccl" and torch.cuda.is_available():
+    ok, replay = _probe_capture(group)
+    ok = _agree(ok, group)                               # before anybody replays: a rank that could not capture has nothing to replay
+    if ok:
         try:
-            x = torch.ones(256, device="cuda")
-            dist.all_reduce(x, group=group)                  # communicator set-up happens eagerly, outside the capture
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    dist.all_reduce(x, group=group)
-            torch.cuda.current_stream().wait_stream(side)
-            g.replay()
-            torch.cuda.synchronize()
-            ok = bool(torch.isfinite(x).all())
-        except Exception as e:                               # noqa: BLE001 — whatever the stack refuses, the eager tail works
-            import sys
-            print("vae_segmentation_amd.ddp: all-reduce is not capturable on this stack (%s: %s); the exchange stays outside the step's graph"
-                  % (type(e).__name__, e), file=sys.stderr)
-            try:
-                torch.cuda.synchronize()
-            except Exception:                                # noqa: BLE001
-                pass
-    if dist.get_world_size(group) > 1 and dist.get_backend(group) == "nccl" and torch.cuda.is_available():
-        # every rank must take the same form of the tail (captured / eager): one that could not capture decides for all
-        try:
-            flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-            ok = bool(flag.item() > 0.5)
-        except Exception:                                    # noqa: BLE001
+            ok = bool(replay())
+        except Exception:                                # noqa: BLE001
             ok = False
+        ok = _agree(ok, group)
     _CAPTURABLE[key] = ok
     return ok
+
+
+def average_supported(group=None):
+    """Does the collective library reduce with ReduceOp.AVG?  Asked ONCE per group with an eager collective (every rank asks, so the ranks
+    stay paired) and remembered: FlatGradSync.start() never has to discover it inside a stream capture, where a fallback would void the graph."""
+    key = id(group)
+    if key not in _AVG_OK:
+        ok = False
+        if dist.is_initialized() and dist.get_backend(group) == "nccl" and torch.cuda.is_available():
+            try:
+                x = torch.ones(4, device="cuda")
+                dist.all_reduce(x, op=dist.ReduceOp.AVG, group=group)
+                torch.cuda.synchronize()
+                ok = bool((x == 1).all())
+            except (RuntimeError, ValueError):           # a build without ncclAvg: sum, then scale
+                ok = False
+            ok = _agree(ok, group)
+        _AVG_OK[key] = ok
+    return _AVG_OK[key]
 
 
 class FlatGradSync:
@@ -80,8 +122,8 @@ class FlatGradSync:
 
         sync = FlatGradSync(params)                  # registers the gradient slots (overlap=True: and two-phase weight gradients)
         ... forward, backward ...
-        views = sync()                               # all-reduce (overlap=True: start(0) -> remaining weight gradients -> start(1) -> wait)
-        optimizer.step_with(sync.params, views)
+        sync()                                       # all-reduce (overlap=True: start(0) -> remaining weight gradients -> start(1) -> wait)
+        optimizer.step_with(*sync.live())            # NOT (sync.params, views): a parameter without a gradient in this pass must not be updated
 
     train.GraphedStep drives the same phases around two captured graphs.  ``direct=False`` keeps the classic form: gradients
     wherever autograd put them, one gather launch (vs_copy_scale_multi), one all-reduce."""
@@ -122,7 +164,7 @@ class FlatGradSync:
         self._async = self.overlap
         self._works = []
         self._no_grad = set()           # ids of parameters whose .grad was None in the last pass (see _stragglers / live)
-        self._avg = True
+        self._avg = None                # ReduceOp.AVG available?  resolve_avg() asks once, eagerly
         if self.direct:
             from . import ops
             for p, v in zip(self.params, self.views):
@@ -147,8 +189,8 @@ class FlatGradSync:
     # -- phases ---------------------------------------------------------------------------------------------------
     def live(self):
         """(params, views) of the parameters that take part in this step: requires_grad may be switched off for some of them after
-        construction (embed_train freezes its Encoder on even epochs, main_source.py:550-554) — their slots are still exchanged (zeros or
-        an old average, harmless) but must never reach the optimiser.  The same holds for a parameter that received NO gradient in this pass
+        construction (embed_train freezes its Encoder on even epochs, main_source.py:550-554) — their slots are still exchanged (zeroed by
+        _stragglers) but must never reach the optimiser.  The same holds for a parameter that received NO gradient in this pass
         (`.grad is None`): the single-GPU path and the reference's optimisers skip it, so it is skipped here too — no momentum drift or
         weight decay on a gradient that does not exist, and the same result at every world size."""
         keep = [i for i, p in enumerate(self.params) if p.requires_grad and id(p) not in self._no_grad]
@@ -158,13 +200,17 @@ class FlatGradSync:
         """Gradients that did not land in their slot (accumulation into an existing .grad, hooks, direct=False, every non-conv parameter:
         Linear weights, BatchNorm affine): gathered by one multi-tensor copy.  In the steady state of the direct mode with conv-only
         networks this list is empty and nothing is launched.  A parameter that received NO gradient in this pass is remembered in
-        self._no_grad: its slot (the previous step's average, or zeros) is exchanged like the rest but live() keeps it from the optimiser.
+        self._no_grad and its slot is ZEROED: the slot is exchanged like the rest, so it must hold a well-defined contribution — if the ranks
+        disagree on who got a gradient (data-dependent branches), the rank that has one applies g / world and not (stale average + g) / world
+        (ADVICE r04); live() keeps the slot from THIS rank's optimiser.
         only: a set of parameter ids restricting the pass to one bucket."""
         src, dst = [], []
         for p, g, v in zip(self.params, grads, self.views):
             if only is not None and id(p) not in only:
                 continue
             if g is None:
+                if id(p) not in self._no_grad or (self.exchange and self.world > 1):     # on one rank a zeroed slot stays zero until a gradient lands in it
+                    v.zero_()
                 self._no_grad.add(id(p))
                 continue
             self._no_grad.discard(id(p))
@@ -198,13 +244,15 @@ class FlatGradSync:
             dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
             b.mul_(1.0 / self.world)
             return
-        if self._avg and dist.get_backend(self.group) == "nccl":
-            try:
-                self._works.append((dist.all_reduce(b, op=dist.ReduceOp.AVG, group=self.group, async_op=self._async), None))   # RCCL averages in the reduction
-                return
-            except (RuntimeError, ValueError):                       # a build without ncclAvg: sum, then scale
-                self._avg = False
+        if self.resolve_avg():
+            self._works.append((dist.all_reduce(b, op=dist.ReduceOp.AVG, group=self.group, async_op=self._async), None))   # RCCL averages in the reduction
+            return
         self._works.append((dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=self._async), b if self.world > 1 else None))
+
+    def resolve_avg(self):
+        if self._avg is None:
+            self._avg = average_supported(self.group)
+        return self._avg
 
     def wait(self):
         """Make the current stream wait for the started collectives (and apply the 1/world scale where the collective only sums)."""
@@ -220,8 +268,6 @@ class FlatGradSync:
         averaged-gradient views (aligned with self.params)."""
         from . import ops
         grads = [p.grad for p in self.params] if grads is None else grads
-        if self.flat.is_cuda and ops._SIDE["enabled"]:
-            ops.join_side()
         if len(self.buckets) == 1:
             if self.flat.is_cuda:
                 ops.flush_wgrads()

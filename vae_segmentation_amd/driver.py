@@ -98,6 +98,7 @@ class DeviceCaseLoader:
         self.names, self.root, self.bs, self.shuffle = names[rank::world], root, batch_size, shuffle
         self.patch, self.mask_index, self.epoch, self.seed = (args.size,) * 3, mask_index_of(args), 0, seed + rank
         self.drop_last = train
+        self.shift = int(getattr(args, "shift", 0)) if train else 0           # main_target.py:204 (training crops only; validation: CropResize default)
         self.transform = None
         if train and not getattr(args, "no_aug", False):                       # main_source.py:195-205
             self.transform = data_gpu.MySpatialTransform(
@@ -121,7 +122,7 @@ class DeviceCaseLoader:
             imgs, labs = [], []
             for i in order[b * self.bs:(b + 1) * self.bs]:
                 merge = torch.from_numpy(np.load(os.path.join(self.root, self.names[i])).astype(np.float32)).cuda(non_blocking=True)
-                img, lab = self._dg.train_sample(merge, self.patch, self.mask_index, self.transform, field=IMG_KEY)
+                img, lab = self._dg.train_sample(merge, self.patch, self.mask_index, self.transform, field=IMG_KEY, shift=self.shift)
                 imgs.append(img); labs.append(lab)
             yield {IMG_KEY: torch.cat(imgs), LABEL_KEY: torch.cat(labs)}
 
@@ -155,8 +156,8 @@ def build_joint(args):
     nc = n_class_of(args)
     seg = Segmentation(n_channels=1, n_class=nc, norm_type=1)
     vae = VAE(n_channels=nc, n_class=nc, norm_type=1, dim=128, spatial=args.size)
-    return Joint(models=[seg, vae], vae_decoder_dropout=getattr(args, "vae_decoder_dropout", 0.0),
-                 seg_dropout=getattr(args, "seg_dropout", 0.0))
+    return Joint(models=[seg, vae], vae_forward_scale=getattr(args, "vae_forward_scale", 0.0),                 # main_target.py:324
+                 vae_decoder_dropout=getattr(args, "vae_decoder_dropout", 0.0), seg_dropout=getattr(args, "seg_dropout", 0.0))
 
 
 def freeze(module):
@@ -268,14 +269,30 @@ def run(args, side="source"):
     else:
         raise ValueError("Try a valid method.")                           # main_source.py:275 / main_target.py:343
     model = model.cuda()
-    if args.load_prefix:
-        load_prefix(model.Seg if hasattr(model, "Seg") else model, args.load_prefix, args.checkpoint_name)
+    from_scratch = bool(getattr(args, "from_scratch", False)) and method == "domain_adaptation"
+    if from_scratch:
+        teacher = teacher.cuda()
+    if args.load_prefix:                                                    # main_target.py:355-366: --from_scratch loads the TEACHER's Seg, the student keeps its initialisation
+        target = teacher if from_scratch else model
+        load_prefix(target.Seg if hasattr(target, "Seg") else target, args.load_prefix, args.checkpoint_name)
     if args.load_prefix_vae and hasattr(model, "Vae"):
+        if from_scratch:
+            load_prefix(teacher.Vae, args.load_prefix_vae)                  # :370-371
         load_prefix(model.Vae, args.load_prefix_vae)
+    if getattr(args, "load_prefix_encoder", None):                          # :384-390
+        if method == "discriminator_train":
+            load_prefix(model, args.load_prefix_encoder)
+        elif hasattr(model, "Dis"):
+            load_prefix(model.Dis, args.load_prefix_encoder)
     if args.load_prefix_joint and hasattr(model, "Seg"):
         load_prefix(model, args.load_prefix_joint, args.checkpoint_name)
     if hasattr(model, "Vae") and method != "refine_vae":
         freeze(model.Vae)                                                   # main_source.py:343-346
+    if getattr(args, "fix_layer", False) and method in ("joint_train", "domain_adaptation"):     # main_target.py:400-406: only the last decoder block and the head train
+        for prm in model.Seg.parameters():
+            prm.requires_grad = False
+        for prm in list(model.Seg.up5.parameters()) + list(model.Seg.out_block.parameters()):
+            prm.requires_grad = True
     if method == "refine_vae":                                              # main_source.py:347-353: VAE encoder half frozen, decoder trained
         for name, prm in model.Vae.named_parameters():
             prm.requires_grad = name.split(".")[0] not in ("in_block", "down1", "down2", "down3", "down4", "down5", "fc_mean", "fc_std")
@@ -295,6 +312,8 @@ def run(args, side="source"):
             model, teacher = teacher, model
             freeze(model.Vae)
             trainable = model.Seg
+        elif not args.test_only and from_scratch:
+            pass                                                            # main_target.py:427: the teacher keeps what --load_prefix* gave it
         elif not args.test_only:
             teacher.load_state_dict(model.state_dict())                     # main_target.py:426-427
         else:
@@ -315,7 +334,6 @@ def run(args, side="source"):
     sync = ddp.FlatGradSync(params) if world > 1 else None
     if sync is not None:
         sync.broadcast_parameters(0)
-    ops.set_overlap(False)          # serial launch order: measured 1-2 % faster than the side-stream branch (train.GraphedStep)
     # fp16 storage: Dice gradients are O(1e-6), below fp16's normal range — dynamic loss scaling on the device (optim.LossScaler)
     scaler = optim.LossScaler() if dtype == torch.float16 else None
     skw = {} if scaler is None else {"scaler": scaler}
@@ -362,11 +380,27 @@ def run(args, side="source"):
             return T.domain_adaptation_dis_losses(model, teacher, img_buf, lab_buf, lambda_vae=lambda_vae, epoch=cur["epoch"],
                                                   lambda_vae_warmup=warmup_epochs,
                                                   use_confident_binarize=getattr(args, "use_confident_binarize", False), eps=eps, n_class=nc)
-        return T.domain_adaptation_losses(model, teacher, img_buf, lab_buf, lambda_vae=lambda_vae,
-                                          domain_loss_type=getattr(args, "domain_loss_type", 0), kl=getattr(args, "kl", False),
-                                          use_confident_binarize=getattr(args, "use_confident_binarize", False), eps=eps, n_class=nc,
-                                          only_pseudo=getattr(args, "only_pseudo", False), epoch=cur["epoch"], turn_epoch=turn_epoch,
-                                          lambda_vae_warmup=warmup_epochs, host_schedule=not use_graph)
+        def da():
+            return T.domain_adaptation_losses(model, teacher, img_buf, lab_buf, lambda_vae=lambda_vae,
+                                              domain_loss_type=getattr(args, "domain_loss_type", 0), kl=getattr(args, "kl", False),
+                                              use_confident_binarize=getattr(args, "use_confident_binarize", False), eps=eps, n_class=nc,
+                                              only_pseudo=getattr(args, "only_pseudo", False), epoch=cur["epoch"], turn_epoch=turn_epoch,
+                                              lambda_vae_warmup=warmup_epochs, host_schedule=not use_graph)
+        n_mc = max(1, int(getattr(args, "vae_mont_number", 1)))
+        if n_mc == 1:
+            return da()
+        # main_target.py:530-603 (--vae_mont_number N): N forward passes of student and teacher per step (they differ by their dropout draws),
+        # the four loss terms averaged, one backward through all of them
+        final, aux = da()
+        tot = {k: v for k, v in aux.items() if k != "batch" and k != "kl_loss"}
+        for _ in range(n_mc - 1):
+            f, a = da()
+            final = final + f
+            tot = {k: tot[k] + a[k] for k in tot}
+            aux = a
+        out = {k: v / n_mc for k, v in tot.items()}
+        out["kl_loss"], out["batch"] = aux["kl_loss"], aux["batch"]         # the reference logs the LAST pass's KL (:605)
+        return final / n_mc, out
 
     def loss_key(epoch):
         """what of the loss expression depends on the epoch (main_target.py:583-592): a captured step is rebuilt when it changes"""
@@ -478,6 +512,28 @@ def run(args, side="source"):
     if rank == 0:
         print("Finished Training")
     return best
+
+
+def check_target_flags(a):
+    """main_target.py:145-170: the reference's own consistency asserts, plus what this entry point does with the flags it does not act on."""
+    import sys
+    if a.vae_mont_number != 1:
+        assert a.vae_forward_scale != 0.0                                    # main_target.py:145
+    if a.from_scratch:
+        assert a.method == "domain_adaptation" and not a.test_only           # :157-159
+    if a.kl:
+        assert a.method == "domain_adaptation" and a.domain_loss_type in (0, 8)      # :162-164
+    if a.update_every_iteration:
+        assert a.pseudo_save_epoch == 1                                      # :168
+    if a.generate_bounding_boxes:
+        assert a.method == "domain_adaptation"                               # :170
+    if a.pseudo_list is not None:
+        raise SystemExit("--pseudo_list: the second (pseudo-labelled) loader and its supervised step (main_target.py:228-307,615-692) are not built "
+                         "in the native entry point; train without it or extend driver.run")
+    ignored = [n for n in ("save_more_reference", "save_eval_result", "analysis_figure_name", "generate_bounding_boxes", "resume") if getattr(a, n)]
+    if ignored:
+        print("main_target.py: accepted and ignored (they drive figure / volume dumps the native entry point does not write): %s"
+              % ", ".join("--" + n for n in ignored), file=sys.stderr)
 
 
 def add_native_flags(parser):

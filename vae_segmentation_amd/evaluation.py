@@ -49,11 +49,9 @@ def KLloss(data_dict, mean_key='mean', std_key='std'):
 
 
 def _hard_onehot(mask):
-    """argmax over channels -> one-hot (validation path, utils/evaluation.py:58-64); 2 classes."""
-    if mask.shape[1] != 2:
-        raise NotImplementedError("hard Dice is written for 2 classes")
-    fg = (mask[:, 1:2] > mask[:, 0:1]).float()     # torch.argmax picks index 0 on ties
-    return ops.onehot(fg, 2)
+    """argmax over channels -> one-hot (validation path, utils/evaluation.py:58-64), any number of classes: vs_hard_onehot
+    (ties go to the first maximal channel, as torch.argmax resolves them)."""
+    return ops.hard_onehot(mask)
 
 
 def avg_dsc(data_dict, source_key='align_lung', target_key='source_lung', binary=False, topindex=2, botindex=0,

@@ -150,82 +150,6 @@ def cpad(c):
 
 
 # ------------------------------------------------------------------------------------------------
-# side stream for weight-gradient kernels
-# ------------------------------------------------------------------------------------------------
-# In backward the chain  bwd-data(L) -> IN-backward(L-1) -> bwd-data(L-1) ...  is strictly sequential, while the weight
-# (and bias) gradient of each layer is a leaf: nothing in backward reads it.  With overlap enabled those kernels are
-# issued on a second HIP stream (forked from / joined to the main stream with events, so it also works inside HIP-graph
-# capture, where it becomes a parallel branch of the graph) and fill the CUs that the small critical-path kernels leave
-# idle.  Inputs are kept referenced until the join so the allocator cannot recycle them under the side stream.  The
-# produced gradients are NOT held: autograd's AccumulateGrad must find them unshared so that it adopts the tensor as
-# .grad without launching a copy on the main stream (a copy would read the buffer before the side stream wrote it).
-_SIDE = {"enabled": False, "stream": None, "pending": [], "forked": False, "queue": [], "callback": False,
-         "batch": int(os.environ.get("VS_SIDE_BATCH", "3"))}
-# Every fork of the side stream is a cross-queue dependency in the captured graph, and the kernel trace shows each one
-# costs a 13-20 us bubble on BOTH branches (signal + barrier packets): forking per layer ate what the overlap won.  The
-# launches are therefore queued as closures and issued in batches of VS_SIDE_BATCH layers behind one fork; the closures
-# write into gradient tensors allocated at submit time, addressed by raw pointer (holding the tensor would make
-# AccumulateGrad copy it on the main stream before the side stream wrote it; .grad keeps the storage alive until the join).
-
-
-def set_overlap(enabled=True):
-    """Issue weight/bias-gradient kernels on a side stream, joined to the launching stream when the backward pass ends."""
-    if not enabled:
-        _flush_side()
-    _SIDE["enabled"] = bool(enabled)
-
-
-def side_submit(weight, keep, fn):
-    """Run fn() — kernel launches into preallocated outputs only — on the side stream with the next batch (immediately, on
-    the current stream, when overlap is off, the parameter accumulates into an existing .grad, or a profile is running)."""
-    if not (_SIDE["enabled"] and weight.grad is None and PROFILE is None):
-        fn()
-        return
-    if not _SIDE["callback"]:
-        # issue the tail of the queue and join when this backward pass ends, so that gradients are complete (in stream
-        # order) by the time backward() returns, whoever reads them
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(_backward_done)
-            _SIDE["callback"] = True
-        except RuntimeError:
-            pass                                # not inside a backward pass: the caller joins
-    _SIDE["queue"].append((fn, keep))
-    if len(_SIDE["queue"]) >= _SIDE["batch"]:
-        _flush_side()
-
-
-def _backward_done():
-    _SIDE["callback"] = False
-    join_side()
-
-
-def _flush_side():
-    q = _SIDE["queue"]
-    if not q:
-        return
-    if _SIDE["stream"] is None:
-        _SIDE["stream"] = torch.cuda.Stream()
-    _SIDE["stream"].wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(_SIDE["stream"]):
-        for fn, keep in q:
-            fn()
-            _SIDE["pending"].extend(keep)      # inputs stay referenced until the join: the allocator must not recycle them
-    q.clear()
-    _SIDE["forked"] = True
-
-
-def join_side():
-    """Issue what is still queued (deferred grouped weight gradients included), make the current stream wait for every
-    side-stream kernel and release the held tensors."""
-    flush_wgrads()
-    _flush_side()
-    if _SIDE["forked"]:
-        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
-        _SIDE["pending"].clear()
-        _SIDE["forked"] = False
-
-
-# ------------------------------------------------------------------------------------------------
 # weight packing (fragment order); frozen weights are packed once and cached
 # ------------------------------------------------------------------------------------------------
 
@@ -359,6 +283,12 @@ def repack_trainable():
     check(lib.vs_pack_weight_multi(r["descs"].data_ptr(), r["n"], r["blocks"], _stream()), "pack_weight_multi")
     for p, ent in r["entries"]:
         ent[1] = (p._version, p.data_ptr(), _TRAIN_EPOCH[0])
+
+
+def repack_table():
+    """The descriptor table repack_trainable() launches with right now (a device tensor, or None).  A captured graph that contains the
+    re-pack launch holds a reference to it: repack_trainable() REPLACES the table when other images register, it never rewrites one in place."""
+    return _REPACK["descs"]
 
 
 _PACK_EPOCH = [0]
@@ -570,12 +500,10 @@ def _pending_done():
 # rstd * (g*mask - m1 - xhat*m2) while it stages its input — the standalone apply launch (3 tensor passes at 96^3) disappears.
 # An entry nobody took by the end of the pass means a consumer treated an un-applied gradient as applied: that is an error, not a fallback.
 FUSE_APPLY = os.environ.get("VS_FUSE_APPLY", "1") != "0"
-# channels of the activations whose producer may have a fused-apply kernel: 8 / 16 (k3t, single-chunk k3b: the 96^3 / 48^3 levels) and, opt-in
-# (VS_FUSE_APPLY_32=1), 32 / 64 (k3b<32,16|32,...,FA>: the 24^3 / 12^3 levels).  The 32-channel form exists, is tested (tests/test_gpu_layers.py)
-# and is OFF by default: measured on the 96^3 step (profiles/README.md, round 4) the fused launch costs 14.0 us at 24^3 x 32 against 8.7 + 4.3 for
-# the pair it replaces and 18.4 against 8.7 + 3.9 at 12^3 x 64 (two chunks) — 2.566 vs 2.519 ms per step.  The library has the last word
-# (vs_conv_k3_fused_apply_supported): a marked tensor whose producer has no such kernel gets the standalone apply in the producer's backward.
-_FA_CHANNELS = (8, 16, 32, 64) if os.environ.get("VS_FUSE_APPLY_32", "0") != "0" else (8, 16)
+# channels of the activations whose producer has a fused-apply kernel: 8 / 16 (k3t, single-chunk k3b: the 96^3 / 48^3 levels).  The 32-channel
+# form (k3b<32,...,FA>, the 24^3 / 12^3 levels) measured slower twice (round 4: 2.519 -> 2.566 ms per step, profiles/r04_ab_fused_apply_32ch.json)
+# and left the library in round 5.  The library has the last word (vs_conv_k3_fused_apply_supported).
+_FA_CHANNELS = (8, 16)
 _LAZY_APPLY = {"grads": {}, "callback": False}
 
 
@@ -762,68 +690,19 @@ _GROUP = {"enabled": os.environ.get("VS_WGRAD_GROUP", "1") != "0", "descs": [], 
 # destination: vs_conv_wgrad_multi sums the uses, and the later uses return None to autograd (nothing left to accumulate).
 
 
-# Early, throttled flush.  The grouped launches above wait for the end of backward, where ~0.33 ms of weight-gradient
-# kernels run alone — while the low-resolution half of the pass (24^3 and below: ~130 launches that occupy a few dozen CUs each for ~8 us)
-# leaves most of the chip idle.  When the first small layer of a pass submits its descriptor and the queue already holds the big decoder-side
-# layers (out_block, up5, up4: their operands are final by then), those are issued AT ONCE on a second stream as persistent grids of
-# EARLY["wgs"] workgroups (vs_conv_wgrad_multi_throttled): a fraction of the chip for proportionally longer, under the latency-bound window.
-# One fork, one join (at the end-of-pass flush); inside a HIP-graph capture the second stream is a parallel branch.  Round 2's attempt used
-# full-width grids on the branch and lost 0.13 ms: the branch took the critical path's CUs and bandwidth.
-EARLY = {"enabled": os.environ.get("VS_WGRAD_EARLY", "0") != "0", "wgs": int(os.environ.get("VS_WGRAD_EARLY_WGS", "64")),
-         "small_voxels": int(os.environ.get("VS_WGRAD_EARLY_SMALL", str(2 * 24 ** 3))),      # a layer at or below this many voxels (batch included) opens the window
-         "min_bytes": float(os.environ.get("VS_WGRAD_EARLY_MIN_MB", "40")) * 1e6,            # worth a fork only if the queued big layers move at least this much
-         "done": False, "stream": None, "forked": False, "keep": [], "flushed": set()}
-
-
-def set_wgrad_early(enabled=True, wgs=None):
-    flush_wgrads()
-    EARLY["enabled"] = bool(enabled)
-    if wgs is not None:
-        EARLY["wgs"] = int(wgs)
-
-
-def _early_join():
-    if EARLY["forked"]:
-        torch.cuda.current_stream().wait_stream(EARLY["stream"])
-        EARLY["forked"] = False
-    EARLY["keep"] = []
-
-
-def _maybe_flush_early(voxels):
-    g, e = _GROUP, EARLY
-    if (not e["enabled"] or e["done"] or g["split"] is not None or PROFILE is not None or voxels > e["small_voxels"] or not g["callback"]
-            or g["dtype"] == torch.float32):
-        return
-    big = [x for x in g["descs"] if x[4] > e["small_voxels"]]
-    if sum(x[2] for x in big) < e["min_bytes"]:
-        return
-    e["done"] = True                              # one fork per pass
-    rest = [x for x in g["descs"] if x[4] <= e["small_voxels"]]
-    if e["stream"] is None:
-        e["stream"] = torch.cuda.Stream()
-    e["stream"].wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(e["stream"]):
-        ws = _issue_wgrads(big, e["wgs"])
-    e["forked"] = True
-    # operands, workspace: referenced until the join (the allocator must not hand their memory to the main stream's next tensors)
-    e["keep"] = g["keep"] + [ws]
-    e["flushed"].update(int(x[0].dw) for x in big)
-    g["descs"], g["keep"] = rest, []
-
-
-def _issue_wgrads(entries, target_wgs=0):
+def _issue_wgrads(entries):
     descs = [x[0] for x in entries]
     arr = (WgradDesc * len(descs))(*descs)
     dt = vs_of(_GROUP["dtype"])
     dev = torch.device("cuda", torch.cuda.current_device())
-    nbytes = lib.vs_conv_wgrad_multi_throttled_workspace_bytes(_ct.addressof(arr), len(descs), dt, target_wgs)
+    nbytes = lib.vs_conv_wgrad_multi_workspace_bytes(_ct.addressof(arr), len(descs), dt)
     if nbytes == 0:
         _GROUP["descs"], _GROUP["keep"] = [], []
         raise _lib.VaesegError("vs_conv_wgrad_multi: unsupported layer in the deferred weight-gradient list")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     nb, fl = sum(x[2] for x in entries), sum(x[3] for x in entries)
     with _timed("wgrad_multi(%d layers)" % len(descs), nb, fl):
-        check(lib.vs_conv_wgrad_multi_throttled(_ct.addressof(arr), len(descs), ws.data_ptr(), nbytes, dt, EPS_IN, target_wgs, _stream()), "conv_wgrad_multi")
+        check(lib.vs_conv_wgrad_multi(_ct.addressof(arr), len(descs), ws.data_ptr(), nbytes, dt, EPS_IN, _stream()), "conv_wgrad_multi")
     return ws
 
 
@@ -850,10 +729,6 @@ def drop_stale_wgrads():
     if g["descs"] or g["callback"]:
         g["descs"], g["keep"], g["callback"], g["bytes"], g["flops"] = [], [], False, 0.0, 0.0
     g["slots"] = {}
-    if EARLY["forked"] or EARLY["done"]:        # a pass that died after its early fork: join the branch, forget its bookkeeping
-        _early_join()
-        EARLY["done"] = False
-        EARLY["flushed"].clear()
     _UP_JOBS.clear()
     # the same for gradients parked / handed over un-applied by a pass that died: their addresses may be recycled by now, and a later
     # backward must never mistake a fresh tensor at such an address for one of them
@@ -893,16 +768,12 @@ def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb, up_co=0):
             g["callback"] = True
         except RuntimeError:
             flush_wgrads()                      # not inside a backward pass: nothing will call back
-            return
-    _maybe_flush_early(voxels)
 
 
 def _group_backward_done():
     _GROUP["callback"] = False
     flush_wgrads(first_only=_GROUP["split"] is not None)
     _GROUP["slots"] = {}
-    EARLY["done"] = False
-    EARLY["flushed"].clear()
 
 
 def pending_wgrads():
@@ -914,7 +785,6 @@ def flush_wgrads(first_only=False):
     set_wgrad_split — only the first phase."""
     g = _GROUP
     if not g["descs"]:
-        _early_join()
         return
     now = [e for e in g["descs"] if e[1]] if first_only else g["descs"]
     later = [e for e in g["descs"] if not e[1]] if first_only else []
@@ -922,7 +792,6 @@ def flush_wgrads(first_only=False):
     if not now:
         return
     _issue_wgrads(now)
-    _early_join()                               # the early branch (if one was forked in this pass) meets the main stream behind the remaining layers' launches
     if not later:
         _run_up_jobs()                          # parameter-space chain rule of the composed Up heads: reads the dWeff the launch above reduced
         g["keep"] = []                          # launched on the current stream: the allocator may recycle the inputs now
@@ -942,25 +811,19 @@ def _has_hooks(t):
 
 
 def _side_grads(weight, keep, wgrad_args, bias_args, bias=None):
-    """Allocate dW (and db) now; their kernels are deferred — grouped at the end of backward (default) or queued for the side
-    stream (set_overlap) — or run at once when the parameter already holds a gradient to accumulate into, carries hooks, or
-    grad mode is on (autograd would then clone the still-unwritten tensor); -> (gw, gb)."""
-    grouping = _GROUP["enabled"] and not _SIDE["enabled"]
+    """Allocate dW (and db) now; their kernels are deferred — grouped at the end of backward (default) — or run at once when grouping is
+    off, the parameter already holds a gradient to accumulate into, carries hooks, or grad mode is on (autograd would then clone the
+    still-unwritten tensor); -> (gw, gb)."""
+    grouping = _GROUP["enabled"]
     slot = _GROUP["slots"].get(id(weight)) if grouping and weight.is_leaf else None
-    if slot is not None and slot[0] in EARLY["flushed"]:
-        # the first use of this weight was reduced by the early branch already: this use gets a destination of its own and autograd adds the two
-        slot = None
-        early_reuse = True
-    else:
-        early_reuse = False
     if slot is not None:
         # a later use of the same weight in this pass: one more descriptor with the first use's destination, nothing returned to autograd
         _group_submit(weight, keep, wgrad_args, bias_args if slot[1] is not None else None, slot[0], slot[1])
         return None, None
-    gw = _grad_slot(weight, weight.shape) if not early_reuse else torch.empty(weight.shape, dtype=torch.float32, device=weight.device)
+    gw = _grad_slot(weight, weight.shape)
     gb = None
     if bias_args is not None:
-        gb = (_grad_slot(bias, (bias_args[1],)) if bias is not None and not early_reuse else
+        gb = (_grad_slot(bias, (bias_args[1],)) if bias is not None else
               torch.empty(bias_args[1], dtype=torch.float32, device=keep[0].device))
     # deferring hands autograd a still-unwritten tensor: only sound when its consumer is the parameter's AccumulateGrad (a leaf), which keeps it
     # untouched until the pass ends; a non-leaf weight's gradient is read by the next backward node at once
@@ -971,16 +834,9 @@ def _side_grads(weight, keep, wgrad_args, bias_args, bias=None):
         # the descriptor holds raw pointers only: AccumulateGrad must find gw / gb unshared to adopt them as .grad without a copy
         _group_submit(weight, keep, wgrad_args, bias_args, gw, gb)
         return gw, gb
-    gw_ptr, gb_ptr = gw.data_ptr(), (gb.data_ptr() if gb is not None else None)
-
-    def launch():
-        conv_wgrad(*wgrad_args, weight.shape, out_ptr=gw_ptr)
-        if bias_args is not None:
-            bias_grad(bias_args[0], bias_args[1], out_ptr=gb_ptr)
-    if deferrable:
-        side_submit(weight, keep, launch)
-    else:
-        launch()
+    conv_wgrad(*wgrad_args, weight.shape, out_ptr=gw.data_ptr())
+    if bias_args is not None:
+        bias_grad(bias_args[0], bias_args[1], out_ptr=gb.data_ptr())
     return gw, gb
 
 
@@ -1376,7 +1232,7 @@ def up_composed_ok(x, tconv, conv3):
     if not FUSE_UP or x.dtype == torch.float32:
         return False
     trainable = wt.requires_grad or w3.requires_grad or (tconv.bias is not None and tconv.bias.requires_grad)
-    if trainable and (not FUSE_UP_TRAINABLE or not _GROUP["enabled"] or _SIDE["enabled"] or _GROUP["split"] is not None
+    if trainable and (not FUSE_UP_TRAINABLE or not _GROUP["enabled"] or _GROUP["split"] is not None
                       or not (wt.is_leaf and w3.is_leaf)):
         return False
     if tuple(wt.shape[2:]) != (2, 2, 2) or tuple(w3.shape[2:]) != (3, 3, 3) or w3.shape[1] != wt.shape[1] or x.shape[-1] != wt.shape[0]:
@@ -2081,6 +1937,16 @@ def onehot(label, n_class=2):
     b = lab.shape[0]
     out = torch.empty((b, n_class) + tuple(lab.shape[2:]), dtype=torch.float32, device=lab.device)
     check(lib.vs_onehot(lab.data_ptr(), out.data_ptr(), b, lab.numel() // b, n_class, _stream()), "onehot")
+    return out
+
+
+def hard_onehot(mask):
+    """(B,C,D,H,W) scores -> planar fp32 one-hot of the channel argmax (utils/evaluation.py:58-64), any C >= 1, one launch."""
+    _require_cuda(mask)
+    m = _contig(mask.detach().float())
+    b, c = m.shape[0], m.shape[1]
+    out = torch.empty_like(m)
+    check(lib.vs_hard_onehot(m.data_ptr(), out.data_ptr(), b, c, m.numel() // (b * c), _stream()), "hard_onehot")
     return out
 
 

@@ -52,15 +52,19 @@ class LossScaler:
         self.found_inf = torch.zeros(1, dtype=torch.float32, device=device)
         self.tracker = torch.zeros(1, dtype=torch.int32, device=device)
         self.cfg = (float(growth_factor), float(backoff_factor), int(growth_interval))
-        self._tab = _Tables()
+        self._tabs = {}                  # one table per caller slot (param group): alternating groups must not rebuild each other's table
 
     @property
     def seed(self):
         """0-dim view of the scale: pass it as the upstream gradient of the (scalar) loss"""
         return self.scale.view(())
 
-    def check(self, grads):
-        (gp, sizes, bm), nb = self._tab.get([grads], grads[0].device)
+    def prepare(self, grads, slot=0):
+        """build the device-side table check(grads, slot) needs (a stream capture cannot contain the host-to-device copy)"""
+        return self._tabs.setdefault(slot, _Tables()).get([grads], grads[0].device)
+
+    def check(self, grads, slot=0):
+        (gp, sizes, bm), nb = self.prepare(grads, slot)
         check(lib.vs_grad_finite_multi(gp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb, self.found_inf.data_ptr(), _stream()), "grad_finite_multi")
 
     def update(self):
@@ -74,22 +78,53 @@ class SGD(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self._tables = {}
+        self._hyper = {}                 # group index -> [device float[3] = (lr, momentum, weight_decay), the host values it holds]
 
     @torch.no_grad()
-    def step_with(self, params, grads, scaler=None):
-        """step() with explicit gradient tensors (e.g. the views of a DDP flat bucket) instead of p.grad."""
-        return self.step(_override={id(p): g for p, g in zip(params, grads)}, scaler=scaler)
+    def step_with(self, params, grads, scaler=None, device_hyper=False):
+        """step() with explicit gradient tensors (e.g. the views of a DDP flat bucket) instead of p.grad.
+        device_hyper: the launch reads lr / momentum / weight decay from device memory (sync_hyper) instead of taking them as kernel
+        arguments — the form a captured HIP graph needs to follow a schedule without re-capture."""
+        return self.step(_override={id(p): g for p, g in zip(params, grads)}, scaler=scaler, _device_hyper=device_hyper)
 
     @torch.no_grad()
-    def prepare(self, params, grads):
-        """Build the device-side pointer tables and the momentum buffers for step_with(params, grads) WITHOUT updating anything: a stream
-        capture that includes the optimiser (train.GraphedStep, captured tail) must find them ready — building them copies host tables
-        to the device, which a capture cannot contain."""
-        return self.step(_override={id(p): g for p, g in zip(params, grads)}, _dry=True)
+    def prepare(self, params, grads, scaler=None):
+        """Build the device-side pointer tables, the momentum buffers and the device-resident hyperparameters for step_with(params, grads)
+        WITHOUT updating anything: a stream capture that includes the optimiser (train.GraphedStep, captured tail) must find them ready —
+        building them copies host tables to the device, which a capture cannot contain."""
+        return self.step(_override={id(p): g for p, g in zip(params, grads)}, scaler=scaler, _dry=True)
+
+    def hyper(self):
+        return [(float(g["lr"]), float(g["momentum"]), float(g["weight_decay"])) for g in self.param_groups]
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale=1.0, _override=None, scaler=None, _dry=False):
-        ops.join_side()
+    def sync_hyper(self):
+        """Write each group's current (lr, momentum, weight_decay) into its device-resident triple if a scheduler moved them (stream-ordered
+        before whatever is launched next: a graph replay that follows reads the new values).  -> number of groups rewritten."""
+        moved = 0
+        for gi, vals in enumerate(self.hyper()):
+            ent = self._hyper.get(gi)
+            if ent is not None and ent[1] != vals:
+                ent[0].copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=False)
+                ent[1] = vals
+                moved += 1
+        return moved
+
+    def _hyper_dev(self, gi, device):
+        vals = self.hyper()[gi]
+        ent = self._hyper.get(gi)
+        if ent is None or ent[0].device != device:
+            ent = self._hyper[gi] = [torch.tensor(vals, dtype=torch.float32).to(device), vals]
+        return ent
+
+    def capture_key(self, params):
+        """what a captured step_with(params, ...) launch has baked in besides the gradient addresses: the parameter set and the momentum buffers"""
+        return tuple((id(p), p.data_ptr(), self.state[p]["momentum_buffer"].data_ptr() if "momentum_buffer" in self.state.get(p, {}) else 0)
+                     for p in params)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0, _override=None, scaler=None, _dry=False, _device_hyper=False):
+        ops.flush_wgrads()
         todo = []
         for gi, group in enumerate(self.param_groups):
             if _override is not None:
@@ -113,14 +148,23 @@ class SGD(torch.optim.Optimizer):
                 bufs.append(st["momentum_buffer"])
             tab = self._tables.setdefault(gi, _Tables())
             (pp, gp, bp, sizes, bm), nb = tab.get([ps, grads, bufs], ps[0].device)
-            todo.append((group, grads, pp, gp, bp, sizes, bm, nb))
+            todo.append((group, grads, pp, gp, bp, sizes, bm, nb, gi))
         if _dry:
+            for t in todo:
+                self._hyper_dev(t[8], t[2].device)
+                if scaler is not None:
+                    scaler.prepare(t[1], t[8])
             return None
         if scaler is not None:
             for t in todo:                                   # every group is checked before any group is updated
-                scaler.check(t[1])
+                scaler.check(t[1], t[8])
         sp, fp = (scaler.scale.data_ptr(), scaler.found_inf.data_ptr()) if scaler is not None else (None, None)
-        for group, grads, pp, gp, bp, sizes, bm, nb in todo:
+        for group, grads, pp, gp, bp, sizes, bm, nb, gi in todo:
+            if _device_hyper:
+                hyp = self._hyper_dev(gi, pp.device)[0]
+                check(lib.vs_sgd_momentum_dev_multi(pp.data_ptr(), gp.data_ptr(), bp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb,
+                                                    hyp.data_ptr(), sp, fp, _stream()), "sgd_momentum_dev_multi")
+                continue
             check(lib.vs_sgd_momentum_scaled_multi(pp.data_ptr(), gp.data_ptr(), bp.data_ptr(), sizes.data_ptr(), bm.data_ptr(), nb,
                                                    float(group["lr"]) * float(grad_scale), float(group["momentum"]),
                                                    float(group["weight_decay"]), 0, sp, fp, _stream()), "sgd_momentum_multi")
@@ -146,7 +190,7 @@ class Adam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, _override=None, scaler=None):
-        ops.join_side()
+        ops.flush_wgrads()
         todo = []
         for gi, group in enumerate(self.param_groups):
             if _override is not None:
@@ -172,8 +216,8 @@ class Adam(torch.optim.Optimizer):
             (pp, gp, ap, vp, sizes, bm), nb = tab.get([ps, grads, m1, m2], ps[0].device)
             todo.append((group, grads, pp, gp, ap, vp, sizes, bm, nb, step))
         if scaler is not None:
-            for t in todo:
-                scaler.check(t[1])
+            for i, t in enumerate(todo):
+                scaler.check(t[1], i)
         sp, fp = (scaler.scale.data_ptr(), scaler.found_inf.data_ptr()) if scaler is not None else (None, None)
         for group, grads, pp, gp, ap, vp, sizes, bm, nb, step in todo:
             b1, b2 = group["betas"]

@@ -237,23 +237,21 @@ class GraphedStep:
     ``grad_sync``: a ddp.FlatGradSync.  With its two buckets the pass is captured as TWO graphs — [forward, backward, bucket-0
     weight gradients] and [bucket-1 weight gradients] — and a step is: replay 1, start the all-reduce of bucket 0 on the
     communication stream, replay 2 underneath it, all-reduce bucket 1, wait, optimiser on the averaged views.
-    ``overlap``: issue the weight-gradient kernels on a side stream (a parallel branch of the graph).  Off by default: with the
-    current kernels the serial graph is 1-2 % faster (3.87 vs 3.94 ms) — the branch's forks/joins and the contention for CUs cost
-    more than the concurrency returns.
     ``scaler``: an optim.LossScaler (fp16 storage) — backward is seeded with its device-resident scale, the optimiser unscales / skips.
     ``capture_tail`` (default: on, VS_GRAPH_TAIL=0 switches it off): the TAIL of the step — the gradient all-reduce (RCCL collectives capture into
-    a HIP graph on this stack: tools/rccl_capture_probe.py), the SGD launch and the re-pack of the trainable weight images — is part of the
-    same graph, so a step is ONE graph launch and nothing else.  Conditions (otherwise the tail stays eager, `self.tail` says which):
-    one bucket (not the two-phase overlapped form), no LossScaler, optim.SGD (Adam's bias corrections are host-side per-step state), every
-    gradient written straight into its flat slot (no stragglers to gather), the process group is RCCL or absent.  The learning rate,
-    momentum and weight decay are kernel ARGUMENTS baked into the captured launch: step() compares the optimiser's current values with the
-    captured ones and re-captures when a scheduler changed them (once per epoch in the reference's schedules, main_source.py:674-677).
+    a HIP graph on this stack: tools/rccl_capture_probe.py), [the LossScaler's finite check,] the SGD launch[, the loss-scale update] and the
+    re-pack of the trainable weight images — is part of the same graph, so a step is ONE graph launch and nothing else.  Conditions (otherwise
+    the tail stays eager, `self.tail` says which): one bucket (not the two-phase overlapped form), optim.SGD (Adam's bias corrections are
+    host-side per-step state), every gradient written straight into its flat slot (no stragglers to gather), the process group is RCCL or absent.
+    The learning rate, momentum and weight decay are read by the captured launch from DEVICE memory (optim.SGD.sync_hyper rewrites the three
+    floats when a scheduler moved them: main_source.py:674-677 — no re-capture); what IS baked in — the set of live parameters and the
+    addresses of parameters and momentum buffers — is compared on every step() and a change (requires_grad toggled, load_state_dict) re-captures
+    (`self.recaptures`).  A LossScaler's scale, overflow flag and growth tracker are device scalars, so the scaled step captures as it is.
     Models with dropout > 0 cannot be captured (ops.next_dropout_seed raises during capture): run them eagerly."""
 
-    def __init__(self, loss_fn, params, optimizer, grad_sync=None, warmup=2, overlap=False, scaler=None, capture_tail=None):
+    def __init__(self, loss_fn, params, optimizer, grad_sync=None, warmup=2, scaler=None, capture_tail=None):
         from . import ddp as _ddp
         from . import optim as _optim
-        ops.set_overlap(overlap and os.environ.get("VS_OVERLAP", "1") != "0")       # VS_OVERLAP=0: measurement aid
         self.loss_fn, self.params, self.optimizer, self.grad_sync = loss_fn, list(params), optimizer, grad_sync
         self._one = None
         self.scaler = scaler                     # optim.LossScaler for fp16 storage: its scale is a device scalar the captured backward reads
@@ -268,30 +266,40 @@ class GraphedStep:
         # grad_sync None = the caller wants no exchange (one rank, or a timing leg): nothing collective is captured then
         rccl_or_none = (grad_sync is None or (not dist.is_initialized()) or not getattr(grad_sync, "exchange", True)
                         or (dist.get_backend(grad_sync.group) == "nccl" and _ddp.collective_capturable(grad_sync.group)))
-        self.tail = (bool(capture_tail) and warmup >= 1 and not two_phase and scaler is None and isinstance(optimizer, _optim.SGD)
+        self.tail = (bool(capture_tail) and warmup >= 1 and not two_phase and isinstance(optimizer, _optim.SGD)
                      and rccl_or_none and all(p.is_cuda for p in self.params))
         self._own_sync = False
         if self.tail and grad_sync is None:
             # one rank, no exchange: the flat buffer still serves — it gives every gradient a FIXED address, which the captured optimiser launch needs
             self.grad_sync = grad_sync = _ddp.FlatGradSync(self.params, overlap=False, exchange=False)
             self._own_sync = True
+        self._warm(warmup)
+        self._capture()
+
+    def _warm(self, passes):
+        """eager passes on a side stream before a capture: every kernel's lazily built state (packed images, plans, arena size) exists, and
+        the pass tells which parameters receive a gradient — _prepare_tail builds the tail's device tables from that, eagerly"""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            self.loss = self.aux = None
             self._accumulators = capture_safe_accumulators(self.params)      # kept: the capture must find these, not default-stream ones
-            for _ in range(warmup):
+            for _ in range(passes):
                 self._eager_fwd_bwd()
             if self.tail:
                 self._prepare_tail()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._capture()
 
-    def _hyper(self):
-        return [(float(g["lr"]), float(g["momentum"]), float(g["weight_decay"])) for g in self.optimizer.param_groups]
+    def _tail_key(self):
+        """what the captured tail has baked in: which parameters take part, where they and their momentum buffers live"""
+        live, _ = self.grad_sync.live()
+        return tuple(p.requires_grad for p in self.params) + self.optimizer.capture_key(live)
 
     def _prepare_tail(self):
-        """after a warm-up pass: can the tail be captured (every live gradient sits in its flat slot), and are the tables it needs built?"""
+        """after a pass (warm-up, or the last replay before a re-capture): can the tail be captured (every live gradient sits in its flat
+        slot), and are the tables it needs built?  Everything that copies a host table to the device happens HERE, eagerly — optimiser
+        pointer tables and momentum buffers, the device-resident hyperparameters, the scaler's table, the re-pack descriptor table."""
         s = self.grad_sync
         src, _ = s._stragglers([p.grad for p in self.params])
         if src or not s.direct:
@@ -300,7 +308,8 @@ class GraphedStep:
                 s.close()
                 self.grad_sync, self._own_sync = None, False
             return
-        self.optimizer.prepare(*s.live())
+        s.resolve_avg()                          # does the collective library average?  asked once, eagerly: a capture cannot fall back
+        self.optimizer.prepare(*s.live(), scaler=self.scaler)
         ops.repack_trainable()                   # builds the descriptor table of the multi-tensor re-pack (same images, same weights: idempotent)
 
     def _capture(self):
@@ -321,8 +330,13 @@ class GraphedStep:
                 s._stragglers([p.grad for p in self.params])      # bookkeeping only (which parameters got no gradient): _prepare_tail saw no stragglers
                 s.start(0)
                 s.wait()
-                self.optimizer.step_with(*s.live())
-        self._tail_hyper = self._hyper()
+                kw = {} if self.scaler is None else {"scaler": self.scaler}
+                self.optimizer.step_with(*s.live(), device_hyper=True, **kw)
+        if self.tail:
+            self._tail_captured = self._tail_key()
+            # the captured re-pack launch reads THIS descriptor table by address: a later registration of other trainable images (another
+            # model's GraphedStep) replaces ops' table, and this graph's must outlive that (it used to be freed under the graph)
+            self._repack_table = ops.repack_table()
         if two_phase:
             self.graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
@@ -340,13 +354,17 @@ class GraphedStep:
                 self._one = torch.ones((), dtype=self.loss.dtype, device=self.loss.device)
             self.loss.backward(gradient=self._one)     # a constant seed: autograd's own ones_like would be a fill launch in every replay
         if rest:
-            ops.join_side()      # side-stream weight gradients (a parallel branch of the captured graph) / the second weight-gradient phase
+            ops.flush_wgrads()   # the second weight-gradient phase (set_wgrad_split), when the caller did not keep it for a graph of its own
 
     def step(self):
         if self.tail:
-            if self._hyper() != self._tail_hyper:            # a scheduler moved lr / momentum / weight decay: they are baked into the captured launch
+            if self._tail_key() != self._tail_captured:      # requires_grad toggled, momentum buffers replaced (load_state_dict): baked into the capture
                 self.recaptures += 1
+                self.graph = None                            # the old capture's pool goes first
+                self._warm(1)                                # one eager pass with the new set: who gets a gradient now, tables rebuilt outside the capture
                 self._capture()
+        if self.tail:                                        # (a re-capture may have found stragglers and left the tail eager)
+            self.optimizer.sync_hyper()                      # a scheduler moved lr / momentum / weight decay: three floats in device memory, no re-capture
             self.graph.replay()
             return self.loss
         self.graph.replay()
