@@ -492,14 +492,18 @@ def _group_layers_backward(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("mpack,uber", [("1", "1"), ("0", "1"), ("1", "0")])
-def test_grouped_weight_gradients_many_layers(dtype, mpack, uber, monkeypatch):
+@pytest.mark.parametrize("mpack,uber,swap,big", [("1", "1", "1", "0"), ("0", "1", "1", "0"), ("1", "0", "1", "0"), ("1", "1", "0", "0"),
+                                                 ("1", "1", "1", "1"), ("1", "1", "0", "1"), ("0", "1", "1", "1")])
+def test_grouped_weight_gradients_many_layers(dtype, mpack, uber, swap, big, monkeypatch):
     """vs_conv_wgrad_multi (main_source.py:660: the gradients the optimiser step reads): 34 layers of all conv kinds deferred to the end of ONE
     backward pass and issued as grouped launches — each against F.conv3d / F.conv_transpose3d autograd on the CPU, against the
     per-layer launches (vs_conv_wgrad), and bitwise reproducible.  mpack: the M-packed form of the layers with 8 stored output channels
-    (csrc/wgrad.hip g3b_body) on / off; uber: all buckets in one grid / one grid per bucket."""
+    (csrc/wgrad.hip g3b_body) on / off; uber: all buckets in one grid / one grid per bucket; swap: operand exchange on / off; big: big-tile kernel."""
     monkeypatch.setenv("VS_WGRAD_MPACK", mpack)
     monkeypatch.setenv("VS_WGRAD_UBER", uber)              # 1: every bucket in one grid (g3b_uber_kernel, the default); 0: one grid per bucket
+    monkeypatch.setenv("VS_WGRAD_SWAP", swap)              # 1 (default): operands of the lazy-input 3x3x3 layers exchanged (csrc/wgrad.hip multi_plan); 0: as submitted
+    # big: the 8 x 8 x 16-tile kernel (g3c_body) takes every layer it supports — by default only tensors of >= 400 k voxels (none of this list) get it
+    monkeypatch.setenv("VS_WGRAD_BIG_MIN_VOXELS", "1" if big == "1" else "1000000000")
     ops = _ops()
     assert ops._GROUP["enabled"]
     got, refs = _group_layers_backward(ops, dtype)

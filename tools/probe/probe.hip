@@ -108,3 +108,81 @@ extern "C" int vs_debug_store_probe(float* p, int n_wg, int mode, void* stream) 
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Composed Down head probe ("measure it"): nn.Conv3d(C, C, 2, stride 2) followed by nn.Conv3d(C, Co, 3, padding 1)
+// with nothing in between (joint_model.py:126-136) as ONE linear operator on the fine grid — a 6x6x6 window with stride 2 and padding 2,
+// Weff[pos] = W3[d] * W2[t] for pos = 2 d + t per axis, 216 taps of (Co x C) instead of 8 (C x C) + 27 (Co x C).  Forward only, bf16, C = 16, Co = 32,
+// no lazy input (the product's kernels also normalise on load: this probe favours the composed form).  Direct-from-global like g1_kernel: a workgroup
+// takes 256 output voxels (64 per wave, four column groups) and both 16-row blocks; k-group kg = taps (2 kg, 2 kg + 1) x 16 channels.
+typedef __attribute__((ext_vector_type(4))) float pf32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int pu32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 pbf16x8;
+__global__ __launch_bounds__(256) void down_composed_probe_kernel(const unsigned short* __restrict__ x, const pu32x4* __restrict__ wp, unsigned short* __restrict__ y,
+                                                                   int N, int D, int H, int W) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
+    const int Do = D / 2, Ho = H / 2, Wo = W / 2, vcol = Do * Ho * Wo;
+    const int tiles = (vcol + 255) / 256;
+    const int n = blockIdx.x / tiles, tile = blockIdx.x - n * tiles;
+    int oz[4], oy[4], ox[4];
+    bool cvalid[4];
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+        int v = tile * 256 + wave * 64 + cg * 16 + col;
+        cvalid[cg] = v < vcol;
+        if (!cvalid[cg]) v = 0;
+        ox[cg] = v % Wo; oy[cg] = (v / Wo) % Ho; oz[cg] = v / (Wo * Ho);
+    }
+    pf32x4 acc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = pf32x4{0.f, 0.f, 0.f, 0.f};
+    const int sub = g >> 1, ch0 = (g & 1) * 8;
+    constexpr int NKG = 108, UN = 4;
+    for (int kgb = 0; kgb < NKG; kgb += UN) {
+        pu32x4 a[UN][2], b[UN][4];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int kg = kgb + u;
+            a[u][0] = wp[(0 * NKG + kg) * 64 + lane];
+            a[u][1] = wp[(1 * NKG + kg) * 64 + lane];
+            const int tap = 2 * kg + sub;
+            const int tz = tap / 36, ty = (tap / 6) % 6, tx = tap % 6;
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) {
+                const int iz = 2 * oz[cg] - 2 + tz, iy = 2 * oy[cg] - 2 + ty, ix = 2 * ox[cg] - 2 + tx;
+                const bool ok = cvalid[cg] && (unsigned)iz < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                b[u][cg] = ok ? *(const pu32x4*)(x + ((((size_t)n * D + iz) * H + iy) * W + ix) * 16 + ch0) : pu32x4{0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+                    acc[rb][cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf16x8, a[u][rb]), __builtin_bit_cast(pbf16x8, b[u][cg]), acc[rb][cg], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+            if (!cvalid[cg]) continue;
+            const size_t e = ((((size_t)n * Do + oz[cg]) * Ho + oy[cg]) * Wo + ox[cg]) * 32 + rb * 16 + 4 * g;
+            typedef __attribute__((ext_vector_type(2))) float pf32x2;
+            typedef __attribute__((ext_vector_type(2))) __bf16 pbf16x2;
+            typedef __attribute__((ext_vector_type(2))) unsigned int pu32x2;
+            pu32x2 pk;
+            pk[0] = __builtin_bit_cast(unsigned int, __builtin_convertvector(pf32x2{acc[rb][cg][0], acc[rb][cg][1]}, pbf16x2));
+            pk[1] = __builtin_bit_cast(unsigned int, __builtin_convertvector(pf32x2{acc[rb][cg][2], acc[rb][cg][3]}, pbf16x2));
+            *(pu32x2*)(y + e) = pk;
+        }
+}
+extern "C" int vs_debug_down_composed_probe(const void* x, const void* w_packed, void* y, int n, int d, int h, int w, void* stream) {
+    if (!x || !w_packed || !y || n <= 0 || d <= 0 || h <= 0 || w <= 0 || ((d | h | w) & 1)) return -1;
+    const int vcol = (d / 2) * (h / 2) * (w / 2);
+    hipLaunchKernelGGL(down_composed_probe_kernel, dim3(((vcol + 255) / 256) * n), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, (const pu32x4*)w_packed,
+                       (unsigned short*)y, n, d, h, w);
+    return (int)hipGetLastError();
+}

@@ -106,7 +106,10 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     if (kind == VS_CONV_K3 && fa_x != nullptr && ck == 32 && mt == 16 && rows16 % 32 == 0) mt = 32;
     const int row_tiles = rows16 / mt;
     if (fa_query != nullptr) {                             // planning only: would a fused-apply launch of this shape find a kernel?
-        *fa_query = (kind == VS_CONV_K3 && dtype != VS_F32) ? g1_k3_fa_supported(p, ck, mt) : 0;
+        if (dtype == VS_F32)                               // parity mode: the 8 -> 8 full-resolution layers (k3xt_kernel<..., FA>, igemm_k3x.h)
+            *fa_query = kind == VS_CONV_K3 && c_in == 8 && m_out == 8 && n * 8 <= 192 && vs_conv_k3_f32_limbs(d, h, w, c_in) && vs_k3x_toeplitz(8, 8, 27);
+        else
+            *fa_query = kind == VS_CONV_K3 ? g1_k3_fa_supported(p, ck, mt) : 0;
         return VS_OK;
     }
     if (kind == VS_CONV_K3) {
@@ -134,14 +137,14 @@ extern "C" int vs_conv_k3_bwd_data_fused_apply(const void* g, const void* act_x,
                                                void* stream) {
     if (!g || !act_x || !act_stats || !act_sums) return VS_EINVAL;
     if ((mask_x == nullptr) != (sums == nullptr) || (mask_x == nullptr) != (mask_stats == nullptr)) return VS_EINVAL;    // all three (lazy conv input) or none
-    if (dtype == VS_F32) return VS_EDTYPE;
+    if (dtype == VS_F32 && !vs_conv_k3_fused_apply_supported(n, d, h, w, c_in, m_out, mask_x != nullptr, dtype)) return VS_ESHAPE;
     if (((uintptr_t)act_x & 15) || (dx_out && ((uintptr_t)dx_out & 15))) return VS_EALIGN;
     return gather_impl(g, act_stats, w_packed, nullptr, y, nullptr, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, VS_CONV_K3, dtype, eps,
                        stream, act_x, act_sums, dx_out);
 }
 
 extern "C" int vs_conv_k3_fused_apply_supported(int n, int d, int h, int w, int c_in, int m_out, int lazy_input, int dtype) {
-    if (dtype == VS_F32 || !vs_dtype_ok(dtype)) return 0;
+    if (!vs_dtype_ok(dtype)) return 0;
     static const char dummy[16] __attribute__((aligned(16))) = {0};        // planning only: no pointer is dereferenced
     static double dsink[2];
     int ok = 0;

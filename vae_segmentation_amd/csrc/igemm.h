@@ -72,10 +72,17 @@ __device__ __forceinline__ u32x4 act_transform(u32x4 raw, const float* s_mean, c
     return frag_pack(v, (T*)nullptr);
 }
 
-template <typename T, int CK, int KIND, int MT, int EPI>
+// LIMB (fp32 storage only; round 5): the parity mode's stride-2 / transposed convolutions on the bf16 matrix cores.  The exact-f32 MFMA issues at 32 cycles per
+// 16x16x4 product, and these launches are a few waves walking a long dependent MFMA chain (a 32-channel stride-2 chunk: 256 of them per wave and column set,
+// 3.9 us) — they were the slowest launches per FLOP of the fp32 step.  Here TWO consecutive fp32 k-groups (2 x 4 k-values per lane, for A and B alike: any
+// lane -> k assignment is valid as long as both operands share it) are split IN REGISTERS into three bf16 limbs each (common.h vs_limb_split4: the arithmetic of
+// igemm_k3x.h) and multiplied by six v_mfma_f32_16x16x32_bf16 — 96 matrix cycles instead of 256 per (row block, column set), no new weight image: the packed fp32
+// fragments are read as they are.  The leading product x0 w0 has its own accumulator where the register budget allows (RB <= 2), as in k3x_kernel.
+template <typename T, int CK, int KIND, int MT, int EPI, bool LIMB = false>
 __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     using E = ET<T>;
     constexpr int EPL = E::EPL, KG = E::KG;
+    static_assert(!LIMB || sizeof(T) == 4, "limb arithmetic: fp32 storage");
     static_assert(KIND == G1_K2S2 || KIND == G1_PW, "the 3x3x3 kernels live in igemm_k3b.h / igemm_k3.h");
     static_assert(EPI == EPI_RAW || EPI == EPI_SCATTER, "softmax epilogue: 3x3x3 kernels only");
     constexpr int NTAPS = KIND == G1_K2S2 ? 8 : 1;
@@ -148,10 +155,36 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     }
 
     f32x4 acc[RB][4];
+    constexpr bool TWO_ACC = LIMB && RB <= 2;            // the five small limb products apart from the leading one (rounded once per k-group pair, not six times)
+    f32x4 acl[TWO_ACC ? RB : 1][4];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cg = 0; cg < 4; ++cg) {
+            acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (TWO_ACC) acl[TWO_ACC ? rb : 0][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    // LIMB: fragments of two consecutive k-groups -> three bf16 limb fragments (8 k-values per lane each)
+    auto split_pair = [&](const u32x4& f0, const u32x4& f1, u32x4 (&out)[3]) {
+        float v0[4], v1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] = __uint_as_float(f0[j]); v1[j] = __uint_as_float(f1[j]); }
+        unsigned int l0[3][2], l1[3][2];
+        vs_limb_split4(v0, l0);
+        vs_limb_split4(v1, l1);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) out[l] = u32x4{l0[l][0], l0[l][1], l1[l][0], l1[l][1]};
+    };
+    auto mfma_limbs = [&](const u32x4 (&al)[3], const u32x4 (&bl)[3], int rb, int cg) {
+        f32x4& small = TWO_ACC ? acl[TWO_ACC ? rb : 0][cg] : acc[rb][cg];
+        small = mfma16(al[0], bl[2], small, (unsigned short*)nullptr);
+        small = mfma16(al[1], bl[1], small, (unsigned short*)nullptr);
+        small = mfma16(al[2], bl[0], small, (unsigned short*)nullptr);
+        small = mfma16(al[0], bl[1], small, (unsigned short*)nullptr);
+        small = mfma16(al[1], bl[0], small, (unsigned short*)nullptr);
+        acc[rb][cg] = mfma16(al[0], bl[0], acc[rb][cg], (unsigned short*)nullptr);
+    };
+    const u32x4 zfrag = u32x4{0u, 0u, 0u, 0u};
 
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
     // The barrier that publishes the statistics tables is taken AFTER the first chunk's loads have been issued (each wave exactly once: in
@@ -195,10 +228,27 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
 #pragma unroll
                         for (int cg = 0; cg < 4; ++cg) bq[kg][cg] = act_transform<T, CK>(bq[kg][cg], s_mean, s_rstd, ch * CK + (g * EPL) % CK);
                     }
+                    if constexpr (!LIMB) {
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb)
+                        for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                        for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(aq[kg][rb], bq[kg][cg], acc[rb][cg], (T*)nullptr);
+                            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(aq[kg][rb], bq[kg][cg], acc[rb][cg], (T*)nullptr);
+                    }
+                }
+                if constexpr (LIMB) {
+#pragma unroll
+                    for (int kg = 0; kg < NKG; kg += 2) {
+                        u32x4 bl[4][3];
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg) split_pair(bq[kg][cg], kg + 1 < NKG ? bq[kg + 1 < NKG ? kg + 1 : kg][cg] : zfrag, bl[cg]);
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb) {
+                            u32x4 al[3];
+                            split_pair(aq[kg][rb], kg + 1 < NKG ? aq[kg + 1 < NKG ? kg + 1 : kg][rb] : zfrag, al);
+#pragma unroll
+                            for (int cg = 0; cg < 4; ++cg) mfma_limbs(al, bl[cg], rb, cg);
+                        }
+                    }
                 }
             } else {
                 // wave-uniform tap; KPT k-groups per tap.
@@ -227,15 +277,33 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
 #pragma unroll
                             for (int cg = 0; cg < 4; ++cg) bq[kg][cg] = act_transform<T, CK>(bq[kg][cg], s_mean, s_rstd, ch * CK + cc);
                         }
+                        if constexpr (!LIMB) {
 #pragma unroll
-                        for (int rb = 0; rb < RB; ++rb)
+                            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(aq[kg][rb], bq[kg][cg], acc[rb][cg], (T*)nullptr);
+                                for (int cg = 0; cg < 4; ++cg) acc[rb][cg] = mfma16(aq[kg][rb], bq[kg][cg], acc[rb][cg], (T*)nullptr);
+                        }
+                    }
+                    if constexpr (LIMB) {
+#pragma unroll
+                        for (int kg = 0; kg < NK; kg += 2) {
+                            u32x4 bl[4][3];
+#pragma unroll
+                            for (int cg = 0; cg < 4; ++cg) split_pair(bq[kg][cg], kg + 1 < NK ? bq[kg + 1 < NK ? kg + 1 : kg][cg] : zfrag, bl[cg]);
+#pragma unroll
+                            for (int rb = 0; rb < RB; ++rb) {
+                                u32x4 al[3];
+                                split_pair(aq[kg][rb], kg + 1 < NK ? aq[kg + 1 < NK ? kg + 1 : kg][rb] : zfrag, al);
+#pragma unroll
+                                for (int cg = 0; cg < 4; ++cg) mfma_limbs(al, bl[cg], rb, cg);
+                            }
+                        }
                     }
                 } else {
                 // The A (weight) fragments come straight from global memory, so the
                 // loop is software-pipelined: fragments for k-group kg+PD are requested while k-group kg is multiplied.
-                constexpr int PD = RB <= 2 ? 9 : 3;          // prefetch distance in k-groups (register budget RB*PD*4 VGPRs)
+                constexpr int PD = LIMB ? (RB <= 2 ? 8 : 4) : (RB <= 2 ? 9 : 3);          // prefetch distance in k-groups (register budget RB*PD*4 VGPRs); LIMB: even (k-groups go in pairs)
+                static_assert(!LIMB || NK % 2 == 0, "limb path: the pipelined chunk loop pairs k-groups");
                 u32x4 abuf[PD][RB];
 #pragma unroll
                 for (int j = 0; j < PD; ++j)
@@ -245,6 +313,45 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                 publish_tables();
 #pragma unroll 1
                 for (int kgb = 0; kgb < NK; kgb += PD) {
+                    if constexpr (LIMB) {
+#pragma unroll
+                        for (int j = 0; j < PD; j += 2) {
+                            const int kg = kgb + j;
+                            if (kg < NK) {
+                                u32x4 a2[2][RB], b2[2][4];
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                                    for (int rb = 0; rb < RB; ++rb) a2[h2][rb] = abuf[j + h2][rb];
+                                    if (kg + h2 + PD < NK) {
+#pragma unroll
+                                        for (int rb = 0; rb < RB; ++rb) abuf[j + h2][rb] = wch[(size_t)(rb0 + rb) * rb_stride + (kg + h2 + PD) * 64];
+                                    }
+                                    const int tap = (kg + h2) / KPT, kk = (kg + h2) - tap * KPT;
+                                    const int dz = (tap >> 2) & 1, dy = (tap >> 1) & 1, dx = tap & 1;
+                                    const int cc = kk * KG + g * EPL;
+                                    const long long toff_g = (((long long)dz * p.H + dy) * p.W + dx) * p.C + ch * CK + cc;
+#pragma unroll
+                                    for (int cg = 0; cg < 4; ++cg) b2[h2][cg] = *(const u32x4*)(xin + gofs[cg] + toff_g);
+                                    if (HS) {
+#pragma unroll
+                                        for (int cg = 0; cg < 4; ++cg) b2[h2][cg] = act_transform<T, CK>(b2[h2][cg], s_mean, s_rstd, ch * CK + cc);
+                                    }
+                                }
+                                u32x4 bl[4][3];
+#pragma unroll
+                                for (int cg = 0; cg < 4; ++cg) split_pair(b2[0][cg], b2[1][cg], bl[cg]);
+#pragma unroll
+                                for (int rb = 0; rb < RB; ++rb) {
+                                    u32x4 al[3];
+                                    split_pair(a2[0][rb], a2[1][rb], al);
+#pragma unroll
+                                    for (int cg = 0; cg < 4; ++cg) mfma_limbs(al, bl[cg], rb, cg);
+                                }
+                            }
+                        }
+                        continue;
+                    }
 #pragma unroll
                     for (int j = 0; j < PD; ++j) {
                         const int kg = kgb + j;
@@ -279,6 +386,12 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
         }
     };
     if (has_stats) chunk_loop(std::true_type{}); else chunk_loop(std::false_type{});
+    if constexpr (TWO_ACC) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] += acl[TWO_ACC ? rb : 0][cg];
+    }
     publish_tables();
     if (splitw) {
         // fixed order w0 + w1 + w2 + w3 (bitwise reproducible); waves 1-3 then hold no columns of their own
@@ -440,10 +553,10 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     }
 }
 
-template <typename T, int CK, int KIND, int MT, int EPI>
+template <typename T, int CK, int KIND, int MT, int EPI, bool LIMB = false>
 static int g1_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
     constexpr size_t lds = G1_LDS_BYTES + (KIND == G1_K2S2 && CK == 32 ? (size_t)3 * (MT / 16) * 4 * 64 * 16 : 0);   // + the wave-split partials
-    auto kern = g1_kernel<T, CK, KIND, MT, EPI>;
+    auto kern = g1_kernel<T, CK, KIND, MT, EPI, LIMB>;
     hipLaunchKernelGGL(kern, dim3(tiles_total, row_tiles), dim3(256), lds, stream, p);
     VS_CHECK_LAUNCH();
     return VS_OK;

@@ -12,3 +12,13 @@ int g1_dispatch_pw(const G1Params& p, int dtype, int ck, int mt, int tiles, int 
     G1_CASE(T, CKV, KIND, 16, EPI) G1_CASE(T, CKV, KIND, 32, EPI) G1_CASE(T, CKV, KIND, 64, EPI)
 
 #define G1_ALL(T, KIND, EPI) G1_ALL_MT(T, 8, KIND, EPI) G1_ALL_MT(T, 16, KIND, EPI) G1_ALL_MT(T, 32, KIND, EPI)
+// fp32 parity mode: the limb form of g1_kernel (igemm.h, LIMB) unless VS_F32_LIMBS=0 asks for the exact-f32 MFMA everywhere
+#define G1L_CASE(CKV, KIND, MTV, EPI) \
+    if (ck == CKV && mt == MTV) return g1_launch<float, CKV, KIND, MTV, EPI, true>(p, tiles, row_tiles, s);
+#define G1L_ALL_MT(CKV, KIND, EPI) G1L_CASE(CKV, KIND, 16, EPI) G1L_CASE(CKV, KIND, 32, EPI) G1L_CASE(CKV, KIND, 64, EPI)
+#define G1L_ALL(KIND, EPI) G1L_ALL_MT(8, KIND, EPI) G1L_ALL_MT(16, KIND, EPI) G1L_ALL_MT(32, KIND, EPI)
+static inline bool g1_f32_limbs() {
+    static const int on = getenv("VS_F32_LIMBS") ? atoi(getenv("VS_F32_LIMBS")) : 1;
+    static const int g1 = getenv("VS_G1_LIMBS") ? atoi(getenv("VS_G1_LIMBS")) : 1;            // A/B switch of this kernel family alone
+    return on != 0 && g1 != 0;
+}

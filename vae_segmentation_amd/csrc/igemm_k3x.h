@@ -428,8 +428,13 @@ static int k3x_launch(const G1Params& p, int tiles_total, int row_tiles, hipStre
 #define K3XT_NWI ((K3XT_NWF + 255) / 256)
 #define K3XT_WB (K3XT_NWI * 256 * 16)
 
-template <int EPI, bool SUMS, bool HS>
+// FA (backward-data only; round 5): the input gradient arrives UN-applied, as in k3t_kernel's fused apply (igemm_k3t.h) — p.x = g = dL/da of the lazy
+// activation a = relu(norm(p.fa_x)), with that activation's statistics (p.x_stats) and IN-backward sums (p.fa_sums) — and rstd * (g [xhat > 0] - m1 - xhat m2)
+// is evaluated in fp32 on the staged fragments before the limb split; the applied gradient of the tile's centre voxels goes to p.fa_dx when given (the
+// layer's weight gradient reads it).  The standalone apply pass of the parity mode is three passes over a 56 MB tensor at 96^3 (~40 us).
+template <int EPI, bool SUMS, bool HS, bool FA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k3xt_kernel(const G1Params p) {
+    static_assert(!FA || (!HS && EPI == EPI_RAW), "fused apply: backward-data use");
     constexpr int TV = K3XT_TV, PLANE = K3XT_HY * K3XT_HX, NIT = K3XT_NIT, PB = K3XT_PB, NWI = K3XT_NWI, NWF = K3XT_NWF, NU = TV * 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_red = (float*)(smem + K3X_LDS_RED);
@@ -439,20 +444,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     float* s_rstd = s_mean + p.N * 8;
     float* s_mkm = s_rstd + p.N * 8;
     float* s_mkr = s_mkm + p.N * 8;
+    float* s_fa = s_mkr + p.N * 8;                       // FA: rstd, -mean*rstd, m1, m2 of the input gradient's activation, [N*8] each
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int total_tiles = p.tiles_per_sample * p.N;
     const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * 8 * 4));
+    const i32x4 frsrc = make_rsrc(FA ? p.fa_x : p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * 8 * 4));
+    const i32x4 dxrsrc = make_rsrc(FA && p.fa_dx != nullptr ? p.fa_dx : p.y, (FA && p.fa_dx != nullptr) ? (unsigned int)((long long)p.N * p.D * p.H * p.W * 8 * 4) : 0u);
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
 
     const double* st_src = SUMS ? p.mask_stats : p.x_stats;
     const int st_n = (SUMS || HS) ? p.N * 8 : 0;
     double st_pre[2] = {0.0, 1.0};
     if (tid < st_n) stat_load(st_src, (size_t)tid, (size_t)st_n, st_pre);
+    double fa_pre[2][2] = {{0.0, 1.0}, {0.0, 0.0}};      // FA: wave 1 requests the activation's (sum, sumsq) and (sum g*mask, sum g*mask*xhat) pairs
+    if constexpr (FA) {
+        if (tid >= 64 && tid < 64 + p.N * 8) {
+            stat_load(p.x_stats, (size_t)(tid - 64), (size_t)p.N * 8, fa_pre[0]);
+            stat_load(p.fa_sums, (size_t)(tid - 64), (size_t)p.N * 8, fa_pre[1]);
+        }
+    }
 
     // fragment b = channels 4*part .. of halo voxel tv_b = (tid + 256 b) >> 1
     const int part = tid & 1;
     int rel_off[NIT], tzyx[NIT];
+    unsigned int cbits = 0;                              // FA: fragment b belongs to a centre (non-halo) voxel of the 4 x 2 x 32 tile
     const int lds_w0 = (tid >> 1) * 16 + part * 8;        // + b * 2048, + limb * PB
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
@@ -461,6 +477,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const int tx_ = tv % K3XT_HX, ty_ = (tv / K3XT_HX) % K3XT_HY, tz_ = tv / PLANE;
         rel_off[b] = (((tz_ * p.H + ty_) * p.W + tx_) * 8 + part * 4) * 4;
         tzyx[b] = u < NU ? (tz_ | (ty_ << 8) | (tx_ << 16)) : 0x00ffffff;
+        cbits |= (u < NU && tz_ >= 1 && tz_ <= 4 && ty_ >= 1 && ty_ <= 2 && tx_ >= 1 && tx_ <= 32) ? (1u << b) : 0u;
     }
     int w_off[NWI];
 #pragma unroll
@@ -468,7 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const int f = tid + i * 256;
         w_off[i] = f > NWF - 1 ? NWF - 1 : f;
     }
-    u32x4 xv[NIT], wv[NWI];
+    u32x4 xv[NIT], wv[NWI], fv[FA ? NIT : 1];
     unsigned int okbits = 0;
     struct Coord { int n, z0, y0, x0; };
     auto tile_coord = [&](int t) {
@@ -490,6 +507,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             okbits |= ok ? (1u << b) : 0u;
             xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, ok ? base + rel_off[b] : -1, 0, 0));
+            if constexpr (FA) fv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(frsrc, ok ? base + rel_off[b] : -1, 0, 0));
+        }
+    };
+    auto write_x_fa = [&](const Coord& c) {             // FA: apply pass in fp32 on the staged fragments, then the limb split [+ the applied gradient of the centre voxels]
+        float rr[4], ss[4], aa[4], bb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rr[j] = s_fa[0 * p.N * 8 + c.n * 8 + part * 4 + j];
+            ss[j] = s_fa[1 * p.N * 8 + c.n * 8 + part * 4 + j];
+            aa[j] = s_fa[2 * p.N * 8 + c.n * 8 + part * 4 + j];
+            bb[j] = s_fa[3 * p.N * 8 + c.n * 8 + part * 4 + j];
+        }
+        const int base = (((c.n * p.D + c.z0 - 1) * p.H + c.y0 - 1) * p.W + c.x0 - 1) * 8 * 4;
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) {
+            const bool ok = (okbits >> b) & 1u;           // out-of-volume halo voxels: the gradient is zero-padded
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gq = __uint_as_float(xv[b][j]);
+                const float xh = __uint_as_float(fv[b][j]) * rr[j] + ss[j];
+                const float gm = xh > 0.f ? gq : 0.f;
+                const float d = rr[j] * (gm - aa[j] - xh * bb[j]);
+                v[j] = ok ? d : 0.f;
+            }
+            unsigned int lm[3][2];
+            vs_limb_split4(v, lm);
+#pragma unroll
+            for (int l = 0; l < 3; ++l) *(u32x2*)(s_tile + l * PB + lds_w0 + b * 2048) = u32x2{lm[l][0], lm[l][1]};
+            if (p.fa_dx != nullptr)                        // workgroup-uniform
+                vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{v[0], v[1], v[2], v[3]}), dxrsrc, (ok && ((cbits >> b) & 1u)) ? base + rel_off[b] : -1, 0, 0);
         }
     };
     auto write_x = [&](int n) {
@@ -542,6 +590,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         if constexpr (SUMS) { s_mkm[tid] = m; s_mkr[tid] = r; }
         else { s_mean[tid] = m; s_rstd[tid] = r; }
     }
+    if constexpr (FA) {
+        if (tid >= 64 && tid < 64 + p.N * 8) {
+            const int i = tid - 64;
+            float m, r;
+            pair_to_mean_rstd(fa_pre[0], p.inv_count_in, p.eps, m, r);
+            s_fa[0 * p.N * 8 + i] = r;
+            s_fa[1 * p.N * 8 + i] = -m * r;
+            s_fa[2 * p.N * 8 + i] = (float)(fa_pre[1][0] * p.inv_count_in);
+            s_fa[3 * p.N * 8 + i] = (float)(fa_pre[1][1] * p.inv_count_in);
+        }
+    }
     // B fragment of (k-group (tz, ty), row cg, lane (col, g)): limb plane + ((wave + tz) * PLANE + (cg + ty) * HX + 2 col + g) * 16
     const int baddr = (wave * PLANE + 2 * col + g) * 16;
     const char* s_wl = s_w + lane * 16;
@@ -563,7 +622,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         for (int cg = 0; cg < 2; ++cg) { acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[cg] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         u32x4 mk[2];
         if (!first) __syncthreads();
-        write_x(n);
+        if constexpr (FA) write_x_fa(cur); else write_x(n);
         first = false;
         __syncthreads();
         if constexpr (EPI == EPI_RAW && SUMS) {
@@ -676,20 +735,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
 }
 
-template <int EPI, bool SUMS, bool HS>
+template <int EPI, bool SUMS, bool HS, bool FA = false>
 static int k3xt_launch_t(const G1Params& p_in, hipStream_t stream) {
     G1Params p = p_in;
     p.tyn = (p.H + 1) / 2; p.txn = (p.W + 31) / 32;
     p.tiles_per_sample = ((p.D + 3) / 4) * p.tyn * p.txn;
     const int tiles_total = p.tiles_per_sample * p.N;
-    const size_t lds = K3X_LDS_TILE + (size_t)3 * K3XT_PB + K3XT_WB + (size_t)4 * p.N * 8 * sizeof(float);
-    if (lds > 160 * 1024 || p.N * 8 > 256) return VS_ESHAPE;
+    const size_t lds = K3X_LDS_TILE + (size_t)3 * K3XT_PB + K3XT_WB + (size_t)(FA ? 8 : 4) * p.N * 8 * sizeof(float);
+    if (lds > 160 * 1024 || p.N * 8 > (FA ? 192 : 256)) return VS_ESHAPE;          // FA: waves 1 .. 3 build the fused-apply tables
+    if (FA && (!p.x_stats || !p.fa_x || !p.fa_sums)) return VS_EINVAL;
     if ((long long)p.N * p.D * p.H * p.W * 8 * 4 >= 2147483648ll) return VS_ESHAPE;
     k3x_fastdiv(p.tiles_per_sample, p.fd_m[0], p.fd_s[0]);
     k3x_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3x_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
-    if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr) || p.C != 8 || p.M != 8) return VS_EINVAL;
-    auto kern = k3xt_kernel<EPI, SUMS, HS>;
+    if (SUMS != (p.sums != nullptr) || (SUMS && !FA && p.x_stats != nullptr) || p.C != 8 || p.M != 8) return VS_EINVAL;
+    auto kern = k3xt_kernel<EPI, SUMS, HS, FA>;
     static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
     const int wg = 512;                                  // two workgroups per CU (73 KB of LDS each)
@@ -701,6 +761,10 @@ static int k3xt_launch_t(const G1Params& p_in, hipStream_t stream) {
 
 template <int EPI>
 static int k3xt_launch(const G1Params& p, hipStream_t stream) {
+    if (p.fa_x != nullptr) {                              // un-applied gradient in: never through a kernel that ignores fa_x
+        if constexpr (EPI == EPI_RAW) return p.sums != nullptr ? k3xt_launch_t<EPI, true, false, true>(p, stream) : k3xt_launch_t<EPI, false, false, true>(p, stream);
+        else return VS_EINVAL;
+    }
     if (p.sums != nullptr) {
         if constexpr (EPI == EPI_RAW) return k3xt_launch_t<EPI, true, false>(p, stream);
         else return VS_EINVAL;

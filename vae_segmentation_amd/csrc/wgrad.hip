@@ -725,6 +725,203 @@ __device__ __forceinline__ void g3x_body(const G3Params& p, const int bx, const 
 template <int CB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 ? 2 : 1))) void g3x_kernel(const G3Params p) { g3x_body<CB>(p, blockIdx.x, blockIdx.y); }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Big-tile 3x3x3 weight gradients (round 5): g3c_body.
+// The grouped launches move 2.15 x their algorithmic bytes (profiles/r04_hbm_traffic.txt) at ~4.6 TB/s: they are bound by that traffic, not by
+// the instruction stream (the operand exchange of multi_plan removed a third of their vector instructions for 0.5 % of the step).  The excess
+// is the halo: a 4x4x16 tile stages (6 x 6 x 18) / (4 x 4 x 16) = 2.53 x its voxels of the halo operand.  Here a tile is TZ x TY x 16 = 8 x 8 x 16
+// voxels — halo 10 x 10 x 18 = 1.76 x — for the layers whose tensors are big enough to matter (the full-resolution ones).  Operands:
+//   A ("P", rows of the MFMA)   the centre operand, no halo: 16 channels of a voxel, or (MP) 8 channels x {this voxel, the next one in x}: the
+//                               shifted rows are READ from the tile one voxel on (a 17-wide tile), not staged twice as g3b_body's M-packed form does
+//   B ("Q", column blocks)      the halo operand, CBH = 8 channels per voxel: blocks of two taps (14), or (MP) of (dz, dy) x {dx = 0, +1} (9)
+// Slab layout, statistics tables, tile walk (ks, ks + ksplit, ...) and the reduction are g3b_body's.
+template <int CBH, bool MP, int TZ, int TY> struct G3CGeo {
+    static constexpr int AC = MP ? 8 : 16, XW = MP ? 17 : 16, AU = AC / 8;
+    static constexpr int PV = TZ * TY * XW, NP = PV * AU, NITP = (NP + 255) / 256;
+    static constexpr int QZ = TZ + 2, QY = TY + 2, QX = 18, QV = QZ * QY * QX, QU = CBH / 8, NQ = QV * QU, NITQ = (NQ + 255) / 256;
+    static constexpr int NCB = MP ? (CBH == 16 ? 18 : 9) : (CBH == 16 ? 27 : 14);
+    static constexpr int P_BYTES = NITP * 4096, Q_BYTES = NITQ * 4096;             // padded: every thread stores every fragment it holds
+    static constexpr size_t LDS = G3B_LDS_P + P_BYTES + Q_BYTES;
+};
+
+template <typename T, int CBH, bool MP, int TZ, int TY>
+__device__ __forceinline__ void g3c_body(const G3Params& p, const int bx, const int ks) {
+    using GEO = G3CGeo<CBH, MP, TZ, TY>;
+    constexpr int AC = GEO::AC, XW = GEO::XW, AU = GEO::AU, NP = GEO::NP, NITP = GEO::NITP;
+    constexpr int QY = GEO::QY, QX = GEO::QX, QU = GEO::QU, NQ = GEO::NQ, NITQ = GEO::NITQ, NCB = GEO::NCB;
+    constexpr int AROW = AC * 2, QROW = CBH * 2;
+    static_assert(TZ % 4 == 0 && TY % 2 == 0, "a wave takes TZ / 4 z-slices of TY / 2 row pairs");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* s_psc = (float*)(smem + G3_LDS_STATS);
+    float* s_psh = s_psc + G3_MAXN * 16;
+    float* s_qsc = s_psh + G3_MAXN * 16;
+    float* s_qsh = s_qsc + G3_MAXN * 16;
+    char* s_p = smem + G3B_LDS_P;
+    char* s_q = s_p + GEO::P_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
+    const int q4 = col >> 2, p4 = col & 3;
+    const int mb = bx / p.cbn, cb = bx - mb * p.cbn;
+    const bool p_stats_in = p.P_stats != nullptr, q_stats_in = p.Q_stats != nullptr;
+    const i32x4 prsrc = make_rsrc(p.P, (unsigned int)((long long)p.N * p.Dp * p.Hp * p.Wp * p.Mch * 2));
+    const i32x4 qrsrc = make_rsrc(p.Q, (unsigned int)((long long)p.N * p.Dq * p.Hq * p.Wq * p.Cch * 2));
+
+    // ---- tile-independent fragment geometry (limit form, as g3b_body) ----
+    const int ppart = tid % AU, qpart = tid % QU;          // 256 % AU == 0, 256 % QU == 0: constant per thread
+    const bool pch_ok = (MP ? 0 : mb * 16) + ppart * 8 < p.Mch, qch_ok = cb * CBH + qpart * 8 < p.Cch;
+    // local coordinates packed (x | y << 8 | z << 16; z = 255 for a fragment that must read as zero): the kernel is bound by its traffic, not by the unpacking,
+    // and 16 fragments x 4 registers of geometry would not fit two waves per SIMD next to the accumulators
+    int prel[NITP], pco[NITP];
+#pragma unroll
+    for (int b = 0; b < NITP; ++b) {
+        const int u = tid + b * 256, v = u / AU;
+        const int lx = v % XW, ly = (v / XW) % TY, lz = v / (XW * TY);
+        prel[b] = (((lz * p.Hp + ly) * p.Wp + lx) * p.Mch + (MP ? 0 : mb * 16) + ppart * 8) * 2;
+        pco[b] = (u < NP && pch_ok) ? (lx | (ly << 8) | (lz << 16)) : 0x7fffffff;
+    }
+    int qrel[NITQ], qco[NITQ];
+#pragma unroll
+    for (int b = 0; b < NITQ; ++b) {
+        const int u = tid + b * 256, v = u / QU;
+        const int lx = v % QX, ly = (v / QX) % QY, lz = v / (QX * QY);
+        qrel[b] = (((lz * p.Hq + ly) * p.Wq + lx) * p.Cch + cb * CBH + qpart * 8) * 2;
+        qco[b] = (u < NQ && qch_ok) ? (lx | (ly << 8) | (lz << 16)) : 0x7fffffff;
+    }
+    u32x4 pv[NITP], qv[NITQ];
+    unsigned int okbits = 0;                              // bit b: P fragment b inside the volume; bit 8 + b: Q fragment b
+    auto coords = [&](int t, int& n, int& z0, int& y0, int& x0) {
+        n = fdiv(t, p.fd_m[0], p.fd_s & 0xff);
+        const int tl = t - n * p.tiles_per_sample;
+        const int tz = fdiv(tl, p.fd_m[1], (p.fd_s >> 8) & 0xff);
+        const int r = tl - tz * p.txn * p.tyn;
+        const int ty = fdiv(r, p.fd_m[2], (p.fd_s >> 16) & 0xff);
+        z0 = tz * TZ; y0 = ty * TY; x0 = (r - ty * p.txn) * 16;
+    };
+    auto request = [&](int t) {
+        int n, z0, y0, x0;
+        coords(t, n, z0, y0, x0);
+        okbits = 0;
+        const int pbase = (((n * p.Dp + z0) * p.Hp + y0) * p.Wp + x0) * p.Mch * 2;
+#pragma unroll
+        for (int b = 0; b < NITP; ++b) {
+            const bool ok = z0 + (pco[b] >> 16) < p.Dp && y0 + ((pco[b] >> 8) & 0xff) < p.Hp && x0 + (pco[b] & 0xff) < p.Wp;
+            okbits |= ok ? (1u << b) : 0u;
+            pv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(prsrc, ok ? pbase + prel[b] : -1, 0, 0));
+        }
+        const int qz0 = z0 - 1, qy0 = y0 - 1, qx0 = x0 - 1;
+        const int qbase = (((n * p.Dq + qz0) * p.Hq + qy0) * p.Wq + qx0) * p.Cch * 2;
+#pragma unroll
+        for (int b = 0; b < NITQ; ++b) {
+            const bool ok = (unsigned)(qz0 + (qco[b] >> 16)) < (unsigned)p.Dq && (unsigned)(qy0 + ((qco[b] >> 8) & 0xff)) < (unsigned)p.Hq &&
+                            (unsigned)(qx0 + (qco[b] & 0xff)) < (unsigned)p.Wq;
+            okbits |= ok ? (0x100u << b) : 0u;
+            qv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(qrsrc, ok ? qbase + qrel[b] : -1, 0, 0));
+        }
+    };
+    auto commit = [&](int n) {                             // registers -> (normalised) LDS tiles; fragment u lies at byte 16 u of its tile
+        f32x2 sc[4], sh[4];
+        if (p_stats_in) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sc[i] = *(const f32x2*)(s_psc + n * 16 + ppart * 8 + 2 * i);
+                sh[i] = *(const f32x2*)(s_psh + n * 16 + ppart * 8 + 2 * i);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NITP; ++b) {
+            u32x4 v = pv[b];
+            if (p_stats_in) {
+                const u32x4 a = act8<T>(v, sc, sh);
+                const bool ok = (okbits >> b) & 1u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
+            }
+            *(u32x4*)(s_p + (tid + b * 256) * 16) = v;
+        }
+        if (q_stats_in) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sc[i] = *(const f32x2*)(s_qsc + n * 16 + qpart * 8 + 2 * i);
+                sh[i] = *(const f32x2*)(s_qsh + n * 16 + qpart * 8 + 2 * i);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NITQ; ++b) {
+            u32x4 v = qv[b];
+            if (q_stats_in) {
+                const u32x4 a = act8<T>(v, sc, sh);
+                const bool ok = (okbits >> (8 + b)) & 1u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
+            }
+            *(u32x4*)(s_q + (tid + b * 256) * 16) = v;
+        }
+    };
+
+    int t = ks;
+    request(t);
+    for (int i = tid; i < p.N * 16; i += 256) {
+        const int n = i >> 4, c = i & 15;
+        float m = 0.f, r = 1.f;
+        const int pc = (MP ? 0 : mb * 16) + c;
+        if (p_stats_in && c < AC && pc < p.Mch) stats_to_mean_rstd_fast(p.P_stats, (size_t)n * p.Mch + pc, (size_t)p.N * p.Mch, p.inv_cnt_p, p.eps, m, r);
+        s_psc[i] = r; s_psh[i] = -m * r;
+        m = 0.f; r = 1.f;
+        const int qc = cb * CBH + c;
+        if (q_stats_in && c < CBH && qc < p.Cch) stats_to_mean_rstd_fast(p.Q_stats, (size_t)n * p.Cch + qc, (size_t)p.N * p.Cch, p.inv_cnt_q, p.eps, m, r);
+        s_qsc[i] = r; s_qsh[i] = -m * r;
+    }
+
+    // this lane's transposing-read offsets: A relative to (z-slice, row 2s [+1], x = 0), B per column block relative to the halo voxel of the same (z, y, x)
+    const int xr = 4 * g + q4;
+    const int pa_lane = MP ? ((xr + (p4 >> 1)) * AROW + (p4 & 1) * 8) : (xr * AROW + p4 * 8);
+    int qoff[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) {
+        int dz, dy, dx, choff;
+        if (MP) {
+            if (CBH == 16) { dz = (k >> 1) / 3; dy = (k >> 1) % 3; dx = 1 + (k & 1); choff = p4 * 8; }
+            else { dz = k / 3; dy = k % 3; dx = 1 + (p4 >> 1); choff = (p4 & 1) * 8; }
+        } else {
+            int tap = CBH == 16 ? k : 2 * k + (p4 >> 1);
+            if (tap >= 27) tap = 13;
+            dz = tap / 9; dy = (tap / 3) % 3; dx = tap % 3;
+            choff = CBH == 16 ? p4 * 8 : (p4 & 1) * 8;
+        }
+        qoff[k] = ((dz * QY + dy) * QX + dx + xr) * QROW + choff;
+    }
+
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int k = 0; k < NCB; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (; t < p.total_tiles; t += p.ksplit) {
+        __syncthreads();                                   // tables visible / every wave is done reading the previous tile
+        commit(fdiv(t, p.fd_m[0], p.fd_s & 0xff));
+        __syncthreads();
+        if (t + p.ksplit < p.total_tiles) request(t + p.ksplit);
+#pragma unroll
+        for (int zi = 0; zi < TZ / 4; ++zi) {
+            const int zs = wave * (TZ / 4) + zi;
+#pragma unroll
+            for (int s = 0; s < TY / 2; ++s) {
+                const int pa0 = ((zs * TY + 2 * s) * XW) * AROW + pa_lane;
+                const u32x4 a = tr_pair(s_p, pa0, pa0 + XW * AROW);
+                const int qb0 = ((zs * QY + 2 * s) * QX) * QROW;
+#pragma unroll
+                for (int k = 0; k < NCB; ++k) {
+                    const u32x4 b = tr_pair(s_q, qb0 + qoff[k], qb0 + QX * QROW + qoff[k]);
+                    acc[k] = mfma16(a, b, acc[k], (T*)nullptr);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const size_t slab_elems = (size_t)p.mbn * p.cbn * NCB * 256;
+    g3_finish<NCB>(acc, (float*)s_p, p.ws + (size_t)ks * slab_elems + ((size_t)bx * NCB) * 256, wave, col, g, NCB);
+}
+
 // Grouped launch: the weight gradients of up to G3_GROUP_MAX layers of one (CB, KIND) instantiation in ONE grid.  Weight
 // gradients are leaves of backward, so the host defers them to the end of the pass and issues them together: the small
 // layers (tens of workgroups each, start-up bound) then share the chip instead of queueing behind one another.
@@ -1156,7 +1353,9 @@ __global__ __launch_bounds__(256) void bias_partial_group_kernel(const G3BiasGro
 // other workgroups' tile loops.  Registers and LDS are those of the largest instantiation (all of the big ones sit at two workgroups per CU anyway).
 // The bias gradients' partial sums ride in the same grid as one more variant: their entries re-use G3Params (P = the gradient rows, ws = the partial sums,
 // total_tiles = rows, Mch / Cch = stored / real channels, ksplit = blocks), so the separate 22 us launch disappears into the grid's tail.
-enum { G3V_K3_16 = 0, G3V_K3_8, G3V_K2S2_16, G3V_K2S2_8, G3V_UP_16, G3V_K3_16_MP, G3V_K3_8_MP, G3V_BIAS, G3V_COUNT };
+enum { G3V_K3_16 = 0, G3V_K3_8, G3V_K2S2_16, G3V_K2S2_8, G3V_UP_16, G3V_K3_16_MP, G3V_K3_8_MP, G3V_BIAS, G3V_BIG_MP8, G3V_BIG_A16H8, G3V_COUNT };
+#define G3C_TZ 8
+#define G3C_TY 8
 template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void g3b_uber_kernel(const G3Group grp) {      // (left alone the union of the variants' registers is 284)
     const int b = blockIdx.x;
@@ -1192,6 +1391,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         case G3V_K2S2_8:   g3b_body<T, 8, G3_K2S2, false>(p, bx, ks); break;
         case G3V_UP_16:    g3b_body<T, 16, G3_UP, false>(p, bx, ks); break;
         case G3V_K3_16_MP: g3b_body<T, 16, G3_K3, true>(p, bx, ks); break;
+        case G3V_BIG_MP8:  g3c_body<T, 8, true, G3C_TZ, G3C_TY>(p, bx, ks); break;
+        case G3V_BIG_A16H8: g3c_body<T, 8, false, G3C_TZ, G3C_TY>(p, bx, ks); break;
         default:           g3b_body<T, 8, G3_K3, true>(p, bx, ks); break;
     }
 }
@@ -1201,6 +1402,7 @@ namespace {
 struct MultiLayer {
     G3Params p;
     int cbsz, ncb, kind, m_real, c_real;
+    int big;                 // 0, or the G3V_BIG_* variant this layer runs (g3c_body: 8 x 8 x 16 tiles)
     int swap;                // operands exchanged (see multi_plan): the slabs hold dW transposed and tap-mirrored, the reduction writes it back
     int primary;             // index of the first descriptor with the same dw (a weight used several times in one backward pass:
                              // all uses write slabs into one contiguous region and ONE reduction sums them); == own index otherwise
@@ -1234,11 +1436,28 @@ static int multi_validate(const vs_wgrad_desc& d) {
 // bf16 plan: every layer gets its own slab region; k-splits are chosen per (CB, KIND) bucket so that the bucket's ONE grid has
 // about `target` workgroups of about equal tile counts.
 static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPlan& plan, int target_wgs = 0, bool pack_m = false) {
-    static const long long target_default = getenv("VS_WGRAD_GROUP_WGS") ? atoll(getenv("VS_WGRAD_GROUP_WGS")) : 512;     // measured best of 384..2560 (two workgroups per CU are resident)
+    // workgroups per bucket.  With one grid PER bucket 512 measured best of 384..2560 (two workgroups per CU are resident); inside the all-buckets grid the
+    // buckets share the chip, every workgroup pays a prologue (statistics tables, first loads) and an epilogue (slab reduction through LDS, slab store, its
+    // share of the reduction launch), and fewer, longer workgroups win: same-box A/B at 96^3 (profiles/r05_ab_wgrad_group_wgs.json)
+    // 768 / 512 / 320 / 256 / 160 -> 2.514 / 2.501 / 2.497 / 2.480 / 2.493 ms per step
+    // ... and at 160^3 512 / 384 / 256 -> 6.373 / 6.380 / 6.396, at 128^3 (B = 1) 512 / 256 -> 3.737 / 3.729: the small target where the largest layer is small
+    static const long long target_env = getenv("VS_WGRAD_GROUP_WGS") ? atoll(getenv("VS_WGRAD_GROUP_WGS")) : 0;
+    long long max_voxels = 0;
+    for (int i = 0; i < count; ++i) max_voxels = std::max(max_voxels, (long long)descs[i].n * descs[i].dp * descs[i].hp * descs[i].wp);
+    const long long target_default = target_env > 0 ? target_env : (max_voxels <= 2500000 ? 256 : 512);
     const long long target = target_wgs > 0 ? target_wgs : target_default;
     plan.layers.resize(count);
-    long long bucket_work[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // (cbsz 16 | 8) x (K3, K2S2, UP, K3 M-packed): one grouped launch each
-    auto bucket_of = [](const MultiLayer& L) { return (L.cbsz == 16 ? 0 : 1) + 2 * (L.p.mp ? 3 : (L.kind == VS_CONV_K3 ? 0 : (L.kind == VS_CONV_K2S2 ? 1 : 2))); };
+    long long bucket_work[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // (cbsz 16 | 8) x (K3, K2S2, UP, K3 M-packed): one grouped launch each; 8, 9: the big-tile variants
+    auto bucket_of = [](const MultiLayer& L) {
+        if (L.big) return L.big == G3V_BIG_MP8 ? 8 : 9;
+        return (L.cbsz == 16 ? 0 : 1) + 2 * (L.p.mp ? 3 : (L.kind == VS_CONV_K3 ? 0 : (L.kind == VS_CONV_K2S2 ? 1 : 2)));
+    };
+    // big tiles (g3c_body) for the 3x3x3 layers whose halo operand has 8 stored channels and whose tensors are large enough for the halo traffic to matter;
+    // only inside the all-buckets grid (the per-bucket launches of VS_WGRAD_UBER=0 keep the 4x4x16 kernels).  VS_WGRAD_BIG=0 switches it off.
+    const char* big_str = getenv("VS_WGRAD_BIG");
+    const char* uber_s = getenv("VS_WGRAD_UBER");
+    const bool big_on = pack_m && (big_str ? atoi(big_str) != 0 : true) && (uber_s ? atoi(uber_s) != 0 : true);
+    const long long big_min_voxels = getenv("VS_WGRAD_BIG_MIN_VOXELS") ? atoll(getenv("VS_WGRAD_BIG_MIN_VOXELS")) : 400000;      // per plan: the tests lower it
     // Operand exchange (round 5).  A 3x3x3 layer's gradient dW[m][c][o] = sum_v P(v)[m] Q(v + o)[c] stages Q with a halo (2.5 x the tile) and P without;
     // when Q is a LAZY activation (statistics given) every halo fragment is normalised + ReLU'd + masked on its way to LDS — 24-28 vector instructions per
     // 16-byte fragment in a kernel that is bound by instruction issue (profiles/r04_wgrad_counters_raw.txt).  The same sums with the roles exchanged,
@@ -1253,8 +1472,8 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         if (rc) return rc;
         vs_wgrad_desc& d = eff[i];
         MultiLayer& L = plan.layers[i];
-        L.swap = 0;
-        if (swap_on && d.kind == VS_CONV_K3 && d.q_stats != nullptr && d.p_stats == nullptr && d.m_ch <= d.c_ch) {
+        L.swap = (d.kind == VS_CONV_K3 && d.reserved_ == -1) ? 1 : 0;        // exchanged by the caller already (fp32 path: f32_effective)
+        if (!L.swap && swap_on && d.kind == VS_CONV_K3 && d.q_stats != nullptr && d.p_stats == nullptr && d.m_ch <= d.c_ch) {
             std::swap(d.p, d.q); std::swap(d.p_stats, d.q_stats); std::swap(d.m_ch, d.c_ch); std::swap(d.m_real, d.c_real);
             L.swap = 1;
         }
@@ -1279,6 +1498,17 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         const char* mp_str = getenv("VS_WGRAD_MPACK");          // read per plan (not cached): the tests switch it between calls
         const bool mp_on = mp_str ? atoi(mp_str) != 0 : true;
         if (pack_m && mp_on && d.kind == VS_CONV_K3 && d.m_ch == 8 && (L.cbsz == 16 || d.c_ch == 8)) { p.mp = 1; L.ncb = L.cbsz == 16 ? 18 : 9; }
+        L.big = 0;
+        if (big_on && d.kind == VS_CONV_K3 && d.c_ch == 8 && (long long)d.n * d.dp * d.hp * d.wp >= big_min_voxels) {
+            if (p.mp) L.big = G3V_BIG_MP8;
+            else if (d.m_ch % 16 == 0) L.big = G3V_BIG_A16H8;
+            if (L.big) {                                   // re-tile: G3C_TZ x G3C_TY x 16
+                p.tyn = (d.hp + G3C_TY - 1) / G3C_TY;
+                p.tiles_per_sample = ((d.dp + G3C_TZ - 1) / G3C_TZ) * p.tyn * p.txn;
+                p.total_tiles = p.tiles_per_sample * d.n;
+                g3_fastdiv(p);
+            }
+        }
         p.eps = eps;
         p.inv_cnt_p = 1.0 / ((double)d.dp * d.hp * d.wp);
         p.inv_cnt_q = 1.0 / ((double)p.Dq * p.Hq * p.Wq);
@@ -1293,7 +1523,8 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         for (int j = 0; j < i; ++j) {
             if (descs[j].dw == descs[i].dw && L.primary == i) {
                 const MultiLayer& F = plan.layers[j];
-                if (F.cbsz != L.cbsz || F.kind != L.kind || F.p.mbn != L.p.mbn || F.p.cbn != L.p.cbn || F.m_real != L.m_real || F.c_real != L.c_real || F.p.mp != L.p.mp || F.swap != L.swap)
+                if (F.cbsz != L.cbsz || F.kind != L.kind || F.p.mbn != L.p.mbn || F.p.cbn != L.p.cbn || F.m_real != L.m_real || F.c_real != L.c_real || F.p.mp != L.p.mp || F.swap != L.swap
+                    || (F.big != 0) != (L.big != 0))
                     return VS_EINVAL;                     // same destination, different layer geometry
                 L.primary = F.primary;
             }
@@ -1365,7 +1596,8 @@ static int g3b_group_run(const G3Group& grp, hipStream_t s) {
 }
 
 
-static int g3v_of(int cbsz, int kind, bool mp) {
+static int g3v_of(int cbsz, int kind, bool mp, int big = 0) {
+    if (big) return big;
     if (kind == VS_CONV_UP) return G3V_UP_16;
     if (kind == VS_CONV_K2S2) return cbsz == 16 ? G3V_K2S2_16 : G3V_K2S2_8;
     if (mp) return cbsz == 16 ? G3V_K3_16_MP : G3V_K3_8_MP;
@@ -1377,6 +1609,8 @@ static size_t g3v_lds(int variant) {
         case G3V_K3_8: case G3V_K3_8_MP:   return G3B_LDS_Q + (size_t)G3Geo<8, G3_K3>::QV * 8 * 2;
         case G3V_K2S2_16:                  return G3B_LDS_Q + (size_t)G3Geo<16, G3_K2S2>::QV * 16 * 2;
         case G3V_K2S2_8:                   return G3B_LDS_Q + (size_t)G3Geo<8, G3_K2S2>::QV * 8 * 2;
+        case G3V_BIG_MP8:                  return G3CGeo<8, true, G3C_TZ, G3C_TY>::LDS;
+        case G3V_BIG_A16H8:                return G3CGeo<8, false, G3C_TZ, G3C_TY>::LDS;
         default:                           return G3B_LDS_Q + (size_t)G3Geo<16, G3_UP>::QV * 16 * 2;
     }
 }
@@ -1384,7 +1618,7 @@ static size_t g3v_lds(int variant) {
 static double g3v_tile_cost(int variant) {
     switch (variant) {
         case G3V_K3_16: return 2.0; case G3V_K3_16_MP: return 1.5; case G3V_K3_8: return 1.0; case G3V_K3_8_MP: return 0.9;
-        case G3V_K2S2_16: return 1.6; case G3V_K2S2_8: return 0.8; default: return 2.0;
+        case G3V_K2S2_16: return 1.6; case G3V_K2S2_8: return 0.8; case G3V_BIG_MP8: return 3.2; case G3V_BIG_A16H8: return 4.5; default: return 2.0;
     }
 }
 template <typename T>
@@ -1407,6 +1641,22 @@ static bool f32_limbs_on() {
 // the fp32 mode's grouped launches: 3x3x3 layers on the limb kernels, stride-2 layers on the exact-f32 MFMA body; 16- and 8-channel blocks each
 struct F32Grp { int kind, cb; };
 static const F32Grp F32_GROUPS[4] = {{VS_CONV_K3, 16}, {VS_CONV_K3, 8}, {VS_CONV_K2S2, 16}, {VS_CONV_K2S2, 8}};
+// fp32 parity mode: the operand exchange of multi_plan applied BEFORE the layers are sorted into channel-block groups (the exchange changes which operand's
+// width picks the group): a 16 -> 8 layer at full resolution becomes 16 full MFMA rows against 14 two-tap blocks of the 8-channel gradient instead of 8 of 16
+// rows against 27 blocks — 84 instead of 162 limb MFMAs per 32 voxels — and the halo operand is the stored gradient (no normalise before the limb split).
+// Marked with reserved_ = -1 (a field only VS_CONV_UP descriptors use).  VS_WGRAD_SWAP=0 switches it off.
+static std::vector<vs_wgrad_desc> f32_effective(const vs_wgrad_desc* descs, int count) {
+    std::vector<vs_wgrad_desc> eff(descs, descs + count);
+    const char* swap_str = getenv("VS_WGRAD_SWAP");
+    if ((swap_str && atoi(swap_str) == 0) || !f32_limbs_on()) return eff;      // only the grouped limb launches write the exchanged form back (G3RedDesc.swap)
+    for (vs_wgrad_desc& d : eff) {
+        if (d.kind == VS_CONV_K3 && d.q_stats != nullptr && d.p_stats == nullptr && d.m_ch <= d.c_ch && d.p && d.q) {
+            std::swap(d.p, d.q); std::swap(d.p_stats, d.q_stats); std::swap(d.m_ch, d.c_ch); std::swap(d.m_real, d.c_real);
+            d.reserved_ = -1;
+        }
+    }
+    return eff;
+}
 static bool f32_grouped_kind(int kind) { return kind == VS_CONV_K2S2 || (kind == VS_CONV_K3 && f32_limbs_on()); }
 static std::vector<vs_wgrad_desc> f32_limb_subset(const vs_wgrad_desc* descs, int count, int cb, int kind = VS_CONV_K3) {
     std::vector<vs_wgrad_desc> out;
@@ -1497,7 +1747,7 @@ static int f32_limb_group_launch(const std::vector<vs_wgrad_desc>& sub, int cb, 
         const long long slab_elems = (long long)L.p.mbn * L.p.cbn * L.ncb * 256;
         int parts = 1;
         while (parts < G3_RED_ROWS && parts * 8 < L.total_slabs) parts *= 2;
-        red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.total_slabs, L.cbsz, kind == VS_CONV_K2S2 ? 8 : 27, L.ncb, 0, parts});
+        red.push_back(G3RedDesc{(const float*)(ws + L.ws_off), L.dw, L.m_real, L.c_real, L.p.mbn, L.p.cbn, L.total_slabs, L.cbsz, kind == VS_CONV_K2S2 ? 8 : 27, L.ncb, 0, parts, L.swap});
         blocks.push_back(vs_ceil_div(slab_elems, 256 * (G3_RED_ROWS / parts)));
     }
     for (size_t at = 0; at < red.size(); at += G3_RED_MAX) {
@@ -1551,7 +1801,10 @@ static size_t f32_bias_bytes(const vs_wgrad_desc* descs, int count, int target_w
 
 static size_t wgrad_multi_workspace_bytes_impl(const vs_wgrad_desc* descs, int count, int dtype, int target_workgroups) {
     if (!descs || count <= 0 || target_workgroups < 0) return 0;
+    std::vector<vs_wgrad_desc> eff32;
     if (dtype == VS_F32) {                        // serial per-layer launches share one region; the uses of one weight need theirs side by side
+        eff32 = f32_effective(descs, count);
+        descs = eff32.data();
         // the 3x3x3 layers of the limb path come first: two grouped regions (16- / 8-channel blocks); the serial region of the other layers follows
         size_t limb_bytes = 0;
         for (const F32Grp& gk : F32_GROUPS) limb_bytes += f32_limb_group_bytes(f32_limb_subset(descs, count, gk.cb, gk.kind), gk.cb, gk.kind);
@@ -1580,11 +1833,14 @@ static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspa
     if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
     const bool f16 = dtype == VS_F16;
     hipStream_t st = (hipStream_t)stream;
+    std::vector<vs_wgrad_desc> eff32;
     if (dtype == VS_F32) {
         for (int i = 0; i < count; ++i) {
             int rc = multi_validate(descs[i]);
             if (rc) return rc;
         }
+        eff32 = f32_effective(descs, count);
+        descs = eff32.data();
         // the 3x3x3 layers: grouped limb launches on the bf16 matrix cores (g3x_group_kernel) — with per-layer launches the 16 small layers of a
         // step cost 30-47 us each (one tile per workgroup under fixed prologue / slab costs); the stride-2 kinds: per-layer exact-f32 kernels
         {
@@ -1693,7 +1949,7 @@ static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspa
     if (uber) {
         std::vector<int> idx(count);
         for (int i = 0; i < count; ++i) idx[i] = i;
-        auto key = [&](int a) { const MultiLayer& L = plan.layers[a]; return (double)L.work * g3v_tile_cost(g3v_of(L.cbsz, L.kind, L.p.mp != 0)); };
+        auto key = [&](int a) { const MultiLayer& L = plan.layers[a]; return (double)L.work * g3v_tile_cost(g3v_of(L.cbsz, L.kind, L.p.mp != 0, L.big)); };
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key(a) > key(b); });
         for (int i = 0; i < count; ++i)                      // the bias gradients' partial sums: entries -(i + 1), behind the weight layers (short workgroups)
             if (descs[i].bias_g && descs[i].bias_rows < 2147483647ll) idx.push_back(-(i + 1));
@@ -1722,7 +1978,7 @@ static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspa
                 if (L.kind == VS_CONV_UP && L.cbsz != 16) return VS_ESHAPE;
                 grp.p[j] = L.p;
                 grp.p[j].ws = (float*)(ws + L.ws_off);
-                grp.p[j].variant = g3v_of(L.cbsz, L.kind, L.p.mp != 0);
+                grp.p[j].variant = g3v_of(L.cbsz, L.kind, L.p.mp != 0, L.big);
                 lds = std::max(lds, g3v_lds(grp.p[j].variant));
                 grp.wg_start[j] = (int)wg;
                 wg += (long long)L.p.mbn * L.p.cbn * L.p.ksplit;

@@ -504,6 +504,8 @@ FUSE_APPLY = os.environ.get("VS_FUSE_APPLY", "1") != "0"
 # form (k3b<32,...,FA>, the 24^3 / 12^3 levels) measured slower twice (round 4: 2.519 -> 2.566 ms per step, profiles/r04_ab_fused_apply_32ch.json)
 # and left the library in round 5.  The library has the last word (vs_conv_k3_fused_apply_supported).
 _FA_CHANNELS = (8, 16)
+_FA_CHANNELS_F32 = (8,)
+FUSE_APPLY_F32 = os.environ.get("VS_FUSE_APPLY_F32", "1") != "0"      # A/B switch of the parity mode's fused apply
 _LAZY_APPLY = {"grads": {}, "callback": False}
 
 
@@ -511,7 +513,9 @@ def mark_defer_apply(x, producer):
     """x: the raw output of `producer` (an nn.Conv3d holder run by ConvK3, 3x3x3) about to be consumed, exactly once, by a conv op that honours
     the mark (ConvK3, ConvK3Softmax[CL], ConvK2S2, ConvT2S2).  Marked when the producer's backward-data launch has a fused-apply kernel
     (vs_conv_k3_fused_apply_supported: the single-chunk layers of the full- and half-resolution levels)."""
-    if FUSE_APPLY and x.dtype != torch.float32 and x.shape[-1] in _FA_CHANNELS and tuple(producer.weight.shape[2:]) == (3, 3, 3):
+    # fp32 parity mode: the 8-channel full-resolution layers only (k3xt_kernel<..., FA>, csrc/igemm_k3x.h; round 5)
+    chans = _FA_CHANNELS if x.dtype != torch.float32 else (_FA_CHANNELS_F32 if FUSE_APPLY_F32 else ())
+    if FUSE_APPLY and x.shape[-1] in chans and tuple(producer.weight.shape[2:]) == (3, 3, 3):
         x._vs_defer_apply = True
     return x
 
