@@ -350,6 +350,30 @@ __device__ __forceinline__ void vs_limb_split4(const float (&v)[4], unsigned int
     }
 }
 
+// In-register limb arithmetic of the direct-from-global fp32 kernels (g1_kernel<float, ..., LIMB>; round 5 — in k3s_kernel<float>, where a B fragment is used
+// once per wave and nothing amortises its split, the same arithmetic measured SLOWER: 6.205 -> 6.287 ms, profiles/r05_ab_fp32_k3s_limbs.json): the fp32 fragments of TWO
+// consecutive k-groups (4 k-values per lane each — for A and B alike: any lane -> k assignment is valid as long as both operands share it) become three
+// bf16 limb fragments of 8 k-values per lane, and one (A pair, B pair) product is six v_mfma_f32_16x16x32_bf16 (96 matrix cycles) instead of eight
+// v_mfma_f32_16x16x4_f32 (256).  `small` takes the five products below the leading one (its own accumulator where the caller has the registers).
+__device__ __forceinline__ void vs_limb_pair(const u32x4& f0, const u32x4& f1, u32x4 (&out)[3]) {
+    float v0[4], v1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v0[j] = __uint_as_float(f0[j]); v1[j] = __uint_as_float(f1[j]); }
+    unsigned int l0[3][2], l1[3][2];
+    vs_limb_split4(v0, l0);
+    vs_limb_split4(v1, l1);
+#pragma unroll
+    for (int l = 0; l < 3; ++l) out[l] = u32x4{l0[l][0], l0[l][1], l1[l][0], l1[l][1]};
+}
+__device__ __forceinline__ void vs_limb_mfma(const u32x4 (&al)[3], const u32x4 (&bl)[3], f32x4& lead, f32x4& small) {
+    small = mfma16(al[0], bl[2], small, (unsigned short*)nullptr);
+    small = mfma16(al[1], bl[1], small, (unsigned short*)nullptr);
+    small = mfma16(al[2], bl[0], small, (unsigned short*)nullptr);
+    small = mfma16(al[0], bl[1], small, (unsigned short*)nullptr);
+    small = mfma16(al[1], bl[0], small, (unsigned short*)nullptr);
+    lead = mfma16(al[0], bl[0], lead, (unsigned short*)nullptr);
+}
+
 // (bf16, 3x3x3, 8 stored k-side channels, <= 8 rows) weights — the 8-channel full-resolution layers — are packed in the Toeplitz
 // fragment order of k3t_kernel (igemm_k3t.h): [k-group (tz,ty)][lane][8], row (lane & 15) = (dx2, co), k = (xpos = lane >> 4, ci),
 // value W[co][ci][tz][ty][xpos - dx2] or 0.  pack.hip (image) and igemm_k3_bf16.hip (dispatch) both key on this predicate.

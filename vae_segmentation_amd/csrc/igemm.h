@@ -164,25 +164,10 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
             acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (TWO_ACC) acl[TWO_ACC ? rb : 0][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    // LIMB: fragments of two consecutive k-groups -> three bf16 limb fragments (8 k-values per lane each)
-    auto split_pair = [&](const u32x4& f0, const u32x4& f1, u32x4 (&out)[3]) {
-        float v0[4], v1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v0[j] = __uint_as_float(f0[j]); v1[j] = __uint_as_float(f1[j]); }
-        unsigned int l0[3][2], l1[3][2];
-        vs_limb_split4(v0, l0);
-        vs_limb_split4(v1, l1);
-#pragma unroll
-        for (int l = 0; l < 3; ++l) out[l] = u32x4{l0[l][0], l0[l][1], l1[l][0], l1[l][1]};
-    };
+    // LIMB: fragments of two consecutive k-groups -> three bf16 limb fragments, six MFMAs (common.h vs_limb_pair / vs_limb_mfma)
+    auto split_pair = [&](const u32x4& f0, const u32x4& f1, u32x4 (&out)[3]) { vs_limb_pair(f0, f1, out); };
     auto mfma_limbs = [&](const u32x4 (&al)[3], const u32x4 (&bl)[3], int rb, int cg) {
-        f32x4& small = TWO_ACC ? acl[TWO_ACC ? rb : 0][cg] : acc[rb][cg];
-        small = mfma16(al[0], bl[2], small, (unsigned short*)nullptr);
-        small = mfma16(al[1], bl[1], small, (unsigned short*)nullptr);
-        small = mfma16(al[2], bl[0], small, (unsigned short*)nullptr);
-        small = mfma16(al[0], bl[1], small, (unsigned short*)nullptr);
-        small = mfma16(al[1], bl[0], small, (unsigned short*)nullptr);
-        acc[rb][cg] = mfma16(al[0], bl[0], acc[rb][cg], (unsigned short*)nullptr);
+        vs_limb_mfma(al, bl, acc[rb][cg], TWO_ACC ? acl[TWO_ACC ? rb : 0][cg] : acc[rb][cg]);
     };
     const u32x4 zfrag = u32x4{0u, 0u, 0u, 0u};
 

@@ -34,13 +34,8 @@ struct K3TGeom {
 // activation's statistics (p.x_stats) and IN-backward sums (p.fa_sums) — and the apply pass rstd * (g*[xhat>0] - m1 - xhat * m2) runs while the
 // halo tile is staged (the standalone vs_instnorm_relu_bwd_apply launch, 3 tensor passes at 96^3, disappears); centre voxels are also
 // written to p.fa_dx when given (the weight gradient of this layer reads the applied gradient).
-// waves per SIMD of the variants without the fused apply (183 - 188 VGPRs as written: two; the counters — profiles/r05_k3t_counters.txt — show a wave waiting
-// 62 % of its cycles on one tile's serial chain, so a third resident wave is worth more than the registers): -DVS_K3T_W=3 builds them for three
-#ifndef VS_K3T_W
-#define VS_K3T_W 2
-#endif
 template <int EPI, bool SUMS, int YT, bool HS, typename T = unsigned short, bool FA = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FA || SUMS) ? 2 : VS_K3T_W, (FA || SUMS) ? 2 : VS_K3T_W))) void k3t_kernel(const G1Params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k3t_kernel(const G1Params p) {
     K3_TICK_INIT
     using GEO = K3TGeom<YT>;
     constexpr int PX = GEO::PX, PY = GEO::PY, PLANE = GEO::PLANE, TV = GEO::TV, NIT = GEO::NIT;
@@ -393,7 +388,7 @@ static int k3t_launch_t(const G1Params& p_in, hipStream_t stream) {
     // persistent grid: two workgroups per CU are resident (185-218 VGPRs).  Measured at 96^3, B = 2 (57 MB algorithmic, 62 MB of HBM
     // traffic by the PMC counters): 21-24 us per launch whichever of 2 / 3 workgroups per CU, 4x4x32 or 4x8x32 tiles, or MFMA loop order
     // is used — ~5 us of that is the launch itself, the rest moves ~4 TB/s (the pure streaming kernels of this library reach 4.7).
-    static const int per_cu = getenv("VS_K3T_WGS_PER_CU") ? atoi(getenv("VS_K3T_WGS_PER_CU")) : ((FA || SUMS) ? 2 : VS_K3T_W);      // the backward-data variants (fused IN-backward sums: 70 registers over the three-wave budget) stay at two
+    static const int per_cu = getenv("VS_K3T_WGS_PER_CU") ? atoi(getenv("VS_K3T_WGS_PER_CU")) : 2;
     const int cap = 256 * per_cu;
     const int gx = tiles < cap ? (int)tiles : cap;
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, stream, p);

@@ -94,6 +94,8 @@ def collective_capturable(group=None):
         except Exception:                                # noqa: BLE001
             ok = False
         ok = _agree(ok, group)
+    if dist.get_backend(group) == "nccl" and torch.cuda.is_available():
+        _let_watchdog_reap()
     _CAPTURABLE[key] = ok
     return ok
 
@@ -113,8 +115,18 @@ def average_supported(group=None):
             except (RuntimeError, ValueError):           # a build without ncclAvg: sum, then scale
                 ok = False
             ok = _agree(ok, group)
+            _let_watchdog_reap()
         _AVG_OK[key] = ok
     return _AVG_OK[key]
+
+
+def _let_watchdog_reap():
+    """torch's RCCL process group checks the completion of every eager collective from a watchdog thread (an event query every 100 ms).  A stream capture
+    that starts before the watchdog has seen the last eager collective complete makes that query an "operation not permitted when stream is capturing"
+    and takes the process down — seen when this module's probes ran right in front of GraphedStep's capture.  The probes run once per group: they wait."""
+    import time
+    torch.cuda.synchronize()
+    time.sleep(0.3)
 
 
 class FlatGradSync:

@@ -268,6 +268,8 @@ class GraphedStep:
                         or (dist.get_backend(grad_sync.group) == "nccl" and _ddp.collective_capturable(grad_sync.group)))
         self.tail = (bool(capture_tail) and warmup >= 1 and not two_phase and isinstance(optimizer, _optim.SGD)
                      and rccl_or_none and all(p.is_cuda for p in self.params))
+        if grad_sync is not None and getattr(grad_sync, "exchange", True) and dist.is_initialized():
+            grad_sync.resolve_avg()              # one eager probe collective per group, HERE — well before the capture (ddp._let_watchdog_reap says why)
         self._own_sync = False
         if self.tail and grad_sync is None:
             # one rank, no exchange: the flat buffer still serves — it gives every gradient a FIXED address, which the captured optimiser launch needs
