@@ -27,3 +27,7 @@ echo "mfma done"
 # 5. the other BASELINE configurations
 python3 $ROOT/tools/run_configs.py all $OUT/other_configs.jsonl > $OUT/other_configs.txt 2> $OUT/other_configs.err
 head -3 $OUT/step_kernels.txt; head -1 $OUT/hbm_traffic.txt; tail -c 300 $OUT/bench.json
+# 6. the fp32 parity mode's per-kernel summary
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats32 -o bench -- python3 $ROOT/bench.py --dtype fp32 --steps 12 --warmup 2 $Q > /dev/null 2> $OUT/stats32.err
+cp $(find $OUT/stats32 -name "*kernel_stats.csv" | head -1) $OUT/fp32_mode_kernel_stats.csv
+echo "fp32 stats done"

@@ -391,11 +391,10 @@ static __host__ __device__ inline bool vs_k3_toeplitz_f32(int rows, int c_pad, i
 // (env, read once; default below).  8: a stage's three limb planes + weight block take 64 KB of LDS — two workgroups per CU, whose staging and MFMA
 // phases overlap; 16: half as many stages per tile, 115 KB — one workgroup per CU.
 static inline int vs_k3x_ck(int c_pad) {
-    // measured on the fp32 96^3 step: 7.34 ms (8 everywhere) vs 7.55 ms (16 everywhere); round 5: 6.299 vs 6.384.  VS_K3X_CK=0 ("auto"): 16 for the layers with
-    // >= VS_K3X_CK16_FROM (default: off) stored channels — the 12^3 levels and below, a few dozen workgroups each, where halving the stages per tile is all that counts
+    // measured on the fp32 96^3 step: 7.34 ms (8) vs 7.55 ms (16); round 5: 6.299 vs 6.384, and 16 only for the layers with >= 64 / 128 channels: 6.213 / 6.207 vs 6.213
+    // (profiles/r05_ab_fp32_ck16_from.json: nothing)
     static const int ck = getenv("VS_K3X_CK") ? atoi(getenv("VS_K3X_CK")) : 8;
-    static const int from = getenv("VS_K3X_CK16_FROM") ? atoi(getenv("VS_K3X_CK16_FROM")) : 1 << 30;
-    const int w = ck == 16 ? 16 : (c_pad >= from ? 16 : 8);
+    const int w = ck == 8 ? 8 : 16;
     return c_pad < w ? c_pad : w;
 }
 
