@@ -502,7 +502,8 @@ def _pending_done():
 FUSE_APPLY = os.environ.get("VS_FUSE_APPLY", "1") != "0"
 # channels of the activations whose producer has a fused-apply kernel: 8 / 16 (k3t, single-chunk k3b: the 96^3 / 48^3 levels).  The 32-channel
 # form (k3b<32,...,FA>, the 24^3 / 12^3 levels) measured slower twice (round 4: 2.519 -> 2.566 ms per step, profiles/r04_ab_fused_apply_32ch.json)
-# and left the library in round 5.  The library has the last word (vs_conv_k3_fused_apply_supported).
+# and left the library in round 5; so did 16-channel half stages of the same layers (two waves per SIMD, 19 launches fewer, +30..+43 us per step:
+# profiles/r05_ab_fused_apply_half_stages.json).  The library has the last word (vs_conv_k3_fused_apply_supported).
 _FA_CHANNELS = (8, 16)
 _FA_CHANNELS_F32 = (8,)
 FUSE_APPLY_F32 = os.environ.get("VS_FUSE_APPLY_F32", "1") != "0"      # A/B switch of the parity mode's fused apply
