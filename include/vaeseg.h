@@ -42,6 +42,8 @@ enum {
     VS_CONV_K3 = 0,     /* 3x3x3, stride 1, pad 1          nn.Conv3d(...,3,padding=1)        joint_model.py:40,43,46,106,224,366 */
     VS_CONV_K2S2 = 1,   /* 2x2x2, stride 2, pad 0          nn.Conv3d(C,C,2,stride=2)         joint_model.py:130 */
     VS_CONV_T2S2 = 2,   /* 2x2x2 transposed, stride 2      nn.ConvTranspose3d(C,C,2,stride=2) joint_model.py:118 */
+    VS_WGRAD_SLABS = 16, /* vs_wgrad_desc only: p = the slabs vs_conv_k3_bwd_data_wgrad wrote, n = their count (vs_conv_k3_bwd_data_wgrad_slabs); m_ch = c_ch = 8,
+                            m_real / c_real / dw as for the layer; the descriptor only takes part in the grouped reduction and must be the only one for its dw */
     VS_CONV_UP = 3      /* vs_wgrad_desc only: the composed Up block (vs_up_*): p = the FINE output gradient (n,2dp,2hp,2wp,Co) read space-to-depth
                            (m_ch = m_real = 8 Co view channels (parity, co); reserved_ = Co), q = the coarse input, dw = dWeff [8 Co][c_real][27] */
 };
@@ -145,6 +147,18 @@ int vs_conv_scatter_bwd_data(const void* x, const void* w_packed, void* y, const
  * 16-bit storage; kernels exist for the single-chunk layers of the full- and half-resolution levels (c_in 8 or 16: igemm_k3t.h, igemm_k3b.h FA);
  * any other shape returns VS_ESHAPE — ask vs_conv_k3_fused_apply_supported first (1 / 0; lazy_input: the conv's own input is a lazy activation). */
 int vs_conv_k3_fused_apply_supported(int n, int d, int h, int w, int c_in, int m_out, int lazy_input, int dtype);
+/* Backward-data of a 3x3x3 conv whose own input is a lazy activation (vs_conv_gather_bwd_data, K3) WITH THE LAYER'S WEIGHT GRADIENT in the same launch
+ * (autograd of joint_model.py:40-48 at full resolution; csrc/igemm_k3tw.h): the launch already holds both operands of dW — the applied output gradient as
+ * its halo tile, relu(instnorm(mask_x)) under every output voxel for the fused sums — so neither is read again by the grouped weight-gradient launch.
+ * act_x / act_stats / act_sums: all three (g arrives un-applied, as for vs_conv_k3_bwd_data_fused_apply; the applied gradient is then never stored) or all NULL.
+ * slabs: vs_conv_k3_bwd_data_wgrad_slabs(n, d, h, w) partial sums float[27][8][8] each, S[o][c][m] = sum_v Q(v)[c] g_applied(v + o)[m] = dW[m][c][-o];
+ * hand them to vs_conv_wgrad_multi as a VS_WGRAD_SLABS descriptor (fixed summation order: bitwise reproducible).
+ * 16-bit storage, c_in = m_out = 8 stored channels (the 96^3 / 128^3 / 160^3 levels); vs_conv_k3_bwd_data_wgrad_supported says 1 / 0 (VS_FUSE_WGRAD=0: always 0). */
+int vs_conv_k3_bwd_data_wgrad_supported(int n, int d, int h, int w, int c_in, int m_out, int dtype);
+int vs_conv_k3_bwd_data_wgrad_slabs(int n, int d, int h, int w);
+int vs_conv_k3_bwd_data_wgrad(const void* g, const void* act_x, const double* act_stats, const double* act_sums, const void* w_packed, void* y,
+                              const void* mask_x, const double* mask_stats, double* sums, float* slabs, int n, int d, int h, int w, int c_in,
+                              int m_out, int dtype, float eps, void* stream);
 /* fp32 parity mode: 1 when a 3x3x3 convolution of dtype VS_F32 on a (d, h, w) volume with c_in stored input channels runs on the bf16 matrix cores through exact three-limb operand splitting
  * (csrc/igemm_k3x.h: every fp32 operand = three bf16 limbs, six exact limb products per product, fp32 accumulation — 2.7x fewer matrix cycles
  * than the exact-f32 MFMA at the accuracy of one fp32 rounding).  Their packed weights must then be VS_F32X3 images: vs_pack_weight /

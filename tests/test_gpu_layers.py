@@ -379,3 +379,84 @@ def test_k3b_bwd_data_with_fused_apply(case, dtype):
     assert lib.vs_conv_k3_fused_apply_supported(n, 6, 6, 6, 128, 128, 1, dt) == 0
     # nor do the 32-channel chunks of the 24^3 / 12^3 levels since round 5 (the fused form measured slower twice: profiles/r04_ab_fused_apply_32ch.json)
     assert lib.vs_conv_k3_fused_apply_supported(2, 24, 24, 24, 32, 32, 1, dt) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("fused_apply", [False, True])
+@pytest.mark.parametrize("case", [(2, 96, 96, 96), (2, 12, 16, 40), (1, 9, 11, 33), (3, 5, 9, 33), (1, 4, 8, 32), (1, 128, 128, 128), (16, 4, 8, 32), (25, 4, 8, 32)])
+def test_k3_bwd_data_with_fused_weight_gradient(case, fused_apply, dtype):
+    """vs_conv_k3_bwd_data_wgrad (igemm_k3tw.h): the backward-data launch of an 8 -> 8 layer that also forms the layer's weight gradient — against the two
+    launches it replaces: backward-data output and fused sums identical to vs_conv_gather_bwd_data / vs_conv_k3_bwd_data_fused_apply (same instruction
+    stream), dW (slabs through a VS_WGRAD_SLABS descriptor of vs_conv_wgrad_multi) against vs_conv_wgrad on the applied gradient; real (2 x 96^3,
+    1 x 128^3), ragged and many-sample shapes; real channel counts below 8 in the descriptor (out_block-like 2 gradient channels)."""
+    import ctypes
+    ops = _ops()
+    from vae_segmentation_amd._lib import check, lib
+    n, d, h, w = case
+    c = 8
+    gen = torch.Generator().manual_seed(d + w)
+    ax = (torch.randn(n, d, h, w, c, generator=gen) * 1.3 + 0.2).to(dtype).cuda()
+    g = torch.randn(n, d, h, w, c, generator=gen).to(dtype).cuda()
+    mx = (torch.randn(n, d, h, w, c, generator=gen) * 0.8 - 0.1).to(dtype).cuda()
+    wt = (torch.randn(c, c, 3, 3, 3, generator=gen) * 0.1).cuda()
+    ops.stats_arena_begin(ax.device)
+    axs, mxs = ops.instnorm_stats(ax), ops.instnorm_stats(mx)
+    vox, dt, st = d * h * w, ops.vs_dtype(ax), ops._stream()
+    if n * 8 > 192:                               # the per-(n, c) tables of the kernel hold 192 pairs
+        assert lib.vs_conv_k3_bwd_data_wgrad_supported(n, d, h, w, 8, 8, dt) == 0
+        return
+    assert lib.vs_conv_k3_bwd_data_wgrad_supported(n, d, h, w, 8, 8, dt) == 1
+    assert lib.vs_conv_k3_bwd_data_wgrad_supported(n, d, h, w, 16, 16, dt) == 0 and lib.vs_conv_k3_bwd_data_wgrad_supported(n, d, h, w, 8, 8, 0) == 0
+    asums = ops._new_stats(n, c, ax.device)
+    check(lib.vs_instnorm_relu_bwd_reduce(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), n, vox, c, dt, 1e-5, st), "reduce")
+    wpb = ops.pack_weight(wt, ops.VS_PACK_ROWS_D1_FLIP, c, dtype)
+    dx_ref = torch.empty_like(g)
+    check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), dx_ref.data_ptr(), n, vox, c, dt, 1e-5, st), "apply")
+    y_ref, y = torch.empty_like(mx), torch.empty_like(mx)
+    s_ref, s2 = ops._new_stats(n, c, ax.device), ops._new_stats(n, c, ax.device)
+    dx = torch.empty_like(g)
+    if fused_apply:
+        check(lib.vs_conv_k3_bwd_data_fused_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), y_ref.data_ptr(),
+                                                  mx.data_ptr(), mxs.data_ptr(), s_ref.data_ptr(), dx.data_ptr(), n, d, h, w, c, c, dt, 1e-5, st), "fused apply")
+    else:
+        check(lib.vs_conv_gather_bwd_data(dx_ref.data_ptr(), wpb.data_ptr(), y_ref.data_ptr(), mx.data_ptr(), mxs.data_ptr(), s_ref.data_ptr(),
+                                          n, d, h, w, c, c, ops.VS_CONV_K3, dt, 1e-5, st), "bwd_data")
+    nslabs = lib.vs_conv_k3_bwd_data_wgrad_slabs(n, d, h, w)
+    assert 0 < nslabs <= 512
+    slabs = torch.full((nslabs * 1728,), float("nan"), dtype=torch.float32, device="cuda")
+    src = g if fused_apply else dx_ref
+    check(lib.vs_conv_k3_bwd_data_wgrad(src.data_ptr(), ax.data_ptr() if fused_apply else None, axs.data_ptr() if fused_apply else None,
+                                        asums.data_ptr() if fused_apply else None, wpb.data_ptr(), y.data_ptr(), mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(),
+                                        slabs.data_ptr(), n, d, h, w, c, c, dt, 1e-5, st), "bwd_data + wgrad")
+    torch.cuda.synchronize()
+    assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
+    t2, tr = ops.stats_total(s2), ops.stats_total(s_ref)
+    assert float((t2 - tr).abs().max() / tr.abs().max()) < 1e-6
+    assert bool(torch.isfinite(slabs).all())
+    applied = dx if fused_apply else dx_ref
+    for m_real, c_real in ((8, 8), (2, 8), (8, 1)):
+        dw = torch.full((m_real, c_real, 27), float("nan"), dtype=torch.float32, device="cuda")
+        desc = ops.WgradDesc(slabs.data_ptr(), None, None, None, dw.data_ptr(), None, None, 0, 0, 0, nslabs, 0, 0, 0, 8, 8, m_real, c_real, ops.VS_WGRAD_SLABS, 0)
+        arr = (ops.WgradDesc * 1)(desc)
+        nbytes = lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(arr), 1, dt)
+        assert nbytes > 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        check(lib.vs_conv_wgrad_multi(ctypes.addressof(arr), 1, ws.data_ptr(), nbytes, dt, 1e-5, st), "wgrad_multi (slabs)")
+        ref = ops.conv_wgrad(applied, None, mx, mxs, m_real, c_real, ops.VS_CONV_K3, (m_real, c_real, 3, 3, 3)).reshape(m_real, c_real, 27)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(dw).all())
+        assert _rel_l2(dw, ref) < 2e-5, (m_real, c_real, _rel_l2(dw, ref))
+    # a slab descriptor next to a regular one in the same call; sharing its destination with another descriptor is refused
+    dw_a = torch.empty(8, 8, 27, dtype=torch.float32, device="cuda")
+    dw_b = torch.empty(8, 8, 27, dtype=torch.float32, device="cuda")
+    d_slab = ops.WgradDesc(slabs.data_ptr(), None, None, None, dw_a.data_ptr(), None, None, 0, 0, 0, nslabs, 0, 0, 0, 8, 8, 8, 8, ops.VS_WGRAD_SLABS, 0)
+    d_reg = ops.WgradDesc(applied.data_ptr(), None, mx.data_ptr(), mxs.data_ptr(), dw_b.data_ptr(), None, None, 0, 0, 0, n, d, h, w, 8, 8, 8, 8, ops.VS_CONV_K3, 0)
+    arr = (ops.WgradDesc * 2)(d_slab, d_reg)
+    nbytes = lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(arr), 2, dt)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    check(lib.vs_conv_wgrad_multi(ctypes.addressof(arr), 2, ws.data_ptr(), nbytes, dt, 1e-5, st), "wgrad_multi (mixed)")
+    torch.cuda.synchronize()
+    assert _rel_l2(dw_a, dw_b) < 2e-5
+    d_reg2 = ops.WgradDesc(applied.data_ptr(), None, mx.data_ptr(), mxs.data_ptr(), dw_a.data_ptr(), None, None, 0, 0, 0, n, d, h, w, 8, 8, 8, 8, ops.VS_CONV_K3, 0)
+    arr = (ops.WgradDesc * 2)(d_slab, d_reg2)
+    assert lib.vs_conv_wgrad_multi(ctypes.addressof(arr), 2, ws.data_ptr(), nbytes, dt, 1e-5, st) == -1

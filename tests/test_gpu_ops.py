@@ -638,3 +638,48 @@ def test_weight_used_several_times_in_one_backward(dtype):
     tol = TOL[dtype] * 4
     for name, r, gq_ in zip(("k3 weight", "k2s2 weight", "k2s2 bias", "convT weight", "convT bias"), ref, gpu):
         assert relerr(gq_.grad.cpu(), r.grad) < tol, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_weight_gradient_fused_into_backward_data_matches_the_grouped_launch(dtype):
+    """ConvK3.backward hands the weight gradient of an 8 -> 8 layer to its backward-data launch (ops._wgrad_fusable, csrc/igemm_k3tw.h) when the weight is used
+    once in the pass; a weight used twice keeps the grouped launch (its uses are summed there).  Same gradients either way."""
+    ops = _ops()
+    n, c = 2, 8
+    x = rnd(n, c, 12, 16, 40, seed=90)
+    w1, w2 = q(rnd(c, c, 3, 3, 3, seed=91, scale=0.08), dtype), q(rnd(c, c, 3, 3, 3, seed=92, scale=0.08), dtype)
+    gsum = to_cl(rnd(n, c, 12, 16, 40, seed=93), c, dtype).float()
+
+    def run(fuse, reuse):
+        ops.FUSE_WGRAD = fuse
+        taken = []
+        orig = ops._group_submit_slabs
+        ops._group_submit_slabs = lambda *a, **k: (taken.append(1), orig(*a, **k))[1]
+        try:
+            ws = [t.clone().cuda().requires_grad_(True) for t in (w1, w2)]
+            ops.stats_arena_begin(torch.device("cuda", 0))
+            x_cl = to_cl(x, c, dtype).requires_grad_(True)
+            st = ops.instnorm_stats(x_cl)
+            y1, s1 = ops.ConvK3.apply(x_cl, st, ws[0], None)
+            y2, s2 = ops.ConvK3.apply(y1, s1, ws[1], None)
+            if reuse:
+                y2, s2 = ops.ConvK3.apply(y2, s2, ws[1], None)
+            (y2.float() * gsum).sum().backward()
+            torch.cuda.synchronize()
+            return [t.grad.clone() for t in ws] + [x_cl.grad.float().clone()], len(taken)
+        finally:
+            ops._group_submit_slabs = orig
+            ops.FUSE_WGRAD = True
+
+    for reuse in (False, True):
+        ref, n_ref = run(False, reuse)
+        got, n_got = run(True, reuse)
+        assert n_ref == 0
+        assert n_got == (1 if reuse else 2)          # the weight applied twice stays with the grouped launch
+        for a, b in zip(got, ref):
+            assert bool(torch.isfinite(a).all())
+            assert relerr(a.cpu(), b.cpu()) < 2e-5
+    # a second pass right away: the use counts start over when a backward pass ends
+    _, n_again = run(True, False)
+    assert n_again == 2

@@ -6,6 +6,7 @@ int g1_dispatch_k3_f32(const G1Params& p, int ck, int mt, int epi, int tiles, in
 int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_dispatch_k3_f16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_k3_fa_supported(const G1Params& p, int ck, int mt);
+int k3tw_slab_count(int n, int d, int h, int w);        // igemm_k3_bf16.hip: workgroups (= slabs) of a k3tw_kernel launch
 int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 
 // fp32 parity mode: the 3x3x3 convolutions run on the bf16 matrix cores through exact three-limb operand splitting (igemm_k3x.h); their packed
@@ -63,7 +64,7 @@ static int check_common(const void* x, const void* w, int n, int d, int h, int w
 static int gather_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                        void* y, double* y_stats, const void* mask_x, const double* mask_stats, double* sums,
                        int n, int d, int h, int w, int c_in, int m_out, int kind, int dtype, float eps, void* stream,
-                       const void* fa_x = nullptr, const double* fa_sums = nullptr, void* fa_dx = nullptr, int* fa_query = nullptr) {
+                       const void* fa_x = nullptr, const double* fa_sums = nullptr, void* fa_dx = nullptr, int* fa_query = nullptr, float* wg_ws = nullptr) {
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
     if (!y || m_out <= 0 || m_out % 8 || ((uintptr_t)y & 15)) return VS_EINVAL;
@@ -72,7 +73,7 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     G1Params p{};
     p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = y; p.y_stats = y_stats; p.prob = nullptr;
     p.mask_x = mask_x; p.mask_stats = mask_stats; p.sums = sums;
-    p.fa_x = fa_x; p.fa_sums = fa_sums; p.fa_dx = fa_dx;
+    p.fa_x = fa_x; p.fa_sums = fa_sums; p.fa_dx = fa_dx; p.wg_ws = wg_ws;
     if (sums && (!mask_x || !mask_stats || y_stats)) return VS_EINVAL;
     p.N = n; p.D = d; p.H = h; p.W = w;
     p.C = c_in; p.M = m_out;
@@ -152,6 +153,31 @@ extern "C" int vs_conv_k3_fused_apply_supported(int n, int d, int h, int w, int 
                                lazy_input ? (const double*)dummy : nullptr, lazy_input ? dsink : nullptr, n, d, h, w, c_in, m_out, VS_CONV_K3,
                                dtype, 1e-5f, nullptr, dummy, (const double*)dummy, nullptr, &ok);
     return rc == VS_OK ? ok : 0;
+}
+
+// ---- backward-data with the layer's weight gradient fused (igemm_k3tw.h) ----
+extern "C" int vs_conv_k3_bwd_data_wgrad_supported(int n, int d, int h, int w, int c_in, int m_out, int dtype) {
+    static const int on = getenv("VS_FUSE_WGRAD") ? atoi(getenv("VS_FUSE_WGRAD")) : 1;
+    if (!on || (dtype != VS_BF16 && dtype != VS_F16)) return 0;
+    if (c_in != 8 || m_out != 8 || n <= 0 || n * 8 > 192 || d <= 0 || h <= 0 || w <= 0) return 0;
+    if ((double)n * d * h * w * 16 >= 2147483648.0) return 0;
+    return vs_k3_toeplitz(8, 8, 27, dtype) ? 1 : 0;     // the weight image is the Toeplitz one of k3t_kernel
+}
+
+extern "C" int vs_conv_k3_bwd_data_wgrad_slabs(int n, int d, int h, int w) {
+    if (n <= 0 || d <= 0 || h <= 0 || w <= 0) return 0;
+    return k3tw_slab_count(n, d, h, w);
+}
+
+extern "C" int vs_conv_k3_bwd_data_wgrad(const void* g, const void* act_x, const double* act_stats, const double* act_sums, const void* w_packed, void* y,
+                                         const void* mask_x, const double* mask_stats, double* sums, float* slabs, int n, int d, int h, int w, int c_in,
+                                         int m_out, int dtype, float eps, void* stream) {
+    if (!g || !slabs || !mask_x || !mask_stats || !sums) return VS_EINVAL;
+    if ((act_x == nullptr) != (act_stats == nullptr) || (act_x == nullptr) != (act_sums == nullptr)) return VS_EINVAL;     // all three (un-applied gradient in) or none
+    if (!vs_conv_k3_bwd_data_wgrad_supported(n, d, h, w, c_in, m_out, dtype)) return VS_ESHAPE;
+    if (((uintptr_t)slabs & 15) || (act_x && ((uintptr_t)act_x & 15))) return VS_EALIGN;
+    return gather_impl(g, act_stats, w_packed, nullptr, y, nullptr, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, VS_CONV_K3, dtype, eps,
+                       stream, act_x, act_sums, nullptr, nullptr, slabs);
 }
 
 static int scatter_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias, void* y,

@@ -50,6 +50,8 @@ struct G1Params {
     const void* up_taps;
     const float* up_btab;
     int up_co;
+    // k3tw_kernel (igemm_k3tw.h): backward-data with the layer's weight gradient fused — one slab [27][8][8] per workgroup goes here
+    float* wg_ws;
 };
 
 // LDS carve (bytes)

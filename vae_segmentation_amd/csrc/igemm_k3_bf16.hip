@@ -7,3 +7,4 @@ int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, i
 
 // conv_api.hip: is there a fused-apply kernel for this (already planned) backward-data launch?  The same for both 16-bit storage types.
 int g1_k3_fa_supported(const G1Params& p, int ck, int mt) { return k3_h16_fa_supported(p, ck, mt) ? 1 : 0; }
+int k3tw_slab_count(int n, int d, int h, int w) { return k3tw_grid(n, d, h, w); }

@@ -1238,6 +1238,44 @@ __global__ __launch_bounds__(64 * G3_RED_ROWS) void g3_reduce_group_kernel(const
     }
     // weight slabs: the rows of the block are (element group, slab partition) pairs — a layer with one slab (deep layers
     // of a grouped launch) spends no threads on partitions it does not have
+    if (d.cb & 0x200) {
+        // slabs of a backward-data launch with the fused weight gradient (igemm_k3tw.h): [tap 27][c 8][m 8] floats, one per workgroup of that launch — up to 512 of
+        // them, more than any layer of the grouped launches has.  A block takes 16 vectors of 4 elements and splits the slabs 16 ways (4 per wave), so that
+        // no thread walks more than 32 slabs and the entry does not outlast the rest of the launch.
+        const int el = lane & 15, sp2 = lane >> 4, P = part * 4 + sp2;
+        const size_t e = ((size_t)lb * 16 + el) * 4;
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        if (e < 1728) {
+            const float* src = d.ws + e;
+            int sl = P;
+            for (; sl + 7 * 16 < d.nslabs; sl += 8 * 16) {
+                f32x4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(src + (size_t)(sl + 16 * j) * 1728);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s4[0] += (double)v[j][0]; s4[1] += (double)v[j][1]; s4[2] += (double)v[j][2]; s4[3] += (double)v[j][3]; }
+            }
+            for (; sl < d.nslabs; sl += 16) {
+                const f32x4 v = *(const f32x4*)(src + (size_t)sl * 1728);
+                s4[0] += (double)v[0]; s4[1] += (double)v[1]; s4[2] += (double)v[2]; s4[3] += (double)v[3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red4[i][part][lane] = s4[i];
+        __syncthreads();
+        if (P == 0 && e < 1728) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                double tot = 0.0;
+                for (int q = 0; q < 16; ++q) tot += red4[i][q >> 2][(q & 3) * 16 + el];       // fixed order: bitwise reproducible
+                // S[o][c][m] = sum_v Q(v)[c] P(v + o)[m] = dW[m][c][-o]
+                const size_t ee = e + i;
+                const int mg = (int)(ee & 7), ci = (int)((ee >> 3) & 7), tp = (int)(ee >> 6);
+                if (mg < d.m_real && ci < d.c_real) d.dw[((size_t)mg * d.c_real + ci) * 27 + (26 - tp)] = (float)tot;
+            }
+        }
+        return;
+    }
     const int parts = d.parts, egrp = part / parts, sp = part - egrp * parts;
     const size_t slab_elems = (size_t)d.mbn * d.cbn * d.ncb * 256;
     // four consecutive slab elements per lane (= rows 4q..4q+3 of one (k, col)): 1 KiB per wave request instead of 256 B
@@ -1799,8 +1837,52 @@ static size_t f32_bias_bytes(const vs_wgrad_desc* descs, int count, int target_w
     return plan.bytes - f32_bias_base(descs, count, plan);
 }
 
+// VS_WGRAD_SLABS descriptors (slabs already computed by vs_conv_k3_bwd_data_wgrad): no grid work, no workspace, one entry of the grouped reduction each
+static std::vector<vs_wgrad_desc> without_slab_descs(const vs_wgrad_desc* descs, int count) {
+    std::vector<vs_wgrad_desc> reg;
+    for (int i = 0; i < count; ++i) if (descs[i].kind != VS_WGRAD_SLABS) reg.push_back(descs[i]);
+    return reg;
+}
+static int slab_desc_validate(const vs_wgrad_desc& d) {
+    if (!d.p || !d.dw || d.n <= 0 || ((uintptr_t)d.p & 15)) return VS_EINVAL;
+    if (d.m_real <= 0 || d.m_real > 8 || d.c_real <= 0 || d.c_real > 8 || d.m_ch != 8 || d.c_ch != 8) return VS_ESHAPE;
+    return VS_OK;
+}
+static void slab_red_entry(const vs_wgrad_desc& d, G3RedDesc& r, int& blocks) {
+    r = G3RedDesc{(const float*)d.p, d.dw, d.m_real, d.c_real, 1, 1, d.n, 0x208, 27, 27, 0, G3_RED_ROWS, 0};
+    blocks = 1728 / 64;                                  // 16 vectors of 4 elements per block (g3_reduce_group_kernel)
+}
+static int slab_reduce_only(const std::vector<vs_wgrad_desc>& slabs, hipStream_t st) {
+    for (size_t at = 0; at < slabs.size(); at += G3_RED_MAX) {
+        G3RedGroup grp{};
+        grp.n = (int)std::min<size_t>(G3_RED_MAX, slabs.size() - at);
+        long long blk = 0;
+        for (int j = 0; j < grp.n; ++j) {
+            int nb = 0;
+            slab_red_entry(slabs[at + j], grp.d[j], nb);
+            grp.blk_start[j] = (int)blk;
+            blk += nb;
+        }
+        for (int j = grp.n; j <= G3_RED_MAX; ++j) grp.blk_start[j] = (int)blk;
+        hipLaunchKernelGGL(g3_reduce_group_kernel, dim3((unsigned)blk), dim3(64 * G3_RED_ROWS), 0, st, grp);
+        VS_CHECK_LAUNCH();
+    }
+    return VS_OK;
+}
+
 static size_t wgrad_multi_workspace_bytes_impl(const vs_wgrad_desc* descs, int count, int dtype, int target_workgroups) {
     if (!descs || count <= 0 || target_workgroups < 0) return 0;
+    std::vector<vs_wgrad_desc> reg_only;
+    {
+        bool any = false;
+        for (int i = 0; i < count; ++i) any = any || descs[i].kind == VS_WGRAD_SLABS;
+        if (any) {
+            if (dtype == VS_F32) return 0;
+            reg_only = without_slab_descs(descs, count);
+            if (reg_only.empty()) return 256;               // nothing but reductions: a token workspace (the caller passes a non-null pointer)
+            descs = reg_only.data(); count = (int)reg_only.size();
+        }
+    }
     std::vector<vs_wgrad_desc> eff32;
     if (dtype == VS_F32) {                        // serial per-layer launches share one region; the uses of one weight need theirs side by side
         eff32 = f32_effective(descs, count);
@@ -1833,6 +1915,20 @@ static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspa
     if (!vs_dtype_ok(dtype)) return VS_EDTYPE;
     const bool f16 = dtype == VS_F16;
     hipStream_t st = (hipStream_t)stream;
+    std::vector<vs_wgrad_desc> reg_only, slab_descs;
+    for (int i = 0; i < count; ++i)
+        if (descs[i].kind == VS_WGRAD_SLABS) {
+            if (dtype == VS_F32) return VS_EINVAL;
+            int rc = slab_desc_validate(descs[i]);
+            if (rc) return rc;
+            for (int j = 0; j < count; ++j) if (j != i && descs[j].dw == descs[i].dw) return VS_EINVAL;      // a slab descriptor is the only contribution to its gradient
+            slab_descs.push_back(descs[i]);
+        }
+    if (!slab_descs.empty()) {
+        reg_only = without_slab_descs(descs, count);
+        if (reg_only.empty()) return slab_reduce_only(slab_descs, st);
+        descs = reg_only.data(); count = (int)reg_only.size();
+    }
     std::vector<vs_wgrad_desc> eff32;
     if (dtype == VS_F32) {
         for (int i = 0; i < count; ++i) {
@@ -2068,6 +2164,13 @@ static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspa
                 red.push_back(G3RedDesc{(const float*)(ws + L.bias_off), descs[i].db, 0, descs[i].bias_c_real, 0, 0, L.bias_total_blk, 0, 0, 0, 1, G3_RED_ROWS});
                 blocks.push_back(vs_ceil_div(descs[i].bias_c_real, 64));
             }
+        }
+        for (const vs_wgrad_desc& sd : slab_descs) {      // the layers whose slabs a backward-data launch wrote
+            G3RedDesc r;
+            int nb = 0;
+            slab_red_entry(sd, r, nb);
+            red.push_back(r);
+            blocks.push_back(nb);
         }
         for (size_t at = 0; at < red.size(); at += G3_RED_MAX) {
             G3RedGroup grp{};

@@ -560,17 +560,37 @@ def apply_lazy(g, lazy):
     return g
 
 
-def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None, defer=False, lazy=None, want_dx=False):
+def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None, defer=False, lazy=None, want_dx=False, fuse_wgrad=None):
     """Gradient w.r.t. the raw tensor x of a lazy activation a = relu(instnorm(x)) that fed a conv:
     g = conv-backward-data(gy) with the InstanceNorm+ReLU-backward sums accumulated in the same kernel's epilogue,
     then the (in-place) apply pass.  kind / scatter select the backward-data form of the forward conv.
     lazy = (act_x, act_stats, act_sums): gy itself is an un-applied gradient (see _LAZY_APPLY) — its apply is fused into this launch's
-    staging and the call returns (g, applied gy or None [want_dx]).  defer: leave g un-applied and register it for x's producer."""
+    staging and the call returns (g, applied gy or None [want_dx]).  defer: leave g un-applied and register it for x's producer.
+    fuse_wgrad = (weight, m_real, c_real): the launch also forms the layer's weight gradient (see _wgrad_fusable) and the call returns (g, gw)."""
     n, c = x.shape[0], x.shape[-1]
     sums = _new_stats(n, c, x.device)
     g = torch.empty_like(x)
     gn, gd, gh, gw, gc = gy.shape
     dt = vs_dtype(x)
+    if fuse_wgrad is not None:
+        weight, m_real, c_real = fuse_wgrad
+        ax, axs, asums = lazy if lazy is not None else (None, None, None)
+        nslabs = lib.vs_conv_k3_bwd_data_wgrad_slabs(gn, gd, gh, gw)
+        slabs = torch.empty(nslabs * 1728, dtype=torch.float32, device=x.device)
+        kid = nb = fl = None
+        if PROFILE is not None:
+            kid = _k3_kid(_tname(x), 8, 16, sums=True, geom=(gn, gd, gh, gw), m=c) + ("+apply" if lazy is not None else "") + "+wgrad"
+            nb = ((3 if lazy is not None else 2) * gy.numel() + 2 * g.numel()) * _esize(x)
+            fl = 2.0 * 2.0 * (g.numel() // c) * 27 * gc * c
+        with _timed(kid, nb, fl, "bwd+wgrad gy%s->m%d" % (tuple(gy.shape), c)):
+            check(lib.vs_conv_k3_bwd_data_wgrad(gy.data_ptr(), _p(ax), _p(axs), _p(asums), wpb.data_ptr(), g.data_ptr(), x.data_ptr(), xs.data_ptr(),
+                                                sums.data_ptr(), slabs.data_ptr(), gn, gd, gh, gw, gc, c, dt, EPS_IN, _stream()), "conv_k3_bwd_data_wgrad")
+        gw_t = _group_submit_slabs(weight, slabs, nslabs, m_real, c_real, (gy, x, xs))
+        if defer:
+            _defer_register(g, x, xs, sums)
+        else:
+            _apply_in_place(g, x, xs, sums)
+        return g, gw_t
     if lazy is not None:
         ax, axs, asums = lazy
         dx = torch.empty_like(gy) if want_dx else None
@@ -776,6 +796,7 @@ def _group_submit(weight, keep, wgrad_args, bias_args, gw, gb, up_co=0):
 
 
 def _group_backward_done():
+    _USE_EPOCH[0] += 1                          # a backward pass ended: the use counts of the next forward start over (_count_use)
     _GROUP["callback"] = False
     flush_wgrads(first_only=_GROUP["split"] is not None)
     _GROUP["slots"] = {}
@@ -800,6 +821,54 @@ def flush_wgrads(first_only=False):
     if not later:
         _run_up_jobs()                          # parameter-space chain rule of the composed Up heads: reads the dWeff the launch above reduced
         g["keep"] = []                          # launched on the current stream: the allocator may recycle the inputs now
+
+
+# Weight gradient fused into the backward-data launch (csrc/igemm_k3tw.h; round 5): the 8 -> 8 3x3x3 layers whose backward-data kernel already holds both
+# operands of dW.  Taken when the weight is used exactly ONCE in this pass (counted at forward time; _USE_EPOCH moves on when a backward pass ends) and its
+# gradient can be deferred like every grouped one; the slabs the launch writes join the grouped reduction as a VS_WGRAD_SLABS descriptor.
+FUSE_WGRAD = os.environ.get("VS_FUSE_WGRAD", "1") != "0"
+VS_WGRAD_SLABS = 16
+_USE_EPOCH = [0]
+
+
+def _count_use(weight):
+    u = getattr(weight, "_vs_use", None)
+    if u is None or u[0] != _USE_EPOCH[0]:
+        weight._vs_use = [_USE_EPOCH[0], 1]
+    else:
+        u[1] += 1
+
+
+def _wgrad_fusable(gy, x, weight):
+    if not (FUSE_WGRAD and _GROUP["enabled"] and gy.dtype != torch.float32 and gy.shape[-1] == 8 and x.shape[-1] == 8):
+        return False
+    if getattr(weight, "_vs_use", None) != [_USE_EPOCH[0], 1] or _GROUP["slots"].get(id(weight)) is not None:
+        return False
+    if not (weight.is_leaf and weight.grad is None and not _has_hooks(weight) and not torch.is_grad_enabled()):
+        return False                            # the conditions under which _side_grads defers a gradient
+    n, d, h, w, _ = gy.shape
+    return bool(lib.vs_conv_k3_bwd_data_wgrad_supported(n, d, h, w, 8, 8, vs_dtype(gy)))
+
+
+def _group_submit_slabs(weight, slabs, nslabs, m_real, c_real, keep):
+    """register the slabs of a fused launch with the pass's grouped weight gradients; -> the (still unwritten) gradient tensor handed to autograd"""
+    g = _GROUP
+    if g["descs"] and g["dtype"] != keep[0].dtype:
+        flush_wgrads()
+    g["dtype"] = keep[0].dtype
+    gw = _grad_slot(weight, weight.shape)
+    g["slots"][id(weight)] = (gw.data_ptr(), None)
+    d = WgradDesc(slabs.data_ptr(), None, None, None, gw.data_ptr(), None, None, 0, 0, 0, nslabs, 0, 0, 0, 8, 8, m_real, c_real, VS_WGRAD_SLABS, 0)
+    first = g["split"] is None or bool(g["split"](weight))
+    g["descs"].append((d, first, float(slabs.numel() * 4), 0.0, 0))
+    g["keep"].append(slabs)
+    if not g["callback"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_group_backward_done)
+            g["callback"] = True
+        except RuntimeError:
+            flush_wgrads()
+    return gw
 
 
 def _grad_slot(param, shape):
@@ -912,6 +981,8 @@ class ConvK3(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias                   # a Parameter (long-lived leaf): only its gradient slot is looked up in backward
         ctx.defer = bool(getattr(x, "_vs_defer_apply", False)) and xs is not None     # see _LAZY_APPLY
+        if ctx.needs_input_grad[2]:
+            _count_use(weight)                # see _wgrad_fusable
         ctx.mark_non_differentiable(ys)
         ctx.set_materialize_grads(False)      # otherwise autograd zero-fills a gradient for the stats output every backward
         return y, ys
@@ -929,6 +1000,13 @@ class ConvK3(torch.autograd.Function):
             gy, lazy = apply_lazy(gy, lazy), None     # no fused-apply kernel for this launch / no input gradient wanted: apply now
         if ctx.needs_input_grad[0]:
             wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, gy.shape[-1], k3_pack_dtype(gy))
+            want_gb0 = ctx.has_bias and ctx.needs_input_grad[3] and ctx.live_bias
+            if xs is not None and ctx.needs_input_grad[2] and not want_gb0 and _wgrad_fusable(gy, x, weight):
+                # the backward-data launch of this layer forms its weight gradient as well (nothing else reads the applied gradient)
+                gx, gw = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K3, real_channels=(cout, cin), defer=ctx.defer, lazy=lazy,
+                                            fuse_wgrad=(weight, cout, cin))
+                gb = _dead_bias_grad(ctx.bias_ref, ctx.bias_ref.shape[0], x.device) if ctx.has_bias and ctx.needs_input_grad[3] else None
+                return gx, None, gw, gb, None
             if lazy is not None and xs is not None:
                 gx, gy = conv_bwd_data_lazy(gy, wpb, x, xs, VS_CONV_K3, real_channels=(cout, cin), defer=ctx.defer, lazy=lazy,
                                             want_dx=ctx.needs_input_grad[2])
