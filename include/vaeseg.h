@@ -159,6 +159,15 @@ int vs_conv_k3_bwd_data_wgrad_slabs(int n, int d, int h, int w);
 int vs_conv_k3_bwd_data_wgrad(const void* g, const void* act_x, const double* act_stats, const double* act_sums, const void* w_packed, void* y,
                               const void* mask_x, const double* mask_stats, double* sums, float* slabs, int n, int d, int h, int w, int c_in,
                               int m_out, int dtype, float eps, void* stream);
+/* out_block's backward (two classes, 8 stored channels; joint_model.py:224-225,265-266 / 366-367,386-388) as ONE launch: the gradient of the logits is formed
+ * from the planar probabilities and their gradient(s) while the tile is staged — exactly vs_softmax2_cl_bwd(prob, gprob, gprob_cl), logit dropout included,
+ * never stored — and multiplied out as vs_conv_gather_bwd_data would (y, fused sums against mask_x / mask_stats).  slabs (nullable): the layer's weight
+ * gradient as for vs_conv_k3_bwd_data_wgrad; bias_part (nullable, needs slabs): one (sum gl0, sum gl1) pair of doubles per slab — give both to
+ * vs_conv_wgrad_multi as ONE VS_WGRAD_SLABS descriptor (bias_g = bias_part, bias_rows = the slab count, bias_c_real = 2, db).  Shapes: those of
+ * vs_conv_k3_bwd_data_wgrad_supported(n, d, h, w, 8, 8, dtype). */
+int vs_conv_k3_softmax2_bwd_data(const float* prob, const float* gprob, const void* gprob_cl, const void* w_packed, void* y, const void* mask_x,
+                                 const double* mask_stats, double* sums, float* slabs, double* bias_part, int n, int d, int h, int w, int dtype,
+                                 float eps, float drop_p, unsigned long long drop_seed, void* stream);
 /* fp32 parity mode: 1 when a 3x3x3 convolution of dtype VS_F32 on a (d, h, w) volume with c_in stored input channels runs on the bf16 matrix cores through exact three-limb operand splitting
  * (csrc/igemm_k3x.h: every fp32 operand = three bf16 limbs, six exact limb products per product, fp32 accumulation — 2.7x fewer matrix cycles
  * than the exact-f32 MFMA at the accuracy of one fp32 rounding).  Their packed weights must then be VS_F32X3 images: vs_pack_weight /

@@ -19,7 +19,7 @@ os.environ.setdefault("VS_DETERMINISTIC", "1")
 BOTH_LIBS = {
     "test_gpu_layers": {"test_k3_layer_shapes", "test_k2s2_layer_shapes", "test_transposed_layer_shapes", "test_out_block_softmax_layer_shapes",
                         "test_skip_merge_layer_shapes", "test_k3_bwd_data_with_fused_apply", "test_k3b_bwd_data_with_fused_apply",
-                        "test_k3_bwd_data_with_fused_weight_gradient"},
+                        "test_k3_bwd_data_with_fused_weight_gradient", "test_out_block_backward_as_one_launch"},
     "test_gpu_up": {"test_up_composed_vs_cpu_autograd", "test_up_composed_weight_gradients_vs_cpu_autograd",
                     "test_up_block_module_uses_composed_path_when_frozen", "test_trainable_composed_up_multi_step_matches_two_launch_form"},
     "test_gpu_ops": {"test_conv_k3_fwd_bwd_large", "test_conv_k3_fwd_bwd", "test_conv_k3_small_volume_odd_chunk_counts", "test_conv_k2s2_fwd_bwd",

@@ -460,3 +460,72 @@ def test_k3_bwd_data_with_fused_weight_gradient(case, fused_apply, dtype):
     d_reg2 = ops.WgradDesc(applied.data_ptr(), None, mx.data_ptr(), mxs.data_ptr(), dw_a.data_ptr(), None, None, 0, 0, 0, n, d, h, w, 8, 8, 8, 8, ops.VS_CONV_K3, 0)
     arr = (ops.WgradDesc * 2)(d_slab, d_reg2)
     assert lib.vs_conv_wgrad_multi(ctypes.addressof(arr), 2, ws.data_ptr(), nbytes, dt, 1e-5, st) == -1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("parts", ["planar", "cl", "both"])
+@pytest.mark.parametrize("case", [(2, 96, 96, 96, 0.0), (2, 12, 16, 40, 0.3), (1, 9, 11, 33, 0.0), (3, 5, 9, 33, 0.25)])
+def test_out_block_backward_as_one_launch(case, parts, dtype):
+    """vs_conv_k3_softmax2_bwd_data (igemm_k3tw.h, SM staging): out_block's backward — softmax backward (planar and / or channels-last gradient parts, logit
+    dropout), backward-data with the fused sums, weight gradient slabs and bias partials — against the launches it replaces: vs_softmax2_cl_bwd,
+    vs_conv_gather_bwd_data, vs_conv_wgrad, vs_bias_grad.  Same arithmetic on the same rounded logit gradients: the backward-data output is bit-identical."""
+    import ctypes
+    ops = _ops()
+    from vae_segmentation_amd._lib import check, lib
+    n, d, h, w, pdrop = case
+    vox, seed = d * h * w, 777
+    gen = torch.Generator().manual_seed(d * 7 + w)
+    logits = torch.randn(n, 2, d, h, w, generator=gen) * 2.0
+    prob = torch.softmax(logits, dim=1).contiguous().cuda()
+    gprob = torch.randn(n, 2, d, h, w, generator=gen).cuda() if parts != "cl" else None
+    gcl = None
+    if parts != "planar":
+        gcl = torch.zeros(n, d, h, w, 8, dtype=dtype)
+        gcl[..., :2] = torch.randn(n, d, h, w, 2, generator=gen).to(dtype)
+        gcl[..., 2:] = 5.0                                       # padded channels of the channels-last part are never read
+        gcl = gcl.cuda()
+    mx = (torch.randn(n, d, h, w, 8, generator=gen) * 0.8 - 0.1).to(dtype).cuda()
+    wt = (torch.randn(2, 8, 3, 3, 3, generator=gen) * 0.1).cuda()      # out_block: 8 -> 2
+    ops.stats_arena_begin(mx.device)
+    mxs = ops.instnorm_stats(mx)
+    dt, st = ops.vs_dtype(mx), ops._stream()
+    wpb = ops.pack_weight(wt, ops.VS_PACK_ROWS_D1_FLIP, 8, dtype)
+    p_ = lambda t: None if t is None else t.data_ptr()
+    gl = torch.empty(n, d, h, w, 8, dtype=dtype, device="cuda")
+    check(lib.vs_softmax2_cl_bwd(prob.data_ptr(), p_(gprob), p_(gcl), gl.data_ptr(), n, vox, 8, dt, pdrop, seed, st), "softmax2_cl_bwd")
+    y_ref, y = torch.empty_like(mx), torch.empty_like(mx)
+    s_ref, s2 = ops._new_stats(n, 8, mx.device), ops._new_stats(n, 8, mx.device)
+    check(lib.vs_conv_gather_bwd_data(gl.data_ptr(), wpb.data_ptr(), y_ref.data_ptr(), mx.data_ptr(), mxs.data_ptr(), s_ref.data_ptr(), n, d, h, w, 8, 8,
+                                      ops.VS_CONV_K3, dt, 1e-5, st), "bwd_data")
+    dw_ref = ops.conv_wgrad(gl, None, mx, mxs, 2, 8, ops.VS_CONV_K3, (2, 8, 3, 3, 3)).reshape(2, 8, 27)
+    db_ref = ops.bias_grad(gl, 2)
+    nslabs = lib.vs_conv_k3_bwd_data_wgrad_slabs(n, d, h, w)
+    for want_w, want_b in ((True, True), (True, False), (False, False)):
+        slabs = torch.full((nslabs * 1728,), float("nan"), dtype=torch.float32, device="cuda") if want_w else None
+        bpart = torch.full((nslabs * 2,), float("nan"), dtype=torch.float64, device="cuda") if want_b else None
+        s2.zero_(); y.fill_(3.0)
+        check(lib.vs_conv_k3_softmax2_bwd_data(prob.data_ptr(), p_(gprob), p_(gcl), wpb.data_ptr(), y.data_ptr(), mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(),
+                                               p_(slabs), p_(bpart), n, d, h, w, dt, 1e-5, pdrop, seed, st), "softmax2_bwd_data")
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(torch.int16), y_ref.view(torch.int16))
+        t2, tr = ops.stats_total(s2), ops.stats_total(s_ref)
+        assert float((t2 - tr).abs().max() / tr.abs().max()) < 1e-6
+        if not want_w:
+            continue
+        dw = torch.full((2, 8, 27), float("nan"), dtype=torch.float32, device="cuda")
+        db = torch.full((2,), float("nan"), dtype=torch.float32, device="cuda")
+        desc = ops.WgradDesc(slabs.data_ptr(), None, None, None, dw.data_ptr(), p_(bpart), db.data_ptr() if want_b else None, nslabs if want_b else 0,
+                             2 if want_b else 0, 2 if want_b else 0, nslabs, 0, 0, 0, 8, 8, 2, 8, ops.VS_WGRAD_SLABS, 0)
+        arr = (ops.WgradDesc * 1)(desc)
+        nbytes = lib.vs_conv_wgrad_multi_workspace_bytes(ctypes.addressof(arr), 1, dt)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        check(lib.vs_conv_wgrad_multi(ctypes.addressof(arr), 1, ws.data_ptr(), nbytes, dt, 1e-5, st), "wgrad_multi (slabs + bias partials)")
+        torch.cuda.synchronize()
+        assert _rel_l2(dw, dw_ref) < 2e-5
+        if want_b:
+            assert _rel_l2(db, db_ref) < 2e-5
+    # the bias partials need the slabs; neither gradient part is refused
+    assert lib.vs_conv_k3_softmax2_bwd_data(prob.data_ptr(), p_(gprob), p_(gcl), wpb.data_ptr(), y.data_ptr(), mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(),
+                                            None, s2.data_ptr(), n, d, h, w, dt, 1e-5, pdrop, seed, st) == -1
+    assert lib.vs_conv_k3_softmax2_bwd_data(prob.data_ptr(), None, None, wpb.data_ptr(), y.data_ptr(), mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(),
+                                            None, None, n, d, h, w, dt, 1e-5, pdrop, seed, st) == -1

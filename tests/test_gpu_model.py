@@ -357,6 +357,11 @@ def test_16bit_joint128_weight_gradients_same_with_and_without_m_packing(dtype, 
     every gradient of the default plan equals the unpacked plan's (VS_WGRAD_MPACK=0) up to the order of the fp32 sums, and the forced-on plan is the
     default plan bit for bit."""
     M, O, T = _mods()
+    from vae_segmentation_amd import ops
+    # the layers under test stay in the grouped launches: no weight gradient inside a backward-data launch (csrc/igemm_k3tw.h takes in_block.conv.3, up5's second
+    # conv and out_block by default)
+    monkeypatch.setattr(ops, "FUSE_WGRAD", False)
+    monkeypatch.setattr(ops, "FUSE_SOFTMAX_BWD", False)
     img, lab = O.synthetic_image(1, 128, 2).cuda(), O.synthetic_label(1, 128, 3).cuda()
     grads = {}
     for mode in ("default", "1", "0"):

@@ -683,3 +683,41 @@ def test_weight_gradient_fused_into_backward_data_matches_the_grouped_launch(dty
     # a second pass right away: the use counts start over when a backward pass ends
     _, n_again = run(True, False)
     assert n_again == 2
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("frozen", [False, True])
+def test_out_block_backward_one_launch_matches_the_three_launch_path(dtype, frozen):
+    """ConvK3SoftmaxCL.backward through vs_conv_k3_softmax2_bwd_data (ops._out_block_bwd_fused) against its softmax-backward + backward-data + grouped-gradient
+    form: both gradient parts of the probabilities (planar and channels-last), logit dropout, trainable and frozen (the VAE inside Joint) out_block."""
+    ops = _ops()
+    n, d, h, w = 2, 12, 16, 40
+    x = rnd(n, 8, d, h, w, seed=21)
+    wt, b = q(rnd(2, 8, 3, 3, 3, seed=22, scale=0.3), dtype), rnd(2, seed=23, scale=0.2)
+    gp = rnd(n, 2, d, h, w, seed=24).cuda()
+    gc = to_cl(rnd(n, 8, d, h, w, seed=25), 8, dtype)
+
+    def run(fuse):
+        ops.FUSE_SOFTMAX_BWD = fuse
+        taken = []
+        orig = ops._out_block_bwd_fused
+        ops._out_block_bwd_fused = lambda *a, **k: (lambda r: (taken.append(r is not None), r)[1])(orig(*a, **k))
+        try:
+            wg, bg = wt.clone().cuda().requires_grad_(not frozen), b.clone().cuda().requires_grad_(not frozen)
+            ops.stats_arena_begin(torch.device("cuda", 0))
+            x_cl = to_cl(x, 8, dtype).requires_grad_(True)
+            xs = ops.instnorm_stats(x_cl.detach())
+            prob, prob_cl = ops.ConvK3SoftmaxCL.apply(x_cl, xs, wg, bg, 0.2, 99)
+            ((prob * gp).sum() + (prob_cl.float() * gc.float()).sum()).backward()
+            torch.cuda.synchronize()
+            return [x_cl.grad.float().clone()] + ([] if frozen else [wg.grad.clone(), bg.grad.clone()]), taken
+        finally:
+            ops._out_block_bwd_fused = orig
+            ops.FUSE_SOFTMAX_BWD = True
+
+    ref, t_ref = run(False)
+    got, t_got = run(True)
+    assert t_ref == [False] and t_got == [True]
+    for a, r in zip(got, ref):
+        assert bool(torch.isfinite(a).all())
+        assert relerr(a.cpu(), r.cpu()) < 2e-5

@@ -263,6 +263,7 @@ __device__ i32x4 vs_raw_buffer_load_b128(i32x4 rsrc, int voffset, int soffset, i
 
 typedef __attribute__((ext_vector_type(2))) int i32x2;
 __device__ i32x2 vs_raw_buffer_load_b64(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2i32");
+__device__ int vs_raw_buffer_load_b32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.i32");
 // raw buffer store: lanes whose byte offset is out of range are dropped
 __device__ void vs_raw_buffer_store_b128(i32x4 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4i32");
 __device__ void vs_raw_buffer_store_b64(i32x2 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2i32");

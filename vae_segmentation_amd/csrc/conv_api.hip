@@ -180,6 +180,26 @@ extern "C" int vs_conv_k3_bwd_data_wgrad(const void* g, const void* act_x, const
                        stream, act_x, act_sums, nullptr, nullptr, slabs);
 }
 
+// out_block's backward in one launch: softmax backward while staging, backward-data with the fused IN-backward sums [, weight gradient slabs, bias partials]
+extern "C" int vs_conv_k3_softmax2_bwd_data(const float* prob, const float* gprob, const void* gprob_cl, const void* w_packed, void* y, const void* mask_x,
+                                            const double* mask_stats, double* sums, float* slabs, double* bias_part, int n, int d, int h, int w, int dtype,
+                                            float eps, float drop_p, unsigned long long drop_seed, void* stream) {
+    if (!prob || (!gprob && !gprob_cl) || !w_packed || !y || !mask_x || !mask_stats || !sums) return VS_EINVAL;
+    if (bias_part && !slabs) return VS_EINVAL;             // the bias partials travel with the weight gradient's slabs
+    if (!vs_conv_k3_bwd_data_wgrad_supported(n, d, h, w, 8, 8, dtype)) return VS_ESHAPE;
+    if (((uintptr_t)w_packed & 15) || ((uintptr_t)y & 15) || ((uintptr_t)mask_x & 15) || (gprob_cl && ((uintptr_t)gprob_cl & 15)) || (slabs && ((uintptr_t)slabs & 15)) ||
+        ((uintptr_t)prob & 3) || ((uintptr_t)gprob & 3)) return VS_EALIGN;
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return VS_EINVAL;
+    G1Params p{};
+    p.wp = w_packed; p.y = y; p.mask_x = mask_x; p.mask_stats = mask_stats; p.sums = sums;
+    p.sm_prob = prob; p.sm_gprob = gprob; p.sm_gcl = gprob_cl; p.wg_ws = slabs; p.wg_bias = bias_part;
+    p.drop_p = drop_p; p.drop_seed = drop_seed;
+    p.N = n; p.D = d; p.H = h; p.W = w; p.Do = d; p.Ho = h; p.Wo = w; p.C = 8; p.M = 8; p.rb_total = 1; p.nch = 1;
+    p.eps = eps;
+    p.inv_count_in = 1.0 / ((double)d * h * w); p.inv_count_out = p.inv_count_in;
+    return dispatch_k3(p, dtype, 8, 16, EPI_RAW, 0, 1, (hipStream_t)stream);
+}
+
 static int scatter_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias, void* y,
                         const void* mask_x, const double* mask_stats, double* sums, int n, int d, int h, int w, int c_in,
                         int m_out, int dtype, float eps, void* stream) {

@@ -52,6 +52,12 @@ struct G1Params {
     int up_co;
     // k3tw_kernel (igemm_k3tw.h): backward-data with the layer's weight gradient fused — one slab [27][8][8] per workgroup goes here
     float* wg_ws;
+    // ... and its out_block form: the input gradient is the two-class softmax backward of (sm_prob, sm_gprob [+ sm_gcl]) formed while staging (drop_p / drop_seed
+    // as in the forward); wg_bias (nullable) receives one (sum gl0, sum gl1) pair of doubles per workgroup
+    const float* sm_prob;
+    const float* sm_gprob;
+    const void* sm_gcl;
+    double* wg_bias;
 };
 
 // LDS carve (bytes)

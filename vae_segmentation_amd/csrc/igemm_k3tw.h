@@ -34,9 +34,14 @@ __device__ __forceinline__ u32x4 pw_tr_pair(const char* s_base, int off0, int of
 #define K3TW_ACC_BYTES (4 * 6 * 64 * 16)   // [wave][block][lane] f32x4
 #define K3TW_SLAB_ELEMS 1728               // [tap 27][c 8][m 8]
 
-template <typename T, bool FA>
+// MODE: how the gradient tile is staged — 0: the applied gradient as stored; 1 (FA): un-applied, with the IN-backward apply of its activation (k3t_kernel FA);
+// 2 (SM, out_block): the two-class softmax backward of planar probabilities and their gradients [+ a channels-last gradient part], logits' dropout included —
+// the launch vs_softmax2_cl_bwd and the tensor it wrote disappear.  WG: form the weight gradient (the frozen VAE's out_block wants SM without it).
+template <typename T, int MODE, bool WG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k3tw_kernel(const G1Params p) {
     constexpr int YT = 8;
+    constexpr bool FA = MODE == 1, SM = MODE == 2;
+    static_assert(WG || SM, "without the weight gradient this is k3t_kernel, except for the softmax-backward staging");
     using GEO = K3TGeom<YT>;
     constexpr int PX = GEO::PX, PY = GEO::PY, PLANE = GEO::PLANE, TV = GEO::TV, NIT = GEO::NIT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -53,8 +58,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int dx2 = g >> 1, c4 = 4 * (g & 1);
     const int total_tiles = p.tiles_per_sample * p.N;
-    const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * 16));
-    const i32x4 frsrc = make_rsrc(FA ? p.fa_x : p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * 16));
+    const long long vol = (long long)p.D * p.H * p.W;
+    const i32x4 xrsrc = make_rsrc(SM ? (const void*)p.sm_prob : p.x, (unsigned int)(SM ? p.N * vol * 8 : p.N * vol * 16));
+    const i32x4 frsrc = make_rsrc(FA ? p.fa_x : (SM ? p.sm_gcl : p.x), (unsigned int)((FA || (SM && p.sm_gcl != nullptr)) ? p.N * vol * 16 : 0));
+    const i32x4 grsrc = make_rsrc(SM ? (const void*)p.sm_gprob : p.x, (unsigned int)((SM && p.sm_gprob != nullptr) ? p.N * vol * 8 : 0));      // absent parts read as zero
 
     const double* st_src = p.mask_stats;
     const int st_n = p.N * 8;
@@ -76,8 +83,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         rel_off[b] = ((tz_ * p.H + ty_) * p.W + tx_) * 16;
         tzyx[b] = tv < TV ? (tz_ | (ty_ << 8) | (tx_ << 16)) : 0x00ffffff;
     }
-    u32x4 xv[NIT], fv[FA ? NIT : 1];
+    u32x4 xv[NIT], fv[(FA || SM) ? NIT : 1];
     unsigned int okbits = 0;
+    unsigned int cbits = 0;                              // SM: fragment b is a centre (non-halo) voxel of the tile (the bias gradient sums those)
+    float bsum[2] = {0.f, 0.f};
+    if constexpr (SM) {
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) {
+            const int tv = tid + b * 256;
+            const int tx_ = tv % PX, ty_ = (tv / PX) % PY, tz_ = tv / PLANE;
+            cbits |= (tv < TV && tz_ >= 1 && tz_ <= 4 && ty_ >= 1 && ty_ <= YT && tx_ >= 1 && tx_ <= 32) ? (1u << b) : 0u;
+        }
+    }
     struct Coord { int n, z0, y0, x0; };
     auto tile_coord = [&](int t) {
         Coord c;
@@ -97,8 +114,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int gz = c.z0 - 1 + (tzyx[b] & 0xff), gy = c.y0 - 1 + ((tzyx[b] >> 8) & 0xff), gx = c.x0 - 1 + (tzyx[b] >> 16);
             const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             okbits |= ok ? (1u << b) : 0u;
-            xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, ok ? base + rel_off[b] : -1, 0, 0));
-            if constexpr (FA) fv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(frsrc, ok ? base + rel_off[b] : -1, 0, 0));
+            if constexpr (SM) {
+                // planar fp32 [N][2][V]: voxel index within the sample = (base + rel_off) / 16 - n V
+                const int vi = ((base + rel_off[b]) >> 4) - c.n * (int)vol;
+                const int o0 = ok ? ((c.n * 2) * (int)vol + vi) * 4 : -1, o1 = ok ? ((c.n * 2 + 1) * (int)vol + vi) * 4 : -1;
+                xv[b][0] = (unsigned int)vs_raw_buffer_load_b32(xrsrc, o0, 0, 0);
+                xv[b][1] = (unsigned int)vs_raw_buffer_load_b32(xrsrc, o1, 0, 0);
+                xv[b][2] = (unsigned int)vs_raw_buffer_load_b32(grsrc, o0, 0, 0);
+                xv[b][3] = (unsigned int)vs_raw_buffer_load_b32(grsrc, o1, 0, 0);
+                fv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(frsrc, ok ? base + rel_off[b] : -1, 0, 0));
+            } else {
+                xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, ok ? base + rel_off[b] : -1, 0, 0));
+                if constexpr (FA) fv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(frsrc, ok ? base + rel_off[b] : -1, 0, 0));
+            }
+        }
+    };
+    auto write_x_sm = [&](const Coord& c) {              // softmax2_bwd_kernel (misc.hip) on the staged voxels
+        const int base = (((c.n * p.D + c.z0 - 1) * p.H + c.y0 - 1) * p.W + c.x0 - 1) * 16;
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) {
+            const float p0 = __uint_as_float(xv[b][0]), p1 = __uint_as_float(xv[b][1]);
+            const float g0 = __uint_as_float(xv[b][2]) + H16<T>::lo(fv[b][0]), g1 = __uint_as_float(xv[b][3]) + H16<T>::hi(fv[b][0]);
+            const float dot = p0 * g0 + p1 * g1;
+            f32x2 f;
+            f[0] = p0 * (g0 - dot);
+            f[1] = p1 * (g1 - dot);
+            if (p.drop_p > 0.f) {                         // workgroup-uniform: backward of the logit dropout fused into the out_block epilogue
+                const long long vi = (long long)((base + rel_off[b]) >> 4) - (long long)c.n * vol;
+                f[0] *= dropout_scale(p.drop_seed, ((unsigned long long)c.n * 2 + 0) * (unsigned long long)vol + (unsigned long long)vi, p.drop_p);
+                f[1] *= dropout_scale(p.drop_seed, ((unsigned long long)c.n * 2 + 1) * (unsigned long long)vol + (unsigned long long)vi, p.drop_p);
+            }
+            const bool ok = (okbits >> b) & 1u;
+            u32x4 v = u32x4{ok ? H16<T>::pack2(f) : 0u, 0u, 0u, 0u};
+            *(u32x4*)(s_tile + (tid + b * 256) * 16) = v;
+            if (ok && ((cbits >> b) & 1u)) { bsum[0] += H16<T>::lo(v[0]); bsum[1] += H16<T>::hi(v[0]); }      // the stored (rounded) values, as vs_bias_grad summed them
         }
     };
     auto write_x_fa = [&](const Coord& c) {
@@ -184,12 +233,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // B (P halo tile): channels 4*half .. of voxel (z + dz, 2s + dy', 16h + 4g + q4 + dx), dx = 2 dxb + hi2 (dxb = 1: dx = 2 for both column halves)
     const int b_lane = (4 * g + q4) * 16 + half * 8;
     int b_blk[6];
+    if constexpr (WG) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int blk = wave + 4 * j;
-        const int dz = blk >> 3, dyp = (blk & 7) >> 1, dxb = blk & 1;
-        b_blk[j] = ((dz * PY + dyp) * PX + (dxb ? 2 : hi2)) * 16 + b_lane;
-        s_acc[(wave * 6 + j) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};           // own slot: read back by this lane only until the end
+        for (int j = 0; j < 6; ++j) {
+            const int blk = wave + 4 * j;
+            const int dz = blk >> 3, dyp = (blk & 7) >> 1, dxb = blk & 1;
+            b_blk[j] = ((dz * PY + dyp) * PX + (dxb ? 2 : hi2)) * 16 + b_lane;
+            s_acc[(wave * 6 + j) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};       // own slot: read back by this lane only until the end
+        }
     }
     bool first = true;
     __syncthreads();
@@ -201,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool zx_ok = oz < p.D && ox < p.W;
         if (!first) __syncthreads();
         first = false;
-        if constexpr (FA) write_x_fa(cur); else write_x(n);
+        if constexpr (FA) write_x_fa(cur); else if constexpr (SM) write_x_sm(cur); else write_x(n);
         __syncthreads();
         u32x2 mk[YT];
 #pragma unroll
@@ -257,9 +308,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     // grouped weight-gradient launch forms with act8
                     qv[r] = valid ? fmaxf(fmaf(xv4[r], mr[r], -mm[r] * mr[r]), 0.f) : 0.f;
                 }
-                f32x2 q0, q1;
-                q0[0] = qv[0]; q0[1] = qv[1]; q1[0] = qv[2]; q1[1] = qv[3];
-                *(u32x2*)(s_q + ((wave * 8 + cg) * 32 + 2 * col + dx2) * 16 + c4 * 2) = u32x2{H16<T>::pack2(q0), H16<T>::pack2(q1)};
+                if constexpr (WG) {
+                    f32x2 q0, q1;
+                    q0[0] = qv[0]; q0[1] = qv[1]; q1[0] = qv[2]; q1[1] = qv[3];
+                    *(u32x2*)(s_q + ((wave * 8 + cg) * 32 + 2 * col + dx2) * 16 + c4 * 2) = u32x2{H16<T>::pack2(q0), H16<T>::pack2(q1)};
+                }
             }
             const bool flush = t + G >= t_end || nxt.n != n;
             if (flush) {
@@ -285,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 
         // ---- weight gradient of this tile: every wave walks the 16 K-steps (z slice, y pair) for its six blocks ----
-        {
+        if constexpr (WG) {
             __syncthreads();                             // the Q tile of all four z slices is complete
             f32x4 wacc[6];
 #pragma unroll
@@ -323,7 +376,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- this workgroup's slab [tap 27][c 8][m 8]: a tap's sum arrives in two parts (the even y rows in block dy' = dy, the odd ones in block dy' = dy + 1,
     // held by different waves); they meet here and the slab goes out as contiguous floats ----
     __syncthreads();
-    {
+    if constexpr (SM) {
+        if (p.wg_bias != nullptr) {                      // this workgroup's share of the bias gradient: sum of the staged centre voxels' logit gradients
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float sb = bsum[k];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) sb += __shfl_xor(sb, off, 64);
+                if (lane == 0) s_red[wave * 2 + k] = sb;
+            }
+            __syncthreads();
+            if (tid < 2) p.wg_bias[(size_t)blockIdx.x * 2 + tid] = (double)s_red[tid] + (double)s_red[2 + tid] + (double)s_red[4 + tid] + (double)s_red[6 + tid];
+        }
+    }
+    if constexpr (WG) {
         float* wsg = p.wg_ws + (size_t)blockIdx.x * 1728;
         const float* s_accf = (const float*)s_acc;
         for (int o = tid; o < 1728; o += 256) {
@@ -355,9 +421,11 @@ static int k3tw_launch(const G1Params& p_in, hipStream_t stream) {
     using GEO = K3TGeom<8>;
     G1Params p = p_in;
     if (p.C != 8 || p.M != 8 || p.N * 8 > 192) return VS_ESHAPE;
-    if (!p.wg_ws || !p.sums || !p.mask_x || !p.mask_stats) return VS_EINVAL;
-    const bool fa = p.fa_x != nullptr;
-    if (fa && (!p.x_stats || !p.fa_sums)) return VS_EINVAL;
+    if (!p.sums || !p.mask_x || !p.mask_stats) return VS_EINVAL;
+    const bool fa = p.fa_x != nullptr, sm = p.sm_prob != nullptr, wg = p.wg_ws != nullptr;
+    if (fa && (sm || !p.x_stats || !p.fa_sums)) return VS_EINVAL;
+    if (sm ? (!p.sm_gprob && !p.sm_gcl) : (!wg || !p.x)) return VS_EINVAL;
+    if ((long long)p.N * p.D * p.H * p.W * 8 >= 2147483648ll) return VS_ESHAPE;       // planar fp32 byte offsets are 32-bit too
     const size_t lds = K3T_LDS_TILE + (size_t)GEO::TILE_BYTES + K3TW_Q_BYTES + K3TW_ACC_BYTES + (size_t)8 * p.N * 8 * sizeof(float);
     p.txn = (p.W + 31) / 32;
     p.tyn = (p.H + 7) / 8;
@@ -368,17 +436,17 @@ static int k3tw_launch(const G1Params& p_in, hipStream_t stream) {
     k3b_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3b_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
     const int gx = k3tw_grid(p.N, p.D, p.H, p.W);
-    if (fa) {
-        auto kern = k3tw_kernel<T, true>;
-        static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (attr_err != hipSuccess) return (int)attr_err;
-        hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, stream, p);
-    } else {
-        auto kern = k3tw_kernel<T, false>;
-        static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (attr_err != hipSuccess) return (int)attr_err;
-        hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, stream, p);
+#define K3TW_GO(MODEV, WGV)                                                                                                              \
+    {                                                                                                                                    \
+        auto kern = k3tw_kernel<T, MODEV, WGV>;                                                                                          \
+        static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        if (attr_err != hipSuccess) return (int)attr_err;                                                                                \
+        hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, stream, p);                                                                   \
     }
+    if (sm) { if (wg) K3TW_GO(2, true) else K3TW_GO(2, false) }
+    else if (fa) K3TW_GO(1, true)
+    else K3TW_GO(0, true)
+#undef K3TW_GO
     VS_CHECK_LAUNCH();
     return VS_OK;
 }

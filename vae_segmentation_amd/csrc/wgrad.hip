@@ -1845,6 +1845,7 @@ static std::vector<vs_wgrad_desc> without_slab_descs(const vs_wgrad_desc* descs,
 }
 static int slab_desc_validate(const vs_wgrad_desc& d) {
     if (!d.p || !d.dw || d.n <= 0 || ((uintptr_t)d.p & 15)) return VS_EINVAL;
+    if (d.bias_g && (!d.db || d.bias_c_real <= 0 || d.bias_c_real > 8 || d.bias_rows != d.n || ((uintptr_t)d.bias_g & 7))) return VS_EINVAL;    // double [n][bias_c_real] partials
     if (d.m_real <= 0 || d.m_real > 8 || d.c_real <= 0 || d.c_real > 8 || d.m_ch != 8 || d.c_ch != 8) return VS_ESHAPE;
     return VS_OK;
 }
@@ -1852,16 +1853,29 @@ static void slab_red_entry(const vs_wgrad_desc& d, G3RedDesc& r, int& blocks) {
     r = G3RedDesc{(const float*)d.p, d.dw, d.m_real, d.c_real, 1, 1, d.n, 0x208, 27, 27, 0, G3_RED_ROWS, 0};
     blocks = 1728 / 64;                                  // 16 vectors of 4 elements per block (g3_reduce_group_kernel)
 }
+// the bias partials a slab descriptor may carry (vs_conv_k3_softmax2_bwd_data): one more entry of the bias kind
+static void slab_bias_entry(const vs_wgrad_desc& d, G3RedDesc& r, int& blocks) {
+    r = G3RedDesc{(const float*)d.bias_g, d.db, 0, d.bias_c_real, 0, 0, d.n, 0, 0, 0, 1, G3_RED_ROWS, 0};
+    blocks = vs_ceil_div(d.bias_c_real, 64);
+}
 static int slab_reduce_only(const std::vector<vs_wgrad_desc>& slabs, hipStream_t st) {
-    for (size_t at = 0; at < slabs.size(); at += G3_RED_MAX) {
+    std::vector<G3RedDesc> ents;
+    std::vector<int> nbs;
+    for (const vs_wgrad_desc& sd : slabs) {
+        G3RedDesc r;
+        int nb = 0;
+        slab_red_entry(sd, r, nb);
+        ents.push_back(r); nbs.push_back(nb);
+        if (sd.bias_g) { slab_bias_entry(sd, r, nb); ents.push_back(r); nbs.push_back(nb); }
+    }
+    for (size_t at = 0; at < ents.size(); at += G3_RED_MAX) {
         G3RedGroup grp{};
-        grp.n = (int)std::min<size_t>(G3_RED_MAX, slabs.size() - at);
+        grp.n = (int)std::min<size_t>(G3_RED_MAX, ents.size() - at);
         long long blk = 0;
         for (int j = 0; j < grp.n; ++j) {
-            int nb = 0;
-            slab_red_entry(slabs[at + j], grp.d[j], nb);
+            grp.d[j] = ents[at + j];
             grp.blk_start[j] = (int)blk;
-            blk += nb;
+            blk += nbs[at + j];
         }
         for (int j = grp.n; j <= G3_RED_MAX; ++j) grp.blk_start[j] = (int)blk;
         hipLaunchKernelGGL(g3_reduce_group_kernel, dim3((unsigned)blk), dim3(64 * G3_RED_ROWS), 0, st, grp);
@@ -2171,6 +2185,7 @@ static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspa
             slab_red_entry(sd, r, nb);
             red.push_back(r);
             blocks.push_back(nb);
+            if (sd.bias_g) { slab_bias_entry(sd, r, nb); red.push_back(r); blocks.push_back(nb); }
         }
         for (size_t at = 0; at < red.size(); at += G3_RED_MAX) {
             G3RedGroup grp{};

@@ -579,7 +579,7 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None, 
         slabs = torch.empty(nslabs * 1728, dtype=torch.float32, device=x.device)
         kid = nb = fl = None
         if PROFILE is not None:
-            kid = _k3_kid(_tname(x), 8, 16, sums=True, geom=(gn, gd, gh, gw), m=c) + ("+apply" if lazy is not None else "") + "+wgrad"
+            kid = "k3tw_kernel<%s,%s>" % (_tname(x), "true" if lazy is not None else "false")
             nb = ((3 if lazy is not None else 2) * gy.numel() + 2 * g.numel()) * _esize(x)
             fl = 2.0 * 2.0 * (g.numel() // c) * 27 * gc * c
         with _timed(kid, nb, fl, "bwd+wgrad gy%s->m%d" % (tuple(gy.shape), c)):
@@ -850,15 +850,21 @@ def _wgrad_fusable(gy, x, weight):
     return bool(lib.vs_conv_k3_bwd_data_wgrad_supported(n, d, h, w, 8, 8, vs_dtype(gy)))
 
 
-def _group_submit_slabs(weight, slabs, nslabs, m_real, c_real, keep):
-    """register the slabs of a fused launch with the pass's grouped weight gradients; -> the (still unwritten) gradient tensor handed to autograd"""
+def _group_submit_slabs(weight, slabs, nslabs, m_real, c_real, keep, bias=None):
+    """register the slabs of a fused launch with the pass's grouped weight gradients; -> the (still unwritten) gradient tensor handed to autograd
+    (bias = (parameter, partial sums double [nslabs][m_real]): -> (gw, gb))"""
     g = _GROUP
     if g["descs"] and g["dtype"] != keep[0].dtype:
         flush_wgrads()
     g["dtype"] = keep[0].dtype
     gw = _grad_slot(weight, weight.shape)
-    g["slots"][id(weight)] = (gw.data_ptr(), None)
+    gb = None
     d = WgradDesc(slabs.data_ptr(), None, None, None, gw.data_ptr(), None, None, 0, 0, 0, nslabs, 0, 0, 0, 8, 8, m_real, c_real, VS_WGRAD_SLABS, 0)
+    if bias is not None:
+        gb = _grad_slot(bias[0], (m_real,))
+        d.bias_g, d.db, d.bias_rows, d.bias_c_ch, d.bias_c_real = bias[1].data_ptr(), gb.data_ptr(), nslabs, m_real, m_real
+        g["keep"].append(bias[1])
+    g["slots"][id(weight)] = (gw.data_ptr(), None if gb is None else gb.data_ptr())
     first = g["split"] is None or bool(g["split"](weight))
     g["descs"].append((d, first, float(slabs.numel() * 4), 0.0, 0))
     g["keep"].append(slabs)
@@ -868,7 +874,7 @@ def _group_submit_slabs(weight, slabs, nslabs, m_real, c_real, keep):
             g["callback"] = True
         except RuntimeError:
             flush_wgrads()
-    return gw
+    return gw if bias is None else (gw, gb)
 
 
 def _grad_slot(param, shape):
@@ -1112,6 +1118,8 @@ class ConvK3SoftmaxCL(torch.autograd.Function):
         ctx.bias_ref = bias
         ctx.drop = (float(drop_p), drop_seed)
         ctx.defer = bool(getattr(x, "_vs_defer_apply", False)) and xs is not None
+        if ctx.needs_input_grad[2]:
+            _count_use(weight)                # see _wgrad_fusable
         ctx.set_materialize_grads(False)
         return prob, prob_cl
 
@@ -1123,6 +1131,9 @@ class ConvK3SoftmaxCL(torch.autograd.Function):
         n, d, h, w, c = x.shape
         gprob = None if gprob is None else _contig(gprob.float())
         gcl = None if gcl is None else _contig(gcl)
+        fused = _out_block_bwd_fused(ctx, x, xs, weight, prob, gprob, gcl)
+        if fused is not None:
+            return fused
         gl = torch.empty((n, d, h, w, 8), dtype=x.dtype, device=x.device)
         check(lib.vs_softmax2_cl_bwd(prob.data_ptr(), _p(gprob), _p(gcl), gl.data_ptr(), n, d * h * w, 8, vs_dtype(x), ctx.drop[0], ctx.drop[1],
                                      _stream()), "softmax2_cl_bwd")
@@ -1139,6 +1150,55 @@ class ConvK3SoftmaxCL(torch.autograd.Function):
         elif ctx.has_bias and ctx.needs_input_grad[3]:
             gb = bias_grad(gl, 2)
         return gx, None, gw, gb, None, None
+
+
+FUSE_SOFTMAX_BWD = os.environ.get("VS_FUSE_SOFTMAX_BWD", "1") != "0"
+
+
+def _out_block_bwd_fused(ctx, x, xs, weight, prob, gprob, gcl):
+    """out_block's backward as ONE launch (vs_conv_k3_softmax2_bwd_data, csrc/igemm_k3tw.h SM): the softmax backward runs while the backward-data kernel stages
+    its tile — the gradient of the logits is never stored — and a trainable layer's weight and bias gradients come out of the same launch (slabs + partials for the
+    grouped reduction).  -> the tuple ConvK3SoftmaxCL.backward returns, or None when this launch does not apply (the three-launch path then runs)."""
+    n, d, h, w, c = x.shape
+    want_w, want_b = ctx.needs_input_grad[2], ctx.has_bias and ctx.needs_input_grad[3]
+    if not (FUSE_SOFTMAX_BWD and ctx.needs_input_grad[0] and xs is not None and c == 8 and (gcl is None or gcl.shape[-1] == 8)):
+        return None
+    if not lib.vs_conv_k3_bwd_data_wgrad_supported(n, d, h, w, 8, 8, vs_dtype(x)):
+        return None
+    if want_w:
+        if not _wgrad_fusable(x, x, weight):    # (the logits' gradient has x's grid, storage type and 8 stored channels)
+            return None
+        bias = ctx.bias_ref
+        if want_b and not (bias.is_leaf and bias.grad is None and not _has_hooks(bias)):
+            return None
+    elif want_b:
+        return None                             # a frozen weight under a trainable bias: not a configuration of the reference
+    wpb = pack_weight_cached(weight, VS_PACK_ROWS_D1_FLIP, 8, k3_pack_dtype(x))
+    sums = _new_stats(n, c, x.device)
+    g = torch.empty_like(x)
+    nslabs = lib.vs_conv_k3_bwd_data_wgrad_slabs(n, d, h, w) if want_w else 0
+    slabs = torch.empty(nslabs * 1728, dtype=torch.float32, device=x.device) if want_w else None
+    bpart = torch.empty(nslabs * 2, dtype=torch.float64, device=x.device) if (want_w and want_b) else None
+    kid = nb = fl = None
+    if PROFILE is not None:
+        kid = "k3tw_kernel<%s,2,%s>" % (_tname(x), "true" if want_w else "false")
+        nb = (4 * n * d * h * w * 4) + (0 if gcl is None else gcl.numel() * _esize(x)) + 2 * g.numel() * _esize(x)
+        fl = (2.0 if want_w else 1.0) * 2.0 * (g.numel() // c) * 27 * 2 * weight.shape[1]
+    with _timed(kid, nb, fl, "out_block bwd%s (%d, %d, %d, %d)" % ("+wgrad" if want_w else "", n, d, h, w)):
+        check(lib.vs_conv_k3_softmax2_bwd_data(prob.data_ptr(), _p(gprob), _p(gcl), wpb.data_ptr(), g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(),
+                                               _p(slabs), _p(bpart), n, d, h, w, vs_dtype(x), EPS_IN, ctx.drop[0], ctx.drop[1], _stream()),
+              "conv_k3_softmax2_bwd_data")
+    gw = gb = None
+    if want_w:
+        if want_b:
+            gw, gb = _group_submit_slabs(weight, slabs, nslabs, 2, weight.shape[1], (x,), bias=(ctx.bias_ref, bpart))
+        else:
+            gw = _group_submit_slabs(weight, slabs, nslabs, 2, weight.shape[1], (x,))
+    if ctx.defer:
+        _defer_register(g, x, xs, sums)
+    else:
+        _apply_in_place(g, x, xs, sums)
+    return g, None, gw, gb, None, None
 
 
 def out_block_softmax(x, xs, weight, bias, drop_p=0.0, drop_seed=0):

@@ -126,7 +126,7 @@ def measured_step_traffic(path=None):
 FAMILIES = (
     ("conv3x3x3, C>=32 levels (k3b<32,..>, k3s)", lambda k: k.startswith("k3b_kernel<32") or k.startswith("k3s_kernel") or k.startswith("chain")),
     ("conv3x3x3, 16-channel layers (k3b<16|8,..>)", lambda k: k.startswith("k3b_kernel<16") or k.startswith("k3b_kernel<8")),
-    ("conv3x3x3, 8-channel full-resolution layers (k3t)", lambda k: k.startswith("k3t_kernel")),
+    ("conv3x3x3, 8-channel full-resolution layers (k3t; k3tw = backward-data + the layer's weight gradient)", lambda k: k.startswith("k3t_kernel") or k.startswith("k3tw_kernel")),
     ("conv3x3x3, fp32 kernels (k3_kernel<float>)", lambda k: k.startswith("k3_kernel")),
     ("composed Up heads: transposed conv + 3x3x3 as one operator (k4t, k4g)", lambda k: k.startswith("k4t_kernel") or k.startswith("k4g_kernel")),
     ("stride-2 / transposed convs (g1)", lambda k: k.startswith("g1_kernel")),
