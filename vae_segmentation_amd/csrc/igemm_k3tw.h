@@ -10,7 +10,7 @@
 // Operands exchanged as in wgrad.hip multi_plan:  S[o][c][m] = sum_v Q(v)[c] * P(v + o)[m]  = dW[m][c][-o], K = voxels through ds_read_b64_tr_b16.
 // One MFMA (16x16x32) covers a whole 32-voxel x row: rows (r, c) = the two y rows of a pair x 8 input channels, columns (t, m) = two neighbouring x taps x 8
 // gradient channels, against halo row 2s + dy' (dy' = 0..3): row r meets tap dy = dy' - r.  24 blocks (dz 3 x dy' 4 x dx pair 2: 27 useful taps of 48
-// computed) x 16 K-steps per tile = 384 MFMAs and 304 transposing read pairs per tile next to the backward-data's 288 MFMAs; the four waves split the BLOCKS (six each: 24 accumulator registers,
+// computed) x 16 K-steps per tile = 384 MFMAs and 184 transposing read pairs per tile next to the backward-data's 288 MFMAs; the four waves split the BLOCKS (six each: 24 accumulator registers,
 // parked in LDS between tiles — the kernel stays at two waves per SIMD) and walk all K-steps.  One slab [27][8][8] per workgroup; the grouped reduction
 // (g3_reduce_group_kernel, VS_WGRAD_SLABS descriptors) sums them in a fixed order.
 // Measured standalone at 2 x 96^3 (tools/k3tw_probe.py, profiles/r05_k3tw_probe.txt): +4.7 us on the fused-apply launch (which no longer stores the applied
@@ -343,27 +343,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             f32x4 wacc[6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) wacc[j] = s_acc[(wave * 6 + j) * 64 + lane];
-            // this wave's blocks are (dz = j >> 1, dy' = a + 2 (j & 1), dx pair w & 1), a = w >> 1: halo row a + 2 s + 2 serves (s, dy' = a + 2) and (s + 1, dy' = a) —
-            // five transposing reads per (z, dz) feed the eight MFMAs of the four y pairs (one read per MFMA before: these reads are what the phase costs)
+            // this wave's blocks are (dz = j >> 1, dy' = a + 2 (j & 1), dx pair w & 1), a = w >> 1.  A halo-row fragment depends on the tile plane tz = z + dz, the
+            // row and the dx pair only: plane tz serves up to three (z, dz) combinations, and within a combination row a + 2 s + 2 serves (s, dy' = a + 2) and
+            // (s + 1, dy' = a).  Walking the six planes, five transposing read pairs feed up to 24 MFMAs (one pair per MFMA in the first version, then five per
+            // eight): 46 read pairs per tile and wave instead of 112 / 76 — these reads are what the phase costs.
+            u32x4 af[4][4];
 #pragma unroll
-            for (int z = 0; z < 4; ++z) {
-                u32x4 af[4];
+            for (int z = 0; z < 4; ++z)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int ao = a_lane + ((z * 8 + 2 * s) * 32) * 16;
-                    af[s] = pw_tr_pair(s_q, ao, ao + 16 * 16);
+                    af[z][s] = pw_tr_pair(s_q, ao, ao + 16 * 16);
+                }
+            const int b_row0 = b_blk[0];                 // block (dz = 0, dy' = a): its plane-0 address; plane tz and row step are immediates
+#pragma unroll
+            for (int tz = 0; tz < 6; ++tz) {
+                u32x4 rows[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int bn = b_row0 + ((tz * PY + 2 * k) * PX) * 16;
+                    rows[k] = pw_tr_pair(s_tile, bn, bn + 16 * 16);
                 }
 #pragma unroll
                 for (int dz = 0; dz < 3; ++dz) {
-                    const int bo = b_blk[2 * dz] + ((z * PY) * PX) * 16;
-                    u32x4 prev = pw_tr_pair(s_tile, bo, bo + 16 * 16);
+                    const int z = tz - dz;
+                    if (z >= 0 && z <= 3) {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const int bn = bo + ((2 * s + 2) * PX) * 16;
-                        const u32x4 cur = pw_tr_pair(s_tile, bn, bn + 16 * 16);
-                        wacc[2 * dz] = mfma16(af[s], prev, wacc[2 * dz], (T*)nullptr);
-                        wacc[2 * dz + 1] = mfma16(af[s], cur, wacc[2 * dz + 1], (T*)nullptr);
-                        prev = cur;
+                        for (int s = 0; s < 4; ++s) {
+                            wacc[2 * dz] = mfma16(af[z][s], rows[s], wacc[2 * dz], (T*)nullptr);
+                            wacc[2 * dz + 1] = mfma16(af[z][s], rows[s + 1], wacc[2 * dz + 1], (T*)nullptr);
+                        }
                     }
                 }
             }
