@@ -687,7 +687,8 @@ def test_weight_gradient_fused_into_backward_data_matches_the_grouped_launch(dty
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("frozen", [False, True])
-def test_out_block_backward_one_launch_matches_the_three_launch_path(dtype, frozen):
+@pytest.mark.parametrize("cl", [True, False])
+def test_out_block_backward_one_launch_matches_the_three_launch_path(dtype, frozen, cl):
     """ConvK3SoftmaxCL.backward through vs_conv_k3_softmax2_bwd_data (ops._out_block_bwd_fused) against its softmax-backward + backward-data + grouped-gradient
     form: both gradient parts of the probabilities (planar and channels-last), logit dropout, trainable and frozen (the VAE inside Joint) out_block."""
     ops = _ops()
@@ -707,8 +708,12 @@ def test_out_block_backward_one_launch_matches_the_three_launch_path(dtype, froz
             ops.stats_arena_begin(torch.device("cuda", 0))
             x_cl = to_cl(x, 8, dtype).requires_grad_(True)
             xs = ops.instnorm_stats(x_cl.detach())
-            prob, prob_cl = ops.ConvK3SoftmaxCL.apply(x_cl, xs, wg, bg, 0.2, 99)
-            ((prob * gp).sum() + (prob_cl.float() * gc.float()).sum()).backward()
+            if cl:                               # the prediction that another network reads (Joint: Segmentation -> VAE)
+                prob, prob_cl = ops.ConvK3SoftmaxCL.apply(x_cl, xs, wg, bg, 0.2, 99)
+                ((prob * gp).sum() + (prob_cl.float() * gc.float()).sum()).backward()
+            else:                                # the VAE's own out_block
+                prob = ops.ConvK3Softmax.apply(x_cl, xs, wg, bg, 0.2, 99)
+                (prob * gp).sum().backward()
             torch.cuda.synchronize()
             return [x_cl.grad.float().clone()] + ([] if frozen else [wg.grad.clone(), bg.grad.clone()]), taken
         finally:

@@ -1066,6 +1066,8 @@ class ConvK3Softmax(torch.autograd.Function):
         ctx.bias_ref = bias
         ctx.drop = (float(drop_p), drop_seed)
         ctx.defer = bool(getattr(x, "_vs_defer_apply", False)) and xs is not None
+        if ctx.needs_input_grad[2]:
+            _count_use(weight)                # see _wgrad_fusable
         return prob
 
     @staticmethod
@@ -1074,6 +1076,10 @@ class ConvK3Softmax(torch.autograd.Function):
         n, d, h, w, c = x.shape
         gprob = _contig(gprob.float())
         nc = weight.shape[0]
+        if nc == 2 and x.dtype != torch.float32:
+            fused = _out_block_bwd_fused(ctx, x, xs, weight, prob, gprob, None)      # the whole backward as one launch (csrc/igemm_k3tw.h SM)
+            if fused is not None:
+                return fused
         gl = torch.empty((n, d, h, w, 8), dtype=x.dtype, device=x.device)
         if nc == 2:
             check(lib.vs_softmax2_dropout_bwd(prob.data_ptr(), gprob.data_ptr(), gl.data_ptr(), n, d * h * w, 8, vs_dtype(x),
