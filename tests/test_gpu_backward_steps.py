@@ -25,12 +25,23 @@ def _planar(t, c):
     return t.double().cpu()[..., :c].permute(0, 4, 1, 2, 3).contiguous()
 
 
-def _rl(a, b, y):
+def _seed_band(y_seed):
+    """Where the SEED gradient of a step was recorded un-applied (deferred apply), the recomputation applies it in fp64 while HIP's fused kernel applied it with its
+    fp32 x_hat: an element of the seed's activation inside the ReLU rounding band may take a different mask there, and through the 3x3x3 backward-data conv that ONE
+    element reaches its 27 neighbours in every channel (seen when the row-tile policy of the upstream launches changed their rounding: one such voxel of
+    up5.conv.6 at 96^3 = 1.5e-4 of the step's norm).  -> [N, 1, D, H, W] mask of the output voxels such a seed element can reach (left out of the norm, counted)."""
+    band = (F.instance_norm(y_seed.detach(), eps=1e-5).abs() < 1e-5).any(dim=1, keepdim=True)
+    return F.max_pool3d(band.double(), 3, stride=1, padding=1) > 0
+
+
+def _rl(a, b, y, reach=None):
     """relative L2 distance of two gradients w.r.t. the raw activation y, outside the ReLU's rounding band: an element whose normalised value
     |x_hat| is below 1e-5 can fall on either side of the ReLU under fp32 rounding (HIP evaluates x_hat in fp32, the recomputation in fp64), and ONE
     such element among the 14 M of a 96^3 x 8 tensor is a relative L2 difference of ~1e-4 (a typical element is 1/sqrt(14 M) = 2.7e-4 of the norm) —
     seen once the upstream fp32 kernels changed their rounding.  Those elements (a handful per tensor; counted and printed) are left out of the norm."""
     band = F.instance_norm(y.detach(), eps=1e-5).abs() < 1e-5
+    if reach is not None:
+        band = band | reach
     d = (a - b).masked_fill(band, 0.0)
     return float(d.norm() / b.norm().clamp_min(1e-300)), int(band.sum())
 
@@ -86,8 +97,8 @@ def test_seg96_every_backward_step_matches_fp64_recomputation(monkeypatch):
         return act_of_leaf.grad if deferred[name] else leaf.grad
     results = []
 
-    def check(tag, got, want, y):
-        e, nband = _rl(got, want, y)
+    def check(tag, got, want, y, reach=None):
+        e, nband = _rl(got, want, y, reach)
         results.append((tag, e))
         print("%-58s %.3e   (%d of %d elements inside the ReLU rounding band, excluded)" % (tag, e, nband, y.numel()))
 
@@ -100,7 +111,8 @@ def test_seg96_every_backward_step_matches_fp64_recomputation(monkeypatch):
             a = _act(y)
             a.retain_grad()
             F.conv3d(a, W(kb), padding=1).backward(Gr(kb))
-            check("%s -> %s%s" % (kb, ka, " (un-applied)" if deferred[ka] else ""), Graw(ka), recomputed(ka, y, a), y)
+            check("%s -> %s%s" % (kb, ka, " (un-applied)" if deferred[ka] else ""), Graw(ka), recomputed(ka, y, a), y,
+                  _seed_band(Y(kb)) if deferred[kb] else None)
     # ---- Down boundaries without a skip consumer: in_block -> down1, down3 -> down4 ----
     for src, blk in (("in_block.conv.0", "down1"), ("down3.conv.1.conv.6", "down4")):
         y = Y(src).requires_grad_(True)
@@ -127,8 +139,11 @@ def test_seg96_every_backward_step_matches_fp64_recomputation(monkeypatch):
         d = F.conv3d(_act(ys), W(down_blk + ".conv.0"), Bv(down_blk + ".conv.0"), stride=2)
         o2 = F.conv3d(d, W(down_blk + ".conv.1.conv.0"), padding=1)
         torch.autograd.backward([o1, o2], [Gr(up_blk + ".conv.1.conv.0"), Gr(down_blk + ".conv.1.conv.0")])
-        check("%s.conv.1.conv.0 -> [convT, skip add] -> %s" % (up_blk, up_src), Graw(up_src), yu.grad, yu)
-        check("%s + %s -> [skip + k2s2] -> %s" % (up_blk, down_blk, skip_src), Graw(skip_src), ys.grad, ys)
+        # an un-applied seed at the fine resolution (up5.conv.1.conv.0 in the parity mode): what its band elements reach, seen from the coarse grid
+        seed = up_blk + ".conv.1.conv.0"
+        reach = (F.max_pool3d(_seed_band(Y(seed)).double(), 2, stride=2) > 0) if deferred[seed] else None
+        check("%s.conv.1.conv.0 -> [convT, skip add] -> %s" % (up_blk, up_src), Graw(up_src), yu.grad, yu, reach)
+        check("%s + %s -> [skip + k2s2] -> %s" % (up_blk, down_blk, skip_src), Graw(skip_src), ys.grad, ys, reach)
     worst = max(results, key=lambda r: r[1])
     print("worst step: %s %.3e" % worst)
     assert worst[1] < 5e-6, worst

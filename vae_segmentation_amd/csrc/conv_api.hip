@@ -41,7 +41,9 @@ static int dispatch_k3(const G1Params& p, int dtype, int ck, int mt, int epi, in
 static int pick_mt(int rows16, long long tiles) {
     // largest row tile that still leaves >= VS_MT_MIN_WGS workgroups; 16 when the layer is too small for that.
     // (more rows per wave = more MFMAs per B fragment read from LDS, fewer workgroups)
-    static const int min_wgs = getenv("VS_MT_MIN_WGS") ? atoi(getenv("VS_MT_MIN_WGS")) : 256;
+    // 1024 since round 5 (256 before; same-box A/B with the round's kernels, profiles/r05_ab_mt_min_wgs_*.json: 96^3 2.416 -> 2.406 ms, 160^3 6.03 -> 6.00, fp32 mode
+    // 6.169 -> 6.148; 128 -> 2.456): the full-resolution stride-2 / transposed launches run 32-row workgroups, twice as many, instead of 64-row ones
+    static const int min_wgs = getenv("VS_MT_MIN_WGS") ? atoi(getenv("VS_MT_MIN_WGS")) : 1024;
     const int cands[3] = {64, 32, 16};
     for (int i = 0; i < 3; ++i) {
         const int mt = cands[i];

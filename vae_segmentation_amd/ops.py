@@ -64,10 +64,11 @@ def _esize(t):
 
 def _pick_mt(rows16, tiles):
     """mirror of pick_mt() in csrc/conv_api.hip (kernel instantiation naming only)."""
+    min_wgs = int(os.environ.get("VS_MT_MIN_WGS", "1024"))
     for mt in (64, 32, 16):
         if rows16 % mt:
             continue
-        if tiles * (rows16 // mt) >= 256 or mt == 16:
+        if tiles * (rows16 // mt) >= min_wgs or mt == 16:
             return mt
     return 16
 
