@@ -6,7 +6,8 @@ int g1_dispatch_k3_f32(const G1Params& p, int ck, int mt, int epi, int tiles, in
 int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_dispatch_k3_f16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_k3_fa_supported(const G1Params& p, int ck, int mt);
-int k3tw_slab_count(int n, int d, int h, int w);        // igemm_k3_bf16.hip: workgroups (= slabs) of a k3tw_kernel launch
+int k3tw_slab_count(int n, int d, int h, int w);
+int k2s2_scatter8_launch(const G1Params& p, int dtype, hipStream_t stream);      // k2s2_scatter8.hip        // igemm_k3_bf16.hip: workgroups (= slabs) of a k3tw_kernel launch
 int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 
 // fp32 parity mode: the 3x3x3 convolutions run on the bf16 matrix cores through exact three-limb operand splitting (igemm_k3x.h); their packed
@@ -222,6 +223,12 @@ static int scatter_impl(const void* x, const double* x_stats, const void* w_pack
     p.inv_count_in = 1.0 / ((double)d * h * w);
     p.tiles_per_sample = vs_ceil_div((long long)d * h * w, 256);
     const long long tiles = (long long)p.tiles_per_sample * n;
+    // the 8 -> 8 backward-data scatter at full resolution (Down1): a streaming kernel instead of an MFMA tile per 256 coarse voxels (k2s2_scatter8.hip)
+    static const int stream8 = getenv("VS_K2S2_STREAM") ? atoi(getenv("VS_K2S2_STREAM")) : 1;
+    if (stream8 && sums && c_in == 8 && m_out == 8 && dtype != VS_F32 && !bias && !x_stats) {
+        rc = k2s2_scatter8_launch(p, dtype, (hipStream_t)stream);
+        if (rc != VS_ESHAPE) return rc;
+    }
     const int rows16 = p.rb_total * 16;
     const int mt = pick_mt(rows16, tiles);
     return g1_dispatch_pw(p, dtype, ck, mt, (int)tiles, rows16 / mt, (hipStream_t)stream);
