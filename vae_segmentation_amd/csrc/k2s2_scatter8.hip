@@ -170,7 +170,8 @@ static int k2s8_go(const G1Params& p, hipStream_t stream) {
 }
 
 // (The kernel is written for C = 8 and 16; the 16-channel form — Down2's 48^3 gradient, 15 MB — measured 6 us per step SLOWER than g1_kernel's 26 us launch
-// (2.3945 vs 2.4006 ms same box, profiles/r05_ab_k2s2_stream_joint96.json) and is not instantiated.)
+// (2.3945 vs 2.4006 ms same box, profiles/r05_ab_k2s2_stream_joint96.json; standalone 42.1 vs 40.3 us at 2 x 48^3 coarse, 11.6 vs 10.0 at 24^3: 128 multiply-adds per
+// 16 bytes written make it ALU-bound where the 8-channel form — 17.9 vs 21.7 us at 2 x 48^3, 30.2 vs 45.7 at 80^3 — streams) and is not instantiated.)
 int k2s2_scatter8_launch(const G1Params& p, int dtype, hipStream_t stream) {
     if (p.C != 8 || p.M != p.C || !p.sums || !p.mask_x || !p.mask_stats || p.bias || p.x_stats) return VS_ESHAPE;
     if (dtype != VS_BF16 && dtype != VS_F16) return VS_EDTYPE;
