@@ -330,8 +330,8 @@ def test_k3_bwd_data_with_fused_apply(case, dtype, want_dx):
                                                mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(), None, n, d, h, w, 256, 256, dt, 1e-5, st) == -2
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("case", [(2, 48, 16, 16, True), (2, 48, 16, 8, False), (2, 48, 16, 32, False), (2, 96, 8, 16, False), (1, 64, 16, 16, True),
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("case", [(2, 48, 16, 16, True), (2, 48, 16, 16, False), (2, 48, 16, 8, False), (2, 48, 16, 32, False), (2, 96, 8, 16, False), (1, 64, 16, 16, True),
                                   (2, 80, 16, 16, True), (1, 20, 16, 16, True), (3, 12, 8, 16, False), (2, 24, 16, 32, False)])
 def test_k3b_bwd_data_with_fused_apply(case, dtype):
     """the same comparison for the k3b_kernel FA instantiations (igemm_k3b.h): the single-chunk backward-data launches of the 48^3 level
@@ -340,6 +340,8 @@ def test_k3b_bwd_data_with_fused_apply(case, dtype):
     ops = _ops()
     from vae_segmentation_amd._lib import check, lib
     n, s_, c, m, lazy_in = case
+    if dtype == torch.float32 and not (c == 16 and m == 16):
+        pytest.skip("parity mode: the fused apply of k3x_kernel exists for the 16 -> 16 layers (k3xt_kernel takes 8 -> 8: test_k3_bwd_data_with_fused_apply)")
     d, h, w = s_, s_, s_ + (4 if s_ < 40 else 0)
     dev = "cuda"
     gen = torch.Generator().manual_seed(s_ + c)
@@ -353,7 +355,7 @@ def test_k3b_bwd_data_with_fused_apply(case, dtype):
     assert lib.vs_conv_k3_fused_apply_supported(n, d, h, w, c, m, int(lazy_in), dt) == 1
     asums = ops._new_stats(n, c, ax.device)
     check(lib.vs_instnorm_relu_bwd_reduce(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), n, vox, c, dt, 1e-5, st), "reduce")
-    wpb = ops.pack_weight(wt, ops.VS_PACK_ROWS_D1_FLIP, c, dtype)
+    wpb = ops.pack_weight(wt, ops.VS_PACK_ROWS_D1_FLIP, c, ops.k3_pack_dtype(g))      # fp32: the three-limb image (k3x_kernel<8, 16, .., FA>, round 5)
     dx_ref = torch.empty_like(g)
     check(lib.vs_instnorm_relu_bwd_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), dx_ref.data_ptr(), n, vox, c, dt, 1e-5, st), "apply")
     y_ref, y = torch.empty_like(mx), torch.empty_like(mx)
@@ -369,7 +371,7 @@ def test_k3b_bwd_data_with_fused_apply(case, dtype):
         check(lib.vs_conv_k3_bwd_data_fused_apply(g.data_ptr(), ax.data_ptr(), axs.data_ptr(), asums.data_ptr(), wpb.data_ptr(), y.data_ptr(),
                                                   None, None, None, dx.data_ptr(), n, d, h, w, c, m, dt, 1e-5, st), "fused")
     torch.cuda.synchronize()
-    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11, torch.float32: 2.0 ** -21}[dtype]
     edge = _dx_agrees(dx, dx_ref, ulp)
     assert _rel_l2(y, y_ref) < 4 * ulp and (edge or relerr(y.float().cpu(), y_ref.float().cpu()) < 4 * ulp)
     if lazy_in:

@@ -111,7 +111,9 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     const int row_tiles = rows16 / mt;
     if (fa_query != nullptr) {                             // planning only: would a fused-apply launch of this shape find a kernel?
         if (dtype == VS_F32)                               // parity mode: the 8 -> 8 full-resolution layers (k3xt_kernel<..., FA>, igemm_k3x.h)
-            *fa_query = kind == VS_CONV_K3 && c_in == 8 && m_out == 8 && n * 8 <= 192 && vs_conv_k3_f32_limbs(d, h, w, c_in) && vs_k3x_toeplitz(8, 8, 27);
+            *fa_query = kind == VS_CONV_K3 && vs_conv_k3_f32_limbs(d, h, w, c_in) &&
+                        ((c_in == 8 && m_out == 8 && n * 8 <= 192 && vs_k3x_toeplitz(8, 8, 27)) ||
+                         (c_in == 16 && m_out == 16 && n * 16 <= 192 && vs_k3x_ck(16) == 8));      // k3xt_kernel / k3x_kernel<8, 16, ..., FA> (igemm_k3x.h)
         else
             *fa_query = kind == VS_CONV_K3 ? g1_k3_fa_supported(p, ck, mt) : 0;
         return VS_OK;

@@ -37,10 +37,14 @@ struct K3XGeom {
 
 // SUMS: backward-data use (fused IN-backward sums of the output against the mask tensor); HS: the input is a lazy activation; MULTI: more than one
 // channel chunk (the weight block is re-staged per chunk) — all compile-time, like every condition on the staging path (igemm_k3b.h)
-template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI>
+// FA (backward-data use; round 5, the 16-channel layers of the 48^3 level): the input gradient arrives UN-applied, as for k3xt_kernel's fused apply below — p.x = g = dL/da
+// of the lazy activation a = relu(norm(p.fa_x)), statistics p.x_stats, IN-backward sums p.fa_sums; the apply runs in fp32 on the staged fragments before the
+// limb split, centre voxels also go to p.fa_dx when given (one row-block workgroup per tile stores them)
+template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI, bool FA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 ? 2 : 1))) void k3x_kernel(const G1Params p) {
     using GEO = K3XGeom<CK, MT>;
     static_assert(CK == 8 || CK == 16, "chunk width");
+    static_assert(!FA || (!HS && EPI == EPI_RAW), "fused apply: backward-data use");
     constexpr int TV = GEO::TV, PLANE = 6 * 18, U = GEO::U, NIT = GEO::NIT, CKB2 = GEO::CKB2, RB = GEO::RB, NKGC = GEO::NKGC;
     constexpr int NU = TV * U, NWF = GEO::NWF, NWI = GEO::NWI, PB = GEO::PLANE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,11 +56,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
     float* s_rstd = s_mean + p.N * p.C;
     float* s_mkm = s_rstd + p.N * p.C;                   // mean / rstd of the mask tensor's channels (fused IN-bwd sums)
     float* s_mkr = s_mkm + p.N * p.M;
+    float* s_fa = s_rstd + p.N * p.C + (SUMS ? 2 * p.N * p.M : 0);   // FA: rstd, -mean*rstd, m1, m2 of the input gradient's activation, [N*C] each
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
     const int rb0 = blockIdx.y * RB;
     const int total_tiles = p.tiles_per_sample * p.N;
     const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.C * 4));
+    const i32x4 frsrc = make_rsrc(FA ? p.fa_x : p.x, (unsigned int)((long long)p.N * p.D * p.H * p.W * p.C * 4));
+    const i32x4 dxrsrc = make_rsrc(FA && p.fa_dx != nullptr ? p.fa_dx : p.x, (FA && p.fa_dx != nullptr) ? (unsigned int)((long long)p.N * p.D * p.H * p.W * p.C * 4) : 0u);
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
 
     // the (sum, sumsq) pair this thread turns into a table entry is requested first of all (oldest load in the queue)
@@ -64,10 +71,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
     const int st_n = SUMS ? p.N * p.M : (HS ? p.N * p.C : 0);
     double st_pre[2] = {0.0, 1.0};
     if (tid < st_n) stat_load(st_src, (size_t)tid, (size_t)st_n, st_pre);
+    double fa_pre[2][2] = {{0.0, 1.0}, {0.0, 0.0}};      // FA: waves 1.. request the activation's (sum, sumsq) and (sum g*mask, sum g*mask*xhat) pairs
+    if constexpr (FA) {
+        if (tid >= 64 && tid < 64 + p.N * p.C) {
+            stat_load(p.x_stats, (size_t)(tid - 64), (size_t)p.N * p.C, fa_pre[0]);
+            stat_load(p.fa_sums, (size_t)(tid - 64), (size_t)p.N * p.C, fa_pre[1]);
+        }
+    }
 
     // ---- per-thread stage geometry (tile independent): fragment b = channels 4*part .. 4*part+3 of tile voxel tv_b ----
     const int part = tid % U;
     int rel_off[NIT], tzyx[NIT];
+    unsigned int cbits = 0;                              // FA: fragment b belongs to a centre (non-halo) voxel of the tile
     const int lds_w0 = (tid / U) * CKB2 + part * 8;       // + b * 2048 (tv advances by 256 / U voxels of CKB2 bytes per b), + limb * PB
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
@@ -76,6 +91,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
         const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / PLANE;
         rel_off[b] = (((tz_ * p.H + ty_) * p.W + tx_) * p.C + part * 4) * 4;              // bytes from the tile's (0,0,0) halo voxel
         tzyx[b] = u < NU ? (tz_ | (ty_ << 8) | (tx_ << 16)) : 0x00ffffff;                 // out-of-list fragments fail every bounds test
+        cbits |= (u < NU && tz_ >= 1 && tz_ <= 4 && ty_ >= 1 && ty_ <= 4 && tx_ >= 1 && tx_ <= 16) ? (1u << b) : 0u;
     }
     int w_off[NWI];
 #pragma unroll
@@ -86,7 +102,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
         w_off[i] = (rb0 + rb) * (p.nch * NKGC * 192) + r;                                  // + ch * NKGC * 192
     }
 
-    u32x4 xv[NIT], wv[NWI];
+    u32x4 xv[NIT], wv[NWI], fv[FA ? NIT : 1];
     unsigned int okbits = 0;
     struct Coord { int n, z0, y0, x0; };
     auto tile_coord = [&](int t) {
@@ -112,6 +128,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
             const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             okbits |= ok ? (1u << b) : 0u;
             xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, ok ? base + rel_off[b] : -1, 0, 0));
+            if constexpr (FA) fv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(frsrc, ok ? base + rel_off[b] : -1, 0, 0));
+        }
+    };
+    auto write_x_fa = [&](const Coord& c, int ch) {     // FA: apply pass in fp32 on the staged fragments, then the limb split [+ the applied gradient of the centre voxels]
+        float rr[4], ss[4], aa[4], bb[4];
+        const int c0 = c.n * p.C + ch * CK + part * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            rr[j] = s_fa[0 * p.N * p.C + c0 + j];
+            ss[j] = s_fa[1 * p.N * p.C + c0 + j];
+            aa[j] = s_fa[2 * p.N * p.C + c0 + j];
+            bb[j] = s_fa[3 * p.N * p.C + c0 + j];
+        }
+        const int base = ((((c.n * p.D + c.z0 - 1) * p.H + c.y0 - 1) * p.W + c.x0 - 1) * p.C + ch * CK) * 4;
+        const bool store_dx = p.fa_dx != nullptr && blockIdx.y == 0;          // workgroup-uniform: once per tile
+#pragma unroll
+        for (int b = 0; b < NIT; ++b) {
+            const bool ok = (okbits >> b) & 1u;           // out-of-volume halo voxels: the gradient is zero-padded
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gq = __uint_as_float(xv[b][j]);
+                const float xh = __uint_as_float(fv[b][j]) * rr[j] + ss[j];
+                const float gm = xh > 0.f ? gq : 0.f;
+                const float d = rr[j] * (gm - aa[j] - xh * bb[j]);
+                v[j] = ok ? d : 0.f;
+            }
+            unsigned int lm[3][2];
+            vs_limb_split4(v, lm);
+#pragma unroll
+            for (int l = 0; l < 3; ++l) *(u32x2*)(s_tile + l * PB + lds_w0 + b * 2048) = u32x2{lm[l][0], lm[l][1]};
+            if (store_dx)
+                vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{v[0], v[1], v[2], v[3]}), dxrsrc, (ok && ((cbits >> b) & 1u)) ? base + rel_off[b] : -1, 0, 0);
         }
     };
     auto write_x = [&](int n, int ch) {                   // normalise + ReLU (fp32), split into limbs, three 8-byte stores
@@ -174,6 +223,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
         if constexpr (SUMS) { s_mkm[i] = m; s_mkr[i] = r; }
         else { s_mean[i] = m; s_rstd[i] = r; }
     }
+    if constexpr (FA) {
+        if (tid >= 64 && tid < 64 + p.N * p.C) {
+            const int i = tid - 64;
+            float m, r;
+            pair_to_mean_rstd(fa_pre[0], p.inv_count_in, p.eps, m, r);
+            s_fa[0 * p.N * p.C + i] = r;
+            s_fa[1 * p.N * p.C + i] = -m * r;
+            s_fa[2 * p.N * p.C + i] = (float)(fa_pre[1][0] * p.inv_count_in);
+            s_fa[3 * p.N * p.C + i] = (float)(fa_pre[1][1] * p.inv_count_in);
+        }
+    }
     // B fragment of (k-group kg, lane group g, column voxel (wave, cg, col)): limb plane + (wave * PLANE + cg * 18 + col) * CKB2 + s_taps[4 kg + g]
     if (tid < NKGC * 4) {
         int tap = (tid >> 2) * (32 / CK) + ((tid & 3) * 8) / CK;
@@ -215,7 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
 
         for (int ch = 0; ch < p.nch; ++ch) {
             if (!first) __syncthreads();                 // every wave is done reading the previous stage
-            write_x(n, ch);
+            if constexpr (FA) write_x_fa(cur, ch); else write_x(n, ch);
             if constexpr (MULTI) write_w();
             first = false;
             __syncthreads();
@@ -373,11 +433,12 @@ static inline void k3x_fastdiv(int d, unsigned int& m, unsigned int& s) {
     m = (unsigned int)((((1ull << (32 + s)) + (unsigned long long)d - 1) / (unsigned long long)d) - (1ull << 32));
 }
 
-template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI>
+template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI, bool FA = false>
 static int k3x_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
     using GEO = K3XGeom<CK, MT>;
     G1Params p = p_in;
-    const size_t tables = (size_t)2 * p.N * p.C * sizeof(float) + (p.sums ? (size_t)2 * p.N * p.M * sizeof(float) : 0);
+    if (FA && (p.N * p.C > 192 || !p.x_stats || !p.fa_sums)) return VS_ESHAPE;      // waves 1 .. 3 build the fused-apply tables
+    const size_t tables = (size_t)(FA ? 6 : 2) * p.N * p.C * sizeof(float) + (p.sums ? (size_t)2 * p.N * p.M * sizeof(float) : 0);
     const size_t lds = K3X_LDS_TILE + (size_t)3 * GEO::PLANE_BYTES + GEO::W_BYTES + tables;
     if (lds > 160 * 1024) return VS_ESHAPE;
     // buffer offsets are 32-bit bytes, signed on the device
@@ -385,8 +446,8 @@ static int k3x_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     k3x_fastdiv(p.tiles_per_sample, p.fd_m[0], p.fd_s[0]);
     k3x_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3x_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
-    if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr) || MULTI != (p.nch > 1)) return VS_EINVAL;
-    auto kern = k3x_kernel<CK, MT, EPI, SUMS, HS, MULTI>;
+    if (SUMS != (p.sums != nullptr) || (SUMS && !FA && p.x_stats != nullptr) || MULTI != (p.nch > 1)) return VS_EINVAL;
+    auto kern = k3x_kernel<CK, MT, EPI, SUMS, HS, MULTI, FA>;
     static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
     // persistent grid: as many workgroups as the LDS lets a CU hold (CK = 8: two, CK = 16: one), each walking a strided slice of the tile list
@@ -401,8 +462,18 @@ static int k3x_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     return VS_OK;
 }
 
+// the fused-apply instantiations: 8-channel chunks, 16-row workgroups (the 16 -> 16 layers of the 48^3 level and their 64^3 / 80^3 counterparts)
+template <int CK, int MT, int EPI, bool MULTI>
+constexpr bool k3x_has_fa() { return CK == 8 && MT == 16 && EPI == EPI_RAW && MULTI; }
+
 template <int CK, int MT, int EPI, bool MULTI>
 static int k3x_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
+    if (p.fa_x != nullptr) {
+        if constexpr (k3x_has_fa<CK, MT, EPI, MULTI>()) {
+            return p.sums ? k3x_launch_t<CK, MT, EPI, true, false, MULTI, true>(p, tiles_total, row_tiles, stream)
+                          : k3x_launch_t<CK, MT, EPI, false, false, MULTI, true>(p, tiles_total, row_tiles, stream);
+        } else return VS_ESHAPE;
+    }
     if (p.sums != nullptr) {
         if constexpr (EPI == EPI_RAW) return k3x_launch_t<CK, MT, EPI, true, false, MULTI>(p, tiles_total, row_tiles, stream);
         else return VS_EINVAL;

@@ -8,7 +8,8 @@ int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int
     // 8 stored input and output channels (the full-resolution layers; out_block's two logits are stored in 8): Toeplitz rows, weights packed to match
     if (ck == 8 && p.C == 8 && p.M == 8 && p.nch == 1 && vs_k3x_toeplitz(8, 8, 27))
         return epi == EPI_SOFTMAX2 ? k3xt_launch<EPI_SOFTMAX2>(p, s) : k3xt_launch<EPI_RAW>(p, s);
-    if (p.fa_x != nullptr) return VS_ESHAPE;              // fused apply: k3xt_kernel only (vs_conv_k3_fused_apply_supported says so beforehand)
+    // fused apply: k3xt_kernel, and k3x_kernel<8, 16, RAW, .., MULTI, FA> for 16 stored input channels (vs_conv_k3_fused_apply_supported says so beforehand)
+    if (p.fa_x != nullptr && !(ck == 8 && mt == 16 && epi == EPI_RAW && p.nch == 2 && p.C == 16)) return VS_ESHAPE;
     if (epi == EPI_SOFTMAX2) {
         if (ck != 8 || mt != 16 || p.nch != 1) return VS_ESHAPE;      // out_block: 8 stored channels -> 2 logits
         return k3x_launch<8, 16, EPI_SOFTMAX2, false>(p, tiles, row_tiles, s);

@@ -506,7 +506,7 @@ FUSE_APPLY = os.environ.get("VS_FUSE_APPLY", "1") != "0"
 # and left the library in round 5; so did 16-channel half stages of the same layers (two waves per SIMD, 19 launches fewer, +30..+43 us per step:
 # profiles/r05_ab_fused_apply_half_stages.json).  The library has the last word (vs_conv_k3_fused_apply_supported).
 _FA_CHANNELS = (8, 16)
-_FA_CHANNELS_F32 = (8,)
+_FA_CHANNELS_F32 = (8, 16)       # 16: k3x_kernel<8, 16, .., FA> (the 16 -> 16 layers of the 48^3 level; the library has the last word)
 FUSE_APPLY_F32 = os.environ.get("VS_FUSE_APPLY_F32", "1") != "0"      # A/B switch of the parity mode's fused apply
 _LAZY_APPLY = {"grads": {}, "callback": False}
 
