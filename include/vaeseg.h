@@ -168,6 +168,38 @@ int vs_conv_k3_bwd_data_wgrad(const void* g, const void* act_x, const double* ac
 int vs_conv_k3_softmax2_bwd_data(const float* prob, const float* gprob, const void* gprob_cl, const void* w_packed, void* y, const void* mask_x,
                                  const double* mask_stats, double* sums, float* slabs, double* bias_part, int n, int d, int h, int w, int dtype,
                                  float eps, float drop_p, unsigned long long drop_seed, void* stream);
+/* One DoubleConv (joint_model.py:35-52: three times [Conv3d 3x3x3 pad 1 -> InstanceNorm3d -> ReLU]) at the small volumes of the deep levels as ONE launch
+ * (csrc/chain.h, round 6).  InstanceNorm3d is per (sample, channel) (joint_model.py:11), so layer l + 1 of sample n depends on layer l of sample n only: the
+ * workgroups of a sample hand the raw output and its statistics over inside the launch (write-through stores, counter, sc1 loads) instead of ending it.
+ * forward (backward = 0): layers[0..n_layers) in order; layer l = vs_conv_gather_fwd(K3) of (x, x_stats) -> (y, y_stats); for l > 0, x / x_stats ARE layer l-1's
+ *   y / y_stats; layer 0's x_stats may be NULL (a stored input).
+ * backward (backward = 1): layers in BACKWARD order; layer l = vs_conv_gather_bwd_data(K3) of the gradient x (layer 0: w.r.t. the block's raw output, applied;
+ *   l > 0: layer l-1's y) with the transposed / mirrored weight image -> y = dL/d(activation), sums against (mask_x, mask_stats) = that activation's raw tensor and
+ *   statistics; apply = 1: vs_instnorm_relu_bwd_apply runs on y IN PLACE inside the launch (y leaves as dL/d(raw tensor): what the next layer and the weight gradient read).
+ *   Every layer but the last must apply; the last may have mask_x = mask_stats = sums = NULL (the block's input is a stored tensor: plain backward-data).
+ *   add (nullable; needs the last layer's apply): a second gradient of the last layer's raw tensor, summed in as vs_instnorm_relu_bwd_apply_add does.
+ * sync: vs_conv_k3_chain_sync_bytes(n) ZEROED bytes, 128-byte aligned, private to this call; fault: a device word the kernel ORs 1 into when a bounded wait gave up
+ *   (never in a correct launch: the library rejects chains whose workgroups cannot all be resident) — results are then invalid, the queue is not hung.
+ * Shapes: (d+2)(h+2)(w+2) <= 512 (up to 6^3), channels multiples of 32 (c_in) / 8 (m_out), at most 256 workgroups per sample (32 per XCD): vs_conv_k3_chain_supported(n, d, h, w,
+ * largest channel count of the chain, dtype) says 1 / 0 (env VS_CHAIN=0: always 0).  All three storage types; results are bit-identical to the per-layer launches
+ * in the deterministic build. */
+typedef struct vs_chain_layer {
+    const void* x;
+    const double* x_stats;
+    const void* w_packed;
+    void* y;
+    double* y_stats;
+    const void* mask_x;
+    const double* mask_stats;
+    double* sums;
+    int c_in, m_out;
+    int apply;
+    int reserved_;
+} vs_chain_layer;
+int vs_conv_k3_chain_supported(int n, int d, int h, int w, int c_max, int dtype);
+long long vs_conv_k3_chain_sync_bytes(int n);
+int vs_conv_k3_chain(const vs_chain_layer* layers, int n_layers, int backward, const void* add, unsigned int* sync, unsigned int* fault,
+                     int n, int d, int h, int w, int dtype, float eps, void* stream);
 /* fp32 parity mode: 1 when a 3x3x3 convolution of dtype VS_F32 on a (d, h, w) volume with c_in stored input channels runs on the bf16 matrix cores through exact three-limb operand splitting
  * (csrc/igemm_k3x.h: every fp32 operand = three bf16 limbs, six exact limb products per product, fp32 accumulation — 2.7x fewer matrix cycles
  * than the exact-f32 MFMA at the accuracy of one fp32 rounding).  Their packed weights must then be VS_F32X3 images: vs_pack_weight /

@@ -125,8 +125,10 @@ _ENV = {}
 
 
 def envelopes():
+    """tests/golden/envelopes.npz (round 5: seg96, joint96, embed128) + envelopes2.npz (round 6: da128 [both gradient sets], joint128, joint64, vae128_train, ft128)"""
     if not _ENV:
         _ENV.update(load("envelopes"))
+        _ENV.update(load("envelopes2"))
     return _ENV
 
 

@@ -166,6 +166,112 @@ def test_joint160_fp16_train_steps_and_memory():
     assert peak < 40.0
 
 
+def _sample_cosine(g, named_grads, scale=1.0):
+    """cosine between the HIP gradients and joint160_bwd's stored samples (64 per tensor, the reference's own fp32 run), over all live tensors, and the worst
+    per-tensor ratio of l2 norms"""
+    mine, ref, ratios = [], [], {}
+    for name, gr in named_grads:
+        key = "seg.grad.%s" % name
+        if G.is_dead_bias(name) or key + ".l2" not in g:
+            continue
+        a = G.flat64(gr) / scale
+        mine.append(a[G.sample_idx(a.size, 64)])
+        ref.append(g[key + ".samples"].astype(np.float64))
+        ratios[name] = float(np.sqrt((a * a).sum()) / max(float(g[key + ".l2"]), 1e-300))
+    m, r = np.concatenate(mine), np.concatenate(ref)
+    return float((m * r).sum() / np.sqrt((m * m).sum() * (r * r).sum())), ratios
+
+
+def test_joint160_backward_vs_reference_fp32_golden_and_fp16_direction():
+    """BASELINE configs[4]'s geometry, the BACKWARD half: tests/golden/joint160_bwd.npz holds the reference's own eager fp32
+    joint_train step at 160^3 (batch 1: its fp64 twin does not fit the build container, so there is no fp64 yardstick and no envelope at this size —
+    two fp32 implementations are two draws of the network's rounding amplification, 1e-2 .. 1e-1 apart at 128^3: tests/golden/envelopes2.npz).
+    Gates: the fp32 (parity) mode's losses to 1e-3, its probabilities to the golden's samples, every live gradient tensor's norm within a factor 1.5 of the
+    reference's and the sampled whole-gradient cosine >= 0.95.  Then the fp16 mode (loss scale 65536) at a TRAINED state — 40 SGD steps of the fp32 mode on
+    this very batch: a state where gradients are not rounding noise (tests/test_gpu_convergence.py says why the random-weight state proves nothing for a
+    16-bit mode) — against the fp32 mode's gradient there: whole-gradient cosine >= 0.9, the link that ties configs[4]'s fp16 gradient to the pinned fp32 kernels."""
+    M, O, T, optim = _mods()
+    from vae_segmentation_amd import ops
+    g = G.load("joint160_bwd")
+    joint = _build_joint(M, O, 160, torch.float32)
+    img, lab = O.synthetic_image(1, 160, 2).cuda(), O.synthetic_label(1, 160, 3).cuda()
+    final, aux = T.joint_train_losses(joint, img, lab)
+    final.backward()
+    torch.cuda.synchronize()
+    for key, val in (("final", final), ("recon_loss", aux["recon_loss"]), ("dice_loss", aux["dice_loss"])):
+        assert abs(val.item() - float(g[key])) <= 1e-3 * abs(float(g[key])), (key, val.item(), float(g[key]))
+    pred = G.flat64(aux["batch"]["pred"])
+    perr = np.abs(pred[G.sample_idx(pred.size, 512)] - g["pred.samples"].astype(np.float64))
+    assert perr.max() < 2e-2 and perr.mean() < 1e-3, (perr.max(), perr.mean())
+    cos, ratios = _sample_cosine(g, [(n, p.grad) for n, p in joint.Seg.named_parameters()])
+    worst = max(ratios.items(), key=lambda kv: abs(np.log(kv[1])))
+    print("\njoint160 backward, fp32 mode vs the reference's fp32 run: sampled whole-gradient cosine %.4f; per-tensor norm ratio worst %s %.3f" % (cos, worst[0], worst[1]))
+    assert cos >= 0.95, cos
+    assert all(1 / 1.5 < r < 1.5 for r in ratios.values()), worst
+    # ---- a trained state, then fp16 against the fp32 mode ----
+    params = list(joint.Seg.parameters())
+    opt = optim.SGD(params, lr=1e-2, momentum=0.9)
+    for p in params:
+        p.grad = None
+    gs = T.GraphedStep(lambda: T.joint_train_losses(joint, img, lab), params, opt, warmup=1)
+    l0 = float(gs.step())
+    for _ in range(39):
+        l1 = float(gs.step())
+    torch.cuda.synchronize()
+    assert l1 < 0.8 * l0, (l0, l1)
+    state = {k: v.detach().clone() for k, v in joint.Seg.state_dict().items()}
+    del gs
+    grads = {}
+    for name, dtype in (("fp32", torch.float32), ("fp16", torch.float16)):
+        j = _build_joint(M, O, 160, dtype)
+        j.Seg.load_state_dict(state)
+        ops.weights_changed()
+        seed = torch.tensor(65536.0, device="cuda") if dtype == torch.float16 else None
+        f, _ = T.joint_train_losses(j, img, lab)
+        f.backward(gradient=seed)
+        torch.cuda.synchronize()
+        sc = 65536.0 if dtype == torch.float16 else 1.0
+        grads[name] = (float(f), torch.cat([p.grad.detach().double().flatten() / sc for n, p in j.Seg.named_parameters() if not G.is_dead_bias(n)]))
+        del j, f
+    (lf, a), (lh, b) = grads["fp32"], grads["fp16"]
+    whole = float((a * b).sum() / (a.norm() * b.norm()))
+    print("joint160 trained state (40 steps, loss %.4f -> %.4f): fp16 loss %.5f vs fp32-mode %.5f, whole-gradient cosine fp16 vs fp32 mode %.4f" % (l0, l1, lh, lf, whole))
+    assert abs(lh - lf) <= 2e-2 * abs(lf)
+    assert torch.isfinite(b).all() and whole >= 0.9, whole
+
+
+def test_activation_recomputation_at_160_cubed_is_bit_identical():
+    """configs[4] as BASELINE words it — 160^3, fp16, WITH activation checkpointing: the recomputing pass gives the stored-activation
+    pass's loss and gradients bit for bit at the configuration's own size (deterministic build), and its peak memory is lower."""
+    M, O, T, optim = _mods()
+    from vae_segmentation_amd import ops
+    assert ops.is_deterministic()
+    img, lab = O.synthetic_image(2, 160, 2).cuda(), O.synthetic_label(2, 160, 3).cuda()
+    seed = torch.tensor(65536.0, device="cuda")
+    res = {}
+    for rec in (False, True):
+        joint = _build_joint(M, O, 160, torch.float16)
+        M.set_recompute(rec)
+        ops.set_wgrad_grouping(False)
+        try:
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            final, aux = T.joint_train_losses(joint, img, lab)
+            final.backward(gradient=seed)
+            torch.cuda.synchronize()
+            res[rec] = (final.detach().clone(), [p.grad.detach().clone() for p in joint.Seg.parameters()], torch.cuda.max_memory_allocated() - base)
+        finally:
+            M.set_recompute(False)
+            ops.set_wgrad_grouping(True)
+        del joint, final, aux
+    assert torch.equal(res[False][0], res[True][0])
+    for a, b in zip(res[False][1], res[True][1]):
+        assert torch.equal(a, b)
+    print("\n160^3 B=2 fp16 joint_train pass: peak %.2f GB kept, %.2f GB with recomputation" % (res[False][2] / 1e9, res[True][2] / 1e9))
+    assert res[True][2] < 0.9 * res[False][2]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 def test_activation_recomputation_gives_identical_gradients_and_saves_memory(dtype):
     """BASELINE configs[4] names activation checkpointing: modules.set_recompute re-runs every Down / Up block in backward instead of keeping

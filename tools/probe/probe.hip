@@ -186,3 +186,125 @@ extern "C" int vs_debug_down_composed_probe(const void* x, const void* w_packed,
                        (unsigned short*)y, n, d, h, w);
     return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Round 6, VERDICT r05 item 1 step 0: the price of ONE layer boundary kept inside a launch when the dependency domain is a SAMPLE
+// (InstanceNorm3d is per (n, c): joint_model.py:11), not the device.  Groups of gsz workgroups stand for the workgroups of one sample's layer.
+// Per round every workgroup: stores `pb` bytes of payload (its output tile), publishes 32 fp64 partial sums (its statistics), drains
+// (`s_waitcnt vmcnt(0)`), workgroup barrier, ONE relaxed agent-scope add to the group's counter, ONE lane polls the counter with sc1 loads;
+// workgroup barrier; then the "next layer's staging": the neighbour's payload and all gsz partial slots are loaded and checked (a stale
+// payload word — value != round — is counted).  No release / acquire fence anywhere in the fast forms (no buffer_wbl2 / buffer_inv).
+//   mode bit 0: members of a group share blockIdx % 8 (one XCD under round-robin placement) instead of being consecutive (spread over XCDs)
+//   mode bit 1: payload stores plain (kept in the XCD's L2) instead of sc1 (write-through)
+//   mode bit 2: payload / partial loads sc0 instead of sc1 (the review's proposal; MI355X_MICROARCH.md says sc0 loads hit L1 like plain)
+//   mode bit 3: statistics by fp64 agent atomics into one table per group instead of one slot per workgroup
+//   mode bit 4: the fenced protocol for comparison: plain stores, release fence before the add, acquire fence after the poll, plain loads
+// out: ticks[b] = memrealtime ticks (100 MHz) of the whole loop or ~0 on a bounded-spin give-up; xcc[b] = HW_REG_XCC_ID; err[0] += stale words.
+typedef __attribute__((ext_vector_type(4))) unsigned int qu32x4;
+__device__ __forceinline__ void st16_sc1(void* p, qu32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ qu32x4 ld16_sc1(const void* p) {
+    qu32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ qu32x4 ld16_sc0(const void* p) {
+    qu32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__global__ __launch_bounds__(256) void xcd_group_probe_kernel(unsigned int* flags, unsigned long long* ticks, unsigned int* xcc, unsigned int* err,
+                                                               unsigned char* payload, double* slots, int n_wg, int iters, int gsz, int pb, int mode) {
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid == 0) {
+        s_fail = 0;
+        xcc[b] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf;      // HW_REG_XCC_ID (id 20), bits [3:0]
+    }
+    int grp, mem;
+    if (mode & 1) { const int x = b & 7, j = b >> 3, per = (n_wg >> 3) / gsz; grp = x * per + j / gsz; mem = j % gsz; if (j / gsz >= per) return; }
+    else { grp = b / gsz; mem = b % gsz; }
+    const int base = (mode & 1) ? -1 : grp * gsz;
+    auto member_block = [&](int m) { return (mode & 1) ? ((((grp % ((n_wg >> 3) / gsz)) * gsz + m) << 3) | (grp / ((n_wg >> 3) / gsz))) : base + m; };
+    const bool plain_st = mode & 2, sc0_ld = mode & 4, atom = mode & 8, fenced = mode & 16;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    double sink = 0.0;
+    unsigned int stale = 0;
+    const int nb = member_block((mem + 1) % gsz);
+    for (int it = 1; it <= iters; ++it) {
+        const int par = it & 1;
+        unsigned char* mine = payload + ((size_t)par * n_wg + b) * pb;
+        const qu32x4 v = {(unsigned)it, (unsigned)it, (unsigned)it, (unsigned)it};
+        for (int o = tid * 16; o < pb; o += 4096) {
+            if (plain_st || fenced) *(qu32x4*)(mine + o) = v;
+            else st16_sc1(mine + o, v);
+        }
+        if (tid < 32) {
+            if (atom) atomicAdd(slots + ((size_t)par * n_wg + grp) * 32 + tid, 1.0);
+            else if (fenced) slots[((size_t)par * n_wg + b) * 32 + tid] = (double)it;
+            else __hip_atomic_store(slots + ((size_t)par * n_wg + b) * 32 + tid, (double)it, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (fenced) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            __hip_atomic_fetch_add(flags + grp * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(flags + grp * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)it * (unsigned int)gsz && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(1);
+            if (spins >= (1 << 18)) s_fail = 1;
+            if (fenced) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        }
+        __syncthreads();
+        if (s_fail) break;
+        const unsigned char* theirs = payload + ((size_t)par * n_wg + nb) * pb;
+        for (int o = tid * 16; o < pb; o += 4096) {
+            const qu32x4 r = fenced ? *(const qu32x4*)(theirs + o) : sc0_ld ? ld16_sc0(theirs + o) : ld16_sc1(theirs + o);
+            stale += (r[0] != (unsigned)it) + (r[3] != (unsigned)it);
+        }
+        if (tid < 32) {
+            if (atom) sink += __hip_atomic_load(slots + ((size_t)par * n_wg + grp) * 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                for (int m = 0; m < gsz; ++m) {
+                    const double* q = slots + ((size_t)par * n_wg + member_block(m)) * 32 + tid;
+                    const double s = fenced ? *q : __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    stale += (s != (double)it);
+                    sink += s;
+                }
+        }
+    }
+    if (stale) atomicAdd(err, stale);
+    if (tid < 32 && sink == -1.0) err[1] = 1u;
+    if (tid == 0) ticks[b] = s_fail ? ~0ull : __builtin_amdgcn_s_memrealtime() - t0;
+}
+extern "C" int vs_debug_xcd_group_probe(unsigned int* flags, unsigned long long* ticks, unsigned int* xcc, unsigned int* err, void* payload, double* slots,
+                                        int n_wg, int iters, int gsz, int pb, int mode, void* stream) {
+    if (!flags || !ticks || !xcc || !err || !payload || !slots || n_wg <= 0 || n_wg > 256 || (n_wg & 7) || iters <= 0 || iters > 100000) return VS_EINVAL;
+    if (gsz <= 0 || pb < 4096 || (pb & 4095) || pb > (64 << 10)) return VS_EINVAL;
+    if ((mode & 1) ? ((n_wg >> 3) % gsz != 0) : (n_wg % gsz != 0)) return VS_EINVAL;      // every workgroup belongs to a full group: nobody waits for an absent member
+    hipLaunchKernelGGL(xcd_group_probe_kernel, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, flags, ticks, xcc, err, (unsigned char*)payload, slots, n_wg, iters, gsz, pb, mode);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}
+
+// the same round as a chain of dependent launches (what the step does today): launch k stores its payload + partials, launch k + 1 reads them
+__global__ __launch_bounds__(256) void xcd_chain_probe_kernel(unsigned int* err, unsigned char* payload, double* slots, int n_wg, int gsz, int pb, int it) {
+    const int tid = threadIdx.x, b = blockIdx.x, grp = b / gsz, mem = b % gsz, par = it & 1, prev = par ^ 1;
+    unsigned int stale = 0;
+    double sink = 0.0;
+    if (it > 1) {
+        const unsigned char* theirs = payload + ((size_t)prev * n_wg + grp * gsz + (mem + 1) % gsz) * pb;
+        for (int o = tid * 16; o < pb; o += 4096) { const qu32x4 r = *(const qu32x4*)(theirs + o); stale += (r[0] != (unsigned)(it - 1)); }
+        if (tid < 32) for (int m = 0; m < gsz; ++m) { const double s = slots[((size_t)prev * n_wg + grp * gsz + m) * 32 + tid]; stale += (s != (double)(it - 1)); sink += s; }
+    }
+    unsigned char* mine = payload + ((size_t)par * n_wg + b) * pb;
+    const qu32x4 v = {(unsigned)it, (unsigned)it, (unsigned)it, (unsigned)it};
+    for (int o = tid * 16; o < pb; o += 4096) *(qu32x4*)(mine + o) = v;
+    if (tid < 32) slots[((size_t)par * n_wg + b) * 32 + tid] = (double)it + (sink == -1.0 ? 1.0 : 0.0);
+    if (stale) atomicAdd(err, stale);
+}
+extern "C" int vs_debug_xcd_chain_probe(unsigned int* err, void* payload, double* slots, int n_wg, int gsz, int pb, int it, void* stream) {
+    if (!err || !payload || !slots || n_wg <= 0 || n_wg > 1024 || gsz <= 0 || n_wg % gsz || pb < 4096 || (pb & 4095) || it < 1) return VS_EINVAL;
+    hipLaunchKernelGGL(xcd_chain_probe_kernel, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, err, (unsigned char*)payload, slots, n_wg, gsz, pb, it);
+    VS_CHECK_LAUNCH();
+    return VS_OK;
+}

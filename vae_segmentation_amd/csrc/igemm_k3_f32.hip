@@ -29,3 +29,6 @@ int g1_dispatch_k3_f32(const G1Params& p, int ck, int mt, int epi, int tiles, in
     K3_ALL_MT(8) K3_ALL_MT(16) K3_ALL_MT(32)
     return VS_ESHAPE;
 }
+
+// chain.h: the DoubleConv chains of the small volumes, fp32 storage (exact-f32 MFMA, as k3s_kernel<float>)
+int chain_dispatch_k3s_f32(const K3Chain& c, int bwd, hipStream_t s) { return k3s_chain_launch<float>(c, bwd != 0, s); }

@@ -12,11 +12,28 @@
 #pragma once
 #include <stdlib.h>
 #include "igemm.h"
+#include "chain.h"
 
 #ifndef K3_TICK                // phase stamps exist in the 16-bit translation units only (igemm_k3b.h)
 #define K3_TICK(i)
 #define K3_TICK_INIT
 #define K3_TICK_FLUSH
+#endif
+
+// diagnostic build only (-DVS_CHAIN_STAMPS, tools/chain_stamps.py): 100 MHz time stamps of the first XCD slot's workgroups, 16 per layer
+#if defined(VS_CHAIN_STAMPS) && defined(VS_CHAIN_STAMPS_TU)
+__device__ unsigned long long g_chain_stamps[64 * 64];
+extern "C" int vs_debug_read_chain_stamps(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_chain_stamps), sizeof(unsigned long long) * n); }
+#define CH_STAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64 && (i) < 64) g_chain_stamps[(blockIdx.x >> 3) * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// per-phase shader-clock sums of the stage loop (phases 1..5 of KS_TICK) -> stamps sb + 10 .. 14, the body's total -> sb + 15
+#define KS_TICK_INIT unsigned long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tk_last = __builtin_amdgcn_s_memtime(); const unsigned long long tk_first = tk_last;
+#define KS_TICK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk_acc[i] += now_ - tk_last; tk_last = now_; } while (0)
+#define KS_TICK_FLUSH do { if (threadIdx.x == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64) { for (int i_ = 1; i_ <= 5; ++i_) g_chain_stamps[(blockIdx.x >> 3) * 64 + sb + 9 + i_] = tk_acc[i_]; g_chain_stamps[(blockIdx.x >> 3) * 64 + sb + 15] = tk_last - tk_first; } } while (0)
+#else
+#define CH_STAMP(i)
+#define KS_TICK_INIT K3_TICK_INIT
+#define KS_TICK(i) K3_TICK(i)
+#define KS_TICK_FLUSH K3_TICK_FLUSH
 #endif
 
 #define K3S_LDS_RED 0          // float[4][16][2]
@@ -30,16 +47,24 @@
 // in every type: a 32-channel chunk of the 16-bit types, HALF a chunk (16 channels, one of the two k-groups the packed image holds per tap) of
 // fp32 — the exact-f32 MFMA runs at 1/16 of the 16-bit rate, so for fp32 the tap split over the waves and the unpadded columns matter even more
 // (k3_kernel at 6^3 x 128: 81 us, at 3^3 x 256: 142 us).
-template <bool SUMS, int TVC, bool HS, typename T = unsigned short>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k3s_kernel(const G1Params p) {
-    K3_TICK_INIT
+// CH (chain.h): the body runs as one layer of a chain kernel — its input (and, forward, the input's statistics) may have been written by other
+// workgroups of THIS launch: the weights of the first two stages are requested, then the workgroup waits for `wait_target` arrivals on `wait_ctr`
+// (none when wait_target == 0), then everything handed over is loaded with sc1 loads; the output is stored write-through (sc1).
+// XR: x stages in flight (registers).  The standalone kernels keep 2 (with the weights: a deeper ring measured slower there, round 3); the chain
+// kernels request up to 4 (6^3) / 8 (3^3) stages of the hand-over tensor at once — behind a layer boundary its lines come from the memory side,
+// not from L2, and a stage requested two stages ahead arrived late every time (tools/chain_stamps.py); the weights keep their ring of 2.
+template <bool SUMS, int TVC, bool HS, typename T, bool CH, int XR = 2>
+__device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const int ct, const int rb0, char* smem, unsigned int* wait_ctr = nullptr,
+                                         unsigned int wait_target = 0, unsigned int* fault = nullptr, const int sb = 0 /* CH_STAMP base */) {
+    KS_TICK_INIT
+    CH_STAMP(sb + 0);
+    constexpr int XAUX = CH ? VS_AUX_SC1 : 0;
     constexpr int NIT = TVC * 4 / 256;                   // 16-byte fragments per thread per stage
     constexpr int NWI = 7;                               // weight fragments per thread per stage (27 * 64 / 256)
     constexpr int NKW = 7;                               // taps per wave per chunk (wave w: w, w + 4, ...)
     constexpr int ES = (int)sizeof(T), EPL = 16 / ES, CHS = 64 / ES;     // element size, elements per fragment, channels per stage
     constexpr int SPC = 32 / CHS;                        // stages per 32-channel chunk of the packed weight image (1, or 2 for fp32)
     constexpr int NCG = TVC == 128 ? 2 : 4;              // 16-column groups that can hold voxels: up to 3x3x3 = 27 voxels fill two (the other two were 4.5 of 13 us of MFMA phase on padding)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_red = (float*)(smem + K3S_LDS_RED);
     char* s_tile = smem + K3S_LDS_TILE;
     const int PX = p.W + 2, PY = p.H + 2, TV = (p.D + 2) * PY * PX, V = p.D * p.H * p.W;
@@ -48,8 +73,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     float* s_shift = s_scale + p.C;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4;
-    const int n = blockIdx.x / p.tiles_per_sample, ct = blockIdx.x - n * p.tiles_per_sample;
-    const int rb0 = blockIdx.y;                          // 16-row block
     constexpr bool has_stats = HS;
     const i32x4 xrsrc = make_rsrc(p.x, (unsigned int)((long long)p.N * V * p.C * ES));
     const int nst = p.nch * SPC;                         // stages
@@ -80,13 +103,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         w_off[i] = rb0 * (p.nch * 27 * 64 * SPC) + kg * (64 * SPC) + (tid & 63);          // + (st / SPC) * 27 * 64 * SPC + (st % SPC) * 64
     }
     // two stages in flight (registers): with the MFMA phase this short, a stage requested only one stage ahead arrived late every time
-    u32x4 xv0[NIT], wv0[NWI], xv1[NIT], wv1[NWI];
-    auto load_stage = [&](int ch, u32x4 (&xv)[NIT], u32x4 (&wv)[NWI]) {
+    static_assert(XR >= 2 && XR % 2 == 0, "x ring depth");
+    u32x4 xv[XR][NIT], wv[2][NWI];
+    auto load_w = [&](int ch, u32x4 (&wv)[NWI]) {
 #pragma unroll
         for (int i = 0; i < NWI; ++i) wv[i] = wp[w_off[i] + (ch / SPC) * (27 * 64 * SPC) + (ch % SPC) * 64];
+    };
+    auto load_x = [&](int ch, u32x4 (&xv)[NIT]) {
 #pragma unroll
         for (int b = 0; b < NIT; ++b)
-            xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, goff[b] >= 0 ? goff[b] + ch * 64 : -1, 0, 0));
+            xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, goff[b] >= 0 ? goff[b] + ch * 64 : -1, 0, XAUX));
     };
     auto write_stage = [&](int ch, const u32x4 (&xv)[NIT], const u32x4 (&wv)[NWI]) {
         f32x2 sc[4], sh[4];                              // 16-bit: 8 channels; fp32: 4 (sc[0..1], sh[0..1])
@@ -122,12 +148,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     };
 
     // ---- first stage in flight; tables; per-lane read offsets ----------------------------------------------------------------
-    load_stage(0, xv0, wv0);
-    if (nst > 1) load_stage(1, xv1, wv1);
+    double st_pre[2] = {0.0, 1.0};                       // chain: this thread's first (sum, sumsq) pair, requested ahead of the fragments (vmcnt retires in order)
+    if constexpr (CH) {
+        load_w(0, wv[0]);
+        if (nst > 1) load_w(1, wv[1]);
+        CH_STAMP(sb + 1);
+        if (wait_target != 0) chain_wait(wait_ctr, wait_target, fault);
+        CH_STAMP(sb + 2);
+        if (has_stats && tid < p.C) stat_load_x<CH>(p.x_stats, (size_t)n * p.C + tid, (size_t)p.N * p.C, st_pre);
+#pragma unroll
+        for (int r = 0; r < XR; ++r)
+            if (r < nst) load_x(r, xv[r]);
+    } else {
+        load_w(0, wv[0]); load_x(0, xv[0]);
+        if (nst > 1) { load_w(1, wv[1]); load_x(1, xv[1]); }
+    }
     if (has_stats) {
         for (int c = tid; c < p.C; c += 256) {
             float m, r;
-            stats_to_mean_rstd_fast(p.x_stats, (size_t)n * p.C + c, (size_t)p.N * p.C, p.inv_count_in, p.eps, m, r);
+            double sv[2] = {st_pre[0], st_pre[1]};
+            if (!CH || c != tid) stat_load_x<CH>(p.x_stats, (size_t)n * p.C + c, (size_t)p.N * p.C, sv);
+            stats_to_mean_rstd_fast(sv, p.inv_count_in, p.eps, m, r);
             s_scale[c] = r; s_shift[c] = -m * r;
         }
     }
@@ -137,7 +178,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (row0 + r < p.M) {
-                stats_to_mean_rstd_fast(p.mask_stats, (size_t)n * p.M + row0 + r, (size_t)p.N * p.M, p.inv_count_out, p.eps, mm[r], mr[r]);
+                stats_to_mean_rstd_fast(p.mask_stats, (size_t)n * p.M + row0 + r, (size_t)p.N * p.M, p.inv_count_out, p.eps, mm[r], mr[r]);     // forward statistics: an earlier launch's
             }
     }
     if (p.bias != nullptr) {
@@ -174,7 +215,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                     // tables visible
-    K3_TICK(0);
+    KS_TICK(0);
+    if constexpr (CH) CH_STAMP(sb + 3);
 
     u32x4 wa[NKW];                                       // the current stage's A fragments (the stage registers are re-requested before the MFMAs)
     auto multiply = [&]() {
@@ -194,36 +236,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma16(a, b[cg], acc[cg], (T*)nullptr);
         }
     };
-    for (int ch = 0; ch < nst; ch += 2) {
-        if (ch > 0) __syncthreads();                     // every wave is done reading the previous stage
-        K3_TICK(1);
-        write_stage(ch, xv0, wv0);
-        K3_TICK(2);
-        __syncthreads();
-        K3_TICK(3);
+    for (int ch0 = 0; ch0 < nst; ch0 += XR) {
 #pragma unroll
-        for (int i = 0; i < NKW; ++i) wa[i] = wv0[i];
-        if (ch + 2 < nst) load_stage(ch + 2, xv0, wv0);
-        K3_TICK(4);
-        multiply();
-        K3_TICK(5);
-        if (ch + 1 < nst) {
+        for (int r = 0; r < XR; ++r) {
+            const int ch = ch0 + r;
+            if (ch >= nst) break;                         // workgroup-uniform
+            if (ch > 0) __syncthreads();                 // every wave is done reading the previous stage
+            KS_TICK(1);
+            write_stage(ch, xv[r], wv[r & 1]);
+            KS_TICK(2);
             __syncthreads();
-            K3_TICK(1);
-            write_stage(ch + 1, xv1, wv1);
-            K3_TICK(2);
-            __syncthreads();
-            K3_TICK(3);
+            KS_TICK(3);
 #pragma unroll
-            for (int i = 0; i < NKW; ++i) wa[i] = wv1[i];
-            if (ch + 3 < nst) load_stage(ch + 3, xv1, wv1);
-            K3_TICK(4);
+            for (int i = 0; i < NKW; ++i) wa[i] = wv[r & 1][i];
+            if (ch + 2 < nst) load_w(ch + 2, wv[r & 1]);
+            if (ch + XR < nst) load_x(ch + XR, xv[r]);
+            KS_TICK(4);
             multiply();
-            K3_TICK(5);
+            KS_TICK(5);
         }
     }
 
     // ---- the four waves' partial sums meet in LDS (the tile is dead); wave w finishes column group w ---------------------------------
+    if constexpr (CH) CH_STAMP(sb + 4);
     __syncthreads();
     f32x4* s_part = (f32x4*)s_tile;                      // [wave][cg][lane]
 #pragma unroll
@@ -262,13 +297,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         i32x2 pk;
         pk[0] = (int)H16<T>::pack2(lo);
         pk[1] = (int)H16<T>::pack2(hi);
-        vs_raw_buffer_store_b64(pk, yrsrc, valid ? e : -1, 0, 0);
+        vs_raw_buffer_store_b64(pk, yrsrc, valid ? e : -1, 0, XAUX);
         sv[0] = H16<T>::lo((unsigned int)pk[0]); sv[1] = H16<T>::hi((unsigned int)pk[0]);
         sv[2] = H16<T>::lo((unsigned int)pk[1]); sv[3] = H16<T>::hi((unsigned int)pk[1]);
     } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) sv[r] = o[r] + bv[r];
-        vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{sv[0], sv[1], sv[2], sv[3]}), yrsrc, valid ? e : -1, 0, 0);
+        vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{sv[0], sv[1], sv[2], sv[3]}), yrsrc, valid ? e : -1, 0, XAUX);
     }
     if (!valid) { sv[0] = 0.f; sv[1] = 0.f; sv[2] = 0.f; sv[3] = 0.f; }
     float ssum[4], ssq[4];
@@ -305,8 +340,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             }
         }
     }
-    K3_TICK(6);
-    K3_TICK_FLUSH;
+    KS_TICK(6);
+    KS_TICK_FLUSH;
+    if constexpr (CH) CH_STAMP(sb + 5);
+}
+
+template <bool SUMS, int TVC, bool HS, typename T = unsigned short>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k3s_kernel(const G1Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = blockIdx.x / p.tiles_per_sample, ct = blockIdx.x - n * p.tiles_per_sample;
+    k3s_body<SUMS, TVC, HS, T, false>(p, n, ct, (int)blockIdx.y /* 16-row block */, smem);
+}
+
+// ---- chain kernels (chain.h): the convolutions of a DoubleConv at one of these volumes in ONE launch --------------------------------------------
+// forward: layers 0 .. nl-1, each a 3x3x3 conv on the previous one's lazy output (layer 0: the chain's input, lazy or stored)
+// backward (BWD): layers in backward order, each a backward-data conv with the fused IN-backward sums of ITS output's activation (p.sums != nullptr;
+// then bit l of apply_mask: the apply pass runs in place before the next layer reads it) or a plain one (the stored input of the block)
+template <int TVC, typename T, bool BWD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k3s_chain_kernel(const K3Chain c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int XRC = TVC == 128 ? 8 : 4;               // x stages in flight: 2 fragments per thread and stage at 3^3, 8 at 6^3
+    const ChainPlace pl = chain_place(c);
+    const int item = pl.item;
+    if (item >= c.items) return;
+    const int ctiles = c.p[0].tiles_per_sample, ct = item % ctiles, rb0 = item / ctiles;
+    const unsigned int items = (unsigned int)c.items;
+    // Warm this XCD's L2 with every layer's weight rows of this workgroup (one dword per 128-byte line; the values are only consumed after the last
+    // layer): a stage's weight request otherwise goes to memory — ~3 us per pair of stages in flight (tools/chain_stamps.py), the largest share of a layer.
+    unsigned int warm[VS_CHAIN_MAX_LAYERS][8];
+#pragma unroll
+    for (int l = 0; l < VS_CHAIN_MAX_LAYERS; ++l) {
+        const G1Params& p = c.p[l < c.nl ? l : 0];
+        constexpr int SPCW = 32 / (64 / (int)sizeof(T));
+        const int lines = p.nch * 27 * 8 * SPCW;          // 128-byte lines of one 16-row block of the packed image
+        const char* base = (const char*)p.wp + (size_t)(rb0 < p.rb_total ? rb0 : 0) * lines * 128;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int ln = (int)threadIdx.x + 256 * k;
+            warm[l][k] = (l < c.nl && ln < lines) ? *(const unsigned int*)(base + (size_t)ln * 128) : 0u;
+        }
+    }
+    for (int n = pl.n0; n < c.p[0].N; n += pl.nstep) {
+        int phase = 0;
+        for (int l = 0; l < c.nl; ++l) {
+            const G1Params& p = c.p[l];
+            unsigned int* wc = phase > 0 ? chain_counter(c, n, phase - 1) : nullptr;
+            const unsigned int wt = phase > 0 ? items : 0u;
+            const bool active = rb0 < p.rb_total;          // layers with fewer output rows than the widest one leave the last workgroups idle (they still arrive)
+            if constexpr (BWD) {
+                if (!active) {}
+                else if (p.sums != nullptr) k3s_body<true, TVC, false, T, true, XRC>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+                else k3s_body<false, TVC, false, T, true, XRC>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+                if ((c.apply_mask >> l) & 1) {
+                    chain_arrive(chain_counter(c, n, phase));
+                    CH_STAMP(l * 16 + 6);
+                    chain_wait(chain_counter(c, n, phase), items, c.fault);
+                    CH_STAMP(l * 16 + 7);
+                    ++phase;
+                    chain_apply<T>(p.y, p.mask_x, p.mask_stats, p.sums, l + 1 == c.nl ? c.add : nullptr, n, p.N, p.D * p.H * p.W, p.M, p.inv_count_out, p.eps,
+                                   item, c.items, (float*)(smem + K3S_LDS_TILE));
+                    CH_STAMP(l * 16 + 8);
+                }
+            } else {
+                if (!active) {}
+                else if (p.x_stats != nullptr) k3s_body<false, TVC, true, T, true, XRC>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+                else k3s_body<false, TVC, false, T, true, XRC>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+            }
+            if (l + 1 < c.nl) { chain_arrive(chain_counter(c, n, phase)); ++phase; }
+            else __syncthreads();                        // the next sample of this slot reuses the LDS
+            CH_STAMP(l * 16 + 9);
+        }
+    }
+    unsigned int wx = 0;
+#pragma unroll
+    for (int l = 0; l < VS_CHAIN_MAX_LAYERS; ++l)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wx |= warm[l][k] & 0x7f800000u;
+    if (wx == 0xffffffffu) atomicOr(c.fault, 2u);        // never true: keeps the warming loads alive
 }
 
 // volumes this kernel takes (C a multiple of 32):
@@ -342,4 +452,43 @@ static int k3s_launch(const G1Params& p_in, hipStream_t stream) {
     if (TV <= 512) K3S_GO(512);
     return VS_ESHAPE;
 #undef K3S_GO
+}
+
+// host side of k3s_chain_kernel: c.p[l] hold pointers, N, D, H, W, C, M, eps, inv_counts; geometry is filled here.  VS_ESHAPE when the chain does not fit this kernel.
+static inline bool k3s_chain_takes(int d, int h, int w, int c_in) {
+    return c_in % 32 == 0 && c_in <= 1024 && (long long)(d + 2) * (h + 2) * (w + 2) <= 512;
+}
+template <typename T>
+static int k3s_chain_launch(K3Chain c, bool bwd, hipStream_t stream) {
+    const G1Params& p0 = c.p[0];
+    const int V = p0.D * p0.H * p0.W, TV = (p0.D + 2) * (p0.H + 2) * (p0.W + 2);
+    const int ctiles = (V + 63) / 64;
+    int rbmax = 0, cmax = 0;
+    for (int l = 0; l < c.nl; ++l) {
+        G1Params& p = c.p[l];
+        if (!k3s_chain_takes(p.D, p.H, p.W, p.C) || p.M % 8 || p.D != p0.D || p.H != p0.H || p.W != p0.W || p.N != p0.N) return VS_ESHAPE;
+        if (bwd ? (p.x_stats != nullptr || (p.sums == nullptr && ((c.apply_mask >> l) & 1))) : (p.sums != nullptr)) return VS_EINVAL;
+        p.tiles_per_sample = ctiles;
+        p.nch = p.C / 32;
+        p.rb_total = (p.M + 15) / 16;
+        rbmax = p.rb_total > rbmax ? p.rb_total : rbmax;
+        cmax = p.C > cmax ? p.C : cmax;
+        cmax = p.M > cmax ? p.M : cmax;
+    }
+    c.items = ctiles * rbmax;
+    const int grid = chain_grid(c);
+    if (grid == 0) return VS_ESHAPE;
+    const bool small = TV <= 128 && V <= 32;
+    const int tvc = small ? 128 : 512;
+    const size_t lds = K3S_LDS_TILE + (size_t)(tvc * 64 > 16384 ? tvc * 64 : 16384) + (size_t)2 * cmax * sizeof(float);
+    if (lds > 160 * 1024 || (size_t)4 * cmax * sizeof(float) > 16384) return VS_ESHAPE;
+    auto go = [&](auto kern) -> int {
+        const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr_err != hipSuccess) return (int)attr_err;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c);
+        VS_CHECK_LAUNCH();
+        return VS_OK;
+    };
+    if (small) return bwd ? go(k3s_chain_kernel<128, T, true>) : go(k3s_chain_kernel<128, T, false>);
+    return bwd ? go(k3s_chain_kernel<512, T, true>) : go(k3s_chain_kernel<512, T, false>);
 }

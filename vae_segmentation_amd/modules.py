@@ -128,13 +128,24 @@ class DoubleConv(nn.Module):
     def forward(self, x, _start=0):
         """_start = 3: x is already the (lazy) output of the first conv triple — Up ran it composed with its transposed conv (ops.UpConvK3)"""
         a, wrapped = _as_act(x, self.kernel_dtype)
-        for i in (0, 3, 6):
-            if i < _start:
-                continue
+        idx = [i for i in (0, 3, 6) if i >= _start]
+        if self.lazy_all() and ops.chain_ok(a.raw, a.stats, [self.conv[i] for i in idx]):
+            # the small volumes of the deep levels: the block's convolutions as ONE launch each way (ops.ConvK3Chain, csrc/chain.h)
+            params = []
+            for i in idx:
+                params += [self.conv[i].weight, self.conv[i].bias]
+            y, ys = ops.ConvK3Chain.apply(a.raw, a.stats, *params)
+            a = Act(y, ys)
+            return _as_tensor(a, self.out_ch) if wrapped else a
+        for i in idx:
             a = _conv_norm_act(self.conv, i, a)
             if i < 6 and a.stats is not None:
                 ops.mark_defer_apply(a.raw, self.conv[i])      # consumed once, by the next 3x3x3 conv: its IN-backward apply can be fused (ops._LAZY_APPLY)
         return _as_tensor(a, self.out_ch) if wrapped else a
+
+    def lazy_all(self):
+        """InstanceNorm + ReLU after every conv (the configuration every entry point of the reference uses)?"""
+        return all(isinstance(self.conv[i + 1], nn.InstanceNorm3d) and isinstance(self.conv[i + 2], nn.ReLU) for i in (0, 3, 6))
 
     def lazy_head(self):
         """InstanceNorm + ReLU after the first conv (the fused configuration)?"""

@@ -1041,6 +1041,153 @@ class ConvK3(torch.autograd.Function):
         return gx, None, gw, gb, None
 
 
+# ------------------------------------------------------------------------------------------------
+# Chains (csrc/chain.h, round 6): the 3x3x3 convolutions of one DoubleConv at the small volumes of the deep levels as ONE launch each way.
+# InstanceNorm3d is per (sample, channel), so consecutive layers of one sample hand their tensors over inside the launch instead of ending it.
+# ------------------------------------------------------------------------------------------------
+CHAIN = os.environ.get("VS_CHAIN", "1") != "0"
+
+
+class ChainLayer(_ct.Structure):
+    """vs_chain_layer (include/vaeseg.h)"""
+    _fields_ = [("x", _ct.c_void_p), ("x_stats", _ct.c_void_p), ("w_packed", _ct.c_void_p), ("y", _ct.c_void_p), ("y_stats", _ct.c_void_p),
+                ("mask_x", _ct.c_void_p), ("mask_stats", _ct.c_void_p), ("sums", _ct.c_void_p), ("c_in", _ct.c_int), ("m_out", _ct.c_int),
+                ("apply", _ct.c_int), ("reserved_", _ct.c_int)]
+
+
+_CHAIN_FAULT = {}
+
+
+def _chain_fault_word(device):
+    """the device word a chain kernel raises when one of its bounded waits gave up (never in a correct launch); read back by chain_fault()"""
+    key = torch.device(device)
+    t = _CHAIN_FAULT.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the chain fault word must exist before a capture starts: run the step eagerly once (GraphedStep warms up)")
+        t = _CHAIN_FAULT[key] = torch.zeros(32, dtype=torch.int32, device=key)
+    return t
+
+
+def chain_fault():
+    """Host check (synchronises): raises if any chain kernel of this process ever gave up a wait — its results, and everything after them, are invalid."""
+    for dev, t in _CHAIN_FAULT.items():
+        if int(t[0].item()) != 0:
+            raise _lib.VaesegError("a chain kernel on %s gave up a bounded wait (workgroups of one sample not co-resident): results invalid; set VS_CHAIN=0" % (dev,))
+
+
+def _chain_sync(n, device):
+    cnt = lib.vs_conv_k3_chain_sync_bytes(n) // 8
+    buf = _new_stats(1, cnt + 16, device, width=1).view(-1)
+    off = ((-buf.data_ptr()) % 128) // 8
+    return buf[off:off + cnt]
+
+
+def chain_ok(x, xs, convs):
+    """may these consecutive 3x3x3 convs (nn.Conv3d holders; InstanceNorm + ReLU between them) on the lazy input (x, xs) run as one chain?"""
+    if not CHAIN or len(convs) < 2 or len(convs) > 3 or x.dtype not in KERNEL_DTYPES:
+        return False
+    if getattr(x, "_vs_defer_apply", False):
+        return False                            # x's producer wants its gradient un-applied (the 8 / 16-channel layers): not these volumes
+    if any(tuple(c.weight.shape[2:]) != (3, 3, 3) for c in convs):
+        return False
+    n, d, h, w, c = x.shape
+    cmax = max([c] + [cpad(cv.weight.shape[0]) for cv in convs])
+    return bool(lib.vs_conv_k3_chain_supported(n, d, h, w, cmax, vs_dtype(x)))
+
+
+class ConvK3Chain(torch.autograd.Function):
+    """2 or 3 consecutive [3x3x3 conv -> InstanceNorm3d -> ReLU] triples of a DoubleConv (joint_model.py:35-52) on a lazy input; the output is lazy.
+    forward: ONE launch (vs_conv_k3_chain); backward: ONE launch for the backward-data convs and the InstanceNorm+ReLU backward applies between them,
+    the weight gradients join the pass's grouped launch as those of ConvK3 do.  The biases are dead, as in ConvK3."""
+
+    @staticmethod
+    def forward(ctx, x, xs, *params):
+        _require_cuda(x)
+        nl = len(params) // 2
+        weights, biases = params[0::2], params[1::2]
+        n, d, h, w, _ = x.shape
+        layers = (ChainLayer * nl)()
+        cur, curs, outs, keep = x, xs, [], []
+        nb = fl = 0.0
+        for l in range(nl):
+            wt = weights[l]
+            m = cpad(wt.shape[0])
+            wp = pack_weight_cached(wt, VS_PACK_ROWS_D0, cur.shape[-1], k3_pack_dtype(cur))
+            y = torch.empty((n, d, h, w, m), dtype=x.dtype, device=x.device)
+            ys = _new_stats(n, m, x.device)
+            layers[l] = ChainLayer(cur.data_ptr(), _p(curs), wp.data_ptr(), y.data_ptr(), ys.data_ptr(), None, None, None, cur.shape[-1], m, 0, 0)
+            keep.append(wp)
+            nb += (cur.numel() + y.numel() + wt.numel()) * _esize(x)
+            fl += 2.0 * n * d * h * w * 27 * wt.shape[0] * wt.shape[1]
+            outs.append((y, ys))
+            cur, curs = y, ys
+            if ctx.needs_input_grad[2 + 2 * l]:
+                _count_use(wt)
+        sync = _chain_sync(n, x.device)
+        with _timed("k3_chain<%s,fwd,%d>" % (_tname(x), nl), nb, fl, "x%s" % (tuple(x.shape),)):
+            check(lib.vs_conv_k3_chain(_ct.addressof(layers), nl, 0, None, sync.data_ptr(), _chain_fault_word(x.device).data_ptr(), n, d, h, w,
+                                       vs_dtype(x), EPS_IN, _stream()), "conv_k3_chain (forward)")
+        ctx.nl = nl
+        ctx.bias_refs = biases
+        ctx.save_for_backward(x, xs, *[t for pair in outs[:-1] for t in pair], *weights)
+        ctx.mark_non_differentiable(outs[-1][1])
+        ctx.set_materialize_grads(False)
+        return outs[-1]
+
+    @staticmethod
+    def backward(ctx, gy, _gys):
+        nl = ctx.nl
+        saved = ctx.saved_tensors
+        none = (None,) * (2 + 2 * nl)
+        if gy is None:
+            return none
+        acts = [(saved[0], saved[1])] + [(saved[2 + 2 * i], saved[3 + 2 * i]) for i in range(nl - 1)]      # the input of layer l
+        weights = saved[2 * nl:]
+        gy = _contig(gy)
+        lazy = _take_lazy(gy)
+        if lazy is not None:
+            gy = apply_lazy(gy, lazy)
+        n, d, h, w, _ = gy.shape
+        dev = gy.device
+        layers = (ChainLayer * nl)()
+        applied = [None] * nl                      # dL/d(raw output of layer l): what layer l's weight gradient reads
+        applied[nl - 1] = gy
+        g_in, add, keep = gy, None, []
+        nb = fl = 0.0
+        for k, l in enumerate(range(nl - 1, -1, -1)):
+            ax, axs = acts[l]
+            wt = weights[l]
+            wpb = pack_weight_cached(wt, VS_PACK_ROWS_D1_FLIP, g_in.shape[-1], k3_pack_dtype(g_in))
+            g = torch.empty_like(ax)
+            sums = _new_stats(n, ax.shape[-1], dev) if axs is not None else None
+            if l == 0 and axs is not None:
+                add = _collect_gradient(ax)         # a skip's gradient of the block's (lazy) input, parked by Materialize.backward
+            layers[k] = ChainLayer(g_in.data_ptr(), None, wpb.data_ptr(), g.data_ptr(), None, ax.data_ptr() if axs is not None else None, _p(axs), _p(sums),
+                                   g_in.shape[-1], ax.shape[-1], 1 if axs is not None else 0, 0)
+            keep += [wpb, sums]
+            nb += (g_in.numel() + (4 if axs is not None else 1) * g.numel() + wt.numel()) * _esize(gy)
+            fl += 2.0 * n * d * h * w * 27 * wt.shape[0] * wt.shape[1]
+            if l > 0:
+                applied[l - 1] = g
+            g_in = g
+        sync = _chain_sync(n, dev)
+        with _timed("k3_chain<%s,bwd,%d>" % (_tname(gy), nl), nb, fl, "gy%s" % (tuple(gy.shape),)):
+            check(lib.vs_conv_k3_chain(_ct.addressof(layers), nl, 1, _p(add), sync.data_ptr(), _chain_fault_word(dev).data_ptr(), n, d, h, w,
+                                       vs_dtype(gy), EPS_IN, _stream()), "conv_k3_chain (backward)")
+        out = [g_in if ctx.needs_input_grad[0] else None, None]
+        for l in range(nl):
+            wt, bias = weights[l], ctx.bias_refs[l]
+            gw = gb = None
+            if ctx.needs_input_grad[2 + 2 * l]:
+                ax, axs = acts[l]
+                gw, _ = _side_grads(wt, (applied[l], ax, axs), (applied[l], None, ax, axs, wt.shape[0], wt.shape[1], VS_CONV_K3), None, None)
+            if bias is not None and ctx.needs_input_grad[3 + 2 * l]:
+                gb = _dead_bias_grad(bias, bias.shape[0], dev)
+            out += [gw, gb]
+        return tuple(out)
+
+
 class ConvK3Softmax(torch.autograd.Function):
     """out_block (3x3x3 conv, live bias) + Softmax(dim=1) -> planar fp32 probabilities (joint_model.py:224-225,265-266 / 366-367,386-388):
     ONE fused launch for two classes (every BASELINE configuration), conv + softmax pass for 1 or 3..8 classes."""
