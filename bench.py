@@ -48,6 +48,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # products per fp32 product (csrc/igemm_k3x.h): its matrix peak is the bf16 dense peak / 6 = 416.7 TFLOP/s of fp32-equivalent work
 # (the exact-f32 MFMA it replaces peaks at 157.3)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 2500.0 / 6.0}
+EXACT_F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 — stated beside the limb peak wherever the fp32 mode's fraction is quoted
 
 
 def parse():
@@ -101,7 +102,7 @@ def build(side, dtype, rank, batch=BATCH, teacher=False):
     teacher: a second, fully frozen Joint whose Seg has another fill (main_target.py:397-406: the teacher starts as a copy and drifts by EMA)."""
     import torch
     import joint_model as M
-    from oracle import ref_cpu as O      # only for the RNG-free weight fill / synthetic inputs shared with the tests
+    from vae_segmentation_amd import synthetic as O      # the package's own RNG-free weight fill / synthetic volumes (the oracle is imported by cpu_baseline only)
     kd = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dtype]
 
     def make(seg_seed=None, frozen=False):
@@ -273,7 +274,9 @@ def step_roofline(dtype, ms_per_step, families, config="joint96"):
     t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flops / (MFMA_PEAK_TFLOPS[dtype] * 1e12)
     out = {"scope": "whole step (one HIP-graph replay + optimiser launches)",
            "algorithmic_bytes_per_step": nbytes, "algorithmic_flops_per_step": flops,
-           "mfma": {"achieved": flops / sec / 1e12, "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": flops / sec / 1e12 / MFMA_PEAK_TFLOPS[dtype]},
+           "mfma": dict({"achieved": flops / sec / 1e12, "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": flops / sec / 1e12 / MFMA_PEAK_TFLOPS[dtype]},
+                        **({"peak_note": "bf16 dense peak / 6 (six limb products per fp32 product); the exact-f32 MFMA peak is %.1f TFLOP/s: frac_of_exact_f32_peak"
+                                         % EXACT_F32_MFMA_PEAK_TFLOPS, "frac_of_exact_f32_peak": flops / sec / 1e12 / EXACT_F32_MFMA_PEAK_TFLOPS} if dtype == "fp32" else {})),
            "hbm": {"achieved": nbytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS}}
     lead = "hbm" if t_hbm >= t_mfma else "mfma"
     out.update({"bound": lead, "achieved": out[lead]["achieved"], "peak": out[lead]["peak"], "unit": out[lead]["unit"], "frac": out[lead]["frac"],
@@ -292,20 +295,29 @@ def other_configs(a, rank, torch):
     10 timed steps each — and the same whole-step roofline object, so that the driver's record carries a number for every single-GPU
     configuration of BASELINE.json."""
     import copy
+    import joint_model
     out = []
-    for name in ("da128", "joint160"):
+    # configs[4] is worded "160^3 fp16 ... WITH activation checkpointing": timed both ways (round 6) — recomputation off is how the step runs by default
+    # (3.5 GB of 288 GB: DESIGN.md section 4.4), recomputation on is the configuration as BASELINE.json names it
+    for name, recompute in (("da128", False), ("joint160", False), ("joint160", True)):
         b = copy.copy(a)
         cfg = CONFIGS[name]
         b.config, b.side, b.batch, b.dtype = name, cfg["side"], cfg["batch"], cfg["dtype"]
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
         info = {}
-        step, _, _, closer = make_step(b, b.dtype, rank, False, info=info)
-        n, w = 10, 3
-        dt, loss = timed_steps(step, n, w, lambda: torch.cuda.synchronize())
+        joint_model.set_recompute(recompute)
+        try:
+            step, _, _, closer = make_step(b, b.dtype, rank, False, info=info)
+            n, w = 10, 3
+            dt, loss = timed_steps(step, n, w, lambda: torch.cuda.synchronize())
+        finally:
+            joint_model.set_recompute(False)
         ms = 1e3 * dt / n
-        out.append({"config": name, "workload": (cfg["name"] % (b.side, b.batch)) + ", %s activations + fp32 accumulate%s, SGD momentum 0.9, VAE frozen, "
-                    "HIP-graph replay" % (b.dtype, " + dynamic loss scaling" if b.dtype == "fp16" else ""),
+        out.append({"config": name, "workload": (cfg["name"] % (b.side, b.batch)) + ", %s activations + fp32 accumulate%s, %s, SGD momentum 0.9, VAE frozen, "
+                    "HIP-graph replay" % (b.dtype, " + dynamic loss scaling" if b.dtype == "fp16" else "",
+                                          "WITH activation recomputation in every Down / Up block (\"checkpointing\")" if recompute else "activations kept (no recomputation)"),
+                    "activation_recomputation": recompute,
                     "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[b.dtype], "value": b.batch * n / dt, "unit": "volumes/s",
                     "ms_per_step": ms, "steps": n, "warmup": w, "final_loss": float(loss.item()), "tail_in_graph": info.get("tail_in_graph", False),
                     "peak_device_memory_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
@@ -444,6 +456,8 @@ def main():
         n32 = max(5, min(a.steps, 10))
         dt32, _ = timed_steps(step32, n32, 2, lambda: torch.cuda.synchronize())
         fp32_mode = {"ms_per_step": 1e3 * dt32 / n32, "value": a.batch * n32 / dt32, "unit": "volumes/s", "steps": n32,
+                     "tflops": CONFIGS[a.config]["flops"] * a.batch * n32 / dt32 / 1e12, "limb_peak_tflops": MFMA_PEAK_TFLOPS["fp32"],
+                     "exact_f32_mfma_peak_tflops": EXACT_F32_MFMA_PEAK_TFLOPS,
                      "note": "fp32 storage; 3x3x3 convolutions and their weight gradients on the bf16 matrix cores through three-limb operand splitting (six exact "
                              "limb products per product, fp32 accumulation: csrc/igemm_k3x.h) - the mode that meets the 1e-3 parity gate (tests/test_gpu_model.py); "
                              "round 3 ran it on the exact-f32 MFMA at 9.83 ms"}

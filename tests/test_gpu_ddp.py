@@ -276,6 +276,21 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     assert cfg["tail_in_graph"] is False                       # gloo collectives are not capturable: the tail stays eager (RCCL: test below)
 
 
+def test_bench_four_gloo_ranks_rendezvous_and_one_json_line():
+    """The world size the driver will use is 8; the one-GPU box admits at most 6 processes on its card (and this pytest process is one of them), so the rendez-vous,
+    port handling, legs budget and the one-JSON-line contract are rehearsed at FOUR ranks sharing cuda:0 through gloo (VERDICT r05 item 7b asked for 8: not runnable
+    here), at a side where a step is milliseconds."""
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--backend", "gloo", "--share-gpu", "--steps", "3", "--warmup", "1",
+                          "--side", "32", "--no-families", "--legs-budget-s", "120", "--master-port", "29561"],
+                         env=dict(os.environ, PYTHONPATH=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 4 and rec["scaling"] == "weak" and rec["value"] > 0 and rec["config"]["global_batch"] == 8 and rec["config"]["nranks"] == 4
+    assert rec["cpu_baseline"] is None and rec["config"]["exchange"]["no_exchange_ms_per_step"] > 0
+
+
 def test_bench_one_rank_rccl_whole_step_is_one_graph():
     """bench.py --force-dist on one rank through RCCL: the all-reduce, the SGD launch and the weight re-pack are captured into the step's graph
     (config.tail_in_graph) and the line carries the exchange legs."""

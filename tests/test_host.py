@@ -233,7 +233,24 @@ def test_main_target_parses_every_reference_flag_with_the_reference_defaults(cap
                            "--alpha", "0.99", "--update_every_iteration", "--generate_bounding_boxes", "--shift", "4"])
     assert a.fix_layer and a.from_scratch and a.vae_mont_number == 2 and a.vae_forward_scale == 0.35 and a.shift == 4 and a.load_prefix_encoder == "e"
     assert "accepted and ignored" in capsys.readouterr().err                       # the dump / figure flags say what happens to them
-    with pytest.raises(AssertionError):                                            # main_target.py:145: more than one pass needs a forward scale
+    with pytest.raises(SystemExit, match="inconsistent flags"):                                            # main_target.py:145: more than one pass needs a forward scale
         main_target.parse(["r", "--vae_mont_number", "2"])
     with pytest.raises(SystemExit, match="pseudo_list"):                           # not built: refuses instead of training something else
         main_target.parse(["r", "--pseudo_list", "NIH_pseudo"])
+
+
+def test_synthetic_matches_the_oracle_generators():
+    """bench.py builds its workload from vae_segmentation_amd/synthetic.py (product code, no oracle import in the benchmark's set-up); the values are
+    the oracle's fixtures' (oracle/ref_cpu.py), so `final_loss` in the bench line stays comparable with the goldens' inputs."""
+    import torch
+    from oracle import ref_cpu as O
+    from vae_segmentation_amd import synthetic as S
+    assert torch.equal(S.synthetic_image(2, 12, 7), O.synthetic_image(2, 12, 7))
+    assert torch.equal(S.synthetic_label(2, 12, 9), O.synthetic_label(2, 12, 9))
+    a, b = O.Segmentation(1, 2, norm_type=1), O.Segmentation(1, 2, norm_type=1)
+    S.deterministic_fill_(a, seed=3)
+    O.deterministic_fill_(b, seed=3)
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+    src = open(os.path.join(REPO, "bench.py")).read()
+    build_src = src[src.index("def build("):src.index("def usable_cores")]
+    assert "oracle" not in build_src.replace("the oracle is imported by cpu_baseline only", "")

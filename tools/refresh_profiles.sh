@@ -16,8 +16,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- p
 python3 $ROOT/tools/step_trace.py $(find $OUT/stats -name "*kernel_trace.csv" | head -1) $OUT/step_kernels.json > $OUT/step_kernels.txt
 echo "stats done"
 # 3. HBM traffic (separate passes, MI355X_MICROARCH.md HBM section)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-other-configs > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-fp32-mode --no-other-configs > /dev/null 2> $OUT/pmc_write.err
+# (--no-families since round 6: the eager family-timing legs put spin_kernel / per-step pack launches into the average — VERDICT r05 weak 8; $Q = graph replay only)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 $ROOT/bench.py --steps 5 --warmup 1 $Q > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 $ROOT/bench.py --steps 5 --warmup 1 $Q > /dev/null 2> $OUT/pmc_write.err
 python3 $ROOT/tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write auto $OUT/hbm_traffic.json > $OUT/hbm_traffic.txt
 echo "traffic done"
 # 4. matrix-core counters

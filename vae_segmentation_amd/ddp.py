@@ -120,13 +120,43 @@ def average_supported(group=None):
     return _AVG_OK[key]
 
 
-def _let_watchdog_reap():
+_WATCHDOG_PERIOD_S = 0.1          # torch's ProcessGroupNCCL watchdog: one event query per collective in flight every 100 ms
+_LAST_EAGER = [0.0]               # time.monotonic() of the last eager collective this package knows of
+
+
+def note_eager_collective():
+    """call after issuing an eager (un-captured) collective: quiesce_before_capture() measures its wait from here"""
+    import time
+    _LAST_EAGER[0] = time.monotonic()
+
+
+def quiesce_before_capture(group=None):
     """torch's RCCL process group checks the completion of every eager collective from a watchdog thread (an event query every 100 ms).  A stream capture
     that starts before the watchdog has seen the last eager collective complete makes that query an "operation not permitted when stream is capturing"
-    and takes the process down — seen when this module's probes ran right in front of GraphedStep's capture.  The probes run once per group: they wait."""
+    and takes the process down — seen when this module's probes ran right in front of GraphedStep's capture, and possible wherever an eager collective
+    (the entry points' per-epoch barrier, broadcast_parameters, an eager step) precedes a (re-)capture.  So EVERY capture of a step goes
+    through here first (train.GraphedStep._capture): the device is drained — every eager collective has completed — and the host then waits until at
+    least three watchdog periods have passed since the last eager collective this package issued (two periods when it knows of none: one issued by
+    other code just before the call), so the watchdog has polled the completed work and holds no event it would query during the capture.
+    A no-op without an initialised RCCL group.  Captures are rare (once per GraphedStep, again when the live parameter set changes)."""
     import time
+    if not (dist.is_available() and dist.is_initialized() and torch.cuda.is_available()):
+        return
+    try:
+        if dist.get_backend(group) != "nccl":
+            return
+    except (RuntimeError, ValueError):
+        return
     torch.cuda.synchronize()
-    time.sleep(0.3)
+    since = time.monotonic() - _LAST_EAGER[0]
+    known_recent = _LAST_EAGER[0] != 0.0 and since <= 3 * _WATCHDOG_PERIOD_S
+    time.sleep(3 * _WATCHDOG_PERIOD_S - since if known_recent else 2 * _WATCHDOG_PERIOD_S)
+
+
+def _let_watchdog_reap():
+    """after one of this module's once-per-group probe collectives"""
+    note_eager_collective()
+    quiesce_before_capture()
 
 
 class FlatGradSync:
@@ -197,6 +227,7 @@ class FlatGradSync:
         if self.world > 1:
             for p in self.params:
                 dist.broadcast(p.data, src, group=self.group)
+            note_eager_collective()
 
     # -- phases ---------------------------------------------------------------------------------------------------
     def live(self):
@@ -256,6 +287,8 @@ class FlatGradSync:
             dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
             b.mul_(1.0 / self.world)
             return
+        if not torch.cuda.is_current_stream_capturing():
+            note_eager_collective()                                 # an eager step's exchange: a (re-)capture that follows must wait for the watchdog (quiesce_before_capture)
         if self.resolve_avg():
             self._works.append((dist.all_reduce(b, op=dist.ReduceOp.AVG, group=self.group, async_op=self._async), None))   # RCCL averages in the reduction
             return

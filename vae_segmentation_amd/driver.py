@@ -195,7 +195,10 @@ def save_checkpoint(prefix, epoch_label, model, optimizer, best):
 # validation (main_source.py:688-822): batch 1, hard Dice of the argmax prediction against the label
 # ----------------------------------------------------------------------------------------------------
 @torch.no_grad()
+@torch.no_grad()
 def validate(method, model, loader, nc):
+    """main_source.py:688-822 / main_target.py:754-805: batch-1 forwards and hard Dice per case.  Forward only (no autograd graph is recorded: nothing is kept
+    for a backward pass — the per-(n, c) statistics the conv epilogues accumulate are the FORWARD's own, the next layer normalises with them)."""
     scores = {}
     for i, batch in enumerate(loader):
         gt = ops.onehot(batch[LABEL_KEY].cuda(non_blocking=True), nc)
@@ -334,6 +337,18 @@ def run(args, side="source"):
     sync = ddp.FlatGradSync(params) if world > 1 else None
     if sync is not None:
         sync.broadcast_parameters(0)
+        # the trainable list is not the whole replica: frozen or freshly initialised layers (--fix_layer, --from_scratch, a VAE without a checkpoint) and
+        # the teacher must agree across ranks too, or the replicas differ from the first forward on
+        seen = {id(p) for p in params}
+        for mod in (model, teacher):
+            if mod is None:
+                continue
+            for t in list(mod.parameters()) + list(mod.buffers()):
+                if id(t) not in seen and t.is_cuda:
+                    seen.add(id(t))
+                    dist.broadcast(t.data, 0)
+        ddp.note_eager_collective()
+        ops.weights_changed()
     # fp16 storage: Dice gradients are O(1e-6), below fp16's normal range — dynamic loss scaling on the device (optim.LossScaler)
     scaler = optim.LossScaler() if dtype == torch.float16 else None
     skw = {} if scaler is None else {"scaler": scaler}
@@ -505,6 +520,7 @@ def run(args, side="source"):
             best = max(best, mean)
         if world > 1:
             dist.barrier()
+            ddp.note_eager_collective()         # the next epoch may rebuild / re-capture its GraphedStep: ddp.quiesce_before_capture waits on this
         if args.test_only:
             break
     if world > 1:
@@ -517,16 +533,19 @@ def run(args, side="source"):
 def check_target_flags(a):
     """main_target.py:145-170: the reference's own consistency asserts, plus what this entry point does with the flags it does not act on."""
     import sys
+    def need(cond, what):                                                    # the reference asserts; `python -O` strips asserts, an entry point must not
+        if not cond:
+            raise SystemExit("main_target.py: inconsistent flags — " + what)
     if a.vae_mont_number != 1:
-        assert a.vae_forward_scale != 0.0                                    # main_target.py:145
+        need(a.vae_forward_scale != 0.0, "--vae_mont_number != 1 needs a non-zero --vae_forward_scale")                                 # main_target.py:145
     if a.from_scratch:
-        assert a.method == "domain_adaptation" and not a.test_only           # :157-159
+        need(a.method == "domain_adaptation" and not a.test_only, "--from_scratch belongs to --method domain_adaptation, not to --test_only")   # :157-159
     if a.kl:
-        assert a.method == "domain_adaptation" and a.domain_loss_type in (0, 8)      # :162-164
+        need(a.method == "domain_adaptation" and a.domain_loss_type in (0, 8), "--kl belongs to domain_adaptation with --domain_loss_type 0 or 8")   # :162-164
     if a.update_every_iteration:
-        assert a.pseudo_save_epoch == 1                                      # :168
+        need(a.pseudo_save_epoch == 1, "--update_every_iteration needs --pseudo_save_epoch 1")                                           # :168
     if a.generate_bounding_boxes:
-        assert a.method == "domain_adaptation"                               # :170
+        need(a.method == "domain_adaptation", "--generate_bounding_boxes belongs to --method domain_adaptation")                        # :170
     if a.pseudo_list is not None:
         raise SystemExit("--pseudo_list: the second (pseudo-labelled) loader and its supervised step (main_target.py:228-307,615-692) are not built "
                          "in the native entry point; train without it or extend driver.run")

@@ -316,6 +316,8 @@ class GraphedStep:
 
     def _capture(self):
         two_phase = self._two_phase
+        from . import ddp as _ddp
+        _ddp.quiesce_before_capture(getattr(self.grad_sync, "group", None))      # an eager collective just before a capture takes the process down (ddp.py)
         self.graph = self.graph2 = None
         self.graph = torch.cuda.CUDAGraph()
         for p in self.params:
