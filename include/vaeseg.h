@@ -168,6 +168,15 @@ int vs_conv_k3_bwd_data_wgrad(const void* g, const void* act_x, const double* ac
 int vs_conv_k3_softmax2_bwd_data(const float* prob, const float* gprob, const void* gprob_cl, const void* w_packed, void* y, const void* mask_x,
                                  const double* mask_stats, double* sums, float* slabs, double* bias_part, int n, int d, int h, int w, int dtype,
                                  float eps, float drop_p, unsigned long long drop_seed, void* stream);
+/* vs_conv_gather_bwd_data (K3) FOLLOWED BY vs_instnorm_relu_bwd_apply of its output, in one launch (csrc/igemm_k3b.h EA, round 6): every workgroup keeps its tile's
+ * rounded outputs in registers, adds its partial IN-backward sums, arrives on its SAMPLE's counter (the statistics of joint_model.py:11's InstanceNorm3d are per
+ * sample: nothing of another sample is waited for), reads the complete sums back and stores y = dL/d(raw tensor) — the un-applied gradient is never written and the
+ * standalone apply launch disappears.  Results equal the two launches' bit for bit in the deterministic build.  sync: n * 1024 ZEROED bytes (8 counter shards per sample), 128-byte aligned,
+ * private to the call; fault: the device word of vs_conv_k3_chain.  16-bit storage, c_in a multiple of 32, volumes above 6^3 whose launch is one resident round
+ * (at most 512 workgroups: the 24^3 / 12^3 levels): vs_conv_k3_bwd_data_applied_supported says 1 / 0 (env VS_EPILOGUE_APPLY=0: always 0). */
+int vs_conv_k3_bwd_data_applied_supported(int n, int d, int h, int w, int c_in, int m_out, int dtype);
+int vs_conv_k3_bwd_data_applied(const void* x, const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,
+                                unsigned int* sync, unsigned int* fault, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);
 /* One DoubleConv (joint_model.py:35-52: three times [Conv3d 3x3x3 pad 1 -> InstanceNorm3d -> ReLU]) at the small volumes of the deep levels as ONE launch
  * (csrc/chain.h, round 6).  InstanceNorm3d is per (sample, channel) (joint_model.py:11), so layer l + 1 of sample n depends on layer l of sample n only: the
  * workgroups of a sample hand the raw output and its statistics over inside the launch (write-through stores, counter, sc1 loads) instead of ending it.

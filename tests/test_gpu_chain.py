@@ -108,3 +108,43 @@ def test_double_conv_module_takes_the_chain_and_matches(monkeypatch):
     assert len(res[False]) == len(res[True])
     for a, b in zip(res[False], res[True]):
         assert torch.equal(a, b)
+
+
+# (N, Cin, Cout, side): the 3x3x3 layers with lazy inputs at the 24^3 / 12^3 levels of configs[1] and at the 32^3 / 16^3 / 8^3 levels of configs[3]
+EA_CASES = [(2, 32, 32, 24), (2, 16, 32, 24), (2, 64, 64, 12), (2, 128, 64, 12), (2, 32, 64, 12), (1, 32, 32, 32), (1, 64, 64, 16), (1, 128, 128, 8), (3, 32, 32, 10)]
+
+
+@pytest.mark.parametrize("lib_mode", ["det", "atomic"], indirect=True)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", EA_CASES)
+def test_epilogue_apply_equals_backward_data_then_apply(case, dtype, lib_mode):
+    """k3b_kernel<..., EA> (csrc/igemm_k3b.h): the backward-data launch of a 3x3x3 conv on a lazy input applies the InstanceNorm+ReLU backward to its own outputs
+    after a per-sample arrival counter — against the two launches it replaces (which tests/test_gpu_layers.py pins to CPU autograd at these shapes)."""
+    ops = _ops()
+    n, cin, cout, side = case
+    torch.manual_seed(11)
+    x_cl = to_cl(torch.randn(n, cin, side, side, side), cin, dtype)
+    xs = ops.instnorm_stats(x_cl)
+    w = (torch.randn(cout, cin, 3, 3, 3) / (27 * cin) ** 0.5).cuda()
+    gy = to_cl(torch.randn(n, cout, side, side, side), cout, dtype)
+    assert ops.lib.vs_conv_k3_bwd_data_applied_supported(n, side, side, side, cout, cin, ops.vs_dtype(x_cl)), "the case must be one the kernel takes"
+    res = {}
+    was = ops.EPILOGUE_APPLY
+    try:
+        for ea in (False, True):
+            ops.EPILOGUE_APPLY = ea
+            x = x_cl.clone().requires_grad_(True)
+            wt = w.clone().requires_grad_(True)
+            with ops.arena_scope(x.device):
+                y, _ = ops.ConvK3.apply(x, xs, wt, None)
+                y.backward(gy)
+            res[ea] = (x.grad.clone(), wt.grad.clone())
+    finally:
+        ops.EPILOGUE_APPLY = was
+    ops.chain_fault()
+    for nm, a, b in zip(("gx", "gw"), res[False], res[True]):
+        if lib_mode == "det":
+            assert torch.equal(a, b), "%s differs (max %g)" % (nm, (a.double() - b.double()).abs().max().item())
+        else:
+            e = relerr(b.double().cpu(), a.double().cpu())
+            assert e < {torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dtype], "%s: %g" % (nm, e)

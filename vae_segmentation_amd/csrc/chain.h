@@ -74,6 +74,29 @@ __device__ __forceinline__ void chain_wait(unsigned int* ctr, unsigned int targe
     __syncthreads();
 }
 
+// The same for large groups (a 24^3 layer: 144 workgroups per sample): the counter is kept in 8 shards on lines of their own — arrivals on one line retire
+// ~12-20 ns apart (MI355X_MICROARCH.md fanin: 255 -> 1 in 3.2 us), so a single word costs a 144-workgroup group 2-3 us; a workgroup adds to shard
+// (blockIdx.x & 7), lanes 0..7 of the polling wave read one shard each.
+__device__ __forceinline__ void chain_arrive8(unsigned int* ctr8) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr8 + ((size_t)blockIdx.x & 7) * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void chain_wait8(unsigned int* ctr8, unsigned int target, unsigned int* fault) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int spins = 0;
+        for (;;) {
+            unsigned int v = lane < 8 ? __hip_atomic_load(ctr8 + (size_t)lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            if (__shfl(v, 0, 64) >= target) break;        // wave-uniform
+            if (++spins > (1 << 18)) { if (lane == 0) atomicOr(fault, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
 // aux bits of the raw buffer intrinsics on gfx950: bit 0 = sc0, bit 1 = nt, bit 4 = sc1
 #define VS_AUX_SC1 16
 

@@ -67,7 +67,8 @@ static int check_common(const void* x, const void* w, int n, int d, int h, int w
 static int gather_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                        void* y, double* y_stats, const void* mask_x, const double* mask_stats, double* sums,
                        int n, int d, int h, int w, int c_in, int m_out, int kind, int dtype, float eps, void* stream,
-                       const void* fa_x = nullptr, const double* fa_sums = nullptr, void* fa_dx = nullptr, int* fa_query = nullptr, float* wg_ws = nullptr) {
+                       const void* fa_x = nullptr, const double* fa_sums = nullptr, void* fa_dx = nullptr, int* fa_query = nullptr, float* wg_ws = nullptr,
+                       unsigned int* ea_sync = nullptr, unsigned int* ea_fault = nullptr, int* ea_query = nullptr) {
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
     if (!y || m_out <= 0 || m_out % 8 || ((uintptr_t)y & 15)) return VS_EINVAL;
@@ -77,6 +78,7 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = y; p.y_stats = y_stats; p.prob = nullptr;
     p.mask_x = mask_x; p.mask_stats = mask_stats; p.sums = sums;
     p.fa_x = fa_x; p.fa_sums = fa_sums; p.fa_dx = fa_dx; p.wg_ws = wg_ws;
+    p.ea_sync = ea_sync; p.ea_fault = ea_fault;
     if (sums && (!mask_x || !mask_stats || y_stats)) return VS_EINVAL;
     p.N = n; p.D = d; p.H = h; p.W = w;
     p.C = c_in; p.M = m_out;
@@ -109,6 +111,11 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     // workgroup per CU (512 VGPRs) — 32-row tiles halve both the repeats and the workgroup count (24^3 x 32: 144 workgroups, one round)
     if (kind == VS_CONV_K3 && fa_x != nullptr && ck == 32 && mt == 16 && rows16 % 32 == 0) mt = 32;
     const int row_tiles = rows16 / mt;
+    if (ea_query != nullptr) {                             // planning only: does k3b_kernel<32, 16, .., EA> take this backward-data launch?  (16-bit storage, 32-channel
+        *ea_query = (kind == VS_CONV_K3 && dtype != VS_F32 && ck == 32 && mt == 16 && sums != nullptr && !fa_x &&        // chunks, not a k3s volume, one resident round)
+                     !((long long)(d + 2) * (h + 2) * (w + 2) <= 512 && c_in <= 1024) && tiles * row_tiles <= 512) ? 1 : 0;
+        return VS_OK;
+    }
     if (fa_query != nullptr) {                             // planning only: would a fused-apply launch of this shape find a kernel?
         if (dtype == VS_F32)                               // parity mode: the 8 -> 8 full-resolution layers (k3xt_kernel<..., FA>, igemm_k3x.h)
             *fa_query = kind == VS_CONV_K3 && vs_conv_k3_f32_limbs(d, h, w, c_in) &&
@@ -158,6 +165,27 @@ extern "C" int vs_conv_k3_fused_apply_supported(int n, int d, int h, int w, int 
                                lazy_input ? (const double*)dummy : nullptr, lazy_input ? dsink : nullptr, n, d, h, w, c_in, m_out, VS_CONV_K3,
                                dtype, 1e-5f, nullptr, dummy, (const double*)dummy, nullptr, &ok);
     return rc == VS_OK ? ok : 0;
+}
+
+// ---- backward-data whose epilogue applies the InstanceNorm+ReLU backward itself (igemm_k3b.h EA, round 6) ----
+extern "C" int vs_conv_k3_bwd_data_applied_supported(int n, int d, int h, int w, int c_in, int m_out, int dtype) {
+    static const int on = getenv("VS_EPILOGUE_APPLY") ? atoi(getenv("VS_EPILOGUE_APPLY")) : 1;
+    if (!on || !vs_dtype_ok(dtype) || dtype == VS_F32) return 0;
+    static const char dummy[16] __attribute__((aligned(16))) = {0};        // planning only: no pointer is dereferenced
+    static double dsink[2];
+    int ok = 0;
+    const int rc = gather_impl(dummy, nullptr, dummy, nullptr, (void*)dummy, nullptr, dummy, (const double*)dummy, dsink, n, d, h, w, c_in, m_out, VS_CONV_K3, dtype,
+                               1e-5f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ok);
+    return rc == VS_OK ? ok : 0;
+}
+
+extern "C" int vs_conv_k3_bwd_data_applied(const void* x, const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,
+                                           unsigned int* sync, unsigned int* fault, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream) {
+    if (!mask_x || !mask_stats || !sums || !sync || !fault) return VS_EINVAL;
+    if (((uintptr_t)sync & 127) || ((uintptr_t)fault & 3)) return VS_EALIGN;
+    if (!vs_conv_k3_bwd_data_applied_supported(n, d, h, w, c_in, m_out, dtype)) return VS_ESHAPE;
+    return gather_impl(x, nullptr, w_packed, nullptr, y, nullptr, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, VS_CONV_K3, dtype, eps, stream,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, sync, fault);
 }
 
 // ---- backward-data with the layer's weight gradient fused (igemm_k3tw.h) ----

@@ -58,6 +58,11 @@ struct G1Params {
     const float* sm_gprob;
     const void* sm_gcl;
     double* wg_bias;
+    // k3b_kernel<..., EA> (igemm_k3b.h, round 6): backward-data whose epilogue also APPLIES the InstanceNorm+ReLU backward to its own outputs once the sample's
+    // sums are complete — per-sample arrival counters ea_sync[n * 32] (zeroed by the caller), ea_items workgroups per sample, ea_fault: chain.h's fault word
+    unsigned int* ea_sync;
+    unsigned int* ea_fault;
+    int ea_items;
 };
 
 // LDS carve (bytes)

@@ -17,6 +17,7 @@
 #pragma once
 #include <stdlib.h>
 #include "igemm.h"
+#include "chain.h"
 
 #ifdef VS_STAMPS   // diagnostic build only (tools/build_stamps.sh, tools/stamps_k3.py): per-phase cycle sums of wave 0
 __device__ unsigned long long g_k3_stamps[2048 * 8];
@@ -40,6 +41,7 @@ extern "C" int vs_debug_read_k3_stamps(unsigned long long* host, int n) {
 #define K3_TICK_FLUSH
 #endif
 
+#define K3B_EA_MAX_WGS 512     // k3b_kernel<..., EA>: workgroups of one launch (256 CUs x 2: 72 KB of LDS and two waves per SIMD each)
 #define K3B_LDS_RED 0          // float[4][64][2]
 #define K3B_LDS_TAPS 2048      // int[64]: byte offset of (k-group, lane group)'s tap in the halo tile (C = 8 / 16)
 #define K3B_LDS_TILE 2304      // halo tile, weight block, then the per-(n,c) tables
@@ -68,12 +70,18 @@ struct K3BGeom {
 // the input gradient arrives un-applied (p.x = g = dL/da of a = relu(norm(p.fa_x)), statistics p.x_stats,
 // IN-backward sums p.fa_sums) and the apply pass runs while the halo tile is staged; centre voxels also go to p.fa_dx when given (see
 // igemm_k3t.h, where the same is done for the 8 -> 8 layers)
-template <int CK, int MT, int EPI, bool SUMS, int YT = 4, bool HS = false, typename T = unsigned short, bool FA = false>
+// EA (backward-data with fused sums, ONE tile per workgroup, every workgroup of the launch resident — the 24^3 / 12^3 levels; round 6): the epilogue keeps its
+// rounded outputs and the mask values in registers, adds its partial sums, arrives on its SAMPLE's counter (chain.h's hand-off: InstanceNorm's dependency
+// domain is the sample), waits for the sample's other workgroups, reads the complete sums back (sc1) and stores the APPLIED gradient
+// rstd * (g * [xhat > 0] - m1 - xhat * m2) — in_relu_bwd_apply_kernel's arithmetic on the same rounded values, bit for bit in the deterministic build.
+// The un-applied tensor is never written, the standalone apply launch (6.2 us for ~1 us of work at these sizes) disappears.
+template <int CK, int MT, int EPI, bool SUMS, int YT = 4, bool HS = false, typename T = unsigned short, bool FA = false, bool EA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     YT == 8 ? 2 : (CK == 32 ? ((MT == 32 || FA) ? 1 : 2) : (MT == 32 ? (SUMS ? 2 : 3) : ((CK == 16 && SUMS) || FA ? 3 : 4))), 8))) void k3b_kernel(const G1Params p) {
     K3_TICK_INIT
     using GEO = K3BGeom<CK, MT, YT>;
     static_assert(!FA || (!HS && EPI == EPI_RAW), "fused apply: backward-data kernels");
+    static_assert(!EA || (SUMS && !FA && !HS && EPI == EPI_RAW), "epilogue apply: backward-data kernels with fused sums");
     static_assert(YT == 4 || (YT == 8 && CK < 32 && MT == 16), "tall tiles: single-chunk layers, 16 rows");
     constexpr int TV = GEO::TV, PLANE = (YT + 2) * 18;
     static_assert(CK == 8 || CK == 16 || CK == 32, "chunk width");
@@ -339,6 +347,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int cg = 0; cg < YT; ++cg) acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
         u32x2 mk[RB][YT];                                // mask tensor values under this tile's outputs (fused IN-bwd sums)
+        i32x2 pkk[EA ? RB : 1][EA ? YT : 1];             // EA: this tile's rounded outputs, kept for the apply
 
         for (int ch = 0; ch < p.nch; ++ch) {
             if (!first) __syncthreads();                 // every wave is done reading the previous stage
@@ -444,7 +453,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
                     i32x2 pk;
                     pk[0] = (int)H16<T>::pack2(lo);
                     pk[1] = (int)H16<T>::pack2(hi);
-                    vs_raw_buffer_store_b64(pk, yrsrc, valid ? ebase + cg * p.W * p.M * 2 + rb * 32 : -1, 0, 0);
+                    if constexpr (EA) pkk[rb][cg] = pk;
+                    else vs_raw_buffer_store_b64(pk, yrsrc, valid ? ebase + cg * p.W * p.M * 2 + rb * 32 : -1, 0, 0);
                     float v[4];
                     v[0] = H16<T>::lo((unsigned int)pk[0]); v[1] = H16<T>::hi((unsigned int)pk[0]);
                     v[2] = H16<T>::lo((unsigned int)pk[1]); v[3] = H16<T>::hi((unsigned int)pk[1]);
@@ -497,6 +507,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
                     if (t + G < t_end) __syncthreads();     // s_red is reused by a later flush
                 }
             }
+            if constexpr (EA) {
+                // ---- the sample's sums are complete once all of its workgroups have arrived; then the apply, on registers ----
+                unsigned int* ctr = p.ea_sync + (size_t)n * 256;          // 8 shards of 128 bytes per sample
+                chain_arrive8(ctr);
+                chain_wait8(ctr, (unsigned int)p.ea_items, p.ea_fault);
+                if (tid < MT) {
+                    const int row = rb0 * 16 + tid;
+                    float m = 0.f, r = 1.f, a = 0.f, b = 0.f;
+                    if (row < p.M) {
+                        stats_to_mean_rstd(p.mask_stats, (size_t)n * p.M + row, (size_t)p.N * p.M, p.inv_count_out, p.eps, m, r);     // the standalone apply's exact form
+                        double sv[2];
+                        stat_load_sc1(p.sums, (size_t)n * p.M + row, (size_t)p.N * p.M, sv);
+                        a = (float)(sv[0] * p.inv_count_out);
+                        b = (float)(sv[1] * p.inv_count_out);
+                    }
+                    *(f32x4*)(s_red + tid * 4) = f32x4{m, r, a, b};
+                }
+                __syncthreads();
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const bool rvalid = (rb0 + rb) * 16 + 4 * g < p.M;
+                    f32x4 tb[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tb[r] = *(const f32x4*)(s_red + (rb * 16 + 4 * g + r) * 4);
+#pragma unroll
+                    for (int cg = 0; cg < YT; ++cg) {
+                        const bool valid = rvalid && zx_ok && y0 + cg < p.H;
+                        const unsigned int gw[2] = {(unsigned int)pkk[rb][cg][0], (unsigned int)pkk[rb][cg][1]};
+                        const u32x2 xx = mk[rb][cg];
+                        const float gv[4] = {H16<T>::lo(gw[0]), H16<T>::hi(gw[0]), H16<T>::lo(gw[1]), H16<T>::hi(gw[1])};
+                        const float xq[4] = {H16<T>::lo(xx[0]), H16<T>::hi(xx[0]), H16<T>::lo(xx[1]), H16<T>::hi(xx[1])};
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float xh = (xq[r] - tb[r][0]) * tb[r][1];
+                            const float gm = xh > 0.f ? gv[r] : 0.f;
+                            o[r] = tb[r][1] * (gm - tb[r][2] - xh * tb[r][3]);
+                        }
+                        i32x2 po;
+                        po[0] = (int)H16<T>::pack2(f32x2{o[0], o[1]});
+                        po[1] = (int)H16<T>::pack2(f32x2{o[2], o[3]});
+                        vs_raw_buffer_store_b64(po, yrsrc, valid ? ebase + cg * p.W * p.M * 2 + rb * 32 : -1, 0, 0);
+                    }
+                }
+            }
         }
         cur = nxt;
         K3_TICK(6);
@@ -511,7 +566,7 @@ static inline void k3b_fastdiv(int d, unsigned int& m, unsigned int& s) {
     m = (unsigned int)((((1ull << (32 + s)) + (unsigned long long)d - 1) / (unsigned long long)d) - (1ull << 32));
 }
 
-template <typename T, int CK, int MT, int EPI, bool SUMS, int YT, bool HS, bool FA = false>
+template <typename T, int CK, int MT, int EPI, bool SUMS, int YT, bool HS, bool FA = false, bool EA = false>
 static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
     using GEO = K3BGeom<CK, MT, YT>;
     if (FA && (p_in.N * p_in.C > 192 || (CK < 32 && p_in.nch != 1) || !p_in.x_stats || !p_in.fa_sums)) return VS_ESHAPE;
@@ -530,7 +585,7 @@ static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     k3b_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3b_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
     if (SUMS != (p.sums != nullptr) || (SUMS && !FA && p.x_stats != nullptr)) return VS_EINVAL;
-    auto kern = k3b_kernel<CK, MT, EPI, SUMS, YT, HS, T, FA>;
+    auto kern = k3b_kernel<CK, MT, EPI, SUMS, YT, HS, T, FA, EA>;
     // idempotent one-time opt-in to the full 160 KiB of dynamic LDS (not a stream operation)
     static const hipError_t attr_err =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -542,6 +597,10 @@ static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     // one workgroup per tile while the tiles fit; the persistent cap `wg` is a multiple of 8 (kernel: XCD-aware walk).  Never round a
     // small grid down to a multiple of 8: the workgroups that then take two tiles double the latency of the whole launch.
     const int gx = tiles_total < wg ? tiles_total : wg;
+    if (EA) {                                            // one tile per workgroup, every workgroup resident (two per CU) while its sample's peers wait for it
+        if (gx != tiles_total || (long long)tiles_total * row_tiles > K3B_EA_MAX_WGS || !p.ea_sync || !p.ea_fault) return VS_ESHAPE;
+        p.ea_items = p.tiles_per_sample * row_tiles;
+    }
     hipLaunchKernelGGL(kern, dim3(gx, row_tiles), dim3(256), lds, stream, p);
     VS_CHECK_LAUNCH();
     return VS_OK;

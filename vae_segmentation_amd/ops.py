@@ -501,6 +501,7 @@ def _pending_done():
 # rstd * (g*mask - m1 - xhat*m2) while it stages its input — the standalone apply launch (3 tensor passes at 96^3) disappears.
 # An entry nobody took by the end of the pass means a consumer treated an un-applied gradient as applied: that is an error, not a fallback.
 FUSE_APPLY = os.environ.get("VS_FUSE_APPLY", "1") != "0"
+EPILOGUE_APPLY = os.environ.get("VS_EPILOGUE_APPLY", "1") != "0"      # A/B switch of k3b_kernel<..., EA> (the library reads the same variable)
 # channels of the activations whose producer has a fused-apply kernel: 8 / 16 (k3t, single-chunk k3b: the 96^3 / 48^3 levels).  The 32-channel
 # form (k3b<32,...,FA>, the 24^3 / 12^3 levels) measured slower twice (round 4: 2.519 -> 2.566 ms per step, profiles/r04_ab_fused_apply_32ch.json)
 # and left the library in round 5; so did 16-channel half stages of the same layers (two waves per SIMD, 19 launches fewer, +30..+43 us per step:
@@ -610,6 +611,23 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None, 
         else:
             _apply_in_place(g, x, xs, sums)
         return g, dx
+    if (not scatter and kind == VS_CONV_K3 and not defer and EPILOGUE_APPLY and (x.data_ptr(), tuple(x.shape)) not in _PENDING["grads"]
+            and lib.vs_conv_k3_bwd_data_applied_supported(gn, gd, gh, gw, gc, c, dt)):
+        # the 24^3 / 12^3 levels: the backward-data launch applies the InstanceNorm+ReLU backward to its own outputs (csrc/igemm_k3b.h EA): no apply launch
+        cnt = 128 * gn                         # 8 counter shards of 128 bytes per sample, zeroed with the arena
+        buf = _new_stats(1, cnt + 16, x.device, width=1).view(-1)
+        off = ((-buf.data_ptr()) % 128) // 8
+        sync = buf[off:off + cnt]
+        kid = nb = fl = None
+        if PROFILE is not None:
+            tiles = gn * ((gd + 3) // 4) * ((gh + 3) // 4) * ((gw + 15) // 16)
+            kid = _k3_kid(_tname(x), min(gc, 32), 16, sums=True, geom=(gn, gd, gh, gw), m=c) + "+ea"
+            nb = (gy.numel() + 2 * g.numel()) * _esize(x) + gc * c * 27 * _esize(x)
+            fl = 2.0 * (g.numel() // c) * 27 * gc * c
+        with _timed(kid, nb, fl, "bwd+ea gy%s->m%d" % (tuple(gy.shape), c)):
+            check(lib.vs_conv_k3_bwd_data_applied(gy.data_ptr(), wpb.data_ptr(), g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), sync.data_ptr(),
+                                                  _chain_fault_word(x.device).data_ptr(), gn, gd, gh, gw, gc, c, dt, EPS_IN, _stream()), "conv_k3_bwd_data_applied")
+        return g
     if scatter:
         kid = nb = fl = None
         if PROFILE is not None:

@@ -266,8 +266,12 @@ class GraphedStep:
         # grad_sync None = the caller wants no exchange (one rank, or a timing leg): nothing collective is captured then
         rccl_or_none = (grad_sync is None or (not dist.is_initialized()) or not getattr(grad_sync, "exchange", True)
                         or (dist.get_backend(grad_sync.group) == "nccl" and _ddp.collective_capturable(grad_sync.group)))
-        self.tail = (bool(capture_tail) and warmup >= 1 and not two_phase and isinstance(optimizer, _optim.SGD)
+        # round 6: the two-bucket overlapped form captures its tail too — ONE graph whose bucket-0 all-reduce node (the process group's stream, forked inside
+        # the capture) runs beside the bucket-1 weight-gradient nodes: no second graph launch, no eager cross-stream edges
+        self.tail = (bool(capture_tail) and warmup >= 1 and isinstance(optimizer, _optim.SGD)
                      and rccl_or_none and all(p.is_cuda for p in self.params))
+        if two_phase and os.environ.get("VS_GRAPH_TAIL_OVERLAP", "1") == "0":
+            self.tail = False                    # A/B: the round-5 form (two graphs, eager exchange between them)
         if grad_sync is not None and getattr(grad_sync, "exchange", True) and dist.is_initialized():
             grad_sync.resolve_avg()              # one eager probe collective per group, HERE — well before the capture (ddp._let_watchdog_reap says why)
         self._own_sync = False
@@ -333,6 +337,9 @@ class GraphedStep:
                 s = self.grad_sync
                 s._stragglers([p.grad for p in self.params])      # bookkeeping only (which parameters got no gradient): _prepare_tail saw no stragglers
                 s.start(0)
+                if two_phase:
+                    ops.flush_wgrads()           # the bucket-1 layers' weight gradients (the 96^3 / 48^3 levels): graph nodes BESIDE bucket 0's all-reduce node
+                    s.start(1)
                 s.wait()
                 kw = {} if self.scaler is None else {"scaler": self.scaler}
                 self.optimizer.step_with(*s.live(), device_hyper=True, **kw)
@@ -341,7 +348,7 @@ class GraphedStep:
             # the captured re-pack launch reads THIS descriptor table by address: a later registration of other trainable images (another
             # model's GraphedStep) replaces ops' table, and this graph's must outlive that (it used to be freed under the graph)
             self._repack_table = ops.repack_table()
-        if two_phase:
+        if two_phase and not self.tail:
             self.graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
                 ops.flush_wgrads()
