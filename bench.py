@@ -470,6 +470,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.side, a.cpu_steps, batch=a.batch, method=CONFIGS[a.config]["method"])
 
+    from vae_segmentation_amd import ops as _ops
+    _ops.chain_fault()                       # a chain / epilogue-apply kernel that gave up a bounded wait (csrc/chain.h) would have produced invalid steps: refuse to report them
     if rank == 0:
         vols = world * a.batch * a.steps / dt
         cfg = CONFIGS[a.config]

@@ -135,7 +135,8 @@ __device__ __forceinline__ void chain_apply(void* g_, const void* x_, const doub
                                             double inv_count, float eps, int item, int items, float* s_tab) {
     constexpr int EPL = ET<T>::EPL, ES = (int)sizeof(T);
     float *s_m = s_tab, *s_r = s_tab + c, *s_a = s_tab + 2 * c, *s_b = s_tab + 3 * c;
-    for (int i = threadIdx.x; i < c; i += 256) {
+    const int nt = (int)blockDim.x;
+    for (int i = threadIdx.x; i < c; i += nt) {
         float m, r;
         stats_to_mean_rstd(xs, (size_t)n * c + i, (size_t)nn * c, inv_count, eps, m, r);
         double sv[2];
@@ -149,7 +150,7 @@ __device__ __forceinline__ void chain_apply(void* g_, const void* x_, const doub
     const unsigned int bytes = (unsigned int)((long long)nn * voxels * c * ES);
     const i32x4 grsrc = make_rsrc(g_, bytes), xrsrc = make_rsrc(x_, bytes), arsrc = make_rsrc(add_ ? add_ : g_, bytes);
     const int sample = n * voxels * c * ES;
-    for (int f = item * 256 + (int)threadIdx.x; f < total; f += items * 256) {
+    for (int f = item * nt + (int)threadIdx.x; f < total; f += items * nt) {
         const int fx = f % frags;
         const int off = sample + f * 16;
         const u32x4 gq = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(grsrc, off, 0, VS_AUX_SC1));

@@ -7,6 +7,7 @@ int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, i
 int g1_dispatch_k3_f16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_k3_fa_supported(const G1Params& p, int ck, int mt);
 int k3tw_slab_count(int n, int d, int h, int w);
+int k3b_ea_capacity(int n, int c, int m);            // igemm_k3_bf16.hip: workgroups of a k3b_kernel<.., EA> launch that are certainly resident together
 int k2s2_scatter8_launch(const G1Params& p, int dtype, hipStream_t stream);      // k2s2_scatter8.hip        // igemm_k3_bf16.hip: workgroups (= slabs) of a k3tw_kernel launch
 int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 
@@ -113,7 +114,7 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     const int row_tiles = rows16 / mt;
     if (ea_query != nullptr) {                             // planning only: does k3b_kernel<32, 16, .., EA> take this backward-data launch?  (16-bit storage, 32-channel
         *ea_query = (kind == VS_CONV_K3 && dtype != VS_F32 && ck == 32 && mt == 16 && sums != nullptr && !fa_x &&        // chunks, not a k3s volume, one resident round)
-                     !((long long)(d + 2) * (h + 2) * (w + 2) <= 512 && c_in <= 1024) && tiles * row_tiles <= 512) ? 1 : 0;
+                     !((long long)(d + 2) * (h + 2) * (w + 2) <= 512 && c_in <= 1024) && tiles * row_tiles <= k3b_ea_capacity(n, c_in, m_out)) ? 1 : 0;
         return VS_OK;
     }
     if (fa_query != nullptr) {                             // planning only: would a fused-apply launch of this shape find a kernel?

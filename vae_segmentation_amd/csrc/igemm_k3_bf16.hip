@@ -12,3 +12,4 @@ int k3tw_slab_count(int n, int d, int h, int w) { return k3tw_grid(n, d, h, w); 
 
 // chain.h: the DoubleConv chains of the small volumes
 int chain_dispatch_k3s_bf16(const K3Chain& c, int bwd, hipStream_t s) { return k3s_chain_launch<unsigned short>(c, bwd != 0, s); }
+int k3b_ea_capacity(int n, int c, int m) { return k3b_ea_max_wgs(n, c, m); }

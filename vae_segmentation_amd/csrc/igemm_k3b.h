@@ -41,7 +41,6 @@ extern "C" int vs_debug_read_k3_stamps(unsigned long long* host, int n) {
 #define K3_TICK_FLUSH
 #endif
 
-#define K3B_EA_MAX_WGS 512     // k3b_kernel<..., EA>: workgroups of one launch (256 CUs x 2: 72 KB of LDS and two waves per SIMD each)
 #define K3B_LDS_RED 0          // float[4][64][2]
 #define K3B_LDS_TAPS 2048      // int[64]: byte offset of (k-group, lane group)'s tap in the halo tile (C = 8 / 16)
 #define K3B_LDS_TILE 2304      // halo tile, weight block, then the per-(n,c) tables
@@ -559,6 +558,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     K3_TICK_FLUSH;
 }
 
+// k3b_kernel<32, 16, .., SUMS, .., EA>: how many workgroups of one launch are certainly resident together — two per CU (two waves per SIMD by the register
+// budget) when two workgroups' LDS fit with room for the allocation granule, else one.  (Found the hard way: 10^3 x 256 rows needs 80 KB, one per CU; 288
+// workgroups then waited for 32 that could not start, gave up after the bounded spin and applied incomplete sums.)
+static inline int k3b_ea_max_wgs(int n, int c, int m) {
+    using GEO = K3BGeom<32, 16, 4>;
+    const size_t lds = K3B_LDS_TILE + (size_t)GEO::TILE_BYTES + GEO::W_BYTES + (size_t)2 * n * c * sizeof(float) + (size_t)2 * n * m * sizeof(float);
+    return 2 * (lds + 1024) <= 160 * 1024 ? 512 : 256;
+}
+
 // (m, s) with n / d == (mulhi(n, m) + n) >> s for every 0 <= n < 2^31
 static inline void k3b_fastdiv(int d, unsigned int& m, unsigned int& s) {
     s = 0;
@@ -597,8 +605,8 @@ static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     // one workgroup per tile while the tiles fit; the persistent cap `wg` is a multiple of 8 (kernel: XCD-aware walk).  Never round a
     // small grid down to a multiple of 8: the workgroups that then take two tiles double the latency of the whole launch.
     const int gx = tiles_total < wg ? tiles_total : wg;
-    if (EA) {                                            // one tile per workgroup, every workgroup resident (two per CU) while its sample's peers wait for it
-        if (gx != tiles_total || (long long)tiles_total * row_tiles > K3B_EA_MAX_WGS || !p.ea_sync || !p.ea_fault) return VS_ESHAPE;
+    if (EA) {                                            // one tile per workgroup, every workgroup resident while its sample's peers wait for it
+        if (gx != tiles_total || (long long)tiles_total * row_tiles > k3b_ea_max_wgs(p.N, p.C, p.M) || !p.ea_sync || !p.ea_fault) return VS_ESHAPE;
         p.ea_items = p.tiles_per_sample * row_tiles;
     }
     hipLaunchKernelGGL(kern, dim3(gx, row_tiles), dim3(256), lds, stream, p);

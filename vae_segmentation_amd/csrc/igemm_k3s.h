@@ -53,15 +53,20 @@ extern "C" int vs_debug_read_chain_stamps(unsigned long long* host, int n) { ret
 // XR: x stages in flight (registers).  The standalone kernels keep 2 (with the weights: a deeper ring measured slower there, round 3); the chain
 // kernels request up to 4 (6^3) / 8 (3^3) stages of the hand-over tensor at once — behind a layer boundary its lines come from the memory side,
 // not from L2, and a stage requested two stages ahead arrived late every time (tools/chain_stamps.py); the weights keep their ring of 2.
-template <bool SUMS, int TVC, bool HS, typename T, bool CH, int XR = 2>
+// NW: waves per workgroup (4, or 8 in the chain kernels).  These bodies are instruction-bound at one wave per SIMD with their phases in series
+// (tools/chain_stamps.py: per stage 0.45 us of normalise + LDS write of the WHOLE padded sample, 0.45 us of LDS reads + MFMA, 0.35 us of barrier skew):
+// with eight waves the staging pass and the 27 taps are split eight ways — two waves per SIMD interleave one another's phases.
+template <bool SUMS, int TVC, bool HS, typename T, bool CH, int XR = 2, int NW = 4>
 __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const int ct, const int rb0, char* smem, unsigned int* wait_ctr = nullptr,
                                          unsigned int wait_target = 0, unsigned int* fault = nullptr, const int sb = 0 /* CH_STAMP base */) {
     KS_TICK_INIT
     CH_STAMP(sb + 0);
     constexpr int XAUX = CH ? VS_AUX_SC1 : 0;
-    constexpr int NIT = TVC * 4 / 256;                   // 16-byte fragments per thread per stage
-    constexpr int NWI = 7;                               // weight fragments per thread per stage (27 * 64 / 256)
-    constexpr int NKW = 7;                               // taps per wave per chunk (wave w: w, w + 4, ...)
+    constexpr int NT = 64 * NW;                          // threads
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
+    constexpr int NIT = TVC * 4 / NT;                    // 16-byte fragments per thread per stage
+    constexpr int NKW = (27 + NW - 1) / NW;              // taps per wave per chunk (wave w: w, w + NW, ...): 7 or 4
+    constexpr int NWI = NKW;                             // weight fragments per thread per stage: its wave's taps
     constexpr int ES = (int)sizeof(T), EPL = 16 / ES, CHS = 64 / ES;     // element size, elements per fragment, channels per stage
     constexpr int SPC = 32 / CHS;                        // stages per 32-channel chunk of the packed weight image (1, or 2 for fp32)
     constexpr int NCG = TVC == 128 ? 2 : 4;              // 16-column groups that can hold voxels: up to 3x3x3 = 27 voxels fill two (the other two were 4.5 of 13 us of MFMA phase on padding)
@@ -88,7 +93,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     unsigned int swzbits = 0;
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
-        const int pv = (tid >> 2) + 64 * b;
+        const int pv = (tid >> 2) + (NT / 4) * b;
         const int t2 = sdiv(pv, inv_px), px = pv - t2 * PX, pz = sdiv(t2, inv_py), py = t2 - pz * PY;
         const bool ok = pv < TV && px >= 1 && px <= p.W && py >= 1 && py <= p.H && pz >= 1 && pz <= p.D;
         goff[b] = ok ? ((((n * p.D + pz - 1) * p.H + py - 1) * p.W + px - 1) * p.C + part * EPL) * ES : -1;
@@ -99,7 +104,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     int w_off[NWI];
 #pragma unroll
     for (int i = 0; i < NWI; ++i) {
-        const int kg = (tid >> 6) + 4 * i < 27 ? (tid >> 6) + 4 * i : 26;
+        const int kg = (tid >> 6) + NW * i < 27 ? (tid >> 6) + NW * i : 26;
         w_off[i] = rb0 * (p.nch * 27 * 64 * SPC) + kg * (64 * SPC) + (tid & 63);          // + (st / SPC) * 27 * 64 * SPC + (st % SPC) * 64
     }
     // two stages in flight (registers): with the MFMA phase this short, a stage requested only one stage ahead arrived late every time
@@ -141,7 +146,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
             }
-            const int pv = (tid >> 2) + 64 * b;           // < TVC: the tile region holds TVC voxels, fragments beyond TV are zeros
+            const int pv = (tid >> 2) + (NT / 4) * b;     // < TVC: the tile region holds TVC voxels, fragments beyond TV are zeros
             const int pw = part ^ (int)(((swzbits >> b) & 1u) << 1);
             *(u32x4*)(s_tile + pv * 64 + pw * 16) = v;
         }
@@ -164,7 +169,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
         if (nst > 1) { load_w(1, wv[1]); load_x(1, xv[1]); }
     }
     if (has_stats) {
-        for (int c = tid; c < p.C; c += 256) {
+        for (int c = tid; c < p.C; c += NT) {
             float m, r;
             double sv[2] = {st_pre[0], st_pre[1]};
             if (!CH || c != tid) stat_load_x<CH>(p.x_stats, (size_t)n * p.C + c, (size_t)p.N * p.C, sv);
@@ -201,7 +206,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
         }
 #pragma unroll
         for (int i = 0; i < NKW; ++i) {
-            int kg = wave + 4 * i;
+            int kg = wave + NW * i;
             if (kg > 26) kg = 26;
             const int dz = kg / 9, dy = (kg / 3) % 3, dx = kg % 3;
 #pragma unroll
@@ -226,7 +231,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
         for (int i = 0; i < NKW; ++i) {
             u32x4 a = wa[i];
             if (i == NKW - 1) {
-                const unsigned int keep = wave + 4 * i < 27 ? 0xffffffffu : 0u;
+                const unsigned int keep = wave + NW * i < 27 ? 0xffffffffu : 0u;
                 a[0] &= keep; a[1] &= keep; a[2] &= keep; a[3] &= keep;
             }
             u32x4 b[NCG];
@@ -267,7 +272,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     const int fcg = wave < NCG ? wave : 0;               // waves beyond the last column group finish nothing (valid = false below)
     f32x4 o = s_part[(0 * NCG + fcg) * 64 + lane];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) {
+    for (int w = 1; w < NW; ++w) {
         const f32x4 q = s_part[(w * NCG + fcg) * 64 + lane];
         o[0] += q[0]; o[1] += q[1]; o[2] += q[2]; o[3] += q[3];
     }
@@ -325,7 +330,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
         for (int r = 0; r < 4; ++r) {
             float s = ssum[r], q = ssq[r];
             { s = row16_sum(s); q = row16_sum(q); }
-            if (col == 0) {
+            if (col == 0 && wave < 4) {                   // (waves 4 .. 7 of an eight-wave workgroup finish no column group: their sums are zero)
                 s_red[(wave * 16 + 4 * g + r) * 2 + 0] = s;
                 s_red[(wave * 16 + 4 * g + r) * 2 + 1] = q;
             }
@@ -345,19 +350,23 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     if constexpr (CH) CH_STAMP(sb + 5);
 }
 
+// waves per workgroup: eight for the 6^3-class volumes (round 6: 2.422 -> 2.387 ms per 96^3 step in the chain kernels, same box), four at 3^3 (one fragment per
+// thread and stage there already; the eight-wave build spills).  Chain and standalone kernels use the same count: their results are bit-identical.
+template <int TVC> struct K3SWaves { static constexpr int NW = TVC == 128 ? 4 : 8; };
+
 template <bool SUMS, int TVC, bool HS, typename T = unsigned short>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k3s_kernel(const G1Params p) {
+__global__ __launch_bounds__(64 * K3SWaves<TVC>::NW) __attribute__((amdgpu_waves_per_eu(K3SWaves<TVC>::NW / 4, 2))) void k3s_kernel(const G1Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = blockIdx.x / p.tiles_per_sample, ct = blockIdx.x - n * p.tiles_per_sample;
-    k3s_body<SUMS, TVC, HS, T, false>(p, n, ct, (int)blockIdx.y /* 16-row block */, smem);
+    k3s_body<SUMS, TVC, HS, T, false, 2, K3SWaves<TVC>::NW>(p, n, ct, (int)blockIdx.y /* 16-row block */, smem);
 }
 
 // ---- chain kernels (chain.h): the convolutions of a DoubleConv at one of these volumes in ONE launch --------------------------------------------
 // forward: layers 0 .. nl-1, each a 3x3x3 conv on the previous one's lazy output (layer 0: the chain's input, lazy or stored)
 // backward (BWD): layers in backward order, each a backward-data conv with the fused IN-backward sums of ITS output's activation (p.sums != nullptr;
 // then bit l of apply_mask: the apply pass runs in place before the next layer reads it) or a plain one (the stored input of the block)
-template <int TVC, typename T, bool BWD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k3s_chain_kernel(const K3Chain c) {
+template <int TVC, typename T, bool BWD, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, 2))) void k3s_chain_kernel(const K3Chain c) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int XRC = TVC == 128 ? 8 : 4;               // x stages in flight: 2 fragments per thread and stage at 3^3, 8 at 6^3
     const ChainPlace pl = chain_place(c);
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const unsigned int items = (unsigned int)c.items;
     // Warm this XCD's L2 with every layer's weight rows of this workgroup (one dword per 128-byte line; the values are only consumed after the last
     // layer): a stage's weight request otherwise goes to memory — ~3 us per pair of stages in flight (tools/chain_stamps.py), the largest share of a layer.
-    unsigned int warm[VS_CHAIN_MAX_LAYERS][8];
+    unsigned int warm[VS_CHAIN_MAX_LAYERS][32 / NW];
 #pragma unroll
     for (int l = 0; l < VS_CHAIN_MAX_LAYERS; ++l) {
         const G1Params& p = c.p[l < c.nl ? l : 0];
@@ -375,8 +384,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const int lines = p.nch * 27 * 8 * SPCW;          // 128-byte lines of one 16-row block of the packed image
         const char* base = (const char*)p.wp + (size_t)(rb0 < p.rb_total ? rb0 : 0) * lines * 128;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int ln = (int)threadIdx.x + 256 * k;
+        for (int k = 0; k < 32 / NW; ++k) {
+            const int ln = (int)threadIdx.x + 64 * NW * k;
             warm[l][k] = (l < c.nl && ln < lines) ? *(const unsigned int*)(base + (size_t)ln * 128) : 0u;
         }
     }
@@ -389,8 +398,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             const bool active = rb0 < p.rb_total;          // layers with fewer output rows than the widest one leave the last workgroups idle (they still arrive)
             if constexpr (BWD) {
                 if (!active) {}
-                else if (p.sums != nullptr) k3s_body<true, TVC, false, T, true, XRC>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
-                else k3s_body<false, TVC, false, T, true, XRC>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+                else if (p.sums != nullptr) k3s_body<true, TVC, false, T, true, XRC, NW>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+                else k3s_body<false, TVC, false, T, true, XRC, NW>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
                 if ((c.apply_mask >> l) & 1) {
                     chain_arrive(chain_counter(c, n, phase));
                     CH_STAMP(l * 16 + 6);
@@ -403,8 +412,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 }
             } else {
                 if (!active) {}
-                else if (p.x_stats != nullptr) k3s_body<false, TVC, true, T, true, XRC>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
-                else k3s_body<false, TVC, false, T, true, XRC>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+                else if (p.x_stats != nullptr) k3s_body<false, TVC, true, T, true, XRC, NW>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+                else k3s_body<false, TVC, false, T, true, XRC, NW>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
             }
             if (l + 1 < c.nl) { chain_arrive(chain_counter(c, n, phase)); ++phase; }
             else __syncthreads();                        // the next sample of this slot reuses the LDS
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
     for (int l = 0; l < VS_CHAIN_MAX_LAYERS; ++l)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) wx |= warm[l][k] & 0x7f800000u;
+        for (int k = 0; k < 32 / NW; ++k) wx |= warm[l][k] & 0x7f800000u;
     if (wx == 0xffffffffu) atomicOr(c.fault, 2u);        // never true: keeps the warming loads alive
 }
 
@@ -434,7 +443,7 @@ static int k3s_launch_t(const G1Params& p, int ctiles, hipStream_t stream) {
     auto kern = k3s_kernel<SUMS, TVC, HS, T>;
     static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
-    hipLaunchKernelGGL(kern, dim3(ctiles * p.N, (p.M + 15) / 16), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, dim3(ctiles * p.N, (p.M + 15) / 16), dim3(64 * K3SWaves<TVC>::NW), lds, stream, p);
     VS_CHECK_LAUNCH();
     return VS_OK;
 }
@@ -482,13 +491,15 @@ static int k3s_chain_launch(K3Chain c, bool bwd, hipStream_t stream) {
     const int tvc = small ? 128 : 512;
     const size_t lds = K3S_LDS_TILE + (size_t)(tvc * 64 > 16384 ? tvc * 64 : 16384) + (size_t)2 * cmax * sizeof(float);
     if (lds > 160 * 1024 || (size_t)4 * cmax * sizeof(float) > 16384) return VS_ESHAPE;
+    int threads = 256;
     auto go = [&](auto kern) -> int {
         const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (attr_err != hipSuccess) return (int)attr_err;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, stream, c);
         VS_CHECK_LAUNCH();
         return VS_OK;
     };
-    if (small) return bwd ? go(k3s_chain_kernel<128, T, true>) : go(k3s_chain_kernel<128, T, false>);
-    return bwd ? go(k3s_chain_kernel<512, T, true>) : go(k3s_chain_kernel<512, T, false>);
+    threads = small ? 64 * K3SWaves<128>::NW : 64 * K3SWaves<512>::NW;
+    if (small) return bwd ? go(k3s_chain_kernel<128, T, true, K3SWaves<128>::NW>) : go(k3s_chain_kernel<128, T, false, K3SWaves<128>::NW>);
+    return bwd ? go(k3s_chain_kernel<512, T, true, K3SWaves<512>::NW>) : go(k3s_chain_kernel<512, T, false, K3SWaves<512>::NW>);
 }
