@@ -69,6 +69,10 @@ def test_seg96_every_backward_step_matches_fp64_recomputation(monkeypatch):
         return out
 
     monkeypatch.setattr(modules, "_conv3", conv3)
+    # the step-by-step recomputation needs every conv's output and gradient: the deep DoubleConvs run layer by layer here, not as chain kernels
+    # (ops.ConvK3Chain keeps its intermediate tensors to itself; tests/test_gpu_chain.py proves the chains equal to these launches bit for bit)
+    from vae_segmentation_amd import ops as _ops
+    monkeypatch.setattr(_ops, "CHAIN", False)
     loss, _ = T.seg_train_losses(seg, O.synthetic_image(2, 96, 2).cuda(), O.synthetic_label(2, 96, 3).cuda())
     # Deferred apply (round 5: the parity mode's 8-channel layers, ops.mark_defer_apply): the gradient that reaches such a tensor's hook is dL/da of
     # a = relu(norm(y)) — UN-applied; the InstanceNorm+ReLU backward runs later, inside the producing conv's backward-data kernel (k3xt_kernel<..., FA>,
@@ -170,6 +174,10 @@ def test_seg96_every_forward_step_matches_fp64_recomputation(monkeypatch):
         return out
 
     monkeypatch.setattr(modules, "_conv3", conv3)
+    # the step-by-step recomputation needs every conv's output and gradient: the deep DoubleConvs run layer by layer here, not as chain kernels
+    # (ops.ConvK3Chain keeps its intermediate tensors to itself; tests/test_gpu_chain.py proves the chains equal to these launches bit for bit)
+    from vae_segmentation_amd import ops as _ops
+    monkeypatch.setattr(_ops, "CHAIN", False)
     img = O.synthetic_image(2, 96, 2)
     with torch.no_grad():
         batch = seg({"img": img.cuda()}, "img", "pred")

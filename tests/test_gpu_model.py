@@ -281,25 +281,41 @@ def test_test_time_finetune128_vs_reference_golden(graph):
     run on the reference's modules: per-iteration losses, the accumulated weight update (= two gradients, the second taken on
     updated weights) and the hard-Dice scores with / without finetuning."""
     M, O, T = _mods()
+    from vae_segmentation_amd import ops
     g = G.load("ft128")
-    model, model_ft, teacher = _build_joint(M, O, 128), _build_joint(M, O, 128), _build_joint(M, O, 128)
-    O.deterministic_fill_(teacher.Seg, seed=1)
-    for p in teacher.parameters():
-        p.requires_grad = False
     img, lab = O.synthetic_image(1, 128, 2).cuda(), O.synthetic_label(1, 128, 3).cuda()
-    runner = T.TestTimeFinetune(model, model_ft, teacher, 128, steps=2, lr=1e-2, lambda_vae=1.0, domain_loss_type=8, graph=graph)
-    for rep in range(2 if graph else 1):            # a second case on the same runner must start from model's weights again
-        log, score_noft, score, pred = runner.run(img, lab)
-        for it, rec in enumerate(log):
-            for k_o, k_g in (("recon_loss", "recon_loss"), ("dice_loss", "dice_loss"), ("dice_loss_fake", "fake_loss"), ("final_loss", "final")):
-                G.scalar_close(g, "it%d.%s" % (it, k_g), rec[k_o].item(), RTOL_FP32)
-        ref = dict(model.Seg.named_parameters())
-        upd = [(n, (p.detach() - ref[n].detach()) / 1e-2) for n, p in model_ft.Seg.named_parameters()]
-        G.envelope_summary(G.check_grads_env(g, "ft128", "upd", upd, floor=RTOL_GRAD_FP32, what="ft128"), "ft128 (%s)" % ("graph" if graph else "eager"))
-        # hard Dice counts argmax voxels: a handful may flip where the two probabilities are within rounding of each other
-        assert abs(score_noft.item() - float(g["score_noft@f64"])) < 2e-3
-        assert abs(score.item() - float(g["score@f64"])) < 2e-3
-        G.check_tensor_env(g, "ft128", "pred", pred, k=512, floor=RTOL_FP32)
+    draws = []
+    # The accumulated update of two chained steps is the most amplified quantity of the suite (the reference's own fp32 run sits 1.4 from its fp64 run in the median
+    # tensor: tests/golden/envelopes2.npz), and the envelope is a 12-run maximum a 13th run of the same arithmetic exceeds with probability 1/13 per tensor: as for
+    # embed128 the gate takes the MEDIAN of three HIP runs, each with the base model's weights moved by +-1 ulp exactly as the envelope's runs were (seed 0: unmoved);
+    # losses, scores and the prediction are gated on the unmoved run.
+    for seed in (0, 1, 2):
+        model, model_ft, teacher = _build_joint(M, O, 128), _build_joint(M, O, 128), _build_joint(M, O, 128)
+        G.perturb_ulp_(model, seed)
+        O.deterministic_fill_(teacher.Seg, seed=1)
+        for p in teacher.parameters():
+            p.requires_grad = False
+        ops.weights_changed()
+        runner = T.TestTimeFinetune(model, model_ft, teacher, 128, steps=2, lr=1e-2, lambda_vae=1.0, domain_loss_type=8, graph=graph)
+        for rep in range(2 if (graph and seed == 0) else 1):            # a second case on the same runner must start from model's weights again
+            log, score_noft, score, pred = runner.run(img, lab)
+            ref = dict(model.Seg.named_parameters())
+            upd = [(n, (p.detach() - ref[n].detach()) / 1e-2) for n, p in model_ft.Seg.named_parameters()]
+            if seed == 0:
+                for it, rec in enumerate(log):
+                    for k_o, k_g in (("recon_loss", "recon_loss"), ("dice_loss", "dice_loss"), ("dice_loss_fake", "fake_loss"), ("final_loss", "final")):
+                        G.scalar_close(g, "it%d.%s" % (it, k_g), rec[k_o].item(), RTOL_FP32)
+                # hard Dice counts argmax voxels: a handful may flip where the two probabilities are within rounding of each other
+                assert abs(score_noft.item() - float(g["score_noft@f64"])) < 2e-3
+                assert abs(score.item() - float(g["score@f64"])) < 2e-3
+                G.check_tensor_env(g, "ft128", "pred", pred, k=512, floor=RTOL_FP32)
+                if rep == 0:
+                    first_case = G.grads_dist(g, "upd", upd, what="ft128")
+                else:
+                    assert G.grads_dist(g, "upd", upd, what="ft128") == first_case, "the second case on the same runner did not start from the model's weights"
+        draws.append(G.grads_dist(g, "upd", upd, what="ft128"))
+        del runner, model, model_ft, teacher
+    G.envelope_summary(G.check_grads_env(g, "ft128", "upd", None, floor=RTOL_GRAD_FP32, what="ft128", draws=draws), "ft128 (%s)" % ("graph" if graph else "eager"))
 
 
 def test_vae128_native_shapes_vs_reference_golden():
