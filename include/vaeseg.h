@@ -168,6 +168,43 @@ int vs_conv_k3_bwd_data_wgrad(const void* g, const void* act_x, const double* ac
 int vs_conv_k3_softmax2_bwd_data(const float* prob, const float* gprob, const void* gprob_cl, const void* w_packed, void* y, const void* mask_x,
                                  const double* mask_stats, double* sums, float* slabs, double* bias_part, int n, int d, int h, int w, int dtype,
                                  float eps, float drop_p, unsigned long long drop_seed, void* stream);
+/* The library's tuning switches, in ONE place (round 6; csrc/config.hip).  The library keeps one process-wide copy: filled on first use from the environment
+ * variables named below (so A/B scripts that set them before the process starts keep working), read by every launcher on EVERY call (nothing is cached in
+ * function-local statics), replaced as a whole by vs_set_config() — the only writer; set it between launches, not concurrently with one.  vs_config_bytes():
+ * sizeof(vs_config) of the loaded library (bindings check their layout against it).  vs_config_from_env(): defaults + environment into *c without installing it. */
+typedef struct vs_config {
+    int k3_small;              /* VS_K3_SMALL 1: volumes up to 6^3 with C % 32 == 0 run k3s_kernel (whole padded sample in LDS) */
+    int k3_tall;               /* VS_K3_TALL -1: 4x8x16 tiles where measured faster (auto); 0 / 1 force */
+    int k3_wgs_per_cu;         /* VS_K3_WGS_PER_CU 0: persistent workgroups per CU of the 3x3x3 kernels (0 = per-kernel default: 3 for k3b, 4 for the exact-f32 k3) */
+    int k3t_wgs_per_cu;        /* VS_K3T_WGS_PER_CU 2: the 8-channel full-resolution kernels (k3t, k3tw) */
+    int k3f_min_wgs;           /* VS_K3F_MIN_WGS 512: exact-f32 C >= 32 layers take shorter tiles until the launch has this many workgroups */
+    int mt_min_wgs;            /* VS_MT_MIN_WGS 1024: largest row tile that still leaves this many workgroups */
+    int f32_limbs;             /* VS_F32_LIMBS 1: fp32 parity mode on the bf16 matrix cores (three-limb operands); 0 = exact-f32 MFMA everywhere */
+    int g1_limbs;              /* VS_G1_LIMBS 1: ... in the stride-2 / transposed kernels */
+    int k3x_ck;                /* VS_K3X_CK 8: channel chunk of the limb kernels (8 or 16) */
+    int k3x_toeplitz;          /* VS_K3X_TOEPLITZ 1 */
+    int fuse_wgrad;            /* VS_FUSE_WGRAD 1: vs_conv_k3_bwd_data_wgrad_supported may say 1 */
+    int epilogue_apply;        /* VS_EPILOGUE_APPLY 1: vs_conv_k3_bwd_data_applied_supported may say 1 */
+    int chain;                 /* VS_CHAIN 1: vs_conv_k3_chain_supported may say 1 */
+    int k2s2_stream;           /* VS_K2S2_STREAM 1: the streaming kernel for the full-resolution stride-2 backward-data scatter */
+    int k2s8_wgs_per_cu;       /* VS_K2S8_WGS_PER_CU 4 */
+    int up_wgs_per_cu;         /* VS_UP_WGS_PER_CU 2: composed Up head kernels */
+    int up_rb;                 /* VS_UP_RB 0: row blocks per workgroup of the composed Up forward (0 = chosen per shape) */
+    int wgrad_uber;            /* VS_WGRAD_UBER 1: every bucket of a grouped weight-gradient pass in one grid */
+    int wgrad_mpack;           /* VS_WGRAD_MPACK 1: M-packed rows for layers with 8 stored output channels */
+    int wgrad_swap;            /* VS_WGRAD_SWAP 1: operand exchange for lazy-input 3x3x3 layers */
+    int wgrad_big;             /* VS_WGRAD_BIG 1: 8x8x16 tiles for the full-resolution layers */
+    int wgrad_xcd;             /* VS_WGRAD_XCD 1: a layer's k-splits dealt per XCD */
+    int reserved_;
+    long long wgrad_wgs;            /* VS_WGRAD_WGS 512: workgroups per ungrouped weight-gradient launch */
+    long long wgrad_f32_tiles;      /* VS_WGRAD_F32_TILES 8 */
+    long long wgrad_group_wgs;      /* VS_WGRAD_GROUP_WGS 0: workgroups per bucket of a grouped pass (0 = chosen per pass) */
+    long long wgrad_big_min_voxels; /* VS_WGRAD_BIG_MIN_VOXELS 400000 */
+} vs_config;
+int vs_config_bytes(void);
+int vs_config_from_env(vs_config* c);
+int vs_get_config(vs_config* out);
+int vs_set_config(const vs_config* cfg);
 /* vs_conv_gather_bwd_data (K3) FOLLOWED BY vs_instnorm_relu_bwd_apply of its output, in one launch (csrc/igemm_k3b.h EA, round 6): every workgroup keeps its tile's
  * rounded outputs in registers, adds its partial IN-backward sums, arrives on its SAMPLE's counter (the statistics of joint_model.py:11's InstanceNorm3d are per
  * sample: nothing of another sample is waited for), reads the complete sums back and stores y = dL/d(raw tensor) — the un-applied gradient is never written and the

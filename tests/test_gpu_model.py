@@ -376,16 +376,14 @@ def test_16bit_joint128_weight_gradients_same_with_and_without_m_packing(dtype, 
     img, lab = O.synthetic_image(1, 128, 2).cuda(), O.synthetic_label(1, 128, 3).cuda()
     grads = {}
     for mode in ("default", "1", "0"):
-        if mode == "default":
-            monkeypatch.delenv("VS_WGRAD_MPACK", raising=False)
-        else:
-            monkeypatch.setenv("VS_WGRAD_MPACK", mode)
+        ops.set_config(wgrad_mpack=1 if mode == "default" else int(mode))        # (the library's default is 1; restored below)
         joint = _build_joint(M, O, 128)
         M.set_kernel_dtype(joint, dtype)
         final, _ = T.joint_train_losses(joint, img, lab)
         final.backward()
         torch.cuda.synchronize()
         grads[mode] = {n: p.grad.detach().float().cpu() for n, p in joint.Seg.named_parameters()}
+    ops.set_config(wgrad_mpack=1)
     for n, g1 in grads["1"].items():
         assert torch.equal(grads["default"][n], g1), n
         g0 = grads["0"][n]

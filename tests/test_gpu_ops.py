@@ -499,33 +499,32 @@ def test_grouped_weight_gradients_many_layers(dtype, mpack, uber, swap, big, mon
     backward pass and issued as grouped launches — each against F.conv3d / F.conv_transpose3d autograd on the CPU, against the
     per-layer launches (vs_conv_wgrad), and bitwise reproducible.  mpack: the M-packed form of the layers with 8 stored output channels
     (csrc/wgrad.hip g3b_body) on / off; uber: all buckets in one grid / one grid per bucket; swap: operand exchange on / off; big: big-tile kernel."""
-    monkeypatch.setenv("VS_WGRAD_MPACK", mpack)
-    monkeypatch.setenv("VS_WGRAD_UBER", uber)              # 1: every bucket in one grid (g3b_uber_kernel, the default); 0: one grid per bucket
-    monkeypatch.setenv("VS_WGRAD_SWAP", swap)              # 1 (default): operands of the lazy-input 3x3x3 layers exchanged (csrc/wgrad.hip multi_plan); 0: as submitted
-    # big: the 8 x 8 x 16-tile kernel (g3c_body) takes every layer it supports — by default only tensors of >= 400 k voxels (none of this list) get it
-    monkeypatch.setenv("VS_WGRAD_BIG_MIN_VOXELS", "1" if big == "1" else "1000000000")
     ops = _ops()
-    assert ops._GROUP["enabled"]
-    got, refs = _group_layers_backward(ops, dtype)
-    tol = TOL[dtype] * 4
-    for (gw, gb), (rw, rb), case in zip(got, refs, GROUP_LAYERS):
-        assert relerr(gw.cpu(), rw) < tol, case
-        if rb is not None:
-            assert relerr(gb.cpu(), rb) < tol, case
-    again, _ = _group_layers_backward(ops, dtype)
-    for (gw, gb), (aw, ab) in zip(got, again):
-        assert torch.equal(gw, aw)
-        if gb is not None and dtype != torch.float32:      # fp32 mode keeps vs_bias_grad (float atomics)
-            assert torch.equal(gb, ab)
-    ops.set_wgrad_grouping(False)
-    try:
-        single, _ = _group_layers_backward(ops, dtype)
-    finally:
-        ops.set_wgrad_grouping(True)
-    for (gw, gb), (sw, sb), case in zip(got, single, GROUP_LAYERS):
-        assert relerr(gw, sw) < 2e-6, case
-        if gb is not None:
-            assert relerr(gb, sb) < 1e-5, case
+    # uber 1: every bucket in one grid (g3b_uber_kernel, the default); 0: one grid per bucket.  swap 1 (default): operands of the lazy-input 3x3x3 layers exchanged
+    # (csrc/wgrad.hip multi_plan); 0: as submitted.  big: the 8 x 8 x 16-tile kernel (g3c_body) takes every layer it supports — by default only tensors of
+    # >= 400 k voxels (none of this list) get it.  Switched through the library's one configuration entry point (vs_set_config), restored afterwards.
+    with ops.config(wgrad_mpack=int(mpack), wgrad_uber=int(uber), wgrad_swap=int(swap), wgrad_big_min_voxels=1 if big == "1" else 1000000000):
+        assert ops._GROUP["enabled"]
+        got, refs = _group_layers_backward(ops, dtype)
+        tol = TOL[dtype] * 4
+        for (gw, gb), (rw, rb), case in zip(got, refs, GROUP_LAYERS):
+            assert relerr(gw.cpu(), rw) < tol, case
+            if rb is not None:
+                assert relerr(gb.cpu(), rb) < tol, case
+        again, _ = _group_layers_backward(ops, dtype)
+        for (gw, gb), (aw, ab) in zip(got, again):
+            assert torch.equal(gw, aw)
+            if gb is not None and dtype != torch.float32:      # fp32 mode keeps vs_bias_grad (float atomics)
+                assert torch.equal(gb, ab)
+        ops.set_wgrad_grouping(False)
+        try:
+            single, _ = _group_layers_backward(ops, dtype)
+        finally:
+            ops.set_wgrad_grouping(True)
+        for (gw, gb), (sw, sb), case in zip(got, single, GROUP_LAYERS):
+            assert relerr(gw, sw) < 2e-6, case
+            if gb is not None:
+                assert relerr(gb, sb) < 1e-5, case
 
 
 def test_dice_loss_sum_label_target_equals_materialised_one_hot():

@@ -254,3 +254,32 @@ def test_synthetic_matches_the_oracle_generators():
     src = open(os.path.join(REPO, "bench.py")).read()
     build_src = src[src.index("def build("):src.index("def usable_cores")]
     assert "oracle" not in build_src.replace("the oracle is imported by cpu_baseline only", "")
+
+
+def test_config_struct_layout_and_single_entry_point():
+    """include/vaeseg.h vs_config: the Python binding's struct is the library's, the environment seeds it once, vs_set_config is the only writer and
+    validates what it is given (no GPU needed)."""
+    from vae_segmentation_amd import ops
+    import ctypes
+    assert ops.lib.vs_config_bytes() == ctypes.sizeof(ops.VsConfig)
+    cfg = ops.get_config()
+    assert cfg["chain"] in (0, 1) and cfg["wgrad_wgs"] >= 1 and cfg["k3x_ck"] in (8, 16)
+    old = ops.set_config(wgrad_mpack=0, wgrad_big_min_voxels=123)
+    try:
+        now = ops.get_config()
+        assert now["wgrad_mpack"] == 0 and now["wgrad_big_min_voxels"] == 123 and now["chain"] == cfg["chain"]
+        assert ops.lib.vs_conv_k3_chain_supported(2, 6, 6, 6, 128, 1) == (1 if cfg["chain"] else 0)
+        ops.set_config(chain=0)
+        assert ops.lib.vs_conv_k3_chain_supported(2, 6, 6, 6, 128, 1) == 0
+        ops.set_config(chain=cfg["chain"])
+        with pytest.raises(KeyError):
+            ops.set_config(no_such_switch=1)
+        with pytest.raises(RuntimeError):
+            ops.set_config(k3x_ck=12)                     # rejected by the library, nothing installed
+        assert ops.get_config()["k3x_ck"] == cfg["k3x_ck"]
+    finally:
+        ops.set_config(**old)
+    assert ops.get_config() == cfg
+    src = "".join(open(os.path.join(REPO, "vae_segmentation_amd", "csrc", f)).read() for f in os.listdir(os.path.join(REPO, "vae_segmentation_amd", "csrc"))
+                  if f.endswith((".h", ".hip", ".inc")) and f != "config.hip")
+    assert src.count("getenv(") == 2, "launchers read vs_cfg(), not the environment (the two left sit inside the VS_G3B_ABLATE diagnostic build)"

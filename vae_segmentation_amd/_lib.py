@@ -92,9 +92,17 @@ class _Lib:
                 self._det = _load(DET_LIB_PATH)
                 if not self._det.vs_get_deterministic():
                     raise ImportError("%s is not a deterministic build (VS_DET_BUILD)" % DET_LIB_PATH)
+                # the second build starts from the first one's CURRENT tuning switches (ops.set_config may have moved them), not from the environment again
+                buf = ctypes.create_string_buffer(self._fast.vs_config_bytes())
+                if self._fast.vs_get_config(ctypes.addressof(buf)) == 0:
+                    self._det.vs_set_config(ctypes.addressof(buf))
             self._active = self._det
         else:
             self._active = self._fast
+
+    def loaded(self):
+        """every build loaded so far (a tuning configuration is set on all of them: ops.set_config)"""
+        return [l for l in (self._fast, self._det) if l is not None]
 
     def __getattr__(self, name):
         return getattr(self._active, name)

@@ -12,7 +12,7 @@ static int chain_shape_ok(int n, int d, int h, int w) {
 }
 
 extern "C" int vs_conv_k3_chain_supported(int n, int d, int h, int w, int c_max, int dtype) {
-    static const int on = getenv("VS_CHAIN") ? atoi(getenv("VS_CHAIN")) : 1;
+    const int on = vs_cfg().chain;
     if (!on || !vs_dtype_ok(dtype) || !chain_shape_ok(n, d, h, w)) return 0;
     if (c_max <= 0 || c_max % 32 || c_max > 1024) return 0;
     const int ctiles = (d * h * w + 63) / 64;

@@ -6,6 +6,9 @@
 #include <type_traits>
 #include "../../include/vaeseg.h"
 
+// the library's tuning switches (config.hip; include/vaeseg.h vs_config): read on every call, set through vs_set_config() only
+const vs_config& vs_cfg();
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef _Float16 vs_half;                                   // IEEE fp16 storage type (VS_F16); bf16 storage is carried as `unsigned short` bits (VS_BF16)
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -394,7 +397,7 @@ static __host__ __device__ inline bool vs_k3_toeplitz_f32(int rows, int c_pad, i
 static inline int vs_k3x_ck(int c_pad) {
     // measured on the fp32 96^3 step: 7.34 ms (8) vs 7.55 ms (16); round 5: 6.299 vs 6.384, and 16 only for the layers with >= 64 / 128 channels: 6.213 / 6.207 vs 6.213
     // (profiles/r05_ab_fp32_ck16_from.json: nothing)
-    static const int ck = getenv("VS_K3X_CK") ? atoi(getenv("VS_K3X_CK")) : 8;
+    const int ck = vs_cfg().k3x_ck;
     const int w = ck == 8 ? 8 : 16;
     return c_pad < w ? c_pad : w;
 }
@@ -403,7 +406,7 @@ static inline int vs_k3x_ck(int c_pad) {
 // order of k3xt_kernel (igemm_k3x.h): [k-group (tz,ty)][limb][lane][8], row (lane & 15) = (dx2, co), k = (xpos = lane >> 4, ci), value
 // W[co][ci][tz][ty][xpos - dx2] or 0.  pack.hip (image) and igemm_k3x.hip (dispatch) both key on this predicate (VS_K3X_TOEPLITZ=0: off).
 static inline bool vs_k3x_toeplitz(int rows, int c_pad, int ntaps) {
-    static const int on = getenv("VS_K3X_TOEPLITZ") ? atoi(getenv("VS_K3X_TOEPLITZ")) : 1;
+    const int on = vs_cfg().k3x_toeplitz;
     return on && ntaps == 27 && c_pad == 8 && rows <= 8;
 }
 

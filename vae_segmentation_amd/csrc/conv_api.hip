@@ -14,11 +14,11 @@ int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int
 // fp32 parity mode: the 3x3x3 convolutions run on the bf16 matrix cores through exact three-limb operand splitting (igemm_k3x.h); their packed
 // weights are VS_F32X3 images (pack.hip).  VS_F32_LIMBS=0 keeps the exact-f32 MFMA kernels (igemm_k3.h) and the plain fp32 images.
 extern "C" int vs_conv_k3_f32_limbs(int d, int h, int w, int c_in) {
-    static const int on = getenv("VS_F32_LIMBS") ? atoi(getenv("VS_F32_LIMBS")) : 1;
+    const int on = vs_cfg().f32_limbs;
     if (!on) return 0;
     // volumes up to 6^3 with C a multiple of 32 stay on k3s_kernel<float> (igemm_k3s.h: the whole padded sample in LDS, the waves split the taps): a
     // 4x4x16 tile is mostly padding there and the limb kernel would walk C / 16 chunk stages per workgroup (3^3 x 256: 92 us against 26)
-    static const int small = getenv("VS_K3_SMALL") ? atoi(getenv("VS_K3_SMALL")) : 1;
+    const int small = vs_cfg().k3_small;
     if (small && c_in % 32 == 0 && c_in <= 1024 && (long long)(d + 2) * (h + 2) * (w + 2) <= 512) return 0;
     return 1;
 }
@@ -45,7 +45,7 @@ static int pick_mt(int rows16, long long tiles) {
     // (more rows per wave = more MFMAs per B fragment read from LDS, fewer workgroups)
     // 1024 since round 5 (256 before; same-box A/B with the round's kernels, profiles/r05_ab_mt_min_wgs_*.json: 96^3 2.416 -> 2.406 ms, 160^3 6.03 -> 6.00, fp32 mode
     // 6.169 -> 6.148; 128 -> 2.456): the full-resolution stride-2 / transposed launches run 32-row workgroups, twice as many, instead of 64-row ones
-    static const int min_wgs = getenv("VS_MT_MIN_WGS") ? atoi(getenv("VS_MT_MIN_WGS")) : 1024;
+    const int min_wgs = vs_cfg().mt_min_wgs;
     const int cands[3] = {64, 32, 16};
     for (int i = 0; i < 3; ++i) {
         const int mt = cands[i];
@@ -170,7 +170,7 @@ extern "C" int vs_conv_k3_fused_apply_supported(int n, int d, int h, int w, int 
 
 // ---- backward-data whose epilogue applies the InstanceNorm+ReLU backward itself (igemm_k3b.h EA, round 6) ----
 extern "C" int vs_conv_k3_bwd_data_applied_supported(int n, int d, int h, int w, int c_in, int m_out, int dtype) {
-    static const int on = getenv("VS_EPILOGUE_APPLY") ? atoi(getenv("VS_EPILOGUE_APPLY")) : 1;
+    const int on = vs_cfg().epilogue_apply;
     if (!on || !vs_dtype_ok(dtype) || dtype == VS_F32) return 0;
     static const char dummy[16] __attribute__((aligned(16))) = {0};        // planning only: no pointer is dereferenced
     static double dsink[2];
@@ -191,7 +191,7 @@ extern "C" int vs_conv_k3_bwd_data_applied(const void* x, const void* w_packed, 
 
 // ---- backward-data with the layer's weight gradient fused (igemm_k3tw.h) ----
 extern "C" int vs_conv_k3_bwd_data_wgrad_supported(int n, int d, int h, int w, int c_in, int m_out, int dtype) {
-    static const int on = getenv("VS_FUSE_WGRAD") ? atoi(getenv("VS_FUSE_WGRAD")) : 1;
+    const int on = vs_cfg().fuse_wgrad;
     if (!on || (dtype != VS_BF16 && dtype != VS_F16)) return 0;
     if (c_in != 8 || m_out != 8 || n <= 0 || n * 8 > 192 || d <= 0 || h <= 0 || w <= 0) return 0;
     if ((double)n * d * h * w * 16 >= 2147483648.0) return 0;
@@ -255,7 +255,7 @@ static int scatter_impl(const void* x, const double* x_stats, const void* w_pack
     p.tiles_per_sample = vs_ceil_div((long long)d * h * w, 256);
     const long long tiles = (long long)p.tiles_per_sample * n;
     // the 8 -> 8 backward-data scatter at full resolution (Down1): a streaming kernel instead of an MFMA tile per 256 coarse voxels (k2s2_scatter8.hip)
-    static const int stream8 = getenv("VS_K2S2_STREAM") ? atoi(getenv("VS_K2S2_STREAM")) : 1;
+    const int stream8 = vs_cfg().k2s2_stream;
     if (stream8 && sums && c_in == 8 && m_out == 8 && dtype != VS_F32 && !bias && !x_stats) {
         rc = k2s2_scatter8_launch(p, dtype, (hipStream_t)stream);
         if (rc != VS_ESHAPE) return rc;

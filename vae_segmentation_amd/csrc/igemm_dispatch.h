@@ -18,7 +18,7 @@ int g1_dispatch_pw(const G1Params& p, int dtype, int ck, int mt, int tiles, int 
 #define G1L_ALL_MT(CKV, KIND, EPI) G1L_CASE(CKV, KIND, 16, EPI) G1L_CASE(CKV, KIND, 32, EPI) G1L_CASE(CKV, KIND, 64, EPI)
 #define G1L_ALL(KIND, EPI) G1L_ALL_MT(8, KIND, EPI) G1L_ALL_MT(16, KIND, EPI) G1L_ALL_MT(32, KIND, EPI)
 static inline bool g1_f32_limbs() {
-    static const int on = getenv("VS_F32_LIMBS") ? atoi(getenv("VS_F32_LIMBS")) : 1;
-    static const int g1 = getenv("VS_G1_LIMBS") ? atoi(getenv("VS_G1_LIMBS")) : 1;            // A/B switch of this kernel family alone
+    const int on = vs_cfg().f32_limbs;
+    const int g1 = vs_cfg().g1_limbs;              // A/B switch of this kernel family alone
     return on != 0 && g1 != 0;
 }

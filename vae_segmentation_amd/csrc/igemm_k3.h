@@ -398,7 +398,7 @@ static int k3_launch(const G1Params& p_in, int tiles_total, int row_tiles, hipSt
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
     // persistent grid: a few workgroups per CU, each walking a strided slice of the tile list
-    static const int per_cu = getenv("VS_K3_WGS_PER_CU") ? atoi(getenv("VS_K3_WGS_PER_CU")) : 4;   // tuning knob
+    const int per_cu = vs_cfg().k3_wgs_per_cu > 0 ? vs_cfg().k3_wgs_per_cu : 4;   // tuning knob (vs_config.k3_wgs_per_cu; 0 = this default)
     int wg = 256 * per_cu / (row_tiles < per_cu ? row_tiles : per_cu);
     if (wg < 256) wg = 256;
     const int gx = tiles_total < wg ? tiles_total : wg;

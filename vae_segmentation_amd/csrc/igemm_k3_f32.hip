@@ -18,7 +18,7 @@ int g1_dispatch_k3_f32(const G1Params& p, int ck, int mt, int epi, int tiles, in
     // most SIMDs idle (12^3 x 64: 72 workgroups).  16-row blocks and the tallest tile (4, 2 or 1 rows of 16 voxels per wave) that still
     // gives >= VS_K3F_MIN_WGS workgroups (default 512 = two waves per SIMD).
     if (ck == 32) {
-        static const int min_wgs = getenv("VS_K3F_MIN_WGS") ? atoi(getenv("VS_K3F_MIN_WGS")) : 512;
+        const int min_wgs = vs_cfg().k3f_min_wgs;
         const long long rows16 = (long long)row_tiles * (mt / 16);
         const long long zx = (long long)((p.D + 3) / 4) * p.txn * p.N;
         if (min_wgs > 0 && zx * ((p.H + 3) / 4) * rows16 < min_wgs) {

@@ -599,7 +599,7 @@ static int k3b_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
     // persistent grid: three workgroups per CU, each walking a strided slice of the tile list
-    static const int per_cu = getenv("VS_K3_WGS_PER_CU") ? atoi(getenv("VS_K3_WGS_PER_CU")) : 3;   // tuning knob (measured: 8->8 @96^3 36.6 / 40.1 / 44.9 / 51.5 us at 3 / 4 / 5 / 6)
+    const int per_cu = vs_cfg().k3_wgs_per_cu > 0 ? vs_cfg().k3_wgs_per_cu : 3;   // tuning knob, vs_config.k3_wgs_per_cu (measured: 8->8 @96^3 36.6 / 40.1 / 44.9 / 51.5 us at 3 / 4 / 5 / 6)
     int wg = 256 * per_cu / (row_tiles < per_cu ? row_tiles : per_cu);
     if (wg < 256) wg = 256;
     // one workgroup per tile while the tiles fit; the persistent cap `wg` is a multiple of 8 (kernel: XCD-aware walk).  Never round a
@@ -636,7 +636,7 @@ static int k3b_launch(const G1Params& p, int tiles_total, int row_tiles, hipStre
 // fatter workgroups, 2.1x instead of 2.5x halo — and slower (8->8 @96^3: 40 -> 45 us) where workgroups walk many tiles and the
 // lower occupancy of the taller tile costs more than its halo saves.  VS_K3_TALL=0/1 forces the choice (tuning / tests).
 static inline bool k3b_use_tall(const G1Params& p) {
-    static const int force = getenv("VS_K3_TALL") ? atoi(getenv("VS_K3_TALL")) : -1;
+    const int force = vs_cfg().k3_tall;
     if (force >= 0) return force != 0;
     const long long tall = (long long)((p.D + 3) / 4) * ((p.H + 7) / 8) * p.txn * p.N;
     return tall >= 256 && (long long)p.tiles_per_sample * p.N <= 2048;

@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 
 // volumes this kernel takes (C a multiple of 32):
 static inline bool k3s_takes(const G1Params& p, int ck) {
-    static const int on = getenv("VS_K3_SMALL") ? atoi(getenv("VS_K3_SMALL")) : 1;
+    const int on = vs_cfg().k3_small;
     // up to 6x6x6 (padded sample chunk <= 512 voxels): at 8^3 (128^3 inputs) the 64 KB chunk and its 16 fragments per thread made this kernel
     // no faster than k3b_kernel (4.51 vs 4.47 ms per 128^3 domain-adaptation step)
     return on && ck == 32 && p.C % 32 == 0 && (p.D + 2) * (p.H + 2) * (p.W + 2) <= 512 && p.C <= 1024;

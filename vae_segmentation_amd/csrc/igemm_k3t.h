@@ -388,7 +388,7 @@ static int k3t_launch_t(const G1Params& p_in, hipStream_t stream) {
     // persistent grid: two workgroups per CU are resident (185-218 VGPRs).  Measured at 96^3, B = 2 (57 MB algorithmic, 62 MB of HBM
     // traffic by the PMC counters): 21-24 us per launch whichever of 2 / 3 workgroups per CU, 4x4x32 or 4x8x32 tiles, or MFMA loop order
     // is used — ~5 us of that is the launch itself, the rest moves ~4 TB/s (the pure streaming kernels of this library reach 4.7).
-    static const int per_cu = getenv("VS_K3T_WGS_PER_CU") ? atoi(getenv("VS_K3T_WGS_PER_CU")) : 2;
+    const int per_cu = vs_cfg().k3t_wgs_per_cu;
     const int cap = 256 * per_cu;
     const int gx = tiles < cap ? (int)tiles : cap;
     hipLaunchKernelGGL(kern, dim3(gx), dim3(256), lds, stream, p);

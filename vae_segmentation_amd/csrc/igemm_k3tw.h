@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // workgroups (= slabs) of the launch for this volume: the persistent grid of k3t_launch_t
 static inline int k3tw_grid(int n, int d, int h, int w) {
-    static const int per_cu = getenv("VS_K3T_WGS_PER_CU") ? atoi(getenv("VS_K3T_WGS_PER_CU")) : 2;
+    const int per_cu = vs_cfg().k3t_wgs_per_cu;
     const long long tiles = (long long)((d + 3) / 4) * ((h + 7) / 8) * ((w + 31) / 32) * n;
     const int cap = 256 * per_cu;
     return tiles < cap ? (int)tiles : cap;

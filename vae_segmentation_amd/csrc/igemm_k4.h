@@ -662,7 +662,7 @@ static inline void k4_fastdiv(int d, unsigned int& m, unsigned int& s) {
 }
 
 static inline int k4_grid_x(int tiles_total, int row_tiles) {
-    static const int per_cu = getenv("VS_UP_WGS_PER_CU") ? atoi(getenv("VS_UP_WGS_PER_CU")) : 2;      // tuning knob
+    const int per_cu = vs_cfg().up_wgs_per_cu;      // tuning knob
     int wg = 256 * per_cu / (row_tiles < per_cu ? row_tiles : per_cu);
     if (wg < 256) wg = 256;
     return tiles_total < wg ? tiles_total : wg;

@@ -159,7 +159,7 @@ static int k2s8_go(const G1Params& p, hipStream_t stream) {
     const int items_per_sample = (int)((S + vpi - 1) / vpi);
     const long long total = (long long)items_per_sample * p.N;
     if (total >= 2147483647ll) return VS_ESHAPE;
-    static const int per_cu = getenv("VS_K2S8_WGS_PER_CU") ? atoi(getenv("VS_K2S8_WGS_PER_CU")) : 4;
+    const int per_cu = vs_cfg().k2s8_wgs_per_cu;
     const long long cap = 256ll * per_cu;
     const int gx = (int)std::min<long long>((total + 3) / 4, cap);
     const size_t lds = ((size_t)L::W_FLOATS + (size_t)(2 * CH + 4 * 2 * CH) * p.N) * sizeof(float);

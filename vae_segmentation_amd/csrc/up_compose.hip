@@ -348,7 +348,7 @@ extern "C" int vs_up_conv_fwd(const void* x, const double* x_stats, const void* 
     p.inv_count_in = 1.0 / ((double)d * h * w);
     p.inv_count_out = 1.0 / (8.0 * d * h * w);
     // 4 row blocks per workgroup (the staged tile is shared by them); 2 where that leaves too few workgroups
-    static const int rb_env = getenv("VS_UP_RB") ? atoi(getenv("VS_UP_RB")) : 0;      // tuning knob
+    const int rb_env = vs_cfg().up_rb;      // tuning knob
     int rb = rb_env ? rb_env : (cin >= 32 ? 2 : 4);
     if (dtype == VS_BF16) return k4t_launch<unsigned short>(p, rb, (hipStream_t)stream);
     return k4t_launch<vs_half>(p, rb, (hipStream_t)stream);

@@ -1041,11 +1041,11 @@ static void g3_plan(int n, int dp, int hp, int wp, int m_ch, int c_ch, int kind,
     tyn = (hp + 3) / 4; txn = (wp + 15) / 16;
     tiles_per_sample = ((dp + 3) / 4) * tyn * txn;
     const long long total = (long long)tiles_per_sample * n;
-    static const long long wg_target = getenv("VS_WGRAD_WGS") ? atoll(getenv("VS_WGRAD_WGS")) : 512;   // tuning knob: ~2 workgroups per CU overall
+    const long long wg_target = vs_cfg().wgrad_wgs;   // tuning knob: ~2 workgroups per CU overall
     long long want = (wg_target + (long long)mbn * cbn - 1) / ((long long)mbn * cbn);
     // fp32 (parity) mode: a bounded number of tiles per workgroup, so that an fp32 MFMA accumulator chains a bounded number of products (64 per
     // tile and wave) before the fp64 slab reduction: VS_WGRAD_F32_TILES tiles (see the default's comment)
-    static const long long f32_tiles = getenv("VS_WGRAD_F32_TILES") ? atoll(getenv("VS_WGRAD_F32_TILES")) : 8;      // 8 x 64 voxels x 32-wide MFMAs: 512-product chains per accumulator and limb pair
+    const long long f32_tiles = vs_cfg().wgrad_f32_tiles;      // 8 x 64 voxels x 32-wide MFMAs: 512-product chains per accumulator and limb pair
     if (short_chains && (total + f32_tiles - 1) / f32_tiles > want) want = (total + f32_tiles - 1) / f32_tiles;
     if (want < 1) want = 1;
     if (want > total) want = total;
@@ -1162,7 +1162,7 @@ static int wgrad_single(const void* P, const double* p_stats, const void* Q, con
     if (dtype == VS_F32 && ((long long)n * dp * hp * wp * m_ch * 4 >= 2147483648ll || (long long)n * p.Dq * p.Hq * p.Wq * c_ch * 4 >= 2147483648ll)) return VS_ESHAPE;
     if (dtype == VS_F32) {
         // 3x3x3 layers: limb arithmetic on the bf16 matrix cores (g3x_kernel); VS_F32_LIMBS=0 and the stride-2 kinds: exact-f32 MFMA (g3_kernel)
-        static const int limbs = getenv("VS_F32_LIMBS") ? atoi(getenv("VS_F32_LIMBS")) : 1;
+        const int limbs = vs_cfg().f32_limbs;
         if (limbs && kind == VS_CONV_K3) return cbsz == 16 ? g3x_run<16>(p, dw, m_real, c_real, st, rws, rsl) : g3x_run<8>(p, dw, m_real, c_real, st, rws, rsl);
         G3_GO(float)
     }
@@ -1479,7 +1479,7 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
     // share of the reduction launch), and fewer, longer workgroups win: same-box A/B at 96^3 (profiles/r05_ab_wgrad_group_wgs.json)
     // 768 / 512 / 320 / 256 / 160 -> 2.514 / 2.501 / 2.497 / 2.480 / 2.493 ms per step
     // ... and at 160^3 512 / 384 / 256 -> 6.373 / 6.380 / 6.396, at 128^3 (B = 1) 512 / 256 -> 3.737 / 3.729: the small target where the largest layer is small
-    static const long long target_env = getenv("VS_WGRAD_GROUP_WGS") ? atoll(getenv("VS_WGRAD_GROUP_WGS")) : 0;
+    const long long target_env = vs_cfg().wgrad_group_wgs;
     long long max_voxels = 0;
     for (int i = 0; i < count; ++i) max_voxels = std::max(max_voxels, (long long)descs[i].n * descs[i].dp * descs[i].hp * descs[i].wp);
     const long long target_default = target_env > 0 ? target_env : (max_voxels <= 2500000 ? 256 : 512);
@@ -1492,18 +1492,15 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
     };
     // big tiles (g3c_body) for the 3x3x3 layers whose halo operand has 8 stored channels and whose tensors are large enough for the halo traffic to matter;
     // only inside the all-buckets grid (the per-bucket launches of VS_WGRAD_UBER=0 keep the 4x4x16 kernels).  VS_WGRAD_BIG=0 switches it off.
-    const char* big_str = getenv("VS_WGRAD_BIG");
-    const char* uber_s = getenv("VS_WGRAD_UBER");
-    const bool big_on = pack_m && (big_str ? atoi(big_str) != 0 : true) && (uber_s ? atoi(uber_s) != 0 : true);
-    const long long big_min_voxels = getenv("VS_WGRAD_BIG_MIN_VOXELS") ? atoll(getenv("VS_WGRAD_BIG_MIN_VOXELS")) : 400000;      // per plan: the tests lower it
+    const bool big_on = pack_m && vs_cfg().wgrad_big != 0 && vs_cfg().wgrad_uber != 0;
+    const long long big_min_voxels = vs_cfg().wgrad_big_min_voxels;      // read per plan: the tests lower it (vs_set_config)
     // Operand exchange (round 5).  A 3x3x3 layer's gradient dW[m][c][o] = sum_v P(v)[m] Q(v + o)[c] stages Q with a halo (2.5 x the tile) and P without;
     // when Q is a LAZY activation (statistics given) every halo fragment is normalised + ReLU'd + masked on its way to LDS — 24-28 vector instructions per
     // 16-byte fragment in a kernel that is bound by instruction issue (profiles/r04_wgrad_counters_raw.txt).  The same sums with the roles exchanged,
     // dW'[c][m][o'] = sum_v Q(v)[c] P(v + o')[m] = dW[m][c][-o'], put the halo on P — a stored gradient, staged as it is, out-of-volume fragments already
     // zero from the bounds-checked load — and normalise Q once per voxel.  The reduction writes the transposed, tap-mirrored slabs back (G3RedDesc.swap).
     // Taken when it does not widen the halo operand (m_ch <= c_ch); VS_WGRAD_SWAP=0 switches it off.
-    const char* swap_str = getenv("VS_WGRAD_SWAP");               // read per plan: the tests and the A/B runs switch it between calls
-    const bool swap_on = pack_m && (swap_str ? atoi(swap_str) != 0 : true);
+    const bool swap_on = pack_m && vs_cfg().wgrad_swap != 0;        // read per plan: the tests and the A/B runs switch it between calls (vs_set_config)
     std::vector<vs_wgrad_desc> eff(descs, descs + count);
     for (int i = 0; i < count; ++i) {
         int rc = multi_validate(descs[i]);
@@ -1533,8 +1530,7 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         // g3b_body's M-packed forms.  Same-box A/B (profiles/r04_ab_wgrad_mpack.json): with one grid per bucket 160^3 B=2 6.74 -> 6.50 ms, 128^3 B=1 3.80 -> 3.75, but
         // 96^3 B=2 2.515 -> 2.526 (the packed layers were two more launches); inside the all-buckets grid (g3b_uber_kernel) 96^3 gains too: 2.531 -> 2.513.
         // VS_WGRAD_MPACK=0 switches it off.
-        const char* mp_str = getenv("VS_WGRAD_MPACK");          // read per plan (not cached): the tests switch it between calls
-        const bool mp_on = mp_str ? atoi(mp_str) != 0 : true;
+        const bool mp_on = vs_cfg().wgrad_mpack != 0;            // read per plan: the tests switch it between calls (vs_set_config)
         if (pack_m && mp_on && d.kind == VS_CONV_K3 && d.m_ch == 8 && (L.cbsz == 16 || d.c_ch == 8)) { p.mp = 1; L.ncb = L.cbsz == 16 ? 18 : 9; }
         L.big = 0;
         if (big_on && d.kind == VS_CONV_K3 && d.c_ch == 8 && (long long)d.n * d.dp * d.hp * d.wp >= big_min_voxels) {
@@ -1672,7 +1668,7 @@ static int g3b_uber_run(const G3Group& grp, size_t lds, hipStream_t s) {
 
 // ---- fp32 parity mode: the 3x3x3 layers of a pass as grouped limb launches (g3x_group_kernel), one grid per channel-block width ----------
 static bool f32_limbs_on() {
-    static const int on = getenv("VS_F32_LIMBS") ? atoi(getenv("VS_F32_LIMBS")) : 1;
+    const int on = vs_cfg().f32_limbs;
     return on != 0;
 }
 // descriptors of the pass that take the limb path, bias requests stripped (the fp32 branch sums biases with vs_bias_grad_acc); cb: 16 / 8
@@ -1685,8 +1681,7 @@ static const F32Grp F32_GROUPS[4] = {{VS_CONV_K3, 16}, {VS_CONV_K3, 8}, {VS_CONV
 // Marked with reserved_ = -1 (a field only VS_CONV_UP descriptors use).  VS_WGRAD_SWAP=0 switches it off.
 static std::vector<vs_wgrad_desc> f32_effective(const vs_wgrad_desc* descs, int count) {
     std::vector<vs_wgrad_desc> eff(descs, descs + count);
-    const char* swap_str = getenv("VS_WGRAD_SWAP");
-    if ((swap_str && atoi(swap_str) == 0) || !f32_limbs_on()) return eff;      // only the grouped limb launches write the exchanged form back (G3RedDesc.swap)
+    if (vs_cfg().wgrad_swap == 0 || !f32_limbs_on()) return eff;      // only the grouped limb launches write the exchanged form back (G3RedDesc.swap)
     for (vs_wgrad_desc& d : eff) {
         if (d.kind == VS_CONV_K3 && d.q_stats != nullptr && d.p_stats == nullptr && d.m_ch <= d.c_ch && d.p && d.q) {
             std::swap(d.p, d.q); std::swap(d.p_stats, d.q_stats); std::swap(d.m_ch, d.c_ch); std::swap(d.m_real, d.c_real);
@@ -2054,8 +2049,7 @@ static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspa
     char* ws = (char*)workspace;
 
     // ---- every bucket in one grid (G3_GROUP_MAX layers per grid, longest workgroups first); VS_WGRAD_UBER=0: one grid per bucket ----
-    const char* uber_str = getenv("VS_WGRAD_UBER");       // read per call (the tests run both forms)
-    const int uber = uber_str ? atoi(uber_str) : 1;
+    const int uber = vs_cfg().wgrad_uber;       // read per call (the tests run both forms)
     if (uber) {
         std::vector<int> idx(count);
         for (int i = 0; i < count; ++i) idx[i] = i;
@@ -2065,7 +2059,7 @@ static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspa
             if (descs[i].bias_g && descs[i].bias_rows < 2147483647ll) idx.push_back(-(i + 1));
         for (size_t at = 0; at < idx.size(); at += G3_GROUP_MAX) {
             G3Group grp{};
-            static const int xcd_walk = getenv("VS_WGRAD_XCD") ? atoi(getenv("VS_WGRAD_XCD")) : 1;
+            const int xcd_walk = vs_cfg().wgrad_xcd;
             grp.xcd = xcd_walk;
             grp.n = (int)std::min<size_t>(G3_GROUP_MAX, idx.size() - at);
             long long wg = 0;
@@ -2108,7 +2102,7 @@ static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspa
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return plan.layers[a].work > plan.layers[b].work; });
         for (size_t at = 0; at < idx.size(); at += G3_GROUP_MAX) {
             G3Group grp{};
-            static const int xcd_walk = getenv("VS_WGRAD_XCD") ? atoi(getenv("VS_WGRAD_XCD")) : 1;
+            const int xcd_walk = vs_cfg().wgrad_xcd;
             grp.xcd = xcd_walk;
             grp.n = (int)std::min<size_t>(G3_GROUP_MAX, idx.size() - at);
             long long wg = 0;

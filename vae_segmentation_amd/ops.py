@@ -9,6 +9,7 @@ A *lazy* activation is the pair ``(raw, stats)``: ``raw`` is a conv output befor
 For autograd, ``stats`` is a non-differentiable side output and the gradient attached to ``raw`` is the
 total derivative (the InstanceNorm+ReLU backward is applied by the consumer's backward).
 """
+import ctypes as _ctypes
 import os
 import weakref as _weakref
 
@@ -62,9 +63,56 @@ def _esize(t):
     return 4 if t.dtype == torch.float32 else 2
 
 
+class VsConfig(_ctypes.Structure):
+    """vs_config (include/vaeseg.h): the library's tuning switches"""
+    _fields_ = [(n, _ctypes.c_int) for n in ("k3_small", "k3_tall", "k3_wgs_per_cu", "k3t_wgs_per_cu", "k3f_min_wgs", "mt_min_wgs", "f32_limbs", "g1_limbs", "k3x_ck",
+                                            "k3x_toeplitz", "fuse_wgrad", "epilogue_apply", "chain", "k2s2_stream", "k2s8_wgs_per_cu", "up_wgs_per_cu", "up_rb",
+                                            "wgrad_uber", "wgrad_mpack", "wgrad_swap", "wgrad_big", "wgrad_xcd", "reserved_")] + \
+               [(n, _ctypes.c_longlong) for n in ("wgrad_wgs", "wgrad_f32_tiles", "wgrad_group_wgs", "wgrad_big_min_voxels")]
+
+
+def get_config():
+    """-> dict of the active library's tuning switches (vs_get_config)"""
+    if lib.vs_config_bytes() != _ctypes.sizeof(VsConfig):
+        raise _lib.VaesegError("vs_config layout mismatch: the library's struct has %d bytes, this binding %d" % (lib.vs_config_bytes(), _ctypes.sizeof(VsConfig)))
+    c = VsConfig()
+    check(lib.vs_get_config(_ctypes.addressof(c)), "get_config")
+    return {n: getattr(c, n) for n, _ in VsConfig._fields_ if n != "reserved_"}
+
+
+def set_config(**kw):
+    """Change tuning switches of the library (vs_set_config, the single writer; every loaded build gets the same values).  Call between launches.
+    -> the previous values of the switches that were changed (hand them back to set_config to restore)."""
+    cur = get_config()
+    unknown = [k for k in kw if k not in cur]
+    if unknown:
+        raise KeyError("not a vs_config field: %s" % ", ".join(unknown))
+    old = {k: cur[k] for k in kw}
+    cur.update(kw)
+    c = VsConfig(**cur)
+    for l in lib.loaded():
+        check(l.vs_set_config(_ctypes.addressof(c)), "set_config")
+    return old
+
+
+class config:
+    """with ops.config(wgrad_mpack=0): ...  — tuning switches changed for a block (tests, A/B runs), restored on the way out"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = set_config(**self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        set_config(**self.old)
+        return False
+
+
 def _pick_mt(rows16, tiles):
     """mirror of pick_mt() in csrc/conv_api.hip (kernel instantiation naming only)."""
-    min_wgs = int(os.environ.get("VS_MT_MIN_WGS", "1024"))
+    min_wgs = get_config()["mt_min_wgs"]
     for mt in (64, 32, 16):
         if rows16 % mt:
             continue
@@ -82,15 +130,16 @@ def _k3_kid(tname, ck, mt, sums=False, geom=None, m=None, lazy=False):
     hs = "true" if (lazy and not sums) else "false"
     if ck == 8 and m == 8:
         return "k3t_kernel<0,%s,8,%s,%s>" % ("true" if sums else "false", hs, tname)
-    if ck == 32 and geom is not None and (geom[1] + 2) * (geom[2] + 2) * (geom[3] + 2) <= 512 and os.environ.get("VS_K3_SMALL", "") != "0":
+    cfg = get_config()
+    if ck == 32 and geom is not None and (geom[1] + 2) * (geom[2] + 2) * (geom[3] + 2) <= 512 and cfg["k3_small"] != 0:
         tv = (geom[1] + 2) * (geom[2] + 2) * (geom[3] + 2)
         return "k3s_kernel<%s,%d,%s,%s>" % ("true" if sums else "false", 128 if tv <= 128 else 512, hs, tname)
     yt = 4
-    if geom is not None and ck < 32 and mt == 16 and os.environ.get("VS_K3_TALL", "") != "0":
+    if geom is not None and ck < 32 and mt == 16 and cfg["k3_tall"] != 0:
         n, d, h, w = geom
         tiles = n * ((d + 3) // 4) * ((h + 3) // 4) * ((w + 15) // 16)
         tall = n * ((d + 3) // 4) * ((h + 7) // 8) * ((w + 15) // 16)
-        if os.environ.get("VS_K3_TALL", "") == "1" or (tall >= 256 and tiles <= 2048):
+        if cfg["k3_tall"] == 1 or (tall >= 256 and tiles <= 2048):
             yt = 8
     return "k3b_kernel<%d,%d,0,%s,%d,%s,%s>" % (ck, min(mt, 32), "true" if sums else "false", yt, hs, tname)
 
