@@ -22,6 +22,9 @@
 #pragma once
 #include "igemm.h"
 
+#ifndef K3S_NCG
+#define K3S_NCG 2                    // igemm_k3s.h: 16-voxel column groups per workgroup of the 6^3-class volumes (the chain planner needs the tile width too)
+#endif
 #define VS_CHAIN_MAX_LAYERS 3
 #define VS_CHAIN_PHASES 8            // counters per sample, one 128-byte line each
 #define VS_CHAIN_MAX_ITEMS 256       // workgroups per sample

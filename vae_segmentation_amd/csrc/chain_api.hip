@@ -15,8 +15,10 @@ extern "C" int vs_conv_k3_chain_supported(int n, int d, int h, int w, int c_max,
     const int on = vs_cfg().chain;
     if (!on || !vs_dtype_ok(dtype) || !chain_shape_ok(n, d, h, w)) return 0;
     if (c_max <= 0 || c_max % 32 || c_max > 1024) return 0;
-    const int ctiles = (d * h * w + 63) / 64;
-    return ctiles * (c_max / 16) <= VS_CHAIN_MAX_ITEMS ? 1 : 0;      // (up to 6^3 x 1024 channels: every shape the first test admits)
+    const int v = d * h * w;
+    const int cw = ((long long)(d + 2) * (h + 2) * (w + 2) <= 128 && v <= 32) ? 64 : 16 * K3S_NCG;      // k3s_col_tile()
+    const int ctiles = (v + cw - 1) / cw;
+    return ctiles * (c_max / 16) <= VS_CHAIN_MAX_ITEMS ? 1 : 0;
 }
 
 extern "C" long long vs_conv_k3_chain_sync_bytes(int n) { return n > 0 ? (long long)n * VS_CHAIN_PHASES * 32 * (long long)sizeof(unsigned int) : 0; }

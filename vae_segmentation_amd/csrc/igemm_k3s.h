@@ -36,6 +36,10 @@ extern "C" int vs_debug_read_chain_stamps(unsigned long long* host, int n) { ret
 #define KS_TICK_FLUSH K3_TICK_FLUSH
 #endif
 
+// K3S_NCG (chain.h): 16-voxel column groups per workgroup at the 6^3-class volumes.  2 since round 6 (32-voxel column tiles, twice the workgroups): these launches
+// use 64 of the 256 CUs with 64-voxel tiles and their MFMA phase is issue-bound per CU — same-box 2.349 -> 2.331 ms per bf16 step, 6.096 -> 5.971 in the fp32
+// mode (whose exact-f32 MFMA phase is the longest); 16-voxel tiles (K3S_NCG=1) lose again (2.401 vs 2.349: every workgroup stages the whole padded sample).
+static inline int k3s_col_tile(bool small) { return small ? 64 : 16 * K3S_NCG; }      // host: voxels per column tile
 #define K3S_LDS_RED 0          // float[4][16][2]
 #define K3S_LDS_TILE 512
 // then: padded sample chunk [TV][64 B] (at least 16 KB: the cross-wave partials alias it), scale / shift tables [C] each
@@ -69,7 +73,8 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     constexpr int NWI = NKW;                             // weight fragments per thread per stage: its wave's taps
     constexpr int ES = (int)sizeof(T), EPL = 16 / ES, CHS = 64 / ES;     // element size, elements per fragment, channels per stage
     constexpr int SPC = 32 / CHS;                        // stages per 32-channel chunk of the packed weight image (1, or 2 for fp32)
-    constexpr int NCG = TVC == 128 ? 2 : 4;              // 16-column groups that can hold voxels: up to 3x3x3 = 27 voxels fill two (the other two were 4.5 of 13 us of MFMA phase on padding)
+    constexpr int NCG = TVC == 128 ? 2 : K3S_NCG;        // 16-column groups that can hold voxels
+    constexpr int CW = TVC == 128 ? 64 : 16 * K3S_NCG;   // voxels per column tile: up to 3x3x3 = 27 voxels fill two (the other two were 4.5 of 13 us of MFMA phase on padding)
     float* s_red = (float*)(smem + K3S_LDS_RED);
     char* s_tile = smem + K3S_LDS_TILE;
     const int PX = p.W + 2, PY = p.H + 2, TV = (p.D + 2) * PY * PX, V = p.D * p.H * p.W;
@@ -197,7 +202,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
         int cz[NCG], cy[NCG], cx[NCG];
 #pragma unroll
         for (int cg = 0; cg < NCG; ++cg) {
-            int v = ct * 64 + cg * 16 + col;
+            int v = ct * CW + cg * 16 + col;
             if (v >= V) v = 0;
             const int t2 = sdiv(v, inv_w);
             cx[cg] = v - t2 * p.W;
@@ -278,7 +283,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     }
 
     // ---- epilogue: column voxel v of sample n, rows row0 .. row0 + 3 ---------------------------------------------------------------------
-    const int v = ct * 64 + wave * 16 + col;
+    const int v = ct * CW + wave * 16 + col;
     const bool valid = v < V && row0 < p.M && wave < NCG;
     const int e = ((n * V + v) * p.M + row0) * ES;       // byte offset in y (and in the mask tensor)
     const i32x4 yrsrc = make_rsrc(p.y, (unsigned int)((long long)p.N * V * p.M * ES));
@@ -453,7 +458,8 @@ static int k3s_launch(const G1Params& p_in, hipStream_t stream) {
     G1Params p = p_in;
     if (SUMS != (p.sums != nullptr) || (SUMS && p.x_stats != nullptr)) return VS_EINVAL;
     const int V = p.D * p.H * p.W, TV = (p.D + 2) * (p.H + 2) * (p.W + 2);
-    const int ctiles = (V + 63) / 64;
+    const bool small_v = TV <= 128 && V <= 32;
+    const int ctiles = (V + k3s_col_tile(small_v) - 1) / k3s_col_tile(small_v);
     p.tiles_per_sample = ctiles;
     const bool hs = !SUMS && p.x_stats != nullptr;
 #define K3S_GO(TVC) return hs ? k3s_launch_t<T, SUMS, TVC, !SUMS>(p, ctiles, stream) : k3s_launch_t<T, SUMS, TVC, false>(p, ctiles, stream)
@@ -471,7 +477,8 @@ template <typename T>
 static int k3s_chain_launch(K3Chain c, bool bwd, hipStream_t stream) {
     const G1Params& p0 = c.p[0];
     const int V = p0.D * p0.H * p0.W, TV = (p0.D + 2) * (p0.H + 2) * (p0.W + 2);
-    const int ctiles = (V + 63) / 64;
+    const bool small_v = TV <= 128 && V <= 32;
+    const int ctiles = (V + k3s_col_tile(small_v) - 1) / k3s_col_tile(small_v);
     int rbmax = 0, cmax = 0;
     for (int l = 0; l < c.nl; ++l) {
         G1Params& p = c.p[l];
