@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
     using GEO = K3BGeom<CK, MT, YT>;
     static_assert(!FA || (!HS && EPI == EPI_RAW), "fused apply: backward-data kernels");
     static_assert(!EA || (SUMS && !FA && !HS && EPI == EPI_RAW), "epilogue apply: backward-data kernels with fused sums");
-    static_assert(YT == 4 || (YT == 8 && CK < 32 && MT == 16), "tall tiles: single-chunk layers, 16 rows");
+    static_assert(YT == 4 || (YT == 8 && CK < 32 && MT == 16) || ((YT == 2 || YT == 1) && CK == 32 && MT == 16), "tall tiles: single-chunk layers, 16 rows; short tiles: 32-channel chunks, 16 rows");
     constexpr int TV = GEO::TV, PLANE = (YT + 2) * 18;
     static_assert(CK == 8 || CK == 16 || CK == 32, "chunk width");
     constexpr int RB = GEO::RB, NKGC = GEO::NKGC, CKB = GEO::CKB, NWF = GEO::NWF;

@@ -67,7 +67,7 @@ class VsConfig(_ctypes.Structure):
     """vs_config (include/vaeseg.h): the library's tuning switches"""
     _fields_ = [(n, _ctypes.c_int) for n in ("k3_small", "k3_tall", "k3_wgs_per_cu", "k3t_wgs_per_cu", "k3f_min_wgs", "mt_min_wgs", "f32_limbs", "g1_limbs", "k3x_ck",
                                             "k3x_toeplitz", "fuse_wgrad", "epilogue_apply", "chain", "k2s2_stream", "k2s8_wgs_per_cu", "up_wgs_per_cu", "up_rb",
-                                            "wgrad_uber", "wgrad_mpack", "wgrad_swap", "wgrad_big", "wgrad_xcd", "reserved_")] + \
+                                            "wgrad_uber", "wgrad_mpack", "wgrad_swap", "wgrad_big", "wgrad_xcd", "k3_short_tiles")] + \
                [(n, _ctypes.c_longlong) for n in ("wgrad_wgs", "wgrad_f32_tiles", "wgrad_group_wgs", "wgrad_big_min_voxels")]
 
 
@@ -135,6 +135,12 @@ def _k3_kid(tname, ck, mt, sums=False, geom=None, m=None, lazy=False):
         tv = (geom[1] + 2) * (geom[2] + 2) * (geom[3] + 2)
         return "k3s_kernel<%s,%d,%s,%s>" % ("true" if sums else "false", 128 if tv <= 128 else 512, hs, tname)
     yt = 4
+    if geom is not None and ck == 32 and mt == 16 and m is not None and cfg["k3_short_tiles"]:      # csrc/igemm_k3_h16.inc: short tiles for the under-filled launches
+        n, d, h, w = geom
+        rt = (m + 15) // 16
+        zx = n * ((d + 3) // 4) * ((w + 15) // 16)
+        if zx * ((h + 3) // 4) * rt <= 128 and zx * ((h + 1) // 2) * rt <= 256:
+            yt = 1 if (cfg["k3_short_tiles"] >= 2 and zx * ((h + 1) // 2) * rt <= 128 and zx * h * rt <= 256) else 2
     if geom is not None and ck < 32 and mt == 16 and cfg["k3_tall"] != 0:
         n, d, h, w = geom
         tiles = n * ((d + 3) // 4) * ((h + 3) // 4) * ((w + 15) // 16)
