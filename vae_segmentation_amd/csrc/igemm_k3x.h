@@ -21,10 +21,10 @@
 #define K3X_LDS_TAPS 2048      // int[64]: byte offset of (k-group, lane group)'s tap in a limb plane
 #define K3X_LDS_TILE 2304      // three limb planes, the weight block, then the per-(n,c) tables
 
-template <int CK, int MT>
+template <int CK, int MT, int YT = 4>
 struct K3XGeom {
     static constexpr int RB = MT / 16;
-    static constexpr int TV = 6 * 6 * 18;                                    // staged halo voxels
+    static constexpr int TV = 6 * (YT + 2) * 18;                             // staged halo voxels (4 x YT x 16 tile)
     static constexpr int U = CK / 4;                                         // fp32 fragments (4 channels) per staged voxel
     static constexpr int NIT = (TV * U + 255) / 256;                         // fragments per thread per stage
     static constexpr int CKB2 = CK * 2;                                      // bytes per voxel in one limb plane
@@ -40,12 +40,14 @@ struct K3XGeom {
 // FA (backward-data use; round 5, the 16-channel layers of the 48^3 level): the input gradient arrives UN-applied, as for k3xt_kernel's fused apply below — p.x = g = dL/da
 // of the lazy activation a = relu(norm(p.fa_x)), statistics p.x_stats, IN-backward sums p.fa_sums; the apply runs in fp32 on the staged fragments before the
 // limb split, centre voxels also go to p.fa_dx when given (one row-block workgroup per tile stores them)
-template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI, bool FA = false>
+// YT (round 6): tile extent in y — 4, or 2 / 1 for the under-filled launches of the 12^3-class levels (igemm_k3_h16.inc says why; dispatch in igemm_k3x.hip)
+template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI, bool FA = false, int YT = 4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 ? 2 : 1))) void k3x_kernel(const G1Params p) {
-    using GEO = K3XGeom<CK, MT>;
+    using GEO = K3XGeom<CK, MT, YT>;
+    static_assert(YT == 4 || ((YT == 2 || YT == 1) && !FA && EPI == EPI_RAW), "short tiles: plain / fused-sums launches");
     static_assert(CK == 8 || CK == 16, "chunk width");
     static_assert(!FA || (!HS && EPI == EPI_RAW), "fused apply: backward-data use");
-    constexpr int TV = GEO::TV, PLANE = 6 * 18, U = GEO::U, NIT = GEO::NIT, CKB2 = GEO::CKB2, RB = GEO::RB, NKGC = GEO::NKGC;
+    constexpr int TV = GEO::TV, PLANE = (YT + 2) * 18, U = GEO::U, NIT = GEO::NIT, CKB2 = GEO::CKB2, RB = GEO::RB, NKGC = GEO::NKGC;
     constexpr int NU = TV * U, NWF = GEO::NWF, NWI = GEO::NWI, PB = GEO::PLANE_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* s_red = (float*)(smem + K3X_LDS_RED);
@@ -88,10 +90,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
     for (int b = 0; b < NIT; ++b) {
         const int u = tid + b * 256;
         const int tv = u / U;
-        const int tx_ = tv % 18, ty_ = (tv / 18) % 6, tz_ = tv / PLANE;
+        const int tx_ = tv % 18, ty_ = (tv / 18) % (YT + 2), tz_ = tv / PLANE;
         rel_off[b] = (((tz_ * p.H + ty_) * p.W + tx_) * p.C + part * 4) * 4;              // bytes from the tile's (0,0,0) halo voxel
         tzyx[b] = u < NU ? (tz_ | (ty_ << 8) | (tx_ << 16)) : 0x00ffffff;                 // out-of-list fragments fail every bounds test
-        cbits |= (u < NU && tz_ >= 1 && tz_ <= 4 && ty_ >= 1 && ty_ <= 4 && tx_ >= 1 && tx_ <= 16) ? (1u << b) : 0u;
+        cbits |= (u < NU && tz_ >= 1 && tz_ <= 4 && ty_ >= 1 && ty_ <= YT && tx_ >= 1 && tx_ <= 16) ? (1u << b) : 0u;
     }
     int w_off[NWI];
 #pragma unroll
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
         const int tz = fdiv(tl, p.fd_m[1], p.fd_s[1]);
         const int r = tl - tz * (p.txn * p.tyn);
         const int ty = fdiv(r, p.fd_m[2], p.fd_s[2]);
-        c.z0 = tz * 4; c.y0 = ty * 4; c.x0 = (r - ty * p.txn) * 16;
+        c.z0 = tz * 4; c.y0 = ty * YT; c.x0 = (r - ty * p.txn) * 16;
         return c;
     };
     auto load_w = [&](int ch) {
@@ -266,12 +268,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
         // two accumulators per output tile: the leading products x0*w0 in `acc`, the five products of weight <= 2^-8 in `acl`, added once in the
         // epilogue.  In one accumulator the big running sum was rounded by all six MFMAs of every k-group; measured on the layer tests (max error of y
         // against CPU fp32 autograd): 1.2e-6 with one accumulator, the exact-f32 kernels' 4e-7 with two
-        f32x4 acc[RB][4], acl[RB][4];
+        f32x4 acc[RB][YT], acl[RB][YT];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) { acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        u32x4 mk[RB][4];                                 // mask tensor values under this tile's outputs (fused IN-bwd sums)
+            for (int cg = 0; cg < YT; ++cg) { acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        u32x4 mk[RB][YT];                                 // mask tensor values under this tile's outputs (fused IN-bwd sums)
 
         for (int ch = 0; ch < p.nch; ++ch) {
             if (!first) __syncthreads();                 // every wave is done reading the previous stage
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                        for (int cg = 0; cg < 4; ++cg) {
+                        for (int cg = 0; cg < YT; ++cg) {
                             const bool valid = zx_ok && y0 + cg < p.H && (rb0 + rb) * 16 + 4 * g < p.M;
                             mk[rb][cg] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(mrsrc, valid ? ebase + cg * p.W * p.M * 4 + rb * 64 : -1, 0, 0));
                         }
@@ -300,18 +302,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
                 }
             }
             // ---- multiply this stage out of LDS: per k-group three A limbs per row block, three B limbs per column group, six MFMAs per pair ----
-            auto read_kg = [&](int kg, u32x4 (&a)[RB][3], u32x4 (&b)[4][3]) {
+            auto read_kg = [&](int kg, u32x4 (&a)[RB][3], u32x4 (&b)[YT][3]) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) a[rb][j] = *(const u32x4*)(s_wl + ((rb * NKGC + kg) * 3 + j) * 1024);
                 const int o = baddr + s_taps[kg * 4 + g];
 #pragma unroll
-                for (int cg = 0; cg < 4; ++cg)
+                for (int cg = 0; cg < YT; ++cg)
 #pragma unroll
                     for (int i = 0; i < 3; ++i) b[cg][i] = *(const u32x4*)(s_tile + i * PB + o + cg * 18 * CKB2);
             };
-            u32x4 fa[2][RB][3], fb[2][4][3];
+            u32x4 fa[2][RB][3], fb[2][YT][3];
             read_kg(0, fa[0], fb[0]);
 #pragma unroll
             for (int kg = 0; kg < NKGC; ++kg) {
@@ -323,12 +325,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                        for (int cg = 0; cg < 4; ++cg)
+                        for (int cg = 0; cg < YT; ++cg)
                             acl[rb][cg] = mfma16(fa[kg & 1][rb][PJ[q]], fb[kg & 1][cg][PI[q]], acl[rb][cg], (unsigned short*)nullptr);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                    for (int cg = 0; cg < 4; ++cg)
+                    for (int cg = 0; cg < YT; ++cg)
                         acc[rb][cg] = mfma16(fa[kg & 1][rb][0], fb[kg & 1][cg][0], acc[rb][cg], (unsigned short*)nullptr);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -338,13 +340,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int cg = 0; cg < 4; ++cg) acc[rb][cg] += acl[rb][cg];
+            for (int cg = 0; cg < YT; ++cg) acc[rb][cg] += acl[rb][cg];
         if constexpr (EPI == EPI_SOFTMAX2) {
             if (g == 0) {
                 const float b0 = bv[0][0], b1 = bv[0][1];
                 const size_t V = (size_t)p.D * p.H * p.W;
 #pragma unroll
-                for (int cg = 0; cg < 4; ++cg) {
+                for (int cg = 0; cg < YT; ++cg) {
                     const int oy = y0 + cg, ox = x0 + col;
                     if (!(oz < p.D && oy < p.H && ox < p.W)) continue;
                     float l0 = acc[0][cg][0] + b0, l1 = acc[0][cg][1] + b1;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
                     for (int r = 0; r < 4; ++r) { mm[r] = s_mkm[n * p.M + row + r]; mr[r] = s_mkr[n * p.M + row + r]; }
                 }
 #pragma unroll
-                for (int cg = 0; cg < 4; ++cg) {
+                for (int cg = 0; cg < YT; ++cg) {
                     const bool valid = rvalid && zx_ok && y0 + cg < p.H;
                     float v[4];
 #pragma unroll
@@ -433,10 +435,15 @@ static inline void k3x_fastdiv(int d, unsigned int& m, unsigned int& s) {
     m = (unsigned int)((((1ull << (32 + s)) + (unsigned long long)d - 1) / (unsigned long long)d) - (1ull << 32));
 }
 
-template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI, bool FA = false>
+template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI, bool FA = false, int YT = 4>
 static int k3x_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
-    using GEO = K3XGeom<CK, MT>;
+    using GEO = K3XGeom<CK, MT, YT>;
     G1Params p = p_in;
+    if (YT != 4) {                                       // re-tile the volume in 4 x YT x 16 tiles
+        p.tyn = (p.H + YT - 1) / YT;
+        p.tiles_per_sample = ((p.D + 3) / 4) * p.tyn * p.txn;
+        tiles_total = p.tiles_per_sample * p.N;
+    }
     if (FA && (p.N * p.C > 192 || !p.x_stats || !p.fa_sums)) return VS_ESHAPE;      // waves 1 .. 3 build the fused-apply tables
     const size_t tables = (size_t)(FA ? 6 : 2) * p.N * p.C * sizeof(float) + (p.sums ? (size_t)2 * p.N * p.M * sizeof(float) : 0);
     const size_t lds = K3X_LDS_TILE + (size_t)3 * GEO::PLANE_BYTES + GEO::W_BYTES + tables;
@@ -447,7 +454,7 @@ static int k3x_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     k3x_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3x_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
     if (SUMS != (p.sums != nullptr) || (SUMS && !FA && p.x_stats != nullptr) || MULTI != (p.nch > 1)) return VS_EINVAL;
-    auto kern = k3x_kernel<CK, MT, EPI, SUMS, HS, MULTI, FA>;
+    auto kern = k3x_kernel<CK, MT, EPI, SUMS, HS, MULTI, FA, YT>;
     static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
     // persistent grid: as many workgroups as the LDS lets a CU hold (CK = 8: two, CK = 16: one), each walking a strided slice of the tile list
@@ -465,6 +472,15 @@ static int k3x_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
 // the fused-apply instantiations: 8-channel chunks, 16-row workgroups (the 16 -> 16 layers of the 48^3 level and their 64^3 / 80^3 counterparts)
 template <int CK, int MT, int EPI, bool MULTI>
 constexpr bool k3x_has_fa() { return CK == 8 && MT == 16 && EPI == EPI_RAW && MULTI; }
+
+// short tiles (YT = 2 / 1): the plain, lazy-input and fused-sums forms only
+template <int CK, int MT, bool MULTI, int YT>
+static int k3x_launch_short(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
+    if (p.fa_x != nullptr) return VS_ESHAPE;
+    if (p.sums != nullptr) return k3x_launch_t<CK, MT, EPI_RAW, true, false, MULTI, false, YT>(p, tiles_total, row_tiles, stream);
+    if (p.x_stats != nullptr) return k3x_launch_t<CK, MT, EPI_RAW, false, true, MULTI, false, YT>(p, tiles_total, row_tiles, stream);
+    return k3x_launch_t<CK, MT, EPI_RAW, false, false, MULTI, false, YT>(p, tiles_total, row_tiles, stream);
+}
 
 template <int CK, int MT, int EPI, bool MULTI>
 static int k3x_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {

@@ -19,6 +19,15 @@ int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int
             if (mt == 16) return k3x_launch<8, 16, EPI_RAW, false>(p, tiles, row_tiles, s);
             if (mt == 32) return k3x_launch<8, 32, EPI_RAW, false>(p, tiles, row_tiles, s);
         } else {                                          // VS_K3X_CK=8: 8-channel chunks for every layer (two workgroups per CU)
+            if (mt == 16 && !p.fa_x && vs_cfg().k3_short_tiles) {
+                // the under-filled launches of the 12^3-class levels (<= 128 workgroups): 4 x 2 x 16 tiles, 4 x 1 x 16 where that still leaves <= 128 (igemm_k3_h16.inc)
+                const long long zx = (long long)p.N * ((p.D + 3) / 4) * p.txn;
+                if ((long long)tiles * row_tiles <= 128 && zx * ((p.H + 1) / 2) * row_tiles <= 256) {
+                    if (vs_cfg().k3_short_tiles >= 2 && zx * ((p.H + 1) / 2) * row_tiles <= 128 && zx * p.H * row_tiles <= 256)
+                        return k3x_launch_short<8, 16, true, 1>(p, tiles, row_tiles, s);
+                    return k3x_launch_short<8, 16, true, 2>(p, tiles, row_tiles, s);
+                }
+            }
             if (mt == 16) return k3x_launch<8, 16, EPI_RAW, true>(p, tiles, row_tiles, s);
             if (mt == 32) return k3x_launch<8, 32, EPI_RAW, true>(p, tiles, row_tiles, s);
         }
