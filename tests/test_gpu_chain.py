@@ -115,10 +115,10 @@ EA_CASES = [(2, 32, 32, 24), (2, 16, 32, 24), (2, 64, 64, 12), (2, 128, 64, 12),
 
 
 @pytest.mark.parametrize("lib_mode", ["det", "atomic"], indirect=True)
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("case", EA_CASES)
 def test_epilogue_apply_equals_backward_data_then_apply(case, dtype, lib_mode):
-    """k3b_kernel<..., EA> (csrc/igemm_k3b.h): the backward-data launch of a 3x3x3 conv on a lazy input applies the InstanceNorm+ReLU backward to its own outputs
+    """k3b_kernel<..., EA> (csrc/igemm_k3b.h; fp32 parity mode: k3x_kernel<..., EA>, csrc/igemm_k3x.h): the backward-data launch of a 3x3x3 conv on a lazy input applies the InstanceNorm+ReLU backward to its own outputs
     after a per-sample arrival counter — against the two launches it replaces (which tests/test_gpu_layers.py pins to CPU autograd at these shapes)."""
     ops = _ops()
     n, cin, cout, side = case
@@ -127,7 +127,9 @@ def test_epilogue_apply_equals_backward_data_then_apply(case, dtype, lib_mode):
     xs = ops.instnorm_stats(x_cl)
     w = (torch.randn(cout, cin, 3, 3, 3) / (27 * cin) ** 0.5).cuda()
     gy = to_cl(torch.randn(n, cout, side, side, side), cout, dtype)
-    assert ops.lib.vs_conv_k3_bwd_data_applied_supported(n, side, side, side, cout, cin, ops.vs_dtype(x_cl)), "the case must be one the kernel takes"
+    if not ops.lib.vs_conv_k3_bwd_data_applied_supported(n, side, side, side, cout, cin, ops.vs_dtype(x_cl)):
+        assert dtype == torch.float32, "the 16-bit cases must be ones the kernel takes"
+        pytest.skip("the parity mode's kernel runs one workgroup per CU: this launch has more than 256")
     res = {}
     was = ops.EPILOGUE_APPLY
     try:
@@ -147,4 +149,4 @@ def test_epilogue_apply_equals_backward_data_then_apply(case, dtype, lib_mode):
             assert torch.equal(a, b), "%s differs (max %g)" % (nm, (a.double() - b.double()).abs().max().item())
         else:
             e = relerr(b.double().cpu(), a.double().cpu())
-            assert e < {torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dtype], "%s: %g" % (nm, e)
+            assert e < {torch.float32: 2e-5, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dtype], "%s: %g" % (nm, e)

@@ -7,6 +7,7 @@ int g1_dispatch_k3_bf16(const G1Params& p, int ck, int mt, int epi, int tiles, i
 int g1_dispatch_k3_f16(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
 int g1_k3_fa_supported(const G1Params& p, int ck, int mt);
 int k3tw_slab_count(int n, int d, int h, int w);
+int k3x_ea_capacity(int n, int c, int m);            // igemm_k3x.hip: the same for the parity mode's k3x_kernel<8, 16, .., EA>
 int k3b_ea_capacity(int n, int c, int m);            // igemm_k3_bf16.hip: workgroups of a k3b_kernel<.., EA> launch that are certainly resident together
 int k2s2_scatter8_launch(const G1Params& p, int dtype, hipStream_t stream);      // k2s2_scatter8.hip        // igemm_k3_bf16.hip: workgroups (= slabs) of a k3tw_kernel launch
 int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int row_tiles, hipStream_t s);
@@ -115,6 +116,12 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     if (ea_query != nullptr) {                             // planning only: does k3b_kernel<32, 16, .., EA> take this backward-data launch?  (16-bit storage, 32-channel
         *ea_query = (kind == VS_CONV_K3 && dtype != VS_F32 && ck == 32 && mt == 16 && sums != nullptr && !fa_x &&        // chunks, not a k3s volume, one resident round)
                      !((long long)(d + 2) * (h + 2) * (w + 2) <= 512 && c_in <= 1024) && tiles * row_tiles <= k3b_ea_capacity(n, c_in, m_out)) ? 1 : 0;
+        if (kind == VS_CONV_K3 && dtype == VS_F32 && sums != nullptr && !fa_x && vs_conv_k3_f32_limbs(d, h, w, c_in) && vs_k3x_ck(c_in) == 8 && c_in > 8) {
+            // parity mode: k3x_kernel<8, 16, .., MULTI, .., EA> — 8-channel chunks, 16-row workgroups (dispatch_k3 takes 32 rows only for launches of >= 256 workgroups)
+            const long long rows16 = p.rb_total;
+            const bool mt32 = (p.rb_total * 16) % 32 == 0 && tiles * (p.rb_total / 2) >= 256;
+            *ea_query = (!mt32 && tiles * rows16 <= k3x_ea_capacity(n, c_in, m_out)) ? 1 : 0;
+        }
         return VS_OK;
     }
     if (fa_query != nullptr) {                             // planning only: would a fused-apply launch of this shape find a kernel?
@@ -171,7 +178,7 @@ extern "C" int vs_conv_k3_fused_apply_supported(int n, int d, int h, int w, int 
 // ---- backward-data whose epilogue applies the InstanceNorm+ReLU backward itself (igemm_k3b.h EA, round 6) ----
 extern "C" int vs_conv_k3_bwd_data_applied_supported(int n, int d, int h, int w, int c_in, int m_out, int dtype) {
     const int on = vs_cfg().epilogue_apply;
-    if (!on || !vs_dtype_ok(dtype) || dtype == VS_F32) return 0;
+    if (!on || !vs_dtype_ok(dtype)) return 0;
     static const char dummy[16] __attribute__((aligned(16))) = {0};        // planning only: no pointer is dereferenced
     static double dsink[2];
     int ok = 0;

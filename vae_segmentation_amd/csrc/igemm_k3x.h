@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include "igemm.h"
 
+#include "chain.h"
 #define K3X_LDS_RED 0          // float[4][64][2]
 #define K3X_LDS_TAPS 2048      // int[64]: byte offset of (k-group, lane group)'s tap in a limb plane
 #define K3X_LDS_TILE 2304      // three limb planes, the weight block, then the per-(n,c) tables
@@ -41,9 +42,12 @@ struct K3XGeom {
 // of the lazy activation a = relu(norm(p.fa_x)), statistics p.x_stats, IN-backward sums p.fa_sums; the apply runs in fp32 on the staged fragments before the
 // limb split, centre voxels also go to p.fa_dx when given (one row-block workgroup per tile stores them)
 // YT (round 6): tile extent in y — 4, or 2 / 1 for the under-filled launches of the 12^3-class levels (igemm_k3_h16.inc says why; dispatch in igemm_k3x.hip)
-template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI, bool FA = false, int YT = 4>
+// EA (round 6): the epilogue apply of igemm_k3b.h for the parity mode — backward-data with fused sums whose workgroups (one tile each, all resident) wait for their
+// SAMPLE's sums and store the applied gradient themselves; fp32 values throughout, so the result equals the standalone apply's bit for bit (deterministic build)
+template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI, bool FA = false, int YT = 4, bool EA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 ? 2 : 1))) void k3x_kernel(const G1Params p) {
     using GEO = K3XGeom<CK, MT, YT>;
+    static_assert(!EA || (SUMS && !FA && !HS && EPI == EPI_RAW), "epilogue apply: backward-data kernels with fused sums");
     static_assert(YT == 4 || ((YT == 2 || YT == 1) && !FA && EPI == EPI_RAW), "short tiles: plain / fused-sums launches");
     static_assert(CK == 8 || CK == 16, "chunk width");
     static_assert(!FA || (!HS && EPI == EPI_RAW), "fused apply: backward-data use");
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
 #pragma unroll
             for (int cg = 0; cg < YT; ++cg) { acc[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; acl[rb][cg] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         u32x4 mk[RB][YT];                                 // mask tensor values under this tile's outputs (fused IN-bwd sums)
+        f32x4 vkeep[EA ? RB : 1][EA ? YT : 1];            // EA: this tile's outputs, kept for the apply
 
         for (int ch = 0; ch < p.nch; ++ch) {
             if (!first) __syncthreads();                 // every wave is done reading the previous stage
@@ -378,7 +383,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = acc[rb][cg][r] + bv[rb][r];
-                    vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{v[0], v[1], v[2], v[3]}), yrsrc, valid ? ebase + cg * p.W * p.M * 4 + rb * 64 : -1, 0, 0);
+                    if constexpr (EA) vkeep[rb][cg] = f32x4{v[0], v[1], v[2], v[3]};
+                    else vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{v[0], v[1], v[2], v[3]}), yrsrc, valid ? ebase + cg * p.W * p.M * 4 + rb * 64 : -1, 0, 0);
                     if (!valid) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
                     if constexpr (SUMS) {
 #pragma unroll
@@ -423,10 +429,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
                     if (t + G < t_end) __syncthreads();     // s_red is reused by a later flush
                 }
             }
+            if constexpr (EA) {
+                unsigned int* ctr = p.ea_sync + (size_t)n * 256;          // 8 shards of 128 bytes per sample (chain.h)
+                chain_arrive8(ctr);
+                chain_wait8(ctr, (unsigned int)p.ea_items, p.ea_fault);
+                if (tid < MT) {
+                    const int row = rb0 * 16 + tid;
+                    float m = 0.f, r = 1.f, a = 0.f, b = 0.f;
+                    if (row < p.M) {
+                        stats_to_mean_rstd(p.mask_stats, (size_t)n * p.M + row, (size_t)p.N * p.M, p.inv_count_out, p.eps, m, r);     // the standalone apply's exact form
+                        double sv[2];
+                        stat_load_sc1(p.sums, (size_t)n * p.M + row, (size_t)p.N * p.M, sv);
+                        a = (float)(sv[0] * p.inv_count_out);
+                        b = (float)(sv[1] * p.inv_count_out);
+                    }
+                    *(f32x4*)(s_red + tid * 4) = f32x4{m, r, a, b};
+                }
+                __syncthreads();
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const bool rvalid = (rb0 + rb) * 16 + 4 * g < p.M;
+                    f32x4 tb[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tb[r] = *(const f32x4*)(s_red + (rb * 16 + 4 * g + r) * 4);
+#pragma unroll
+                    for (int cg = 0; cg < YT; ++cg) {
+                        const bool valid = rvalid && zx_ok && y0 + cg < p.H;
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float xh = (__uint_as_float(mk[rb][cg][r]) - tb[r][0]) * tb[r][1];
+                            const float gm = xh > 0.f ? vkeep[rb][cg][r] : 0.f;
+                            o[r] = tb[r][1] * (gm - tb[r][2] - xh * tb[r][3]);
+                        }
+                        vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{o[0], o[1], o[2], o[3]}), yrsrc, valid ? ebase + cg * p.W * p.M * 4 + rb * 64 : -1, 0, 0);
+                    }
+                }
+            }
         }
         cur = nxt;
     }
 }
+
+// workgroups of one k3x_kernel<8, 16, .., EA> launch that are certainly resident together: ONE per CU — the 4 x 4 x 16 instantiation holds 226 + 48 registers
+// (one wave per SIMD), whatever the LDS would allow (the first version counted LDS only: 288 workgroups waited for 32 that could not start, and the fault word said so)
+static inline int k3x_ea_max_wgs(int, int, int) { return 256; }
 
 // (m, s) with n / d == (mulhi(n, m) + n) >> s for every 0 <= n < 2^31
 static inline void k3x_fastdiv(int d, unsigned int& m, unsigned int& s) {
@@ -435,7 +482,7 @@ static inline void k3x_fastdiv(int d, unsigned int& m, unsigned int& s) {
     m = (unsigned int)((((1ull << (32 + s)) + (unsigned long long)d - 1) / (unsigned long long)d) - (1ull << 32));
 }
 
-template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI, bool FA = false, int YT = 4>
+template <int CK, int MT, int EPI, bool SUMS, bool HS, bool MULTI, bool FA = false, int YT = 4, bool EA = false>
 static int k3x_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hipStream_t stream) {
     using GEO = K3XGeom<CK, MT, YT>;
     G1Params p = p_in;
@@ -454,7 +501,7 @@ static int k3x_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     k3x_fastdiv(p.txn * p.tyn, p.fd_m[1], p.fd_s[1]);
     k3x_fastdiv(p.txn, p.fd_m[2], p.fd_s[2]);
     if (SUMS != (p.sums != nullptr) || (SUMS && !FA && p.x_stats != nullptr) || MULTI != (p.nch > 1)) return VS_EINVAL;
-    auto kern = k3x_kernel<CK, MT, EPI, SUMS, HS, MULTI, FA, YT>;
+    auto kern = k3x_kernel<CK, MT, EPI, SUMS, HS, MULTI, FA, YT, EA>;
     static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_err != hipSuccess) return (int)attr_err;
     // persistent grid: as many workgroups as the LDS lets a CU hold (CK = 8: two, CK = 16: one), each walking a strided slice of the tile list
@@ -464,6 +511,10 @@ static int k3x_launch_t(const G1Params& p_in, int tiles_total, int row_tiles, hi
     if (row_tiles > per_cu) wg = (256 * per_cu + row_tiles - 1) / row_tiles / 8 * 8;
     if (wg < 8) wg = 8;
     const int gx = tiles_total < wg ? tiles_total : wg;
+    if (EA) {                                            // one tile per workgroup, every workgroup resident while its sample's peers wait for it
+        if (gx != tiles_total || (long long)tiles_total * row_tiles > k3x_ea_max_wgs(p.N, p.C, p.M) || !p.ea_sync || !p.ea_fault) return VS_ESHAPE;
+        p.ea_items = p.tiles_per_sample * row_tiles;
+    }
     hipLaunchKernelGGL(kern, dim3(gx, row_tiles), dim3(256), lds, stream, p);
     VS_CHECK_LAUNCH();
     return VS_OK;
@@ -477,6 +528,10 @@ constexpr bool k3x_has_fa() { return CK == 8 && MT == 16 && EPI == EPI_RAW && MU
 template <int CK, int MT, bool MULTI, int YT>
 static int k3x_launch_short(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
     if (p.fa_x != nullptr) return VS_ESHAPE;
+    if (p.ea_sync != nullptr) {
+        if (!p.sums) return VS_EINVAL;
+        return k3x_launch_t<CK, MT, EPI_RAW, true, false, MULTI, false, YT, true>(p, tiles_total, row_tiles, stream);
+    }
     if (p.sums != nullptr) return k3x_launch_t<CK, MT, EPI_RAW, true, false, MULTI, false, YT>(p, tiles_total, row_tiles, stream);
     if (p.x_stats != nullptr) return k3x_launch_t<CK, MT, EPI_RAW, false, true, MULTI, false, YT>(p, tiles_total, row_tiles, stream);
     return k3x_launch_t<CK, MT, EPI_RAW, false, false, MULTI, false, YT>(p, tiles_total, row_tiles, stream);

@@ -19,6 +19,7 @@ int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int
             if (mt == 16) return k3x_launch<8, 16, EPI_RAW, false>(p, tiles, row_tiles, s);
             if (mt == 32) return k3x_launch<8, 32, EPI_RAW, false>(p, tiles, row_tiles, s);
         } else {                                          // VS_K3X_CK=8: 8-channel chunks for every layer (two workgroups per CU)
+            if (p.ea_sync != nullptr && mt != 16) return VS_ESHAPE;       // the epilogue apply exists for the 16-row workgroups (conv_api.hip asks k3x_ea_capacity first)
             if (mt == 16 && !p.fa_x && vs_cfg().k3_short_tiles) {
                 // the under-filled launches of the 12^3-class levels (<= 128 workgroups): 4 x 2 x 16 tiles, 4 x 1 x 16 where that still leaves <= 128 (igemm_k3_h16.inc)
                 const long long zx = (long long)p.N * ((p.D + 3) / 4) * p.txn;
@@ -28,11 +29,13 @@ int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int
                     return k3x_launch_short<8, 16, true, 2>(p, tiles, row_tiles, s);
                 }
             }
+            if (mt == 16 && p.ea_sync != nullptr) return k3x_launch_short<8, 16, true, 4>(p, tiles, row_tiles, s);
             if (mt == 16) return k3x_launch<8, 16, EPI_RAW, true>(p, tiles, row_tiles, s);
             if (mt == 32) return k3x_launch<8, 32, EPI_RAW, true>(p, tiles, row_tiles, s);
         }
         return VS_ESHAPE;
     }
+    if (p.ea_sync != nullptr) return VS_ESHAPE;
     if (ck == 16) {
         if (p.nch == 1) {
             if (mt == 16) return k3x_launch<16, 16, EPI_RAW, false>(p, tiles, row_tiles, s);
@@ -44,3 +47,6 @@ int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int
     }
     return VS_ESHAPE;
 }
+
+// conv_api.hip: workgroups of a k3x_kernel<8, 16, .., EA> launch that are certainly resident together
+int k3x_ea_capacity(int n, int c, int m) { return k3x_ea_max_wgs(n, c, m); }
