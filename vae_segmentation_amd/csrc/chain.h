@@ -25,6 +25,9 @@
 #ifndef K3S_NCG
 #define K3S_NCG 2                    // igemm_k3s.h: 16-voxel column groups per workgroup of the 6^3-class volumes (the chain planner needs the tile width too)
 #endif
+#ifndef K3S_NCG_SMALL
+#define K3S_NCG_SMALL 1              // ... and of the 3^3-class volumes (27 voxels: one group per workgroup, two workgroups — fp32 mode 5.735 -> 5.692 ms same box; two groups in one: 2)
+#endif
 #define VS_CHAIN_MAX_LAYERS 3
 #define VS_CHAIN_PHASES 8            // counters per sample, one 128-byte line each
 #define VS_CHAIN_MAX_ITEMS 256       // workgroups per sample

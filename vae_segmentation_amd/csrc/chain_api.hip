@@ -16,7 +16,7 @@ extern "C" int vs_conv_k3_chain_supported(int n, int d, int h, int w, int c_max,
     if (!on || !vs_dtype_ok(dtype) || !chain_shape_ok(n, d, h, w)) return 0;
     if (c_max <= 0 || c_max % 32 || c_max > 1024) return 0;
     const int v = d * h * w;
-    const int cw = ((long long)(d + 2) * (h + 2) * (w + 2) <= 128 && v <= 32) ? 64 : 16 * K3S_NCG;      // k3s_col_tile()
+    const int cw = ((long long)(d + 2) * (h + 2) * (w + 2) <= 128 && v <= 32) ? 16 * K3S_NCG_SMALL : 16 * K3S_NCG;      // k3s_col_tile()
     const int ctiles = (v + cw - 1) / cw;
     return ctiles * (c_max / 16) <= VS_CHAIN_MAX_ITEMS ? 1 : 0;
 }

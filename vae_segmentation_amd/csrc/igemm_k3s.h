@@ -39,7 +39,7 @@ extern "C" int vs_debug_read_chain_stamps(unsigned long long* host, int n) { ret
 // K3S_NCG (chain.h): 16-voxel column groups per workgroup at the 6^3-class volumes.  2 since round 6 (32-voxel column tiles, twice the workgroups): these launches
 // use 64 of the 256 CUs with 64-voxel tiles and their MFMA phase is issue-bound per CU — same-box 2.349 -> 2.331 ms per bf16 step, 6.096 -> 5.971 in the fp32
 // mode (whose exact-f32 MFMA phase is the longest); 16-voxel tiles (K3S_NCG=1) lose again (2.401 vs 2.349: every workgroup stages the whole padded sample).
-static inline int k3s_col_tile(bool small) { return small ? 64 : 16 * K3S_NCG; }      // host: voxels per column tile
+static inline int k3s_col_tile(bool small) { return small ? 16 * K3S_NCG_SMALL : 16 * K3S_NCG; }      // host: voxels per column tile
 #define K3S_LDS_RED 0          // float[4][16][2]
 #define K3S_LDS_TILE 512
 // then: padded sample chunk [TV][64 B] (at least 16 KB: the cross-wave partials alias it), scale / shift tables [C] each
@@ -73,8 +73,8 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     constexpr int NWI = NKW;                             // weight fragments per thread per stage: its wave's taps
     constexpr int ES = (int)sizeof(T), EPL = 16 / ES, CHS = 64 / ES;     // element size, elements per fragment, channels per stage
     constexpr int SPC = 32 / CHS;                        // stages per 32-channel chunk of the packed weight image (1, or 2 for fp32)
-    constexpr int NCG = TVC == 128 ? 2 : K3S_NCG;        // 16-column groups that can hold voxels
-    constexpr int CW = TVC == 128 ? 64 : 16 * K3S_NCG;   // voxels per column tile: up to 3x3x3 = 27 voxels fill two (the other two were 4.5 of 13 us of MFMA phase on padding)
+    constexpr int NCG = TVC == 128 ? K3S_NCG_SMALL : K3S_NCG;        // 16-column groups that can hold voxels
+    constexpr int CW = 16 * NCG;                         // voxels per column tile: up to 3x3x3 = 27 voxels fill two (the other two were 4.5 of 13 us of MFMA phase on padding)
     float* s_red = (float*)(smem + K3S_LDS_RED);
     char* s_tile = smem + K3S_LDS_TILE;
     const int PX = p.W + 2, PY = p.H + 2, TV = (p.D + 2) * PY * PX, V = p.D * p.H * p.W;
