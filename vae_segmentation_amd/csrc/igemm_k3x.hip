@@ -23,6 +23,7 @@ int g1_dispatch_k3_x3(const G1Params& p, int ck, int mt, int epi, int tiles, int
             if (mt == 16 && !p.fa_x && vs_cfg().k3_short_tiles) {
                 // the under-filled launches of the 12^3-class levels (<= 128 workgroups): 4 x 2 x 16 tiles, 4 x 1 x 16 where that still leaves <= 128 (igemm_k3_h16.inc)
                 const long long zx = (long long)p.N * ((p.D + 3) / 4) * p.txn;
+                // (4 x 2 x 16 for EVERY launch — two waves per SIMD instead of one — measured slower: fp32 step 5.748 -> 5.846 ms; the halo grows 2.5 x -> 3.4 x)
                 if ((long long)tiles * row_tiles <= 128 && zx * ((p.H + 1) / 2) * row_tiles <= 256) {
                     if (vs_cfg().k3_short_tiles >= 2 && zx * ((p.H + 1) / 2) * row_tiles <= 128 && zx * p.H * row_tiles <= 256)
                         return k3x_launch_short<8, 16, true, 1>(p, tiles, row_tiles, s);
