@@ -531,3 +531,35 @@ def test_out_block_backward_as_one_launch(case, parts, dtype):
                                             None, s2.data_ptr(), n, d, h, w, dt, 1e-5, pdrop, seed, st) == -1
     assert lib.vs_conv_k3_softmax2_bwd_data(prob.data_ptr(), None, None, wpb.data_ptr(), y.data_ptr(), mx.data_ptr(), mxs.data_ptr(), s2.data_ptr(),
                                             None, None, n, d, h, w, dt, 1e-5, pdrop, seed, st) == -1
+
+
+@pytest.mark.parametrize("lib_mode", ["det", "atomic"], indirect=True)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [(3, 8, 50), (2, 8, 26), (3, 8, 18), (1, 8, 34)])
+def test_k2s2_scatter8_streaming_kernel_equals_the_mfma_tile_kernel(case, dtype, lib_mode):
+    """the 8 -> 8 stride-2 backward-data at full resolution runs k2s2_scatter8_kernel (csrc/k2s2_scatter8.hip) by default; A/B against the
+    g1_kernel<8, PW, SCATTER> it replaced (vs_config.k2s2_stream = 0) on shapes where the coarse voxel count is NOT a multiple of 32 (25^3, 13^3, 9^3, 17^3:
+    partial last items, sample boundaries inside a workgroup's run with N = 3): the applied gradient (un-applied values + fused InstanceNorm-backward sums) and
+    the weight gradient that reads it."""
+    ops = _ops()
+    n, c, s = case
+    x = rnd(n, c, s, s, s, seed=31)
+    wt = q(rnd(c, c, 2, 2, 2, seed=32, scale=(3.0 / (8 * c)) ** 0.5), dtype)
+    gy = to_cl(rnd(n, c, s // 2, s // 2, s // 2, seed=33), c, dtype)
+    res = {}
+    for stream in (0, 1):
+        with ops.config(k2s2_stream=stream):
+            x_cl = to_cl(x, c, dtype).requires_grad_(True)
+            xs = ops.instnorm_stats(x_cl.detach())
+            w_gpu = wt.clone().cuda().requires_grad_(True)
+            ops.stats_arena_begin(x_cl.device)
+            y = ops.ConvK2S2.apply(x_cl, xs, w_gpu, None)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res[stream] = (x_cl.grad.detach().clone(), w_gpu.grad.detach().clone())
+    tol = {torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dtype]
+    e = relerr(res[1][0].double().cpu(), res[0][0].double().cpu())
+    # the two kernels form the 8 x 8 products in different orders (MFMA tile vs vector ALU) and sum the fused statistics in different orders: the applied
+    # gradients agree to fp32 summation rounding (measured 1.2e-6 of the tensor's maximum at 25^3 x 3), far inside one rounding of the storage type
+    assert e < tol, "applied gradient: %g" % e          # (fp16: a few elements round the other way, 1 ulp = 4.9e-4 of their value)
+    assert relerr(res[1][1].cpu(), res[0][1].cpu()) < 2e-5, "weight gradient"

@@ -682,6 +682,27 @@ def test_weight_gradient_fused_into_backward_data_matches_the_grouped_launch(dty
     # a second pass right away: the use counts start over when a backward pass ends
     _, n_again = run(True, False)
     assert n_again == 2
+    # forward(W), an UNRELATED backward pass ends, forward(W) again, then ONE backward through both uses — the forward-time use count reads 1 with two
+    # live uses; the first use's gradient rides in its backward-data launch (slabs), the second must get a destination of its own and autograd must add the two
+    def interleaved(fuse):
+        ops.FUSE_WGRAD = fuse
+        try:
+            wt = w1.clone().cuda().requires_grad_(True)
+            other = w2.clone().cuda().requires_grad_(True)
+            ops.stats_arena_begin(torch.device("cuda", 0))
+            x_cl = to_cl(x, c, dtype)
+            st = ops.instnorm_stats(x_cl)
+            ya, _ = ops.ConvK3.apply(x_cl, st, wt, None)                       # first forward through W
+            yo, _ = ops.ConvK3.apply(x_cl, st, other, None)
+            (yo.float() * gsum).sum().backward()                               # an unrelated backward pass ends in between
+            yb, _ = ops.ConvK3.apply(x_cl, st, wt, None)                       # second forward through W
+            ((ya.float() + 2.0 * yb.float()) * gsum).sum().backward()
+            torch.cuda.synchronize()
+            return wt.grad.clone()
+        finally:
+            ops.FUSE_WGRAD = True
+    g_ref, g_got = interleaved(False), interleaved(True)
+    assert bool(torch.isfinite(g_got).all()) and relerr(g_got.cpu(), g_ref.cpu()) < 2e-5
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -938,7 +938,9 @@ def _group_submit_slabs(weight, slabs, nslabs, m_real, c_real, keep, bias=None):
         gb = _grad_slot(bias[0], (m_real,))
         d.bias_g, d.db, d.bias_rows, d.bias_c_ch, d.bias_c_real = bias[1].data_ptr(), gb.data_ptr(), nslabs, m_real, m_real
         g["keep"].append(bias[1])
-    g["slots"][id(weight)] = (gw.data_ptr(), None if gb is None else gb.data_ptr())
+    # third field: this destination belongs to a SLAB descriptor — vs_conv_wgrad_multi does not let a regular descriptor share it (the forward-time use
+    # count can read 1 with two live uses when an unrelated backward pass ended between two forwards of the same weight); _side_grads gives a later use its own
+    g["slots"][id(weight)] = (gw.data_ptr(), None if gb is None else gb.data_ptr(), True)
     first = g["split"] is None or bool(g["split"](weight))
     g["descs"].append((d, first, float(slabs.numel() * 4), 0.0, 0))
     g["keep"].append(slabs)
@@ -970,6 +972,8 @@ def _side_grads(weight, keep, wgrad_args, bias_args, bias=None):
     still-unwritten tensor); -> (gw, gb)."""
     grouping = _GROUP["enabled"]
     slot = _GROUP["slots"].get(id(weight)) if grouping and weight.is_leaf else None
+    if slot is not None and len(slot) > 2 and slot[2]:
+        slot = None                             # the first use went into its backward-data launch (slabs): this use gets a destination of its own, autograd adds the two
     if slot is not None:
         # a later use of the same weight in this pass: one more descriptor with the first use's destination, nothing returned to autograd
         _group_submit(weight, keep, wgrad_args, bias_args if slot[1] is not None else None, slot[0], slot[1])
