@@ -262,6 +262,26 @@ class FlatGradSync:
                 dst.append(v)
         return src, dst
 
+    def verify_live_agreement(self):
+        """Every rank must skip the SAME parameters (those that received no gradient in the last pass): live() filters by this rank's own set, and a captured
+        tail freezes it — ranks that disagreed would apply g / world on one side and nothing on the other, and the replicas would drift apart silently
+        (ADVICE r05).  An eager collective (MIN and MAX of a hash of the set): called once per capture by train.GraphedStep (after its warm-up pass) and
+        available to eager loops; raises on every rank when the ranks disagree.  A no-op on one rank."""
+        if not self.exchange or self.world == 1 or not dist.is_initialized():
+            return
+        h = 0
+        for i, p in enumerate(self.params):
+            if id(p) in self._no_grad or not p.requires_grad:
+                h = (h * 1000003 + i + 1) % 2147483647
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([h, -h], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        note_eager_collective()
+        lo, hi = int(t[0].item()), -int(t[1].item())
+        if lo != hi:
+            raise RuntimeError("data-parallel ranks disagree on which parameters received a gradient in this pass (rank-dependent control flow in the "
+                               "loss?): the update would differ per rank and the replicas diverge — make the pass identical on every rank")
+
     def gather(self, grads=None, tab=None, only=None):
         grads = [p.grad for p in self.params] if grads is None else grads
         src, dst = self._stragglers(grads, only)

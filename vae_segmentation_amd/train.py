@@ -315,6 +315,7 @@ class GraphedStep:
                 self.grad_sync, self._own_sync = None, False
             return
         s.resolve_avg()                          # does the collective library average?  asked once, eagerly: a capture cannot fall back
+        s.verify_live_agreement()                # the set of parameters the captured tail will skip is frozen now: it must be the same on every rank
         self.optimizer.prepare(*s.live(), scaler=self.scaler)
         ops.repack_trainable()                   # builds the descriptor table of the multi-tensor re-pack (same images, same weights: idempotent)
 
