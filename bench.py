@@ -345,6 +345,9 @@ def main():
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if a.share_gpu:
+        from vae_segmentation_amd import ops as _ops0
+        _ops0.device_is_shared(True)            # several ranks on one card: no in-kernel hand-offs (they need the device to themselves: ops.device_is_shared)
+    if a.share_gpu:
         local = 0
     torch.cuda.set_device(local)
     use_dist = world > 1 or a.force_dist

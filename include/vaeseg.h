@@ -226,6 +226,11 @@ int vs_conv_k3_bwd_data_applied(const void* x, const void* w_packed, void* y, co
  *   add (nullable; needs the last layer's apply): a second gradient of the last layer's raw tensor, summed in as vs_instnorm_relu_bwd_apply_add does.
  * sync: vs_conv_k3_chain_sync_bytes(n) ZEROED bytes, 128-byte aligned, private to this call; fault: a device word the kernel ORs 1 into when a bounded wait gave up
  *   (never in a correct launch: the library rejects chains whose workgroups cannot all be resident) — results are then invalid, the queue is not hung.
+ * CONCURRENCY: the workgroups of a sample wait for one another inside the launch, so all of them must be resident together.  The library guarantees that for a
+ *   launch that is not competing for CUs with ANOTHER launch of this kind (vs_conv_k3_chain, vs_conv_k3_bwd_data_applied): one process per GPU issuing its step on
+ *   one stream — the deployment model.  Two such launches running at the same time on one device (two processes sharing a GPU, two streams) can each hold part of
+ *   the chip and starve the other's waiters; the bounded waits then give up and raise `fault`.  A host that shares a device switches the two forms off first
+ *   (vs_set_config: chain = 0, epilogue_apply = 0; Python: ops.device_is_shared()).
  * Shapes: (d+2)(h+2)(w+2) <= 512 (up to 6^3), channels multiples of 32 (c_in) / 8 (m_out), at most 256 workgroups per sample (32 per XCD): vs_conv_k3_chain_supported(n, d, h, w,
  * largest channel count of the chain, dtype) says 1 / 0 (env VS_CHAIN=0: always 0).  All three storage types; results are bit-identical to the per-layer launches
  * in the deterministic build. */

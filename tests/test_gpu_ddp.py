@@ -34,6 +34,8 @@ import joint_model as M
 from oracle import ref_cpu as O
 from vae_segmentation_amd import ddp, optim, ops
 from vae_segmentation_amd import train as T
+if world > 1:
+    ops.device_is_shared(True)                  # the ranks of this test share ONE card: the in-kernel hand-offs need the device to themselves (ops.device_is_shared)
 
 SIDE, MB = 32, 2
 
@@ -166,6 +168,7 @@ import joint_model as M
 from oracle import ref_cpu as O
 from vae_segmentation_amd import ddp, optim, ops
 from vae_segmentation_amd import train as T
+ops.device_is_shared(True)                      # two ranks, one card (ops.device_is_shared)
 
 # ---- (1) collective_capturable: one rank cannot capture -> NO rank replays, every rank answers False ------------------------
 replayed = []

@@ -1153,6 +1153,18 @@ def chain_fault():
             raise _lib.VaesegError("a chain kernel on %s gave up a bounded wait (workgroups of one sample not co-resident): results invalid; set VS_CHAIN=0" % (dev,))
 
 
+def device_is_shared(shared=True):
+    """The in-kernel hand-offs (csrc/chain.h: chain kernels, epilogue apply) need every workgroup of a sample resident while its peers wait for it — true for a
+    launch that has the device to itself (one process per GPU, the step's one stream: the deployment model), NOT when another process or stream runs kernels of the
+    same kind on the same GPU at the same time: two launches that each hold part of the chip and wait for workgroups the other one keeps out never finish their
+    waits (the bounded spins give up and raise the fault word: wrong numbers, reported by chain_fault()).  A host that shares a GPU between ranks (the test-suite's
+    gloo ranks on one card, bench.py --share-gpu) calls this first: both forms are switched off in the library (vs_set_config) and here."""
+    global CHAIN, EPILOGUE_APPLY
+    on = 0 if shared else 1
+    set_config(chain=on, epilogue_apply=on)
+    CHAIN = EPILOGUE_APPLY = not shared
+
+
 def _chain_sync(n, device):
     cnt = lib.vs_conv_k3_chain_sync_bytes(n) // 8
     buf = _new_stats(1, cnt + 16, device, width=1).view(-1)
