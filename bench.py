@@ -181,6 +181,8 @@ def cpu_baseline(side, steps, budget_s=40.0, batch=BATCH, method="joint_train"):
     timed = sorted(times[1:]) if len(times) > 1 else times
     med = timed[len(timed) // 2]
     return {"value": batch / med, "unit": "volumes/s", "cores": cores, "kind": "port",
+            # the spread of the timed steps (the figure wobbles 0.76 - 1.2 volumes/s from box to box and run to run: host cores shared with other tenants)
+            "value_min": batch / timed[-1], "value_max": batch / timed[0], "seconds_per_step": [round(t, 3) for t in times[1:]],
             "sample": "1 warm-up + %d timed %s steps at %d^3 B=%d, eager PyTorch fp32 (oracle/ref_cpu.py), "
                       "median, %d threads" % (len(timed), method, side, batch, cores)}
 
