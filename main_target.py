@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Target-domain trainer — every flag of the reference's main_target.py:29-81 parses (same names, short options and defaults), native step.
 Flags that only drive outputs this entry point does not produce (figures, extra reference dumps: --save_more_reference, --save_eval_result,
---analysis_figure_name, --generate_bounding_boxes, -P) are accepted with a warning; the pseudo-labelled second loader (--pseudo_list with
---pseudo_data_root / --pseudo_pan_index, main_target.py:228-307,615-692) is not built and says so instead of training something else.  Methods (all native): vae_train, domain_adaptation (student/teacher Joint nets, binarised or confident pseudo-labels,
+--analysis_figure_name, --generate_bounding_boxes, -P) are accepted with a warning.  --pseudo_list (with --pseudo_data_root / --pseudo_pan_index, main_target.py:228-307) adds the second, pseudo-labelled
+loader and switches domain_adaptation to the step of main_target.py:615-692 (its own loss ladder, teacher re-loaded from the student, and a logged-only
+forward on one pseudo-labelled batch per iteration).  Methods (all native): vae_train, domain_adaptation (student/teacher Joint nets, binarised or confident pseudo-labels,
 domain_loss_type 0 / 8 / 9 / 11-16, --only_pseudo, --turn_epoch, --lambda_vae_warmup, optional KL term, optional EMA teacher, test-time
 training with --val_finetune), discriminator_train, domain_adaptation_dis.  Uses the
 utils/evaluation.py epsilon (1e-6), as main_target.py does (it imports avg_dsc from there, main_target.py:23)."""
@@ -29,7 +30,7 @@ def parse(argv=None):
     p.add_argument("--pseudo_data_root", default="../nih_data/numpy_data/")
     p.add_argument("-t", "--train_list", default="NIH_train")
     p.add_argument("-v", "--val_list", default="NIH_val")
-    p.add_argument("--pseudo_list", default=None, help="NOT built: the second, pseudo-labelled loader and its supervised step (main_target.py:615-692)")
+    p.add_argument("--pseudo_list", default=None, help="case list of the second, pseudo-labelled loader: domain_adaptation then runs the step of main_target.py:615-692")
     p.add_argument("--load_prefix", default=None)
     p.add_argument("--checkpoint_name", default="best_model.ckpt")
     p.add_argument("--load_prefix_vae", default=None)

@@ -33,6 +33,13 @@ def test_main_source_joint_train_then_main_target_domain_adaptation(tmp_path):
                 "--checkpoint_name", "model_epoch1.ckpt", "--domain_loss_type", "8", "--train_first_epoch", "--pseudo_save_epoch", "1",
                 "--update_every_iteration"] + common, str(tmp_path))
     assert "Finished Training" in out and "graph replay" in out
+    # --pseudo_list (main_target.py:615-692): its own loss ladder, teacher re-loaded from the student, one logged-only pseudo-labelled batch per iteration
+    for extra in (["--domain_loss_type", "8"], ["--lambda_vae", "2000"], ["--tag", "--no_graph"]):
+        out = _run([os.path.join(REPO, "main_target.py"), "tgt_ps", "-M", "domain_adaptation", "--load_prefix_joint", "src",
+                    "--checkpoint_name", "model_epoch1.ckpt", "--train_first_epoch", "--pseudo_save_epoch", "1", "--pseudo_list", "synthetic_pseudo"] + extra + common,
+                   str(tmp_path))
+        assert "Finished Training" in out and "dice_loss_pseudo" in out and "final_loss_pseudo" in out and "recon_loss_pseudo" in out
+        assert ("graph replay" in out) == ("--no_graph" not in extra)
     # epoch 0 of domain_adaptation only validates in the reference (main_target.py:506); dropout > 0 falls back to eager launches
     out = _run([os.path.join(REPO, "main_target.py"), "tgt_do", "-M", "domain_adaptation", "--load_prefix_joint", "src",
                 "--checkpoint_name", "model_epoch1.ckpt", "--seg_dropout", "0.1", "--train_first_epoch"] + common, str(tmp_path))

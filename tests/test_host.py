@@ -235,8 +235,10 @@ def test_main_target_parses_every_reference_flag_with_the_reference_defaults(cap
     assert "accepted and ignored" in capsys.readouterr().err                       # the dump / figure flags say what happens to them
     with pytest.raises(SystemExit, match="inconsistent flags"):                                            # main_target.py:145: more than one pass needs a forward scale
         main_target.parse(["r", "--vae_mont_number", "2"])
-    with pytest.raises(SystemExit, match="pseudo_list"):                           # not built: refuses instead of training something else
-        main_target.parse(["r", "--pseudo_list", "NIH_pseudo"])
+    a = main_target.parse(["r", "-M", "domain_adaptation", "--pseudo_list", "NIH_pseudo", "--pseudo_pan_index", "1"])     # main_target.py:228-307,615-692
+    assert a.pseudo_list == "NIH_pseudo"
+    with pytest.raises(SystemExit, match="pseudo_list"):                           # the reference's other methods never read the second loader (:689)
+        main_target.parse(["r", "-M", "domain_adaptation_dis", "--pseudo_list", "NIH_pseudo"])
 
 
 def test_synthetic_matches_the_oracle_generators():

@@ -145,6 +145,19 @@ def make_loaders(args, rank, world):
     return tl, vl, sampler
 
 
+def make_pseudo_loader(args, rank, world):
+    """main_target.py:228-258,299-307: the second, pseudo-labelled training loader of a --pseudo_list run — its own case list, data root and structure indices
+    (--pseudo_data_root, --pseudo_pan_index), the training transform stack, shuffled, drop_last."""
+    if getattr(args, "real_data", False):
+        import copy
+        pargs = copy.copy(args)
+        pargs.pan_index = args.pseudo_pan_index                # main_target.py:233: NumpyLoader_Multi_merge(mask_index=pseudo_mask_index)
+        return DeviceCaseLoader(filedict_from_json(os.path.join("lists", args.data_path), args.pseudo_list, args.eval_epoch), args.pseudo_data_root, pargs,
+                                args.batch_size, True, shuffle=True, rank=rank, world=world)
+    ds = SyntheticVolumes(args.synthetic_train, args.size, seed=3)
+    return torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=True, num_workers=0, pin_memory=True, drop_last=True)
+
+
 # ----------------------------------------------------------------------------------------------------
 # model / optimiser construction (main_source.py:245-294, 300-346; main_target.py:314-352, 395-433)
 # ----------------------------------------------------------------------------------------------------
@@ -363,6 +376,9 @@ def run(args, side="source"):
                                     use_confident_binarize=getattr(args, "use_confident_binarize", False), n_class=nc)
 
     train_loader, val_loader, sampler = make_loaders(args, rank, world)
+    pseudo_loader = make_pseudo_loader(args, rank, world) if (method == "domain_adaptation" and getattr(args, "pseudo_list", None) is not None) else None
+    pseudo_itr = None
+    pimg_buf = plab_buf = None
     lambda_vae = args.lambda_vae
     turn_epoch, warmup_epochs = getattr(args, "turn_epoch", -1), getattr(args, "lambda_vae_warmup", 0)
     has_dropout = bool(getattr(args, "seg_dropout", 0.0) or getattr(args, "vae_decoder_dropout", 0.0))
@@ -395,6 +411,12 @@ def run(args, side="source"):
             return T.domain_adaptation_dis_losses(model, teacher, img_buf, lab_buf, lambda_vae=lambda_vae, epoch=cur["epoch"],
                                                   lambda_vae_warmup=warmup_epochs,
                                                   use_confident_binarize=getattr(args, "use_confident_binarize", False), eps=eps, n_class=nc)
+        if pseudo_loader is not None:                                       # main_target.py:615-661: a --pseudo_list run has its own loss ladder
+            return T.domain_adaptation_pseudo_losses(model, teacher, img_buf, lab_buf, lambda_vae=lambda_vae,
+                                                     domain_loss_type=getattr(args, "domain_loss_type", 0),
+                                                     use_confident_binarize=getattr(args, "use_confident_binarize", False), eps=eps, n_class=nc,
+                                                     host_schedule=not use_graph)
+
         def da():
             return T.domain_adaptation_losses(model, teacher, img_buf, lab_buf, lambda_vae=lambda_vae,
                                               domain_loss_type=getattr(args, "domain_loss_type", 0), kl=getattr(args, "kl", False),
@@ -455,7 +477,16 @@ def run(args, side="source"):
                 lab_buf.copy_(batch[LABEL_KEY], non_blocking=True)
                 if method == "discriminator_train":          # synthetic stand-in for the venous_score field: a function of the mask
                     score_buf.copy_(batch[LABEL_KEY].float().mean((1, 2, 3, 4)).view(-1, 1) * 4, non_blocking=True)
-                if method == "domain_adaptation" and getattr(args, "pseudo_save_epoch", 0):
+                teacher_next = None
+                if pseudo_loader is not None and getattr(args, "pseudo_save_epoch", 0) and epoch % args.pseudo_save_epoch == 0:
+                    # main_target.py:633-635 (--pseudo_list runs): the pseudo-label network is re-loaded from the student AFTER this iteration's two forwards and
+                    # BEFORE its optimizer step, i.e. the next iteration's pseudo-labels come from the weights this one started with: keep them, load after the step
+                    with torch.no_grad():
+                        teacher_next = {k: v.clone() for k, v in model.state_dict().items()}
+                    if getattr(args, "tag", False):                                  # :635 — ahead of this iteration's loss
+                        lambda_vae /= 10
+                        stepper_key = None
+                elif pseudo_loader is None and method == "domain_adaptation" and getattr(args, "pseudo_save_epoch", 0):
                     # EMA teacher (main_target.py:508-518): every `pseudo_save_epoch` epochs, at the first iteration of an epoch slice or
                     # every iteration; never in epoch 0
                     every = max(1, args.pseudo_save_epoch // args.eval_epoch)
@@ -493,6 +524,23 @@ def run(args, side="source"):
                         optimizer.step_with(*sync.live(), **skw)
                     else:
                         optimizer.step(**skw)
+                if teacher_next is not None:
+                    with torch.no_grad():
+                        teacher.load_state_dict(teacher_next)                        # in place: a captured graph replays the same storage
+                    ops.clear_pack_cache()
+                    ops.refresh_frozen_packs(teacher)
+                if pseudo_loader is not None:
+                    # main_target.py:663-687: the next batch of the pseudo-labelled loader (cycled), student forward, two Dice terms — logged, never stepped on
+                    pb = next(pseudo_itr, None) if pseudo_itr is not None else None
+                    if pb is None:
+                        pseudo_itr = iter(pseudo_loader)
+                        pb = next(pseudo_itr)
+                    if pimg_buf is None:
+                        pimg_buf, plab_buf = torch.zeros_like(img_buf), torch.zeros_like(lab_buf)
+                    pimg_buf.copy_(pb[IMG_KEY], non_blocking=True)
+                    plab_buf.copy_(pb[LABEL_KEY], non_blocking=True)
+                    aux = dict(aux)
+                    aux.update(T.pseudo_batch_losses(model, pimg_buf, plab_buf, eps=eps, n_class=nc))
                 seen += bs
                 if rank == 0 and idx % args.display_freq == 0:              # logging syncs the host every display_freq steps only
                     parts = ", ".join("%s %.4f" % (k, v.item()) for k, v in aux.items() if k != "batch")
@@ -547,8 +595,8 @@ def check_target_flags(a):
     if a.generate_bounding_boxes:
         need(a.method == "domain_adaptation", "--generate_bounding_boxes belongs to --method domain_adaptation")                        # :170
     if a.pseudo_list is not None:
-        raise SystemExit("--pseudo_list: the second (pseudo-labelled) loader and its supervised step (main_target.py:228-307,615-692) are not built "
-                         "in the native entry point; train without it or extend driver.run")
+        need(a.method == "domain_adaptation", "--pseudo_list is read by --method domain_adaptation only (main_target.py:615; domain_adaptation_dis runs "
+                                              "without it, :689)")
     ignored = [n for n in ("save_more_reference", "save_eval_result", "analysis_figure_name", "generate_bounding_boxes", "resume") if getattr(a, n)]
     if ignored:
         print("main_target.py: accepted and ignored (they drive figure / volume dumps the native entry point does not write): %s"

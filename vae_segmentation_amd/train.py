@@ -125,6 +125,43 @@ def domain_adaptation_losses(student, teacher, img, label, lambda_vae=1.0, domai
                    "batch": batch}
 
 
+def domain_adaptation_pseudo_losses(student, teacher, img, label, lambda_vae=1.0, domain_loss_type=0, use_confident_binarize=False,
+                                    eps=EPS_EVALUATION, n_class=2, host_schedule=True):
+    """main_target.py:615-661 — the domain-adaptation step of a run started with --pseudo_list (a second, pseudo-labelled loader exists): the same two
+    forwards and three Dice terms as domain_adaptation_losses, but its own, shorter ladder of final losses: domain_loss_type 8 (:636-647), lambda_vae >= 1000
+    (recon * lambda / 10000, :648-649), else lambda * recon + fake (:650-651); no KL term, no turn_epoch / warm-up branches."""
+    batch = {"img": img, "gt": ops.onehot(label, n_class)}
+    batch = student(batch, "img", "pred", "recon", dropout=True)
+    with torch.no_grad():
+        batch = teacher(batch, "img", "fake", "_unused")
+    batch["fake"] = confident_binarize(batch["fake"]) if use_confident_binarize else binarize(batch["fake"])
+    recon_loss = 1 - avg_dsc(batch, "pred", "recon", botindex=1, topindex=n_class, eps=eps)
+    dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=eps)
+    fake_loss = 1 - avg_dsc(batch, "pred", "fake", botindex=1, topindex=n_class, eps=eps)
+    if domain_loss_type == 8 and not host_schedule:
+        final = finetune_loss(recon_loss, fake_loss, None, lambda_vae, 8, False, False)
+    elif domain_loss_type == 8:
+        cur = lambda_schedule(recon_loss.detach(), lambda_vae)
+        final = recon_loss + 1 / cur * fake_loss if cur > 1 else cur * recon_loss + fake_loss
+    elif lambda_vae >= 1000:
+        final = recon_loss * lambda_vae / 10000
+    else:
+        final = lambda_vae * recon_loss + fake_loss
+    return final, {"recon_loss": recon_loss, "dice_loss_fake": fake_loss, "dice_loss": dsc_loss, "batch": batch}
+
+
+@torch.no_grad()
+def pseudo_batch_losses(student, img, label, eps=EPS_EVALUATION, n_class=2):
+    """main_target.py:667-687 — the batch of the pseudo-labelled loader that follows every such step: one student forward (dropout on, as in the reference) and
+    the two Dice terms against its own reconstruction and the pseudo label.  The reference computes `final_loss = dsc_loss` here and then only LOGS it — there
+    is no backward / optimizer.step() behind it (:681-687) — so this is a forward-only evaluation (no autograd graph is recorded)."""
+    batch = {"img": img, "gt": ops.onehot(label, n_class)}
+    batch = student(batch, "img", "pred", "recon", dropout=True)
+    recon_loss = 1 - avg_dsc(batch, "pred", "recon", botindex=1, topindex=n_class, eps=eps)
+    dsc_loss = 1 - avg_dsc(batch, "pred", "gt", botindex=1, topindex=n_class, eps=eps)
+    return {"recon_loss_pseudo": recon_loss, "dice_loss_pseudo": dsc_loss, "final_loss_pseudo": dsc_loss}
+
+
 # ----------------------------------------------------------------------------------------------------
 # remaining train methods of the reference (SURVEY.md §8f rank 4): loss bodies on the native modules
 # ----------------------------------------------------------------------------------------------------
