@@ -194,8 +194,9 @@ typedef struct vs_config {
     int wgrad_mpack;           /* VS_WGRAD_MPACK 1: M-packed rows for layers with 8 stored output channels */
     int wgrad_swap;            /* VS_WGRAD_SWAP 1: operand exchange for lazy-input 3x3x3 layers */
     int wgrad_big;             /* VS_WGRAD_BIG 1: 8x8x16 tiles for the full-resolution layers */
-    int wgrad_xcd;             /* VS_WGRAD_XCD 1: a layer's k-splits dealt per XCD */
+    int wgrad_xcd;             /* VS_WGRAD_XCD 2: a layer's workgroups re-ranked so that one XCD walks neighbouring tiles and holds all channel-block pairs of a tile (1: single-pair layers only; 0: plain order) */
     int k3_short_tiles;        /* VS_K3_SHORT_TILES 2: 4x2x16 tiles for the 32-channel 3x3x3 launches of at most 128 workgroups (the 12^3-class levels), 4x1x16 where that still leaves at most 128 (2); 1: 4x2x16 only; 0: off */
+    int wgrad_bias_fold;       /* VS_WGRAD_BIAS_FOLD 1: a ConvTranspose3d's bias gradient is summed by its weight-gradient workgroups (the same tensor is their Q operand) */
     long long wgrad_wgs;            /* VS_WGRAD_WGS 512: workgroups per ungrouped weight-gradient launch */
     long long wgrad_f32_tiles;      /* VS_WGRAD_F32_TILES 8 */
     long long wgrad_group_wgs;      /* VS_WGRAD_GROUP_WGS 0: workgroups per bucket of a grouped pass (0 = chosen per pass) */

@@ -492,9 +492,9 @@ def _group_layers_backward(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("mpack,uber,swap,big", [("1", "1", "1", "0"), ("0", "1", "1", "0"), ("1", "0", "1", "0"), ("1", "1", "0", "0"),
-                                                 ("1", "1", "1", "1"), ("1", "1", "0", "1"), ("0", "1", "1", "1")])
-def test_grouped_weight_gradients_many_layers(dtype, mpack, uber, swap, big, monkeypatch):
+@pytest.mark.parametrize("mpack,uber,swap,big,fold", [("1", "1", "1", "0", "1"), ("0", "1", "1", "0", "1"), ("1", "0", "1", "0", "1"), ("1", "1", "0", "0", "1"),
+                                                      ("1", "1", "1", "1", "1"), ("1", "1", "0", "1", "1"), ("0", "1", "1", "1", "1"), ("1", "1", "1", "0", "0")])
+def test_grouped_weight_gradients_many_layers(dtype, mpack, uber, swap, big, fold, monkeypatch):
     """vs_conv_wgrad_multi (main_source.py:660: the gradients the optimiser step reads): 34 layers of all conv kinds deferred to the end of ONE
     backward pass and issued as grouped launches — each against F.conv3d / F.conv_transpose3d autograd on the CPU, against the
     per-layer launches (vs_conv_wgrad), and bitwise reproducible.  mpack: the M-packed form of the layers with 8 stored output channels
@@ -503,7 +503,9 @@ def test_grouped_weight_gradients_many_layers(dtype, mpack, uber, swap, big, mon
     # uber 1: every bucket in one grid (g3b_uber_kernel, the default); 0: one grid per bucket.  swap 1 (default): operands of the lazy-input 3x3x3 layers exchanged
     # (csrc/wgrad.hip multi_plan); 0: as submitted.  big: the 8 x 8 x 16-tile kernel (g3c_body) takes every layer it supports — by default only tensors of
     # >= 400 k voxels (none of this list) get it.  Switched through the library's one configuration entry point (vs_set_config), restored afterwards.
-    with ops.config(wgrad_mpack=int(mpack), wgrad_uber=int(uber), wgrad_swap=int(swap), wgrad_big_min_voxels=1 if big == "1" else 1000000000):
+    # fold 1 (default): a transposed conv's bias gradient is summed by its own weight-gradient workgroups (their Q operand is that tensor); 0: a pass of its own.
+    with ops.config(wgrad_mpack=int(mpack), wgrad_uber=int(uber), wgrad_swap=int(swap), wgrad_big_min_voxels=1 if big == "1" else 1000000000,
+                    wgrad_bias_fold=int(fold), wgrad_xcd=2 if fold == "1" else 1):
         assert ops._GROUP["enabled"]
         got, refs = _group_layers_backward(ops, dtype)
         tol = TOL[dtype] * 4
@@ -525,6 +527,43 @@ def test_grouped_weight_gradients_many_layers(dtype, mpack, uber, swap, big, mon
             assert relerr(gw, sw) < 2e-6, case
             if gb is not None:
                 assert relerr(gb, sb) < 1e-5, case
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_transposed_conv_bias_gradient_folded_into_its_weight_gradient(dtype):
+    """wgrad.hip g3b_body, stride-2 kind (round 6): db of nn.ConvTranspose3d (joint_model.py:118) = the per-channel sum of the fine gradient its weight-gradient
+    workgroups stage as Q — summed there.  With FEW workgroups per layer (wgrad_group_wgs) every workgroup walks several tiles, ragged ones included; against the
+    CPU autograd and against the separate pass (wgrad_bias_fold=0)."""
+    ops = _ops()
+    res = {}
+    for fold in (1, 0):
+        with ops.config(wgrad_bias_fold=fold, wgrad_group_wgs=6):
+            outs, refs = [], []
+            total = None
+            for i, (n, c, d, h, w) in enumerate([(2, 16, 9, 7, 19), (1, 32, 6, 10, 17), (2, 8, 5, 9, 33), (2, 64, 3, 4, 5)]):
+                x = rnd(n, c, d, h, w, seed=200 + i)
+                a = in_relu(q(x, dtype))
+                x_cl = to_cl(x, ops.cpad(c), dtype)
+                xs = ops.instnorm_stats(x_cl)
+                wt = q(rnd(c, c, 2, 2, 2, seed=210 + i, scale=(3.0 / (8 * c)) ** 0.5), dtype).requires_grad_(True)
+                bt = rnd(c, seed=220 + i).requires_grad_(True)
+                y_ref = F.conv_transpose3d(a, wt, bt, stride=2)
+                gy = rnd(*y_ref.shape, seed=230 + i)
+                (y_ref * q(gy, dtype)).sum().backward()
+                refs.append((wt.grad.clone(), bt.grad.clone()))
+                w_gpu, b_gpu = wt.detach().cuda().requires_grad_(True), bt.detach().cuda().requires_grad_(True)
+                y = ops.ConvT2S2.apply(x_cl, xs, w_gpu, b_gpu)
+                term = (y.float() * to_cl(gy, ops.cpad(c), dtype).float()).sum()
+                total = term if total is None else total + term
+                outs.append((w_gpu, b_gpu))
+            total.backward()
+            torch.cuda.synchronize()
+            res[fold] = [(wg.grad.clone(), bg.grad.clone()) for wg, bg in outs]
+            for (gw, gb), (rw, rb) in zip(res[fold], refs):
+                assert relerr(gw.cpu(), rw) < TOL[dtype] * 4 and relerr(gb.cpu(), rb) < TOL[dtype] * 4, (fold, relerr(gb.cpu(), rb))
+    for (fw, fb), (sw, sb) in zip(res[1], res[0]):
+        assert torch.equal(fw, sw)                               # the weight gradient itself is untouched by the fold
+        assert relerr(fb, sb) < 1e-5
 
 
 def test_dice_loss_sum_label_target_equals_materialised_one_hot():

@@ -36,8 +36,9 @@ extern "C" int vs_config_from_env(vs_config* c) {
     c->wgrad_mpack = env_int("VS_WGRAD_MPACK", 1);
     c->wgrad_swap = env_int("VS_WGRAD_SWAP", 1);
     c->wgrad_big = env_int("VS_WGRAD_BIG", 1);
-    c->wgrad_xcd = env_int("VS_WGRAD_XCD", 1);
+    c->wgrad_xcd = env_int("VS_WGRAD_XCD", 2);
     c->k3_short_tiles = env_int("VS_K3_SHORT_TILES", 2);
+    c->wgrad_bias_fold = env_int("VS_WGRAD_BIAS_FOLD", 1);
     c->wgrad_wgs = env_ll("VS_WGRAD_WGS", 512);
     c->wgrad_f32_tiles = env_ll("VS_WGRAD_F32_TILES", 8);
     c->wgrad_group_wgs = env_ll("VS_WGRAD_GROUP_WGS", 0);

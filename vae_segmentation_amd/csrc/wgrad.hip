@@ -361,6 +361,11 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
     }
     u32x4 pv[2], qv[NITQ];
     unsigned int okbits = 0;                     // bit b: P fragment b inside the volume; bit 2 + b: Q fragment b
+    // Stride-2 kind, round 6: the bias gradient of a ConvTranspose3d is the per-channel sum of the very tensor this kernel stages as Q (its fine output gradient);
+    // the m-block-0 workgroups add their Q fragments up on the way to LDS instead of a second pass re-reading the tensor (56.6 MB at 96^3, p.up_co = where the
+    // partial sums go, in doubles behind p.ws; 0 = not asked for).  Out-of-volume fragments arrive as zeros from the bounds-checked loads.
+    const bool qfold = KIND == G3_K2S2 && p.up_co != 0 && mb == 0;
+    float qsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto request = [&](int t) {
         int n, z0, y0, x0;
         g3_tile_coords(p, t, n, z0, y0, x0);
@@ -413,6 +418,14 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
 #pragma unroll
         for (int b = 0; b < NITQ; ++b) {
             u32x4 v = qv[b];
+            if constexpr (KIND == G3_K2S2) {
+                if (qfold) {
+                    float f[8];
+                    frag_unpack(v, f, (T*)nullptr);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) qsum[j] += f[j];
+                }
+            }
             if (q_stats) {
                 const u32x4 a = act8<T>(v, sc, sh);
                 const bool ok = (okbits >> (2 + b)) & 1u;
@@ -548,6 +561,20 @@ __device__ __forceinline__ void g3b_body(const G3Params& p, const int bx, const 
 
     const size_t slab_elems = (size_t)p.mbn * p.cbn * nk * 256;
     g3_finish<NCB>(acc, (float*)s_p, p.ws + (size_t)ks * slab_elems + ((size_t)bx * nk) * 256, wave, col, g, nk);
+    if constexpr (KIND == G3_K2S2) {
+        if (qfold) {                             // uniform per workgroup: partial sums [k-split][Cch] in double, summed by g3_reduce_group_kernel like bias_partial_body's
+            float* s_red = (float*)s_q;          // every wave left the tile loop before g3_finish's barriers
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_red[tid * 8 + j] = qsum[j];
+            __syncthreads();
+            if (tid < CB && cb * CB + tid < p.Cch) {
+                const int part = tid >> 3, j = tid & 7;
+                double tot = 0.0;
+                for (int y = 0; y < 256 / QU; ++y) tot += (double)s_red[(y * QU + part) * 8 + j];
+                ((double*)p.ws + (size_t)p.up_co)[(size_t)ks * p.Cch + cb * CB + tid] = tot;
+            }
+        }
+    }
 }
 
 template <int CB, int KIND, typename T = unsigned short>
@@ -931,11 +958,27 @@ struct G3Group {
     G3Params p[G3_GROUP_MAX];
     int wg_start[G3_GROUP_MAX + 1];
     int n;
-    int xcd;          // the k-splits of a single-block-pair layer are dealt so that the workgroups of one XCD walk neighbouring tiles (their Q halos then meet in that
-                      // XCD's L2: 8-channel bucket 572 -> 343 MB per launch, step time unchanged); VS_WGRAD_XCD=0 restores the plain order
+    int xcd;          // g3_xcd_rank below: 0 = plain order, 1 = single-block-pair layers only (rounds 3-5), 2 = every layer (default since round 6); VS_WGRAD_XCD
 };
 
 static_assert(sizeof(G3Group) <= 4096, "G3Group travels as the kernel argument");
+
+// The hardware deals consecutive workgroup ids to the 8 XCDs in turn.  A layer's workgroups [b0, b0 + count) are re-ranked so that XCD x owns ONE contiguous run of
+// ranks; rank -> (k-split = rank / pairs, block pair = rank % pairs).  The k-splits of a run walk neighbouring tiles (their Q halos meet in that XCD's L2) and, round 6,
+// the block pairs of one k-split — mbn x cbn workgroups that stage the SAME P / Q tiles for different channel blocks — sit on one XCD too instead of on mbn * cbn
+// different ones (each with an L2 of its own: a 64 -> 32 layer at 24^3 fetched its tensors 7.7 x, profiles/r06_wgrad_layer_traffic.txt).
+__device__ __forceinline__ int g3_xcd_rank(int b0, int local, int count, bool on) {
+    if (!on) return local;
+    const int x = (b0 + local) & 7;
+    int start = 0;
+#pragma unroll
+    for (int xx = 0; xx < 8; ++xx) {
+        const int first = (xx - b0) & 7;                                        // smallest local index on XCD xx
+        const int cnt = first < count ? (count - first + 7) >> 3 : 0;
+        start += xx < x ? cnt : 0;
+    }
+    return start + ((local - ((x - b0) & 7)) >> 3);
+}
 
 template <int CB, int KIND, typename T = unsigned short, bool MP = false>
 // (3 waves per SIMD for the 8-channel bucket — the compiler gets there without AGPRs — changed nothing: 2.814 vs 2.810 ms per step)
@@ -947,19 +990,9 @@ __global__ __launch_bounds__(256) void g3b_group_kernel(const G3Group grp) {
     const G3Params p = grp.p[l];
     const int local = b - grp.wg_start[l];
     const int pairs = p.mbn * p.cbn;
-    int ks = local / pairs;
-    if (grp.xcd && pairs == 1 && p.ksplit >= 16) {          // hardware deals consecutive workgroup ids to the 8 XCDs in turn: XCD x gets one contiguous run of k-splits
-        const int b0 = grp.wg_start[l], x = b & 7;
-        int start = 0;
-#pragma unroll
-        for (int xx = 0; xx < 8; ++xx) {
-            const int first = (xx - b0) & 7;                                        // smallest local index on XCD xx
-            const int cnt = first < p.ksplit ? (p.ksplit - first + 7) >> 3 : 0;
-            start += xx < x ? cnt : 0;
-        }
-        ks = start + ((local - ((x - b0) & 7)) >> 3);
-    }
-    g3b_body<T, CB, KIND, MP>(p, local - (local / pairs) * pairs, ks);
+    const int rank = (grp.xcd && p.ksplit * pairs >= 16) ? g3_xcd_rank(grp.wg_start[l], local, p.ksplit * pairs, grp.xcd > 1 || pairs == 1) : local;
+    const int ks = rank / pairs;
+    g3b_body<T, CB, KIND, MP>(p, rank - ks * pairs, ks);
 }
 
 // the same grouping for the limb kernel of the fp32 parity mode (3x3x3 layers): one grid per channel-block width
@@ -1403,19 +1436,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const G3Params p = grp.p[l];
     const int local = b - grp.wg_start[l];
     const int pairs = p.mbn * p.cbn;
-    int ks = local / pairs;
-    if (grp.xcd && pairs == 1 && p.ksplit >= 16) {          // as g3b_group_kernel: XCD x walks one contiguous run of k-splits
-        const int b0 = grp.wg_start[l], x = b & 7;
-        int start = 0;
-#pragma unroll
-        for (int xx = 0; xx < 8; ++xx) {
-            const int first = (xx - b0) & 7;
-            const int cnt = first < p.ksplit ? (p.ksplit - first + 7) >> 3 : 0;
-            start += xx < x ? cnt : 0;
-        }
-        ks = start + ((local - ((x - b0) & 7)) >> 3);
-    }
-    const int bx = local - (local / pairs) * pairs;
+    const int rank = (grp.xcd && p.variant != G3V_BIAS && p.ksplit * pairs >= 16) ? g3_xcd_rank(grp.wg_start[l], local, p.ksplit * pairs, grp.xcd > 1 || pairs == 1) : local;
+    const int ks = rank / pairs;
+    const int bx = rank - ks * pairs;
     if (p.variant == G3V_BIAS) {
         extern __shared__ __attribute__((aligned(16))) char smem_b[];
         const G3BiasDesc d{p.P, (double*)p.ws, (long long)p.total_tiles, p.Mch, p.Cch, p.ksplit, 0};
@@ -1446,6 +1469,7 @@ struct MultiLayer {
                              // all uses write slabs into one contiguous region and ONE reduction sums them); == own index otherwise
     int total_slabs;         // primary only: slabs of all its parts
     int bias_primary, bias_total_blk;
+    int bias_fold;           // the bias partial sums come out of this layer's own launch (g3b_body, stride-2 kind: bias_g IS its Q operand) — no G3V_BIAS entry
     float* dw;
     size_t ws_off;           // byte offset of this layer's slabs
     long long work;          // tiles per workgroup (sort key)
@@ -1501,6 +1525,7 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
     // zero from the bounds-checked load — and normalise Q once per voxel.  The reduction writes the transposed, tap-mirrored slabs back (G3RedDesc.swap).
     // Taken when it does not widen the halo operand (m_ch <= c_ch); VS_WGRAD_SWAP=0 switches it off.
     const bool swap_on = pack_m && vs_cfg().wgrad_swap != 0;        // read per plan: the tests and the A/B runs switch it between calls (vs_set_config)
+    const bool fold_on = pack_m && vs_cfg().wgrad_uber != 0 && vs_cfg().wgrad_bias_fold != 0;
     std::vector<vs_wgrad_desc> eff(descs, descs + count);
     for (int i = 0; i < count; ++i) {
         int rc = multi_validate(descs[i]);
@@ -1583,10 +1608,17 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
         L.total_slabs = 0; L.bias_total_blk = 0;
         const vs_wgrad_desc& d = descs[i];
         L.bias_nblk = 0; L.bias_off = 0;
+        L.bias_fold = 0;
         if (d.bias_g) {
             const int rpi = 256 / (d.bias_c_ch / 8);
             long long nb = (d.bias_rows + (long long)rpi * 32 - 1) / ((long long)rpi * 32);
             L.bias_nblk = (int)std::min<long long>(std::max<long long>(nb, 1), target_wgs > 0 ? std::max(8, target_wgs / 2) : 256);     // <= 2 rounds of the reduce's 16 x 8 loads
+            // ConvTranspose3d's bias: the gradient rows are the fine tensor the stride-2 kernel stages as Q — summed there (all-buckets grid, 16-bit storage)
+            if (fold_on && d.kind == VS_CONV_K2S2 && d.bias_g == d.q && d.bias_c_ch == d.c_ch && d.bias_c_real == d.c_ch &&
+                d.bias_rows == (long long)d.n * p.Dq * p.Hq * p.Wq) {
+                L.bias_fold = 1;
+                L.bias_nblk = p.ksplit;
+            }
         }
     }
     for (int i = 0; i < count; ++i) {                      // slab regions: the parts of one gradient lie back to back
@@ -1607,6 +1639,11 @@ static int multi_plan(const vs_wgrad_desc* descs, int count, float eps, MultiPla
             L.bias_off = off;
             off += (size_t)L.bias_nblk * descs[j].bias_c_real * sizeof(double);
             plan.layers[i].bias_total_blk += L.bias_nblk;
+            if (L.bias_fold) {
+                const size_t rel = (L.bias_off - L.ws_off) / sizeof(double);          // bias regions lie behind every slab region; both are multiples of 8 bytes
+                if ((L.bias_off - L.ws_off) % sizeof(double) || rel == 0 || rel >= 2147483647ull) return VS_ESHAPE;
+                L.p.up_co = (int)rel;
+            }
         }
         off = (off + 255) / 256 * 256;
     }
@@ -2056,7 +2093,7 @@ static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspa
         auto key = [&](int a) { const MultiLayer& L = plan.layers[a]; return (double)L.work * g3v_tile_cost(g3v_of(L.cbsz, L.kind, L.p.mp != 0, L.big)); };
         std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return key(a) > key(b); });
         for (int i = 0; i < count; ++i)                      // the bias gradients' partial sums: entries -(i + 1), behind the weight layers (short workgroups)
-            if (descs[i].bias_g && descs[i].bias_rows < 2147483647ll) idx.push_back(-(i + 1));
+            if (descs[i].bias_g && descs[i].bias_rows < 2147483647ll && !plan.layers[i].bias_fold) idx.push_back(-(i + 1));
         for (size_t at = 0; at < idx.size(); at += G3_GROUP_MAX) {
             G3Group grp{};
             const int xcd_walk = vs_cfg().wgrad_xcd;
@@ -2134,7 +2171,7 @@ static int wgrad_multi_impl(const vs_wgrad_desc* descs, int count, void* workspa
     // ---- bias partials (in the all-buckets grid above when it is on) ----
     {
         std::vector<int> idx;
-        for (int i = 0; i < count; ++i) if (descs[i].bias_g && (!uber || descs[i].bias_rows >= 2147483647ll)) idx.push_back(i);
+        for (int i = 0; i < count; ++i) if (descs[i].bias_g && !plan.layers[i].bias_fold && (!uber || descs[i].bias_rows >= 2147483647ll)) idx.push_back(i);
         for (size_t at = 0; at < idx.size(); at += G3_BIAS_MAX) {
             G3BiasGroup grp{};
             grp.n = (int)std::min<size_t>(G3_BIAS_MAX, idx.size() - at);

@@ -67,7 +67,7 @@ class VsConfig(_ctypes.Structure):
     """vs_config (include/vaeseg.h): the library's tuning switches"""
     _fields_ = [(n, _ctypes.c_int) for n in ("k3_small", "k3_tall", "k3_wgs_per_cu", "k3t_wgs_per_cu", "k3f_min_wgs", "mt_min_wgs", "f32_limbs", "g1_limbs", "k3x_ck",
                                             "k3x_toeplitz", "fuse_wgrad", "epilogue_apply", "chain", "k2s2_stream", "k2s8_wgs_per_cu", "up_wgs_per_cu", "up_rb",
-                                            "wgrad_uber", "wgrad_mpack", "wgrad_swap", "wgrad_big", "wgrad_xcd", "k3_short_tiles")] + \
+                                            "wgrad_uber", "wgrad_mpack", "wgrad_swap", "wgrad_big", "wgrad_xcd", "k3_short_tiles", "wgrad_bias_fold")] + \
                [(n, _ctypes.c_longlong) for n in ("wgrad_wgs", "wgrad_f32_tiles", "wgrad_group_wgs", "wgrad_big_min_voxels")]
 
 
