@@ -1005,7 +1005,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CB == 8 
     const G3Params p = grp.p[l];
     const int local = b - grp.wg_start[l];
     const int pairs = p.mbn * p.cbn;
-    g3x_body<CB>(p, local - (local / pairs) * pairs, local / pairs);
+    const int rank = (grp.xcd > 1 && p.ksplit * pairs >= 16) ? g3_xcd_rank(grp.wg_start[l], local, p.ksplit * pairs, true) : local;
+    g3x_body<CB>(p, rank - (rank / pairs) * pairs, rank / pairs);
 }
 
 // Sum the partial slabs (fixed order, fp64) into the reference's [m][c][tap] layout.  A block = 64 consecutive slab
@@ -1020,8 +1021,9 @@ __global__ __launch_bounds__(256) void g3_group_kernel(const G3Group grp) {
     const G3Params p = grp.p[l];
     const int local = b - grp.wg_start[l];
     const int pairs = p.mbn * p.cbn;
-    const int ks = local / pairs;
-    g3_body<float, CB, KIND>(p, local - ks * pairs, ks);
+    const int rank = (grp.xcd > 1 && p.ksplit * pairs >= 16) ? g3_xcd_rank(grp.wg_start[l], local, p.ksplit * pairs, true) : local;
+    const int ks = rank / pairs;
+    g3_body<float, CB, KIND>(p, rank - ks * pairs, ks);
 }
 
 template <int CB, int KIND>
@@ -1793,7 +1795,7 @@ static int f32_limb_group_launch(const std::vector<vs_wgrad_desc>& sub, int cb, 
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return plan.layers[a].work > plan.layers[b].work; });
     for (size_t at = 0; at < idx.size(); at += G3_GROUP_MAX) {
         G3Group grp{};
-        grp.xcd = 0;
+        grp.xcd = vs_cfg().wgrad_xcd;                    // >= 2: g3_xcd_rank (the channel-block pairs of a tile on one XCD)
         grp.n = (int)std::min<size_t>(G3_GROUP_MAX, idx.size() - at);
         long long wg = 0;
         for (int j = 0; j < grp.n; ++j) {
