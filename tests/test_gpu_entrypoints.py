@@ -84,3 +84,9 @@ def test_real_data_cases_through_the_device_pipeline(tmp_path):
     assert "Finished Training" in out and "graph replay" in out and "validation result" in out
     assert out.count("loss:") >= 6                                   # 3 cases x 2 epochs
     assert json.load(open(tmp_path / "tensorboard" / "real" / "score_0.json"))
+    # main_target.py:228-307: the second, pseudo-labelled case list of a --pseudo_list run through the same device pipeline (its own root and structure index)
+    json.dump({"NIH_train": names[:3], "NIH_val": names[3:], "NIH_pseudo": names[1:3]}, open(tmp_path / "lists" / "Multi_all.json", "w"))
+    out = _run([os.path.join(REPO, "main_target.py"), "realda", "-M", "domain_adaptation", "--real_data", "-R", str(tmp_path / "data"), "-V", str(tmp_path / "data"),
+                "--pseudo_list", "NIH_pseudo", "--pseudo_data_root", str(tmp_path / "data"), "--pseudo_pan_index", "1", "--train_first_epoch",
+                "--size", "64", "-b", "1", "-E", "1", "--eval_epoch", "1", "--save_epoch", "1", "--display_freq", "1"], str(tmp_path))
+    assert "Finished Training" in out and out.count("dice_loss_pseudo") >= 3      # 3 training cases, the 2 pseudo cases cycled

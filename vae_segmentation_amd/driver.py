@@ -153,7 +153,7 @@ def make_pseudo_loader(args, rank, world):
         pargs = copy.copy(args)
         pargs.pan_index = args.pseudo_pan_index                # main_target.py:233: NumpyLoader_Multi_merge(mask_index=pseudo_mask_index)
         return DeviceCaseLoader(filedict_from_json(os.path.join("lists", args.data_path), args.pseudo_list, args.eval_epoch), args.pseudo_data_root, pargs,
-                                args.batch_size, True, shuffle=True, rank=rank, world=world)
+                                args.batch_size, True, shuffle=True, rank=rank, world=world, seed=7)
     ds = SyntheticVolumes(args.synthetic_train, args.size, seed=3)
     return torch.utils.data.DataLoader(ds, batch_size=args.batch_size, shuffle=True, num_workers=0, pin_memory=True, drop_last=True)
 
@@ -377,7 +377,7 @@ def run(args, side="source"):
 
     train_loader, val_loader, sampler = make_loaders(args, rank, world)
     pseudo_loader = make_pseudo_loader(args, rank, world) if (method == "domain_adaptation" and getattr(args, "pseudo_list", None) is not None) else None
-    pseudo_itr = None
+    pseudo_itr, pseudo_cycles = None, 0
     pimg_buf = plab_buf = None
     lambda_vae = args.lambda_vae
     turn_epoch, warmup_epochs = getattr(args, "turn_epoch", -1), getattr(args, "lambda_vae_warmup", 0)
@@ -533,6 +533,9 @@ def run(args, side="source"):
                     # main_target.py:663-687: the next batch of the pseudo-labelled loader (cycled), student forward, two Dice terms — logged, never stepped on
                     pb = next(pseudo_itr, None) if pseudo_itr is not None else None
                     if pb is None:
+                        pseudo_cycles += 1
+                        if hasattr(pseudo_loader, "set_epoch"):
+                            pseudo_loader.set_epoch(pseudo_cycles)                  # a DataLoader(shuffle=True) draws a new order per pass (main_target.py:299-307)
                         pseudo_itr = iter(pseudo_loader)
                         pb = next(pseudo_itr)
                     if pimg_buf is None:
