@@ -282,9 +282,12 @@ def test_pack_unpack_planar_roundtrip():
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_linear_layers(dtype):
+@pytest.mark.parametrize("c,s", [(256, 3), (32, 4), (128, 6)])
+def test_linear_layers(dtype, c, s):
+    """(256, 3): one k per lane (27 voxels per channel); (32, 4): four k per lane with the activation staged through LDS; (128, 6): the 96^3 bottleneck's
+    27648-wide layers — four k per lane, x gathered from memory (its fp32 image does not fit the LDS); the frozen fc2's transposed copy takes the unpermuted path."""
     ops = _ops()
-    b, c, s, dim = 2, 256, 3, 128
+    b, dim = 2, 128
     feat = rnd(b, c, s, s, s, seed=20)
     w1, b1 = rnd(dim, c * s ** 3, seed=21, scale=0.02), rnd(dim, seed=22, scale=0.1)
     fq, w1r, b1r = q(feat, dtype).requires_grad_(True), w1.clone().requires_grad_(True), b1.clone().requires_grad_(True)

@@ -299,34 +299,94 @@ __device__ __forceinline__ void st_any(void* p, int dtype, long long i, float v)
 // one workgroup per output j: y[b][j] = act(bias[j] + sum_k W[j][k] x[b][phys(k)]).  NB = batch rounded up to 1/2/4/8/16 at compile
 // time (padding rows re-read row batch-1 and are dropped), k unrolled by 4: 4 weight + 4*NB activation loads are in flight per
 // thread instead of one dependent load per FMA (the bottleneck GEMV is latency-, not bandwidth-bound: 27 k-steps per thread).
+// Round 6: (1) 16-byte weight loads, four consecutive k per lane and load — the bottleneck widths finish in ONE round of <= 8 loads per thread (dword loads in
+// two dependent rounds streamed the frozen fc2's 14 MB at 1.1 TB/s: 12.6 us); (2) a PERMUTED activation (pc > 0: the channels-last bottleneck tensor read in the
+// reference's (c, z, y, x) flattening order) made every lane gather 2-byte elements pc apart; when its fp32 image fits the LDS (s_x, [NB][k_in]) the workgroup reads x
+// once in PHYSICAL order (coalesced) and writes it at its logical index, and the k loop reads consecutive words.
 template <int NB>
 __device__ __forceinline__ void linear_fwd_body(const void* __restrict__ x, int x_dtype, const float* __restrict__ w,
                                                 const float* __restrict__ bias, float* __restrict__ y, int batch, int k_in,
-                                                int j_out, int pc, int pv, int relu) {
+                                                int j_out, int pc, int pv, int relu, float* s_x) {
     const int j = blockIdx.x;
     float acc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = 0.f;
     const float* wr = w + (size_t)j * k_in;
-    // LU k-steps per round: the 6912-wide bottleneck layers finish in two rounds of independent loads (with 4 per round the seven
-    // dependent rounds made this 22 us for 3.5 MB of weights)
-    constexpr int LU = NB <= 2 ? 16 : (NB <= 4 ? 8 : 4);
     const int nt = (int)blockDim.x;                       // 256, or 1024 for the wide layers (one round of loads instead of several)
-    for (int k0 = threadIdx.x; k0 < k_in; k0 += nt * LU) {
-        float wv[LU], xv[LU][NB];
+    // four k per lane: every row of w and x 16-byte aligned, and (permuted x) the four k of a group in one channel (pv % 4 == 0)
+    const bool vec = (k_in & 3) == 0 && ((uintptr_t)w & 15) == 0 && (pc == 0 ? ((uintptr_t)x & 15) == 0 : (pv & 3) == 0);
+    if (vec) {
+        constexpr int LU4 = NB <= 1 ? 8 : (NB <= 2 ? 4 : (NB <= 4 ? 4 : (NB <= 8 ? 2 : 1)));      // 1024-thread workgroups: 128 VGPRs (LU4 * NB * 4 activation values in flight)
+        const int nk4 = k_in >> 2;
+        const f32x4* wr4 = (const f32x4*)wr;
+        if (s_x != nullptr) {                             // workgroup-uniform
+            for (int qi = threadIdx.x; qi < k_in; qi += nt) {
+                const int v = qi / pc, c = qi - v * pc;   // physical index qi = v * pc + c  <->  logical k = c * pv + v (phys_index's inverse)
 #pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const int k = k0 + u * nt;
-            const bool ok = k < k_in;
-            wv[u] = ok ? wr[k] : 0.f;
-            const long long ph = phys_index(ok ? k : 0, pc, pv);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) xv[u][b] = ld_any(x, x_dtype, (long long)(b < batch ? b : batch - 1) * k_in + ph);
+                for (int b = 0; b < NB; ++b) s_x[b * k_in + c * pv + v] = ld_any(x, x_dtype, (long long)(b < batch ? b : batch - 1) * k_in + qi);
+            }
+            __syncthreads();
         }
+        for (int k0 = threadIdx.x; k0 < nk4; k0 += nt * LU4) {
+            f32x4 wv[LU4];
+            float xv[LU4][NB][4];
 #pragma unroll
-        for (int u = 0; u < LU; ++u)
+            for (int u = 0; u < LU4; ++u) {
+                const int k4 = k0 + u * nt;
+                const bool ok = k4 < nk4;
+                wv[u] = ok ? wr4[k4] : f32x4{0.f, 0.f, 0.f, 0.f};
+                const int kk = 4 * (ok ? k4 : 0);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) acc[b] += wv[u] * xv[u][b];
+                for (int b = 0; b < NB; ++b) {
+                    const long long row = (long long)(b < batch ? b : batch - 1) * k_in;
+                    if (s_x != nullptr) {
+                        const f32x4 t = *(const f32x4*)(s_x + b * k_in + kk);
+                        xv[u][b][0] = t[0]; xv[u][b][1] = t[1]; xv[u][b][2] = t[2]; xv[u][b][3] = t[3];
+                    } else if (pc > 0) {
+                        const long long ph = phys_index(kk, pc, pv);              // k .. k + 3: the same channel, voxels v .. v + 3
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xv[u][b][i] = ld_any(x, x_dtype, row + ph + (long long)i * pc);
+                    } else if (x_dtype == VS_F32) {
+                        const f32x4 t = *(const f32x4*)((const float*)x + row + kk);
+                        xv[u][b][0] = t[0]; xv[u][b][1] = t[1]; xv[u][b][2] = t[2]; xv[u][b][3] = t[3];
+                    } else {
+                        const u32x2 t = *(const u32x2*)((const unsigned short*)x + row + kk);
+                        if (x_dtype == VS_BF16) {
+                            xv[u][b][0] = H16<unsigned short>::lo(t[0]); xv[u][b][1] = H16<unsigned short>::hi(t[0]);
+                            xv[u][b][2] = H16<unsigned short>::lo(t[1]); xv[u][b][3] = H16<unsigned short>::hi(t[1]);
+                        } else {
+                            xv[u][b][0] = H16<vs_half>::lo(t[0]); xv[u][b][1] = H16<vs_half>::hi(t[0]);
+                            xv[u][b][2] = H16<vs_half>::lo(t[1]); xv[u][b][3] = H16<vs_half>::hi(t[1]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LU4; ++u)
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[b] += wv[u][i] * xv[u][b][i];
+        }
+    } else {
+        // one k per lane and load (ragged widths, pv % 4 != 0): LU k-steps per round
+        constexpr int LU = NB <= 2 ? 16 : (NB <= 4 ? 8 : 4);
+        for (int k0 = threadIdx.x; k0 < k_in; k0 += nt * LU) {
+            float wv[LU], xv[LU][NB];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const int k = k0 + u * nt;
+                const bool ok = k < k_in;
+                wv[u] = ok ? wr[k] : 0.f;
+                const long long ph = phys_index(ok ? k : 0, pc, pv);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) xv[u][b] = ld_any(x, x_dtype, (long long)(b < batch ? b : batch - 1) * k_in + ph);
+            }
+#pragma unroll
+            for (int u = 0; u < LU; ++u)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b] += wv[u] * xv[u][b];
+        }
     }
     __shared__ float red[16][NB];
 #pragma unroll
@@ -345,16 +405,23 @@ __device__ __forceinline__ void linear_fwd_body(const void* __restrict__ x, int 
 template <int NB>
 __global__ __launch_bounds__(1024) void linear_fwd_kernel(const void* __restrict__ x, int x_dtype, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int batch, int k_in,
-                                                         int j_out, int pc, int pv, int relu) {
-    linear_fwd_body<NB>(x, x_dtype, w, bias, y, batch, k_in, j_out, pc, pv, relu);
+                                                         int j_out, int pc, int pv, int relu, int lds_x) {
+    extern __shared__ __attribute__((aligned(16))) float s_lin[];
+    linear_fwd_body<NB>(x, x_dtype, w, bias, y, batch, k_in, j_out, pc, pv, relu, lds_x ? s_lin : nullptr);
 }
 // fc_mean and fc_std read the same bottleneck activation (joint_model.py:241-243): blockIdx.y picks the layer, one launch for both
 struct LinearPair { const float* w[2]; const float* bias[2]; float* y[2]; int relu[2]; };
 template <int NB>
 __global__ __launch_bounds__(1024) void linear_fwd_pair_kernel(const void* __restrict__ x, int x_dtype, const LinearPair a, int batch, int k_in,
-                                                              int j_out, int pc, int pv) {
+                                                              int j_out, int pc, int pv, int lds_x) {
+    extern __shared__ __attribute__((aligned(16))) float s_lin[];
     const int op = blockIdx.y;
-    linear_fwd_body<NB>(x, x_dtype, a.w[op], a.bias[op], a.y[op], batch, k_in, j_out, pc, pv, a.relu[op]);
+    linear_fwd_body<NB>(x, x_dtype, a.w[op], a.bias[op], a.y[op], batch, k_in, j_out, pc, pv, a.relu[op], lds_x ? s_lin : nullptr);
+}
+// bytes of the LDS image of x (0: read it from memory as before — not permuted, or too large for the default 64 KB)
+static inline size_t lin_lds_bytes(int nb, int k_in, int pc, int pv) {
+    const size_t need = (size_t)nb * k_in * sizeof(float);
+    return (pc > 0 && (k_in & 3) == 0 && (pv & 3) == 0 && need <= 64 * 1024) ? need : 0;      // only the four-k-per-lane path stages x
 }
 
 extern "C" int vs_linear_fwd(const void* x, int x_dtype, const float* wgt, const float* bias, float* y, int batch, int k_in,
@@ -362,7 +429,7 @@ extern "C" int vs_linear_fwd(const void* x, int x_dtype, const float* wgt, const
     if (!x || !wgt || !y || batch <= 0 || batch > LIN_MAXB || k_in <= 0 || j_out <= 0) return VS_EINVAL;
     if (pc > 0 && (long long)pc * pv != k_in) return VS_ESHAPE;
     const int lin_threads = k_in >= 4096 ? 1024 : 256;
-#define LIN_FWD(NB) hipLaunchKernelGGL(linear_fwd_kernel<NB>, dim3(j_out), dim3(lin_threads), 0, (hipStream_t)stream, x, x_dtype, wgt, bias, y, batch, k_in, j_out, pc, pv, relu)
+#define LIN_FWD(NB) hipLaunchKernelGGL(linear_fwd_kernel<NB>, dim3(j_out), dim3(lin_threads), lin_lds_bytes(NB, k_in, pc, pv), (hipStream_t)stream, x, x_dtype, wgt, bias, y, batch, k_in, j_out, pc, pv, relu, lin_lds_bytes(NB, k_in, pc, pv) ? 1 : 0)
     if (batch == 1) LIN_FWD(1); else if (batch == 2) LIN_FWD(2); else if (batch <= 4) LIN_FWD(4); else if (batch <= 8) LIN_FWD(8); else LIN_FWD(16);
 #undef LIN_FWD
     VS_CHECK_LAUNCH();
@@ -376,7 +443,7 @@ extern "C" int vs_linear_fwd_pair(const void* x, int x_dtype, const float* w1, c
     LinearPair a;
     a.w[0] = w1; a.w[1] = w2; a.bias[0] = b1; a.bias[1] = b2; a.y[0] = y1; a.y[1] = y2; a.relu[0] = relu1; a.relu[1] = relu2;
     const int lin_threads = k_in >= 4096 ? 1024 : 256;
-#define LIN_FWD2(NB) hipLaunchKernelGGL(linear_fwd_pair_kernel<NB>, dim3(j_out, 2), dim3(lin_threads), 0, (hipStream_t)stream, x, x_dtype, a, batch, k_in, j_out, pc, pv)
+#define LIN_FWD2(NB) hipLaunchKernelGGL(linear_fwd_pair_kernel<NB>, dim3(j_out, 2), dim3(lin_threads), lin_lds_bytes(NB, k_in, pc, pv), (hipStream_t)stream, x, x_dtype, a, batch, k_in, j_out, pc, pv, lin_lds_bytes(NB, k_in, pc, pv) ? 1 : 0)
     if (batch == 1) LIN_FWD2(1); else if (batch == 2) LIN_FWD2(2); else if (batch <= 4) LIN_FWD2(4); else if (batch <= 8) LIN_FWD2(8); else LIN_FWD2(16);
 #undef LIN_FWD2
     VS_CHECK_LAUNCH();
@@ -409,23 +476,26 @@ extern "C" int vs_linear_fwd_perm_out(const float* z, const float* wgt, const fl
     return VS_OK;
 }
 
-// gx[b][phys(k)] = sum_j gy'[b][j] W[j][k]   (gy' = gy masked by y>0 when y_for_relu given); one thread per k, 8 weight rows in
-// flight per step (a dependent load per FMA made this the longest launch of the step: 64 us for 6912 x 128)
+// gx[b][phys(k)] = sum_j gy'[b][j] W[j][k]   (gy' = gy masked by y>0 when y_for_relu given).  A workgroup = 64 values of k x 4 waves; wave w walks the
+// weight rows j = w, w + 4, ... with 8 rows in flight per step and the waves' partial sums meet in LDS (fixed order).  (One thread per k walking all j_out rows
+// — 16 dependent rounds of 8 loads on 108 waves — was 11.7 us for 3.5 MB of weights; before that, a dependent load per FMA: 64 us.)
 template <int NB>
-__global__ void linear_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ gy, const float* __restrict__ yrelu,
-                                    void* __restrict__ gx, int x_dtype, int batch, int k_in, int j_out, int pc, int pv) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= k_in) return;
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* __restrict__ w, const float* __restrict__ gy, const float* __restrict__ yrelu,
+                                                          void* __restrict__ gx, int x_dtype, int batch, int k_in, int j_out, int pc, int pv) {
+    __shared__ float red[3][NB][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int k = blockIdx.x * 64 + lane;
+    const bool kok = k < k_in;
     float s[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) s[b] = 0.f;
-    for (int j0 = 0; j0 < j_out; j0 += 8) {
+    for (int j0 = wave; j0 < j_out; j0 += 32) {
         float wv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) wv[u] = j0 + u < j_out ? w[(size_t)(j0 + u) * k_in + k] : 0.f;
+        for (int u = 0; u < 8; ++u) wv[u] = (kok && j0 + 4 * u < j_out) ? w[(size_t)(j0 + 4 * u) * k_in + k] : 0.f;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int j = j0 + u < j_out ? j0 + u : j_out - 1;
+            const int j = j0 + 4 * u < j_out ? j0 + 4 * u : j_out - 1;     // rows past the end carry a zero weight
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 const int bb = b < batch ? b : batch - 1;
@@ -435,10 +505,17 @@ __global__ void linear_bwd_x_kernel(const float* __restrict__ w, const float* __
             }
         }
     }
-    const long long ph = phys_index(k, pc, pv);
+    if (wave > 0) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
-        if (b < batch) st_any(gx, x_dtype, (long long)b * k_in + ph, s[b]);
+        for (int b = 0; b < NB; ++b) red[wave - 1][b][lane] = s[b];
+    }
+    __syncthreads();
+    if (wave == 0 && kok) {
+        const long long ph = phys_index(k, pc, pv);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (b < batch) st_any(gx, x_dtype, (long long)b * k_in + ph, ((s[b] + red[0][b][lane]) + red[1][b][lane]) + red[2][b][lane]);
+    }
 }
 // gw[j][k] = sum_b gy'[b][j] x[b][phys(k)] ; gb[j] = sum_b gy'[b][j]
 __global__ void linear_bwd_w_kernel(const void* __restrict__ x, int x_dtype, const float* __restrict__ gy, const float* __restrict__ yrelu,
@@ -464,7 +541,7 @@ extern "C" int vs_linear_bwd(const void* x, int x_dtype, const float* wgt, const
     if (pc > 0 && (long long)pc * pv != k_in) return VS_ESHAPE;
     if (gx) {
         if (batch > LIN_MAXB) return VS_EINVAL;
-#define LIN_BX(NB) hipLaunchKernelGGL(linear_bwd_x_kernel<NB>, dim3((k_in + 63) / 64), dim3(64), 0, (hipStream_t)stream, wgt, gy, y_for_relu, gx, x_dtype, batch, k_in, j_out, pc, pv)
+#define LIN_BX(NB) hipLaunchKernelGGL(linear_bwd_x_kernel<NB>, dim3((k_in + 63) / 64), dim3(256), 0, (hipStream_t)stream, wgt, gy, y_for_relu, gx, x_dtype, batch, k_in, j_out, pc, pv)
         if (batch == 1) LIN_BX(1); else if (batch == 2) LIN_BX(2); else if (batch <= 4) LIN_BX(4); else if (batch <= 8) LIN_BX(8); else LIN_BX(16);
 #undef LIN_BX
         VS_CHECK_LAUNCH();
