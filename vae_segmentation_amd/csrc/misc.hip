@@ -1068,6 +1068,33 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(float* const* params, co
     // every operand of the chunk is requested before the first store: the compiler cannot move a load over a store that may alias, and
     // sixteen dependent load -> store rounds made this 2.3 M-parameter update 25 us
     constexpr int R = MT_CHUNK / 256;
+    if (end - start == MT_CHUNK && ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m) & 15) == 0)) {      // a full, 16-byte-aligned chunk (uniform): 12 vector loads instead of 48 dword loads (same 12.5 us: the update moves 49 MB at 3.9 TB/s either way)
+        constexpr int R4 = R / 4;
+        f32x4 g4[R4], p4[R4], m4[R4];
+        const f32x4* gq = (const f32x4*)(g + start);
+        f32x4* pq = (f32x4*)(p + start);
+        f32x4* mq = (f32x4*)(m + start);
+#pragma unroll
+        for (int r = 0; r < R4; ++r) {
+            const int i = threadIdx.x + r * 256;
+            g4[r] = gq[i]; p4[r] = pq[i];
+            m4[r] = first ? f32x4{0.f, 0.f, 0.f, 0.f} : mq[i];
+        }
+#pragma unroll
+        for (int r = 0; r < R4; ++r) {
+            const int i = threadIdx.x + r * 256;
+            f32x4 bo, po;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gi = g4[r][e] * inv_scale + wd * p4[r][e];
+                const float bi = first ? gi : momentum * m4[r][e] + gi;
+                bo[e] = bi;
+                po[e] = p4[r][e] - lr * (momentum != 0.f ? bi : gi);
+            }
+            mq[i] = bo; pq[i] = po;
+        }
+        return;
+    }
     float gv[R], pv[R], mv[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
