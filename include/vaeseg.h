@@ -215,6 +215,16 @@ int vs_set_config(const vs_config* cfg);
 int vs_conv_k3_bwd_data_applied_supported(int n, int d, int h, int w, int c_in, int m_out, int dtype);
 int vs_conv_k3_bwd_data_applied(const void* x, const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums,
                                 unsigned int* sync, unsigned int* fault, int n, int d, int h, int w, int c_in, int m_out, int dtype, float eps, void* stream);
+/* The same for the stride-2 kinds (csrc/igemm.h g1_kernel, round 6): scatter = 0: vs_conv_gather_bwd_data(kind K2S2) — the backward-data of
+ * nn.ConvTranspose3d(C, C, 2, stride=2) (joint_model.py:118) — scatter = 1: vs_conv_scatter_bwd_data — the backward-data of nn.Conv3d(C, C, 2, stride=2)
+ * (joint_model.py:130) — FOLLOWED BY vs_instnorm_relu_bwd_apply_add of its output, in one launch.  add (nullable, y's shape and type): a second gradient of the same raw
+ * tensor (the U-Net skip's, joint_model.py:380,382), summed in after the apply as vs_instnorm_relu_bwd_apply_add does.  Any storage type; launches of at most 256
+ * workgroups (the <= 48^3 levels at batch 2).  sync / fault / concurrency rule: as vs_conv_k3_bwd_data_applied.  Results equal the two launches' bit for bit in the
+ * deterministic build. */
+int vs_conv_s2_bwd_data_applied_supported(int n, int d, int h, int w, int c_in, int m_out, int scatter, int dtype);
+int vs_conv_s2_bwd_data_applied(const void* x, const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums, const void* add,
+                                unsigned int* sync, unsigned int* fault, int n, int d, int h, int w, int c_in, int m_out, int scatter, int dtype, float eps,
+                                void* stream);
 /* One DoubleConv (joint_model.py:35-52: three times [Conv3d 3x3x3 pad 1 -> InstanceNorm3d -> ReLU]) at the small volumes of the deep levels as ONE launch
  * (csrc/chain.h, round 6).  InstanceNorm3d is per (sample, channel) (joint_model.py:11), so layer l + 1 of sample n depends on layer l of sample n only: the
  * workgroups of a sample hand the raw output and its statistics over inside the launch (write-through stores, counter, sc1 loads) instead of ending it.

@@ -150,3 +150,54 @@ def test_epilogue_apply_equals_backward_data_then_apply(case, dtype, lib_mode):
         else:
             e = relerr(b.double().cpu(), a.double().cpu())
             assert e < {torch.float32: 2e-5, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dtype], "%s: %g" % (nm, e)
+
+
+@pytest.mark.parametrize("lib_mode", ["det", "atomic"], indirect=True)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("case", [(1, 2, 64, 6, False), (1, 2, 32, 12, True), (0, 2, 64, 6, False), (0, 2, 32, 12, True), (1, 1, 128, 3, True), (0, 2, 16, 24, False),
+                                  (1, 2, 16, 24, True)])
+def test_stride2_epilogue_apply_equals_backward_data_then_apply(case, dtype, lib_mode):
+    """g1_kernel's epilogue apply (csrc/igemm.h, vs_conv_s2_bwd_data_applied): the backward-data launch of Conv3d(k2, s2) (scatter) / ConvTranspose3d(k2, s2) (gather) on a
+    lazy input applies the InstanceNorm+ReLU backward to its own outputs — with the U-Net skip's parked gradient summed in — against the two launches it replaces
+    (which tests/test_gpu_layers.py pins to CPU autograd)."""
+    ops = _ops()
+    scatter, n, c, side, with_add = case          # side: the COARSE grid's extent; c channels on both sides
+    torch.manual_seed(5)
+    fine, coarse = (side * 2,) * 3, (side,) * 3
+    if scatter:      # backward of Conv3d(c, c, 2, stride 2): x fine (lazy), gy coarse
+        x_cl = to_cl(torch.randn(n, c, *fine), c, dtype)
+        gy = to_cl(torch.randn(n, c, *coarse), c, dtype)
+        w = (torch.randn(c, c, 2, 2, 2) / (8 * c) ** 0.5).cuda()
+        form = ops.VS_PACK_SCATTER_D1
+    else:            # backward of ConvTranspose3d(c, c, 2, stride 2): x coarse (lazy), gy fine
+        x_cl = to_cl(torch.randn(n, c, *coarse), c, dtype)
+        gy = to_cl(torch.randn(n, c, *fine), c, dtype)
+        w = (torch.randn(c, c, 2, 2, 2) / (8 * c) ** 0.5).cuda()
+        form = ops.VS_PACK_ROWS_D0
+    xs = ops.instnorm_stats(x_cl)
+    add = to_cl(torch.randn(n, c, *(fine if scatter else coarse)) * 0.1, c, dtype) if with_add else None
+    gn, gd, gh, gw, gc = gy.shape
+    if not ops.lib.vs_conv_s2_bwd_data_applied_supported(gn, gd, gh, gw, gc, c, 1 if scatter else 0, ops.vs_dtype(x_cl)):
+        assert scatter and side == 24, "a case the kernel must take"
+        pytest.skip("48^3 x 16 scatter: 864 workgroups, more than the 256 that are certainly resident")
+    wpb = ops.pack_weight(w, form, gc, dtype)
+    res = {}
+    was = ops.EPILOGUE_APPLY
+    try:
+        for ea in (False, True):
+            ops.EPILOGUE_APPLY = ea
+            with ops.arena_scope(x_cl.device):
+                if add is not None:
+                    ops._PENDING["grads"][(x_cl.data_ptr(), tuple(x_cl.shape))] = add
+                res[ea] = ops.conv_bwd_data_lazy(gy, wpb, x_cl, xs, ops.VS_CONV_K2S2, scatter=bool(scatter)).clone()
+                assert not ops._PENDING["grads"]
+    finally:
+        ops.EPILOGUE_APPLY = was
+        ops._PENDING["grads"].clear()
+    ops.chain_fault()
+    a, b = res[False], res[True]
+    if lib_mode == "det":
+        assert torch.equal(a, b), "gx differs (max %g)" % (a.double() - b.double()).abs().max().item()
+    else:
+        e = relerr(b.double().cpu(), a.double().cpu())
+        assert e < {torch.float32: 2e-5, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dtype], "gx: %g" % e

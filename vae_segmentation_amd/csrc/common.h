@@ -286,6 +286,22 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base, unsigned int bytes)
 
 // The two 16-bit storage formats of the throughput kernels (k3b / k3t / k3s / g3b are templated on T = unsigned short | vs_half):
 // one dword = two elements; pack2 rounds to nearest even in both formats, lo / hi widen exactly.
+// One element of the InstanceNorm+ReLU backward apply, rstd * (g * [xhat > 0] - m1 - xhat * m2), with its floating-point contraction PINNED (one fused
+// multiply-add, written out; nothing else may fuse).  Under the default -ffp-contract=fast the optimiser fuses `gm - a - xh * b` differently from one kernel to
+// the next; the standalone pass (norm.hip), the chains' in-place apply (chain.h) and every epilogue apply (igemm_k3b.h, igemm_k3x.h, igemm.h) must agree bit for
+// bit in the deterministic build, so they all go through this one function.  -> the un-rounded fp32 value.
+__device__ __forceinline__ float vs_in_bwd_apply1(float g, float x, float mean, float rstd, float m1, float m2) {
+#pragma clang fp contract(off)
+    const float xh = (x - mean) * rstd;
+    const float gm = xh > 0.f ? g : 0.f;
+    const float base = gm - m1;
+    float out = rstd * __builtin_fmaf(-xh, m2, base);
+    // the product is an fp32 VALUE before anything rounds it to 16 bits: left to itself the backend fuses `multiply, then convert` into v_fma_mixlo_f16 (one rounding of
+    // the exact product) in some kernels and not in others — 29 of 884,736 outputs of a 24^3 x 32 fp16 layer differed by an ulp between two forms of the same apply
+    asm volatile("" : "+v"(out));
+    return out;
+}
+
 template <typename T> struct H16;
 template <> struct H16<unsigned short> {
     __device__ static __forceinline__ unsigned int pack2(f32x2 v) { return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2)); }

@@ -66,11 +66,13 @@ static int check_common(const void* x, const void* w, int n, int d, int h, int w
     return VS_OK;
 }
 
+static inline long long g1_ea_capacity() { return 256; }     // g1_kernel<..., epilogue apply>: workgroups of one launch that are certainly resident together (one per CU)
+
 static int gather_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias,
                        void* y, double* y_stats, const void* mask_x, const double* mask_stats, double* sums,
                        int n, int d, int h, int w, int c_in, int m_out, int kind, int dtype, float eps, void* stream,
                        const void* fa_x = nullptr, const double* fa_sums = nullptr, void* fa_dx = nullptr, int* fa_query = nullptr, float* wg_ws = nullptr,
-                       unsigned int* ea_sync = nullptr, unsigned int* ea_fault = nullptr, int* ea_query = nullptr) {
+                       unsigned int* ea_sync = nullptr, unsigned int* ea_fault = nullptr, int* ea_query = nullptr, const void* ea_add = nullptr) {
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
     if (!y || m_out <= 0 || m_out % 8 || ((uintptr_t)y & 15)) return VS_EINVAL;
@@ -80,7 +82,7 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     p.x = x; p.x_stats = x_stats; p.wp = w_packed; p.bias = bias; p.y = y; p.y_stats = y_stats; p.prob = nullptr;
     p.mask_x = mask_x; p.mask_stats = mask_stats; p.sums = sums;
     p.fa_x = fa_x; p.fa_sums = fa_sums; p.fa_dx = fa_dx; p.wg_ws = wg_ws;
-    p.ea_sync = ea_sync; p.ea_fault = ea_fault;
+    p.ea_sync = ea_sync; p.ea_fault = ea_fault; p.ea_add = ea_add;
     if (sums && (!mask_x || !mask_stats || y_stats)) return VS_EINVAL;
     p.N = n; p.D = d; p.H = h; p.W = w;
     p.C = c_in; p.M = m_out;
@@ -113,6 +115,13 @@ static int gather_impl(const void* x, const double* x_stats, const void* w_packe
     // workgroup per CU (512 VGPRs) — 32-row tiles halve both the repeats and the workgroup count (24^3 x 32: 144 workgroups, one round)
     if (kind == VS_CONV_K3 && fa_x != nullptr && ck == 32 && mt == 16 && rows16 % 32 == 0) mt = 32;
     const int row_tiles = rows16 / mt;
+    if (kind == VS_CONV_K2S2 && (ea_query != nullptr || ea_sync != nullptr)) {
+        // g1_kernel's epilogue apply (igemm.h): any storage type; every workgroup of the launch resident — one per CU is certain (up to 256 VGPRs + AGPRs)
+        const bool ok = sums != nullptr && mt == 16 && tiles * row_tiles <= g1_ea_capacity();      // the epilogue-apply instantiations: 16-row workgroups
+        if (ea_query != nullptr) { *ea_query = ok ? 1 : 0; return VS_OK; }
+        if (!ok) return VS_ESHAPE;
+        p.ea_items = p.tiles_per_sample * row_tiles;
+    }
     if (ea_query != nullptr) {                             // planning only: does k3b_kernel<32, 16, .., EA> take this backward-data launch?  (16-bit storage, 32-channel
         *ea_query = (kind == VS_CONV_K3 && dtype != VS_F32 && ck == 32 && mt == 16 && sums != nullptr && !fa_x &&        // chunks, not a k3s volume, one resident round)
                      !((long long)(d + 2) * (h + 2) * (w + 2) <= 512 && c_in <= 1024) && tiles * row_tiles <= k3b_ea_capacity(n, c_in, m_out)) ? 1 : 0;
@@ -243,7 +252,8 @@ extern "C" int vs_conv_k3_softmax2_bwd_data(const float* prob, const float* gpro
 
 static int scatter_impl(const void* x, const double* x_stats, const void* w_packed, const float* bias, void* y,
                         const void* mask_x, const double* mask_stats, double* sums, int n, int d, int h, int w, int c_in,
-                        int m_out, int dtype, float eps, void* stream) {
+                        int m_out, int dtype, float eps, void* stream,
+                        unsigned int* ea_sync = nullptr, unsigned int* ea_fault = nullptr, int* ea_query = nullptr, const void* ea_add = nullptr) {
     int rc = check_common(x, w_packed, n, d, h, w, c_in, dtype);
     if (rc) return rc;
     if (!y || m_out <= 0 || m_out % 8 || ((uintptr_t)y & 15)) return VS_EINVAL;
@@ -263,12 +273,20 @@ static int scatter_impl(const void* x, const double* x_stats, const void* w_pack
     const long long tiles = (long long)p.tiles_per_sample * n;
     // the 8 -> 8 backward-data scatter at full resolution (Down1): a streaming kernel instead of an MFMA tile per 256 coarse voxels (k2s2_scatter8.hip)
     const int stream8 = vs_cfg().k2s2_stream;
-    if (stream8 && sums && c_in == 8 && m_out == 8 && dtype != VS_F32 && !bias && !x_stats) {
+    const bool ea_asked = ea_query != nullptr || ea_sync != nullptr;
+    if (!ea_asked && stream8 && sums && c_in == 8 && m_out == 8 && dtype != VS_F32 && !bias && !x_stats) {
         rc = k2s2_scatter8_launch(p, dtype, (hipStream_t)stream);
         if (rc != VS_ESHAPE) return rc;
     }
     const int rows16 = p.rb_total * 16;
     const int mt = pick_mt(rows16, tiles);
+    if (ea_asked) {                                        // g1_kernel's epilogue apply (see gather_impl); not the streaming 8 -> 8 kernel's shapes (full resolution: never resident)
+        const bool ok = sums != nullptr && mt == 16 && tiles * (rows16 / mt) <= g1_ea_capacity();
+        if (ea_query != nullptr) { *ea_query = ok ? 1 : 0; return VS_OK; }
+        if (!ok) return VS_ESHAPE;
+        p.ea_sync = ea_sync; p.ea_fault = ea_fault; p.ea_add = ea_add;
+        p.ea_items = p.tiles_per_sample * (rows16 / mt);
+    }
     return g1_dispatch_pw(p, dtype, ck, mt, (int)tiles, rows16 / mt, (hipStream_t)stream);
 }
 
@@ -283,6 +301,32 @@ extern "C" int vs_conv_scatter_bwd_data(const void* x, const void* w_packed, voi
                                         int m_out, int dtype, float eps, void* stream) {
     if (!mask_x || !mask_stats || !sums) return VS_EINVAL;
     return scatter_impl(x, nullptr, w_packed, nullptr, y, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, dtype, eps, stream);
+}
+
+// ---- the same for the stride-2 kinds (igemm.h g1_kernel's epilogue apply): scatter = 0: backward-data of ConvTranspose3d(k2, s2) (a stride-2 gather);
+// scatter = 1: backward-data of Conv3d(k2, s2) (the scatter form).  add (nullable): a second gradient of the same raw tensor, summed in after the apply ----
+extern "C" int vs_conv_s2_bwd_data_applied_supported(int n, int d, int h, int w, int c_in, int m_out, int scatter, int dtype) {
+    const int on = vs_cfg().epilogue_apply;
+    if (!on || !vs_dtype_ok(dtype)) return 0;
+    static const char dummy[16] __attribute__((aligned(16))) = {0};        // planning only: no pointer is dereferenced
+    static double dsink[2];
+    int ok = 0;
+    const int rc = scatter ? scatter_impl(dummy, nullptr, dummy, nullptr, (void*)dummy, dummy, (const double*)dummy, dsink, n, d, h, w, c_in, m_out, dtype, 1e-5f, nullptr,
+                                          nullptr, nullptr, &ok)
+                           : gather_impl(dummy, nullptr, dummy, nullptr, (void*)dummy, nullptr, dummy, (const double*)dummy, dsink, n, d, h, w, c_in, m_out, VS_CONV_K2S2, dtype,
+                                         1e-5f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &ok);
+    return rc == VS_OK ? ok : 0;
+}
+
+extern "C" int vs_conv_s2_bwd_data_applied(const void* x, const void* w_packed, void* y, const void* mask_x, const double* mask_stats, double* sums, const void* add,
+                                           unsigned int* sync, unsigned int* fault, int n, int d, int h, int w, int c_in, int m_out, int scatter, int dtype, float eps,
+                                           void* stream) {
+    if (!mask_x || !mask_stats || !sums || !sync || !fault) return VS_EINVAL;
+    if (((uintptr_t)sync & 127) || ((uintptr_t)fault & 3) || (add && ((uintptr_t)add & 15))) return VS_EALIGN;
+    if (!vs_conv_s2_bwd_data_applied_supported(n, d, h, w, c_in, m_out, scatter, dtype)) return VS_ESHAPE;
+    if (scatter) return scatter_impl(x, nullptr, w_packed, nullptr, y, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, dtype, eps, stream, sync, fault, nullptr, add);
+    return gather_impl(x, nullptr, w_packed, nullptr, y, nullptr, mask_x, mask_stats, sums, n, d, h, w, c_in, m_out, VS_CONV_K2S2, dtype, eps, stream,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, sync, fault, nullptr, add);
 }
 
 extern "C" int vs_conv_k3_softmax2_fwd(const void* x, const double* x_stats, const void* w_packed, const float* bias,

@@ -10,6 +10,7 @@
 #pragma once
 #include <type_traits>
 #include "common.h"
+#include "handoff.h"
 
 enum { G1_K3 = 0, G1_K2S2 = 1, G1_PW = 2 };
 enum { EPI_RAW = 0, EPI_SOFTMAX2 = 1, EPI_SCATTER = 2 };
@@ -63,6 +64,7 @@ struct G1Params {
     unsigned int* ea_sync;
     unsigned int* ea_fault;
     int ea_items;
+    const void* ea_add;      // g1_kernel's epilogue apply only: a second gradient of the same raw tensor, summed in after the apply (vs_instnorm_relu_bwd_apply_add's form)
 };
 
 // LDS carve (bytes)
@@ -91,7 +93,9 @@ __device__ __forceinline__ u32x4 act_transform(u32x4 raw, const float* s_mean, c
 // lane -> k assignment is valid as long as both operands share it) are split IN REGISTERS into three bf16 limbs each (common.h vs_limb_split4: the arithmetic of
 // igemm_k3x.h) and multiplied by six v_mfma_f32_16x16x32_bf16 — 96 matrix cycles instead of 256 per (row block, column set), no new weight image: the packed fp32
 // fragments are read as they are.  The leading product x0 w0 has its own accumulator where the register budget allows (RB <= 2), as in k3x_kernel.
-template <typename T, int CK, int KIND, int MT, int EPI, bool LIMB = false>
+// EA: the epilogue apply (see the epilogue) — instantiations of their own (16-row workgroups only): as a run-time branch its registers cost every launch of the
+// family 0.3-0.5 us and the 64-row transposed conv at 96^3 16 us
+template <typename T, int CK, int KIND, int MT, int EPI, bool LIMB = false, bool EA = false>
 __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     using E = ET<T>;
     constexpr int EPL = E::EPL, KG = E::KG;
@@ -446,6 +450,13 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
     // full memory round trip: 16 in a row for a 64-row scatter workgroup)
     constexpr int MKW = sizeof(T) == 4 ? 4 : 2;
     unsigned int mkv[RB][4][MKW];
+    // Epilogue apply (round 6; backward-data use with fused sums, every workgroup of the launch resident — the stride-2 / transposed launches of the <= 48^3 levels):
+    // the workgroup keeps its outputs and mask values in registers, adds its partial sums, arrives on its SAMPLE's counter, waits for the sample's other workgroups,
+    // reads the complete sums back and stores the APPLIED gradient rstd * (g * [xhat > 0] - m1 - xhat * m2) [rounded, + ea_add] — the arithmetic of
+    // vs_instnorm_relu_bwd_apply_add on the same rounded values; the un-applied tensor is never written and the standalone apply launch (~5 us) disappears.
+    constexpr bool ea = EA;
+    static_assert(!EA || MT == 16, "epilogue apply: 16-row workgroups");
+    unsigned int adv[EA ? RB : 1][4][MKW];
     if (p.sums != nullptr) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -454,14 +465,26 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
                 int m; bool ok;
                 const size_t e = out_elem(rb, cg, m, ok);
 #pragma unroll
-                for (int i = 0; i < MKW; ++i) mkv[rb][cg][i] = 0u;
+                for (int i = 0; i < MKW; ++i) { mkv[rb][cg][i] = 0u; if constexpr (EA) adv[rb][cg][i] = 0u; }
                 if (ok) {
                     if constexpr (sizeof(T) == 4) {
                         const u32x4 xx = *(const u32x4*)((const float*)p.mask_x + e);
                         mkv[rb][cg][0] = xx[0]; mkv[rb][cg][1] = xx[1]; mkv[rb][cg][2] = xx[2]; mkv[rb][cg][3] = xx[3];
+                        if constexpr (EA) {
+                            if (p.ea_add != nullptr) {
+                                const u32x4 aa = *(const u32x4*)((const float*)p.ea_add + e);
+                                adv[rb][cg][0] = aa[0]; adv[rb][cg][1] = aa[1]; adv[rb][cg][2] = aa[2]; adv[rb][cg][3] = aa[3];
+                            }
+                        }
                     } else {
                         const u32x2 xx = *(const u32x2*)((const T*)p.mask_x + e);
                         mkv[rb][cg][0] = xx[0]; mkv[rb][cg][1] = xx[1];
+                        if constexpr (EA) {
+                            if (p.ea_add != nullptr) {
+                                const u32x2 aa = *(const u32x2*)((const T*)p.ea_add + e);
+                                adv[rb][cg][0] = aa[0]; adv[rb][cg][1] = aa[1];
+                            }
+                        }
                     }
                 }
             }
@@ -497,7 +520,7 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = E::rnd(acc[rb][cg][r] + bv[r]);
-            store4<T>(yout + e, v);
+            if (!ea) store4<T>(yout + e, v);
             if (p.sums != nullptr) {
                 float xv[4];
                 widen4<T>(mkv[rb][cg], xv);
@@ -549,12 +572,55 @@ __global__ __launch_bounds__(256) void g1_kernel(const G1Params p) {
             if (ch_out >= 0) stat_add(red_dst, (size_t)n * p.M + ch_out, (size_t)p.N * p.M, st, tot);
         }
     }
+    if constexpr (EA) {
+        // ---- the sample's sums are complete once all of its workgroups have arrived; then the apply, on registers (k3b_kernel<..., EA>'s form) ----
+        unsigned int* ctr = p.ea_sync + (size_t)n * 256;     // 8 shards of 128 bytes per sample
+        chain_arrive8(ctr);
+        chain_wait8(ctr, (unsigned int)p.ea_items, p.ea_fault);
+        if (tid < MT) {
+            const int row = rb0 * 16 + tid;
+            const bool rok = EPI == EPI_SCATTER ? (row < 8 * p.M) : (row < p.M);
+            const int ch = EPI == EPI_SCATTER ? row % p.M : row;
+            float m = 0.f, r = 1.f, a = 0.f, b = 0.f;
+            if (rok) {
+                stats_to_mean_rstd(p.mask_stats, (size_t)n * p.M + ch, (size_t)p.N * p.M, p.inv_count_out, p.eps, m, r);     // the standalone apply's exact form
+                double sv[2];
+                stat_load_sc1(p.sums, (size_t)n * p.M + ch, (size_t)p.N * p.M, sv);
+                a = (float)(sv[0] * p.inv_count_out);
+                b = (float)(sv[1] * p.inv_count_out);
+            }
+            *(f32x4*)(s_red + tid * 4) = f32x4{m, r, a, b};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            f32x4 tb[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tb[r] = *(const f32x4*)(s_red + (rb * 16 + 4 * g + r) * 4);
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) {
+                int m2; bool ok;
+                const size_t e = out_elem(rb, cg, m2, ok);
+                if (!ok) continue;
+                float xv[4], av[4], o[4];
+                widen4<T>(mkv[rb][cg], xv);
+                widen4<T>(adv[rb][cg], av);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gv = E::rnd(acc[rb][cg][r] + bvq[rb][r]);
+                    o[r] = vs_in_bwd_apply1(gv, xv[r], tb[r][0], tb[r][1], tb[r][2], tb[r][3]);
+                    if (p.ea_add != nullptr) o[r] = E::rnd(o[r]) + av[r];
+                }
+                store4<T>(yout + e, o);
+            }
+        }
+    }
 }
 
-template <typename T, int CK, int KIND, int MT, int EPI, bool LIMB = false>
+template <typename T, int CK, int KIND, int MT, int EPI, bool LIMB = false, bool EA = false>
 static int g1_launch(const G1Params& p, int tiles_total, int row_tiles, hipStream_t stream) {
     constexpr size_t lds = G1_LDS_BYTES + (KIND == G1_K2S2 && CK == 32 ? (size_t)3 * (MT / 16) * 4 * 64 * 16 : 0);   // + the wave-split partials
-    auto kern = g1_kernel<T, CK, KIND, MT, EPI, LIMB>;
+    auto kern = g1_kernel<T, CK, KIND, MT, EPI, LIMB, EA>;
     hipLaunchKernelGGL(kern, dim3(tiles_total, row_tiles), dim3(256), lds, stream, p);
     VS_CHECK_LAUNCH();
     return VS_OK;

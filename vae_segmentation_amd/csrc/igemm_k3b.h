@@ -540,9 +540,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(
                         float o[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float xh = (xq[r] - tb[r][0]) * tb[r][1];
-                            const float gm = xh > 0.f ? gv[r] : 0.f;
-                            o[r] = tb[r][1] * (gm - tb[r][2] - xh * tb[r][3]);
+                            o[r] = vs_in_bwd_apply1(gv[r], xq[r], tb[r][0], tb[r][1], tb[r][2], tb[r][3]);
                         }
                         i32x2 po;
                         po[0] = (int)H16<T>::pack2(f32x2{o[0], o[1]});

@@ -458,9 +458,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, CK == 8 
                         float o[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float xh = (__uint_as_float(mk[rb][cg][r]) - tb[r][0]) * tb[r][1];
-                            const float gm = xh > 0.f ? vkeep[rb][cg][r] : 0.f;
-                            o[r] = tb[r][1] * (gm - tb[r][2] - xh * tb[r][3]);
+                            o[r] = vs_in_bwd_apply1(vkeep[rb][cg][r], __uint_as_float(mk[rb][cg][r]), tb[r][0], tb[r][1], tb[r][2], tb[r][3]);
                         }
                         vs_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{o[0], o[1], o[2], o[3]}), yrsrc, valid ? ebase + cg * p.W * p.M * 4 + rb * 64 : -1, 0, 0);
                     }

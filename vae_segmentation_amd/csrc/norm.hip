@@ -243,11 +243,7 @@ __device__ __forceinline__ void in_relu_bwd_apply_body(const T* __restrict__ g, 
             frag_unpack(gc[u], fg, (T*)nullptr);
             frag_unpack(xc[u], fx_, (T*)nullptr);
 #pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-                const float xh = (fx_[j] - m[j]) * r[j];
-                const float gm = xh > 0.f ? fg[j] : 0.f;
-                o[j] = r[j] * (gm - a[j] - xh * b[j]);
-            }
+            for (int j = 0; j < EPL; ++j) o[j] = vs_in_bwd_apply1(fg[j], fx_[j], m[j], r[j], a[j], b[j]);
             if (add != nullptr) {
                 float fa[EPL];
                 frag_unpack(ac[u], fa, (T*)nullptr);

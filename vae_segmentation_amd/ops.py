@@ -557,6 +557,7 @@ def _pending_done():
 # An entry nobody took by the end of the pass means a consumer treated an un-applied gradient as applied: that is an error, not a fallback.
 FUSE_APPLY = os.environ.get("VS_FUSE_APPLY", "1") != "0"
 EPILOGUE_APPLY = os.environ.get("VS_EPILOGUE_APPLY", "1") != "0"      # A/B switch of k3b_kernel<..., EA> (the library reads the same variable)
+EPILOGUE_APPLY_S2 = os.environ.get("VS_EPILOGUE_APPLY_S2", "1") != "0"      # ... of g1_kernel's epilogue apply alone (the stride-2 / transposed backward-data launches)
 # channels of the activations whose producer has a fused-apply kernel: 8 / 16 (k3t, single-chunk k3b: the 96^3 / 48^3 levels).  The 32-channel
 # form (k3b<32,...,FA>, the 24^3 / 12^3 levels) measured slower twice (round 4: 2.519 -> 2.566 ms per step, profiles/r04_ab_fused_apply_32ch.json)
 # and left the library in round 5; so did 16-channel half stages of the same layers (two waves per SIMD, 19 launches fewer, +30..+43 us per step:
@@ -617,6 +618,14 @@ def apply_lazy(g, lazy):
     return g
 
 
+def _ea_sync(n, device):
+    """the arrival counters of one epilogue-apply launch: 8 shards of 128 bytes per sample, 128-byte aligned, zeroed with the statistics arena"""
+    cnt = 128 * n
+    buf = _new_stats(1, cnt + 16, device, width=1).view(-1)
+    off = ((-buf.data_ptr()) % 128) // 8
+    return buf[off:off + cnt]
+
+
 def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None, defer=False, lazy=None, want_dx=False, fuse_wgrad=None):
     """Gradient w.r.t. the raw tensor x of a lazy activation a = relu(instnorm(x)) that fed a conv:
     g = conv-backward-data(gy) with the InstanceNorm+ReLU-backward sums accumulated in the same kernel's epilogue,
@@ -669,10 +678,7 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None, 
     if (not scatter and kind == VS_CONV_K3 and not defer and EPILOGUE_APPLY and (x.data_ptr(), tuple(x.shape)) not in _PENDING["grads"]
             and lib.vs_conv_k3_bwd_data_applied_supported(gn, gd, gh, gw, gc, c, dt)):
         # the 24^3 / 12^3 levels: the backward-data launch applies the InstanceNorm+ReLU backward to its own outputs (csrc/igemm_k3b.h EA): no apply launch
-        cnt = 128 * gn                         # 8 counter shards of 128 bytes per sample, zeroed with the arena
-        buf = _new_stats(1, cnt + 16, x.device, width=1).view(-1)
-        off = ((-buf.data_ptr()) % 128) // 8
-        sync = buf[off:off + cnt]
+        sync = _ea_sync(gn, x.device)
         kid = nb = fl = None
         if PROFILE is not None:
             tiles = gn * ((gd + 3) // 4) * ((gh + 3) // 4) * ((gw + 15) // 16)
@@ -682,6 +688,23 @@ def conv_bwd_data_lazy(gy, wpb, x, xs, kind, scatter=False, real_channels=None, 
         with _timed(kid, nb, fl, "bwd+ea gy%s->m%d" % (tuple(gy.shape), c)):
             check(lib.vs_conv_k3_bwd_data_applied(gy.data_ptr(), wpb.data_ptr(), g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), sync.data_ptr(),
                                                   _chain_fault_word(x.device).data_ptr(), gn, gd, gh, gw, gc, c, dt, EPS_IN, _stream()), "conv_k3_bwd_data_applied")
+        return g
+    if (kind != VS_CONV_K3 and not defer and EPILOGUE_APPLY and EPILOGUE_APPLY_S2 and lib.vs_conv_s2_bwd_data_applied_supported(gn, gd, gh, gw, gc, c, 1 if scatter else 0, dt)):
+        # the stride-2 / transposed launches of the <= 48^3 levels: g1_kernel applies the InstanceNorm+ReLU backward to its own outputs (csrc/igemm.h), the
+        # skip's parked gradient of the same tensor summed in as the standalone apply would
+        sync = _ea_sync(gn, x.device)
+        add = _collect_gradient(x)
+        kid = nb = fl = None
+        if PROFILE is not None:
+            tiles = gn * ((gd * gh * gw + 255) // 256) if scatter else n * ((g.numel() // (n * c) + 255) // 256)
+            rows = (8 * c + 15) // 16 * 16 if scatter else (c + 15) // 16 * 16
+            kid = "g1_kernel<%s,%d,%d,%d,%d>+ea" % (_tname(x), min(gc, 32), 2 if scatter else kind, _pick_mt(rows, tiles), 2 if scatter else 0)
+            nb = (gy.numel() + (2 if add is None else 3) * g.numel()) * _esize(x) + 8 * gc * c * _esize(x)
+            fl = 2.0 * ((gy.numel() // gc) if scatter else (g.numel() // c)) * 8 * gc * c
+        with _timed(kid, nb, fl, "bwd+ea gy%s->m%d" % (tuple(gy.shape), c)):
+            check(lib.vs_conv_s2_bwd_data_applied(gy.data_ptr(), wpb.data_ptr(), g.data_ptr(), x.data_ptr(), xs.data_ptr(), sums.data_ptr(), _p(add), sync.data_ptr(),
+                                                  _chain_fault_word(x.device).data_ptr(), gn, gd, gh, gw, gc, c, 1 if scatter else 0, dt, EPS_IN, _stream()),
+                  "conv_s2_bwd_data_applied")
         return g
     if scatter:
         kid = nb = fl = None
