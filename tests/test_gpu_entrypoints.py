@@ -90,3 +90,30 @@ def test_real_data_cases_through_the_device_pipeline(tmp_path):
                 "--pseudo_list", "NIH_pseudo", "--pseudo_data_root", str(tmp_path / "data"), "--pseudo_pan_index", "1", "--train_first_epoch",
                 "--size", "64", "-b", "1", "-E", "1", "--eval_epoch", "1", "--save_epoch", "1", "--display_freq", "1"], str(tmp_path))
     assert "Finished Training" in out and out.count("dice_loss_pseudo") >= 3      # 3 training cases, the 2 pseudo cases cycled
+
+
+def test_pseudo_list_step_losses_follow_the_reference_ladder():
+    """main_target.py:636-651 — the final loss of a --pseudo_list iteration: type 8 with the stepped lambda (both of its arms), lambda_vae >= 1000
+    (recon * lambda / 10000), else lambda * recon + fake; host and device forms of the type-8 schedule agree; the pseudo-labelled batch's terms
+    (main_target.py:677-684) come without an autograd graph."""
+    import torch
+    sys.path.insert(0, REPO)
+    import bench
+    from vae_segmentation_amd import train as T
+    joint, img, lab, teacher = bench.build(64, "fp32", 0, batch=1, teacher=True)
+
+    def expect(r, f, dlt, lam):
+        if dlt == 8:
+            cur = lam * (0.6 if r < 0.15 else 1.2 if r < 0.225 else 2.0 if r < 0.3 else 3.0)
+            return r + f / cur if cur > 1 else cur * r + f
+        return r * lam / 10000 if lam >= 1000 else lam * r + f
+
+    for dlt, lam in ((8, 1.0), (8, 0.2), (0, 2000.0), (0, 0.5)):
+        for host in (True, False) if dlt == 8 else (True,):
+            final, aux = T.domain_adaptation_pseudo_losses(joint, teacher, img, lab, lambda_vae=lam, domain_loss_type=dlt, host_schedule=host)
+            r, f = aux["recon_loss"].item(), aux["dice_loss_fake"].item()
+            assert abs(final.item() - expect(r, f, dlt, lam)) < 1e-5 * max(1.0, abs(final.item())), (dlt, lam, host)
+            assert final.requires_grad
+    out = T.pseudo_batch_losses(joint, img, lab)
+    assert set(out) == {"recon_loss_pseudo", "dice_loss_pseudo", "final_loss_pseudo"} and not any(v.requires_grad for v in out.values())
+    assert out["final_loss_pseudo"].item() == out["dice_loss_pseudo"].item()
