@@ -285,3 +285,31 @@ def test_config_struct_layout_and_single_entry_point():
     src = "".join(open(os.path.join(REPO, "vae_segmentation_amd", "csrc", f)).read() for f in os.listdir(os.path.join(REPO, "vae_segmentation_amd", "csrc"))
                   if f.endswith((".h", ".hip", ".inc")) and f != "config.hip")
     assert src.count("getenv(") == 2, "launchers read vs_cfg(), not the environment (the two left sit inside the VS_G3B_ABLATE diagnostic build)"
+
+
+def test_wgrad_xcd_rank_model_is_a_bijection():
+    """csrc/wgrad.hip g3_xcd_rank (round 6): a layer's workgroups [b0, b0 + count) of the grouped weight-gradient grid are re-ranked so that XCD x (= workgroup
+    id mod 8) owns one contiguous run of ranks.  The same arithmetic in Python: every rank is hit exactly once for any start and count, and the ranks of one XCD
+    are consecutive (what puts the channel-block pairs of a tile, rank = k-split * pairs + pair, into one L2)."""
+    import random
+
+    def rank(b0, local, count):
+        x = (b0 + local) & 7
+        start = 0
+        for xx in range(8):
+            first = (xx - b0) & 7
+            cnt = (count - first + 7) >> 3 if first < count else 0
+            if xx < x:
+                start += cnt
+        return start + ((local - ((x - b0) & 7)) >> 3)
+
+    src = open(os.path.join(REPO, "vae_segmentation_amd", "csrc", "wgrad.hip")).read()
+    assert "const int first = (xx - b0) & 7;" in src and "return start + ((local - ((x - b0) & 7)) >> 3);" in src      # the model is the kernel's formula
+    rng = random.Random(1)
+    for _ in range(300):
+        b0, count = rng.randrange(0, 5000), rng.randrange(16, 1500)
+        ranks = [rank(b0, l, count) for l in range(count)]
+        assert sorted(ranks) == list(range(count)), (b0, count)
+        for x in range(8):
+            mine = sorted(r for l, r in enumerate(ranks) if (b0 + l) & 7 == x)
+            assert mine == list(range(mine[0], mine[0] + len(mine))) if mine else True
