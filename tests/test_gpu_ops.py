@@ -323,6 +323,29 @@ def test_linear_layers(dtype, c, s):
     assert relerr(b2g.grad.cpu(), b2.grad) < 2e-5
 
 
+@pytest.mark.parametrize("b", [1, 3, 4, 7, 16])
+def test_linear_layers_other_batch_sizes(b):
+    """vs_linear_fwd / vs_linear_bwd at the batch sizes behind the kernels' other NB instantiations (1 | 2 | 4 | 8 | 16 rows per workgroup; test_linear_layers runs b = 2):
+    the four-k-per-lane path with a gathered, an LDS-staged and an unpermuted activation, and the one-k path."""
+    ops = _ops()
+    dtype, dim = torch.bfloat16, 64
+    for c, s in ((32, 4), (256, 3), (64, 6)):
+        feat = rnd(b, c, s, s, s, seed=300 + c)
+        w1, b1 = rnd(dim, c * s ** 3, seed=301, scale=0.02), rnd(dim, seed=302, scale=0.1)
+        fq, w1r, b1r = q(feat, dtype).requires_grad_(True), w1.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+        y_ref = torch.relu(F.linear(fq.reshape(b, -1), w1r, b1r))
+        gy = rnd(b, dim, seed=303)
+        (y_ref * gy).sum().backward()
+        x_cl = to_cl(feat, c, dtype).requires_grad_(True)
+        wg, bg = w1.cuda().requires_grad_(True), b1.cuda().requires_grad_(True)
+        y = ops.LinearCL.apply(x_cl, wg, bg, True)
+        assert relerr(y.cpu(), y_ref.detach()) < 2e-5, (b, c, s)
+        y.backward(gy.cuda())
+        torch.cuda.synchronize()
+        assert relerr(from_cl(x_cl.grad, c), fq.grad) < TOL[dtype], (b, c, s)
+        assert relerr(wg.grad.cpu(), w1r.grad) < 2e-5 and relerr(bg.grad.cpu(), b1r.grad) < 2e-5, (b, c, s)
+
+
 def test_reparam_kl_dice_bce_label_ops():
     ops = _ops()
     from oracle import ref_cpu as O
