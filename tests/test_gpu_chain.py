@@ -160,7 +160,10 @@ def test_stride2_epilogue_apply_equals_backward_data_then_apply(case, dtype, lib
     """g1_kernel's epilogue apply (csrc/igemm.h, vs_conv_s2_bwd_data_applied): the backward-data launch of Conv3d(k2, s2) (scatter) / ConvTranspose3d(k2, s2) (gather) on a
     lazy input applies the InstanceNorm+ReLU backward to its own outputs — with the U-Net skip's parked gradient summed in — against the two launches it replaces
     (which tests/test_gpu_layers.py pins to CPU autograd)."""
-    ops = _ops()
+    _stride2_case(_ops(), case, dtype, lib_mode)
+
+
+def _stride2_case(ops, case, dtype, lib_mode):
     scatter, n, c, side, with_add = case          # side: the COARSE grid's extent; c channels on both sides
     torch.manual_seed(5)
     fine, coarse = (side * 2,) * 3, (side,) * 3
@@ -201,3 +204,16 @@ def test_stride2_epilogue_apply_equals_backward_data_then_apply(case, dtype, lib
     else:
         e = relerr(b.double().cpu(), a.double().cpu())
         assert e < {torch.float32: 2e-5, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}[dtype], "gx: %g" % e
+
+
+@pytest.mark.parametrize("scatter", [0, 1])
+def test_stride2_epilogue_apply_on_the_exact_f32_kernels(scatter):
+    """the same with the parity mode's limb arithmetic switched off (vs_config.f32_limbs = 0: g1_kernel<float, ..., LIMB = false, EA>) — an A/B configuration, kept correct"""
+    ops = _ops()
+    with ops.config(f32_limbs=0):
+        was = ops.is_deterministic()
+        ops.set_deterministic(True)
+        try:
+            _stride2_case(ops, (scatter, 2, 32, 6, True), torch.float32, "det")
+        finally:
+            ops.set_deterministic(was)
