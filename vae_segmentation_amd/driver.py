@@ -208,7 +208,6 @@ def save_checkpoint(prefix, epoch_label, model, optimizer, best):
 # validation (main_source.py:688-822): batch 1, hard Dice of the argmax prediction against the label
 # ----------------------------------------------------------------------------------------------------
 @torch.no_grad()
-@torch.no_grad()
 def validate(method, model, loader, nc):
     """main_source.py:688-822 / main_target.py:754-805: batch-1 forwards and hard Dice per case.  Forward only (no autograd graph is recorded: nothing is kept
     for a backward pass — the per-(n, c) statistics the conv epilogues accumulate are the FORWARD's own, the next layer normalises with them)."""
@@ -251,7 +250,8 @@ def run(args, side="source"):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert args.save_epoch % args.eval_epoch == 0
+    if args.save_epoch % args.eval_epoch != 0:                            # main_source.py asserts this; an assert would vanish under python -O
+        raise SystemExit("--save_epoch must be a multiple of --eval_epoch")
     nc = n_class_of(args)
     method = args.method
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
