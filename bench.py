@@ -74,7 +74,10 @@ def parse():
     ap.add_argument("--master-port", type=int, default=29533)
     ap.add_argument("--recompute", action="store_true", help="activation recomputation in the Down / Up blocks (joint_model.set_recompute, DESIGN 4.4)")
     ap.add_argument("--no-exchange-forms", action="store_true", help="N > 1: skip the no-exchange / other-exchange-form timing legs")
-    ap.add_argument("--no-other-form", action="store_true", help="N > 1: time the no-exchange leg but not the other exchange form")
+    ap.add_argument("--other-form", action="store_true", help="N > 1: after the no-exchange leg, also time the OTHER exchange form (two buckets, bucket 0 all-reduced beside "
+                    "the remaining weight-gradient nodes of the same graph) for the record.  Opt-in since the end of round 6: the form has never run on more than one "
+                    "RCCL rank, and rank 0's line must not depend on a leg that is not the measurement")
+    ap.add_argument("--no-other-form", action="store_true", help="(default since round 6; kept for older command lines)")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1, default workload: skip the configs[3] / configs[4] entries (`other_configs`)")
     ap.add_argument("--legs-budget-s", type=float, default=60.0, help="N > 1: the other exchange form is timed only if everything before it "
                     "(set-up, main timing, the no-exchange leg) took less than this on every rank: rank 0's line must not wait for it")
@@ -427,10 +430,11 @@ def main():
         # every rank takes the same branch (the legs are collective): the slowest rank's clock decides
         spent = max_over_ranks(time.perf_counter() - t_process)
         exchange["seconds_before_other_form"] = round(spent, 1)
-        if a.no_other_form or spent > a.legs_budget_s:
-            if not a.no_other_form:
+        if not a.other_form or a.no_other_form or spent > a.legs_budget_s:
+            if a.other_form and not a.no_other_form:
                 exchange["other_form_skipped"] = "%.0f s spent before it (budget %.0f s): the line is printed instead" % (spent, a.legs_budget_s)
-            step, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, True, info=info1)
+            # the step rebuilt here only feeds rank 0's eager family-timing pass (loss_fn, seg_params): without the exchange — no further collective is captured
+            step, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, False, info=info1)
         else:
             step, loss_fn, seg_params, closer = make_step(a, a.dtype, rank, True, overlap=other, info=info1)
             dt_o, _ = timed_steps(step, n_x, 3, fence)

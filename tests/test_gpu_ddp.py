@@ -122,7 +122,9 @@ sync2.broadcast_parameters(0)
 gs = T.GraphedStep(lambda: T.seg_train_losses(seg2, img_g, lab_g, eps=1e-6), params2, opt2, grad_sync=sync2, warmup=1)
 # overlapped form: ONE graph holding the exchange when the collectives capture (RCCL: round 6), two graphs around an eager exchange otherwise (gloo)
 assert (gs.graph2 is not None) == (OVERLAP and not gs.tail)
-assert gs.tail == (backend == "nccl"), (gs.tail, backend)
+INJECT = os.environ.get("VS_TEST_FAIL_TAIL_CAPTURE") == "1"     # a failure raised INSIDE the capture of the tail: every rank must fall back to the eager tail
+assert gs.tail == (backend == "nccl" and not INJECT), (gs.tail, backend)
+assert gs.tail_fallback == (backend == "nccl" and INJECT)
 with torch.no_grad():                                          # the capture's warm-up moved nothing (no optimiser step), start is the fill
     pass
 for _ in range(3):
@@ -231,11 +233,11 @@ print("rank %%d ok" %% rank)
 """
 
 
-def _launch(tmp_path, world, backend, port, overlap=False, worker=None):
+def _launch(tmp_path, world, backend, port, overlap=False, worker=None, extra_env=None):
     script = tmp_path / "ddp_worker.py"
     script.write_text((worker or WORKER) % {"repo": REPO})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), VS_TEST_BACKEND=backend,
-               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", VS_TEST_OVERLAP="1" if overlap else "0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4", VS_TEST_OVERLAP="1" if overlap else "0", **(extra_env or {}))
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(world)]
     outs = [p.communicate(timeout=900)[0].decode() for p in procs]
@@ -248,6 +250,13 @@ def _launch(tmp_path, world, backend, port, overlap=False, worker=None):
 @pytest.mark.parametrize("overlap", [False, True])
 def test_one_rank_rccl_graphed_step_with_flat_grad_sync(tmp_path, overlap):
     _launch(tmp_path, 1, "nccl", 29551 + 10 * overlap, overlap)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_one_rank_rccl_tail_capture_failure_falls_back_to_the_eager_tail(tmp_path, overlap):
+    """train.GraphedStep._capture_guarded: an exception raised inside the capture of the tail (injected right after the all-reduce was captured) must leave a
+    working step — pass replayed from the graph, exchange / optimiser / re-pack eager — whose three steps equal the single-process run like the captured form's."""
+    _launch(tmp_path, 1, "nccl", 29581 + 10 * overlap, overlap, extra_env={"VS_TEST_FAIL_TAIL_CAPTURE": "1"})
 
 
 @pytest.mark.parametrize("overlap", [False, True])
@@ -264,7 +273,7 @@ def test_two_rank_capturable_agreement_and_loss_scaler_overflow_on_one_rank(tmp_
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` (no torchrun) must start its ranks itself and print ONE JSON line with n_gpus = 2."""
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "3",
-                          "--warmup", "1", "--side", "64", "--no-families", "--master-port", "29553"],
+                          "--warmup", "1", "--side", "64", "--no-families", "--other-form", "--master-port", "29553"],
                          env=dict(os.environ, PYTHONPATH=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -300,7 +309,7 @@ def test_bench_one_rank_rccl_whole_step_is_one_graph():
     """bench.py --force-dist on one rank through RCCL: the all-reduce, the SGD launch and the weight re-pack are captured into the step's graph
     (config.tail_in_graph) and the line carries the exchange legs."""
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "5", "--warmup", "2", "--side", "64",
-                          "--no-families", "--no-cpu-baseline", "--no-fp32-mode", "--master-port", "29557"],
+                          "--no-families", "--no-cpu-baseline", "--no-fp32-mode", "--other-form", "--master-port", "29557"],
                          env=dict(os.environ, PYTHONPATH=REPO, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])

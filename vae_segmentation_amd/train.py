@@ -296,6 +296,7 @@ class GraphedStep:
         self.loss = None
         self.aux = None
         self.recaptures = 0
+        self.tail_fallback = False               # True: the tail was meant to be captured and the capture failed (see _capture_guarded)
         two_phase = self._two_phase = grad_sync is not None and len(grad_sync.buckets) > 1
         if capture_tail is None:
             capture_tail = os.environ.get("VS_GRAPH_TAIL", "1") != "0"
@@ -317,6 +318,42 @@ class GraphedStep:
             self.grad_sync = grad_sync = _ddp.FlatGradSync(self.params, overlap=False, exchange=False)
             self._own_sync = True
         self._warm(warmup)
+        self._capture_guarded()
+
+    def _capture_guarded(self):
+        """_capture(); when the captured tail holds a collective (RCCL all-reduce inside the graph), a capture that fails on ANY rank sends EVERY rank to the
+        eager tail instead of ending the job: the ranks agree on the outcome with one eager collective (nothing collective was executed by the capture
+        itself, on the rank that failed or on the ones that did not, so they stay paired), the pass is warmed once more and captured WITHOUT the tail —
+        step() then runs exchange, optimiser and re-pack eagerly behind the replay (the round-3 form).  ddp.collective_capturable() probes a tiny
+        all-reduce beforehand; this covers what the probe cannot (the real bucket, more than one rank, the stack's state at that moment)."""
+        import torch.distributed as dist
+        from . import ddp as _ddp
+        s = self.grad_sync
+        if not (self.tail and s is not None and getattr(s, "exchange", True) and dist.is_initialized()):
+            return self._capture()
+        err = None
+        try:
+            self._capture()
+        except Exception as e:                   # noqa: BLE001 — whatever the stack refused inside the capture
+            err = e
+            if torch.cuda.is_current_stream_capturing():
+                raise                            # the failed capture could not even be ended: nothing to fall back to in this process
+            try:
+                torch.cuda.synchronize()
+            except Exception:                    # noqa: BLE001
+                pass
+        ok = _ddp._agree(err is None, s.group)
+        _ddp.note_eager_collective()
+        if ok:
+            return
+        import sys
+        print("vae_segmentation_amd.train: capturing the step's tail (all-reduce + optimiser) failed on %s (%s); every rank keeps the tail eager"
+              % ("this rank" if err is not None else "another rank", "%s: %s" % (type(err).__name__, err) if err is not None else "-"), file=sys.stderr, flush=True)
+        self.graph = self.graph2 = None
+        self.tail = False
+        self.tail_fallback = True
+        s._works = []
+        self._warm(1)
         self._capture()
 
     def _warm(self, passes):
@@ -374,11 +411,22 @@ class GraphedStep:
             if self.tail:
                 s = self.grad_sync
                 s._stragglers([p.grad for p in self.params])      # bookkeeping only (which parameters got no gradient): _prepare_tail saw no stragglers
-                s.start(0)
-                if two_phase:
-                    ops.flush_wgrads()           # the bucket-1 layers' weight gradients (the 96^3 / 48^3 levels): graph nodes BESIDE bucket 0's all-reduce node
-                    s.start(1)
-                s.wait()
+                try:
+                    s.start(0)
+                    if os.environ.get("VS_TEST_FAIL_TAIL_CAPTURE") == "1" and getattr(s, "exchange", True):
+                        raise RuntimeError("injected failure inside the capture (tests/test_gpu_ddp.py)")
+                    if two_phase:
+                        ops.flush_wgrads()       # the bucket-1 layers' weight gradients (the 96^3 / 48^3 levels): graph nodes BESIDE bucket 0's all-reduce node
+                        s.start(1)
+                    s.wait()
+                except Exception:
+                    # leave the capture JOINED before the error travels on: a collective started on the process group's stream that never joins back makes
+                    # capture_end fail ("unjoined work") with the capture still active — nothing could be captured in this process afterwards (_capture_guarded)
+                    try:
+                        s.wait()
+                    except Exception:            # noqa: BLE001
+                        pass
+                    raise
                 kw = {} if self.scaler is None else {"scaler": self.scaler}
                 self.optimizer.step_with(*s.live(), device_hyper=True, **kw)
         if self.tail:
@@ -411,7 +459,7 @@ class GraphedStep:
                 self.recaptures += 1
                 self.graph = None                            # the old capture's pool goes first
                 self._warm(1)                                # one eager pass with the new set: who gets a gradient now, tables rebuilt outside the capture
-                self._capture()
+                self._capture_guarded()
         if self.tail:                                        # (a re-capture may have found stragglers and left the tail eager)
             self.optimizer.sync_hyper()                      # a scheduler moved lr / momentum / weight decay: three floats in device memory, no re-capture
             self.graph.replay()
