@@ -339,6 +339,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(a))        # nothing in this process has touched the GPU
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this pool's driver supports dmabuf IPC only: RCCL needs it on every rank, whoever launched us (before the HIP runtime loads)
     # fd 1 carries the JSON line and nothing else: native libraries (RCCL prints a version banner to stdout at init) get fd 2
     sys.stdout.flush()
     json_fd = os.dup(1)

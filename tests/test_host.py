@@ -313,3 +313,18 @@ def test_wgrad_xcd_rank_model_is_a_bijection():
         for x in range(8):
             mine = sorted(r for l, r in enumerate(ranks) if (b0 + l) & 7 == x)
             assert mine == list(range(mine[0], mine[0] + len(mine))) if mine else True
+
+
+def test_isa_phase_counts_finds_the_tile_loop_of_k3t():
+    """tools/isa_phase_counts.py (no GPU: device-only compile to assembly): the persistent loop of the 8-channel full-resolution kernel holds the tile's 72 MFMAs
+    (9 k-groups x 8 output rows), two barriers per tile plus the statistics flush's, and a vector instruction count in the range DESIGN.md section 9 reasons with."""
+    import re
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "isa_phase_counts.py"), os.path.join(REPO, "vae_segmentation_amd", "csrc", "igemm_k3_bf16.hip"),
+                          "k3t_kernel<0, false, 8, true, unsigned short, false>"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    m = re.search(r"loop: (\d+) instructions, (\d+) barriers", out.stdout)
+    assert m and int(m.group(2)) == 3, out.stdout
+    tot = [ln for ln in out.stdout.splitlines() if ln.startswith("loop total")][0].split()
+    valu, packed, mfma = int(tot[2]), int(tot[3]), int(tot[4])
+    assert mfma == 72 and 300 <= valu + packed <= 800, out.stdout
