@@ -68,7 +68,10 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     constexpr int XAUX = CH ? VS_AUX_SC1 : 0;
     constexpr int NT = 64 * NW;                          // threads
     static_assert(NW == 4 || NW == 8, "waves per workgroup");
-    constexpr int NIT = TVC * 4 / NT;                    // 16-byte fragments per thread per stage
+    // Only the REAL voxels of the padded sample are staged (end of round 6): the zero padding — 296 of the 512 voxels of a padded 6^3 sample, 98 of 125 at 3^3 — is
+    // written to LDS ONCE per body instead of being loaded (offset -1), normalised and masked again in every stage by every workgroup of the sample.
+    constexpr int VRMAX = TVC == 128 ? 32 : 216;         // real voxels: V <= 32 in the small class (k3s_launch), <= 6^3 where the padded volume is <= 512
+    constexpr int NIT = (VRMAX * 4 + NT - 1) / NT;       // 16-byte fragments per thread per stage
     constexpr int NKW = (27 + NW - 1) / NW;              // taps per wave per chunk (wave w: w, w + NW, ...): 7 or 4
     constexpr int NWI = NKW;                             // weight fragments per thread per stage: its wave's taps
     constexpr int ES = (int)sizeof(T), EPL = 16 / ES, CHS = 64 / ES;     // element size, elements per fragment, channels per stage
@@ -92,17 +95,25 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     // division — 24 of those made the prologue the longest phase of the launch
     const float inv_px = 1.0f / (float)PX, inv_py = 1.0f / (float)PY, inv_w = 1.0f / (float)p.W, inv_h = 1.0f / (float)p.H;
     auto sdiv = [](int a, float inv_d) { return (int)(((float)a + 0.5f) * inv_d); };
-    // ---- staging geometry: fragment b = 16-byte part (tid & 3) of padded voxel (tid >> 2) + 64 b ---------------------------
+    // ---- staging geometry: fragment b = 16-byte part (tid & 3) of REAL voxel (tid >> 2) + (NT / 4) b of the sample ---------------------------
     const int part = tid & 3;
-    int goff[NIT];                                       // byte offset in x of this fragment for chunk 0, -1 = padding
-    unsigned int swzbits = 0;
+    int goff[NIT];                                       // byte offset in x of this fragment for chunk 0, -1 = no such voxel
+    int loff[NIT];                                       // its LDS byte offset in the padded tile, part swizzle included (no such voxel: a zero written to padding voxel 0)
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
-        const int pv = (tid >> 2) + (NT / 4) * b;
-        const int t2 = sdiv(pv, inv_px), px = pv - t2 * PX, pz = sdiv(t2, inv_py), py = t2 - pz * PY;
-        const bool ok = pv < TV && px >= 1 && px <= p.W && py >= 1 && py <= p.H && pz >= 1 && pz <= p.D;
-        goff[b] = ok ? ((((n * p.D + pz - 1) * p.H + py - 1) * p.W + px - 1) * p.C + part * EPL) * ES : -1;
-        swzbits |= (unsigned int)((px >> 2) & 1) << b;
+        const int rv = (tid >> 2) + (NT / 4) * b;
+        const bool ok = rv < V;
+        const int t2 = sdiv(rv, inv_w), vx = rv - t2 * p.W, vz = sdiv(t2, inv_h), vy = t2 - vz * p.H;
+        const int px = vx + 1, pv = ((vz + 1) * PY + vy + 1) * PX + px;
+        goff[b] = ok ? ((n * V + rv) * p.C + part * EPL) * ES : -1;
+        loff[b] = ok ? pv * 64 + ((part ^ (((px >> 2) & 1) << 1)) * 16) : part * 16;
+    }
+    static_assert((TVC * 4) % NT == 0, "zero fill: whole rounds of 16-byte stores");
+    {
+        // the padding (and everything the previous user of this LDS left there: cross-wave partials, apply tables): zeros, once per body — real voxels are rewritten by every stage
+        const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < TVC * 4 / NT; ++k) *(u32x4*)(s_tile + (tid + NT * k) * 16) = z4;
     }
     // weights: with the taps split over the waves, tap (wave + 4 i)'s A fragment is used by this wave only — it goes from global
     // straight into the lane's registers (through LDS it cost 7 ds_write_b128 + 7 ds_read_b128 per thread and stage for no reuse)
@@ -151,9 +162,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
             }
-            const int pv = (tid >> 2) + (NT / 4) * b;     // < TVC: the tile region holds TVC voxels, fragments beyond TV are zeros
-            const int pw = part ^ (int)(((swzbits >> b) & 1u) << 1);
-            *(u32x4*)(s_tile + pv * 64 + pw * 16) = v;
+            *(u32x4*)(s_tile + loff[b]) = v;
         }
     };
 
