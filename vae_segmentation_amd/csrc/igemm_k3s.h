@@ -60,6 +60,8 @@ static inline int k3s_col_tile(bool small) { return small ? 16 * K3S_NCG_SMALL :
 // NW: waves per workgroup (4, or 8 in the chain kernels).  These bodies are instruction-bound at one wave per SIMD with their phases in series
 // (tools/chain_stamps.py: per stage 0.45 us of normalise + LDS write of the WHOLE padded sample, 0.45 us of LDS reads + MFMA, 0.35 us of barrier skew):
 // with eight waves the staging pass and the 27 taps are split eight ways — two waves per SIMD interleave one another's phases.
+template <int TVC> static constexpr int k3s_tile_bytes() { return 2 * TVC * 64 > 16384 ? 2 * TVC * 64 : 16384; }      // two stage buffers; at least 16 KB (the cross-wave partials alias them)
+
 template <bool SUMS, int TVC, bool HS, typename T, bool CH, int XR = 2, int NW = 4>
 __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const int ct, const int rb0, char* smem, unsigned int* wait_ctr = nullptr,
                                          unsigned int wait_target = 0, unsigned int* fault = nullptr, const int sb = 0 /* CH_STAMP base */) {
@@ -81,7 +83,10 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     float* s_red = (float*)(smem + K3S_LDS_RED);
     char* s_tile = smem + K3S_LDS_TILE;
     const int PX = p.W + 2, PY = p.H + 2, TV = (p.D + 2) * PY * PX, V = p.D * p.H * p.W;
-    constexpr int tile_bytes = TVC * 64 > 16384 ? TVC * 64 : 16384;
+    // TWO tile buffers (end of round 6): stage ch goes to buffer ch & 1, so the write of stage ch + 1 need not wait until every wave has read stage ch — one barrier
+    // per stage instead of two (with eight waves a barrier is ~0.17 us of arrival skew: tools/chain_stamps.py).  Safe with one: a wave writes stage ch + 1 into the
+    // buffer stage ch - 1 was read from only after passing the barrier of stage ch, which every wave reaches after its MFMAs of stage ch - 1.
+    constexpr int tile_bytes = k3s_tile_bytes<TVC>();
     float* s_scale = (float*)(s_tile + tile_bytes);
     float* s_shift = s_scale + p.C;
 
@@ -113,7 +118,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
         // the padding (and everything the previous user of this LDS left there: cross-wave partials, apply tables): zeros, once per body — real voxels are rewritten by every stage
         const u32x4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int k = 0; k < TVC * 4 / NT; ++k) *(u32x4*)(s_tile + (tid + NT * k) * 16) = z4;
+        for (int k = 0; k < 2 * TVC * 4 / NT; ++k) *(u32x4*)(s_tile + (tid + NT * k) * 16) = z4;      // both stage buffers
     }
     // weights: with the taps split over the waves, tap (wave + 4 i)'s A fragment is used by this wave only — it goes from global
     // straight into the lane's registers (through LDS it cost 7 ds_write_b128 + 7 ds_read_b128 per thread and stage for no reuse)
@@ -135,7 +140,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
         for (int b = 0; b < NIT; ++b)
             xv[b] = __builtin_bit_cast(u32x4, vs_raw_buffer_load_b128(xrsrc, goff[b] >= 0 ? goff[b] + ch * 64 : -1, 0, XAUX));
     };
-    auto write_stage = [&](int ch, const u32x4 (&xv)[NIT], const u32x4 (&wv)[NWI]) {
+    auto write_stage = [&](int ch, const u32x4 (&xv)[NIT], const int buf) {
         f32x2 sc[4], sh[4];                              // 16-bit: 8 channels; fp32: 4 (sc[0..1], sh[0..1])
         if (has_stats) {
 #pragma unroll
@@ -162,7 +167,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
             }
-            *(u32x4*)(s_tile + loff[b]) = v;
+            *(u32x4*)(s_tile + buf * (TVC * 64) + loff[b]) = v;
         }
     };
 
@@ -238,7 +243,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     if constexpr (CH) CH_STAMP(sb + 3);
 
     u32x4 wa[NKW];                                       // the current stage's A fragments (the stage registers are re-requested before the MFMAs)
-    auto multiply = [&]() {
+    auto multiply = [&](const int buf) {
         // no branches: a wave whose 7th tap does not exist (waves 3: taps 3, 7, ..., 27) multiplies a zeroed A fragment, so the
         // scheduler sees one block and keeps the next taps' LDS reads in flight under the MFMAs
 #pragma unroll
@@ -250,7 +255,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
             }
             u32x4 b[NCG];
 #pragma unroll
-            for (int cg = 0; cg < NCG; ++cg) b[cg] = *(const u32x4*)(s_tile + boff[i][cg]);
+            for (int cg = 0; cg < NCG; ++cg) b[cg] = *(const u32x4*)(s_tile + buf * (TVC * 64) + boff[i][cg]);
 #pragma unroll
             for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma16(a, b[cg], acc[cg], (T*)nullptr);
         }
@@ -260,9 +265,8 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
         for (int r = 0; r < XR; ++r) {
             const int ch = ch0 + r;
             if (ch >= nst) break;                         // workgroup-uniform
-            if (ch > 0) __syncthreads();                 // every wave is done reading the previous stage
             KS_TICK(1);
-            write_stage(ch, xv[r], wv[r & 1]);
+            write_stage(ch, xv[r], r & 1);               // XR is even: ch & 1 == r & 1
             KS_TICK(2);
             __syncthreads();
             KS_TICK(3);
@@ -271,7 +275,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
             if (ch + 2 < nst) load_w(ch + 2, wv[r & 1]);
             if (ch + XR < nst) load_x(ch + XR, xv[r]);
             KS_TICK(4);
-            multiply();
+            multiply(r & 1);
             KS_TICK(5);
         }
     }
@@ -452,7 +456,7 @@ static inline bool k3s_takes(const G1Params& p, int ck) {
 
 template <typename T, bool SUMS, int TVC, bool HS>
 static int k3s_launch_t(const G1Params& p, int ctiles, hipStream_t stream) {
-    const size_t lds = K3S_LDS_TILE + (size_t)(TVC * 64 > 16384 ? TVC * 64 : 16384) + (size_t)2 * p.C * sizeof(float);
+    const size_t lds = K3S_LDS_TILE + (size_t)k3s_tile_bytes<TVC>() + (size_t)2 * p.C * sizeof(float);
     if (lds > 160 * 1024) return VS_ESHAPE;
     auto kern = k3s_kernel<SUMS, TVC, HS, T>;
     static const hipError_t attr_err = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -505,7 +509,7 @@ static int k3s_chain_launch(K3Chain c, bool bwd, hipStream_t stream) {
     if (grid == 0) return VS_ESHAPE;
     const bool small = TV <= 128 && V <= 32;
     const int tvc = small ? 128 : 512;
-    const size_t lds = K3S_LDS_TILE + (size_t)(tvc * 64 > 16384 ? tvc * 64 : 16384) + (size_t)2 * cmax * sizeof(float);
+    const size_t lds = K3S_LDS_TILE + (size_t)(small ? k3s_tile_bytes<128>() : k3s_tile_bytes<512>()) + (size_t)2 * cmax * sizeof(float);
     if (lds > 160 * 1024 || (size_t)4 * cmax * sizeof(float) > 16384) return VS_ESHAPE;
     int threads = 256;
     auto go = [&](auto kern) -> int {
