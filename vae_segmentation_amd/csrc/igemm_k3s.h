@@ -60,10 +60,64 @@ static inline int k3s_col_tile(bool small) { return small ? 16 * K3S_NCG_SMALL :
 // NW: waves per workgroup (4, or 8 in the chain kernels).  These bodies are instruction-bound at one wave per SIMD with their phases in series
 // (tools/chain_stamps.py: per stage 0.45 us of normalise + LDS write of the WHOLE padded sample, 0.45 us of LDS reads + MFMA, 0.35 us of barrier skew):
 // with eight waves the staging pass and the 27 taps are split eight ways — two waves per SIMD interleave one another's phases.
+// What a body's threads need to know about the volume and their column tile, and nothing about the layer: computed once per kernel (the chain kernels' layers share
+// it; recomputed per layer it was ~0.6 us of every layer's prologue — tools/chain_stamps.py, "entry -> weights requested").
+template <int TVC, int NW> struct K3SGeo {
+    static constexpr int NT = 64 * NW;
+    static constexpr int VRMAX = TVC == 128 ? 32 : 216;                  // real voxels: V <= 32 in the small class (k3s_launch), <= 6^3 where the padded volume is <= 512
+    static constexpr int NIT = (VRMAX * 4 + NT - 1) / NT;                // 16-byte fragments per thread per stage
+    static constexpr int NKW = (27 + NW - 1) / NW;                       // taps per wave per chunk
+    static constexpr int NCG = TVC == 128 ? K3S_NCG_SMALL : K3S_NCG;    // 16-column groups per workgroup
+    int loff[NIT];                                       // staging: LDS byte offset of fragment b in the padded tile, part swizzle included (no such voxel: padding voxel 0)
+    int boff[NKW][NCG];                                  // B fragment of (tap wave + NW i, column group cg): LDS byte offset
+};
+template <int TVC, int NW>
+__device__ __forceinline__ void k3s_geometry(K3SGeo<TVC, NW>& geo, const int D, const int H, const int W, const int ct) {
+    using G = K3SGeo<TVC, NW>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 15, g = lane >> 4, part = tid & 3;
+    const int PX = W + 2, PY = H + 2, V = D * H * W;
+    // a / d for 0 <= a < 2048, 1 <= d <= 10 (everything here is that small): one multiply instead of a ~45-instruction integer
+    // division — 24 of those made the prologue the longest phase of the launch
+    const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H;
+    auto sdiv = [](int a, float inv_d) { return (int)(((float)a + 0.5f) * inv_d); };
+    // staging: fragment b = 16-byte part (tid & 3) of REAL voxel (tid >> 2) + (NT / 4) b of the sample
+#pragma unroll
+    for (int b = 0; b < G::NIT; ++b) {
+        const int rv = (tid >> 2) + (G::NT / 4) * b;
+        const int t2 = sdiv(rv, inv_w), vx = rv - t2 * W, vz = sdiv(t2, inv_h), vy = t2 - vz * H;
+        const int px = vx + 1, pv = ((vz + 1) * PY + vy + 1) * PX + px;
+        geo.loff[b] = rv < V ? pv * 64 + ((part ^ (((px >> 2) & 1) << 1)) * 16) : part * 16;
+    }
+    // B fragment of (tap kg = wave + NW i, column group cg): padded voxel (z + dz, y + dy, x + dx) of column voxel (z, y, x), part g
+    // stored at part ^ ((px >> 2) & 1) << 1
+    constexpr int CW = 16 * G::NCG;
+    int cz[G::NCG], cy[G::NCG], cx[G::NCG];
+#pragma unroll
+    for (int cg = 0; cg < G::NCG; ++cg) {
+        int v = ct * CW + cg * 16 + col;
+        if (v >= V) v = 0;
+        const int t2 = sdiv(v, inv_w);
+        cx[cg] = v - t2 * W;
+        cz[cg] = sdiv(t2, inv_h);
+        cy[cg] = t2 - cz[cg] * H;
+    }
+#pragma unroll
+    for (int i = 0; i < G::NKW; ++i) {
+        int kg = wave + NW * i;
+        if (kg > 26) kg = 26;
+        const int dz = kg / 9, dy = (kg / 3) % 3, dx = kg % 3;
+#pragma unroll
+        for (int cg = 0; cg < G::NCG; ++cg) {
+            const int px = cx[cg] + dx;
+            geo.boff[i][cg] = (((cz[cg] + dz) * PY + cy[cg] + dy) * PX + px) * 64 + ((g ^ (((px >> 2) & 1) << 1)) * 16);
+        }
+    }
+}
+
 template <int TVC> static constexpr int k3s_tile_bytes() { return 2 * TVC * 64 > 16384 ? 2 * TVC * 64 : 16384; }      // two stage buffers; at least 16 KB (the cross-wave partials alias them)
 
 template <bool SUMS, int TVC, bool HS, typename T, bool CH, int XR = 2, int NW = 4>
-__device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const int ct, const int rb0, char* smem, unsigned int* wait_ctr = nullptr,
+__device__ __forceinline__ void k3s_body(const G1Params& p, const K3SGeo<TVC, NW>& geo, const int n, const int ct, const int rb0, char* smem, unsigned int* wait_ctr = nullptr,
                                          unsigned int wait_target = 0, unsigned int* fault = nullptr, const int sb = 0 /* CH_STAMP base */) {
     KS_TICK_INIT
     CH_STAMP(sb + 0);
@@ -72,8 +126,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     static_assert(NW == 4 || NW == 8, "waves per workgroup");
     // Only the REAL voxels of the padded sample are staged (end of round 6): the zero padding — 296 of the 512 voxels of a padded 6^3 sample, 98 of 125 at 3^3 — is
     // written to LDS ONCE per body instead of being loaded (offset -1), normalised and masked again in every stage by every workgroup of the sample.
-    constexpr int VRMAX = TVC == 128 ? 32 : 216;         // real voxels: V <= 32 in the small class (k3s_launch), <= 6^3 where the padded volume is <= 512
-    constexpr int NIT = (VRMAX * 4 + NT - 1) / NT;       // 16-byte fragments per thread per stage
+    constexpr int NIT = K3SGeo<TVC, NW>::NIT;            // 16-byte fragments per thread per stage
     constexpr int NKW = (27 + NW - 1) / NW;              // taps per wave per chunk (wave w: w, w + NW, ...): 7 or 4
     constexpr int NWI = NKW;                             // weight fragments per thread per stage: its wave's taps
     constexpr int ES = (int)sizeof(T), EPL = 16 / ES, CHS = 64 / ES;     // element size, elements per fragment, channels per stage
@@ -96,22 +149,13 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
     const int nst = p.nch * SPC;                         // stages
     const u32x4* __restrict__ wp = (const u32x4*)p.wp;
 
-    // a / d for 0 <= a < 2048, 1 <= d <= 10 (everything here is that small): one multiply instead of a ~45-instruction integer
-    // division — 24 of those made the prologue the longest phase of the launch
-    const float inv_px = 1.0f / (float)PX, inv_py = 1.0f / (float)PY, inv_w = 1.0f / (float)p.W, inv_h = 1.0f / (float)p.H;
-    auto sdiv = [](int a, float inv_d) { return (int)(((float)a + 0.5f) * inv_d); };
-    // ---- staging geometry: fragment b = 16-byte part (tid & 3) of REAL voxel (tid >> 2) + (NT / 4) b of the sample ---------------------------
+    // ---- staging: fragment b = 16-byte part (tid & 3) of REAL voxel (tid >> 2) + (NT / 4) b of the sample (LDS offsets: geo.loff) ---------------------------
     const int part = tid & 3;
     int goff[NIT];                                       // byte offset in x of this fragment for chunk 0, -1 = no such voxel
-    int loff[NIT];                                       // its LDS byte offset in the padded tile, part swizzle included (no such voxel: a zero written to padding voxel 0)
 #pragma unroll
     for (int b = 0; b < NIT; ++b) {
         const int rv = (tid >> 2) + (NT / 4) * b;
-        const bool ok = rv < V;
-        const int t2 = sdiv(rv, inv_w), vx = rv - t2 * p.W, vz = sdiv(t2, inv_h), vy = t2 - vz * p.H;
-        const int px = vx + 1, pv = ((vz + 1) * PY + vy + 1) * PX + px;
-        goff[b] = ok ? ((n * V + rv) * p.C + part * EPL) * ES : -1;
-        loff[b] = ok ? pv * 64 + ((part ^ (((px >> 2) & 1) << 1)) * 16) : part * 16;
+        goff[b] = rv < V ? ((n * V + rv) * p.C + part * EPL) * ES : -1;
     }
     static_assert((TVC * 4) % NT == 0, "zero fill: whole rounds of 16-byte stores");
     {
@@ -167,7 +211,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = ok ? a[i] : 0u;
             }
-            *(u32x4*)(s_tile + buf * (TVC * 64) + loff[b]) = v;
+            *(u32x4*)(s_tile + buf * (TVC * 64) + geo.loff[b]) = v;
         }
     };
 
@@ -209,32 +253,6 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = row0 + r < p.M ? p.bias[row0 + r] : 0.f;
     }
-    // B fragment of (tap kg = wave + 4 i, column group cg): padded voxel (z + dz, y + dy, x + dx) of column voxel (z, y, x), part g
-    // stored at part ^ ((px >> 2) & 1) << 1
-    int boff[NKW][NCG];
-    {
-        int cz[NCG], cy[NCG], cx[NCG];
-#pragma unroll
-        for (int cg = 0; cg < NCG; ++cg) {
-            int v = ct * CW + cg * 16 + col;
-            if (v >= V) v = 0;
-            const int t2 = sdiv(v, inv_w);
-            cx[cg] = v - t2 * p.W;
-            cz[cg] = sdiv(t2, inv_h);
-            cy[cg] = t2 - cz[cg] * p.H;
-        }
-#pragma unroll
-        for (int i = 0; i < NKW; ++i) {
-            int kg = wave + NW * i;
-            if (kg > 26) kg = 26;
-            const int dz = kg / 9, dy = (kg / 3) % 3, dx = kg % 3;
-#pragma unroll
-            for (int cg = 0; cg < NCG; ++cg) {
-                const int px = cx[cg] + dx;
-                boff[i][cg] = (((cz[cg] + dz) * PY + cy[cg] + dy) * PX + px) * 64 + ((g ^ (((px >> 2) & 1) << 1)) * 16);
-            }
-        }
-    }
     f32x4 acc[NCG];
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) acc[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -255,7 +273,7 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const int n, const i
             }
             u32x4 b[NCG];
 #pragma unroll
-            for (int cg = 0; cg < NCG; ++cg) b[cg] = *(const u32x4*)(s_tile + buf * (TVC * 64) + boff[i][cg]);
+            for (int cg = 0; cg < NCG; ++cg) b[cg] = *(const u32x4*)(s_tile + buf * (TVC * 64) + geo.boff[i][cg]);
 #pragma unroll
             for (int cg = 0; cg < NCG; ++cg) acc[cg] = mfma16(a, b[cg], acc[cg], (T*)nullptr);
         }
@@ -376,7 +394,9 @@ template <bool SUMS, int TVC, bool HS, typename T = unsigned short>
 __global__ __launch_bounds__(64 * K3SWaves<TVC>::NW) __attribute__((amdgpu_waves_per_eu(K3SWaves<TVC>::NW / 4, 2))) void k3s_kernel(const G1Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = blockIdx.x / p.tiles_per_sample, ct = blockIdx.x - n * p.tiles_per_sample;
-    k3s_body<SUMS, TVC, HS, T, false, 2, K3SWaves<TVC>::NW>(p, n, ct, (int)blockIdx.y /* 16-row block */, smem);
+    K3SGeo<TVC, K3SWaves<TVC>::NW> geo;
+    k3s_geometry(geo, p.D, p.H, p.W, ct);
+    k3s_body<SUMS, TVC, HS, T, false, 2, K3SWaves<TVC>::NW>(p, geo, n, ct, (int)blockIdx.y /* 16-row block */, smem);
 }
 
 // ---- chain kernels (chain.h): the convolutions of a DoubleConv at one of these volumes in ONE launch --------------------------------------------
@@ -392,6 +412,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
     if (item >= c.items) return;
     const int ctiles = c.p[0].tiles_per_sample, ct = item % ctiles, rb0 = item / ctiles;
     const unsigned int items = (unsigned int)c.items;
+    K3SGeo<TVC, NW> geo;                                 // the layers of a chain share the volume and the column tile
+    k3s_geometry(geo, c.p[0].D, c.p[0].H, c.p[0].W, ct);
     // Warm this XCD's L2 with every layer's weight rows of this workgroup (one dword per 128-byte line; the values are only consumed after the last
     // layer): a stage's weight request otherwise goes to memory — ~3 us per pair of stages in flight (tools/chain_stamps.py), the largest share of a layer.
     unsigned int warm[VS_CHAIN_MAX_LAYERS][32 / NW];
@@ -416,8 +438,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
             const bool active = rb0 < p.rb_total;          // layers with fewer output rows than the widest one leave the last workgroups idle (they still arrive)
             if constexpr (BWD) {
                 if (!active) {}
-                else if (p.sums != nullptr) k3s_body<true, TVC, false, T, true, XRC, NW>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
-                else k3s_body<false, TVC, false, T, true, XRC, NW>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+                else if (p.sums != nullptr) k3s_body<true, TVC, false, T, true, XRC, NW>(p, geo, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+                else k3s_body<false, TVC, false, T, true, XRC, NW>(p, geo, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
                 if ((c.apply_mask >> l) & 1) {
                     chain_arrive(chain_counter(c, n, phase));
                     CH_STAMP(l * 16 + 6);
@@ -430,8 +452,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
                 }
             } else {
                 if (!active) {}
-                else if (p.x_stats != nullptr) k3s_body<false, TVC, true, T, true, XRC, NW>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
-                else k3s_body<false, TVC, false, T, true, XRC, NW>(p, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+                else if (p.x_stats != nullptr) k3s_body<false, TVC, true, T, true, XRC, NW>(p, geo, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
+                else k3s_body<false, TVC, false, T, true, XRC, NW>(p, geo, n, ct, rb0, smem, wc, wt, c.fault, l * 16);
             }
             if (l + 1 < c.nl) { chain_arrive(chain_counter(c, n, phase)); ++phase; }
             else __syncthreads();                        // the next sample of this slot reuses the LDS
