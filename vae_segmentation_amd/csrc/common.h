@@ -194,6 +194,29 @@ __device__ __forceinline__ void stat_load(const double* __restrict__ st, size_t 
     out[0] = a; out[1] = b;
 #endif
 }
+// stat_load in two halves: the four copies (limbs) requested now, combined later (the same arithmetic, in the same order) — for a consumer that needs the pair only
+// in its epilogue and must not wait for cold lines in its prologue (igemm_k3s.h, the mask tensor's statistics of the backward bodies)
+__device__ __forceinline__ void stat_load_raw(const double* __restrict__ st, size_t pair, size_t pairs, double (&raw)[4][2]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        raw[s][0] = st[stat_index(pair, pairs, s)];
+        raw[s][1] = st[stat_index(pair, pairs, s) + 1];
+    }
+}
+__device__ __forceinline__ void stat_combine(const double (&raw)[4][2], double (&out)[2]) {
+#if VS_DET_BUILD
+    long long a[4], b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { a[s] = __double_as_longlong(raw[s][0]); b[s] = __double_as_longlong(raw[s][1]); }
+    out[0] = ((double)a[0] * 0x1p40 + (double)a[1]) + ((double)a[2] * 0x1p-40 + (double)a[3] * 0x1p-80);
+    out[1] = ((double)b[0] * 0x1p40 + (double)b[1]) + ((double)b[2] * 0x1p-40 + (double)b[3] * 0x1p-80);
+#else
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int s = 0; s < VS_STAT_SLOTS; ++s) { a += raw[s][0]; b += raw[s][1]; }
+    out[0] = a; out[1] = b;
+#endif
+}
 // this workgroup's contribution `tot` to statistic `which` (0 / 1) of `pair`: one fp64 atomic into copy (blockIdx.x mod 4), or —
 // deterministic build — four integer atomics into the four limbs
 __device__ __forceinline__ void stat_add(double* st, size_t pair, size_t pairs, int which, double tot) {

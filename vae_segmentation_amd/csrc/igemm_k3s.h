@@ -242,12 +242,13 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const K3SGeo<TVC, NW
     }
     const int row0 = rb0 * 16 + 4 * g;                   // first of this lane's 4 accumulator rows
     float mm[4] = {0.f, 0.f, 0.f, 0.f}, mr[4] = {0.f, 0.f, 0.f, 0.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+    // SUMS: mean / rstd of the mask tensor's 16 channels under this workgroup's rows (forward statistics: an earlier launch's, cold lines).  They are needed in the
+    // EPILOGUE only: thread t < 16 requests row t's four copies here — behind the x stages in the load queue, so no stage waits for them — and turns them into the
+    // table entry after the stage loop.  (Every lane used to run the whole statistics -> mean / rstd chain for its four rows right here: 1.7-2 us of every backward
+    // body's prologue went into waiting for these lines — tools/chain_stamps.py, "tables built".)
+    double mraw[4][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
     if constexpr (SUMS) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (row0 + r < p.M) {
-                stats_to_mean_rstd_fast(p.mask_stats, (size_t)n * p.M + row0 + r, (size_t)p.N * p.M, p.inv_count_out, p.eps, mm[r], mr[r]);     // forward statistics: an earlier launch's
-            }
+        if (tid < 16 && rb0 * 16 + tid < p.M) stat_load_raw(p.mask_stats, (size_t)n * p.M + rb0 * 16 + tid, (size_t)p.N * p.M, mraw);
     }
     if (p.bias != nullptr) {
 #pragma unroll
@@ -300,11 +301,26 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const K3SGeo<TVC, NW
 
     // ---- the four waves' partial sums meet in LDS (the tile is dead); wave w finishes column group w ---------------------------------
     if constexpr (CH) CH_STAMP(sb + 4);
+    if constexpr (SUMS) {                                // the mask tensor's table (s_scale / s_shift are free: a backward body's input is a stored gradient)
+        if (tid < 16) {
+            float m = 0.f, r = 0.f;
+            if (rb0 * 16 + tid < p.M) {
+                double sv2[2];
+                stat_combine(mraw, sv2);
+                stats_to_mean_rstd_fast(sv2, p.inv_count_out, p.eps, m, r);
+            }
+            s_scale[tid] = m; s_shift[tid] = r;
+        }
+    }
     __syncthreads();
     f32x4* s_part = (f32x4*)s_tile;                      // [wave][cg][lane]
 #pragma unroll
     for (int cg = 0; cg < NCG; ++cg) s_part[(wave * NCG + cg) * 64 + lane] = acc[cg];
     __syncthreads();
+    if constexpr (SUMS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { mm[r] = s_scale[4 * g + r]; mr[r] = s_shift[4 * g + r]; }
+    }
     const int fcg = wave < NCG ? wave : 0;               // waves beyond the last column group finish nothing (valid = false below)
     f32x4 o = s_part[(0 * NCG + fcg) * 64 + lane];
 #pragma unroll
