@@ -7,7 +7,8 @@
 //   * the four waves share those columns and SPLIT the 27 taps of a chunk (wave w: taps w, w+4, ...): a wave's weight fragments are
 //     its own (global -> registers, no LDS) and it reads a quarter of the B fragments — 112 KB of LDS reads per stage instead of 540;
 //     the partial accumulators meet in LDS after the last stage and every wave finishes one column group;
-//   * the whole zero-padded sample chunk ((D+2)(H+2)(W+2) voxels x 32 channels: 32 KB at 6^3) is staged per chunk, whatever the tile.
+//   * the whole zero-padded sample chunk ((D+2)(H+2)(W+2) voxels x 32 channels: 32 KB at 6^3) is in LDS per chunk, whatever the tile — its zero padding written
+//     once per body, its REAL voxels loaded / normalised / written per stage (end of round 6), into two alternating buffers (one barrier per stage).
 // Staging (buffer loads two stages ahead, normalise-on-load, swizzled parts), statistics and fused IN-backward sums follow k3b_kernel; results are summed in a fixed order (bitwise reproducible).
 #pragma once
 #include <stdlib.h>
@@ -42,7 +43,7 @@ extern "C" int vs_debug_read_chain_stamps(unsigned long long* host, int n) { ret
 static inline int k3s_col_tile(bool small) { return small ? 16 * K3S_NCG_SMALL : 16 * K3S_NCG; }      // host: voxels per column tile
 #define K3S_LDS_RED 0          // float[4][16][2]
 #define K3S_LDS_TILE 512
-// then: padded sample chunk [TV][64 B] (at least 16 KB: the cross-wave partials alias it), scale / shift tables [C] each
+// then: two padded sample chunks [2][TVC][64 B] (k3s_tile_bytes; at least 16 KB: the cross-wave partials alias them), scale / shift tables [C] each
 
 // TVC: compile-time bound of the padded voxel count (128: up to 3x3x3, 512: up to 6x6x6) -> staging fragments per thread
 // HS: the input is a lazy activation (normalise + ReLU while staging) — compile-time, like every other condition on the staging path: a
