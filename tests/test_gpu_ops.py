@@ -123,6 +123,15 @@ def test_conv_k3_small_volume_odd_chunk_counts(case, dtype):
     test_conv_k3_fwd_bwd(case, False, dtype)
 
 
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("lazy", [False, True])
+@pytest.mark.parametrize("case", [(1, 32, 32, 1, 1, 54), (2, 32, 64, 30, 2, 2), (1, 64, 32, 1, 7, 16), (2, 32, 32, 2, 30, 2)])
+def test_conv_k3_small_volume_extreme_aspects(case, lazy, dtype):
+    """The small-volume kernel stages the REAL voxels of the padded sample (igemm_k3s.h, end of round 6): a thread's fragment is voxel rv -> (z, y, x) by
+    reciprocal multiplication.  Volumes far from cubic — one long axis up to the 512-voxel padded limit — put the largest divisors and the most padding there."""
+    test_conv_k3_fwd_bwd(case, lazy, dtype)
+
+
 K2_CASES = [(2, 8, 8, 8, 16), (1, 16, 4, 6, 10), (1, 32, 4, 4, 4), (1, 64, 2, 2, 6), (1, 128, 2, 2, 2), (2, 256, 2, 2, 2)]
 
 
