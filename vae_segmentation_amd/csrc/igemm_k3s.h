@@ -403,9 +403,10 @@ __device__ __forceinline__ void k3s_body(const G1Params& p, const K3SGeo<TVC, NW
     if constexpr (CH) CH_STAMP(sb + 5);
 }
 
-// waves per workgroup: eight for the 6^3-class volumes (round 6: 2.422 -> 2.387 ms per 96^3 step in the chain kernels, same box), four at 3^3 (one fragment per
-// thread and stage there already; the eight-wave build spills).  Chain and standalone kernels use the same count: their results are bit-identical.
-template <int TVC> struct K3SWaves { static constexpr int NW = TVC == 128 ? 4 : 8; };
+// waves per workgroup: eight (round 6: 2.422 -> 2.387 ms per 96^3 step in the chain kernels of the 6^3 class, same box).  The 3^3 class ran four — its eight-wave build
+// spilled — until the bodies stopped holding the padding's fragments in registers (end of round 6: 164-178 registers, no spills): eight there too, 2.2274 -> 2.2225 ms
+// same box, the fp32 mode unchanged (profiles/r06_ab_k3s_eight_waves_3cube*.json).  Chain and standalone kernels use the same count: their results are bit-identical.
+template <int TVC> struct K3SWaves { static constexpr int NW = 8; };
 
 template <bool SUMS, int TVC, bool HS, typename T = unsigned short>
 __global__ __launch_bounds__(64 * K3SWaves<TVC>::NW) __attribute__((amdgpu_waves_per_eu(K3SWaves<TVC>::NW / 4, 2))) void k3s_kernel(const G1Params p) {
